@@ -1,0 +1,117 @@
+/*
+ * trre_mi355x.h — C ABI of the MI355X-native transducer scan engine.
+ *
+ * Drop-in boundary for the scan-mode hot path of c0stya/trre.  The reference
+ * has no library interface: both engines are main() programs whose only seam
+ * is the per-position call inside the scan line loop
+ *
+ *     ioffset = infer_backtrack(start, ch, stack, mode, all);   trre_nft.c:781
+ *     ioffset = infer_dft(dstart, (unsigned char*)ch, dcache, mode);  trre_dft.c:1278
+ *
+ * (contract: NUL-terminated bytes in -> bytes appended to stdout, returns the
+ * number of bytes consumed or <= 0).  One device call per input position is
+ * far too fine a grain, so the boundary sits one level up: a whole
+ * '\n'-delimited input buffer in, the whole output buffer out, same per-line
+ * function, i.e. what main()'s scan branch computes for a FILE
+ * (trre_nft.c:775-790, trre_dft.c:1272-1286).  INTEGRATION.md shows the
+ * binding a maintainer of the reference would add.
+ *
+ * Plain C types only.  The scan itself always runs on the GPU; there is no CPU
+ * fallback in this library (a missing/failed device is an error).
+ */
+#ifndef TRRE_MI355X_H
+#define TRRE_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* engines: which reference binary's semantics to reproduce */
+#define TRRE_ENGINE_NFT 0 /* ./trre      priority backtracking, trre_nft.c:593-657 */
+#define TRRE_ENGINE_DFT 1 /* ./trre_dft  shortest-match determinised, trre_dft.c:1110-1196 */
+
+/* return codes */
+#define TRRE_OK 0
+#define TRRE_E_SYNTAX (-1)      /* the reference prints "error: ..." and exits 1 (message kept) */
+#define TRRE_E_UNDEFINED (-2)   /* the reference reads outside its buffers on this pattern */
+#define TRRE_E_EPS_CYCLE (-3)   /* epsilon cycle: the reference recurses without bound (DFT) */
+#define TRRE_E_TOO_BIG (-4)     /* determinisation exceeds the state/residual caps */
+#define TRRE_E_UNSUPPORTED (-5) /* legal pattern, outside this engine's GPU limits (e.g. >64 CONS states, NFT) */
+#define TRRE_E_DEVICE (-6)      /* HIP runtime failure / no GPU */
+#define TRRE_E_ARG (-7)
+#define TRRE_E_DIVERGES (-8)    /* the reference would not terminate on this input (NFT epsilon cycle entered) */
+#define TRRE_E_CAPACITY (-9)    /* output buffer too small; *out_len holds the size needed */
+
+/* kernel families (trre_info.kernel, trre_set_kernel) */
+#define TRRE_KERNEL_AUTO 0
+#define TRRE_KERNEL_BYTEMAP 1   /* memoryless tables: streaming byte map */
+#define TRRE_KERNEL_TILE_LP 2   /* length-preserving tables: one lane per line, single launch */
+#define TRRE_KERNEL_TILE_GEN 3  /* any tables: count + scan + emit */
+
+typedef struct trre_prog trre_prog;
+
+typedef struct trre_info {
+    int32_t engine;
+    int32_t kernel;            /* family AUTO resolves to */
+    uint32_t nft_states;       /* states of the compiled NFT (trre_nft.c:334-340) */
+    uint32_t nft_cons_states;
+    uint32_t dft_states;       /* determinised states incl. final ones (DFT engine) */
+    uint32_t table_rows;       /* rows kept on the device (non-final states) */
+    uint32_t table_classes;    /* byte classes (columns) */
+    uint32_t table_bytes;      /* size of the device blob */
+    uint32_t flags;            /* bit0 length-preserving, bit1 memoryless, bit2 no-overrun */
+    uint32_t chunk_bytes;      /* input bytes owned by one workgroup */
+} trre_info;
+
+/* Replaces parse() + create_nft() (trre_nft.c:752-754) and, for the DFT engine,
+ * the lazy table construction of infer_dft (trre_dft.c:1135-1175) run to
+ * completion.  Host-only; no GPU needed.  On failure returns a negative code
+ * and *out = NULL; trre_last_error() then holds the reference's stderr text. */
+int trre_compile(const char* pattern, int engine, trre_prog** out);
+int trre_compile_bytes(const uint8_t* pattern, size_t len, int engine, trre_prog** out);
+void trre_free(trre_prog* p);
+const char* trre_last_error(void); /* thread-local */
+int trre_get_info(const trre_prog* p, trre_info* info);
+int trre_set_kernel(trre_prog* p, int kernel_family); /* force a family (benchmarks/tests) */
+
+/* Copy of the device table blob (for offline inspection and the host-side table
+ * tests).  Returns the blob size; copies min(size, cap) bytes. */
+size_t trre_export_tables(const trre_prog* p, void* buf, size_t cap);
+
+/* Replaces the scan branch of main() (trre_nft.c:775-790 / trre_dft.c:1272-1286)
+ * for a whole buffer that is already resident in HBM.
+ *   d_in/d_out : device pointers (any alignment; 16-byte aligned is the fast path)
+ *   n          : input bytes        cap : capacity of d_out in bytes
+ *   out_len    : bytes produced (or needed, with TRRE_E_CAPACITY)
+ *   stream     : hipStream_t (NULL = default stream)
+ * Semantics, byte for byte: output = concat over getline() records of
+ * scan_line(record minus its last byte, cut at the first NUL) + "\n".
+ * Synchronous with respect to `stream` on return. */
+int trre_scan_device(trre_prog* p, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, size_t* out_len,
+                     void* stream);
+
+/* Split form for back-to-back launches: enqueue only (no host sync), then
+ * collect status/size once.  One scan may be in flight per (prog, device). */
+int trre_scan_enqueue(trre_prog* p, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, void* stream);
+int trre_scan_finish(trre_prog* p, size_t* out_len);
+
+/* Host-buffer convenience: H2D copy, scan, D2H copy on `device`. */
+int trre_scan_host(trre_prog* p, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_len, int device);
+
+/* Kernel timing for the last finished scan on this prog (HIP events recorded on
+ * the launch stream around the scan kernels).  Enable first. */
+int trre_set_profiling(trre_prog* p, int on);
+int trre_last_kernel_ms(trre_prog* p, float* ms);
+
+/* Line sharding (multi-GPU, trre has no exchange step: lines are independent).
+ * Fills bounds[0..nshards] with byte offsets such that every shard but the
+ * last ends just past a '\n'.  `in` is a host pointer. */
+int trre_shard_bounds(const uint8_t* in, size_t n, int nshards, size_t* bounds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRRE_MI355X_H */

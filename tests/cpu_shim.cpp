@@ -1,0 +1,172 @@
+// cpu_shim.cpp — TEST INFRASTRUCTURE: runs the kernels' per-thread phase bodies
+// (trre_amd/csrc/scan_block.hpp, scan_core.hpp) on the host, thread by thread,
+// with barriers replaced by loop boundaries, so that the lane logic, the tile
+// geometry, chunk ownership, the long-line slow path and the copy-out can be
+// checked against the oracle in the CPU test tier (no GPU in the build
+// container).  It is NOT a product path: libtrre_mi355x.so has no CPU scan and
+// nothing in trre_amd/ links this file.
+//
+// Besides the production geometry it instantiates a tiny one (4 lanes, 64-byte
+// chunks, 32-byte halo) so that small inputs cross chunk and tile boundaries.
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../trre_amd/csrc/scan_block.hpp"
+
+using namespace trre;
+
+namespace {
+
+using GeoTiny = Geometry<4, 64, 32>;
+
+template <class G, class Engine>
+struct Block {
+    std::vector<uint8_t> tin, tout, tab, mask;
+    Block() : tin(G::TILE_ALLOC + 16), tout(G::TILE_ALLOC + 16), tab(Engine::kLdsBytes + 16),
+              mask((size_t)G::TILE_ALLOC * (Engine::kMaskBytes ? Engine::kMaskBytes : 1) + 16) {}
+    uint8_t* al(std::vector<uint8_t>& v) { return reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(v.data()) + 15) & ~(uintptr_t)15); }
+};
+
+template <class G, class Engine>
+void run_lp(const ScanArgs& a, int64_t n_chunks, uint32_t& status) {
+    Block<G, Engine> blk;
+    uint8_t *tin = blk.al(blk.tin), *tout = blk.al(blk.tout), *tab = blk.al(blk.tab), *mask = blk.al(blk.mask);
+    for (int64_t b = 0; b < n_chunks; ++b) {
+        const int64_t v0 = b * G::CHUNK - G::PRE;
+        for (int t = 0; t < G::THREADS; ++t) { Engine::stage(a.blob, tab, t, G::THREADS); tile_load<G>(a, v0, tin, t); }
+        std::memset(tout, 0xEE, G::TILE_ALLOC);          // poison: unwritten output must never be copied out
+        const typename Engine::View T = Engine::view(a.blob, tab);
+        int32_t first = 0x7fffffff, last = -1;
+        for (int t = 0; t < G::THREADS; ++t) {
+            typename Engine::Lane L = Engine::make_lane(mask);
+            int32_t f, l;
+            lane_walk_lp<G, Engine>(a, T, L, v0, tin, tout, t, f, l, status);
+            if (f < first) first = f;
+            if (l > last) last = l;
+        }
+        for (int t = 0; t < G::THREADS; ++t) tile_store_lp<G>(a, v0, tout, first, last, t);
+    }
+}
+
+template <class G, class Engine>
+void run_gen(ScanArgs a, int64_t n_chunks, uint32_t& status, uint64_t& total_out) {
+    Block<G, Engine> blk;
+    uint8_t *tin = blk.al(blk.tin), *tout = blk.al(blk.tout), *tab = blk.al(blk.tab), *mask = blk.al(blk.mask);
+    std::vector<uint32_t> lane_counts((size_t)n_chunks * G::THREADS);
+    std::vector<uint64_t> chunk_total(n_chunks), chunk_base(n_chunks + 1);
+    for (int64_t b = 0; b < n_chunks; ++b) {             // pass 1: count
+        const int64_t v0 = b * G::CHUNK - G::PRE;
+        for (int t = 0; t < G::THREADS; ++t) { Engine::stage(a.blob, tab, t, G::THREADS); tile_load<G>(a, v0, tin, t); }
+        const typename Engine::View T = Engine::view(a.blob, tab);
+        uint64_t tot = 0;
+        for (int t = 0; t < G::THREADS; ++t) {
+            typename Engine::Lane L = Engine::make_lane(mask);
+            CountSink s;
+            lane_walk_gen<G, Engine>(a, T, L, v0, tin, t, s, status);
+            lane_counts[(size_t)b * G::THREADS + t] = (uint32_t)s.n;
+            tot += s.n;
+        }
+        chunk_total[b] = tot;
+    }
+    uint64_t run = 0;                                    // chunk scan
+    for (int64_t b = 0; b < n_chunks; ++b) { chunk_base[b] = run; run += chunk_total[b]; }
+    chunk_base[n_chunks] = run;
+    total_out = run;
+    if (run > a.cap) { status |= kStCapacity; return; }
+    for (int64_t b = 0; b < n_chunks; ++b) {             // pass 2: emit
+        const int64_t v0 = b * G::CHUNK - G::PRE;
+        for (int t = 0; t < G::THREADS; ++t) { Engine::stage(a.blob, tab, t, G::THREADS); tile_load<G>(a, v0, tin, t); }
+        std::memset(tout, 0xEE, G::TILE_ALLOC);
+        const typename Engine::View T = Engine::view(a.blob, tab);
+        const uint64_t total = chunk_total[b], gbase = chunk_base[b];
+        const int shift = (int)((reinterpret_cast<uintptr_t>(a.out) + gbase) & 15u);
+        const bool staged = (uint64_t)shift + total <= (uint64_t)G::TILE;
+        uint64_t lane_base = 0;
+        for (int t = 0; t < G::THREADS; ++t) {
+            typename Engine::Lane L = Engine::make_lane(mask);
+            ByteSink s{staged ? tout + shift + lane_base : a.out + gbase + lane_base};
+            lane_walk_gen<G, Engine>(a, T, L, v0, tin, t, s, status);
+            if (s.n != lane_counts[(size_t)b * G::THREADS + t]) status |= 1u << 30;   // count/emit disagree
+            lane_base += lane_counts[(size_t)b * G::THREADS + t];
+        }
+        if (staged)
+            for (int t = 0; t < G::THREADS; ++t) tile_store_seq<G>(a.out + gbase, tout, shift, (int64_t)total, t);
+    }
+}
+
+void run_bytemap(const ScanArgs& a, uint32_t& status) {
+    const DftBlobHeader& h = *reinterpret_cast<const DftBlobHeader*>(a.blob);
+    const uint8_t* map = a.blob + h.off_bytemap;
+    const bool aligned = (reinterpret_cast<uintptr_t>(a.out_v0) & 15u) == 0;
+    const int64_t vfirst = a.vbeg & ~(int64_t)15;
+    const int64_t nvec = (a.vend - vfirst + 15) / 16;
+    uint32_t zero = 0;
+    for (int64_t k = 0; k < nvec; ++k) {
+        U128 w = *reinterpret_cast<const U128*>(a.in_v0 + vfirst + k * 16);
+        bytemap_vec(a, map, w, vfirst + k * 16, aligned, zero);
+    }
+    if (zero) status |= kStNul;
+}
+
+template <class G, class Engine>
+int run_family(int family, ScanArgs& a, uint32_t& status, uint64_t& total) {
+    const int64_t n_chunks = (a.vend + G::CHUNK - 1) / G::CHUNK;
+    if (family == 2) { run_lp<G, Engine>(a, n_chunks, status); total = (uint64_t)(a.vend - a.vbeg); }
+    else run_gen<G, Engine>(a, n_chunks, status, total);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// family: 1 bytemap, 2 tile LP, 3 tile general.  geo: 0 production, 1 tiny.
+// in_mis/out_mis: address misalignment (0..15) to give the staged buffers.
+// want_scratch: pass a mask scratch to the NFT long-line path.
+int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int geo, const uint8_t* in, size_t n,
+              int in_mis, uint8_t* out, size_t cap, int out_mis, int want_scratch, size_t* m, uint32_t* status_out) {
+    if (n == 0) { *m = 0; *status_out = 0; return 0; }
+    std::vector<uint8_t> ibuf(n + 64, 0xAA), obuf(cap + 64, 0xEE);
+    uint8_t* ia = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(ibuf.data()) + 15) & ~(uintptr_t)15) + in_mis;
+    uint8_t* oa = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(obuf.data()) + 15) & ~(uintptr_t)15) + out_mis;
+    std::memcpy(ia, in, n);
+    std::vector<uint8_t> scratch(want_scratch ? (n + 64) * 8 : 0);
+    ScanArgs a{};
+    const int64_t al = (int64_t)(reinterpret_cast<uintptr_t>(ia) & 15u);
+    a.in_v0 = ia - al;
+    a.out_v0 = oa - al;
+    a.out = oa;
+    a.vbeg = al;
+    a.vend = al + (int64_t)n;
+    a.blob = blob;
+    a.cap = cap;
+    a.gscratch = want_scratch ? scratch.data() : nullptr;
+    uint32_t status = 0;
+    uint64_t total = 0;
+    if (family != 3 && cap < n) return -9;
+    if (family == 1) { run_bytemap(a, status); total = n; }
+    else if (engine == 1) {
+        if (geo == 0) run_family<GeoDft, DftEngine>(family, a, status, total);
+        else run_family<GeoTiny, DftEngine>(family, a, status, total);
+    } else if (mask_bytes == 1) {
+        if (geo == 0) run_family<GeoNft8, NftEngine<uint8_t>>(family, a, status, total);
+        else run_family<GeoTiny, NftEngine<uint8_t>>(family, a, status, total);
+    } else if (mask_bytes == 2) {
+        if (geo == 0) run_family<GeoNft16, NftEngine<uint16_t>>(family, a, status, total);
+        else run_family<GeoTiny, NftEngine<uint16_t>>(family, a, status, total);
+    } else if (mask_bytes == 4) {
+        if (geo == 0) run_family<GeoNft32, NftEngine<uint32_t>>(family, a, status, total);
+        else run_family<GeoTiny, NftEngine<uint32_t>>(family, a, status, total);
+    } else {
+        if (geo == 0) run_family<GeoNft64, NftEngine<uint64_t>>(family, a, status, total);
+        else run_family<GeoTiny, NftEngine<uint64_t>>(family, a, status, total);
+    }
+    *status_out = status;
+    *m = (size_t)total;
+    if (total <= cap) std::memcpy(out, oa, (size_t)total);
+    return 0;
+}
+
+}  // extern "C"

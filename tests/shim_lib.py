@@ -1,0 +1,72 @@
+"""ctypes binding of tests/cpu_shim.cpp — TEST INFRASTRUCTURE (see that file)."""
+import ctypes
+import os
+import struct
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "cpu_shim.cpp")
+SO = os.path.join(HERE, "_shim", "libcpu_shim.so")
+CSRC = os.path.join(os.path.dirname(HERE), "trre_amd", "csrc")
+
+ST_NUL, ST_DIVERGE, ST_CAPACITY, ST_LONGLINE, ST_NEEDSCRATCH, ST_MISMATCH = 1, 2, 4, 8, 16, 1 << 30
+
+
+def build():
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("scan_block.hpp", "scan_core.hpp", "device_blob.hpp")]
+    if os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(d) for d in deps):
+        return SO
+    os.makedirs(os.path.dirname(SO), exist_ok=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", SRC, "-o", SO], check=True)
+    return SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = ctypes.CDLL(build())
+        L.shim_scan.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
+                                ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t),
+                                ctypes.POINTER(ctypes.c_uint32)]
+        _lib = L
+    return _lib
+
+
+def mask_bytes_of(blob, engine):
+    if engine == 1:
+        return 0
+    n_cons = struct.unpack_from("<I", blob, 4)[0]
+    return 1 if n_cons <= 8 else 2 if n_cons <= 16 else 4 if n_cons <= 32 else 8
+
+
+def shim_scan(blob, engine, family, data, geo=1, in_mis=0, out_mis=0, scratch=True, cap=None):
+    """Run one kernel family of the device code on the host.  Returns (output bytes, status)."""
+    if cap is None:
+        cap = len(data) * 8 + 64 if family == 3 else len(data)
+    out = ctypes.create_string_buffer(max(cap, 1))
+    m = ctypes.c_size_t()
+    st = ctypes.c_uint32()
+    rc = lib().shim_scan(blob, engine, mask_bytes_of(blob, engine), family, geo, data, len(data), in_mis, out, cap,
+                         out_mis, 1 if scratch else 0, ctypes.byref(m), ctypes.byref(st))
+    if rc:
+        raise RuntimeError("shim rc %d" % rc)
+    return out.raw[:m.value], st.value
+
+
+def scan_like_runtime(prog, data, geo=1, family=None, in_mis=0, out_mis=0):
+    """Mirror of runtime.cpp's policy (finish()): auto family, NUL -> general family."""
+    info = prog.info
+    blob = prog.export_tables()
+    fam = family if family else info.kernel
+    out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
+    assert not st & ST_MISMATCH, "count and emit passes disagree"
+    if st & ST_DIVERGE:
+        raise RuntimeError("diverges")
+    if fam != 3 and st & ST_NUL:
+        out, st = shim_scan(blob, info.engine, 3, data, geo, in_mis, out_mis)
+        assert not st & ST_MISMATCH
+    return out

@@ -1,0 +1,187 @@
+"""ctypes binding of libtrre_mi355x.so (include/trre_mi355x.h).
+
+Host-side mirror of the reference's command-line interface for the scan path:
+``Program(pattern, engine)`` plays ``./trre PATTERN`` (engine="nft",
+trre_nft.c:713-790) or ``./trre_dft PATTERN`` (engine="dft",
+trre_dft.c:1199-1286); ``Program.scan(data)`` is the scan branch of main() over
+a whole buffer.  The scan always runs on the GPU through the C ABI — there is no
+Python or CPU implementation of it here, and a missing library or device raises.
+
+PyTorch is used only as plumbing (device buffers, streams); it is imported
+lazily so that pattern compilation and table inspection work without it.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtrre_mi355x.so")
+
+ENGINE_NFT, ENGINE_DFT = 0, 1
+_ENGINES = {"nft": ENGINE_NFT, "dft": ENGINE_DFT, ENGINE_NFT: ENGINE_NFT, ENGINE_DFT: ENGINE_DFT}
+
+KERNEL_AUTO, KERNEL_BYTEMAP, KERNEL_TILE_LP, KERNEL_TILE_GEN = 0, 1, 2, 3
+KERNEL_NAMES = {0: "auto", 1: "bytemap", 2: "tile_lp", 3: "tile_gen"}
+
+FLAG_LENGTH_PRESERVING, FLAG_MEMORYLESS, FLAG_NO_OVERRUN = 1, 2, 4
+
+E_SYNTAX, E_UNDEFINED, E_EPS_CYCLE, E_TOO_BIG, E_UNSUPPORTED = -1, -2, -3, -4, -5
+E_DEVICE, E_ARG, E_DIVERGES, E_CAPACITY = -6, -7, -8, -9
+
+
+class TrreError(RuntimeError):
+    """A failed library call; .code is the TRRE_E_* value, .message the
+    reference-style 'error: ...' text."""
+
+    def __init__(self, code, message):
+        super().__init__("%s (code %d)" % (message, code))
+        self.code = code
+        self.message = message
+
+
+class Info(ctypes.Structure):
+    _fields_ = [("engine", ctypes.c_int32), ("kernel", ctypes.c_int32), ("nft_states", ctypes.c_uint32),
+                ("nft_cons_states", ctypes.c_uint32), ("dft_states", ctypes.c_uint32),
+                ("table_rows", ctypes.c_uint32), ("table_classes", ctypes.c_uint32),
+                ("table_bytes", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("chunk_bytes", ctypes.c_uint32)]
+
+
+def build_library(force=False):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.run(["make", "-s", "-C", os.path.join(_HERE, "csrc"), "all"], check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TrreError(E_DEVICE, "error: %s is missing — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                      "(the scan has no CPU fallback)" % LIB_PATH)
+        try:
+            import torch  # noqa: F401  (load torch's HIP runtime first so both share one libamdhip64)
+        except Exception:  # pragma: no cover - torch is optional for host-only use
+            pass
+        L = ctypes.CDLL(LIB_PATH)
+        vp, sz = ctypes.c_void_p, ctypes.c_size_t
+        L.trre_compile_bytes.argtypes = [ctypes.c_char_p, sz, ctypes.c_int, ctypes.POINTER(vp)]
+        L.trre_free.argtypes = [vp]
+        L.trre_free.restype = None
+        L.trre_last_error.restype = ctypes.c_char_p
+        L.trre_get_info.argtypes = [vp, ctypes.POINTER(Info)]
+        L.trre_set_kernel.argtypes = [vp, ctypes.c_int]
+        L.trre_export_tables.argtypes = [vp, vp, sz]
+        L.trre_export_tables.restype = sz
+        L.trre_scan_device.argtypes = [vp, vp, sz, vp, sz, ctypes.POINTER(sz), vp]
+        L.trre_scan_enqueue.argtypes = [vp, vp, sz, vp, sz, vp]
+        L.trre_scan_finish.argtypes = [vp, ctypes.POINTER(sz)]
+        L.trre_scan_host.argtypes = [vp, ctypes.c_char_p, sz, vp, sz, ctypes.POINTER(sz), ctypes.c_int]
+        L.trre_set_profiling.argtypes = [vp, ctypes.c_int]
+        L.trre_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+        L.trre_shard_bounds.argtypes = [ctypes.c_char_p, sz, ctypes.c_int, ctypes.POINTER(sz)]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise TrreError(rc, lib().trre_last_error().decode("latin-1"))
+
+
+def _bytes(x):
+    return x.encode("latin-1") if isinstance(x, str) else bytes(x)
+
+
+class Program:
+    """A compiled pattern bound to one engine."""
+
+    def __init__(self, pattern, engine="nft"):
+        self.pattern = _bytes(pattern)
+        self.engine = _ENGINES[engine]
+        self._h = ctypes.c_void_p()
+        _check(lib().trre_compile_bytes(self.pattern, len(self.pattern), self.engine, ctypes.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().trre_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def info(self):
+        i = Info()
+        _check(lib().trre_get_info(self._h, ctypes.byref(i)))
+        return i
+
+    def set_kernel(self, family):
+        _check(lib().trre_set_kernel(self._h, family))
+
+    def export_tables(self):
+        n = lib().trre_export_tables(self._h, None, 0)
+        buf = ctypes.create_string_buffer(n)
+        lib().trre_export_tables(self._h, buf, n)
+        return buf.raw
+
+    # ---- device path ---------------------------------------------------------------
+    def scan_tensor(self, inp, out=None, stream=None):
+        """inp: 1-D uint8 CUDA tensor.  Returns a uint8 CUDA tensor view of the output."""
+        import torch
+        assert inp.is_cuda and inp.dtype == torch.uint8 and inp.dim() == 1 and inp.is_contiguous()
+        n = inp.numel()
+        if out is None:
+            out = torch.empty(max(n, 1) + 16, dtype=torch.uint8, device=inp.device)
+        s = stream if stream is not None else torch.cuda.current_stream(inp.device).cuda_stream
+        m = ctypes.c_size_t()
+        with torch.cuda.device(inp.device):
+            rc = lib().trre_scan_device(self._h, inp.data_ptr(), n, out.data_ptr(), out.numel(), ctypes.byref(m), s)
+            if rc == E_CAPACITY:                       # variable-length output: retry with the size asked for
+                out = torch.empty(m.value + 16, dtype=torch.uint8, device=inp.device)
+                rc = lib().trre_scan_device(self._h, inp.data_ptr(), n, out.data_ptr(), out.numel(), ctypes.byref(m), s)
+        _check(rc)
+        return out[:m.value]
+
+    def enqueue(self, inp, out, stream=None):
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream(inp.device).cuda_stream
+        _check(lib().trre_scan_enqueue(self._h, inp.data_ptr(), inp.numel(), out.data_ptr(), out.numel(), s))
+
+    def finish(self):
+        m = ctypes.c_size_t()
+        _check(lib().trre_scan_finish(self._h, ctypes.byref(m)))
+        return m.value
+
+    def scan(self, data, device=0):
+        """bytes in -> bytes out through trre_scan_host (H2D, GPU scan, D2H)."""
+        data = _bytes(data)
+        cap = len(data) + 64
+        for _ in range(2):
+            out = ctypes.create_string_buffer(cap)
+            m = ctypes.c_size_t()
+            rc = lib().trre_scan_host(self._h, data, len(data), out, cap, ctypes.byref(m), device)
+            if rc == E_CAPACITY:
+                cap = m.value + 64
+                continue
+            _check(rc)
+            return out.raw[:m.value]
+        _check(rc)
+
+    def set_profiling(self, on=True):
+        _check(lib().trre_set_profiling(self._h, 1 if on else 0))
+
+    def last_kernel_ms(self):
+        ms = ctypes.c_float()
+        _check(lib().trre_last_kernel_ms(self._h, ctypes.byref(ms)))
+        return ms.value
+
+
+def shard_bounds(data, nshards):
+    """Byte offsets that cut `data` into nshards pieces at '\\n' boundaries."""
+    data = _bytes(data)
+    b = (ctypes.c_size_t * (nshards + 1))()
+    _check(lib().trre_shard_bounds(data, len(data), nshards, b))
+    return list(b)

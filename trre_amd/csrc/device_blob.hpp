@@ -1,0 +1,36 @@
+// device_blob.hpp — byte layout of the compiled tables as uploaded to HBM.
+// Shared by the host serialiser (runtime.cpp), the kernels (scan_kernels.hip)
+// and the test shim.  All offsets are from the start of the blob.
+#pragma once
+#include <cstdint>
+
+namespace trre {
+
+constexpr uint32_t kMagicDft = 0x31445254u;   // "TRD1"
+constexpr uint32_t kMagicNft = 0x314e5254u;   // "TRN1"
+
+struct DftBlobHeader {
+    uint32_t magic, n_rows, n_cls, flags;
+    uint32_t off_ent0;       // u64[256]  start row by raw byte
+    uint32_t off_cls;        // u8[256]
+    uint32_t off_bytemap;    // u8[256]   (kFlagMemoryless)
+    uint32_t off_ent;        // u64[n_rows][n_cls]
+    uint32_t off_pool, pool_bytes;
+    uint32_t total_bytes, max_edge_out, n_states;
+    uint32_t pad[3];
+};
+static_assert(sizeof(DftBlobHeader) == 64, "header layout");
+
+struct NftBlobHeader {
+    uint32_t magic, n_cons, flags, n_follow;
+    uint32_t off_cons_mask;  // u64[256]
+    uint32_t off_pred;       // u64[n_cons + 1]
+    uint32_t off_follow_off; // u32[n_cons + 2]
+    uint32_t off_follow;     // NftFollow[n_follow] (8 bytes each)
+    uint32_t off_pool, pool_bytes;
+    uint32_t total_bytes, n_states;
+    uint32_t pad[4];
+};
+static_assert(sizeof(NftBlobHeader) == 64, "header layout");
+
+}  // namespace trre

@@ -1,0 +1,158 @@
+// front.hpp — host-side pattern front end of the MI355X transducer scan engine.
+//
+// pattern string -> AST -> NFT (consume/produce automaton) -> device tables.
+// Everything here runs once per pattern on the host; the per-byte work is in
+// scan_kernels.hip.  The language and its corner cases are those of the
+// reference (c0stya/trre); citations are file:line into /root/reference.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace trre {
+
+// ---- error codes shared with include/trre_mi355x.h -------------------------
+enum : int {
+    kOk = 0,
+    kErrSyntax = -1,        // the reference prints "error: ..." and exits 1
+    kErrUndefined = -2,     // the reference runs into undefined behaviour here
+    kErrEpsCycle = -3,      // epsilon cycle: the reference recurses/loops without bound
+    kErrTooBig = -4,        // determinisation exceeds the state / residual caps
+    kErrUnsupported = -5,   // legal pattern, not supported by this engine on the GPU
+    kErrDevice = -6,        // HIP runtime failure
+    kErrArg = -7,
+    kErrDiverges = -8,      // at run time: the reference would not terminate on this input
+    kErrCapacity = -9       // output buffer too small (needed size is reported)
+};
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+// ---- AST --------------------------------------------------------------------
+// type: '|' '.' ':' '-' '*' '+' '?' 'I' (iteration) 'c' (byte) 'e' (epsilon
+// placeholder); the bounds node under an 'I' stores {lower, upper} in
+// {type, val}, both reduced mod 256 (trre_nft.c:142).
+struct AstNode {
+    uint8_t type = 0;
+    uint8_t val = 0;
+    int32_t l = -1, r = -1;
+};
+struct Ast {
+    std::vector<AstNode> nodes;
+    int32_t root = -1;
+    int32_t add(uint8_t type, int32_t l = -1, int32_t r = -1, uint8_t val = 0) {
+        AstNode n; n.type = type; n.val = val; n.l = l; n.r = r;
+        nodes.push_back(n);
+        return (int32_t)nodes.size() - 1;
+    }
+};
+Ast parse_pattern(const std::string& pattern);
+
+// ---- NFT ----------------------------------------------------------------------
+enum class NKind : uint8_t { Prod, Cons, Split, SplitNg, Join, Final };
+struct NState {
+    NKind kind;
+    uint8_t val = 0;
+    int32_t a = -1;   // primary successor ("nexta")
+    int32_t b = -1;   // secondary successor of a split ("nextb")
+};
+struct Nft {
+    std::vector<NState> st;
+    int32_t start = -1;
+    int32_t n_cons = 0;
+    int32_t add(NKind k, int32_t a = -1, int32_t b = -1, uint8_t val = 0) {
+        NState s; s.kind = k; s.a = a; s.b = b; s.val = val;
+        st.push_back(s);
+        return (int32_t)st.size() - 1;
+    }
+    // preferred / fallback successor of a split in depth-first priority order
+    // (trre_nft.c:623-630): SPLIT takes b (the loop body) first, SPLITNG takes a.
+    int32_t first(int32_t s) const { return st[s].kind == NKind::Split ? st[s].b : st[s].a; }
+    int32_t second(int32_t s) const { return st[s].kind == NKind::Split ? st[s].a : st[s].b; }
+};
+// with_initial_join: the deterministic engine's automaton starts with an extra
+// JOIN so that the start state is never a CONS (trre_dft.c:516-523).
+Nft build_nft(const Ast& ast, bool with_initial_join);
+
+// ---- deterministic transducer (eager subset construction) ---------------------
+struct DftEdge {
+    int32_t to = -1;          // -1 = dead
+    std::string out;          // output factored onto the edge (longest common prefix)
+};
+struct DftState {
+    bool final = false;
+    std::string final_out;
+    std::array<DftEdge, 256> edge;   // only filled for non-final states
+    bool expanded = false;
+};
+struct Dft {
+    std::vector<DftState> st;     // st[0] = start (never final: trre_dft.c:938,1120)
+};
+struct DftLimits {
+    size_t max_states = 60000;
+    size_t max_residual = 4096;
+};
+Dft determinize(const Nft& nft, const DftLimits& lim = DftLimits());
+
+// ---- device tables --------------------------------------------------------------
+// Deterministic engine.  Rows exist only for non-final states (a final state is
+// left immediately: shortest match, trre_dft.c:1120-1125).  Bytes with identical
+// columns share a class.  Entry (64 bit):
+//   [1:0]   kind      0 dead, 1 goto, 2 accept (edge output already includes the
+//                     target's final_out)
+//   [4:2]   ilen      0..4 output bytes held inline in [63:32]; 7 = pooled:
+//                     [63:32] is a byte offset into the pool of a record
+//                     {u32 len, bytes...} (4-byte aligned)
+//   [31:5]  next row  (goto only)
+constexpr uint32_t kEntDead = 0, kEntGoto = 1, kEntAccept = 2;
+constexpr uint32_t kIlenPooled = 7;
+constexpr uint32_t kClassEol = 0;      // '\n' and NUL: never inside a line
+
+enum : uint32_t {
+    kFlagLengthPreserving = 1u << 0,   // every accepted attempt emits exactly what it consumed
+    kFlagMemoryless = 1u << 1,         // every start edge is dead or accepts with one output byte
+    kFlagNoOverrun = 1u << 2           // pending output never exceeds consumed input inside an attempt
+};
+
+struct DftTables {
+    uint32_t n_rows = 0, n_cls = 0, flags = 0, max_edge_out = 0;
+    std::array<uint8_t, 256> cls{};
+    std::vector<uint64_t> ent;           // [n_rows][n_cls]
+    std::vector<uint8_t> pool;
+    std::array<uint8_t, 256> bytemap{};  // valid when kFlagMemoryless
+    uint32_t n_states = 0;               // determinised states incl. final ones
+};
+DftTables flatten_dft(const Dft& dft);
+
+// Non-deterministic engine (priority-exact).  Only CONS states (and FINAL) are
+// materialised; for each CONS state s (and for the start) `follow` lists, in the
+// reference's depth-first priority order, the CONS/FINAL states reachable from
+// s's successor through epsilon states, each with the bytes produced on the way.
+// A list stops at its first FINAL (which always accepts in scan mode,
+// trre_nft.c:643-648) or with a Diverge marker where the reference's search
+// would run around an epsilon cycle for ever.
+constexpr uint8_t kTgtFinal = 0xFF, kTgtDiverge = 0xFE;
+struct NftFollow {
+    uint8_t target;        // CONS index 0..n_cons-1, kTgtFinal or kTgtDiverge
+    uint8_t mute;          // output contains a NUL: emit up to it, then mute the attempt (fputs)
+    uint16_t out_len;
+    uint32_t out_off;      // into pool
+};
+struct NftTables {
+    uint32_t n_cons = 0;                    // <= 64
+    std::array<uint64_t, 256> cons_mask{};  // CONS states that read byte c
+    std::vector<uint64_t> pred;             // [n_cons]: CONS states whose follow list holds t
+    uint64_t to_final = 0;                  // CONS states whose follow list holds FINAL
+    std::vector<uint32_t> follow_off;       // [n_cons + 2]; index n_cons = start
+    std::vector<NftFollow> follow;
+    std::vector<uint8_t> pool;
+    uint32_t flags = 0;                     // kFlagLengthPreserving
+    uint32_t n_states = 0;
+};
+NftTables build_nft_tables(const Nft& nft);
+
+}  // namespace trre

@@ -1,0 +1,20 @@
+// launch.hpp — host-callable launchers implemented in scan_kernels.hip.
+#pragma once
+#include <cstdint>
+
+namespace trre {
+
+struct ScanArgs;
+
+constexpr int kEngineNft = 0, kEngineDft = 1;
+
+// bytes of input owned by one workgroup / threads per workgroup for an engine
+int chunk_bytes(int engine, int mask_bytes);
+int block_threads(int engine, int mask_bytes);
+
+// which: 0 length-preserving scan, 1 count pass, 2 emit pass
+void launch_tile_kernel(int which, int engine, int mask_bytes, const ScanArgs& a, int64_t n_chunks, void* stream);
+void launch_chunk_scan(const uint64_t* total, uint64_t* base, int64_t n_chunks, void* stream);
+void launch_bytemap(const ScanArgs& a, void* stream);
+
+}  // namespace trre

@@ -1,0 +1,460 @@
+// runtime.cpp — C ABI (include/trre_mi355x.h) and host runtime: pattern
+// compilation, table upload, kernel-family selection, launches, status
+// collection.  The scan always runs on the GPU; nothing here computes output
+// bytes on the host.
+#include <hip/hip_runtime_api.h>
+
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/trre_mi355x.h"
+#include "device_blob.hpp"
+#include "front.hpp"
+#include "launch.hpp"
+#include "scan_block.hpp"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string& msg) {
+    g_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(TRRE_E_DEVICE, std::string("hip: ") + hipGetErrorString(e_) + " at " #expr); \
+    } while (0)
+
+struct DeviceState {
+    uint8_t* d_blob = nullptr;
+    uint32_t* d_status = nullptr;     // [4]
+    uint32_t* h_status = nullptr;     // pinned mirror: [0] status bits; [2..3] total (u64)
+    uint32_t* d_lane_counts = nullptr;
+    uint64_t* d_chunk_total = nullptr;
+    uint64_t* d_chunk_base = nullptr;
+    int64_t ws_chunks = 0;
+    uint8_t* d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+struct Pending {
+    bool active = false;
+    int device = 0;
+    int family = 0;
+    const uint8_t* d_in = nullptr;
+    uint8_t* d_out = nullptr;
+    size_t n = 0, cap = 0;
+    hipStream_t stream = nullptr;
+    bool launched = false;
+    bool timed = false;
+};
+
+template <class T>
+void put(std::vector<uint8_t>& b, size_t off, const T* src, size_t count) {
+    if (b.size() < off + count * sizeof(T)) b.resize(off + count * sizeof(T));
+    if (count) std::memcpy(b.data() + off, src, count * sizeof(T));
+}
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+struct trre_prog {
+    int engine = 0;
+    int forced_family = TRRE_KERNEL_AUTO;
+    uint32_t nft_states = 0, nft_cons = 0;
+    trre::DftTables dt;
+    trre::NftTables nt;
+    std::vector<uint8_t> blob;
+    int mask_bytes = 0;
+    bool profiling = false;
+    float last_ms = -1.f;
+    std::map<int, DeviceState> dev;
+    Pending pend;
+};
+
+namespace {
+
+void serialize_dft(trre_prog& p) {
+    using namespace trre;
+    const DftTables& t = p.dt;
+    DftBlobHeader h{};
+    h.magic = kMagicDft;
+    h.n_rows = t.n_rows;
+    h.n_cls = t.n_cls;
+    h.flags = t.flags;
+    h.max_edge_out = t.max_edge_out;
+    h.n_states = t.n_states;
+    size_t off = sizeof h;
+    h.off_ent0 = (uint32_t)off; off += 256 * 8;
+    h.off_cls = (uint32_t)off; off += 256;
+    h.off_bytemap = (uint32_t)off; off += 256;
+    h.off_ent = (uint32_t)off; off += t.ent.size() * 8;
+    h.off_pool = (uint32_t)off; h.pool_bytes = (uint32_t)t.pool.size(); off += t.pool.size();
+    off = align_up(off + 16, 16);
+    h.total_bytes = (uint32_t)off;
+    std::vector<uint8_t>& b = p.blob;
+    b.assign(off, 0);
+    std::vector<uint64_t> ent0(256);
+    for (int c = 0; c < 256; ++c) ent0[c] = t.ent[t.cls[c]];      // row 0, expanded over raw bytes
+    put(b, 0, &h, 1);
+    put(b, h.off_ent0, ent0.data(), 256);
+    put(b, h.off_cls, t.cls.data(), 256);
+    put(b, h.off_bytemap, t.bytemap.data(), 256);
+    put(b, h.off_ent, t.ent.data(), t.ent.size());
+    put(b, h.off_pool, t.pool.data(), t.pool.size());
+}
+
+void serialize_nft(trre_prog& p) {
+    using namespace trre;
+    const NftTables& t = p.nt;
+    NftBlobHeader h{};
+    h.magic = kMagicNft;
+    h.n_cons = t.n_cons;
+    h.flags = t.flags;
+    h.n_follow = (uint32_t)t.follow.size();
+    h.n_states = t.n_states;
+    size_t off = sizeof h;
+    h.off_cons_mask = (uint32_t)off; off += 256 * 8;
+    h.off_pred = (uint32_t)off; off += (t.n_cons + 1) * 8;
+    h.off_follow_off = (uint32_t)off; off += align_up((t.n_cons + 2) * 4, 8);
+    h.off_follow = (uint32_t)off; off += t.follow.size() * sizeof(NftFollow);
+    h.off_pool = (uint32_t)off; h.pool_bytes = (uint32_t)t.pool.size(); off += t.pool.size();
+    off = align_up(off + 16, 16);
+    h.total_bytes = (uint32_t)off;
+    std::vector<uint8_t>& b = p.blob;
+    b.assign(off, 0);
+    std::vector<uint64_t> pred(t.pred);
+    pred.push_back(t.to_final);
+    put(b, 0, &h, 1);
+    put(b, h.off_cons_mask, t.cons_mask.data(), 256);
+    put(b, h.off_pred, pred.data(), pred.size());
+    put(b, h.off_follow_off, t.follow_off.data(), t.follow_off.size());
+    put(b, h.off_follow, t.follow.data(), t.follow.size());
+    put(b, h.off_pool, t.pool.data(), t.pool.size());
+}
+
+int auto_family(const trre_prog& p) {
+    using namespace trre;
+    if (p.engine == TRRE_ENGINE_DFT) {
+        if (p.dt.flags & kFlagMemoryless) return TRRE_KERNEL_BYTEMAP;
+        if ((p.dt.flags & kFlagLengthPreserving) && (p.dt.flags & kFlagNoOverrun)) return TRRE_KERNEL_TILE_LP;
+        return TRRE_KERNEL_TILE_GEN;
+    }
+    return (p.nt.flags & kFlagLengthPreserving) ? TRRE_KERNEL_TILE_LP : TRRE_KERNEL_TILE_GEN;
+}
+
+bool family_allowed(const trre_prog& p, int fam) {
+    using namespace trre;
+    if (fam == TRRE_KERNEL_TILE_GEN) return true;
+    if (p.engine == TRRE_ENGINE_DFT) {
+        if (fam == TRRE_KERNEL_BYTEMAP) return (p.dt.flags & kFlagMemoryless) != 0;
+        return (p.dt.flags & kFlagLengthPreserving) && (p.dt.flags & kFlagNoOverrun);
+    }
+    if (fam == TRRE_KERNEL_BYTEMAP) return false;
+    return (p.nt.flags & kFlagLengthPreserving) != 0;
+}
+
+int device_state(trre_prog* p, int dev, DeviceState** out) {
+    auto it = p->dev.find(dev);
+    if (it == p->dev.end()) {
+        DeviceState st;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st.d_blob), p->blob.size()));
+        HIP_TRY(hipMemcpy(st.d_blob, p->blob.data(), p->blob.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st.d_status), 16));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&st.h_status), 16, hipHostMallocDefault));
+        HIP_TRY(hipEventCreate(&st.ev0));
+        HIP_TRY(hipEventCreate(&st.ev1));
+        it = p->dev.emplace(dev, st).first;
+    }
+    *out = &it->second;
+    return TRRE_OK;
+}
+
+int ensure_workspace(trre_prog* p, DeviceState* st, int64_t n_chunks) {
+    if (n_chunks <= st->ws_chunks) return TRRE_OK;
+    if (st->d_lane_counts) { (void)hipFree(st->d_lane_counts); (void)hipFree(st->d_chunk_total); (void)hipFree(st->d_chunk_base); }
+    st->ws_chunks = 0;
+    const int threads = trre::block_threads(p->engine, p->mask_bytes);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st->d_lane_counts), (size_t)n_chunks * threads * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st->d_chunk_total), (size_t)n_chunks * 8));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st->d_chunk_base), (size_t)(n_chunks + 1) * 8));
+    st->ws_chunks = n_chunks;
+    return TRRE_OK;
+}
+
+int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, hipStream_t stream) {
+    using namespace trre;
+    Pending& pd = p->pend;
+    pd = Pending();
+    pd.active = true;
+    pd.family = family;
+    pd.d_in = d_in; pd.d_out = d_out; pd.n = n; pd.cap = cap; pd.stream = stream;
+    HIP_TRY(hipGetDevice(&pd.device));
+    if (n == 0) return TRRE_OK;
+    DeviceState* st;
+    int rc = device_state(p, pd.device, &st);
+    if (rc) return rc;
+
+    const int64_t a = (int64_t)(reinterpret_cast<uintptr_t>(d_in) & 15u);
+    ScanArgs args{};
+    args.in_v0 = d_in - a;
+    args.out_v0 = d_out - a;
+    args.out = d_out;
+    args.vbeg = a;
+    args.vend = a + (int64_t)n;
+    args.blob = st->d_blob;
+    args.status = st->d_status;
+    args.cap = cap;
+    args.gscratch = st->d_scratch;
+    const int chunk = chunk_bytes(p->engine, p->mask_bytes);
+    const int64_t n_chunks = (args.vend + chunk - 1) / chunk;
+
+    if (family != TRRE_KERNEL_TILE_GEN && cap < n) return TRRE_OK;   // finish() reports the capacity error
+    if (family == TRRE_KERNEL_TILE_GEN) {
+        rc = ensure_workspace(p, st, n_chunks);
+        if (rc) return rc;
+        args.lane_counts = st->d_lane_counts;
+        args.chunk_total = st->d_chunk_total;
+        args.chunk_base = st->d_chunk_base;
+    }
+    HIP_TRY(hipMemsetAsync(st->d_status, 0, 16, stream));
+    if (p->profiling) { HIP_TRY(hipEventRecord(st->ev0, stream)); pd.timed = true; }
+    if (family == TRRE_KERNEL_BYTEMAP) {
+        launch_bytemap(args, stream);
+    } else if (family == TRRE_KERNEL_TILE_LP) {
+        launch_tile_kernel(0, p->engine, p->mask_bytes, args, n_chunks, stream);
+    } else {
+        launch_tile_kernel(1, p->engine, p->mask_bytes, args, n_chunks, stream);
+        launch_chunk_scan(st->d_chunk_total, st->d_chunk_base, n_chunks, stream);
+        launch_tile_kernel(2, p->engine, p->mask_bytes, args, n_chunks, stream);
+        HIP_TRY(hipMemcpyAsync(st->h_status + 2, st->d_chunk_base + n_chunks, 8, hipMemcpyDeviceToHost, stream));
+    }
+    HIP_TRY(hipGetLastError());
+    if (p->profiling) HIP_TRY(hipEventRecord(st->ev1, stream));
+    HIP_TRY(hipMemcpyAsync(st->h_status, st->d_status, 4, hipMemcpyDeviceToHost, stream));
+    pd.launched = true;
+    return TRRE_OK;
+}
+
+int finish(trre_prog* p, size_t* out_len) {
+    using namespace trre;
+    Pending& pd = p->pend;
+    if (!pd.active) return fail(TRRE_E_ARG, "error: no scan in flight");
+    pd.active = false;
+    if (pd.n == 0) { if (out_len) *out_len = 0; return TRRE_OK; }
+    if (!pd.launched) {                                  // length-preserving family, buffer too small
+        if (out_len) *out_len = pd.n;
+        return fail(TRRE_E_CAPACITY, "error: output buffer too small");
+    }
+    DeviceState* st = &p->dev[pd.device];
+    HIP_TRY(hipStreamSynchronize(pd.stream));
+    if (pd.timed) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, st->ev0, st->ev1));
+        p->last_ms = ms;
+    }
+    const uint32_t status = st->h_status[0];
+    if (status & kStDiverge)
+        return fail(TRRE_E_DIVERGES, "error: stack max capacity reached (the reference's search does not terminate on this input)");
+    if (status & kStNeedScratch) {
+        // a line longer than the LDS tile met the non-deterministic engine: give it
+        // a mask scratch (one mask per input byte) and run again
+        const size_t need = (pd.n + 32) * (size_t)p->mask_bytes;
+        if (st->scratch_bytes < need) {
+            if (st->d_scratch) (void)hipFree(st->d_scratch);
+            st->d_scratch = nullptr; st->scratch_bytes = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st->d_scratch), need));
+            st->scratch_bytes = need;
+        }
+        int rc = enqueue(p, pd.family, pd.d_in, pd.n, pd.d_out, pd.cap, pd.stream);
+        if (rc) return rc;
+        return finish(p, out_len);
+    }
+    if (pd.family != TRRE_KERNEL_TILE_GEN) {
+        if (status & kStNul) {
+            // a NUL cuts its line short, so output positions no longer equal input
+            // positions: redo with the general family
+            int rc = enqueue(p, TRRE_KERNEL_TILE_GEN, pd.d_in, pd.n, pd.d_out, pd.cap, pd.stream);
+            if (rc) return rc;
+            return finish(p, out_len);
+        }
+        if (out_len) *out_len = pd.n;
+        return TRRE_OK;
+    }
+    uint64_t total;
+    std::memcpy(&total, st->h_status + 2, 8);
+    if (out_len) *out_len = (size_t)total;
+    if ((status & kStCapacity) || total > pd.cap) return fail(TRRE_E_CAPACITY, "error: output buffer too small");
+    return TRRE_OK;
+}
+
+int compile_impl(const std::string& pattern, int engine, trre_prog** out) {
+    using namespace trre;
+    if (!out) return fail(TRRE_E_ARG, "error: null output handle");
+    *out = nullptr;
+    if (engine != TRRE_ENGINE_NFT && engine != TRRE_ENGINE_DFT) return fail(TRRE_E_ARG, "error: unknown engine");
+    try {
+        std::unique_ptr<trre_prog> p(new trre_prog);
+        p->engine = engine;
+        Ast ast = parse_pattern(pattern);
+        Nft nft = build_nft(ast, engine == TRRE_ENGINE_DFT);
+        p->nft_states = (uint32_t)nft.st.size();
+        p->nft_cons = (uint32_t)nft.n_cons;
+        if (engine == TRRE_ENGINE_DFT) {
+            Dft dft = determinize(nft);
+            p->dt = flatten_dft(dft);
+            serialize_dft(*p);
+        } else {
+            p->nt = build_nft_tables(nft);
+            p->mask_bytes = p->nt.n_cons <= 8 ? 1 : p->nt.n_cons <= 16 ? 2 : p->nt.n_cons <= 32 ? 4 : 8;
+            serialize_nft(*p);
+        }
+        *out = p.release();
+        return TRRE_OK;
+    } catch (const Error& e) {
+        return fail(e.code, e.what());
+    } catch (const std::bad_alloc&) {
+        return fail(TRRE_E_TOO_BIG, "error: out of memory while compiling the pattern");
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int trre_compile(const char* pattern, int engine, trre_prog** out) {
+    if (!pattern) return fail(TRRE_E_ARG, "error: missing trre expression");
+    return compile_impl(std::string(pattern), engine, out);
+}
+
+int trre_compile_bytes(const uint8_t* pattern, size_t len, int engine, trre_prog** out) {
+    if (!pattern) return fail(TRRE_E_ARG, "error: missing trre expression");
+    return compile_impl(std::string(reinterpret_cast<const char*>(pattern), len), engine, out);
+}
+
+void trre_free(trre_prog* p) {
+    if (!p) return;
+    for (auto& kv : p->dev) {
+        DeviceState& st = kv.second;
+        (void)hipFree(st.d_blob);
+        (void)hipFree(st.d_status);
+        (void)hipHostFree(st.h_status);
+        (void)hipFree(st.d_lane_counts);
+        (void)hipFree(st.d_chunk_total);
+        (void)hipFree(st.d_chunk_base);
+        (void)hipFree(st.d_scratch);
+        if (st.ev0) (void)hipEventDestroy(st.ev0);
+        if (st.ev1) (void)hipEventDestroy(st.ev1);
+    }
+    delete p;
+}
+
+const char* trre_last_error(void) { return g_error.c_str(); }
+
+int trre_get_info(const trre_prog* p, trre_info* info) {
+    if (!p || !info) return fail(TRRE_E_ARG, "error: null argument");
+    std::memset(info, 0, sizeof *info);
+    info->engine = p->engine;
+    info->kernel = p->forced_family ? p->forced_family : auto_family(*p);
+    info->nft_states = p->nft_states;
+    info->nft_cons_states = p->nft_cons;
+    if (p->engine == TRRE_ENGINE_DFT) {
+        info->dft_states = p->dt.n_states;
+        info->table_rows = p->dt.n_rows;
+        info->table_classes = p->dt.n_cls;
+        info->flags = p->dt.flags;
+    } else {
+        info->table_rows = p->nt.n_cons;
+        info->flags = p->nt.flags;
+    }
+    info->table_bytes = (uint32_t)p->blob.size();
+    info->chunk_bytes = (uint32_t)trre::chunk_bytes(p->engine, p->mask_bytes);
+    return TRRE_OK;
+}
+
+int trre_set_kernel(trre_prog* p, int family) {
+    if (!p) return fail(TRRE_E_ARG, "error: null argument");
+    if (family != TRRE_KERNEL_AUTO && !family_allowed(*p, family))
+        return fail(TRRE_E_UNSUPPORTED, "error: this kernel family cannot run these tables");
+    p->forced_family = family;
+    return TRRE_OK;
+}
+
+size_t trre_export_tables(const trre_prog* p, void* buf, size_t cap) {
+    if (!p) return 0;
+    if (buf && cap) std::memcpy(buf, p->blob.data(), cap < p->blob.size() ? cap : p->blob.size());
+    return p->blob.size();
+}
+
+int trre_scan_enqueue(trre_prog* p, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, void* stream) {
+    if (!p || (n && (!d_in || !d_out))) return fail(TRRE_E_ARG, "error: null argument");
+    const int fam = p->forced_family ? p->forced_family : auto_family(*p);
+    return enqueue(p, fam, d_in, n, d_out, cap, static_cast<hipStream_t>(stream));
+}
+
+int trre_scan_finish(trre_prog* p, size_t* out_len) {
+    if (!p) return fail(TRRE_E_ARG, "error: null argument");
+    return finish(p, out_len);
+}
+
+int trre_scan_device(trre_prog* p, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, size_t* out_len,
+                     void* stream) {
+    int rc = trre_scan_enqueue(p, d_in, n, d_out, cap, stream);
+    if (rc) return rc;
+    return trre_scan_finish(p, out_len);
+}
+
+int trre_scan_host(trre_prog* p, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_len, int device) {
+    if (!p || (n && !in)) return fail(TRRE_E_ARG, "error: null argument");
+    HIP_TRY(hipSetDevice(device));
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_in), n + 16));
+    if (hipMalloc(reinterpret_cast<void**>(&d_out), cap + 16) != hipSuccess) {
+        (void)hipFree(d_in);
+        return fail(TRRE_E_DEVICE, "hip: out of device memory");
+    }
+    int rc = TRRE_OK;
+    size_t m = 0;
+    if (hipMemcpy(d_in, in, n, hipMemcpyHostToDevice) != hipSuccess) rc = fail(TRRE_E_DEVICE, "hip: H2D copy failed");
+    if (!rc) rc = trre_scan_device(p, d_in, n, d_out, cap, &m, nullptr);
+    if (out_len) *out_len = m;
+    if (!rc && m && hipMemcpy(out, d_out, m, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(TRRE_E_DEVICE, "hip: D2H copy failed");
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+int trre_set_profiling(trre_prog* p, int on) {
+    if (!p) return fail(TRRE_E_ARG, "error: null argument");
+    p->profiling = on != 0;
+    return TRRE_OK;
+}
+
+int trre_last_kernel_ms(trre_prog* p, float* ms) {
+    if (!p || !ms) return fail(TRRE_E_ARG, "error: null argument");
+    *ms = p->last_ms;
+    return p->last_ms < 0 ? TRRE_E_ARG : TRRE_OK;
+}
+
+int trre_shard_bounds(const uint8_t* in, size_t n, int nshards, size_t* bounds) {
+    if (nshards < 1 || !bounds || (n && !in)) return fail(TRRE_E_ARG, "error: bad shard request");
+    bounds[0] = 0;
+    for (int s = 1; s < nshards; ++s) {
+        size_t cut = n / (size_t)nshards * (size_t)s;
+        if (cut < bounds[s - 1]) cut = bounds[s - 1];
+        const void* nl = cut < n ? std::memchr(in + cut, '\n', n - cut) : nullptr;
+        bounds[s] = nl ? (size_t)(static_cast<const uint8_t*>(nl) - in) + 1 : n;
+    }
+    bounds[nshards] = n;
+    return TRRE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,383 @@
+// scan_block.hpp — what one workgroup does with one chunk of the input.
+//
+// Data layout.  The input is cut into CHUNK-byte chunks in
+// "v-space": v = g + a where g is the byte offset in the caller's buffer and
+// a = (address of in) & 15, so every tile row is a 16-byte aligned HBM
+// address.  Workgroup b owns the lines that START inside chunk b.  It stages
+// the v-range [b*CHUNK - PRE, b*CHUNK + CHUNK + HALO) into an LDS tile with
+// coalesced 16-byte loads (the PRE bytes give the left context that decides
+// whether the chunk begins at a line start, HALO lets the last owned line run
+// past the chunk end).  Lane t then owns the lines that start inside its SUB =
+// CHUNK/THREADS byte sub-range — one lane per line at a time, lanes walking
+// disjoint lines from LDS.  Bytes outside the input are staged as '\n', and so
+// is the input's very last byte (a final record without '\n' loses its last
+// byte: trre_nft.c:777, trre_dft.c:1274), hence every record ends in '\n'.
+// A line that leaves the tile (longer than HALO) is redone by its lane straight
+// from HBM (slow path, correctness only).
+//
+// The functions here are the per-thread bodies of the kernel phases; the
+// kernels in scan_kernels.hip put barriers and wave reductions between them,
+// tests/cpu_shim.cpp runs them thread by thread on the host.
+#pragma once
+#include <cstdint>
+
+#include "device_blob.hpp"
+#include "scan_core.hpp"
+
+namespace trre {
+
+struct alignas(16) U128 { uint32_t x, y, z, w; };
+
+template <int THREADS_, int CHUNK_, int HALO_>
+struct Geometry {
+    static constexpr int THREADS = THREADS_;
+    static constexpr int CHUNK = CHUNK_;
+    static constexpr int HALO = HALO_;
+    static constexpr int PRE = 16;
+    static constexpr int TILE = PRE + CHUNK + HALO;   // staged bytes; tile[TILE] = '\n' sentinel
+    static constexpr int TILE_ALLOC = TILE + 16;
+    static constexpr int SUB = CHUNK / THREADS;
+    static_assert(CHUNK % THREADS == 0 && TILE % 16 == 0, "geometry");
+};
+
+struct ScanArgs {
+    const uint8_t* in_v0;    // in - a   (16-byte aligned)
+    uint8_t* out_v0;         // out - a  (length-preserving launches: out position == in position)
+    uint8_t* out;            // general launches: sequential output
+    int64_t vbeg, vend;      // valid input is v in [vbeg, vend)
+    const uint8_t* blob;     // compiled tables in HBM
+    uint32_t* status;        // status bits (kSt*)
+    uint32_t* lane_counts;   // [n_chunks][THREADS] output bytes per lane (general path)
+    uint64_t* chunk_total;   // [n_chunks]
+    uint64_t* chunk_base;    // [n_chunks + 1] exclusive scan of chunk_total; [n_chunks] = total
+    uint64_t cap;            // capacity of out
+    uint8_t* gscratch;       // NFT long-line mask scratch (or null)
+};
+
+// ---- phase: stage the tile -------------------------------------------------------------
+template <class G>
+TRRE_HD void tile_load(const ScanArgs& a, int64_t v0, uint8_t* tin, int tid) {
+    const uint32_t nl4 = 0x0a0a0a0au;
+    for (int j = tid * 16; j < G::TILE; j += G::THREADS * 16) {
+        const int64_t v = v0 + j;
+        U128 w;
+        if (v + 16 <= a.vbeg || v >= a.vend) {
+            w.x = w.y = w.z = w.w = nl4;
+        } else {
+            w = *reinterpret_cast<const U128*>(a.in_v0 + v);
+            if (v < a.vbeg || v + 16 > a.vend - 1) {       // vector straddles an end of the input
+                uint8_t* b = reinterpret_cast<uint8_t*>(&w);
+                for (int k = 0; k < 16; ++k) {
+                    const int64_t vv = v + k;
+                    if (vv < a.vbeg || vv >= a.vend - 1) b[k] = (uint8_t)'\n';
+                }
+            }
+        }
+        *reinterpret_cast<U128*>(tin + j) = w;
+    }
+    if (tid == 0) tin[G::TILE] = (uint8_t)'\n';
+}
+
+// first line start inside [lo, hi) (tile coordinates), or hi if none
+TRRE_HD int64_t first_line_start(const uint8_t* tin, int64_t lo, int64_t hi) {
+    int64_t q = lo;
+    while (q < hi && tin[q - 1] != (uint8_t)'\n') ++q;
+    return q;
+}
+
+template <class G>
+TRRE_HD void lane_range(const ScanArgs& a, int64_t v0, int tid, int64_t& lo, int64_t& hi) {
+    lo = G::PRE + (int64_t)tid * G::SUB;
+    hi = lo + G::SUB;
+    const int64_t lim_lo = a.vbeg - v0, lim_hi = a.vend - v0;
+    if (lo < lim_lo) lo = lim_lo;
+    if (hi > lim_hi) hi = lim_hi;
+}
+
+// ---- phase: length-preserving walk -------------------------------------------------------
+// Writes the lane's lines into tout at the input's own tile positions and
+// reports the tile range [first, last) it produced.
+template <class G, class Engine>
+TRRE_HD void lane_walk_lp(const ScanArgs& a, const typename Engine::View& T, typename Engine::Lane& L, int64_t v0,
+                          const uint8_t* tin, uint8_t* tout, int tid, int32_t& first, int32_t& last, uint32_t& status) {
+    int64_t lo, hi;
+    lane_range<G>(a, v0, tid, lo, hi);
+    first = 0x7fffffff;
+    last = -1;
+    if (lo >= hi) return;
+    int64_t q = first_line_start(tin, lo, hi);
+    if (q >= hi) return;
+    first = (int32_t)q;
+    while (q < hi) {
+        const int64_t e = Engine::line_lp_tile(T, L, tin, tout, q, G::TILE, status);
+        if (e >= G::TILE) {                   // reached the sentinel: the line leaves the tile
+            status |= kStLongLine;
+            Engine::line_lp_global(T, L, a, v0 + q, status);
+            last = (int32_t)q;
+            return;
+        }
+        q = e + 1;
+    }
+    last = (int32_t)q;
+}
+
+// ---- phase: write the produced tile range back, coalesced ---------------------------------
+template <class G>
+TRRE_HD void tile_store_lp(const ScanArgs& a, int64_t v0, const uint8_t* tout, int first, int last, int tid) {
+    if (first >= last) return;
+    const bool aligned = (reinterpret_cast<uintptr_t>(a.out_v0) & 15u) == 0;
+    for (int j = (first & ~15) + tid * 16; j < last; j += G::THREADS * 16) {
+        if (aligned && j >= first && j + 16 <= last) {
+            *reinterpret_cast<U128*>(a.out_v0 + v0 + j) = *reinterpret_cast<const U128*>(tout + j);
+        } else {
+            for (int k = 0; k < 16; ++k) {
+                const int jj = j + k;
+                if (jj >= first && jj < last) a.out_v0[v0 + jj] = tout[jj];
+            }
+        }
+    }
+}
+
+// ---- phase: general walk (count or emit into a sequential sink) ---------------------------
+template <class G, class Engine, class Sink>
+TRRE_HD void lane_walk_gen(const ScanArgs& a, const typename Engine::View& T, typename Engine::Lane& L, int64_t v0,
+                           const uint8_t* tin, int tid, Sink& sink, uint32_t& status) {
+    int64_t lo, hi;
+    lane_range<G>(a, v0, tid, lo, hi);
+    if (lo >= hi) return;
+    int64_t q = first_line_start(tin, lo, hi);
+    while (q < hi) {
+        const uint64_t mark = sink.n;
+        const int64_t e = Engine::line_gen_tile(T, L, tin, sink, q, G::TILE, status);
+        if (e >= G::TILE) {
+            status |= kStLongLine;
+            sink.n = mark;                    // forget the partial line, redo it from HBM
+            Engine::line_gen_global(T, L, a, sink, v0 + q, status);
+            return;
+        }
+        q = e + 1;
+    }
+}
+
+// copy `total` staged bytes (tout[shift .. shift+total)) to dst, where
+// (dst - shift) is 16-byte aligned
+template <class G>
+TRRE_HD void tile_store_seq(uint8_t* dst, const uint8_t* tout, int shift, int64_t total, int tid) {
+    const int64_t end = shift + total;
+    uint8_t* base = dst - shift;
+    for (int64_t j = (int64_t)tid * 16; j < end; j += G::THREADS * 16) {
+        if (j >= shift && j + 16 <= end) {
+            *reinterpret_cast<U128*>(base + j) = *reinterpret_cast<const U128*>(tout + j);
+        } else {
+            for (int k = 0; k < 16; ++k) {
+                const int64_t jj = j + k;
+                if (jj >= shift && jj < end) base[jj] = tout[jj];
+            }
+        }
+    }
+}
+
+// =============================================================================================
+// Deterministic engine
+// =============================================================================================
+struct DftEngine {
+    static constexpr int kLdsEntBytes = 8192;   // rows kept in LDS when the whole table fits
+    using View = DftView;
+    struct Lane {};
+    static constexpr int kMaskBytes = 0;
+    TRRE_HD static Lane make_lane(uint8_t*) { return Lane{}; }
+
+    // LDS carve for the tables: ent0[256] u64, cls[256], ent[...]
+    static constexpr int kLdsBytes = 2048 + 256 + kLdsEntBytes;
+
+    TRRE_HD static bool ent_fits(const DftBlobHeader& h) { return (uint64_t)h.n_rows * h.n_cls * 8u <= (uint64_t)kLdsEntBytes; }
+
+    // cooperative copy of the hot tables into LDS
+    TRRE_HD static void stage(const uint8_t* blob, uint8_t* lds, int tid, int nthreads) {
+        const DftBlobHeader& h = *reinterpret_cast<const DftBlobHeader*>(blob);
+        const uint64_t* e0 = reinterpret_cast<const uint64_t*>(blob + h.off_ent0);
+        uint64_t* d0 = reinterpret_cast<uint64_t*>(lds);
+        for (int k = tid; k < 256; k += nthreads) d0[k] = e0[k];
+        const uint8_t* c = blob + h.off_cls;
+        for (int k = tid; k < 256; k += nthreads) lds[2048 + k] = c[k];
+        if (ent_fits(h)) {
+            const uint64_t* e = reinterpret_cast<const uint64_t*>(blob + h.off_ent);
+            uint64_t* d = reinterpret_cast<uint64_t*>(lds + 2048 + 256);
+            const int n = (int)(h.n_rows * h.n_cls);
+            for (int k = tid; k < n; k += nthreads) d[k] = e[k];
+        }
+    }
+    TRRE_HD static View view(const uint8_t* blob, const uint8_t* lds) {
+        const DftBlobHeader& h = *reinterpret_cast<const DftBlobHeader*>(blob);
+        View v;
+        v.ent0 = reinterpret_cast<const uint64_t*>(lds);
+        v.cls = lds + 2048;
+        v.ent = ent_fits(h) ? reinterpret_cast<const uint64_t*>(lds + 2048 + 256)
+                            : reinterpret_cast<const uint64_t*>(blob + h.off_ent);
+        v.pool = blob + h.off_pool;
+        v.n_cls = h.n_cls;
+        return v;
+    }
+
+    TRRE_HD static int64_t line_lp_tile(const View& T, Lane&, const uint8_t* tin, uint8_t* tout, int64_t q, int64_t, uint32_t& st) {
+        return dft_line_lp(T, TileIn{tin}, PosOut{tout}, q, st);
+    }
+    TRRE_HD static void line_lp_global(const View& T, Lane&, const ScanArgs& a, int64_t v, uint32_t& st) {
+        dft_line_lp(T, GlobalIn{a.in_v0, a.vend - 1}, PosOut{a.out_v0}, v, st);
+    }
+    template <class Sink>
+    TRRE_HD static int64_t line_gen_tile(const View& T, Lane&, const uint8_t* tin, Sink& s, int64_t q, int64_t, uint32_t&) {
+        return dft_line_gen(T, TileIn{tin}, s, q);
+    }
+    template <class Sink>
+    TRRE_HD static void line_gen_global(const View& T, Lane&, const ScanArgs& a, Sink& s, int64_t v, uint32_t&) {
+        dft_line_gen(T, GlobalIn{a.in_v0, a.vend - 1}, s, v);
+    }
+};
+
+// =============================================================================================
+// Non-deterministic engine.  MaskT is the narrowest unsigned type that holds
+// one bit per CONS state; the G tile holds one MaskT per input byte.
+// =============================================================================================
+template <class MaskT>
+struct NftEngine {
+    using View = NftView;
+    struct Lane { MaskT* gt; };                  // G tile (LDS), indexed by tile position
+    static constexpr int kMaskBytes = (int)sizeof(MaskT);
+    TRRE_HD static Lane make_lane(uint8_t* lds) { return Lane{reinterpret_cast<MaskT*>(lds)}; }
+    static constexpr int kMaxConsLds = 64;
+    // LDS carve: cons_mask[256] u64 + pred[65] u64 + follow_off[66] u32 (+ pad) ; follow lists stay in HBM/L2
+    static constexpr int kLdsBytes = 2048 + 65 * 8 + 66 * 4 + 8;
+
+    TRRE_HD static void stage(const uint8_t* blob, uint8_t* lds, int tid, int nthreads) {
+        const NftBlobHeader& h = *reinterpret_cast<const NftBlobHeader*>(blob);
+        const uint64_t* cm = reinterpret_cast<const uint64_t*>(blob + h.off_cons_mask);
+        uint64_t* d = reinterpret_cast<uint64_t*>(lds);
+        for (int k = tid; k < 256; k += nthreads) d[k] = cm[k];
+        const uint64_t* pr = reinterpret_cast<const uint64_t*>(blob + h.off_pred);
+        for (int k = tid; k <= (int)h.n_cons; k += nthreads) d[256 + k] = pr[k];
+        const uint32_t* fo = reinterpret_cast<const uint32_t*>(blob + h.off_follow_off);
+        uint32_t* df = reinterpret_cast<uint32_t*>(lds + 2048 + 65 * 8);
+        for (int k = tid; k < (int)h.n_cons + 2; k += nthreads) df[k] = fo[k];
+    }
+    TRRE_HD static View view(const uint8_t* blob, const uint8_t* lds) {
+        const NftBlobHeader& h = *reinterpret_cast<const NftBlobHeader*>(blob);
+        View v;
+        v.cons_mask = reinterpret_cast<const uint64_t*>(lds);
+        v.pred = reinterpret_cast<const uint64_t*>(lds) + 256;
+        v.follow_off = reinterpret_cast<const uint32_t*>(lds + 2048 + 65 * 8);
+        v.follow = reinterpret_cast<const NftFollowDev*>(blob + h.off_follow);
+        v.pool = blob + h.off_pool;
+        v.n_cons = h.n_cons;
+        return v;
+    }
+
+    struct TileMask { const MaskT* g; TRRE_HD uint64_t operator()(int64_t i) const { return (uint64_t)g[i]; } };
+    struct GlobalMask { const MaskT* g; TRRE_HD uint64_t operator()(int64_t i) const { return (uint64_t)g[i]; } };
+
+    // line content ends at the first '\n' or NUL; returns that position and the
+    // position of the record's '\n' through rec_end
+    template <class In>
+    TRRE_HD static int64_t line_end(In in, int64_t q, int64_t limit, int64_t& rec_end) {
+        int64_t e = q;
+        uint8_t c;
+        while ((c = in(e)) != (uint8_t)'\n' && c != 0 && e < limit) ++e;
+        rec_end = e;
+        if (c == 0 && e < limit) { do { ++rec_end; } while (in(rec_end) != (uint8_t)'\n' && rec_end < limit); }
+        return e;
+    }
+
+    template <class Sink>
+    TRRE_HD static int64_t line_tile(const View& T, Lane& L, const uint8_t* tin, Sink& s, int64_t q, int64_t tile_len, uint32_t& st) {
+        TileIn in{tin};
+        int64_t rec_end;
+        const int64_t end = line_end(in, q, tile_len, rec_end);
+        if (rec_end >= tile_len) return tile_len;          // leaves the tile: caller takes the slow path
+        uint64_t alive = 0;
+        for (int64_t i = end - 1; i >= q; --i) {           // backward co-reachability sweep
+            alive = nft_back(T, alive, tin[i]);
+            L.gt[i] = (MaskT)alive;
+        }
+        nft_line(T, in, TileMask{L.gt}, s, q, end, st);
+        return rec_end;
+    }
+    template <class Sink>
+    TRRE_HD static int64_t line_global(const View& T, Lane&, const ScanArgs& a, Sink& s, int64_t v, uint32_t& st) {
+        GlobalIn in{a.in_v0, a.vend - 1};
+        int64_t rec_end;
+        const int64_t end = line_end(in, v, a.vend, rec_end);
+        MaskT* g = reinterpret_cast<MaskT*>(a.gscratch);   // one mask per input byte, indexed by v
+        uint64_t alive = 0;
+        for (int64_t i = end - 1; i >= v; --i) {
+            alive = nft_back(T, alive, in(i));
+            g[i] = (MaskT)alive;
+        }
+        nft_line(T, in, GlobalMask{g}, s, v, end, st);
+        return rec_end;
+    }
+
+    // length-preserving: the guided walk never discards output, so a line is
+    // written front to back starting at its own position
+    TRRE_HD static int64_t line_lp_tile(const View& T, Lane& L, const uint8_t* tin, uint8_t* tout, int64_t q, int64_t tile_len, uint32_t& st) {
+        ByteSink s{tout + q};
+        const int64_t e = line_tile(T, L, tin, s, q, tile_len, st);
+        if (e < tile_len && (int64_t)s.n != e - q + 1) st |= kStNul;   // a NUL shortened the record
+        return e;
+    }
+    TRRE_HD static void line_lp_global(const View& T, Lane& L, const ScanArgs& a, int64_t v, uint32_t& st) {
+        if (!a.gscratch) { st |= kStNeedScratch(); return; }
+        ByteSink s{a.out_v0 + v};
+        const int64_t e = line_global(T, L, a, s, v, st);
+        if ((int64_t)s.n != e - v + 1) st |= kStNul;
+    }
+    template <class Sink>
+    TRRE_HD static int64_t line_gen_tile(const View& T, Lane& L, const uint8_t* tin, Sink& s, int64_t q, int64_t tile_len, uint32_t& st) {
+        return line_tile(T, L, tin, s, q, tile_len, st);
+    }
+    template <class Sink>
+    TRRE_HD static void line_gen_global(const View& T, Lane& L, const ScanArgs& a, Sink& s, int64_t v, uint32_t& st) {
+        if (!a.gscratch) { st |= kStNeedScratch(); return; }
+        line_global(T, L, a, s, v, st);
+    }
+    TRRE_HD static constexpr uint32_t kStNeedScratch() { return 1u << 4; }
+};
+constexpr uint32_t kStNeedScratch = 1u << 4;   // NFT long line met without mask scratch: relaunch with it
+
+// =============================================================================================
+// Memoryless tables: out[v] = map[in[v]] for one 16-byte vector at v.
+// =============================================================================================
+TRRE_HD uint32_t map4(const uint8_t* m, uint32_t w) {
+    return (uint32_t)m[w & 0xffu] | (uint32_t)m[(w >> 8) & 0xffu] << 8 | (uint32_t)m[(w >> 16) & 0xffu] << 16 |
+           (uint32_t)m[w >> 24] << 24;
+}
+TRRE_HD uint32_t has_zero_byte(uint32_t w) { return (w - 0x01010101u) & ~w & 0x80808080u; }
+
+TRRE_HD void bytemap_vec(const ScanArgs& a, const uint8_t* map, const U128& w, int64_t v, bool aligned, uint32_t& zero) {
+    U128 r;
+    r.x = map4(map, w.x); r.y = map4(map, w.y); r.z = map4(map, w.z); r.w = map4(map, w.w);
+    if (v >= a.vbeg && v + 16 <= a.vend - 1) {            // interior vector
+        zero |= has_zero_byte(w.x) | has_zero_byte(w.y) | has_zero_byte(w.z) | has_zero_byte(w.w);
+        if (aligned) { *reinterpret_cast<U128*>(a.out_v0 + v) = r; return; }
+    }
+    const uint8_t* src = reinterpret_cast<const uint8_t*>(&w);
+    const uint8_t* dst = reinterpret_cast<const uint8_t*>(&r);
+    for (int b = 0; b < 16; ++b) {
+        const int64_t vv = v + b;
+        if (vv < a.vbeg || vv >= a.vend) continue;
+        if (vv == a.vend - 1) { a.out_v0[vv] = (uint8_t)'\n'; continue; }   // the last byte is a terminator
+        if (src[b] == 0) zero = 1;
+        a.out_v0[vv] = dst[b];
+    }
+}
+
+// =============================================================================================
+// Production geometry per engine: tiles sized so that two workgroups share a
+// CU's 160 KiB of LDS (one for 64-bit masks).
+// =============================================================================================
+using GeoDft = Geometry<256, 32768, 2032>;
+using GeoNft8 = Geometry<256, 16384, 2032>;
+using GeoNft16 = Geometry<256, 16384, 2032>;
+using GeoNft32 = Geometry<256, 8192, 2032>;
+using GeoNft64 = Geometry<256, 8192, 2032>;
+
+}  // namespace trre

@@ -1,0 +1,294 @@
+// scan_kernels.hip — gfx950 kernels of the transducer scan engine.
+//
+// Branchy byte/integer work: no MFMA; the governing roofline is HBM bandwidth
+// (1 byte read + ~1 byte written per input byte).  Kernels:
+//
+//   k_bytemap     memoryless tables (every attempt is one byte -> one byte):
+//                 a pure streaming byte map, 16 bytes per lane per load.
+//   k_scan_lp     length-preserving tables: one launch, output position ==
+//                 input position; tile in LDS, one lane per line, speculative
+//                 in-position writes, coalesced 16-byte copy-out.
+//   k_scan_count  general tables, pass 1: output bytes per lane and per chunk.
+//   k_chunk_scan  exclusive scan of the chunk totals (one workgroup).
+//   k_scan_emit   general tables, pass 2: lane offsets by workgroup scan, lines
+//                 emitted into an LDS staging tile, coalesced copy-out.
+//
+// The per-thread phase bodies live in scan_block.hpp / scan_core.hpp.
+#include <hip/hip_runtime.h>
+
+#include "launch.hpp"
+#include "scan_block.hpp"
+
+namespace trre {
+namespace {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ int wave_min(int v) {
+    for (int d = 32; d; d >>= 1) v = min(v, __shfl_xor(v, d, kWave));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+    for (int d = 32; d; d >>= 1) v = max(v, __shfl_xor(v, d, kWave));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
+    for (int d = 32; d; d >>= 1) v |= (uint32_t)__shfl_xor((int)v, d, kWave);
+    return v;
+}
+__device__ __forceinline__ uint64_t wave_sum(uint64_t v) {
+    for (int d = 32; d; d >>= 1) {
+        uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, d, kWave);
+        uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d, kWave);
+        v += (uint64_t)hi << 32 | lo;
+    }
+    return v;
+}
+// inclusive scan inside a wave
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
+    const int lane = threadIdx.x & (kWave - 1);
+    for (int d = 1; d < kWave; d <<= 1) {
+        uint32_t u = (uint32_t)__shfl_up((int)v, d, kWave);
+        if (lane >= d) v += u;
+    }
+    return v;
+}
+
+// LDS carve shared by the tile kernels
+template <class G, class Engine>
+struct Carve {
+    static constexpr int kTab = (Engine::kLdsBytes + 15) & ~15;
+    static constexpr int kMask = G::TILE_ALLOC * Engine::kMaskBytes;
+    static constexpr int off_tin = 0;
+    static constexpr int off_tout = G::TILE_ALLOC;
+    static constexpr int off_tab = 2 * G::TILE_ALLOC;
+    static constexpr int off_mask = off_tab + kTab;
+    static constexpr int off_red = off_mask + ((kMask + 15) & ~15);
+    static constexpr int kBytes = off_red + 64 + 16 * 8;   // reduction words + per-wave partials
+};
+
+// ------------------------------------------------------------------------------------------
+template <class G, class Engine>
+__global__ __launch_bounds__(G::THREADS) void k_scan_lp(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    using C = Carve<G, Engine>;
+    uint8_t* tin = smem + C::off_tin;
+    uint8_t* tout = smem + C::off_tout;
+    uint8_t* tab = smem + C::off_tab;
+    int32_t* red = reinterpret_cast<int32_t*>(smem + C::off_red);
+    const int tid = threadIdx.x;
+    const int64_t v0 = (int64_t)blockIdx.x * G::CHUNK - G::PRE;
+
+    Engine::stage(a.blob, tab, tid, G::THREADS);
+    tile_load<G>(a, v0, tin, tid);
+    if (tid == 0) { red[0] = 0x7fffffff; red[1] = -1; }
+    __syncthreads();
+
+    const typename Engine::View T = Engine::view(a.blob, tab);
+    typename Engine::Lane L = Engine::make_lane(smem + C::off_mask);
+    int32_t first, last;
+    uint32_t st = 0;
+    lane_walk_lp<G, Engine>(a, T, L, v0, tin, tout, tid, first, last, st);
+
+    first = wave_min(first);
+    last = wave_max(last);
+    st = wave_or(st);
+    if ((tid & (kWave - 1)) == 0) {
+        atomicMin(&red[0], first);
+        atomicMax(&red[1], last);
+        if (st) atomicOr(a.status, st);
+    }
+    __syncthreads();
+    tile_store_lp<G>(a, v0, tout, red[0], red[1], tid);
+}
+
+// ------------------------------------------------------------------------------------------
+template <class G, class Engine>
+__global__ __launch_bounds__(G::THREADS) void k_scan_count(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    using C = Carve<G, Engine>;
+    uint8_t* tin = smem + C::off_tin;
+    uint8_t* tab = smem + C::off_tab;
+    uint64_t* part = reinterpret_cast<uint64_t*>(smem + C::off_red + 64);
+    const int tid = threadIdx.x;
+    const int64_t v0 = (int64_t)blockIdx.x * G::CHUNK - G::PRE;
+
+    Engine::stage(a.blob, tab, tid, G::THREADS);
+    tile_load<G>(a, v0, tin, tid);
+    __syncthreads();
+
+    const typename Engine::View T = Engine::view(a.blob, tab);
+    typename Engine::Lane L = Engine::make_lane(smem + C::off_mask);
+    CountSink sink;
+    uint32_t st = 0;
+    lane_walk_gen<G, Engine>(a, T, L, v0, tin, tid, sink, st);
+    if (sink.n > 0xffffffffull) { st |= kStCapacity; sink.n = 0xffffffffull; }
+    a.lane_counts[(size_t)blockIdx.x * G::THREADS + tid] = (uint32_t)sink.n;
+
+    const uint64_t wsum = wave_sum(sink.n);
+    st = wave_or(st);
+    if ((tid & (kWave - 1)) == 0) {
+        part[tid / kWave] = wsum;
+        if (st) atomicOr(a.status, st);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint64_t t = 0;
+        for (int w = 0; w < G::THREADS / kWave; ++w) t += part[w];
+        a.chunk_total[blockIdx.x] = t;
+    }
+}
+
+// exclusive scan of chunk_total[0..n) into chunk_base[0..n], chunk_base[n] = total
+__global__ __launch_bounds__(1024) void k_chunk_scan(const uint64_t* total, uint64_t* base, int64_t n) {
+    __shared__ uint64_t seg[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t lo = tid * per, hi = lo + per < n ? lo + per : n;
+    uint64_t s = 0;
+    for (int64_t k = lo; k < hi; ++k) s += total[k];
+    seg[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        uint64_t run = 0;
+        for (int k = 0; k < 1024; ++k) { uint64_t t = seg[k]; seg[k] = run; run += t; }
+        base[n] = run;
+    }
+    __syncthreads();
+    uint64_t run = seg[tid];
+    for (int64_t k = lo; k < hi; ++k) { base[k] = run; run += total[k]; }
+}
+
+// ------------------------------------------------------------------------------------------
+template <class G, class Engine>
+__global__ __launch_bounds__(G::THREADS) void k_scan_emit(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    using C = Carve<G, Engine>;
+    uint8_t* tin = smem + C::off_tin;
+    uint8_t* tout = smem + C::off_tout;
+    uint8_t* tab = smem + C::off_tab;
+    uint32_t* wpart = reinterpret_cast<uint32_t*>(smem + C::off_red);
+    const int tid = threadIdx.x;
+    const int64_t v0 = (int64_t)blockIdx.x * G::CHUNK - G::PRE;
+
+    Engine::stage(a.blob, tab, tid, G::THREADS);
+    tile_load<G>(a, v0, tin, tid);
+
+    // lane offsets: workgroup-wide exclusive scan of the counts from pass 1
+    const uint32_t mine = a.lane_counts[(size_t)blockIdx.x * G::THREADS + tid];
+    const uint32_t incl = wave_scan_incl(mine);
+    if ((tid & (kWave - 1)) == kWave - 1) wpart[tid / kWave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < tid / kWave; ++w) wbase += wpart[w];
+    const uint64_t lane_base = (uint64_t)wbase + incl - mine;
+    const uint64_t total = a.chunk_total[blockIdx.x];
+    const uint64_t gbase = a.chunk_base[blockIdx.x];
+    if (gbase + total > a.cap) {                       // uniform for the workgroup
+        if (tid == 0) atomicOr(a.status, kStCapacity);
+        return;
+    }
+    const int shift = (int)((reinterpret_cast<uintptr_t>(a.out) + gbase) & 15u);
+    const bool staged = (uint64_t)shift + total <= (uint64_t)G::TILE;
+
+    const typename Engine::View T = Engine::view(a.blob, tab);
+    typename Engine::Lane L = Engine::make_lane(smem + C::off_mask);
+    ByteSink sink{staged ? tout + shift + lane_base : a.out + gbase + lane_base};
+    uint32_t st = 0;
+    lane_walk_gen<G, Engine>(a, T, L, v0, tin, tid, sink, st);
+    st = wave_or(st);
+    if (st && (tid & (kWave - 1)) == 0) atomicOr(a.status, st);
+    if (staged) {
+        __syncthreads();
+        tile_store_seq<G>(a.out + gbase, tout, shift, (int64_t)total, tid);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// memoryless byte map: out[v] = map[in[v]], 16 bytes per lane per step
+constexpr int kMapThreads = 256;
+constexpr int kMapUnroll = 4;
+
+__global__ __launch_bounds__(kMapThreads) void k_bytemap(ScanArgs a, int64_t nvec) {
+    __shared__ uint8_t map[256];
+    const DftBlobHeader& h = *reinterpret_cast<const DftBlobHeader*>(a.blob);
+    map[threadIdx.x] = a.blob[h.off_bytemap + threadIdx.x];
+    __syncthreads();
+    const bool aligned = (reinterpret_cast<uintptr_t>(a.out_v0) & 15u) == 0;
+    const int64_t vfirst = a.vbeg & ~(int64_t)15;
+    uint32_t zero = 0;
+    const int64_t stride = (int64_t)gridDim.x * kMapThreads * kMapUnroll;
+    for (int64_t base = (int64_t)blockIdx.x * kMapThreads * kMapUnroll; base < nvec; base += stride) {
+        U128 w[kMapUnroll];
+#pragma unroll
+        for (int u = 0; u < kMapUnroll; ++u) {
+            const int64_t k = base + u * kMapThreads + threadIdx.x;
+            if (k < nvec) w[u] = *reinterpret_cast<const U128*>(a.in_v0 + vfirst + k * 16);
+        }
+#pragma unroll
+        for (int u = 0; u < kMapUnroll; ++u) {
+            const int64_t k = base + u * kMapThreads + threadIdx.x;
+            if (k >= nvec) continue;
+            bytemap_vec(a, map, w[u], vfirst + k * 16, aligned, zero);
+        }
+    }
+    if (zero) atomicOr(a.status, kStNul);
+}
+
+// ------------------------------------------------------------------------------------------
+template <class G, class Engine>
+void launch3(int which, const ScanArgs& a, int64_t n_chunks, hipStream_t s) {
+    using C = Carve<G, Engine>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan_lp<G, Engine>), hipFuncAttributeMaxDynamicSharedMemorySize, C::kBytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan_count<G, Engine>), hipFuncAttributeMaxDynamicSharedMemorySize, C::kBytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan_emit<G, Engine>), hipFuncAttributeMaxDynamicSharedMemorySize, C::kBytes);
+        attr_done = true;
+    }
+    const dim3 grid((unsigned)n_chunks), block(G::THREADS);
+    if (which == 0) hipLaunchKernelGGL((k_scan_lp<G, Engine>), grid, block, C::kBytes, s, a);
+    else if (which == 1) hipLaunchKernelGGL((k_scan_count<G, Engine>), grid, block, C::kBytes, s, a);
+    else hipLaunchKernelGGL((k_scan_emit<G, Engine>), grid, block, C::kBytes, s, a);
+}
+
+}  // namespace
+
+int chunk_bytes(int engine, int mask_bytes) {
+    if (engine == kEngineDft) return GeoDft::CHUNK;
+    switch (mask_bytes) {
+    case 1: return GeoNft8::CHUNK;
+    case 2: return GeoNft16::CHUNK;
+    case 4: return GeoNft32::CHUNK;
+    default: return GeoNft64::CHUNK;
+    }
+}
+int block_threads(int, int) { return 256; }
+
+void launch_tile_kernel(int which, int engine, int mask_bytes, const ScanArgs& a, int64_t n_chunks, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (engine == kEngineDft) { launch3<GeoDft, DftEngine>(which, a, n_chunks, s); return; }
+    switch (mask_bytes) {
+    case 1: launch3<GeoNft8, NftEngine<uint8_t>>(which, a, n_chunks, s); break;
+    case 2: launch3<GeoNft16, NftEngine<uint16_t>>(which, a, n_chunks, s); break;
+    case 4: launch3<GeoNft32, NftEngine<uint32_t>>(which, a, n_chunks, s); break;
+    default: launch3<GeoNft64, NftEngine<uint64_t>>(which, a, n_chunks, s); break;
+    }
+}
+
+void launch_chunk_scan(const uint64_t* total, uint64_t* base, int64_t n_chunks, void* stream) {
+    hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), total, base, n_chunks);
+}
+
+void launch_bytemap(const ScanArgs& a, void* stream) {
+    const int64_t vfirst = a.vbeg & ~(int64_t)15;
+    const int64_t nvec = (a.vend - vfirst + 15) / 16;
+    const int64_t per_block = (int64_t)kMapThreads * kMapUnroll;
+    int64_t blocks = (nvec + per_block - 1) / per_block;
+    const int64_t cap = 256 * 16;                     // 256 CUs x 16 resident workgroups, grid-stride beyond
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_bytemap, dim3((unsigned)blocks), dim3(kMapThreads), 0, static_cast<hipStream_t>(stream), a, nvec);
+}
+
+}  // namespace trre
