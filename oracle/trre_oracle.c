@@ -506,7 +506,6 @@ static void create_nft(P *p, int root)
 /* The reference doubles its stack 32,64,... and aborts when the next doubling
  * would exceed 100000 (nft.c:35-36,548-556): at most 65536 live items. */
 #define ORC_BT_MAX 65536u
-#define ORC_OUT_MAX ((size_t)1 << 28)
 
 static void bt_push(P *p, int s, size_t i, size_t o)
 {
@@ -529,6 +528,10 @@ static long nft_attempt(P *p, const unsigned char *in, size_t len, bvec *dst)
     size_t i = 0, o = 0;
     int s = p->start;
     bvec *out = &p->attempt_out;
+    /* an attempt that never goes round an epsilon cycle produces at most one
+     * cycle-free epsilon path (< nns bytes) per consumed byte; far beyond that
+     * the reference is in an output-producing loop that only ends with RAM */
+    const size_t out_max = 8 * (len + 1) * ((size_t)p->nns + 1) + 65536;
     p->nbt = 0;
     while (p->nbt || s >= 0) {
         if (s < 0) {
@@ -543,7 +546,7 @@ static long nft_attempt(P *p, const unsigned char *in, size_t len, bvec *dst)
             else s = -1;
             break;
         case K_PROD:
-            if (o >= ORC_OUT_MAX) fail(p, ORC_E_DIVERGE, "error: attempt output diverges");
+            if (o >= out_max) fail(p, ORC_E_DIVERGE, "error: attempt output diverges");
             bv_reserve(out, o + 1);
             out->b[o++] = st->val;
             s = st->a;
@@ -595,7 +598,6 @@ static void dl_free(dlist *l)
     l->it = NULL; l->n = l->cap = 0;
 }
 
-#define ORC_CLOSURE_DEPTH 20000
 #define ORC_SUFFIX_MAX ((size_t)1 << 20)
 
 /* Priority-ordered epsilon closure carrying the pending output, dft.c:874-907.
@@ -606,7 +608,8 @@ static void dl_free(dlist *l)
  * CONS/FINAL targets are first-writer-wins through `mark` (dft.c:893-903). */
 static void closure(P *p, int s, bvec *o, int c, dlist *sl, int depth)
 {
-    if (depth > ORC_CLOSURE_DEPTH) fail(p, ORC_E_DIVERGE, "error: epsilon cycle (unbounded recursion in the reference)");
+    /* a closure path longer than the automaton has gone round an epsilon cycle */
+    if (depth > p->nns + 1) fail(p, ORC_E_DIVERGE, "error: epsilon cycle (unbounded recursion in the reference)");
     while (s >= 0) {
         nstate *st = &p->ns[s];
         switch (st->kind) {

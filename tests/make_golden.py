@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/golden.json from the COMPILED REFERENCE binaries
+(oracle/_ref/trre, oracle/_ref/trre_dft — built by oracle/Makefile from the
+sources under /root/reference).  Run in the build container only:
+
+    python tests/make_golden.py
+
+The file holds data only: named inputs and, per (pattern, input, engine), the
+bytes the reference printed in scan mode (or "fail" when it exited non-zero /
+did not terminate).  Byte strings are zlib+base64 encoded.
+"""
+import base64
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import zlib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import corpus  # noqa: E402
+from oracle_lib import REF_DIR, build_oracle  # noqa: E402
+
+
+def enc(b):
+    return base64.b64encode(zlib.compress(b, 9)).decode("ascii")
+
+
+def run_ref(engine, pattern, path):
+    binary = os.path.join(REF_DIR, "trre" if engine == "nft" else "trre_dft")
+    try:
+        p = subprocess.run([binary, pattern.encode("latin-1"), path], stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=20)
+    except subprocess.TimeoutExpired:
+        return None
+    return p.stdout if p.returncode == 0 else None
+
+
+def main():
+    build_oracle()
+    inputs = dict(corpus.edge_inputs())
+    cases = []
+    # 1. the reference's own S rows and README examples: their tiny inputs, expected text kept too
+    for k, (inp, pat, exp) in enumerate(corpus.REF_S_CASES + corpus.README_CASES):
+        name = "ref_%02d" % k
+        inputs[name] = inp.encode("latin-1") + b"\n"
+        cases.append({"pattern": pat, "input": name, "expect_nft_text": exp})
+    small = ["words", "embedded_nul", "no_trailing_newline", "many_short", "high_bytes", "empty"]
+    for pat in corpus.CONFIG_PATTERNS:
+        for name in corpus.edge_inputs():
+            cases.append({"pattern": pat, "input": name})
+    for pat in corpus.QUIRK_PATTERNS + sorted({c[1] for c in corpus.REF_S_CASES}):
+        for name in small:
+            cases.append({"pattern": pat, "input": name})
+    out_cases = []
+    with tempfile.TemporaryDirectory() as td:
+        paths = {}
+        for name, data in inputs.items():
+            paths[name] = os.path.join(td, name)
+            with open(paths[name], "wb") as f:
+                f.write(data)
+        for c in cases:
+            for engine in ("nft", "dft"):
+                got = run_ref(engine, c["pattern"], paths[c["input"]])
+                c[engine] = "fail" if got is None else enc(got)
+            if "expect_nft_text" in c:
+                want = (c["expect_nft_text"] + "\n").encode("latin-1")
+                assert zlib.decompress(base64.b64decode(c["nft"])) == want, c
+            out_cases.append(c)
+    doc = {"about": "scan-mode outputs of the compiled reference (c0stya/trre @ 2025-05-23), see make_golden.py",
+           "inputs": {k: enc(v) for k, v in inputs.items()}, "cases": out_cases}
+    os.makedirs(os.path.join(HERE, "golden"), exist_ok=True)
+    path = os.path.join(HERE, "golden", "golden.json")
+    with open(path, "w") as f:
+        json.dump(doc, f, indent=0, sort_keys=True)
+    nfail = sum(1 for c in out_cases for e in ("nft", "dft") if c[e] == "fail")
+    print("wrote %s: %d inputs, %d cases (%d reference failures), %d bytes"
+          % (path, len(inputs), len(out_cases), nfail, os.path.getsize(path)))
+
+
+if __name__ == "__main__":
+    main()

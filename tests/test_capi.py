@@ -1,0 +1,74 @@
+"""The C ABI: the shared library loads, exports every symbol include/trre_mi355x.h
+declares, compiles patterns on the host and reports reference-style errors.
+No compute calls (no GPU in this tier)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import trre_amd
+from trre_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "trre_mi355x.h")).read()
+    return sorted(set(re.findall(r"\b(trre_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = ctypes.CDLL(api.LIB_PATH)
+    syms = declared_symbols()
+    assert len(syms) >= 14
+    for s in syms:
+        assert hasattr(L, s), s
+
+
+def test_compile_reports_reference_error_text():
+    for pat, msg in [("(a", "error: unmached parenthesis"), ("a)", "error: unmached parenthesis"),
+                     ("[a", "error: unmached square brackets"), ("a{1,2,3}", "error: more then one comma in curly brackets"),
+                     ("|a", "error: unexpected symbol |"), ("[a-c:z]", "error: unexpected range syntax")]:
+        with pytest.raises(trre_amd.TrreError) as e:
+            trre_amd.Program(pat, "nft")
+        assert e.value.code == api.E_SYNTAX and e.value.message == msg
+
+
+def test_engine_limits_are_errors_not_fallbacks():
+    big = "|".join("w%03d:x" % k for k in range(40))       # 160 CONS states
+    with pytest.raises(trre_amd.TrreError) as e:
+        trre_amd.Program(big, "nft")
+    assert e.value.code == api.E_UNSUPPORTED
+    assert trre_amd.Program(big, "dft").info.table_rows == 7   # start, w, w0, w00..w03 (trie)
+    with pytest.raises(trre_amd.TrreError) as e:
+        trre_amd.Program("(a*)*", "dft")
+    assert e.value.code == api.E_EPS_CYCLE
+
+
+def test_info_and_table_export():
+    p = trre_amd.Program("(cat:dog|dog:cat)", "dft")
+    blob = p.export_tables()
+    assert blob[:4] == b"TRD1" and len(blob) == p.info.table_bytes
+    p = trre_amd.Program("(cat:dog|dog:cat)", "nft")
+    assert p.export_tables()[:4] == b"TRN1"
+    with pytest.raises(trre_amd.TrreError):
+        p.set_kernel(trre_amd.KERNEL_BYTEMAP)
+
+
+def test_shard_bounds_cut_at_newlines():
+    data = b"".join(b"line %d\n" % k for k in range(1000))
+    b = trre_amd.shard_bounds(data, 8)
+    assert b[0] == 0 and b[-1] == len(data) and b == sorted(b)
+    for x in b[1:-1]:
+        assert data[x - 1:x] == b"\n"
+    assert trre_amd.shard_bounds(b"no newline at all", 4) == [0, 17, 17, 17, 17]
+
+
+def test_scan_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(trre_amd.TrreError) as e:
+        trre_amd.Program("cat:dog", "nft").scan(b"cat\n")
+    assert e.value.code == api.E_DEVICE

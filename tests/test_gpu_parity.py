@@ -1,0 +1,144 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the
+golden vectors (outputs of the compiled reference), the oracle and — when the
+prebuilt binaries travelled along — the reference itself.  Bit-exact: this is
+byte/integer work, the tolerance is zero."""
+import random
+
+import pytest
+
+import corpus
+import golden_lib
+import trre_amd
+from conftest import have_gpu
+from oracle_lib import Oracle, ref_available, ref_scan
+
+pytestmark = pytest.mark.gpu
+
+_progs = {}
+
+
+def prog(pat, eng):
+    key = (pat, eng)
+    if key not in _progs:
+        try:
+            _progs[key] = trre_amd.Program(pat, eng)
+        except trre_amd.TrreError as e:
+            _progs[key] = e
+    return _progs[key]
+
+
+def gpu_scan(p, data, family=None):
+    import torch
+    p.set_kernel(family or trre_amd.KERNEL_AUTO)
+    try:
+        if not data:
+            return p.scan(data)
+        t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+        return p.scan_tensor(t).cpu().numpy().tobytes()
+    finally:
+        p.set_kernel(trre_amd.KERNEL_AUTO)
+
+
+def test_gpu_present_and_native_library_loaded():
+    import torch
+    assert have_gpu(), "the -m gpu tier needs a GPU"
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+    assert trre_amd.api.lib() is not None
+    with open("/proc/self/maps") as f:
+        assert "libtrre_mi355x.so" in f.read()
+
+
+def test_golden_vectors_on_gpu():
+    n = 0
+    for pat, name, data, engine, exp in golden_lib.cases():
+        p = prog(pat, engine)
+        if isinstance(p, trre_amd.TrreError):
+            assert p.code in (trre_amd.api.E_UNSUPPORTED, trre_amd.api.E_EPS_CYCLE, trre_amd.api.E_TOO_BIG)
+            continue
+        assert gpu_scan(p, data) == exp, (pat, name, engine)
+        n += 1
+    assert n > 700
+
+
+def test_every_kernel_family_agrees_on_gpu():
+    rng = random.Random(5)
+    data = corpus.word_soup(rng, 300000) + corpus.printable_lines(rng, 300000) + b"tail without newline"
+    for pat, eng in [("[a:A-z:Z]", "dft"), ("[a:b-y:zz:a]", "dft"), ("(cat:dog|dog:cat)", "dft"),
+                     ("(cat:dog|dog:cat)", "nft"), ("cat:dog", "nft"), ("cat:dog", "dft"), ("a:xyz", "dft"),
+                     ("[aie]:", "nft"), ("abc:2|ab:1", "nft"), ("abc:2|ab:1", "dft")]:
+        p = prog(pat, eng)
+        want = Oracle(pat, eng).scan(data)
+        fams = [3] + ([2] if p.info.flags & 1 and (eng == "nft" or p.info.flags & 4) else []) + ([1] if p.info.flags & 2 else [])
+        for fam in fams:
+            assert gpu_scan(p, data, fam) == want, (pat, eng, fam)
+
+
+def test_unaligned_device_buffers():
+    import torch
+    rng = random.Random(9)
+    data = corpus.word_soup(rng, 100000)
+    for pat, eng in [("[a:A-z:Z]", "dft"), ("(cat:dog|dog:cat)", "nft"), ("cat:dog", "dft"), ("a:xyz", "dft")]:
+        p = prog(pat, eng)
+        want = Oracle(pat, eng).scan(data)
+        for in_mis, out_mis in [(1, 1), (5, 5), (3, 0), (0, 7), (9, 12)]:
+            src = torch.zeros(len(data) + 64, dtype=torch.uint8, device="cuda")
+            src[in_mis:in_mis + len(data)] = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+            dst = torch.zeros(len(want) + 64, dtype=torch.uint8, device="cuda")
+            got = p.scan_tensor(src[in_mis:in_mis + len(data)], out=dst[out_mis:])
+            assert got.cpu().numpy().tobytes() == want, (pat, eng, in_mis, out_mis)
+
+
+def test_long_lines_on_gpu():
+    base = b"cat dog ca do " * 400           # 5.6 kB lines: longer than the tile halo
+    data = b"short cat\n" + base + b"\n" + b"dog\n" + base * 3 + b"\nend cat"
+    for pat, eng in [("(cat:dog|dog:cat)", "dft"), ("(cat:dog|dog:cat)", "nft"), ("a:xyz", "dft"), ("[aie]:", "nft"), ("[a:A-z:Z]", "dft")]:
+        assert gpu_scan(prog(pat, eng), data) == Oracle(pat, eng).scan(data), (pat, eng)
+    one = b"cat " * 300000                     # a single 1.2 MB line without a newline
+    assert gpu_scan(prog("(cat:dog|dog:cat)", "dft"), one) == Oracle("(cat:dog|dog:cat)", "dft").scan(one)
+
+
+def test_capacity_error_reports_needed_size():
+    import ctypes
+    import torch
+    p = prog("a:xyz", "dft")
+    data = b"banana\n" * 1000
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    small = torch.empty(100, dtype=torch.uint8, device="cuda")
+    m = ctypes.c_size_t()
+    rc = trre_amd.api.lib().trre_scan_device(p._h, t.data_ptr(), t.numel(), small.data_ptr(), small.numel(),
+                                             ctypes.byref(m), None)
+    assert rc == trre_amd.api.E_CAPACITY and m.value == len(Oracle("a:xyz", "dft").scan(data))
+
+
+@pytest.mark.skipif(not ref_available(), reason="compiled reference (oracle/_ref) did not travel")
+def test_against_the_compiled_reference_binary():
+    rng = random.Random(21)
+    data = corpus.word_soup(rng, 2 << 20) + corpus.printable_lines(rng, 2 << 20)
+    for pat, eng in [("[a:A-z:Z]", "dft"), ("[a:b-y:zz:a]", "dft"), ("(cat:dog|dog:cat)", "nft"),
+                     ("(cat:dog|dog:cat)", "dft"), ("cat:dog", "nft")]:
+        assert gpu_scan(prog(pat, eng), data) == ref_scan(pat, eng, data, timeout=600), (pat, eng)
+
+
+def test_full_size_properties_1gib_uppercase():
+    """BASELINE config 2 at full size through a size-independent property: the
+    output must equal the input with a-z shifted to A-Z (computed independently
+    with torch on the device), and an oracle-checked 8 MiB slice."""
+    import torch
+    n = 1 << 30
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    data = torch.randint(0x20, 0x7f, (n,), dtype=torch.uint8, device="cuda", generator=g)
+    ends = torch.cumsum(torch.randint(33, 162, (n // 90,), device="cuda", generator=g), 0)
+    data[ends[ends < n]] = 10
+    data[-1] = 10
+    p = prog("[a:A-z:Z]", "dft")
+    for fam in (trre_amd.KERNEL_AUTO, trre_amd.KERNEL_TILE_LP, trre_amd.KERNEL_TILE_GEN):
+        p.set_kernel(fam)
+        out = p.scan_tensor(data)
+        p.set_kernel(trre_amd.KERNEL_AUTO)
+        lower = (data >= 97) & (data <= 122)
+        assert out.numel() == n
+        assert torch.equal(out, torch.where(lower, data - 32, data)), fam
+        del lower
+    cut = int((data[: 8 << 20] == 10).nonzero()[-1]) + 1
+    host = data[:cut].cpu().numpy().tobytes()
+    assert out[:cut].cpu().numpy().tobytes() == Oracle("[a:A-z:Z]", "dft").scan(host)

@@ -1,0 +1,63 @@
+"""The oracle (oracle/trre_oracle.c) against the reference's own results.
+
+Pins the CPU restatement to (a) the reference's scan-mode test rows and README
+examples and (b) outputs of the compiled reference on the configuration
+patterns and quirk probes (tests/golden/golden.json, made by make_golden.py)."""
+import pytest
+
+import corpus
+import golden_lib
+from oracle_lib import Oracle, OracleError, ref_available, ref_scan, scan_mt
+
+
+def test_reference_scan_rows_and_readme():
+    # test.sh `S` rows and README examples: NFT engine (./trre)
+    for inp, pat, exp in corpus.REF_S_CASES + corpus.README_CASES:
+        got = Oracle(pat, "nft").scan(inp.encode("latin-1") + b"\n")
+        assert got == exp.encode("latin-1") + b"\n", (inp, pat)
+
+
+def test_oracle_matches_every_golden_vector():
+    n = 0
+    for pat, name, data, engine, exp in golden_lib.cases():
+        if exp is None:
+            with pytest.raises(OracleError):
+                Oracle(pat, engine).scan(data)
+        else:
+            assert Oracle(pat, engine).scan(data) == exp, (pat, name, engine)
+        n += 1
+    assert n > 700
+
+
+def test_oracle_state_counts():
+    # NFT sizes of the configuration patterns
+    assert Oracle("cat:dog", "nft").nft_states == 7
+    assert Oracle("(cat:dog|dog:cat)", "nft").nft_states == 15
+    assert Oracle("[a:A-z:Z]", "nft").nft_states == 80
+    assert Oracle("[a:A-z:Z]", "dft").nft_states == 81
+    o = Oracle("[a:A-z:Z]", "dft")
+    o.scan(bytes(range(1, 256)).replace(b"\n", b"") + b"\n")
+    assert o.dft_states == 27          # start + 26 one-byte finals
+
+
+def test_oracle_rejects_what_the_reference_rejects():
+    for pat in ["(a", "a)", "[a", "a{1,2,3}", "a{x}", "|a", "*a", "[a-c:z]"]:
+        with pytest.raises(OracleError):
+            Oracle(pat, "nft")
+
+
+def test_line_sharded_threads_equal_single_thread():
+    import random
+    data = corpus.word_soup(random.Random(3), 200000)
+    for pat, eng in [("(cat:dog|dog:cat)", "nft"), ("[a:A-z:Z]", "dft"), ("a:xyz", "dft")]:
+        assert scan_mt(pat, eng, 4, data) == Oracle(pat, eng).scan(data)
+
+
+@pytest.mark.skipif(not ref_available(), reason="compiled reference (oracle/_ref) not present")
+def test_oracle_equals_compiled_reference_on_fresh_inputs():
+    import random
+    rng = random.Random(11)
+    data = corpus.word_soup(rng, 30000) + corpus.printable_lines(rng, 30000)
+    for pat in corpus.CONFIG_PATTERNS + ["a:xyz", "[aie]:", "abc:2|ab:1"]:
+        for eng in ("nft", "dft"):
+            assert Oracle(pat, eng).scan(data) == ref_scan(pat, eng, data), (pat, eng)

@@ -69,6 +69,8 @@ private:
         while (s >= 0) {
             if (++hops > nft_.st.size() + 1)
                 throw Error(kErrEpsCycle, "error: epsilon cycle in the pattern (unbounded recursion in the reference)");
+            if (++work_ > lim_.max_work)
+                throw Error(kErrTooBig, "error: pattern is too expensive to determinise eagerly (closure work cap)");
             const NState& st = nft_.st[s];
             switch (st.kind) {
             case NKind::Split:
@@ -160,6 +162,7 @@ private:
     const Nft& nft_;
     DftLimits lim_;
     std::vector<uint8_t> mark_;
+    uint64_t work_ = 0;
     std::vector<ItemList> lists_;
     std::unordered_map<ItemList, int32_t, ListHash> index_;
     Dft dft_;

@@ -95,6 +95,7 @@ struct Dft {
 struct DftLimits {
     size_t max_states = 60000;
     size_t max_residual = 4096;
+    uint64_t max_work = 40000000;   // epsilon-closure steps over the whole construction
 };
 Dft determinize(const Nft& nft, const DftLimits& lim = DftLimits());
 

@@ -55,6 +55,7 @@ struct Pending {
     hipStream_t stream = nullptr;
     bool launched = false;
     bool timed = false;
+    int count = 0;          // launches in the current batch
 };
 
 template <class T>
@@ -193,8 +194,13 @@ int ensure_workspace(trre_prog* p, DeviceState* st, int64_t n_chunks) {
 int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, hipStream_t stream) {
     using namespace trre;
     Pending& pd = p->pend;
+    // back-to-back enqueues without a finish() in between form one batch: status
+    // bits accumulate and the timing events bracket the whole batch
+    const bool batch = pd.active && pd.launched;
+    const int batch_count = batch ? pd.count : 0;
     pd = Pending();
     pd.active = true;
+    pd.count = batch_count;
     pd.family = family;
     pd.d_in = d_in; pd.d_out = d_out; pd.n = n; pd.cap = cap; pd.stream = stream;
     HIP_TRY(hipGetDevice(&pd.device));
@@ -225,8 +231,11 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
         args.chunk_total = st->d_chunk_total;
         args.chunk_base = st->d_chunk_base;
     }
-    HIP_TRY(hipMemsetAsync(st->d_status, 0, 16, stream));
-    if (p->profiling) { HIP_TRY(hipEventRecord(st->ev0, stream)); pd.timed = true; }
+    if (!batch) {
+        HIP_TRY(hipMemsetAsync(st->d_status, 0, 16, stream));
+        if (p->profiling) HIP_TRY(hipEventRecord(st->ev0, stream));
+    }
+    pd.timed = p->profiling;
     if (family == TRRE_KERNEL_BYTEMAP) {
         launch_bytemap(args, stream);
     } else if (family == TRRE_KERNEL_TILE_LP) {
@@ -241,6 +250,7 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
     if (p->profiling) HIP_TRY(hipEventRecord(st->ev1, stream));
     HIP_TRY(hipMemcpyAsync(st->h_status, st->d_status, 4, hipMemcpyDeviceToHost, stream));
     pd.launched = true;
+    pd.count += 1;
     return TRRE_OK;
 }
 
@@ -259,7 +269,7 @@ int finish(trre_prog* p, size_t* out_len) {
     if (pd.timed) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, st->ev0, st->ev1));
-        p->last_ms = ms;
+        p->last_ms = ms / (float)(pd.count > 0 ? pd.count : 1);   // average per launch of the batch
     }
     const uint32_t status = st->h_status[0];
     if (status & kStDiverge)
