@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--bytes", type=int, default=1 << 30, help="input bytes per GPU")
     ap.add_argument("--pattern", default="[a:A-z:Z]")
     ap.add_argument("--engine", default="dft", choices=["dft", "nft"])
-    ap.add_argument("--kernel", default="auto", choices=["auto", "bytemap", "tile_lp", "tile_gen"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "bytemap", "tile_lp", "tile_gen", "stream_lp", "stream_gen"])
     ap.add_argument("--cpu-sample-mib", type=int, default=512)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
@@ -120,7 +120,7 @@ def main():
         torch.cuda.synchronize()
 
     n = args.bytes
-    fam = {"auto": 0, "bytemap": 1, "tile_lp": 2, "tile_gen": 3}[args.kernel]
+    fam = {"auto": 0, "bytemap": 1, "tile_lp": 2, "tile_gen": 3, "stream_lp": 4, "stream_gen": 5}[args.kernel]
     prog = trre_amd.Program(args.pattern, args.engine)
     prog.set_kernel(fam)
     info = prog.info
@@ -181,7 +181,8 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-            "kernel": {"bytemap": "k_bytemap", "tile_lp": "k_scan_lp", "tile_gen": "k_scan_emit"}[trre_amd.KERNEL_NAMES[info.kernel]],
+            "kernel": {"bytemap": "k_bytemap", "tile_lp": "k_scan_lp", "tile_gen": "k_scan_emit", "stream_lp": "k_stream_lp",
+                       "stream_gen": "k_stream_emit"}[trre_amd.KERNEL_NAMES[info.kernel]],
             "kernel_ms": round(kernel_ms, 4),
             "algorithmic_bytes_per_launch": n,
             "achieved_read_plus_write": round((n + m) / (kernel_ms * 1e-3) / 1e9, 1),
@@ -193,14 +194,12 @@ def main():
         # the other kernel families on the same input (fewer steps): the general
         # lane-per-line kernels are what non-memoryless patterns run on
         extra = {}
-        for name, f in (("tile_lp", 2), ("tile_gen", 3)):
-            try:
-                q = trre_amd.Program(args.pattern, args.engine)
-                q.set_kernel(f)
-            except trre_amd.TrreError:
-                continue
+        q = trre_amd.Program(args.pattern, args.engine)
+        for f in q.allowed_kernels():
+            name = trre_amd.KERNEL_NAMES[f]
             if f == info.kernel:
                 continue
+            q.set_kernel(f)
             run_steps(q, 1)
             q.set_profiling(True)
             torch.cuda.synchronize()

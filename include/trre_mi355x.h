@@ -50,6 +50,8 @@ extern "C" {
 #define TRRE_KERNEL_BYTEMAP 1   /* memoryless tables: streaming byte map */
 #define TRRE_KERNEL_TILE_LP 2   /* length-preserving tables: one lane per line, single launch */
 #define TRRE_KERNEL_TILE_GEN 3  /* any tables: count + scan + emit */
+#define TRRE_KERNEL_STREAM_LP 4 /* scan loop folded into the tables, length-preserving: in-place, single launch */
+#define TRRE_KERNEL_STREAM_GEN 5 /* scan loop folded into the tables, any output length: count + scan + emit */
 
 typedef struct trre_prog trre_prog;
 
@@ -64,6 +66,8 @@ typedef struct trre_info {
     uint32_t table_bytes;      /* size of the device blob */
     uint32_t flags;            /* bit0 length-preserving, bit1 memoryless, bit2 no-overrun */
     uint32_t chunk_bytes;      /* input bytes owned by one workgroup */
+    uint32_t stream_states;    /* states of the folded scan transducer (0 = pattern does not fold) */
+    uint32_t stream_classes;
 } trre_info;
 
 /* Replaces parse() + create_nft() (trre_nft.c:752-754) and, for the DFT engine,
@@ -80,6 +84,7 @@ int trre_set_kernel(trre_prog* p, int kernel_family); /* force a family (benchma
 /* Copy of the device table blob (for offline inspection and the host-side table
  * tests).  Returns the blob size; copies min(size, cap) bytes. */
 size_t trre_export_tables(const trre_prog* p, void* buf, size_t cap);
+size_t trre_export_stream_tables(const trre_prog* p, void* buf, size_t cap); /* 0 if the pattern does not fold */
 
 /* Replaces the scan branch of main() (trre_nft.c:775-790 / trre_dft.c:1272-1286)
  * for a whole buffer that is already resident in HBM.

@@ -96,6 +96,85 @@ void run_gen(ScanArgs a, int64_t n_chunks, uint32_t& status, uint64_t& total_out
     }
 }
 
+// ---- stream engine ------------------------------------------------------------------------
+template <class G>
+void run_stream_lp(const ScanArgs& a, uint32_t& status) {
+    const int64_t n_chunks = (a.vend + G::CHUNK - 1) / G::CHUNK;
+    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
+    std::vector<uint8_t> tile_v(G::TILE_ALLOC + 32), tab_v(StreamEngine::kLdsBytes + 32);
+    uint8_t* tile = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(tile_v.data()) + 15) & ~(uintptr_t)15);
+    uint8_t* tab = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(tab_v.data()) + 15) & ~(uintptr_t)15);
+    for (int64_t b = 0; b < n_chunks; ++b) {
+        const int64_t v0 = b * G::CHUNK - G::PRE;
+        for (int t = 0; t < G::THREADS; ++t) { StreamEngine::stage(a.blob, tab, t, G::THREADS); tile_load<G>(a, v0, tile, t); }
+        std::vector<int64_t> q(G::THREADS), hi(G::THREADS);
+        for (int t = 0; t < G::THREADS; ++t) {            // phase: first line starts, before any in-place write
+            int64_t lo;
+            lane_range<G>(a, v0, t, lo, hi[t]);
+            q[t] = lo < hi[t] ? first_line_start(tile, lo, hi[t]) : hi[t];
+        }
+        const StreamView T = StreamEngine::ent_fits(h) ? StreamEngine::view<true>(a.blob, tab) : StreamEngine::view<false>(a.blob, tab);
+        int32_t first = 0x7fffffff, last = -1;
+        // lanes run in REVERSE order here: a later lane rewriting its bytes must never
+        // disturb an earlier lane that is still reading (they touch disjoint lines)
+        for (int t = G::THREADS - 1; t >= 0; --t) {
+            int32_t f, l;
+            stream_lane_lp<G>(a, T, v0, tile, q[t], hi[t], f, l, status);
+            if (f < first) first = f;
+            if (l > last) last = l;
+        }
+        for (int t = 0; t < G::THREADS; ++t) tile_store_lp<G>(a, v0, tile, first, last, t);
+    }
+}
+
+template <class G>
+void run_stream_gen(ScanArgs a, uint32_t& status, uint64_t& total_out) {
+    const int64_t n_chunks = (a.vend + G::CHUNK - 1) / G::CHUNK;
+    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
+    std::vector<uint8_t> tin_v(G::TILE_ALLOC + 32), tout_v(G::TILE_ALLOC + 32), tab_v(StreamEngine::kLdsBytes + 32);
+    uint8_t* tin = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(tin_v.data()) + 15) & ~(uintptr_t)15);
+    uint8_t* tout = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(tout_v.data()) + 15) & ~(uintptr_t)15);
+    uint8_t* tab = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(tab_v.data()) + 15) & ~(uintptr_t)15);
+    std::vector<uint32_t> lane_counts((size_t)n_chunks * G::THREADS);
+    std::vector<uint64_t> chunk_total(n_chunks), chunk_base(n_chunks + 1);
+    auto view = [&]() { return StreamEngine::ent_fits(h) ? StreamEngine::view<true>(a.blob, tab) : StreamEngine::view<false>(a.blob, tab); };
+    for (int64_t b = 0; b < n_chunks; ++b) {
+        const int64_t v0 = b * G::CHUNK - G::PRE;
+        for (int t = 0; t < G::THREADS; ++t) { StreamEngine::stage(a.blob, tab, t, G::THREADS); tile_load<G>(a, v0, tin, t); }
+        const StreamView T = view();
+        uint64_t tot = 0;
+        for (int t = 0; t < G::THREADS; ++t) {
+            CountSink s;
+            stream_lane_gen<G>(a, T, v0, tin, t, s, status);
+            lane_counts[(size_t)b * G::THREADS + t] = (uint32_t)s.n;
+            tot += s.n;
+        }
+        chunk_total[b] = tot;
+    }
+    uint64_t run = 0;
+    for (int64_t b = 0; b < n_chunks; ++b) { chunk_base[b] = run; run += chunk_total[b]; }
+    total_out = run;
+    if (run > a.cap) { status |= kStCapacity; return; }
+    for (int64_t b = 0; b < n_chunks; ++b) {
+        const int64_t v0 = b * G::CHUNK - G::PRE;
+        for (int t = 0; t < G::THREADS; ++t) { StreamEngine::stage(a.blob, tab, t, G::THREADS); tile_load<G>(a, v0, tin, t); }
+        std::memset(tout, 0xEE, G::TILE_ALLOC);
+        const StreamView T = view();
+        const uint64_t total = chunk_total[b], gbase = chunk_base[b];
+        const int shift = (int)((reinterpret_cast<uintptr_t>(a.out) + gbase) & 15u);
+        const bool staged = (uint64_t)shift + total <= (uint64_t)G::TILE;
+        uint64_t lane_base = 0;
+        for (int t = 0; t < G::THREADS; ++t) {
+            ByteSink s{staged ? tout + shift + lane_base : a.out + gbase + lane_base};
+            stream_lane_gen<G>(a, T, v0, tin, t, s, status);
+            if (s.n != lane_counts[(size_t)b * G::THREADS + t]) status |= 1u << 30;
+            lane_base += lane_counts[(size_t)b * G::THREADS + t];
+        }
+        if (staged)
+            for (int t = 0; t < G::THREADS; ++t) tile_store_seq<G>(a.out + gbase, tout, shift, (int64_t)total, t);
+    }
+}
+
 void run_bytemap(const ScanArgs& a, uint32_t& status) {
     const DftBlobHeader& h = *reinterpret_cast<const DftBlobHeader*>(a.blob);
     const uint8_t* map = a.blob + h.off_bytemap;
@@ -122,7 +201,8 @@ int run_family(int family, ScanArgs& a, uint32_t& status, uint64_t& total) {
 
 extern "C" {
 
-// family: 1 bytemap, 2 tile LP, 3 tile general.  geo: 0 production, 1 tiny.
+// family: 1 bytemap, 2 tile LP, 3 tile general, 4 stream LP (in place), 5 stream general.
+// geo: 0 production, 1 tiny.
 // in_mis/out_mis: address misalignment (0..15) to give the staged buffers.
 // want_scratch: pass a mask scratch to the NFT long-line path.
 int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int geo, const uint8_t* in, size_t n,
@@ -145,8 +225,14 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
     a.gscratch = want_scratch ? scratch.data() : nullptr;
     uint32_t status = 0;
     uint64_t total = 0;
-    if (family != 3 && cap < n) return -9;
+    if (family != 3 && family != 5 && cap < n) return -9;
     if (family == 1) { run_bytemap(a, status); total = n; }
+    else if (family == 4) {
+        if (geo == 0) run_stream_lp<GeoStream>(a, status); else run_stream_lp<GeoTiny>(a, status);
+        total = n;
+    } else if (family == 5) {
+        if (geo == 0) run_stream_gen<GeoStreamGen>(a, status, total); else run_stream_gen<GeoTiny>(a, status, total);
+    }
     else if (engine == 1) {
         if (geo == 0) run_family<GeoDft, DftEngine>(family, a, status, total);
         else run_family<GeoTiny, DftEngine>(family, a, status, total);

@@ -36,11 +36,13 @@ def test_compile_reports_reference_error_text():
 
 
 def test_engine_limits_are_errors_not_fallbacks():
-    big = "|".join("w%03d:x" % k for k in range(40))       # 160 CONS states
-    with pytest.raises(trre_amd.TrreError) as e:
-        trre_amd.Program(big, "nft")
-    assert e.value.code == api.E_UNSUPPORTED
+    big = "|".join("w%03d:x" % k for k in range(40))       # 160 CONS states: too many for the bitmask kernels,
+    p = trre_amd.Program(big, "nft")                        # but the scan loop folds into a stream table
+    assert p.info.kernel == trre_amd.KERNEL_STREAM_GEN and trre_amd.KERNEL_TILE_GEN not in p.allowed_kernels()
     assert trre_amd.Program(big, "dft").info.table_rows == 7   # start, w, w0, w00..w03 (trie)
+    with pytest.raises(trre_amd.TrreError) as e:            # unbounded look-ahead AND > 64 CONS states
+        trre_amd.Program("(" + big.replace(":x", "") + ")*z:y", "nft")
+    assert e.value.code == api.E_UNSUPPORTED
     with pytest.raises(trre_amd.TrreError) as e:
         trre_amd.Program("(a*)*", "dft")
     assert e.value.code == api.E_EPS_CYCLE
@@ -49,7 +51,8 @@ def test_engine_limits_are_errors_not_fallbacks():
 def test_info_and_table_export():
     p = trre_amd.Program("(cat:dog|dog:cat)", "dft")
     blob = p.export_tables()
-    assert blob[:4] == b"TRD1" and len(blob) == p.info.table_bytes
+    sblob = p.export_stream_tables()
+    assert blob[:4] == b"TRD1" and sblob[:4] == b"TRS1" and len(blob) + len(sblob) == p.info.table_bytes
     p = trre_amd.Program("(cat:dog|dog:cat)", "nft")
     assert p.export_tables()[:4] == b"TRN1"
     with pytest.raises(trre_amd.TrreError):

@@ -59,8 +59,7 @@ def test_every_family_agrees():
                      ("(cat:dog|dog:cat)", "nft"), ("cat:dog", "nft"), ("cat:dog", "dft")]:
         p = prog(pat, eng)
         want = Oracle(pat, eng).scan(data)
-        fams = [3] + ([2] if p.info.flags & 1 else []) + ([1] if p.info.flags & 2 else [])
-        for fam in fams:
+        for fam in p.allowed_kernels():
             assert shim_lib.scan_like_runtime(p, data, geo=1, family=fam) == want, (pat, eng, fam)
             assert shim_lib.scan_like_runtime(p, data, geo=0, family=fam) == want, (pat, eng, fam)
 
@@ -72,7 +71,7 @@ def test_unaligned_buffers():
         p = prog(pat, eng)
         want = Oracle(pat, eng).scan(data)
         for in_mis, out_mis in [(0, 0), (1, 1), (5, 5), (15, 15), (3, 0), (0, 7), (9, 12)]:
-            for fam in {p.info.kernel, 3}:
+            for fam in p.allowed_kernels():
                 got = shim_lib.scan_like_runtime(p, data, geo=1, family=fam, in_mis=in_mis, out_mis=out_mis)
                 assert got == want, (pat, eng, fam, in_mis, out_mis)
 
@@ -85,7 +84,7 @@ def test_long_lines_leave_the_tile():
         for pat, eng in [("(cat:dog|dog:cat)", "dft"), ("(cat:dog|dog:cat)", "nft"), ("a:xyz", "dft"), ("[aie]:", "nft"), ("[a:A-z:Z]", "dft")]:
             p = prog(pat, eng)
             want = Oracle(pat, eng).scan(data)
-            for fam in {p.info.kernel, 3}:
+            for fam in p.allowed_kernels():
                 assert shim_lib.scan_like_runtime(p, data, geo=geo, family=fam) == want, (pat, eng, fam, geo)
 
 
@@ -102,11 +101,15 @@ def test_static_properties_of_config_tables():
     i = prog("[a:b-y:zz:a]", "dft").info
     assert (i.dft_states, i.table_rows) == (27, 1) and i.kernel == trre_amd.KERNEL_BYTEMAP
     i = prog("(cat:dog|dog:cat)", "dft").info
-    assert (i.dft_states, i.table_rows) == (7, 5) and i.kernel == trre_amd.KERNEL_TILE_LP
+    assert (i.dft_states, i.table_rows) == (7, 5) and i.kernel == trre_amd.KERNEL_STREAM_LP
+    assert (i.stream_states, i.stream_classes) == (6, 9)      # root, skip, c, ca, d, do  x  c a t d o g other \n NUL
     i = prog("(cat:dog|dog:cat)", "nft").info
-    assert (i.nft_states, i.nft_cons_states) == (15, 6) and i.kernel == trre_amd.KERNEL_TILE_LP
+    assert (i.nft_states, i.nft_cons_states) == (15, 6) and i.kernel == trre_amd.KERNEL_STREAM_LP
     i = prog("a:xyz", "dft").info
-    assert i.kernel == trre_amd.KERNEL_TILE_GEN and not i.flags & 1
+    assert i.kernel == trre_amd.KERNEL_STREAM_GEN and not i.flags & 1
+    # attempts that need unbounded look-ahead do not fold: the tile kernels run them
+    i = prog("a*b:x", "nft").info
+    assert i.stream_states == 0 and i.kernel == trre_amd.KERNEL_TILE_GEN
 
 
 def test_random_patterns_against_oracle():
@@ -135,12 +138,13 @@ def test_random_patterns_against_oracle():
                 assert want is None or e.code in (trre_amd.api.E_UNSUPPORTED, trre_amd.api.E_EPS_CYCLE,
                                                   trre_amd.api.E_TOO_BIG), (pat, eng, str(e))
                 continue
-            try:
-                got = shim_lib.scan_like_runtime(p, data, geo=1)
-            except RuntimeError:
-                got = None                # diverges: the reference's search does not terminate either
-            if want is None:
-                continue                  # reference undefined/diverging on this input: nothing to compare
-            assert got == want, (pat, eng, data)
-            checked += 1
-    assert checked > 150
+            for fam in p.allowed_kernels():
+                try:
+                    got = shim_lib.scan_like_runtime(p, data, geo=1, family=fam)
+                except RuntimeError:
+                    got = None            # diverges: the reference's search does not terminate either
+                if want is None:
+                    continue              # reference undefined/diverging on this input: nothing to compare
+                assert got == want, (pat, eng, fam, data)
+                checked += 1
+    assert checked > 200

@@ -5,5 +5,5 @@ Only what the hot path needs lives here:
   api.py  ctypes mirror of the reference's scan interface
   cli.py  `trre` / `trre_dft` work-alike entry points for scan mode
 """
-from .api import (ENGINE_DFT, ENGINE_NFT, KERNEL_AUTO, KERNEL_BYTEMAP, KERNEL_NAMES, KERNEL_TILE_GEN,  # noqa: F401
-                  KERNEL_TILE_LP, Program, TrreError, build_library, shard_bounds)
+from .api import (ENGINE_DFT, ENGINE_NFT, KERNEL_AUTO, KERNEL_BYTEMAP, KERNEL_NAMES, KERNEL_STREAM_GEN,  # noqa: F401
+                  KERNEL_STREAM_LP, KERNEL_TILE_GEN, KERNEL_TILE_LP, Program, TrreError, build_library, shard_bounds)

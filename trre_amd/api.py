@@ -20,8 +20,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtrre_mi355x.so")
 ENGINE_NFT, ENGINE_DFT = 0, 1
 _ENGINES = {"nft": ENGINE_NFT, "dft": ENGINE_DFT, ENGINE_NFT: ENGINE_NFT, ENGINE_DFT: ENGINE_DFT}
 
-KERNEL_AUTO, KERNEL_BYTEMAP, KERNEL_TILE_LP, KERNEL_TILE_GEN = 0, 1, 2, 3
-KERNEL_NAMES = {0: "auto", 1: "bytemap", 2: "tile_lp", 3: "tile_gen"}
+KERNEL_AUTO, KERNEL_BYTEMAP, KERNEL_TILE_LP, KERNEL_TILE_GEN, KERNEL_STREAM_LP, KERNEL_STREAM_GEN = 0, 1, 2, 3, 4, 5
+KERNEL_NAMES = {0: "auto", 1: "bytemap", 2: "tile_lp", 3: "tile_gen", 4: "stream_lp", 5: "stream_gen"}
 
 FLAG_LENGTH_PRESERVING, FLAG_MEMORYLESS, FLAG_NO_OVERRUN = 1, 2, 4
 
@@ -43,7 +43,8 @@ class Info(ctypes.Structure):
     _fields_ = [("engine", ctypes.c_int32), ("kernel", ctypes.c_int32), ("nft_states", ctypes.c_uint32),
                 ("nft_cons_states", ctypes.c_uint32), ("dft_states", ctypes.c_uint32),
                 ("table_rows", ctypes.c_uint32), ("table_classes", ctypes.c_uint32),
-                ("table_bytes", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("chunk_bytes", ctypes.c_uint32)]
+                ("table_bytes", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("chunk_bytes", ctypes.c_uint32),
+                ("stream_states", ctypes.c_uint32), ("stream_classes", ctypes.c_uint32)]
 
 
 def build_library(force=False):
@@ -76,6 +77,8 @@ def lib():
         L.trre_set_kernel.argtypes = [vp, ctypes.c_int]
         L.trre_export_tables.argtypes = [vp, vp, sz]
         L.trre_export_tables.restype = sz
+        L.trre_export_stream_tables.argtypes = [vp, vp, sz]
+        L.trre_export_stream_tables.restype = sz
         L.trre_scan_device.argtypes = [vp, vp, sz, vp, sz, ctypes.POINTER(sz), vp]
         L.trre_scan_enqueue.argtypes = [vp, vp, sz, vp, sz, vp]
         L.trre_scan_finish.argtypes = [vp, ctypes.POINTER(sz)]
@@ -126,6 +129,20 @@ class Program:
         buf = ctypes.create_string_buffer(n)
         lib().trre_export_tables(self._h, buf, n)
         return buf.raw
+
+    def export_stream_tables(self):
+        n = lib().trre_export_stream_tables(self._h, None, 0)
+        buf = ctypes.create_string_buffer(max(n, 1))
+        lib().trre_export_stream_tables(self._h, buf, n)
+        return buf.raw[:n]
+
+    def allowed_kernels(self):
+        ok = []
+        for fam in (KERNEL_BYTEMAP, KERNEL_TILE_LP, KERNEL_TILE_GEN, KERNEL_STREAM_LP, KERNEL_STREAM_GEN):
+            if lib().trre_set_kernel(self._h, fam) == 0:
+                ok.append(fam)
+        lib().trre_set_kernel(self._h, KERNEL_AUTO)
+        return ok
 
     # ---- device path ---------------------------------------------------------------
     def scan_tensor(self, inp, out=None, stream=None):

@@ -33,4 +33,16 @@ struct NftBlobHeader {
 };
 static_assert(sizeof(NftBlobHeader) == 64, "header layout");
 
+constexpr uint32_t kMagicStream = 0x31535254u;   // "TRS1"
+struct StreamBlobHeader {
+    uint32_t magic, n_states, n_cls, flags;
+    uint32_t off_cls;        // u8[256]
+    uint32_t off_ent;        // u64[n_states][n_cls]
+    uint32_t ent_bytes;
+    uint32_t off_pool, pool_bytes;
+    uint32_t total_bytes, max_out;
+    uint32_t pad[5];
+};
+static_assert(sizeof(StreamBlobHeader) == 64, "header layout");
+
 }  // namespace trre

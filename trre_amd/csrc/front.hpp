@@ -129,6 +129,29 @@ struct DftTables {
 };
 DftTables flatten_dft(const Dft& dft);
 
+// Stream tables: the scan line loop folded into one deterministic transducer over
+// the raw byte stream (stream_build.cpp).  Entry (64 bit):
+//   [23:0]  next state's row offset (state * n_cls)
+//   [26:24] olen   0..4 bytes held inline in [63:32]; 7 = pooled: [63:32] is the
+//                  offset of a {u32 len, bytes} record in the pool
+//   [27]    after those bytes, also emit the input byte itself
+//   [28]    this byte ends the record ('\n')
+struct StreamLimits {
+    size_t max_states = 4096;
+    size_t max_pending = 64;
+    size_t max_out = 4096;
+};
+struct StreamTables {
+    bool ok = false;
+    uint32_t n_states = 0, n_cls = 0, flags = 0, max_out = 0;
+    std::array<uint8_t, 256> cls{};
+    std::vector<uint64_t> ent;              // [n_states][n_cls]
+    std::vector<uint8_t> pool;
+    std::vector<uint32_t> pending_len;      // bytes consumed but not yet emitted, per state
+};
+StreamTables build_stream_dft(const Dft& dft, const StreamLimits& lim = StreamLimits());
+StreamTables build_stream_nft(const Nft& nft, const StreamLimits& lim = StreamLimits());
+
 // Non-deterministic engine (priority-exact).  Only CONS states (and FINAL) are
 // materialised; for each CONS state s (and for the start) `follow` lists, in the
 // reference's depth-first priority order, the CONS/FINAL states reachable from

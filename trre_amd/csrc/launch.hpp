@@ -14,6 +14,10 @@ int block_threads(int engine, int mask_bytes);
 
 // which: 0 length-preserving scan, 1 count pass, 2 emit pass
 void launch_tile_kernel(int which, int engine, int mask_bytes, const ScanArgs& a, int64_t n_chunks, void* stream);
+// stream engine (tables from stream_build.cpp); which: 0 in-place length-preserving, 1 count, 2 emit
+int stream_chunk_bytes(int which);
+int stream_block_threads(int which);
+void launch_stream_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t n_chunks, void* stream);
 void launch_chunk_scan(const uint64_t* total, uint64_t* base, int64_t n_chunks, void* stream);
 void launch_bytemap(const ScanArgs& a, void* stream);
 

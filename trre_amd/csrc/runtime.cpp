@@ -34,6 +34,7 @@ int fail(int code, const std::string& msg) {
 
 struct DeviceState {
     uint8_t* d_blob = nullptr;
+    uint8_t* d_sblob = nullptr;       // stream tables
     uint32_t* d_status = nullptr;     // [4]
     uint32_t* h_status = nullptr;     // pinned mirror: [0] status bits; [2..3] total (u64)
     uint32_t* d_lane_counts = nullptr;
@@ -73,7 +74,10 @@ struct trre_prog {
     uint32_t nft_states = 0, nft_cons = 0;
     trre::DftTables dt;
     trre::NftTables nt;
+    trre::StreamTables stt;
+    bool has_engine_tables = false;   // tile kernels available (always for DFT; NFT: <= 64 CONS states)
     std::vector<uint8_t> blob;
+    std::vector<uint8_t> sblob;
     int mask_bytes = 0;
     bool profiling = false;
     float last_ms = -1.f;
@@ -142,10 +146,37 @@ void serialize_nft(trre_prog& p) {
     put(b, h.off_pool, t.pool.data(), t.pool.size());
 }
 
+void serialize_stream(trre_prog& p) {
+    using namespace trre;
+    const StreamTables& t = p.stt;
+    StreamBlobHeader h{};
+    h.magic = kMagicStream;
+    h.n_states = t.n_states;
+    h.n_cls = t.n_cls;
+    h.flags = t.flags;
+    h.max_out = t.max_out;
+    size_t off = sizeof h;
+    h.off_cls = (uint32_t)off; off += 256;
+    h.off_ent = (uint32_t)off; h.ent_bytes = (uint32_t)(t.ent.size() * 8); off += t.ent.size() * 8;
+    h.off_pool = (uint32_t)off; h.pool_bytes = (uint32_t)t.pool.size(); off += t.pool.size();
+    off = align_up(off + 16, 16);
+    h.total_bytes = (uint32_t)off;
+    std::vector<uint8_t>& b = p.sblob;
+    b.assign(off, 0);
+    put(b, 0, &h, 1);
+    put(b, h.off_cls, t.cls.data(), 256);
+    put(b, h.off_ent, t.ent.data(), t.ent.size());
+    put(b, h.off_pool, t.pool.data(), t.pool.size());
+}
+
+bool is_stream(int fam) { return fam == TRRE_KERNEL_STREAM_LP || fam == TRRE_KERNEL_STREAM_GEN; }
+bool is_gen(int fam) { return fam == TRRE_KERNEL_TILE_GEN || fam == TRRE_KERNEL_STREAM_GEN; }
+
 int auto_family(const trre_prog& p) {
     using namespace trre;
+    if (p.engine == TRRE_ENGINE_DFT && (p.dt.flags & kFlagMemoryless)) return TRRE_KERNEL_BYTEMAP;
+    if (p.stt.ok) return (p.stt.flags & kFlagLengthPreserving) ? TRRE_KERNEL_STREAM_LP : TRRE_KERNEL_STREAM_GEN;
     if (p.engine == TRRE_ENGINE_DFT) {
-        if (p.dt.flags & kFlagMemoryless) return TRRE_KERNEL_BYTEMAP;
         if ((p.dt.flags & kFlagLengthPreserving) && (p.dt.flags & kFlagNoOverrun)) return TRRE_KERNEL_TILE_LP;
         return TRRE_KERNEL_TILE_GEN;
     }
@@ -154,6 +185,9 @@ int auto_family(const trre_prog& p) {
 
 bool family_allowed(const trre_prog& p, int fam) {
     using namespace trre;
+    if (fam == TRRE_KERNEL_STREAM_GEN) return p.stt.ok;
+    if (fam == TRRE_KERNEL_STREAM_LP) return p.stt.ok && (p.stt.flags & kFlagLengthPreserving);
+    if (!p.has_engine_tables) return false;
     if (fam == TRRE_KERNEL_TILE_GEN) return true;
     if (p.engine == TRRE_ENGINE_DFT) {
         if (fam == TRRE_KERNEL_BYTEMAP) return (p.dt.flags & kFlagMemoryless) != 0;
@@ -167,8 +201,14 @@ int device_state(trre_prog* p, int dev, DeviceState** out) {
     auto it = p->dev.find(dev);
     if (it == p->dev.end()) {
         DeviceState st;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st.d_blob), p->blob.size()));
-        HIP_TRY(hipMemcpy(st.d_blob, p->blob.data(), p->blob.size(), hipMemcpyHostToDevice));
+        if (!p->blob.empty()) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st.d_blob), p->blob.size()));
+            HIP_TRY(hipMemcpy(st.d_blob, p->blob.data(), p->blob.size(), hipMemcpyHostToDevice));
+        }
+        if (!p->sblob.empty()) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st.d_sblob), p->sblob.size()));
+            HIP_TRY(hipMemcpy(st.d_sblob, p->sblob.data(), p->sblob.size(), hipMemcpyHostToDevice));
+        }
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st.d_status), 16));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&st.h_status), 16, hipHostMallocDefault));
         HIP_TRY(hipEventCreate(&st.ev0));
@@ -179,12 +219,12 @@ int device_state(trre_prog* p, int dev, DeviceState** out) {
     return TRRE_OK;
 }
 
-int ensure_workspace(trre_prog* p, DeviceState* st, int64_t n_chunks) {
+int ensure_workspace(trre_prog* p, DeviceState* st, int64_t n_chunks, int threads) {
+    n_chunks = n_chunks * ((threads + 255) / 256);      // sized in units of 256-lane chunks
     if (n_chunks <= st->ws_chunks) return TRRE_OK;
     if (st->d_lane_counts) { (void)hipFree(st->d_lane_counts); (void)hipFree(st->d_chunk_total); (void)hipFree(st->d_chunk_base); }
     st->ws_chunks = 0;
-    const int threads = trre::block_threads(p->engine, p->mask_bytes);
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st->d_lane_counts), (size_t)n_chunks * threads * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st->d_lane_counts), (size_t)n_chunks * 256 * 4));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st->d_chunk_total), (size_t)n_chunks * 8));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st->d_chunk_base), (size_t)(n_chunks + 1) * 8));
     st->ws_chunks = n_chunks;
@@ -216,16 +256,20 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
     args.out = d_out;
     args.vbeg = a;
     args.vend = a + (int64_t)n;
-    args.blob = st->d_blob;
+    args.blob = is_stream(family) ? st->d_sblob : st->d_blob;
     args.status = st->d_status;
     args.cap = cap;
     args.gscratch = st->d_scratch;
-    const int chunk = chunk_bytes(p->engine, p->mask_bytes);
+    const int chunk = is_stream(family) ? stream_chunk_bytes(family == TRRE_KERNEL_STREAM_LP ? 0 : 1)
+                                        : chunk_bytes(p->engine, p->mask_bytes);
+    const int threads = is_stream(family) ? stream_block_threads(family == TRRE_KERNEL_STREAM_LP ? 0 : 1)
+                                          : block_threads(p->engine, p->mask_bytes);
     const int64_t n_chunks = (args.vend + chunk - 1) / chunk;
+    const bool ent_lds = p->stt.ok && p->stt.ent.size() * 8 <= (size_t)StreamEngine::kLdsEntBytes;
 
-    if (family != TRRE_KERNEL_TILE_GEN && cap < n) return TRRE_OK;   // finish() reports the capacity error
-    if (family == TRRE_KERNEL_TILE_GEN) {
-        rc = ensure_workspace(p, st, n_chunks);
+    if (!is_gen(family) && cap < n) return TRRE_OK;   // finish() reports the capacity error
+    if (is_gen(family)) {
+        rc = ensure_workspace(p, st, n_chunks, threads);
         if (rc) return rc;
         args.lane_counts = st->d_lane_counts;
         args.chunk_total = st->d_chunk_total;
@@ -240,6 +284,13 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
         launch_bytemap(args, stream);
     } else if (family == TRRE_KERNEL_TILE_LP) {
         launch_tile_kernel(0, p->engine, p->mask_bytes, args, n_chunks, stream);
+    } else if (family == TRRE_KERNEL_STREAM_LP) {
+        launch_stream_kernel(0, ent_lds, args, n_chunks, stream);
+    } else if (family == TRRE_KERNEL_STREAM_GEN) {
+        launch_stream_kernel(1, ent_lds, args, n_chunks, stream);
+        launch_chunk_scan(st->d_chunk_total, st->d_chunk_base, n_chunks, stream);
+        launch_stream_kernel(2, ent_lds, args, n_chunks, stream);
+        HIP_TRY(hipMemcpyAsync(st->h_status + 2, st->d_chunk_base + n_chunks, 8, hipMemcpyDeviceToHost, stream));
     } else {
         launch_tile_kernel(1, p->engine, p->mask_bytes, args, n_chunks, stream);
         launch_chunk_scan(st->d_chunk_total, st->d_chunk_base, n_chunks, stream);
@@ -288,11 +339,12 @@ int finish(trre_prog* p, size_t* out_len) {
         if (rc) return rc;
         return finish(p, out_len);
     }
-    if (pd.family != TRRE_KERNEL_TILE_GEN) {
+    if (!is_gen(pd.family)) {
         if (status & kStNul) {
             // a NUL cuts its line short, so output positions no longer equal input
             // positions: redo with the general family
-            int rc = enqueue(p, TRRE_KERNEL_TILE_GEN, pd.d_in, pd.n, pd.d_out, pd.cap, pd.stream);
+            const int gen = p->stt.ok ? TRRE_KERNEL_STREAM_GEN : TRRE_KERNEL_TILE_GEN;
+            int rc = enqueue(p, gen, pd.d_in, pd.n, pd.d_out, pd.cap, pd.stream);
             if (rc) return rc;
             return finish(p, out_len);
         }
@@ -322,11 +374,23 @@ int compile_impl(const std::string& pattern, int engine, trre_prog** out) {
             Dft dft = determinize(nft);
             p->dt = flatten_dft(dft);
             serialize_dft(*p);
+            p->has_engine_tables = true;
+            p->stt = build_stream_dft(dft);
         } else {
-            p->nt = build_nft_tables(nft);
-            p->mask_bytes = p->nt.n_cons <= 8 ? 1 : p->nt.n_cons <= 16 ? 2 : p->nt.n_cons <= 32 ? 4 : 8;
-            serialize_nft(*p);
+            std::unique_ptr<Error> deferred;
+            try {
+                p->nt = build_nft_tables(nft);
+                p->mask_bytes = p->nt.n_cons <= 8 ? 1 : p->nt.n_cons <= 16 ? 2 : p->nt.n_cons <= 32 ? 4 : 8;
+                serialize_nft(*p);
+                p->has_engine_tables = true;
+            } catch (const Error& e) {
+                if (e.code != kErrUnsupported) throw;
+                deferred.reset(new Error(e));            // too many CONS states for the bitmask kernels
+            }
+            p->stt = build_stream_nft(nft);
+            if (!p->stt.ok && deferred) throw *deferred;  // neither kernel family can run this pattern
         }
+        if (p->stt.ok) serialize_stream(*p);
         *out = p.release();
         return TRRE_OK;
     } catch (const Error& e) {
@@ -355,6 +419,7 @@ void trre_free(trre_prog* p) {
     for (auto& kv : p->dev) {
         DeviceState& st = kv.second;
         (void)hipFree(st.d_blob);
+        (void)hipFree(st.d_sblob);
         (void)hipFree(st.d_status);
         (void)hipHostFree(st.h_status);
         (void)hipFree(st.d_lane_counts);
@@ -385,8 +450,9 @@ int trre_get_info(const trre_prog* p, trre_info* info) {
         info->table_rows = p->nt.n_cons;
         info->flags = p->nt.flags;
     }
-    info->table_bytes = (uint32_t)p->blob.size();
+    info->table_bytes = (uint32_t)(p->blob.size() + p->sblob.size());
     info->chunk_bytes = (uint32_t)trre::chunk_bytes(p->engine, p->mask_bytes);
+    if (p->stt.ok) { info->stream_states = p->stt.n_states; info->stream_classes = p->stt.n_cls; }
     return TRRE_OK;
 }
 
@@ -402,6 +468,12 @@ size_t trre_export_tables(const trre_prog* p, void* buf, size_t cap) {
     if (!p) return 0;
     if (buf && cap) std::memcpy(buf, p->blob.data(), cap < p->blob.size() ? cap : p->blob.size());
     return p->blob.size();
+}
+
+size_t trre_export_stream_tables(const trre_prog* p, void* buf, size_t cap) {
+    if (!p) return 0;
+    if (buf && cap) std::memcpy(buf, p->sblob.data(), cap < p->sblob.size() ? cap : p->sblob.size());
+    return p->sblob.size();
 }
 
 int trre_scan_enqueue(trre_prog* p, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, void* stream) {

@@ -344,6 +344,140 @@ struct NftEngine {
 constexpr uint32_t kStNeedScratch = 1u << 4;   // NFT long line met without mask scratch: relaunch with it
 
 // =============================================================================================
+// Stream engine: one table lookup per byte, no rollback.  Lanes run a flat loop
+// over all their lines (no per-line reconvergence).
+// =============================================================================================
+struct StreamEngine {
+    using View = StreamView;
+    static constexpr int kLdsEntBytes = 8192;    // table rows kept in LDS when they fit, else read through L2
+    static constexpr int kLdsBytes = 256 + kLdsEntBytes;
+
+    TRRE_HD static bool ent_fits(const StreamBlobHeader& h) { return h.ent_bytes <= (uint32_t)kLdsEntBytes; }
+    TRRE_HD static void stage(const uint8_t* blob, uint8_t* lds, int tid, int nthreads) {
+        const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(blob);
+        const uint8_t* c = blob + h.off_cls;
+        for (int k = tid; k < 256; k += nthreads) lds[k] = c[k];
+        if (ent_fits(h)) {
+            const uint64_t* e = reinterpret_cast<const uint64_t*>(blob + h.off_ent);
+            uint64_t* d = reinterpret_cast<uint64_t*>(lds + 256);
+            const int n = (int)(h.ent_bytes / 8);
+            for (int k = tid; k < n; k += nthreads) d[k] = e[k];
+        }
+    }
+    template <bool kLdsEnt>
+    TRRE_HD static View view(const uint8_t* blob, const uint8_t* lds) {
+        const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(blob);
+        View v;
+        v.cls = lds;
+        v.ent = kLdsEnt ? reinterpret_cast<const uint64_t*>(lds + 256) : reinterpret_cast<const uint64_t*>(blob + h.off_ent);
+        v.pool = blob + h.off_pool;
+        return v;
+    }
+};
+
+// one line redone straight from HBM (it left the tile); LP: out position == in position
+TRRE_HD void stream_line_lp_global(const ScanArgs& a, const StreamView& T, int64_t v, uint32_t& status) {
+    GlobalIn in{a.in_v0, a.vend - 1};
+    int64_t p = v, o = v;
+    uint32_t row = 0;
+    for (;;) {
+        const uint8_t c = in(p);
+        const uint64_t e = T.ent[row + T.cls[c]];
+        const uint32_t lo = (uint32_t)e, hi = (uint32_t)(e >> 32);
+        o = str_emit(T, a.out_v0, o, lo, hi, c);
+        row = str_next(lo);
+        ++p;
+        if (lo & kStrEol) break;
+    }
+    if (o != p) status |= kStNul;
+}
+template <class Sink>
+TRRE_HD void stream_line_gen_global(const ScanArgs& a, const StreamView& T, Sink& sink, int64_t v) {
+    GlobalIn in{a.in_v0, a.vend - 1};
+    int64_t p = v;
+    uint32_t row = 0;
+    for (;;) {
+        const uint8_t c = in(p);
+        const uint64_t e = T.ent[row + T.cls[c]];
+        const uint32_t lo = (uint32_t)e, hi = (uint32_t)(e >> 32);
+        if constexpr (Sink::kCountOnly) sink.add(str_count(T, lo, hi));
+        else sink.n = (uint64_t)str_emit(T, sink.o, (int64_t)sink.n, lo, hi, c);
+        row = str_next(lo);
+        ++p;
+        if (lo & kStrEol) break;
+    }
+}
+
+// ---- phase: length-preserving IN-PLACE walk: the tile is input and output ------------------
+// `q` = the lane's first line start (found in an earlier phase, before anyone
+// writes).  Output never overtakes input (the cursor trails by the pending
+// bytes), so writing at tile[o] is safe.  Reports the produced range [first,last).
+template <class G>
+TRRE_HD void stream_lane_lp(const ScanArgs& a, const StreamView& T, int64_t v0, uint8_t* tile, int64_t q, int64_t hi_lim,
+                            int32_t& first, int32_t& last, uint32_t& status) {
+    first = 0x7fffffff;
+    last = -1;
+    if (q >= hi_lim) return;
+    first = (int32_t)q;
+    int64_t p = q, o = q, ls = q;
+    uint32_t row = 0;
+    for (;;) {
+        const uint8_t c = tile[p];
+        const uint64_t e = T.ent[row + T.cls[c]];
+        const uint32_t lo = (uint32_t)e, hi = (uint32_t)(e >> 32);
+        o = str_emit(T, tile, o, lo, hi, c);
+        row = str_next(lo);
+        ++p;
+        if (lo & kStrEol) {
+            if (p > G::TILE) {                 // consumed the sentinel: line `ls` leaves the tile
+                status |= kStLongLine;
+                stream_line_lp_global(a, T, v0 + ls, status);
+                last = (int32_t)ls;
+                return;
+            }
+            if (o != p) { status |= kStNul; o = p; }
+            if (p >= hi_lim) break;
+            ls = p;
+        }
+    }
+    last = (int32_t)p;
+}
+
+// ---- phase: general stream walk into a sequential sink (count or emit) ----------------------
+template <class G, class Sink>
+TRRE_HD void stream_lane_gen(const ScanArgs& a, const StreamView& T, int64_t v0, const uint8_t* tin, int tid, Sink& sink,
+                             uint32_t& status) {
+    int64_t lo_p, hi_p;
+    lane_range<G>(a, v0, tid, lo_p, hi_p);
+    if (lo_p >= hi_p) return;
+    int64_t p = first_line_start(tin, lo_p, hi_p);
+    if (p >= hi_p) return;
+    int64_t ls = p;
+    uint64_t mark = sink.n;
+    uint32_t row = 0;
+    for (;;) {
+        const uint8_t c = tin[p];
+        const uint64_t e = T.ent[row + T.cls[c]];
+        const uint32_t lo = (uint32_t)e, hi = (uint32_t)(e >> 32);
+        if constexpr (Sink::kCountOnly) sink.add(str_count(T, lo, hi));
+        else sink.n = (uint64_t)str_emit(T, sink.o, (int64_t)sink.n, lo, hi, c);
+        row = str_next(lo);
+        ++p;
+        if (lo & kStrEol) {
+            if (p > G::TILE) {
+                status |= kStLongLine;
+                sink.n = mark;
+                stream_line_gen_global(a, T, sink, v0 + ls);
+                return;
+            }
+            if (p >= hi_p) break;
+            ls = p;
+            mark = sink.n;
+        }
+    }
+}
+
+// =============================================================================================
 // Memoryless tables: out[v] = map[in[v]] for one 16-byte vector at v.
 // =============================================================================================
 TRRE_HD uint32_t map4(const uint8_t* m, uint32_t w) {
@@ -379,5 +513,7 @@ using GeoNft8 = Geometry<256, 16384, 2032>;
 using GeoNft16 = Geometry<256, 16384, 2032>;
 using GeoNft32 = Geometry<256, 8192, 2032>;
 using GeoNft64 = Geometry<256, 8192, 2032>;
+using GeoStream = Geometry<512, 65536, 2032>;     // in-place: one tile per workgroup, two workgroups per CU
+using GeoStreamGen = Geometry<256, 32768, 2032>;  // count / emit passes (input tile + staging tile)
 
 }  // namespace trre

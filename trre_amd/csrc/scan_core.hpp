@@ -185,6 +185,46 @@ TRRE_HD int64_t dft_line_gen(const DftView& T, In in, Sink& sink, int64_t p) {
     }
 }
 
+// ---- stream tables (the scan loop folded into one transducer, stream_build.cpp) -----------
+struct StreamView {
+    const uint8_t* cls;     // [256]
+    const uint64_t* ent;    // [n_states][n_cls]
+    const uint8_t* pool;
+};
+constexpr uint32_t kStrCopyC = 1u << 27, kStrEol = 1u << 28;
+
+TRRE_HD uint32_t str_olen(uint32_t lo) { return (lo >> 24) & 7u; }
+TRRE_HD uint32_t str_next(uint32_t lo) { return lo & 0xffffffu; }
+TRRE_HD uint32_t str_pool_len(const StreamView& T, uint32_t hi) {
+    const uint8_t* r = T.pool + hi;
+    return (uint32_t)r[0] | (uint32_t)r[1] << 8 | (uint32_t)r[2] << 16 | (uint32_t)r[3] << 24;
+}
+// number of bytes one transition emits
+TRRE_HD uint32_t str_count(const StreamView& T, uint32_t lo, uint32_t hi) {
+    const uint32_t ol = str_olen(lo);
+    return (ol == 7u ? str_pool_len(T, hi) : ol) + ((lo >> 27) & 1u);
+}
+// write one transition's bytes at o (in-place or staging buffer); returns the new cursor
+TRRE_HD int64_t str_emit(const StreamView& T, uint8_t* dst, int64_t o, uint32_t lo, uint32_t hi, uint8_t c) {
+    const uint32_t ol = str_olen(lo);
+    const uint32_t cc = (lo >> 27) & 1u;
+    if (ol != 7u) {
+        const uint32_t n = ol + cc;
+        if (n) dst[o] = ol ? (uint8_t)hi : c;                  // the common case: at most one byte
+        if (n >= 2u) {                                        // rare: replacement text / flushed pending bytes
+            uint32_t w = hi >> 8;
+            for (uint32_t k = 1; k < ol; ++k) { dst[o + k] = (uint8_t)w; w >>= 8; }
+            if (cc) dst[o + ol] = c;
+        }
+        return o + n;
+    }
+    const uint8_t* r = T.pool + hi;
+    const uint32_t len = str_pool_len(T, hi);
+    for (uint32_t k = 0; k < len; ++k) dst[o + k] = r[4 + k];
+    if (cc) dst[o + len] = c;
+    return o + len + cc;
+}
+
 // ---- non-deterministic tables as the kernel sees them ---------------------------------
 struct NftFollowDev {      // mirrors trre::NftFollow
     uint8_t target, mute;

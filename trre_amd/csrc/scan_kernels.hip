@@ -205,6 +205,133 @@ __global__ __launch_bounds__(G::THREADS) void k_scan_emit(ScanArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Stream engine kernels (tables from stream_build.cpp): no rollback, flat per-lane loops.
+template <class G>
+struct StreamCarve {
+    static constexpr int kTab = (StreamEngine::kLdsBytes + 15) & ~15;
+    static constexpr int off_tin = 0;
+    static constexpr int off_tab = G::TILE_ALLOC;
+    static constexpr int off_red = off_tab + kTab;
+    static constexpr int kBytesOneTile = off_red + 64 + 16 * 8;
+    static constexpr int off_tout = kBytesOneTile;                 // emit pass only
+    static constexpr int kBytesTwoTiles = off_tout + G::TILE_ALLOC;
+};
+
+// length-preserving, in place: the LDS tile is loaded, rewritten by the lanes and copied out
+template <class G, bool kLdsEnt>
+__global__ __launch_bounds__(G::THREADS) void k_stream_lp(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    using C = StreamCarve<G>;
+    uint8_t* tile = smem + C::off_tin;
+    uint8_t* tab = smem + C::off_tab;
+    int32_t* red = reinterpret_cast<int32_t*>(smem + C::off_red);
+    const int tid = threadIdx.x;
+    const int64_t v0 = (int64_t)blockIdx.x * G::CHUNK - G::PRE;
+
+    StreamEngine::stage(a.blob, tab, tid, G::THREADS);
+    tile_load<G>(a, v0, tile, tid);
+    if (tid == 0) { red[0] = 0x7fffffff; red[1] = -1; }
+    __syncthreads();
+
+    // every lane finds its first line start BEFORE anyone overwrites the tile
+    int64_t lo, hi;
+    lane_range<G>(a, v0, tid, lo, hi);
+    const int64_t q = lo < hi ? first_line_start(tile, lo, hi) : hi;
+    __syncthreads();
+
+    const StreamView T = StreamEngine::view<kLdsEnt>(a.blob, tab);
+    int32_t first, last;
+    uint32_t st = 0;
+    stream_lane_lp<G>(a, T, v0, tile, q, hi, first, last, st);
+
+    first = wave_min(first);
+    last = wave_max(last);
+    st = wave_or(st);
+    if ((tid & (kWave - 1)) == 0) {
+        atomicMin(&red[0], first);
+        atomicMax(&red[1], last);
+        if (st) atomicOr(a.status, st);
+    }
+    __syncthreads();
+    tile_store_lp<G>(a, v0, tile, red[0], red[1], tid);
+}
+
+template <class G, bool kLdsEnt>
+__global__ __launch_bounds__(G::THREADS) void k_stream_count(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    using C = StreamCarve<G>;
+    uint8_t* tin = smem + C::off_tin;
+    uint8_t* tab = smem + C::off_tab;
+    uint64_t* part = reinterpret_cast<uint64_t*>(smem + C::off_red + 64);
+    const int tid = threadIdx.x;
+    const int64_t v0 = (int64_t)blockIdx.x * G::CHUNK - G::PRE;
+
+    StreamEngine::stage(a.blob, tab, tid, G::THREADS);
+    tile_load<G>(a, v0, tin, tid);
+    __syncthreads();
+
+    const StreamView T = StreamEngine::view<kLdsEnt>(a.blob, tab);
+    CountSink sink;
+    uint32_t st = 0;
+    stream_lane_gen<G>(a, T, v0, tin, tid, sink, st);
+    if (sink.n > 0xffffffffull) { st |= kStCapacity; sink.n = 0xffffffffull; }
+    a.lane_counts[(size_t)blockIdx.x * G::THREADS + tid] = (uint32_t)sink.n;
+    const uint64_t wsum = wave_sum(sink.n);
+    st = wave_or(st);
+    if ((tid & (kWave - 1)) == 0) {
+        part[tid / kWave] = wsum;
+        if (st) atomicOr(a.status, st);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint64_t t = 0;
+        for (int w = 0; w < G::THREADS / kWave; ++w) t += part[w];
+        a.chunk_total[blockIdx.x] = t;
+    }
+}
+
+template <class G, bool kLdsEnt>
+__global__ __launch_bounds__(G::THREADS) void k_stream_emit(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    using C = StreamCarve<G>;
+    uint8_t* tin = smem + C::off_tin;
+    uint8_t* tout = smem + C::off_tout;
+    uint8_t* tab = smem + C::off_tab;
+    uint32_t* wpart = reinterpret_cast<uint32_t*>(smem + C::off_red);
+    const int tid = threadIdx.x;
+    const int64_t v0 = (int64_t)blockIdx.x * G::CHUNK - G::PRE;
+
+    StreamEngine::stage(a.blob, tab, tid, G::THREADS);
+    tile_load<G>(a, v0, tin, tid);
+    const uint32_t mine = a.lane_counts[(size_t)blockIdx.x * G::THREADS + tid];
+    const uint32_t incl = wave_scan_incl(mine);
+    if ((tid & (kWave - 1)) == kWave - 1) wpart[tid / kWave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < tid / kWave; ++w) wbase += wpart[w];
+    const uint64_t lane_base = (uint64_t)wbase + incl - mine;
+    const uint64_t total = a.chunk_total[blockIdx.x];
+    const uint64_t gbase = a.chunk_base[blockIdx.x];
+    if (gbase + total > a.cap) {
+        if (tid == 0) atomicOr(a.status, kStCapacity);
+        return;
+    }
+    const int shift = (int)((reinterpret_cast<uintptr_t>(a.out) + gbase) & 15u);
+    const bool staged = (uint64_t)shift + total <= (uint64_t)G::TILE;
+
+    const StreamView T = StreamEngine::view<kLdsEnt>(a.blob, tab);
+    ByteSink sink{staged ? tout + shift + lane_base : a.out + gbase + lane_base};
+    uint32_t st = 0;
+    stream_lane_gen<G>(a, T, v0, tin, tid, sink, st);
+    st = wave_or(st);
+    if (st && (tid & (kWave - 1)) == 0) atomicOr(a.status, st);
+    if (staged) {
+        __syncthreads();
+        tile_store_seq<G>(a.out + gbase, tout, shift, (int64_t)total, tid);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // memoryless byte map: out[v] = map[in[v]], 16 bytes per lane per step
 constexpr int kMapThreads = 256;
 constexpr int kMapUnroll = 4;
@@ -274,6 +401,28 @@ void launch_tile_kernel(int which, int engine, int mask_bytes, const ScanArgs& a
     case 4: launch3<GeoNft32, NftEngine<uint32_t>>(which, a, n_chunks, s); break;
     default: launch3<GeoNft64, NftEngine<uint64_t>>(which, a, n_chunks, s); break;
     }
+}
+
+template <bool kLdsEnt>
+void launch_stream_t(int which, const ScanArgs& a, int64_t n_chunks, hipStream_t s) {
+    using GL = GeoStream;
+    using GG = GeoStreamGen;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_lp<GL, kLdsEnt>), hipFuncAttributeMaxDynamicSharedMemorySize, StreamCarve<GL>::kBytesOneTile);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_count<GG, kLdsEnt>), hipFuncAttributeMaxDynamicSharedMemorySize, StreamCarve<GG>::kBytesOneTile);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_emit<GG, kLdsEnt>), hipFuncAttributeMaxDynamicSharedMemorySize, StreamCarve<GG>::kBytesTwoTiles);
+    const dim3 grid((unsigned)n_chunks);
+    if (which == 0) hipLaunchKernelGGL((k_stream_lp<GL, kLdsEnt>), grid, dim3(GL::THREADS), StreamCarve<GL>::kBytesOneTile, s, a);
+    else if (which == 1) hipLaunchKernelGGL((k_stream_count<GG, kLdsEnt>), grid, dim3(GG::THREADS), StreamCarve<GG>::kBytesOneTile, s, a);
+    else hipLaunchKernelGGL((k_stream_emit<GG, kLdsEnt>), grid, dim3(GG::THREADS), StreamCarve<GG>::kBytesTwoTiles, s, a);
+}
+
+int stream_chunk_bytes(int which) { return which == 0 ? GeoStream::CHUNK : GeoStreamGen::CHUNK; }
+int stream_block_threads(int which) { return which == 0 ? GeoStream::THREADS : GeoStreamGen::THREADS; }
+
+void launch_stream_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t n_chunks, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (ent_in_lds) launch_stream_t<true>(which, a, n_chunks, s);
+    else launch_stream_t<false>(which, a, n_chunks, s);
 }
 
 void launch_chunk_scan(const uint64_t* total, uint64_t* base, int64_t n_chunks, void* stream) {

@@ -1,0 +1,320 @@
+// stream_build.cpp — folds the reference's scan line loop INTO the tables.
+//
+// The reference scans a line by repeated attempts: run the automaton from the
+// current position; on success print the attempt's output and skip what it
+// consumed, otherwise copy one raw byte and retry one position further
+// (trre_dft.c:1277-1283, trre_nft.c:780-786).  A failed attempt therefore
+// re-reads input ("rollback"), which on a GPU means divergent, latency-bound
+// lanes.  When every attempt is decided after a bounded number of bytes, the
+// whole loop is itself a deterministic transducer over the raw byte stream:
+//
+//   state    = the bytes consumed since the start of the still-undecided
+//              attempt (the "pending" string; root = empty);
+//   on byte c: pending += c, then resolve from the left exactly as the line
+//              loop would — decided success: emit its output, drop what it
+//              consumed (or, if it consumed nothing, emit one raw byte: the NFT
+//              empty-match rule, trre_nft.c:782-785); decided failure: emit one
+//              raw byte; undecided: stop — what is left is the next state;
+//   on '\n'  : the rest of the line is known to be empty, so everything pending
+//              is resolved (plus the NFT's extra attempt on the empty tail,
+//              trre_nft.c:788), '\n' is emitted and the state returns to root;
+//   on NUL   : like '\n', then a SKIP state swallows the rest of the record
+//              (C-string semantics, trre_nft.c:780 / trre_dft.c:1277,1118).
+//
+// One table lookup per input byte, no rollback, no special cases in the kernel.
+// "Decided" is engine specific and exact: the deterministic engine accepts at
+// the first final state (trre_dft.c:1120-1125); the backtracking engine takes the
+// first path in priority order, so an attempt is undecided as long as a path
+// that is still waiting for input precedes every accepting one
+// (trre_nft.c:593-657).  Patterns whose attempts need unbounded look-ahead
+// (loops before a decision) make the state set infinite; the builder then gives
+// up and the launcher uses the general tile kernels instead.
+#include <algorithm>
+#include <map>
+#include <unordered_map>
+
+#include "front.hpp"
+
+namespace trre {
+namespace {
+
+struct Outcome {
+    enum Kind { Undecided, Fail, Accept } kind = Fail;
+    std::string out;
+    size_t consumed = 0;
+};
+
+struct GiveUp {};   // the pattern does not fold into a bounded stream table
+
+class AttemptModel {
+public:
+    virtual ~AttemptModel() {}
+    virtual Outcome attempt(const std::string& w, bool at_eol) const = 0;
+    virtual bool tries_empty_tail() const = 0;   // the NFT's extra attempt at end of line
+};
+
+// ---- deterministic engine: infer_dft, trre_dft.c:1110-1196 --------------------------------
+class DftModel : public AttemptModel {
+public:
+    explicit DftModel(const Dft& d) : d_(d) {}
+    Outcome attempt(const std::string& w, bool at_eol) const override {
+        Outcome r;
+        int32_t s = 0;
+        for (size_t i = 0; i < w.size(); ++i) {
+            const DftEdge& e = d_.st[s].edge[(uint8_t)w[i]];
+            if (e.to < 0) { r.kind = Outcome::Fail; r.out.clear(); return r; }
+            r.out += e.out;
+            s = e.to;
+            if (d_.st[s].final) {
+                r.kind = Outcome::Accept;
+                r.out += d_.st[s].final_out;
+                r.consumed = i + 1;
+                return r;
+            }
+        }
+        r.out.clear();
+        r.kind = at_eol ? Outcome::Fail : Outcome::Undecided;
+        return r;
+    }
+    bool tries_empty_tail() const override { return false; }   // never accepts: the start state is not final
+
+private:
+    const Dft& d_;
+};
+
+// ---- backtracking engine: infer_backtrack, trre_nft.c:593-657 ------------------------------
+class NftModel : public AttemptModel {
+public:
+    explicit NftModel(const Nft& n) : n_(n) {}
+    Outcome attempt(const std::string& w, bool at_eol) const override {
+        struct Item { int32_t s; size_t i, o; };
+        std::vector<Item> stack;
+        std::string out;
+        Outcome r;
+        int32_t s = n_.start;
+        size_t i = 0, o = 0, steps = 0;
+        while (!stack.empty() || s >= 0) {
+            if (++steps > 2000000 || ++work_ > 30000000) throw GiveUp();   // per-attempt and whole-build budgets
+            if (s < 0) {
+                s = stack.back().s; i = stack.back().i; o = stack.back().o;
+                stack.pop_back();
+                if (s < 0) continue;
+            }
+            const NState& st = n_.st[s];
+            switch (st.kind) {
+            case NKind::Cons:
+                if (i < w.size()) {
+                    if (st.val == (uint8_t)w[i]) { ++i; s = st.a; } else s = -1;
+                } else if (at_eol) {
+                    s = -1;
+                } else {
+                    // this path outranks everything explored later and needs input we
+                    // have not seen: the attempt cannot be decided yet
+                    r.kind = Outcome::Undecided;
+                    return r;
+                }
+                break;
+            case NKind::Prod:
+                if (out.size() <= o) out.resize(o + 1);
+                out[o++] = (char)st.val;
+                if (o > (1u << 16)) throw GiveUp();
+                s = st.a;
+                break;
+            case NKind::Split:
+            case NKind::SplitNg:
+                if (stack.size() >= 65536) throw GiveUp();   // "stack max capacity reached" in the reference
+                stack.push_back(Item{n_.second(s), i, o});
+                s = n_.first(s);
+                break;
+            case NKind::Join:
+                s = st.a;
+                break;
+            case NKind::Final: {
+                r.kind = Outcome::Accept;
+                r.out.assign(out.data(), o);
+                size_t nul = r.out.find('\0');                // fputs stops at a NUL
+                if (nul != std::string::npos) r.out.resize(nul);
+                r.consumed = i;
+                return r;
+            }
+            }
+        }
+        r.kind = Outcome::Fail;
+        return r;
+    }
+    bool tries_empty_tail() const override { return true; }
+
+private:
+    const Nft& n_;
+    mutable uint64_t work_ = 0;
+};
+
+class StreamBuilder {
+public:
+    StreamBuilder(const AttemptModel& m, const StreamLimits& lim) : m_(m), lim_(lim) {}
+
+    StreamTables run() {
+        StreamTables t;
+        intern("");                       // 0 = root
+        skip_ = (uint32_t)names_.size();  // 1 = SKIP (after a NUL)
+        names_.push_back(std::string("\0skip", 5));
+        rows_.emplace_back();
+        for (uint32_t s = 0; s < names_.size(); ++s) {
+            rows_[s].resize(256);
+            if (s == skip_) {
+                for (int c = 0; c < 256; ++c) rows_[s][c] = Cell{c == '\n' ? 0u : skip_, std::string(), false, c == '\n'};
+                continue;
+            }
+            const std::string w = names_[s];
+            for (int c = 0; c < 256; ++c) rows_[s][c] = transition(w, c);
+        }
+        return pack(t);
+    }
+
+private:
+    struct Cell {
+        uint32_t next = 0;
+        std::string out;     // bytes emitted before the optional copy of the input byte
+        bool copy_c = false;
+        bool eol = false;
+    };
+
+    uint32_t intern(const std::string& w) {
+        auto hit = index_.find(w);
+        if (hit != index_.end()) return hit->second;
+        if (names_.size() >= lim_.max_states || w.size() > lim_.max_pending) throw GiveUp();
+        uint32_t id = (uint32_t)names_.size();
+        names_.push_back(w);
+        rows_.emplace_back();
+        index_.emplace(w, id);
+        return id;
+    }
+
+    // resolve pending attempts from the left, exactly like the scan line loop
+    std::string resolve(std::string w, bool at_eol, std::string& out) {
+        while (!w.empty()) {
+            Outcome r = m_.attempt(w, at_eol);
+            if (r.kind == Outcome::Undecided) break;
+            if (r.kind == Outcome::Accept) {
+                out += r.out;
+                if (r.consumed > 0) { w.erase(0, r.consumed); continue; }
+            }
+            out.push_back(w[0]);          // no match here (or an empty one): one raw byte
+            w.erase(0, 1);
+        }
+        if (out.size() > lim_.max_out) throw GiveUp();
+        return w;
+    }
+
+    Cell transition(const std::string& w, int c) {
+        Cell cell;
+        if (c == '\n' || c == 0) {
+            std::string rest = resolve(w, true, cell.out);
+            if (!rest.empty()) throw GiveUp();           // cannot happen: at end of line everything is decided
+            if (m_.tries_empty_tail()) {
+                Outcome r = m_.attempt(std::string(), true);
+                if (r.kind == Outcome::Accept) cell.out += r.out;
+            }
+            cell.out.push_back('\n');
+            cell.next = c == 0 ? skip_ : 0u;
+            cell.eol = c == '\n';          // record end (a NUL only ends the line's content)
+            return cell;
+        }
+        std::string rest = resolve(w + (char)c, false, cell.out);
+        cell.next = intern(rest);
+        // express "... then the input byte itself" through the copy flag so that
+        // bytes the pattern never mentions share one column
+        // (an exact re-encoding of this cell: the last emitted byte equals the byte read)
+        if (!cell.out.empty() && (uint8_t)cell.out.back() == (uint8_t)c) {
+            cell.out.pop_back();
+            cell.copy_c = true;
+        }
+        return cell;
+    }
+
+    StreamTables pack(StreamTables& t) {
+        const uint32_t n = (uint32_t)names_.size();
+        t.n_states = n;
+        t.pending_len.resize(n);
+        for (uint32_t s = 0; s < n; ++s) t.pending_len[s] = s == skip_ ? 0 : (uint32_t)names_[s].size();
+        // byte classes: identical columns over all states
+        std::map<std::vector<std::string>, uint32_t> col_index;
+        std::vector<int> rep;
+        for (int c = 0; c < 256; ++c) {
+            std::vector<std::string> key;
+            key.reserve(n);
+            for (uint32_t s = 0; s < n; ++s) {
+                const Cell& x = rows_[s][c];
+                key.push_back(std::to_string(x.next) + (x.copy_c ? "C" : "-") + (x.eol ? "E" : "-") + x.out);
+            }
+            auto hit = col_index.find(key);
+            if (hit == col_index.end()) {
+                hit = col_index.emplace(std::move(key), (uint32_t)rep.size()).first;
+                rep.push_back(c);
+            }
+            t.cls[c] = (uint8_t)hit->second;
+        }
+        t.n_cls = (uint32_t)rep.size();
+        if ((uint64_t)n * t.n_cls >= (1u << 24)) throw GiveUp();
+        t.ent.resize((size_t)n * t.n_cls);
+        std::unordered_map<std::string, uint32_t> pooled;
+        bool lp = true;
+        for (uint32_t s = 0; s < n; ++s) {
+            for (uint32_t k = 0; k < t.n_cls; ++k) {
+                const Cell& x = rows_[s][rep[k]];
+                uint64_t lo = (uint64_t)x.next * t.n_cls;
+                uint64_t hi = 0;
+                if (x.out.size() <= 4) {
+                    lo |= (uint64_t)x.out.size() << 24;
+                    for (size_t b = 0; b < x.out.size(); ++b) hi |= (uint64_t)(uint8_t)x.out[b] << (8 * b);
+                } else {
+                    lo |= 7ull << 24;
+                    auto hit = pooled.find(x.out);
+                    if (hit == pooled.end()) {
+                        while (t.pool.size() % 4) t.pool.push_back(0);
+                        hit = pooled.emplace(x.out, (uint32_t)t.pool.size()).first;
+                        uint32_t len = (uint32_t)x.out.size();
+                        for (int b = 0; b < 4; ++b) t.pool.push_back((uint8_t)(len >> (8 * b)));
+                        t.pool.insert(t.pool.end(), x.out.begin(), x.out.end());
+                    }
+                    hi = hit->second;
+                }
+                if (x.copy_c) lo |= 1ull << 27;
+                if (x.eol) lo |= 1ull << 28;
+                t.ent[(size_t)s * t.n_cls + k] = lo | hi << 32;
+                t.max_out = std::max<uint32_t>(t.max_out, (uint32_t)x.out.size() + (x.copy_c ? 1 : 0));
+                // length-preserving: bytes emitted = pending released + the byte read
+                if (s != skip_ && rep[k] != 0) {
+                    const int64_t emitted = (int64_t)x.out.size() + (x.copy_c ? 1 : 0);
+                    const int64_t expect = (int64_t)t.pending_len[s] + 1 - (int64_t)t.pending_len[x.next];
+                    if (emitted != expect) lp = false;
+                }
+            }
+        }
+        t.ok = true;
+        if (lp) t.flags |= kFlagLengthPreserving | kFlagNoOverrun;
+        return t;
+    }
+
+    const AttemptModel& m_;
+    StreamLimits lim_;
+    std::vector<std::string> names_;
+    std::vector<std::vector<Cell>> rows_;
+    std::unordered_map<std::string, uint32_t> index_;
+    uint32_t skip_ = 1;
+};
+
+StreamTables build(const AttemptModel& m, const StreamLimits& lim) {
+    try {
+        return StreamBuilder(m, lim).run();
+    } catch (const GiveUp&) {
+        return StreamTables();        // ok == false
+    }
+}
+
+}  // namespace
+
+StreamTables build_stream_dft(const Dft& dft, const StreamLimits& lim) { return build(DftModel(dft), lim); }
+StreamTables build_stream_nft(const Nft& nft, const StreamLimits& lim) { return build(NftModel(nft), lim); }
+
+}  // namespace trre
