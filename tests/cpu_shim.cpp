@@ -20,6 +20,7 @@ using namespace trre;
 namespace {
 
 using GeoTiny = Geometry<4, 64, 32>;
+using GeoTinyStream = Geometry<4, 4 * 20, 32>;   // SUB = 20 bytes = 5 dwords (odd), like the production stream geometry
 
 template <class G, class Engine>
 struct Block {
@@ -107,19 +108,13 @@ void run_stream_lp(const ScanArgs& a, uint32_t& status) {
     for (int64_t b = 0; b < n_chunks; ++b) {
         const int64_t v0 = b * G::CHUNK - G::PRE;
         for (int t = 0; t < G::THREADS; ++t) { StreamEngine::stage(a.blob, tab, t, G::THREADS); tile_load<G>(a, v0, tile, t); }
-        std::vector<int64_t> q(G::THREADS), hi(G::THREADS);
-        for (int t = 0; t < G::THREADS; ++t) {            // phase: first line starts, before any in-place write
-            int64_t lo;
-            lane_range<G>(a, v0, t, lo, hi[t]);
-            q[t] = lo < hi[t] ? first_line_start(tile, lo, hi[t]) : hi[t];
-        }
         const StreamView T = StreamEngine::ent_fits(h) ? StreamEngine::view<true>(a.blob, tab) : StreamEngine::view<false>(a.blob, tab);
         int32_t first = 0x7fffffff, last = -1;
         // lanes run in REVERSE order here: a later lane rewriting its bytes must never
         // disturb an earlier lane that is still reading (they touch disjoint lines)
         for (int t = G::THREADS - 1; t >= 0; --t) {
             int32_t f, l;
-            stream_lane_lp<G>(a, T, v0, tile, q[t], hi[t], f, l, status);
+            stream_lane_lp<G>(a, T, h.n_cls, v0, tile, t, f, l, status);
             if (f < first) first = f;
             if (l > last) last = l;
         }
@@ -145,7 +140,7 @@ void run_stream_gen(ScanArgs a, uint32_t& status, uint64_t& total_out) {
         uint64_t tot = 0;
         for (int t = 0; t < G::THREADS; ++t) {
             CountSink s;
-            stream_lane_gen<G>(a, T, v0, tin, t, s, status);
+            stream_lane_gen<G>(a, T, h.n_cls, v0, tin, t, s, status);
             lane_counts[(size_t)b * G::THREADS + t] = (uint32_t)s.n;
             tot += s.n;
         }
@@ -166,7 +161,7 @@ void run_stream_gen(ScanArgs a, uint32_t& status, uint64_t& total_out) {
         uint64_t lane_base = 0;
         for (int t = 0; t < G::THREADS; ++t) {
             ByteSink s{staged ? tout + shift + lane_base : a.out + gbase + lane_base};
-            stream_lane_gen<G>(a, T, v0, tin, t, s, status);
+            stream_lane_gen<G>(a, T, h.n_cls, v0, tin, t, s, status);
             if (s.n != lane_counts[(size_t)b * G::THREADS + t]) status |= 1u << 30;
             lane_base += lane_counts[(size_t)b * G::THREADS + t];
         }
@@ -228,10 +223,10 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
     if (family != 3 && family != 5 && cap < n) return -9;
     if (family == 1) { run_bytemap(a, status); total = n; }
     else if (family == 4) {
-        if (geo == 0) run_stream_lp<GeoStream>(a, status); else run_stream_lp<GeoTiny>(a, status);
+        if (geo == 0) run_stream_lp<GeoStream>(a, status); else run_stream_lp<GeoTinyStream>(a, status);
         total = n;
     } else if (family == 5) {
-        if (geo == 0) run_stream_gen<GeoStreamGen>(a, status, total); else run_stream_gen<GeoTiny>(a, status, total);
+        if (geo == 0) run_stream_gen<GeoStreamGen>(a, status, total); else run_stream_gen<GeoTinyStream>(a, status, total);
     }
     else if (engine == 1) {
         if (geo == 0) run_family<GeoDft, DftEngine>(family, a, status, total);

@@ -102,7 +102,7 @@ def test_static_properties_of_config_tables():
     assert (i.dft_states, i.table_rows) == (27, 1) and i.kernel == trre_amd.KERNEL_BYTEMAP
     i = prog("(cat:dog|dog:cat)", "dft").info
     assert (i.dft_states, i.table_rows) == (7, 5) and i.kernel == trre_amd.KERNEL_STREAM_LP
-    assert (i.stream_states, i.stream_classes) == (6, 9)      # root, skip, c, ca, d, do  x  c a t d o g other \n NUL
+    assert (i.stream_states, i.stream_classes) == (7, 9)      # root, skip, done, c, ca, d, do  x  c a t d o g other \n NUL
     i = prog("(cat:dog|dog:cat)", "nft").info
     assert (i.nft_states, i.nft_cons_states) == (15, 6) and i.kernel == trre_amd.KERNEL_STREAM_LP
     i = prog("a:xyz", "dft").info

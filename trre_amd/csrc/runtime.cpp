@@ -175,7 +175,8 @@ bool is_gen(int fam) { return fam == TRRE_KERNEL_TILE_GEN || fam == TRRE_KERNEL_
 int auto_family(const trre_prog& p) {
     using namespace trre;
     if (p.engine == TRRE_ENGINE_DFT && (p.dt.flags & kFlagMemoryless)) return TRRE_KERNEL_BYTEMAP;
-    if (p.stt.ok) return (p.stt.flags & kFlagLengthPreserving) ? TRRE_KERNEL_STREAM_LP : TRRE_KERNEL_STREAM_GEN;
+    if (p.stt.ok)
+        return ((p.stt.flags & kFlagLengthPreserving) && (p.stt.flags & kFlagNoOverrun)) ? TRRE_KERNEL_STREAM_LP : TRRE_KERNEL_STREAM_GEN;
     if (p.engine == TRRE_ENGINE_DFT) {
         if ((p.dt.flags & kFlagLengthPreserving) && (p.dt.flags & kFlagNoOverrun)) return TRRE_KERNEL_TILE_LP;
         return TRRE_KERNEL_TILE_GEN;
@@ -186,7 +187,7 @@ int auto_family(const trre_prog& p) {
 bool family_allowed(const trre_prog& p, int fam) {
     using namespace trre;
     if (fam == TRRE_KERNEL_STREAM_GEN) return p.stt.ok;
-    if (fam == TRRE_KERNEL_STREAM_LP) return p.stt.ok && (p.stt.flags & kFlagLengthPreserving);
+    if (fam == TRRE_KERNEL_STREAM_LP) return p.stt.ok && (p.stt.flags & kFlagLengthPreserving) && (p.stt.flags & kFlagNoOverrun);
     if (!p.has_engine_tables) return false;
     if (fam == TRRE_KERNEL_TILE_GEN) return true;
     if (p.engine == TRRE_ENGINE_DFT) {

@@ -61,15 +61,19 @@ TRRE_HD void tile_load(const ScanArgs& a, int64_t v0, uint8_t* tin, int tid) {
     for (int j = tid * 16; j < G::TILE; j += G::THREADS * 16) {
         const int64_t v = v0 + j;
         U128 w;
-        if (v + 16 <= a.vbeg || v >= a.vend) {
+        if (v >= a.vend) {
             w.x = w.y = w.z = w.w = nl4;
+        } else if (v + 16 <= a.vbeg) {                     // before the input: filler, '\n' only right before it
+            w.x = w.y = w.z = 0x78787878u;
+            w.w = v + 16 == a.vbeg ? 0x0a787878u : 0x78787878u;
         } else {
             w = *reinterpret_cast<const U128*>(a.in_v0 + v);
             if (v < a.vbeg || v + 16 > a.vend - 1) {       // vector straddles an end of the input
                 uint8_t* b = reinterpret_cast<uint8_t*>(&w);
                 for (int k = 0; k < 16; ++k) {
                     const int64_t vv = v + k;
-                    if (vv < a.vbeg || vv >= a.vend - 1) b[k] = (uint8_t)'\n';
+                    if (vv >= a.vend - 1) b[k] = (uint8_t)'\n';
+                    else if (vv < a.vbeg) b[k] = vv == a.vbeg - 1 ? (uint8_t)'\n' : (uint8_t)'x';
                 }
             }
         }
@@ -408,72 +412,141 @@ TRRE_HD void stream_line_gen_global(const ScanArgs& a, const StreamView& T, Sink
     }
 }
 
-// ---- phase: length-preserving IN-PLACE walk: the tile is input and output ------------------
-// `q` = the lane's first line start (found in an earlier phase, before anyone
-// writes).  Output never overtakes input (the cursor trails by the pending
-// bytes), so writing at tile[o] is safe.  Reports the produced range [first,last).
+// start of the line that contains position v (HBM, slow path only)
+TRRE_HD int64_t line_start_global(const ScanArgs& a, int64_t v) {
+    while (v > a.vbeg && a.in_v0[v - 1] != (uint8_t)'\n') --v;
+    return v;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TRRE_WAVE_ANY(x) __any(x)
+#else
+#define TRRE_WAVE_ANY(x) (x)
+#endif
+
+constexpr uint32_t kStrNul = 1u << 29;
+constexpr uint32_t kSkipState = 1, kDoneState = 2;
+
+// Lane start for the synchronous walks.  Every lane of a wave reads byte
+// (lo + k) at step k: sub-ranges start 4-byte aligned and SUB/4 is odd, so the
+// 64 dword reads of a wave fall into distinct LDS banks.  A lane whose sub-range
+// does not begin at a line start begins in SKIP (silent until the first '\n'),
+// a lane without input begins in DONE.
 template <class G>
-TRRE_HD void stream_lane_lp(const ScanArgs& a, const StreamView& T, int64_t v0, uint8_t* tile, int64_t q, int64_t hi_lim,
+TRRE_HD void stream_lane_start(const ScanArgs& a, int64_t v0, const uint8_t* tile, int tid, uint32_t n_cls, int& lo, int& hi,
+                               uint32_t& row) {
+    int64_t lo64, hi64;
+    lane_range<G>(a, v0, tid, lo64, hi64);
+    lo = (int)lo64 & ~3;          // only a lane clamped to the start of the input is unaligned; the bytes
+    hi = (int)hi64;               // before the input are staged as non-newline filler + one '\n'
+    if (lo64 >= hi64) { row = kDoneState * n_cls; lo = hi = G::PRE; return; }
+    row = tile[lo - 1] == (uint8_t)'\n' ? 0u : kSkipState * n_cls;
+}
+
+// ---- phase: length-preserving IN-PLACE walk: the tile is input and output ------------------
+// Output never overtakes input (the cursor trails by the pending bytes) and a
+// record end resynchronises it, so writing at tile[o] is safe; lanes in SKIP or
+// DONE write nothing.  Reports [first,last): first owned line start .. end of the
+// last owned line.  One table lookup per byte, no data-dependent branches except
+// the rare multi-byte emission.
+template <class G>
+TRRE_HD void stream_lane_lp(const ScanArgs& a, const StreamView& T, uint32_t n_cls, int64_t v0, uint8_t* tile, int tid,
                             int32_t& first, int32_t& last, uint32_t& status) {
-    first = 0x7fffffff;
-    last = -1;
-    if (q >= hi_lim) return;
-    first = (int32_t)q;
-    int64_t p = q, o = q, ls = q;
-    uint32_t row = 0;
-    for (;;) {
-        const uint8_t c = tile[p];
-        const uint64_t e = T.ent[row + T.cls[c]];
-        const uint32_t lo = (uint32_t)e, hi = (uint32_t)(e >> 32);
-        o = str_emit(T, tile, o, lo, hi, c);
-        row = str_next(lo);
-        ++p;
-        if (lo & kStrEol) {
-            if (p > G::TILE) {                 // consumed the sentinel: line `ls` leaves the tile
-                status |= kStLongLine;
-                stream_line_lp_global(a, T, v0 + ls, status);
-                last = (int32_t)ls;
-                return;
+    int lo, hi;
+    uint32_t row;
+    stream_lane_start<G>(a, v0, tile, tid, n_cls, lo, hi, row);
+    const uint32_t done_row = kDoneState * n_cls;
+    int o = lo;
+    int ls = row == 0u ? lo : -1;          // start of the line being scanned (position after the last record end)
+    int fs = row == 0u ? lo : 0x7fffffff;  // first line start seen
+    uint32_t seen = 0;
+    bool over = false;
+    const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tile);
+    for (int p = lo; TRRE_WAVE_ANY(row != done_row); p += 4) {
+        const int pr = p < G::TILE ? p : G::TILE;           // finished lanes idle on the sentinel dword
+        uint32_t w = t32[pr >> 2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint8_t c = (uint8_t)(w >> (8 * j));
+            const uint64_t e = T.ent[row + T.cls[c]];
+            const uint32_t elo = (uint32_t)e, ehi = (uint32_t)(e >> 32);
+            const uint32_t ol = str_olen(elo), cc = (elo >> 27) & 1u;
+            uint32_t n = ol + cc;
+            if (n) tile[o] = ol ? (uint8_t)ehi : c;
+            if (TRRE_WAVE_ANY(n >= 2u)) {                     // rare: replacement text / flushed pending bytes
+                if (n >= 2u) n = (uint32_t)(str_emit(T, tile, o, elo, ehi, c) - o);
             }
-            if (o != p) { status |= kStNul; o = p; }
-            if (p >= hi_lim) break;
-            ls = p;
+            o += (int)n;
+            row = str_next(elo);
+            seen |= elo;
+            if (elo & kStrEol) {
+                const int p1 = p + j + 1;
+                if (p1 <= G::TILE) {
+                    o = p1;                                   // resynchronise (leaving SKIP, or after a NUL)
+                    ls = p1;
+                    fs = fs < p1 ? fs : p1;
+                } else {
+                    over = true;                              // that was the sentinel, not a record end
+                }
+                if (p1 >= hi) row = done_row;
+            }
         }
     }
-    last = (int32_t)p;
+    if (seen & kStrNul) status |= kStNul;
+    first = fs;
+    last = ls;
+    if (over && ls >= 0) {                    // the line that starts at ls leaves the tile: redo it from HBM
+        status |= kStLongLine;
+        stream_line_lp_global(a, T, v0 + ls, status);
+    }
 }
 
 // ---- phase: general stream walk into a sequential sink (count or emit) ----------------------
 template <class G, class Sink>
-TRRE_HD void stream_lane_gen(const ScanArgs& a, const StreamView& T, int64_t v0, const uint8_t* tin, int tid, Sink& sink,
-                             uint32_t& status) {
-    int64_t lo_p, hi_p;
-    lane_range<G>(a, v0, tid, lo_p, hi_p);
-    if (lo_p >= hi_p) return;
-    int64_t p = first_line_start(tin, lo_p, hi_p);
-    if (p >= hi_p) return;
-    int64_t ls = p;
-    uint64_t mark = sink.n;
-    uint32_t row = 0;
-    for (;;) {
-        const uint8_t c = tin[p];
-        const uint64_t e = T.ent[row + T.cls[c]];
-        const uint32_t lo = (uint32_t)e, hi = (uint32_t)(e >> 32);
-        if constexpr (Sink::kCountOnly) sink.add(str_count(T, lo, hi));
-        else sink.n = (uint64_t)str_emit(T, sink.o, (int64_t)sink.n, lo, hi, c);
-        row = str_next(lo);
-        ++p;
-        if (lo & kStrEol) {
-            if (p > G::TILE) {
-                status |= kStLongLine;
-                sink.n = mark;
-                stream_line_gen_global(a, T, sink, v0 + ls);
-                return;
+TRRE_HD void stream_lane_gen(const ScanArgs& a, const StreamView& T, uint32_t n_cls, int64_t v0, const uint8_t* tin, int tid,
+                             Sink& sink, uint32_t& status) {
+    int lo, hi;
+    uint32_t row;
+    stream_lane_start<G>(a, v0, tin, tid, n_cls, lo, hi, row);
+    const uint32_t done_row = kDoneState * n_cls;
+    int ls = row == 0u ? lo : -1;
+    bool over = false;
+    uint64_t mark = sink.n;                   // sink position at the start of the current line
+    const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tin);
+    for (int p = lo; TRRE_WAVE_ANY(row != done_row); p += 4) {
+        const int pr = p < G::TILE ? p : G::TILE;
+        uint32_t w = t32[pr >> 2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint8_t c = (uint8_t)(w >> (8 * j));
+            const uint64_t e = T.ent[row + T.cls[c]];
+            const uint32_t elo = (uint32_t)e, ehi = (uint32_t)(e >> 32);
+            if constexpr (Sink::kCountOnly) {
+                const uint32_t ol = str_olen(elo);
+                uint32_t n = ol + ((elo >> 27) & 1u);
+                if (TRRE_WAVE_ANY(ol == 7u)) { if (ol == 7u) n = str_count(T, elo, ehi); }
+                sink.n += n;
+            } else {
+                const uint32_t ol = str_olen(elo), cc = (elo >> 27) & 1u;
+                uint32_t n = ol + cc;
+                if (n) sink.o[sink.n] = ol ? (uint8_t)ehi : c;
+                if (TRRE_WAVE_ANY(n >= 2u)) {
+                    if (n >= 2u) n = (uint32_t)(str_emit(T, sink.o, (int64_t)sink.n, elo, ehi, c) - (int64_t)sink.n);
+                }
+                sink.n += n;
             }
-            if (p >= hi_p) break;
-            ls = p;
-            mark = sink.n;
+            row = str_next(elo);
+            if (elo & kStrEol) {
+                const int p1 = p + j + 1;
+                if (p1 <= G::TILE) { ls = p1; mark = sink.n; } else over = true;
+                if (p1 >= hi) row = done_row;
+            }
         }
+    }
+    if (over && ls >= 0) {                    // the line that starts at ls leaves the tile: redo it from HBM
+        status |= kStLongLine;
+        sink.n = mark;
+        stream_line_gen_global(a, T, sink, v0 + ls);
     }
 }
 
@@ -513,7 +586,8 @@ using GeoNft8 = Geometry<256, 16384, 2032>;
 using GeoNft16 = Geometry<256, 16384, 2032>;
 using GeoNft32 = Geometry<256, 8192, 2032>;
 using GeoNft64 = Geometry<256, 8192, 2032>;
-using GeoStream = Geometry<512, 65536, 2032>;     // in-place: one tile per workgroup, two workgroups per CU
-using GeoStreamGen = Geometry<256, 32768, 2032>;  // count / emit passes (input tile + staging tile)
+// stream engine: SUB = 132 bytes = 33 dwords per lane (odd), see stream_lane_start
+using GeoStream = Geometry<512, 512 * 132, 2032>;     // in-place: one tile per workgroup, two workgroups per CU
+using GeoStreamGen = Geometry<256, 256 * 132, 2032>;  // count / emit passes (input tile + staging tile)
 
 }  // namespace trre

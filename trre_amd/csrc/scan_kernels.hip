@@ -233,16 +233,11 @@ __global__ __launch_bounds__(G::THREADS) void k_stream_lp(ScanArgs a) {
     if (tid == 0) { red[0] = 0x7fffffff; red[1] = -1; }
     __syncthreads();
 
-    // every lane finds its first line start BEFORE anyone overwrites the tile
-    int64_t lo, hi;
-    lane_range<G>(a, v0, tid, lo, hi);
-    const int64_t q = lo < hi ? first_line_start(tile, lo, hi) : hi;
-    __syncthreads();
-
     const StreamView T = StreamEngine::view<kLdsEnt>(a.blob, tab);
+    const uint32_t n_cls = reinterpret_cast<const StreamBlobHeader*>(a.blob)->n_cls;
     int32_t first, last;
     uint32_t st = 0;
-    stream_lane_lp<G>(a, T, v0, tile, q, hi, first, last, st);
+    stream_lane_lp<G>(a, T, n_cls, v0, tile, tid, first, last, st);
 
     first = wave_min(first);
     last = wave_max(last);
@@ -273,7 +268,8 @@ __global__ __launch_bounds__(G::THREADS) void k_stream_count(ScanArgs a) {
     const StreamView T = StreamEngine::view<kLdsEnt>(a.blob, tab);
     CountSink sink;
     uint32_t st = 0;
-    stream_lane_gen<G>(a, T, v0, tin, tid, sink, st);
+    const uint32_t n_cls = reinterpret_cast<const StreamBlobHeader*>(a.blob)->n_cls;
+    stream_lane_gen<G>(a, T, n_cls, v0, tin, tid, sink, st);
     if (sink.n > 0xffffffffull) { st |= kStCapacity; sink.n = 0xffffffffull; }
     a.lane_counts[(size_t)blockIdx.x * G::THREADS + tid] = (uint32_t)sink.n;
     const uint64_t wsum = wave_sum(sink.n);
@@ -322,7 +318,8 @@ __global__ __launch_bounds__(G::THREADS) void k_stream_emit(ScanArgs a) {
     const StreamView T = StreamEngine::view<kLdsEnt>(a.blob, tab);
     ByteSink sink{staged ? tout + shift + lane_base : a.out + gbase + lane_base};
     uint32_t st = 0;
-    stream_lane_gen<G>(a, T, v0, tin, tid, sink, st);
+    const uint32_t n_cls = reinterpret_cast<const StreamBlobHeader*>(a.blob)->n_cls;
+    stream_lane_gen<G>(a, T, n_cls, v0, tin, tid, sink, st);
     st = wave_or(st);
     if (st && (tid & (kWave - 1)) == 0) atomicOr(a.status, st);
     if (staged) {

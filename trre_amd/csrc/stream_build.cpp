@@ -156,13 +156,20 @@ public:
     StreamTables run() {
         StreamTables t;
         intern("");                       // 0 = root
-        skip_ = (uint32_t)names_.size();  // 1 = SKIP (after a NUL)
-        names_.push_back(std::string("\0skip", 5));
+        skip_ = (uint32_t)names_.size();  // 1 = SKIP: swallow the rest of the record (after a NUL; also a
+        names_.push_back(std::string("\0skip", 5));   //     lane's state before its first line start)
+        rows_.emplace_back();
+        done_ = (uint32_t)names_.size();  // 2 = DONE: absorbing, silent (a lane that has finished its lines)
+        names_.push_back(std::string("\0done", 5));
         rows_.emplace_back();
         for (uint32_t s = 0; s < names_.size(); ++s) {
             rows_[s].resize(256);
             if (s == skip_) {
                 for (int c = 0; c < 256; ++c) rows_[s][c] = Cell{c == '\n' ? 0u : skip_, std::string(), false, c == '\n'};
+                continue;
+            }
+            if (s == done_) {
+                for (int c = 0; c < 256; ++c) rows_[s][c] = Cell{done_, std::string(), false, false};
                 continue;
             }
             const std::string w = names_[s];
@@ -236,7 +243,7 @@ private:
         const uint32_t n = (uint32_t)names_.size();
         t.n_states = n;
         t.pending_len.resize(n);
-        for (uint32_t s = 0; s < n; ++s) t.pending_len[s] = s == skip_ ? 0 : (uint32_t)names_[s].size();
+        for (uint32_t s = 0; s < n; ++s) t.pending_len[s] = (s == skip_ || s == done_) ? 0 : (uint32_t)names_[s].size();
         // byte classes: identical columns over all states
         std::map<std::vector<std::string>, uint32_t> col_index;
         std::vector<int> rep;
@@ -258,7 +265,7 @@ private:
         if ((uint64_t)n * t.n_cls >= (1u << 24)) throw GiveUp();
         t.ent.resize((size_t)n * t.n_cls);
         std::unordered_map<std::string, uint32_t> pooled;
-        bool lp = true;
+        bool lp = true, inplace_ok = true;
         for (uint32_t s = 0; s < n; ++s) {
             for (uint32_t k = 0; k < t.n_cls; ++k) {
                 const Cell& x = rows_[s][rep[k]];
@@ -281,10 +288,17 @@ private:
                 }
                 if (x.copy_c) lo |= 1ull << 27;
                 if (x.eol) lo |= 1ull << 28;
+                if (rep[k] == 0 && s != skip_ && s != done_) lo |= 1ull << 29;   // a NUL cut a line short
+                // in-place safety: an emitted '\n' may only be the last byte of a record-end transition
+                if (rep[k] != 0) {   // (a NUL voids the in-place launch anyway: kStNul)
+                    const size_t nl = x.out.find('\n');
+                    if (nl != std::string::npos && !(x.eol && nl + 1 == x.out.size())) inplace_ok = false;
+                    if (x.copy_c && rep[k] == '\n') inplace_ok = false;
+                }
                 t.ent[(size_t)s * t.n_cls + k] = lo | hi << 32;
                 t.max_out = std::max<uint32_t>(t.max_out, (uint32_t)x.out.size() + (x.copy_c ? 1 : 0));
                 // length-preserving: bytes emitted = pending released + the byte read
-                if (s != skip_ && rep[k] != 0) {
+                if (s != skip_ && s != done_ && rep[k] != 0) {
                     const int64_t emitted = (int64_t)x.out.size() + (x.copy_c ? 1 : 0);
                     const int64_t expect = (int64_t)t.pending_len[s] + 1 - (int64_t)t.pending_len[x.next];
                     if (emitted != expect) lp = false;
@@ -292,7 +306,8 @@ private:
             }
         }
         t.ok = true;
-        if (lp) t.flags |= kFlagLengthPreserving | kFlagNoOverrun;
+        if (lp) t.flags |= kFlagLengthPreserving;
+        if (lp && inplace_ok) t.flags |= kFlagNoOverrun;    // the in-place kernel may run
         return t;
     }
 
@@ -301,7 +316,7 @@ private:
     std::vector<std::string> names_;
     std::vector<std::vector<Cell>> rows_;
     std::unordered_map<std::string, uint32_t> index_;
-    uint32_t skip_ = 1;
+    uint32_t skip_ = 1, done_ = 2;
 };
 
 StreamTables build(const AttemptModel& m, const StreamLimits& lim) {
