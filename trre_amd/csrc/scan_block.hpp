@@ -443,12 +443,32 @@ TRRE_HD void stream_lane_start(const ScanArgs& a, int64_t v0, const uint8_t* til
     row = tile[lo - 1] == (uint8_t)'\n' ? 0u : kSkipState * n_cls;
 }
 
+// Input pipeline of the synchronous walks: the dword two steps ahead and the
+// byte classes of the dword one step ahead are fetched while the current dword
+// is being walked, so the only LDS access on a lane's dependent chain is the
+// table entry itself.
+struct StreamPipe {
+    uint32_t w0, w1;             // current dword, next dword
+    uint8_t k0, k1, k2, k3;      // classes of the current dword's bytes
+};
+template <class G>
+TRRE_HD uint32_t pipe_load(const uint32_t* t32, int p) {
+    const int pr = p < G::TILE ? p : G::TILE;       // finished lanes idle on the sentinel dword
+    return t32[pr >> 2];
+}
+template <class G>
+TRRE_HD void pipe_init(StreamPipe& q, const StreamView& T, const uint32_t* t32, int p) {
+    q.w0 = pipe_load<G>(t32, p);
+    q.w1 = pipe_load<G>(t32, p + 4);
+    q.k0 = T.cls[q.w0 & 0xffu]; q.k1 = T.cls[(q.w0 >> 8) & 0xffu]; q.k2 = T.cls[(q.w0 >> 16) & 0xffu]; q.k3 = T.cls[q.w0 >> 24];
+}
+
 // ---- phase: length-preserving IN-PLACE walk: the tile is input and output ------------------
 // Output never overtakes input (the cursor trails by the pending bytes) and a
 // record end resynchronises it, so writing at tile[o] is safe; lanes in SKIP or
 // DONE write nothing.  Reports [first,last): first owned line start .. end of the
 // last owned line.  One table lookup per byte, no data-dependent branches except
-// the rare multi-byte emission.
+// the rare multi-byte emission and the record-end bookkeeping.
 template <class G>
 TRRE_HD void stream_lane_lp(const ScanArgs& a, const StreamView& T, uint32_t n_cls, int64_t v0, uint8_t* tile, int tid,
                             int32_t& first, int32_t& last, uint32_t& status) {
@@ -462,13 +482,20 @@ TRRE_HD void stream_lane_lp(const ScanArgs& a, const StreamView& T, uint32_t n_c
     uint32_t seen = 0;
     bool over = false;
     const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tile);
+    StreamPipe q;
+    pipe_init<G>(q, T, t32, lo);
     for (int p = lo; TRRE_WAVE_ANY(row != done_row); p += 4) {
-        const int pr = p < G::TILE ? p : G::TILE;           // finished lanes idle on the sentinel dword
-        uint32_t w = t32[pr >> 2];
+        const uint32_t w = q.w0;
+        const uint8_t kk[4] = {q.k0, q.k1, q.k2, q.k3};
+        // prefetch: dword p+8, classes of dword p+4
+        const uint32_t w2 = pipe_load<G>(t32, p + 8);
+        q.k0 = T.cls[q.w1 & 0xffu]; q.k1 = T.cls[(q.w1 >> 8) & 0xffu]; q.k2 = T.cls[(q.w1 >> 16) & 0xffu]; q.k3 = T.cls[q.w1 >> 24];
+        q.w0 = q.w1;
+        q.w1 = w2;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint8_t c = (uint8_t)(w >> (8 * j));
-            const uint64_t e = T.ent[row + T.cls[c]];
+            const uint64_t e = T.ent[row + kk[j]];
             const uint32_t elo = (uint32_t)e, ehi = (uint32_t)(e >> 32);
             const uint32_t ol = str_olen(elo), cc = (elo >> 27) & 1u;
             uint32_t n = ol + cc;
@@ -513,13 +540,19 @@ TRRE_HD void stream_lane_gen(const ScanArgs& a, const StreamView& T, uint32_t n_
     bool over = false;
     uint64_t mark = sink.n;                   // sink position at the start of the current line
     const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tin);
+    StreamPipe q;
+    pipe_init<G>(q, T, t32, lo);
     for (int p = lo; TRRE_WAVE_ANY(row != done_row); p += 4) {
-        const int pr = p < G::TILE ? p : G::TILE;
-        uint32_t w = t32[pr >> 2];
+        const uint32_t w = q.w0;
+        const uint8_t kk[4] = {q.k0, q.k1, q.k2, q.k3};
+        const uint32_t w2 = pipe_load<G>(t32, p + 8);
+        q.k0 = T.cls[q.w1 & 0xffu]; q.k1 = T.cls[(q.w1 >> 8) & 0xffu]; q.k2 = T.cls[(q.w1 >> 16) & 0xffu]; q.k3 = T.cls[q.w1 >> 24];
+        q.w0 = q.w1;
+        q.w1 = w2;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint8_t c = (uint8_t)(w >> (8 * j));
-            const uint64_t e = T.ent[row + T.cls[c]];
+            const uint64_t e = T.ent[row + kk[j]];
             const uint32_t elo = (uint32_t)e, ehi = (uint32_t)(e >> 32);
             if constexpr (Sink::kCountOnly) {
                 const uint32_t ol = str_olen(elo);
