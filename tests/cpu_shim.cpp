@@ -170,6 +170,47 @@ void run_stream_gen(ScanArgs a, uint32_t& status, uint64_t& total_out) {
     }
 }
 
+// ---- direct stream kernels (no tile): lanes run one after the other --------------------------
+StreamView direct_view(const ScanArgs& a) {
+    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
+    StreamView T;
+    T.cls = a.blob + h.off_cls;
+    T.ent = reinterpret_cast<const uint64_t*>(a.blob + h.off_ent);
+    T.pool = a.blob + h.off_pool;
+    return T;
+}
+void run_direct_lp(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
+    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
+    const StreamView T = direct_view(a);
+    const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
+    alignas(16) uint8_t ring[80];
+    for (int64_t lane = n_lanes - 1; lane >= 0; --lane) {      // any order: lanes write disjoint bytes
+        DirectLane L;
+        stream_direct_lane<0>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
+    }
+}
+void run_direct_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64_t& total_out) {
+    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
+    const StreamView T = direct_view(a);
+    const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
+    alignas(16) uint8_t ring[80];
+    std::vector<uint64_t> cnt(n_lanes);
+    for (int64_t lane = 0; lane < n_lanes; ++lane) {
+        DirectLane L;
+        stream_direct_lane<1>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
+        cnt[lane] = L.count;
+    }
+    uint64_t run = 0;
+    std::vector<uint64_t> base(n_lanes);
+    for (int64_t lane = 0; lane < n_lanes; ++lane) { base[lane] = run; run += cnt[lane]; }
+    total_out = run;
+    if (run > a.cap) { status |= kStCapacity; return; }
+    for (int64_t lane = n_lanes - 1; lane >= 0; --lane) {
+        DirectLane L;
+        stream_direct_lane<2>(a, T, h.n_cls, lane, lane_bytes, ring, base[lane], L, status);
+    }
+}
+
 void run_bytemap(const ScanArgs& a, uint32_t& status) {
     const DftBlobHeader& h = *reinterpret_cast<const DftBlobHeader*>(a.blob);
     const uint8_t* map = a.blob + h.off_bytemap;
@@ -197,6 +238,7 @@ int run_family(int family, ScanArgs& a, uint32_t& status, uint64_t& total) {
 extern "C" {
 
 // family: 1 bytemap, 2 tile LP, 3 tile general, 4 stream LP (in place), 5 stream general.
+// 6 direct stream LP, 7 direct stream general (geo: 0 -> 2048-byte lanes, 1 -> 48-byte lanes).
 // geo: 0 production, 1 tiny.
 // in_mis/out_mis: address misalignment (0..15) to give the staged buffers.
 // want_scratch: pass a mask scratch to the NFT long-line path.
@@ -220,8 +262,10 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
     a.gscratch = want_scratch ? scratch.data() : nullptr;
     uint32_t status = 0;
     uint64_t total = 0;
-    if (family != 3 && family != 5 && cap < n) return -9;
+    if (family != 3 && family != 5 && family != 7 && cap < n) return -9;
     if (family == 1) { run_bytemap(a, status); total = n; }
+    else if (family == 6) { run_direct_lp(a, geo == 0 ? 2048 : 48, status); total = n; }
+    else if (family == 7) { run_direct_gen(a, geo == 0 ? 2048 : 48, status, total); }
     else if (family == 4) {
         if (geo == 0) run_stream_lp<GeoStream>(a, status); else run_stream_lp<GeoTinyStream>(a, status);
         total = n;

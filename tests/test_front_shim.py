@@ -59,9 +59,19 @@ def test_every_family_agrees():
                      ("(cat:dog|dog:cat)", "nft"), ("cat:dog", "nft"), ("cat:dog", "dft")]:
         p = prog(pat, eng)
         want = Oracle(pat, eng).scan(data)
-        for fam in p.allowed_kernels():
+        for fam in shim_families(p):
             assert shim_lib.scan_like_runtime(p, data, geo=1, family=fam) == want, (pat, eng, fam)
             assert shim_lib.scan_like_runtime(p, data, geo=0, family=fam) == want, (pat, eng, fam)
+
+
+def shim_families(p):
+    """kernel families to run through the shim: the ABI's plus the direct (no-tile) stream walkers"""
+    fams = list(p.allowed_kernels())
+    if 4 in fams:
+        fams.append(6)
+    if 5 in fams:
+        fams.append(7)
+    return fams
 
 
 def test_unaligned_buffers():
@@ -71,7 +81,7 @@ def test_unaligned_buffers():
         p = prog(pat, eng)
         want = Oracle(pat, eng).scan(data)
         for in_mis, out_mis in [(0, 0), (1, 1), (5, 5), (15, 15), (3, 0), (0, 7), (9, 12)]:
-            for fam in p.allowed_kernels():
+            for fam in shim_families(p):
                 got = shim_lib.scan_like_runtime(p, data, geo=1, family=fam, in_mis=in_mis, out_mis=out_mis)
                 assert got == want, (pat, eng, fam, in_mis, out_mis)
 
@@ -84,7 +94,7 @@ def test_long_lines_leave_the_tile():
         for pat, eng in [("(cat:dog|dog:cat)", "dft"), ("(cat:dog|dog:cat)", "nft"), ("a:xyz", "dft"), ("[aie]:", "nft"), ("[a:A-z:Z]", "dft")]:
             p = prog(pat, eng)
             want = Oracle(pat, eng).scan(data)
-            for fam in p.allowed_kernels():
+            for fam in shim_families(p):
                 assert shim_lib.scan_like_runtime(p, data, geo=geo, family=fam) == want, (pat, eng, fam, geo)
 
 
@@ -138,7 +148,7 @@ def test_random_patterns_against_oracle():
                 assert want is None or e.code in (trre_amd.api.E_UNSUPPORTED, trre_amd.api.E_EPS_CYCLE,
                                                   trre_amd.api.E_TOO_BIG), (pat, eng, str(e))
                 continue
-            for fam in p.allowed_kernels():
+            for fam in shim_families(p):
                 try:
                     got = shim_lib.scan_like_runtime(p, data, geo=1, family=fam)
                 except RuntimeError:

@@ -18,6 +18,10 @@ void launch_tile_kernel(int which, int engine, int mask_bytes, const ScanArgs& a
 int stream_chunk_bytes(int which);
 int stream_block_threads(int which);
 void launch_stream_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t n_chunks, void* stream);
+// direct stream kernels (no LDS tile); which: 0 length-preserving, 1 count, 2 emit
+int direct_ent_lds_bytes();
+int direct_block_threads();
+void launch_direct_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, void* stream);
 void launch_chunk_scan(const uint64_t* total, uint64_t* base, int64_t n_chunks, void* stream);
 void launch_bytemap(const ScanArgs& a, void* stream);
 

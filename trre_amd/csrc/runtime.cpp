@@ -4,6 +4,7 @@
 // bytes on the host.
 #include <hip/hip_runtime_api.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -265,12 +266,18 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
                                         : chunk_bytes(p->engine, p->mask_bytes);
     const int threads = is_stream(family) ? stream_block_threads(family == TRRE_KERNEL_STREAM_LP ? 0 : 1)
                                           : block_threads(p->engine, p->mask_bytes);
-    const int64_t n_chunks = (args.vend + chunk - 1) / chunk;
+    int64_t n_chunks = (args.vend + chunk - 1) / chunk;
     const bool ent_lds = p->stt.ok && p->stt.ent.size() * 8 <= (size_t)StreamEngine::kLdsEntBytes;
+    // stream families have two implementations: LDS-tile (0) and direct (1)
+    static const int stream_impl = getenv("TRRE_STREAM_IMPL") ? atoi(getenv("TRRE_STREAM_IMPL")) : 0;
+    static const int64_t lane_bytes = getenv("TRRE_LANE_BYTES") ? atoll(getenv("TRRE_LANE_BYTES")) : 2048;
+    const bool direct = is_stream(family) && stream_impl == 1;
+    const bool direct_ent_lds = p->stt.ok && p->stt.ent.size() * 8 <= (size_t)direct_ent_lds_bytes();
+    if (direct) n_chunks = (args.vend + lane_bytes * direct_block_threads() - 1) / (lane_bytes * direct_block_threads());
 
     if (!is_gen(family) && cap < n) return TRRE_OK;   // finish() reports the capacity error
     if (is_gen(family)) {
-        rc = ensure_workspace(p, st, n_chunks, threads);
+        rc = ensure_workspace(p, st, n_chunks, direct ? direct_block_threads() : threads);
         if (rc) return rc;
         args.lane_counts = st->d_lane_counts;
         args.chunk_total = st->d_chunk_total;
@@ -285,6 +292,13 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
         launch_bytemap(args, stream);
     } else if (family == TRRE_KERNEL_TILE_LP) {
         launch_tile_kernel(0, p->engine, p->mask_bytes, args, n_chunks, stream);
+    } else if (direct && family == TRRE_KERNEL_STREAM_LP) {
+        launch_direct_kernel(0, direct_ent_lds, args, lane_bytes, n_chunks, stream);
+    } else if (direct) {
+        launch_direct_kernel(1, direct_ent_lds, args, lane_bytes, n_chunks, stream);
+        launch_chunk_scan(st->d_chunk_total, st->d_chunk_base, n_chunks, stream);
+        launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream);
+        HIP_TRY(hipMemcpyAsync(st->h_status + 2, st->d_chunk_base + n_chunks, 8, hipMemcpyDeviceToHost, stream));
     } else if (family == TRRE_KERNEL_STREAM_LP) {
         launch_stream_kernel(0, ent_lds, args, n_chunks, stream);
     } else if (family == TRRE_KERNEL_STREAM_GEN) {

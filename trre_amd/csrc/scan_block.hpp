@@ -584,6 +584,147 @@ TRRE_HD void stream_lane_gen(const ScanArgs& a, const StreamView& T, uint32_t n_
 }
 
 // =============================================================================================
+// Direct stream walk: no LDS tile.  Each lane streams a long contiguous sub-range
+// (lane_bytes, a few KiB) straight from HBM/L2 with 16-byte loads held in
+// registers, so a wave can keep all 8 wave slots of a SIMD busy (no LDS capacity
+// limit) and a lane's tail — the part of its last line beyond its sub-range — is
+// small against its sub-range.  Output bytes go through a 64-byte per-lane LDS
+// ring and leave as aligned 16-byte stores.
+//   kMode 0: length-preserving (output address = input address), 1: count, 2: emit
+// =============================================================================================
+constexpr int kRingStride = 68;                       // bytes per lane: 17 dwords (odd) -> conflict-free byte writes
+
+struct DirectLane {
+    uint64_t count = 0;        // kMode 1: bytes this lane emits
+};
+
+TRRE_HD U128 direct_load(const ScanArgs& a, int64_t v) {
+    const uint32_t nl4 = 0x0a0a0a0au;
+    U128 w;
+    if (v >= a.vend) { w.x = w.y = w.z = w.w = nl4; return w; }
+    w = *reinterpret_cast<const U128*>(a.in_v0 + v);
+    if (v < a.vbeg || v + 16 > a.vend - 1) {
+        uint8_t* b = reinterpret_cast<uint8_t*>(&w);
+        for (int k = 0; k < 16; ++k) {
+            const int64_t vv = v + k;
+            if (vv >= a.vend - 1) b[k] = (uint8_t)'\n';
+            else if (vv < a.vbeg) b[k] = vv == a.vbeg - 1 ? (uint8_t)'\n' : (uint8_t)'x';
+        }
+    }
+    return w;
+}
+
+// flush the ring: bytes [of, o) of the lane's output (offsets from obase) are in ring[x & 63]
+template <bool kAll>
+TRRE_HD void direct_flush(uint8_t* obase, const uint8_t* ring, uint32_t& of, uint32_t o) {
+    // head: single bytes up to the first 16-byte boundary of the output address
+    while (of < o && (of & 15u)) { obase[of] = ring[of & 63u]; ++of; }
+    while (o - of >= 16u) {
+        const uint32_t r = of & 63u;
+        U128 q;
+        q.x = *reinterpret_cast<const uint32_t*>(ring + r);
+        q.y = *reinterpret_cast<const uint32_t*>(ring + r + 4);
+        q.z = *reinterpret_cast<const uint32_t*>(ring + r + 8);
+        q.w = *reinterpret_cast<const uint32_t*>(ring + r + 12);
+        *reinterpret_cast<U128*>(obase + of) = q;
+        of += 16u;
+    }
+    if (kAll) while (of < o) { obase[of] = ring[of & 63u]; ++of; }
+}
+
+template <int kMode>
+TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, int64_t lane, int64_t lane_bytes,
+                                uint8_t* ring, uint64_t out_base, DirectLane& L, uint32_t& status) {
+    const uint32_t done_row = kDoneState * n_cls;
+    int64_t lo = lane * lane_bytes, hi = lo + lane_bytes;
+    if (hi > a.vend) hi = a.vend;
+    uint32_t row;
+    if (lo >= hi) row = done_row;
+    else if (lo < a.vbeg) row = kSkipState * n_cls;                  // filler then '\n' right before the input
+    else row = (lo == a.vbeg || a.in_v0[lo - 1] == (uint8_t)'\n') ? 0u : kSkipState * n_cls;
+
+    // output cursor as a 32-bit offset from a 64-byte aligned base address
+    uint8_t* obase;
+    uint32_t o;
+    if (kMode == 0) {
+        const uintptr_t start = reinterpret_cast<uintptr_t>(a.out_v0 + lo);
+        obase = reinterpret_cast<uint8_t*>(start & ~(uintptr_t)63);
+        o = (uint32_t)(start & 63u);
+    } else {
+        const uintptr_t start = reinterpret_cast<uintptr_t>(a.out) + out_base;
+        obase = reinterpret_cast<uint8_t*>(start & ~(uintptr_t)63);
+        o = (uint32_t)(start & 63u);
+    }
+    const uint32_t o_of_lo = o;           // kMode 0: offset that corresponds to position lo
+    uint32_t of = o;                      // everything below `of` has left the ring
+    uint64_t cnt = 0;
+    uint32_t seen = 0;
+
+    U128 blk = direct_load(a, lo), nxt = direct_load(a, lo + 16);
+    for (int64_t v = lo; TRRE_WAVE_ANY(row != done_row); v += 16) {
+        const U128 cur = blk;
+        blk = nxt;
+        nxt = direct_load(a, v + 32);
+        const uint32_t wd[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const uint32_t w = wd[d];
+            const uint8_t kk[4] = {T.cls[w & 0xffu], T.cls[(w >> 8) & 0xffu], T.cls[(w >> 16) & 0xffu], T.cls[w >> 24]};
+            if (kMode == 2) {                         // expanding programs can fill the ring inside a block
+                if (TRRE_WAVE_ANY(o - of >= 32u)) direct_flush<false>(obase, ring, of, o);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint8_t c = (uint8_t)(w >> (8 * j));
+                const uint64_t e = T.ent[row + kk[j]];
+                const uint32_t elo = (uint32_t)e, ehi = (uint32_t)(e >> 32);
+                const uint32_t ol = str_olen(elo), cc = (elo >> 27) & 1u;
+                uint32_t n = ol + cc;
+                if (kMode == 1) {
+                    if (TRRE_WAVE_ANY(ol == 7u)) { if (ol == 7u) n = str_count(T, elo, ehi); }
+                    cnt += n;
+                } else {
+                    if (n) ring[o & 63u] = ol ? (uint8_t)ehi : c;
+                    if (TRRE_WAVE_ANY(n >= 2u)) {
+                        if (n >= 2u) {
+                            if (ol != 7u) {
+                                uint32_t x = ehi >> 8;
+                                for (uint32_t i = 1; i < ol; ++i) { ring[(o + i) & 63u] = (uint8_t)x; x >>= 8; }
+                                if (cc) ring[(o + ol) & 63u] = c;
+                            } else {
+                                // long replacement text: empty the ring, then write straight to HBM
+                                direct_flush<true>(obase, ring, of, o);
+                                const uint8_t* r = T.pool + ehi;
+                                const uint32_t len = str_pool_len(T, ehi);
+                                for (uint32_t i = 0; i < len; ++i) obase[o + i] = r[4 + i];
+                                if (cc) obase[o + len] = c;
+                                n = len + cc;
+                                of = o + n;
+                            }
+                        }
+                    }
+                    o += n;
+                }
+                row = str_next(elo);
+                seen |= elo;
+                if (elo & kStrEol) {
+                    const int64_t p1 = v + 4 * d + j + 1;
+                    if (kMode == 0) {
+                        const uint32_t sync = o_of_lo + (uint32_t)(p1 - lo);
+                        if (o != sync) { o = sync; of = sync; }       // leaving SKIP (or after a NUL: launch is void)
+                    }
+                    if (p1 >= hi) row = done_row;
+                }
+            }
+        }
+        if (kMode != 1) direct_flush<false>(obase, ring, of, o);
+    }
+    if (kMode != 1) direct_flush<true>(obase, ring, of, o);
+    if (kMode == 0 && (seen & kStrNul)) status |= kStNul;
+    L.count = cnt;
+}
+
+// =============================================================================================
 // Memoryless tables: out[v] = map[in[v]] for one 16-byte vector at v.
 // =============================================================================================
 TRRE_HD uint32_t map4(const uint8_t* m, uint32_t w) {

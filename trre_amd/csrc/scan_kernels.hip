@@ -16,6 +16,8 @@
 // The per-thread phase bodies live in scan_block.hpp / scan_core.hpp.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "launch.hpp"
 #include "scan_block.hpp"
 
@@ -329,6 +331,72 @@ __global__ __launch_bounds__(G::THREADS) void k_stream_emit(ScanArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Direct stream kernels: no tile, one long sub-range per lane (see stream_direct_lane).
+constexpr int kDirectThreads = 256;
+constexpr int kDirectEntBytes = 2048;      // table rows in LDS when they fit
+constexpr int kDirectLds = 256 + kDirectEntBytes + kDirectThreads * kRingStride + 64;
+
+template <bool kLdsEnt>
+__device__ __forceinline__ StreamView direct_stage(const ScanArgs& a, uint8_t* smem) {
+    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
+    for (int k = threadIdx.x; k < 256; k += kDirectThreads) smem[k] = a.blob[h.off_cls + k];
+    if (kLdsEnt) {
+        const uint64_t* e = reinterpret_cast<const uint64_t*>(a.blob + h.off_ent);
+        uint64_t* d = reinterpret_cast<uint64_t*>(smem + 256);
+        for (int k = threadIdx.x; k < (int)(h.ent_bytes / 8); k += kDirectThreads) d[k] = e[k];
+    }
+    __syncthreads();
+    StreamView T;
+    T.cls = smem;
+    T.ent = kLdsEnt ? reinterpret_cast<const uint64_t*>(smem + 256) : reinterpret_cast<const uint64_t*>(a.blob + h.off_ent);
+    T.pool = a.blob + h.off_pool;
+    return T;
+}
+
+template <int kMode, bool kLdsEnt>
+__global__ __launch_bounds__(kDirectThreads) void k_stream_direct(ScanArgs a, int64_t lane_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const StreamView T = direct_stage<kLdsEnt>(a, smem);
+    const uint32_t n_cls = reinterpret_cast<const StreamBlobHeader*>(a.blob)->n_cls;
+    uint8_t* ring = smem + 256 + kDirectEntBytes + threadIdx.x * kRingStride;
+    const int64_t lane = (int64_t)blockIdx.x * kDirectThreads + threadIdx.x;
+    DirectLane L;
+    uint32_t st = 0;
+    uint64_t base = 0;
+    if (kMode == 2) {
+        // lane offsets: workgroup-wide exclusive scan of the counts from the count launch
+        uint32_t* wpart = reinterpret_cast<uint32_t*>(smem + kDirectLds - 64);
+        const uint32_t mine = a.lane_counts[lane];
+        const uint32_t incl = wave_scan_incl(mine);
+        if ((threadIdx.x & (kWave - 1)) == kWave - 1) wpart[threadIdx.x / kWave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (int w = 0; w < (int)threadIdx.x / kWave; ++w) wbase += wpart[w];
+        base = a.chunk_base[blockIdx.x] + wbase + incl - mine;
+        if (a.chunk_base[blockIdx.x] + a.chunk_total[blockIdx.x] > a.cap) {
+            if (threadIdx.x == 0) atomicOr(a.status, kStCapacity);
+            return;
+        }
+    }
+    stream_direct_lane<kMode>(a, T, n_cls, lane, lane_bytes, ring, base, L, st);
+    if (kMode == 1) {
+        uint64_t* part = reinterpret_cast<uint64_t*>(smem + kDirectLds - 64);
+        if (L.count > 0xffffffffull) { st |= kStCapacity; L.count = 0xffffffffull; }
+        a.lane_counts[lane] = (uint32_t)L.count;
+        const uint64_t wsum = wave_sum(L.count);
+        if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = wsum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t t = 0;
+            for (int w = 0; w < kDirectThreads / kWave; ++w) t += part[w];
+            a.chunk_total[blockIdx.x] = t;
+        }
+    }
+    st = wave_or(st);
+    if (st && (threadIdx.x & (kWave - 1)) == 0) atomicOr(a.status, st);
+}
+
+// ------------------------------------------------------------------------------------------
 // memoryless byte map: out[v] = map[in[v]], 16 bytes per lane per step
 constexpr int kMapThreads = 256;
 constexpr int kMapUnroll = 4;
@@ -400,8 +468,23 @@ void launch_tile_kernel(int which, int engine, int mask_bytes, const ScanArgs& a
     }
 }
 
+// experiment hook: alternative in-place geometries (TRRE_STREAM_GEO=1|2)
+using GeoStreamB = Geometry<256, 256 * 260, 2032>;    // 65 dwords per lane, 8 waves/CU
+using GeoStreamC = Geometry<512, 512 * 260, 2032>;    // 65 dwords per lane, one workgroup per CU
+template <class GL, bool kLdsEnt>
+void launch_stream_lp_geo(const ScanArgs& a, hipStream_t s) {
+    const int64_t n_chunks = (a.vend + GL::CHUNK - 1) / GL::CHUNK;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_lp<GL, kLdsEnt>), hipFuncAttributeMaxDynamicSharedMemorySize, StreamCarve<GL>::kBytesOneTile);
+    hipLaunchKernelGGL((k_stream_lp<GL, kLdsEnt>), dim3((unsigned)n_chunks), dim3(GL::THREADS), StreamCarve<GL>::kBytesOneTile, s, a);
+}
+
 template <bool kLdsEnt>
 void launch_stream_t(int which, const ScanArgs& a, int64_t n_chunks, hipStream_t s) {
+    if (which == 0) {
+        static const int geo = getenv("TRRE_STREAM_GEO") ? atoi(getenv("TRRE_STREAM_GEO")) : 0;
+        if (geo == 1) { launch_stream_lp_geo<GeoStreamB, kLdsEnt>(a, s); return; }
+        if (geo == 2) { launch_stream_lp_geo<GeoStreamC, kLdsEnt>(a, s); return; }
+    }
     using GL = GeoStream;
     using GG = GeoStreamGen;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_lp<GL, kLdsEnt>), hipFuncAttributeMaxDynamicSharedMemorySize, StreamCarve<GL>::kBytesOneTile);
@@ -411,6 +494,20 @@ void launch_stream_t(int which, const ScanArgs& a, int64_t n_chunks, hipStream_t
     if (which == 0) hipLaunchKernelGGL((k_stream_lp<GL, kLdsEnt>), grid, dim3(GL::THREADS), StreamCarve<GL>::kBytesOneTile, s, a);
     else if (which == 1) hipLaunchKernelGGL((k_stream_count<GG, kLdsEnt>), grid, dim3(GG::THREADS), StreamCarve<GG>::kBytesOneTile, s, a);
     else hipLaunchKernelGGL((k_stream_emit<GG, kLdsEnt>), grid, dim3(GG::THREADS), StreamCarve<GG>::kBytesTwoTiles, s, a);
+}
+
+template <int kMode>
+void launch_direct_t(bool ent_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, hipStream_t s) {
+    if (ent_lds) hipLaunchKernelGGL((k_stream_direct<kMode, true>), dim3((unsigned)n_blocks), dim3(kDirectThreads), kDirectLds, s, a, lane_bytes);
+    else hipLaunchKernelGGL((k_stream_direct<kMode, false>), dim3((unsigned)n_blocks), dim3(kDirectThreads), kDirectLds, s, a, lane_bytes);
+}
+int direct_ent_lds_bytes() { return kDirectEntBytes; }
+int direct_block_threads() { return kDirectThreads; }
+void launch_direct_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (which == 0) launch_direct_t<0>(ent_in_lds, a, lane_bytes, n_blocks, s);
+    else if (which == 1) launch_direct_t<1>(ent_in_lds, a, lane_bytes, n_blocks, s);
+    else launch_direct_t<2>(ent_in_lds, a, lane_bytes, n_blocks, s);
 }
 
 int stream_chunk_bytes(int which) { return which == 0 ? GeoStream::CHUNK : GeoStreamGen::CHUNK; }
