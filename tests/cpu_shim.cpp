@@ -211,6 +211,16 @@ void run_direct_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uin
     }
 }
 
+void run_lpw(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
+    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
+    LpwView T;
+    T.cls = a.blob + h.off_cls;
+    T.ent = reinterpret_cast<const U128*>(a.blob + h.off_lpw);
+    T.delay = h.lpw_delay;
+    const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
+    for (int64_t lane = n_lanes - 1; lane >= 0; --lane) stream_lpw_lane(a, T, h.n_cls, lane, lane_bytes, status);
+}
+
 void run_bytemap(const ScanArgs& a, uint32_t& status) {
     const DftBlobHeader& h = *reinterpret_cast<const DftBlobHeader*>(a.blob);
     const uint8_t* map = a.blob + h.off_bytemap;
@@ -238,7 +248,7 @@ int run_family(int family, ScanArgs& a, uint32_t& status, uint64_t& total) {
 extern "C" {
 
 // family: 1 bytemap, 2 tile LP, 3 tile general, 4 stream LP (in place), 5 stream general.
-// 6 direct stream LP, 7 direct stream general (geo: 0 -> 2048-byte lanes, 1 -> 48-byte lanes).
+// 8 positional-window stream LP, 6 direct stream LP, 7 direct stream general (geo: 0 -> 2048-byte lanes, 1 -> 48-byte lanes).
 // geo: 0 production, 1 tiny.
 // in_mis/out_mis: address misalignment (0..15) to give the staged buffers.
 // want_scratch: pass a mask scratch to the NFT long-line path.
@@ -264,6 +274,10 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
     uint64_t total = 0;
     if (family != 3 && family != 5 && family != 7 && cap < n) return -9;
     if (family == 1) { run_bytemap(a, status); total = n; }
+    else if (family == 8) {
+        if (reinterpret_cast<const StreamBlobHeader*>(blob)->lpw_bytes == 0) return -5;
+        run_lpw(a, geo == 0 ? 2048 : 48, status); total = n;
+    }
     else if (family == 6) { run_direct_lp(a, geo == 0 ? 2048 : 48, status); total = n; }
     else if (family == 7) { run_direct_gen(a, geo == 0 ? 2048 : 48, status, total); }
     else if (family == 4) {

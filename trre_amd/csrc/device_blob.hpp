@@ -41,7 +41,8 @@ struct StreamBlobHeader {
     uint32_t ent_bytes;
     uint32_t off_pool, pool_bytes;
     uint32_t total_bytes, max_out;
-    uint32_t pad[5];
+    uint32_t off_lpw, lpw_bytes, lpw_delay;   // window form (0 bytes when not available)
+    uint32_t pad[2];
 };
 static_assert(sizeof(StreamBlobHeader) == 64, "header layout");
 

@@ -148,6 +148,15 @@ struct StreamTables {
     std::vector<uint64_t> ent;              // [n_states][n_cls]
     std::vector<uint8_t> pool;
     std::vector<uint32_t> pending_len;      // bytes consumed but not yet emitted, per state
+    // "window" form for length-preserving programs whose pending string never exceeds 3 bytes
+    // and whose transitions emit at most 4 bytes: 16 bytes per entry
+    //   x  byte offset of the next state's row (state * n_cls * 16)
+    //   y  [4:0] insert shift = 8 * (delay - pending(source state)), [5] record end, [6] NUL
+    //   z  up to four inline output bytes
+    //   w  v_perm_b32 selector that builds the emitted byte sequence from {input byte, z}
+    bool lpw_ok = false;
+    uint32_t lpw_delay = 0;                 // max pending length
+    std::vector<uint32_t> lpw;              // [n_states][n_cls][4]
 };
 StreamTables build_stream_dft(const Dft& dft, const StreamLimits& lim = StreamLimits());
 StreamTables build_stream_nft(const Nft& nft, const StreamLimits& lim = StreamLimits());

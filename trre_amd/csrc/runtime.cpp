@@ -160,6 +160,8 @@ void serialize_stream(trre_prog& p) {
     h.off_cls = (uint32_t)off; off += 256;
     h.off_ent = (uint32_t)off; h.ent_bytes = (uint32_t)(t.ent.size() * 8); off += t.ent.size() * 8;
     h.off_pool = (uint32_t)off; h.pool_bytes = (uint32_t)t.pool.size(); off += t.pool.size();
+    off = align_up(off, 16);
+    h.off_lpw = (uint32_t)off; h.lpw_bytes = (uint32_t)(t.lpw.size() * 4); h.lpw_delay = t.lpw_delay; off += t.lpw.size() * 4;
     off = align_up(off + 16, 16);
     h.total_bytes = (uint32_t)off;
     std::vector<uint8_t>& b = p.sblob;
@@ -168,6 +170,7 @@ void serialize_stream(trre_prog& p) {
     put(b, h.off_cls, t.cls.data(), 256);
     put(b, h.off_ent, t.ent.data(), t.ent.size());
     put(b, h.off_pool, t.pool.data(), t.pool.size());
+    put(b, h.off_lpw, t.lpw.data(), t.lpw.size());
 }
 
 bool is_stream(int fam) { return fam == TRRE_KERNEL_STREAM_LP || fam == TRRE_KERNEL_STREAM_GEN; }
@@ -271,7 +274,7 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
     // stream families have two implementations: LDS-tile (0) and direct (1)
     static const int stream_impl = getenv("TRRE_STREAM_IMPL") ? atoi(getenv("TRRE_STREAM_IMPL")) : 0;
     static const int64_t lane_bytes = getenv("TRRE_LANE_BYTES") ? atoll(getenv("TRRE_LANE_BYTES")) : 2048;
-    const bool direct = is_stream(family) && stream_impl == 1;
+    const bool direct = is_stream(family) && stream_impl >= 1;
     const bool direct_ent_lds = p->stt.ok && p->stt.ent.size() * 8 <= (size_t)direct_ent_lds_bytes();
     if (direct) n_chunks = (args.vend + lane_bytes * direct_block_threads() - 1) / (lane_bytes * direct_block_threads());
 
@@ -292,6 +295,8 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
         launch_bytemap(args, stream);
     } else if (family == TRRE_KERNEL_TILE_LP) {
         launch_tile_kernel(0, p->engine, p->mask_bytes, args, n_chunks, stream);
+    } else if (is_stream(family) && stream_impl == 2 && family == TRRE_KERNEL_STREAM_LP && p->stt.lpw_ok) {
+        launch_lpw_kernel(p->stt.lpw.size() * 4 <= (size_t)lpw_ent_lds_bytes(), args, lane_bytes, stream);
     } else if (direct && family == TRRE_KERNEL_STREAM_LP) {
         launch_direct_kernel(0, direct_ent_lds, args, lane_bytes, n_chunks, stream);
     } else if (direct) {

@@ -725,6 +725,137 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
 }
 
 // =============================================================================================
+// Positional-window walk for length-preserving stream tables (window form of
+// stream_build.cpp).  Per byte: one class lookup (prefetched), one 16-byte table
+// entry, and five register operations — no branch, no output cursor:
+//
+//   seq  = v_perm_b32(input byte, entry.bytes, entry.selector)   the bytes this step emits
+//   win |= seq << entry.shift        they land at (delay - pending) bytes past the release point
+//   R    = alignbit(win, R, 8)       the byte for position p - delay is final: release it
+//   win >>= 8 ; row = entry.next
+//
+// Output position == input position, so released bytes are packed into aligned
+// dwords statically and leave as one 16-byte store per 16 input bytes straight
+// from registers (no LDS staging at all).  Each lane streams a long sub-range of
+// the input from HBM/L2 (lane_bytes); it starts at its first line start and runs
+// to the end of its last line.
+// =============================================================================================
+struct LpwView {
+    const uint8_t* cls;      // [256]
+    const U128* ent;         // [n_states][n_cls]
+    uint32_t delay;
+};
+constexpr uint32_t kLpwEol = 32u, kLpwNul = 64u;
+
+// position after the first '\n' at or after lo - 1 (the lane's first line start); >= hi: none
+TRRE_HD int64_t first_line_start_global(const ScanArgs& a, int64_t lo, int64_t hi) {
+    if (lo <= a.vbeg) return a.vbeg;
+    if (a.in_v0[lo - 1] == (uint8_t)'\n') return lo;
+    for (int64_t v = lo & ~(int64_t)15; v < hi; v += 16) {
+        const U128 q = direct_load(a, v);
+        const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+        for (int d = 0; d < 4; ++d) {
+            const uint32_t x = wd[d] ^ 0x0a0a0a0au;
+            const uint32_t m = (x - 0x01010101u) & ~x & 0x80808080u;   // the lowest flag is exact
+            if (m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                const int bit = __ffs((int)m) - 1;
+#else
+                const int bit = __builtin_ctz(m);
+#endif
+                return v + 4 * d + (bit >> 3) + 1;
+            }
+        }
+    }
+    return hi;
+}
+
+// store one 16-byte output block; only positions in [fs, end) belong to this lane
+TRRE_HD void lpw_store(const ScanArgs& a, int64_t vb, const U128& q, int64_t fs, int64_t end, bool aligned) {
+    if (aligned && vb >= fs && vb + 16 <= end) {
+        *reinterpret_cast<U128*>(a.out_v0 + vb) = q;
+        return;
+    }
+    const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+    for (int i = 0; i < 16; ++i) {
+        const int64_t pos = vb + i;
+        if (pos >= fs && pos < end) a.out_v0[pos] = (uint8_t)(wd[i >> 2] >> (8 * (i & 3)));
+    }
+}
+
+template <bool kCheckEnd>
+TRRE_HD void lpw_block(const LpwView& T, const U128& cur, int64_t v, int64_t hi, uint32_t done_row, uint32_t& row, uint32_t& win,
+                       uint32_t& seen, uint32_t (&Rm)[4], bool& done, int64_t& end) {
+    const uint32_t wd[4] = {cur.x, cur.y, cur.z, cur.w};
+    uint32_t R = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        uint32_t w = wd[d];
+        const uint32_t k0 = T.cls[w & 0xffu], k1 = T.cls[(w >> 8) & 0xffu], k2 = T.cls[(w >> 16) & 0xffu], k3 = T.cls[w >> 24];
+        const uint32_t kk[4] = {k0, k1, k2, k3};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const U128 e = *reinterpret_cast<const U128*>(reinterpret_cast<const uint8_t*>(T.ent) + row + (kk[j] << 4));
+            const uint32_t seq = perm_b32(w, e.z, e.w);
+            win |= seq << (e.y & 31u);
+            R = alignbit_b32(win, R, 8);
+            win >>= 8;
+            row = e.x;
+            seen |= e.y;
+            if (kCheckEnd) {
+                if ((e.y & kLpwEol) && !done) {
+                    const int64_t p1 = v + 4 * d + j + 1;
+                    if (p1 >= hi) { done = true; end = p1; row = done_row; }
+                }
+            }
+            w >>= 8;
+        }
+        Rm[d] = R;
+    }
+}
+
+TRRE_HD void stream_lpw_lane(const ScanArgs& a, const LpwView& T, uint32_t n_cls, int64_t lane, int64_t lane_bytes, uint32_t& status) {
+    const int64_t lo = lane * lane_bytes;
+    int64_t hi = lo + lane_bytes;
+    if (hi > a.vend) hi = a.vend;
+    if (lo >= hi) return;
+    const int64_t fs = first_line_start_global(a, lo, hi);
+    if (fs >= hi) return;                                     // no line starts in this sub-range
+    const uint32_t D = T.delay;
+    const uint32_t done_row = kDoneState * n_cls * 16u;
+    const bool aligned = (reinterpret_cast<uintptr_t>(a.out_v0) & 15u) == 0;
+    int64_t v = fs & ~(int64_t)15;
+    uint32_t row = v == fs ? 0u : kSkipState * n_cls * 16u;   // the byte before fs is '\n': SKIP reaches root exactly at fs
+    uint32_t win = 0, seen = 0, Rprev = 0;
+    bool done = false, have_prev = false;
+    int64_t end = INT64_MAX, vprev = 0;
+    U128 outb{};
+    U128 blk = direct_load(a, v), nxt = direct_load(a, v + 16);
+    for (;;) {
+        const U128 cur = blk;
+        blk = nxt;
+        nxt = direct_load(a, v + 32);
+        uint32_t Rm[4];
+        if (v + 16 < hi) lpw_block<false>(T, cur, v, hi, done_row, row, win, seen, Rm, done, end);
+        else lpw_block<true>(T, cur, v, hi, done_row, row, win, seen, Rm, done, end);
+        // released dword m holds positions [v + 4m - D, v + 4m - D + 4): realign by D bytes
+        if (have_prev) {
+            outb.w = alignbyte_b32(Rm[0], Rprev, D);
+            lpw_store(a, vprev, outb, fs, end, aligned);
+        }
+        outb.x = alignbyte_b32(Rm[1], Rm[0], D);
+        outb.y = alignbyte_b32(Rm[2], Rm[1], D);
+        outb.z = alignbyte_b32(Rm[3], Rm[2], D);
+        Rprev = Rm[3];
+        vprev = v;
+        have_prev = true;
+        if (done && v >= end) break;                          // everything up to `end` has been stored
+        v += 16;
+    }
+    if (seen & kLpwNul) status |= kStNul;
+}
+
+// =============================================================================================
 // Memoryless tables: out[v] = map[in[v]] for one 16-byte vector at v.
 // =============================================================================================
 TRRE_HD uint32_t map4(const uint8_t* m, uint32_t w) {

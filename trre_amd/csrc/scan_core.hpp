@@ -225,6 +225,36 @@ TRRE_HD int64_t str_emit(const StreamView& T, uint8_t* dst, int64_t o, uint32_t 
     return o + len + cc;
 }
 
+// ---- byte permute / funnel shifts (v_perm_b32, v_alignbit_b32, v_alignbyte_b32) -------------
+TRRE_HD uint32_t perm_b32(uint32_t s0, uint32_t s1, uint32_t sel) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(s0, s1, sel);
+#else
+    const uint64_t src = (uint64_t)s0 << 32 | s1;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t b = (sel >> (8 * i)) & 0xffu;
+        const uint32_t byte = b <= 7u ? (uint32_t)(src >> (8 * b)) & 0xffu : (b >= 0x0du ? 0xffu : 0u);
+        r |= byte << (8 * i);
+    }
+    return r;
+#endif
+}
+TRRE_HD uint32_t alignbit_b32(uint32_t hi, uint32_t lo, uint32_t sh) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+    return (uint32_t)(((uint64_t)hi << 32 | lo) >> (sh & 31u));
+#endif
+}
+TRRE_HD uint32_t alignbyte_b32(uint32_t hi, uint32_t lo, uint32_t sh) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbyte(hi, lo, sh);
+#else
+    return (uint32_t)(((uint64_t)hi << 32 | lo) >> (8u * (sh & 3u)));
+#endif
+}
+
 // ---- non-deterministic tables as the kernel sees them ---------------------------------
 struct NftFollowDev {      // mirrors trre::NftFollow
     uint8_t target, mute;

@@ -496,6 +496,37 @@ void launch_stream_t(int which, const ScanArgs& a, int64_t n_chunks, hipStream_t
     else hipLaunchKernelGGL((k_stream_emit<GG, kLdsEnt>), grid, dim3(GG::THREADS), StreamCarve<GG>::kBytesTwoTiles, s, a);
 }
 
+// positional-window kernel (length-preserving stream tables in window form)
+constexpr int kLpwThreads = 256;
+constexpr int kLpwEntBytes = 8192;
+template <bool kLdsEnt>
+__global__ __launch_bounds__(kLpwThreads) void k_stream_lpw(ScanArgs a, int64_t lane_bytes) {
+    __shared__ __attribute__((aligned(16))) uint8_t smem[256 + (kLdsEnt ? kLpwEntBytes : 16)];
+    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
+    for (int k = threadIdx.x; k < 256; k += kLpwThreads) smem[k] = a.blob[h.off_cls + k];
+    if (kLdsEnt) {
+        const U128* e = reinterpret_cast<const U128*>(a.blob + h.off_lpw);
+        U128* d = reinterpret_cast<U128*>(smem + 256);
+        for (int k = threadIdx.x; k < (int)(h.lpw_bytes / 16); k += kLpwThreads) d[k] = e[k];
+    }
+    __syncthreads();
+    LpwView T;
+    T.cls = smem;
+    T.ent = kLdsEnt ? reinterpret_cast<const U128*>(smem + 256) : reinterpret_cast<const U128*>(a.blob + h.off_lpw);
+    T.delay = h.lpw_delay;
+    uint32_t st = 0;
+    stream_lpw_lane(a, T, h.n_cls, (int64_t)blockIdx.x * kLpwThreads + threadIdx.x, lane_bytes, st);
+    if (st) atomicOr(a.status, st);
+}
+int lpw_ent_lds_bytes() { return kLpwEntBytes; }
+void launch_lpw_kernel(bool ent_in_lds, const ScanArgs& a, int64_t lane_bytes, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
+    const dim3 grid((unsigned)((n_lanes + kLpwThreads - 1) / kLpwThreads));
+    if (ent_in_lds) hipLaunchKernelGGL((k_stream_lpw<true>), grid, dim3(kLpwThreads), 0, s, a, lane_bytes);
+    else hipLaunchKernelGGL((k_stream_lpw<false>), grid, dim3(kLpwThreads), 0, s, a, lane_bytes);
+}
+
 template <int kMode>
 void launch_direct_t(bool ent_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, hipStream_t s) {
     if (ent_lds) hipLaunchKernelGGL((k_stream_direct<kMode, true>), dim3((unsigned)n_blocks), dim3(kDirectThreads), kDirectLds, s, a, lane_bytes);

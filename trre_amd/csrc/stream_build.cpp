@@ -306,9 +306,42 @@ private:
             }
         }
         t.ok = true;
+        if (lp) build_window_form(t, rep);
         if (lp) t.flags |= kFlagLengthPreserving;
         if (lp && inplace_ok) t.flags |= kFlagNoOverrun;    // the in-place kernel may run
         return t;
+    }
+
+    // 16-byte entries for the positional-window kernel (see front.hpp)
+    void build_window_form(StreamTables& t, const std::vector<int>& rep) {
+        uint32_t delay = 0;
+        for (uint32_t s = 0; s < t.n_states; ++s) delay = std::max(delay, t.pending_len[s]);
+        if (delay > 3) return;
+        std::vector<uint32_t> v((size_t)t.n_states * t.n_cls * 4, 0);
+        for (uint32_t s = 0; s < t.n_states; ++s) {
+            for (uint32_t k = 0; k < t.n_cls; ++k) {
+                const Cell& x = rows_[s][rep[k]];
+                const size_t n = x.out.size() + (x.copy_c ? 1 : 0);
+                if (n > 4) return;                       // (a NUL flushes pending + '\n': at most delay + 1 <= 4)
+                uint32_t* e = &v[((size_t)s * t.n_cls + k) * 4];
+                e[0] = x.next * t.n_cls * 16u;
+                const bool silent = s == skip_ || s == done_;
+                e[1] = (silent ? 0u : 8u * (delay - t.pending_len[s])) | (x.eol ? 32u : 0u) |
+                       ((rep[k] == 0 && !silent) ? 64u : 0u);
+                uint32_t bytes = 0, sel = 0;
+                for (size_t b = 0; b < 4; ++b) {
+                    uint32_t pick = 0x0cu;                                   // constant 0x00
+                    if (b < x.out.size()) { bytes |= (uint32_t)(uint8_t)x.out[b] << (8 * b); pick = (uint32_t)b; }
+                    else if (b == x.out.size() && x.copy_c) pick = 4u;       // byte 0 of the input register
+                    sel |= pick << (8 * b);
+                }
+                e[2] = bytes;
+                e[3] = sel;
+            }
+        }
+        t.lpw = std::move(v);
+        t.lpw_delay = delay;
+        t.lpw_ok = true;
     }
 
     const AttemptModel& m_;
