@@ -218,7 +218,17 @@ void run_lpw(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
     T.ent = reinterpret_cast<const U128*>(a.blob + h.off_lpw);
     T.delay = h.lpw_delay;
     const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
-    for (int64_t lane = n_lanes - 1; lane >= 0; --lane) stream_lpw_lane(a, T, h.n_cls, lane, lane_bytes, status);
+    std::vector<uint32_t> redo(n_lanes + 1, 0);
+    ScanArgs b = a;
+    b.redo = redo.data();
+    for (int64_t lane = n_lanes - 1; lane >= 0; --lane) stream_lpw_lane(b, T, h.n_cls, lane, lane_bytes, status);
+    // second launch: the lanes that touch an end of the input
+    const StreamView TS = direct_view(a);
+    alignas(16) uint8_t ring[80];
+    for (uint32_t k = 0; k < redo[0]; ++k) {
+        DirectLane L;
+        stream_direct_lane<0>(a, TS, h.n_cls, (int64_t)redo[1 + k], lane_bytes, ring, 0, L, status);
+    }
 }
 
 void run_bytemap(const ScanArgs& a, uint32_t& status) {

@@ -44,6 +44,8 @@ struct DeviceState {
     int64_t ws_chunks = 0;
     uint8_t* d_scratch = nullptr;
     size_t scratch_bytes = 0;
+    uint32_t* d_redo = nullptr;       // window kernel redo list
+    int64_t redo_lanes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -265,6 +267,8 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
     args.status = st->d_status;
     args.cap = cap;
     args.gscratch = st->d_scratch;
+    static const uint32_t ablate = getenv("TRRE_ABLATE") ? (uint32_t)atoi(getenv("TRRE_ABLATE")) : 0u;
+    args.ablate = ablate;
     const int chunk = is_stream(family) ? stream_chunk_bytes(family == TRRE_KERNEL_STREAM_LP ? 0 : 1)
                                         : chunk_bytes(p->engine, p->mask_bytes);
     const int threads = is_stream(family) ? stream_block_threads(family == TRRE_KERNEL_STREAM_LP ? 0 : 1)
@@ -296,7 +300,16 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
     } else if (family == TRRE_KERNEL_TILE_LP) {
         launch_tile_kernel(0, p->engine, p->mask_bytes, args, n_chunks, stream);
     } else if (is_stream(family) && stream_impl == 2 && family == TRRE_KERNEL_STREAM_LP && p->stt.lpw_ok) {
-        launch_lpw_kernel(p->stt.lpw.size() * 4 <= (size_t)lpw_ent_lds_bytes(), args, lane_bytes, stream);
+        const int64_t n_lanes = (args.vend + lane_bytes - 1) / lane_bytes;
+        if (st->redo_lanes < n_lanes) {
+            if (st->d_redo) (void)hipFree(st->d_redo);
+            st->d_redo = nullptr; st->redo_lanes = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st->d_redo), (size_t)(n_lanes + 1) * 4));
+            st->redo_lanes = n_lanes;
+        }
+        HIP_TRY(hipMemsetAsync(st->d_redo, 0, 4, stream));
+        args.redo = st->d_redo;
+        launch_lpw_kernel(p->stt.lpw.size() * 4 <= (size_t)lpw_ent_lds_bytes(), direct_ent_lds, args, lane_bytes, stream);
     } else if (direct && family == TRRE_KERNEL_STREAM_LP) {
         launch_direct_kernel(0, direct_ent_lds, args, lane_bytes, n_chunks, stream);
     } else if (direct) {
@@ -446,6 +459,7 @@ void trre_free(trre_prog* p) {
         (void)hipFree(st.d_chunk_total);
         (void)hipFree(st.d_chunk_base);
         (void)hipFree(st.d_scratch);
+        (void)hipFree(st.d_redo);
         if (st.ev0) (void)hipEventDestroy(st.ev0);
         if (st.ev1) (void)hipEventDestroy(st.ev1);
     }

@@ -52,6 +52,8 @@ struct ScanArgs {
     uint64_t* chunk_base;    // [n_chunks + 1] exclusive scan of chunk_total; [n_chunks] = total
     uint64_t cap;            // capacity of out
     uint8_t* gscratch;       // NFT long-line mask scratch (or null)
+    uint32_t ablate;         // experiments only (TRRE_ABLATE): 1 no stores
+    uint32_t* redo;          // window kernel: [0] = count, [1..] = lanes to redo with the general direct walker
 };
 
 // ---- phase: stage the tile -------------------------------------------------------------
@@ -420,8 +422,10 @@ TRRE_HD int64_t line_start_global(const ScanArgs& a, int64_t v) {
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define TRRE_WAVE_ANY(x) __any(x)
+#define TRRE_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)   // keep the scheduler from interleaving blocks
 #else
 #define TRRE_WAVE_ANY(x) (x)
+#define TRRE_SCHED_FENCE() ((void)0)
 #endif
 
 constexpr uint32_t kStrNul = 1u << 29;
@@ -749,10 +753,9 @@ constexpr uint32_t kLpwEol = 32u, kLpwNul = 64u;
 
 // position after the first '\n' at or after lo - 1 (the lane's first line start); >= hi: none
 TRRE_HD int64_t first_line_start_global(const ScanArgs& a, int64_t lo, int64_t hi) {
-    if (lo <= a.vbeg) return a.vbeg;
     if (a.in_v0[lo - 1] == (uint8_t)'\n') return lo;
     for (int64_t v = lo & ~(int64_t)15; v < hi; v += 16) {
-        const U128 q = direct_load(a, v);
+        const U128 q = *reinterpret_cast<const U128*>(a.in_v0 + v);     // callers keep [lo, hi + 16) inside the input
         const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
         for (int d = 0; d < 4; ++d) {
             const uint32_t x = wd[d] ^ 0x0a0a0a0au;
@@ -770,22 +773,40 @@ TRRE_HD int64_t first_line_start_global(const ScanArgs& a, int64_t lo, int64_t h
     return hi;
 }
 
-// store one 16-byte output block; only positions in [fs, end) belong to this lane
-TRRE_HD void lpw_store(const ScanArgs& a, int64_t vb, const U128& q, int64_t fs, int64_t end, bool aligned) {
-    if (aligned && vb >= fs && vb + 16 <= end) {
-        *reinterpret_cast<U128*>(a.out_v0 + vb) = q;
-        return;
-    }
-    const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
-    for (int i = 0; i < 16; ++i) {
-        const int64_t pos = vb + i;
-        if (pos >= fs && pos < end) a.out_v0[pos] = (uint8_t)(wd[i >> 2] >> (8 * (i & 3)));
+// The window kernel's hot loop has no code for the two ends of the whole input (filler before
+// it, the last byte acting as '\n', nothing readable after it).  A lane whose pieces would touch
+// an end hands itself over to the general direct walker (stream_direct_lane<0>, run by a small
+// second launch): outputs are position-determined, so whatever the lane already wrote is simply
+// written again with the same bytes.
+TRRE_HD void lpw_redo(const ScanArgs& a, int64_t lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t k = atomicAdd(a.redo, 1u);
+#else
+    const uint32_t k = a.redo[0]++;
+#endif
+    a.redo[1 + k] = (uint32_t)lane;
+}
+
+// slow path of the piece store: only offsets in [fs, end) belong to this lane
+TRRE_HD void store_dword_partial(uint8_t* out, int32_t pos, uint32_t w, int32_t fs, int32_t end) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (pos + k >= fs && pos + k < end) out[pos + k] = (uint8_t)(w >> (8 * k));
+}
+TRRE_HD void lpw_store_partial(uint8_t* out, int32_t r0, const U128 (&outq)[4], int32_t fs, int32_t end) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        store_dword_partial(out, r0 + 16 * q, outq[q].x, fs, end);
+        store_dword_partial(out, r0 + 16 * q + 4, outq[q].y, fs, end);
+        store_dword_partial(out, r0 + 16 * q + 8, outq[q].z, fs, end);
+        store_dword_partial(out, r0 + 16 * q + 12, outq[q].w, fs, end);
     }
 }
 
+// Positions inside the hot loop are 32-bit offsets from the lane's sub-range start.
 template <bool kCheckEnd>
-TRRE_HD void lpw_block(const LpwView& T, const U128& cur, int64_t v, int64_t hi, uint32_t done_row, uint32_t& row, uint32_t& win,
-                       uint32_t& seen, uint32_t (&Rm)[4], bool& done, int64_t& end) {
+TRRE_HD void lpw_block(const LpwView& T, const U128& cur, int32_t rv, int32_t rhi, uint32_t done_row, uint32_t& row, uint32_t& win,
+                       uint32_t& seen, uint32_t (&Rm)[4], uint32_t& done, int32_t& rend) {
     const uint32_t wd[4] = {cur.x, cur.y, cur.z, cur.w};
     uint32_t R = 0;
 #pragma unroll
@@ -803,54 +824,100 @@ TRRE_HD void lpw_block(const LpwView& T, const U128& cur, int64_t v, int64_t hi,
             row = e.x;
             seen |= e.y;
             if (kCheckEnd) {
-                if ((e.y & kLpwEol) && !done) {
-                    const int64_t p1 = v + 4 * d + j + 1;
-                    if (p1 >= hi) { done = true; end = p1; row = done_row; }
-                }
+                // a record end at or beyond the end of the sub-range finishes the lane (branch-free)
+                const int32_t p1 = rv + 4 * d + j + 1;
+                const uint32_t hit = ((e.y >> 5) & 1u) & (uint32_t)(p1 >= rhi) & (done ^ 1u);
+                rend = hit ? p1 : rend;
+                row = hit ? done_row : row;
+                done |= hit;
             }
             w >>= 8;
         }
         Rm[d] = R;
+        TRRE_SCHED_FENCE();
+    }
+}
+
+template <bool kCheckEnd>
+TRRE_HD void lpw_piece(const LpwView& T, const U128 (&cur)[4], int32_t rv, int32_t rhi, uint32_t done_row, uint32_t D, uint32_t& row,
+                       uint32_t& win, uint32_t& seen, uint32_t& Rprev, U128& carry, U128 (&outq)[4], uint32_t& done, int32_t& rend) {
+    // outq[0] = block rv-16 (needs this piece's first released dword), outq[1..3] = blocks rv, rv+16, rv+32;
+    // block rv+48 stays in `carry` until the next piece
+    uint32_t Rm[4];
+    lpw_block<kCheckEnd>(T, cur[0], rv, rhi, done_row, row, win, seen, Rm, done, rend);
+    outq[0] = carry;
+    outq[0].w = alignbyte_b32(Rm[0], Rprev, D);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        U128 o;
+        o.x = alignbyte_b32(Rm[1], Rm[0], D);
+        o.y = alignbyte_b32(Rm[2], Rm[1], D);
+        o.z = alignbyte_b32(Rm[3], Rm[2], D);
+        o.w = 0;
+        const uint32_t r3 = Rm[3];
+        if (q < 3) {
+            lpw_block<kCheckEnd>(T, cur[q + 1], rv + 16 * (q + 1), rhi, done_row, row, win, seen, Rm, done, rend);
+            o.w = alignbyte_b32(Rm[0], r3, D);
+            outq[q + 1] = o;
+        } else {
+            carry = o;
+            Rprev = r3;
+        }
     }
 }
 
 TRRE_HD void stream_lpw_lane(const ScanArgs& a, const LpwView& T, uint32_t n_cls, int64_t lane, int64_t lane_bytes, uint32_t& status) {
-    const int64_t lo = lane * lane_bytes;
+    const int64_t lo = lane * lane_bytes;            // lane_bytes is a multiple of 64
     int64_t hi = lo + lane_bytes;
     if (hi > a.vend) hi = a.vend;
     if (lo >= hi) return;
+    // keep slack to both ends of the input; lanes that need the edge fix-ups are redone
+    if (lo < a.vbeg + 64 || hi + 192 > a.vend) { lpw_redo(a, lane); return; }
     const int64_t fs = first_line_start_global(a, lo, hi);
     if (fs >= hi) return;                                     // no line starts in this sub-range
-    const uint32_t D = T.delay;
+    const uint32_t D = T.delay & 3u;
     const uint32_t done_row = kDoneState * n_cls * 16u;
     const bool aligned = (reinterpret_cast<uintptr_t>(a.out_v0) & 15u) == 0;
-    int64_t v = fs & ~(int64_t)15;
-    uint32_t row = v == fs ? 0u : kSkipState * n_cls * 16u;   // the byte before fs is '\n': SKIP reaches root exactly at fs
-    uint32_t win = 0, seen = 0, Rprev = 0;
-    bool done = false, have_prev = false;
-    int64_t end = INT64_MAX, vprev = 0;
-    U128 outb{};
-    U128 blk = direct_load(a, v), nxt = direct_load(a, v + 16);
+    const uint8_t* in = a.in_v0 + lo;
+    uint8_t* out = a.out_v0 + lo;
+    const int32_t rhi = (int32_t)(hi - lo), rfs = (int32_t)(fs - lo);
+    // never run into the end of the input, and keep 32-bit offsets exact
+    const int64_t room = a.vend - lo - 192;
+    const int32_t rlimit = room < 0x40000000 ? (int32_t)room : 0x40000000;
+    // HBM/L2 traffic in 64-byte pieces per lane: four 16-byte loads issued together one piece ahead,
+    // four 16-byte stores issued together.
+    int32_t rv = rfs & ~63;
+    uint32_t row = rv == rfs ? 0u : kSkipState * n_cls * 16u;   // the byte before fs is '\n': SKIP reaches root exactly at fs
+    uint32_t win = 0, seen = 0, Rprev = 0, done = 0;
+    int32_t rend = 0x7fffffff;
+    U128 carry{};
+    U128 cur[4], nxt[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const U128*>(in + rv + 16 * q);
     for (;;) {
-        const U128 cur = blk;
-        blk = nxt;
-        nxt = direct_load(a, v + 32);
-        uint32_t Rm[4];
-        if (v + 16 < hi) lpw_block<false>(T, cur, v, hi, done_row, row, win, seen, Rm, done, end);
-        else lpw_block<true>(T, cur, v, hi, done_row, row, win, seen, Rm, done, end);
-        // released dword m holds positions [v + 4m - D, v + 4m - D + 4): realign by D bytes
-        if (have_prev) {
-            outb.w = alignbyte_b32(Rm[0], Rprev, D);
-            lpw_store(a, vprev, outb, fs, end, aligned);
+        if (rv > rlimit) { lpw_redo(a, lane); return; }         // a very long last line: hand over
+#pragma unroll
+        for (int q = 0; q < 4; ++q) nxt[q] = *reinterpret_cast<const U128*>(in + rv + 64 + 16 * q);
+        U128 outq[4];
+        if (rv + 64 < rhi) lpw_piece<false>(T, cur, rv, rhi, done_row, D, row, win, seen, Rprev, carry, outq, done, rend);
+        else lpw_piece<true>(T, cur, rv, rhi, done_row, D, row, win, seen, Rprev, carry, outq, done, rend);
+        // outq covers offsets [rv - 16, rv + 48); only [rfs, rend) is this lane's
+        const bool full = aligned && rv - 16 >= rfs && rv + 48 <= rend;
+        bool stored = false;
+        if (TRRE_WAVE_ANY(!full)) {
+            if (!full) {
+                if (!(a.ablate & 1u)) lpw_store_partial(out, rv - 16, outq, rfs, rend);
+                stored = true;
+            }
         }
-        outb.x = alignbyte_b32(Rm[1], Rm[0], D);
-        outb.y = alignbyte_b32(Rm[2], Rm[1], D);
-        outb.z = alignbyte_b32(Rm[3], Rm[2], D);
-        Rprev = Rm[3];
-        vprev = v;
-        have_prev = true;
-        if (done && v >= end) break;                          // everything up to `end` has been stored
-        v += 16;
+        if (!stored && !(a.ablate & 1u)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<U128*>(out + rv - 16 + 16 * q) = outq[q];
+        }
+        if (done && rend <= rv + 48) break;                   // every offset below `rend` has been stored
+        rv += 64;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
     }
     if (seen & kLpwNul) status |= kStNul;
 }

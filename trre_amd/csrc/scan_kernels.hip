@@ -518,13 +518,32 @@ __global__ __launch_bounds__(kLpwThreads) void k_stream_lpw(ScanArgs a, int64_t 
     stream_lpw_lane(a, T, h.n_cls, (int64_t)blockIdx.x * kLpwThreads + threadIdx.x, lane_bytes, st);
     if (st) atomicOr(a.status, st);
 }
+// second launch of the window path: the few lanes that touch an end of the input, redone by the
+// general direct walker (grid-stride over the redo list)
+template <bool kLdsEnt>
+__global__ __launch_bounds__(kDirectThreads) void k_stream_redo(ScanArgs a, int64_t lane_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const StreamView T = direct_stage<kLdsEnt>(a, smem);
+    const uint32_t n_cls = reinterpret_cast<const StreamBlobHeader*>(a.blob)->n_cls;
+    uint8_t* ring = smem + 256 + kDirectEntBytes + threadIdx.x * kRingStride;
+    const uint32_t n = a.redo[0];
+    uint32_t st = 0;
+    for (uint32_t k = blockIdx.x * kDirectThreads + threadIdx.x; k < n; k += gridDim.x * kDirectThreads) {
+        DirectLane L;
+        stream_direct_lane<0>(a, T, n_cls, (int64_t)a.redo[1 + k], lane_bytes, ring, 0, L, st);
+    }
+    if (st) atomicOr(a.status, st);
+}
 int lpw_ent_lds_bytes() { return kLpwEntBytes; }
-void launch_lpw_kernel(bool ent_in_lds, const ScanArgs& a, int64_t lane_bytes, void* stream) {
+void launch_lpw_kernel(bool ent_in_lds, bool direct_ent_in_lds, const ScanArgs& a, int64_t lane_bytes, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
     const dim3 grid((unsigned)((n_lanes + kLpwThreads - 1) / kLpwThreads));
     if (ent_in_lds) hipLaunchKernelGGL((k_stream_lpw<true>), grid, dim3(kLpwThreads), 0, s, a, lane_bytes);
     else hipLaunchKernelGGL((k_stream_lpw<false>), grid, dim3(kLpwThreads), 0, s, a, lane_bytes);
+    const bool ring_lds = reinterpret_cast<const void*>(a.blob) != nullptr && direct_ent_in_lds;
+    if (ring_lds) hipLaunchKernelGGL((k_stream_redo<true>), dim3(16), dim3(kDirectThreads), kDirectLds, s, a, lane_bytes);
+    else hipLaunchKernelGGL((k_stream_redo<false>), dim3(16), dim3(kDirectThreads), kDirectLds, s, a, lane_bytes);
 }
 
 template <int kMode>
