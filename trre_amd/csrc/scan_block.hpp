@@ -866,60 +866,92 @@ TRRE_HD void lpw_piece(const LpwView& T, const U128 (&cur)[4], int32_t rv, int32
     }
 }
 
-TRRE_HD void stream_lpw_lane(const ScanArgs& a, const LpwView& T, uint32_t n_cls, int64_t lane, int64_t lane_bytes, uint32_t& status) {
-    const int64_t lo = lane * lane_bytes;            // lane_bytes is a multiple of 64
-    int64_t hi = lo + lane_bytes;
-    if (hi > a.vend) hi = a.vend;
-    if (lo >= hi) return;
-    // keep slack to both ends of the input; lanes that need the edge fix-ups are redone
-    if (lo < a.vbeg + 64 || hi + 192 > a.vend) { lpw_redo(a, lane); return; }
-    const int64_t fs = first_line_start_global(a, lo, hi);
-    if (fs >= hi) return;                                     // no line starts in this sub-range
-    const uint32_t D = T.delay & 3u;
-    const uint32_t done_row = kDoneState * n_cls * 16u;
-    const bool aligned = (reinterpret_cast<uintptr_t>(a.out_v0) & 15u) == 0;
-    const uint8_t* in = a.in_v0 + lo;
-    uint8_t* out = a.out_v0 + lo;
-    const int32_t rhi = (int32_t)(hi - lo), rfs = (int32_t)(fs - lo);
-    // never run into the end of the input, and keep 32-bit offsets exact
-    const int64_t room = a.vend - lo - 192;
-    const int32_t rlimit = room < 0x40000000 ? (int32_t)room : 0x40000000;
-    // HBM/L2 traffic in 64-byte pieces per lane: four 16-byte loads issued together one piece ahead,
-    // four 16-byte stores issued together.
-    int32_t rv = rfs & ~63;
-    uint32_t row = rv == rfs ? 0u : kSkipState * n_cls * 16u;   // the byte before fs is '\n': SKIP reaches root exactly at fs
-    uint32_t win = 0, seen = 0, Rprev = 0, done = 0;
-    int32_t rend = 0x7fffffff;
-    U128 carry{};
-    U128 cur[4], nxt[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const U128*>(in + rv + 16 * q);
-    for (;;) {
-        if (rv > rlimit) { lpw_redo(a, lane); return; }         // a very long last line: hand over
-#pragma unroll
-        for (int q = 0; q < 4; ++q) nxt[q] = *reinterpret_cast<const U128*>(in + rv + 64 + 16 * q);
-        U128 outq[4];
+// Per-lane state of the window walk, split from its I/O so that the kernel can move the 64-byte
+// pieces cooperatively (transposed through LDS: adjacent lanes touch adjacent 16-byte blocks) while
+// the host shim and the fallback use plain per-lane loads and stores.
+struct LpwLane {
+    const uint8_t* in;     // a.in_v0 + lo
+    uint8_t* out;          // a.out_v0 + lo
+    int32_t rhi, rfs, rlimit, rv, rend;
+    uint32_t D, done_row, row, win, seen, Rprev, done;
+    U128 carry;
+    bool active, aligned;
+
+    TRRE_HD void init(const ScanArgs& a, const LpwView& T, uint32_t n_cls, int64_t lane, int64_t lane_bytes) {
+        active = false;
+        seen = 0;
+        const int64_t lo = lane * lane_bytes;            // lane_bytes is a multiple of 64
+        int64_t hi = lo + lane_bytes;
+        if (hi > a.vend) hi = a.vend;
+        if (lo >= hi) return;
+        // keep slack to both ends of the input; lanes that need the edge fix-ups are redone
+        if (lo < a.vbeg + 64 || hi + 192 > a.vend) { lpw_redo(a, lane); return; }
+        const int64_t fs = first_line_start_global(a, lo, hi);
+        if (fs >= hi) return;                                     // no line starts in this sub-range
+        D = T.delay & 3u;
+        done_row = kDoneState * n_cls * 16u;
+        aligned = (reinterpret_cast<uintptr_t>(a.out_v0) & 15u) == 0;
+        in = a.in_v0 + lo;
+        out = a.out_v0 + lo;
+        rhi = (int32_t)(hi - lo);
+        rfs = (int32_t)(fs - lo);
+        const int64_t room = a.vend - lo - 192;                   // never run into the end of the input,
+        rlimit = room < 0x40000000 ? (int32_t)room : 0x40000000;  // and keep 32-bit offsets exact
+        rv = rfs & ~63;
+        row = rv == rfs ? 0u : kSkipState * n_cls * 16u;          // the byte before fs is '\n': SKIP reaches root exactly at fs
+        win = 0; Rprev = 0; done = 0;
+        rend = 0x7fffffff;
+        carry = U128{};
+        active = true;
+    }
+    // one 64-byte piece at offset rv: outq = output for offsets [rv - 16, rv + 48), of which only
+    // [rfs, rend) is this lane's (`full` = all of it, 16-byte aligned).  Returns false when the lane
+    // must stop without storing (handed over to the redo launch).
+    TRRE_HD bool piece(const ScanArgs& a, const LpwView& T, int64_t lane, const U128 (&cur)[4], U128 (&outq)[4], bool& full) {
+        if (rv > rlimit) { lpw_redo(a, lane); active = false; return false; }   // a very long last line: hand over
         if (rv + 64 < rhi) lpw_piece<false>(T, cur, rv, rhi, done_row, D, row, win, seen, Rprev, carry, outq, done, rend);
         else lpw_piece<true>(T, cur, rv, rhi, done_row, D, row, win, seen, Rprev, carry, outq, done, rend);
-        // outq covers offsets [rv - 16, rv + 48); only [rfs, rend) is this lane's
-        const bool full = aligned && rv - 16 >= rfs && rv + 48 <= rend;
-        bool stored = false;
-        if (TRRE_WAVE_ANY(!full)) {
-            if (!full) {
-                if (!(a.ablate & 1u)) lpw_store_partial(out, rv - 16, outq, rfs, rend);
-                stored = true;
+        full = aligned && rv - 16 >= rfs && rv + 48 <= rend;
+        return true;
+    }
+    // after the piece's output has been stored
+    TRRE_HD void advance() {
+        if (done && rend <= rv + 48) active = false;              // every offset below `rend` has been stored
+        else rv += 64;
+    }
+};
+
+// plain per-lane I/O (host shim; also the non-cooperative device path)
+TRRE_HD void stream_lpw_lane(const ScanArgs& a, const LpwView& T, uint32_t n_cls, int64_t lane, int64_t lane_bytes, uint32_t& status) {
+    LpwLane L;
+    L.init(a, T, n_cls, lane, lane_bytes);
+    if (!L.active) return;
+    U128 cur[4], nxt[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const U128*>(L.in + L.rv + 16 * q);
+    while (L.active) {
+        if (L.rv <= L.rlimit) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nxt[q] = *reinterpret_cast<const U128*>(L.in + L.rv + 64 + 16 * q);
+        }
+        U128 outq[4];
+        bool full;
+        if (!L.piece(a, T, lane, cur, outq, full)) break;
+        if (!(a.ablate & 1u)) {
+            bool stored = false;
+            if (TRRE_WAVE_ANY(!full)) {
+                if (!full) { lpw_store_partial(L.out, L.rv - 16, outq, L.rfs, L.rend); stored = true; }
+            }
+            if (!stored) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<U128*>(L.out + L.rv - 16 + 16 * q) = outq[q];
             }
         }
-        if (!stored && !(a.ablate & 1u)) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) *reinterpret_cast<U128*>(out + rv - 16 + 16 * q) = outq[q];
-        }
-        if (done && rend <= rv + 48) break;                   // every offset below `rend` has been stored
-        rv += 64;
+        L.advance();
 #pragma unroll
         for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
     }
-    if (seen & kLpwNul) status |= kStNul;
+    if (L.seen & kLpwNul) status |= kStNul;
 }
 
 // =============================================================================================

@@ -499,9 +499,19 @@ void launch_stream_t(int which, const ScanArgs& a, int64_t n_chunks, hipStream_t
 // positional-window kernel (length-preserving stream tables in window form)
 constexpr int kLpwThreads = 256;
 constexpr int kLpwEntBytes = 8192;
+// Cooperative piece I/O of the window kernel.  Each lane works on its own 64-byte piece, but the
+// pieces of a wave's 64 lanes lie lane_bytes apart, so per-lane 16-byte accesses would be 64
+// separate cache lines per instruction.  Instead every lane publishes the address of its piece in
+// a per-wave LDS table and the wave moves the 64 pieces transposed: in access i lane L handles
+// quarter (L & 3) of the piece of lane 16 i + (L >> 2), i.e. four adjacent lanes cover one
+// contiguous 64-byte piece.  Rows are 80 bytes: 64 data + address + flag.
+constexpr int kLpwRow = 80;
+constexpr int kLpwWaveLds = 64 * kLpwRow;
+constexpr int kLpwWaves = kLpwThreads / kWave;
+
 template <bool kLdsEnt>
 __global__ __launch_bounds__(kLpwThreads) void k_stream_lpw(ScanArgs a, int64_t lane_bytes) {
-    __shared__ __attribute__((aligned(16))) uint8_t smem[256 + (kLdsEnt ? kLpwEntBytes : 16)];
+    __shared__ __attribute__((aligned(16))) uint8_t smem[256 + (kLdsEnt ? kLpwEntBytes : 16) + kLpwWaves * kLpwWaveLds];
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
     for (int k = threadIdx.x; k < 256; k += kLpwThreads) smem[k] = a.blob[h.off_cls + k];
     if (kLdsEnt) {
@@ -514,10 +524,66 @@ __global__ __launch_bounds__(kLpwThreads) void k_stream_lpw(ScanArgs a, int64_t 
     T.cls = smem;
     T.ent = kLdsEnt ? reinterpret_cast<const U128*>(smem + 256) : reinterpret_cast<const U128*>(a.blob + h.off_lpw);
     T.delay = h.lpw_delay;
-    uint32_t st = 0;
-    stream_lpw_lane(a, T, h.n_cls, (int64_t)blockIdx.x * kLpwThreads + threadIdx.x, lane_bytes, st);
+    const int lid = threadIdx.x & (kWave - 1);
+    uint8_t* wave_lds = smem + 256 + (kLdsEnt ? kLpwEntBytes : 16) + (threadIdx.x / kWave) * kLpwWaveLds;
+    uint8_t* my_row = wave_lds + lid * kLpwRow;
+    const int64_t lane = (int64_t)blockIdx.x * kLpwThreads + threadIdx.x;
+
+    LpwLane L;
+    L.init(a, T, h.n_cls, lane, lane_bytes);
+    U128 cur[4] = {}, tmp[4] = {};
+    if (L.active) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const U128*>(L.in + L.rv + 16 * q);
+    }
+    while (__any(L.active)) {
+        // ---- A. transposed prefetch of every lane's next piece (into tmp, lands during the compute)
+        {
+            const bool want = L.active && L.rv <= L.rlimit;
+            *reinterpret_cast<uint64_t*>(my_row + 64) = want ? reinterpret_cast<uint64_t>(L.in + L.rv + 64) : 0ull;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint8_t* r = wave_lds + (16 * i + (lid >> 2)) * kLpwRow;
+                const uint64_t src = *reinterpret_cast<const uint64_t*>(r + 64);
+                if (src) tmp[i] = *reinterpret_cast<const U128*>(reinterpret_cast<const uint8_t*>(src) + 16 * (lid & 3));
+            }
+        }
+        // ---- B. compute
+        U128 outq[4];
+        bool full = false, ok = false;
+        if (L.active) ok = L.piece(a, T, lane, cur, outq, full);
+        // ---- C. transposed store of the pieces that are entirely their lane's; the others store bytewise
+        {
+            const bool coop = ok && full && !(a.ablate & 1u);
+            if (ok && !full && !(a.ablate & 1u)) lpw_store_partial(L.out, L.rv - 16, outq, L.rfs, L.rend);
+            *reinterpret_cast<uint64_t*>(my_row + 64) = coop ? reinterpret_cast<uint64_t>(L.out + L.rv - 16) : 0ull;
+            if (coop) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<U128*>(my_row + 16 * q) = outq[q];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint8_t* r = wave_lds + (16 * i + (lid >> 2)) * kLpwRow;
+                const uint64_t dst = *reinterpret_cast<const uint64_t*>(r + 64);
+                if (dst) *reinterpret_cast<U128*>(reinterpret_cast<uint8_t*>(dst) + 16 * (lid & 3)) = *reinterpret_cast<const U128*>(r + 16 * (lid & 3));
+            }
+        }
+        if (ok) L.advance();
+        // ---- D. the prefetched pieces: back through LDS to their owners
+        {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint8_t* r = wave_lds + (16 * i + (lid >> 2)) * kLpwRow;
+                *reinterpret_cast<U128*>(r + 16 * (lid & 3)) = tmp[i];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const U128*>(my_row + 16 * q);
+        }
+    }
+    uint32_t st = (L.seen & kLpwNul) ? kStNul : 0u;
     if (st) atomicOr(a.status, st);
 }
+
 // second launch of the window path: the few lanes that touch an end of the input, redone by the
 // general direct walker (grid-stride over the redo list)
 template <bool kLdsEnt>
