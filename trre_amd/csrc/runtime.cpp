@@ -275,9 +275,13 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
                                           : block_threads(p->engine, p->mask_bytes);
     int64_t n_chunks = (args.vend + chunk - 1) / chunk;
     const bool ent_lds = p->stt.ok && p->stt.ent.size() * 8 <= (size_t)StreamEngine::kLdsEntBytes;
-    // stream families have two implementations: LDS-tile (0) and direct (1)
-    static const int stream_impl = getenv("TRRE_STREAM_IMPL") ? atoi(getenv("TRRE_STREAM_IMPL")) : 0;
-    static const int64_t lane_bytes = getenv("TRRE_LANE_BYTES") ? atoll(getenv("TRRE_LANE_BYTES")) : 2048;
+    // stream families have three implementations (TRRE_STREAM_IMPL, for A/B measurements):
+    //   0 LDS tile (k_stream_lp / k_stream_count+emit)      1 direct walker with an LDS output ring
+    //   2 (default) positional-window kernel for length-preserving tables that have the window
+    //     form, direct walker otherwise
+    static const int stream_impl = getenv("TRRE_STREAM_IMPL") ? atoi(getenv("TRRE_STREAM_IMPL")) : 2;
+    static const int64_t lane_bytes_env = getenv("TRRE_LANE_BYTES") ? atoll(getenv("TRRE_LANE_BYTES")) : 0;
+    const int64_t lane_bytes = lane_bytes_env > 0 ? (lane_bytes_env + 63) / 64 * 64 : (family == TRRE_KERNEL_STREAM_LP ? 1024 : 2048);
     const bool direct = is_stream(family) && stream_impl >= 1;
     const bool direct_ent_lds = p->stt.ok && p->stt.ent.size() * 8 <= (size_t)direct_ent_lds_bytes();
     if (direct) n_chunks = (args.vend + lane_bytes * direct_block_threads() - 1) / (lane_bytes * direct_block_threads());

@@ -510,7 +510,7 @@ constexpr int kLpwWaveLds = 64 * kLpwRow;
 constexpr int kLpwWaves = kLpwThreads / kWave;
 
 template <bool kLdsEnt>
-__global__ __launch_bounds__(kLpwThreads) void k_stream_lpw(ScanArgs a, int64_t lane_bytes) {
+__global__ __launch_bounds__(kLpwThreads) void k_stream_lpw_coop(ScanArgs a, int64_t lane_bytes) {
     __shared__ __attribute__((aligned(16))) uint8_t smem[256 + (kLdsEnt ? kLpwEntBytes : 16) + kLpwWaves * kLpwWaveLds];
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
     for (int k = threadIdx.x; k < 256; k += kLpwThreads) smem[k] = a.blob[h.off_cls + k];
@@ -584,6 +584,27 @@ __global__ __launch_bounds__(kLpwThreads) void k_stream_lpw(ScanArgs a, int64_t 
     if (st) atomicOr(a.status, st);
 }
 
+// plain per-lane piece I/O (four 16-byte loads / stores per lane per piece)
+template <bool kLdsEnt>
+__global__ __launch_bounds__(kLpwThreads) void k_stream_lpw(ScanArgs a, int64_t lane_bytes) {
+    __shared__ __attribute__((aligned(16))) uint8_t smem[256 + (kLdsEnt ? kLpwEntBytes : 16)];
+    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
+    for (int k = threadIdx.x; k < 256; k += kLpwThreads) smem[k] = a.blob[h.off_cls + k];
+    if (kLdsEnt) {
+        const U128* e = reinterpret_cast<const U128*>(a.blob + h.off_lpw);
+        U128* d = reinterpret_cast<U128*>(smem + 256);
+        for (int k = threadIdx.x; k < (int)(h.lpw_bytes / 16); k += kLpwThreads) d[k] = e[k];
+    }
+    __syncthreads();
+    LpwView T;
+    T.cls = smem;
+    T.ent = kLdsEnt ? reinterpret_cast<const U128*>(smem + 256) : reinterpret_cast<const U128*>(a.blob + h.off_lpw);
+    T.delay = h.lpw_delay;
+    uint32_t st = 0;
+    stream_lpw_lane(a, T, h.n_cls, (int64_t)blockIdx.x * kLpwThreads + threadIdx.x, lane_bytes, st);
+    if (st) atomicOr(a.status, st);
+}
+
 // second launch of the window path: the few lanes that touch an end of the input, redone by the
 // general direct walker (grid-stride over the redo list)
 template <bool kLdsEnt>
@@ -605,8 +626,14 @@ void launch_lpw_kernel(bool ent_in_lds, bool direct_ent_in_lds, const ScanArgs& 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
     const dim3 grid((unsigned)((n_lanes + kLpwThreads - 1) / kLpwThreads));
-    if (ent_in_lds) hipLaunchKernelGGL((k_stream_lpw<true>), grid, dim3(kLpwThreads), 0, s, a, lane_bytes);
-    else hipLaunchKernelGGL((k_stream_lpw<false>), grid, dim3(kLpwThreads), 0, s, a, lane_bytes);
+    static const bool coop = getenv("TRRE_LPW_COOP") && atoi(getenv("TRRE_LPW_COOP")) != 0;
+    if (coop) {
+        if (ent_in_lds) hipLaunchKernelGGL((k_stream_lpw_coop<true>), grid, dim3(kLpwThreads), 0, s, a, lane_bytes);
+        else hipLaunchKernelGGL((k_stream_lpw_coop<false>), grid, dim3(kLpwThreads), 0, s, a, lane_bytes);
+    } else {
+        if (ent_in_lds) hipLaunchKernelGGL((k_stream_lpw<true>), grid, dim3(kLpwThreads), 0, s, a, lane_bytes);
+        else hipLaunchKernelGGL((k_stream_lpw<false>), grid, dim3(kLpwThreads), 0, s, a, lane_bytes);
+    }
     const bool ring_lds = reinterpret_cast<const void*>(a.blob) != nullptr && direct_ent_in_lds;
     if (ring_lds) hipLaunchKernelGGL((k_stream_redo<true>), dim3(16), dim3(kDirectThreads), kDirectLds, s, a, lane_bytes);
     else hipLaunchKernelGGL((k_stream_redo<false>), dim3(16), dim3(kDirectThreads), kDirectLds, s, a, lane_bytes);
