@@ -181,8 +181,8 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-            "kernel": {"bytemap": "k_bytemap", "tile_lp": "k_scan_lp", "tile_gen": "k_scan_emit", "stream_lp": "k_stream_lp",
-                       "stream_gen": "k_stream_emit"}[trre_amd.KERNEL_NAMES[info.kernel]],
+            "kernel": {"bytemap": "k_bytemap", "tile_lp": "k_scan_lp", "tile_gen": "k_scan_emit", "stream_lp": "k_stream_lpw",
+                       "stream_gen": "k_stream_direct<emit>"}[trre_amd.KERNEL_NAMES[info.kernel]],
             "kernel_ms": round(kernel_ms, 4),
             "algorithmic_bytes_per_launch": n,
             "achieved_read_plus_write": round((n + m) / (kernel_ms * 1e-3) / 1e9, 1),

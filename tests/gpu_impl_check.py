@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Run by tests/test_gpu_parity.py in a subprocess with TRRE_STREAM_IMPL / TRRE_LPW_COOP /
+TRRE_LANE_BYTES set: checks the alternative implementations of the stream kernel families
+against the oracle (the environment is read once per process by the library)."""
+import os
+import random
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+import torch  # noqa: E402
+
+import corpus  # noqa: E402
+import trre_amd  # noqa: E402
+from oracle_lib import Oracle  # noqa: E402
+
+
+def main():
+    rng = random.Random(31)
+    long_line = b"cat dog ca do " * 700
+    data = (corpus.word_soup(rng, 400000) + b"short cat\n" + long_line + b"\n" + corpus.printable_lines(rng, 300000)
+            + b"nul\0cat dog\n" + b"tail cat without newline")
+    clean = data.replace(b"\0", b" ")
+    bad = 0
+    for pat, eng in [("[a:A-z:Z]", "dft"), ("(cat:dog|dog:cat)", "nft"), ("(cat:dog|dog:cat)", "dft"), ("cat:dog", "nft"),
+                     ("a:xyz", "dft"), ("[aie]:", "nft"), ("abc:2|ab:1", "nft"), ("abc:2|ab:1", "dft")]:
+        p = trre_amd.Program(pat, eng)
+        for fam in [f for f in p.allowed_kernels() if f in (trre_amd.KERNEL_STREAM_LP, trre_amd.KERNEL_STREAM_GEN)]:
+            p.set_kernel(fam)
+            for buf in (clean, data, b"cat\n", b"cat"):
+                t = torch.frombuffer(bytearray(buf), dtype=torch.uint8).cuda()
+                got = p.scan_tensor(t).cpu().numpy().tobytes()
+                if got != Oracle(pat, eng).scan(buf):
+                    print("MISMATCH", pat, eng, fam, len(buf))
+                    bad += 1
+    print("impl check: %s" % ("ok" if not bad else "%d mismatches" % bad))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

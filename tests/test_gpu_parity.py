@@ -99,6 +99,21 @@ def test_long_lines_on_gpu():
     assert gpu_scan(prog("(cat:dog|dog:cat)", "dft"), one) == Oracle("(cat:dog|dog:cat)", "dft").scan(one)
 
 
+@pytest.mark.parametrize("env", [{"TRRE_STREAM_IMPL": "0"}, {"TRRE_STREAM_IMPL": "1"}, {"TRRE_STREAM_IMPL": "1", "TRRE_LANE_BYTES": "256"},
+                                 {"TRRE_STREAM_IMPL": "2", "TRRE_LANE_BYTES": "4096"}, {"TRRE_STREAM_IMPL": "2", "TRRE_LPW_COOP": "1"}])
+def test_alternative_stream_implementations(env):
+    """LDS-tile, direct and cooperative variants of the stream families (selected by environment,
+    which the library reads once per process)"""
+    import os
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.update(env)
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_impl_check.py")
+    r = subprocess.run([sys.executable, script], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode("latin-1")[-2000:]
+
+
 def test_capacity_error_reports_needed_size():
     import ctypes
     import torch
