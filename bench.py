@@ -51,6 +51,28 @@ def synth_lines(n, seed, device):
     return data
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this same
+    command (profiles/*_bench_pmc_{FETCH,WRITE}_SIZE.txt, newest round).  FETCH_SIZE / WRITE_SIZE
+    are in KB; on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced read
+    (MI355X_MICROARCH.md, HBM section), so it is doubled."""
+    import glob
+    import re
+    vals = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_pmc_%s.txt" % c)))
+        if not files:
+            return None
+        text = open(files[-1]).read()
+        if kernel_name not in text:
+            return None
+        m = re.search(r"%s\s+([0-9.]+)" % c, text)
+        if not m:
+            return None
+        vals[c] = float(m.group(1))
+    return int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
+
+
 def cpu_baseline(pattern, engine, sample, cores_mt):
     """Time the reference's CPU path on the host cores over a bounded sample.
     Prefers the compiled reference binary (kind "reference"); falls back to the
@@ -180,7 +202,8 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "traffic": pmc_traffic("k_bytemap") if (info.kernel == 1 and n == 1 << 30) else None,
             "kernel": {"bytemap": "k_bytemap", "tile_lp": "k_scan_lp", "tile_gen": "k_scan_emit", "stream_lp": "k_stream_lpw",
                        "stream_gen": "k_stream_direct<emit>"}[trre_amd.KERNEL_NAMES[info.kernel]],
             "kernel_ms": round(kernel_ms, 4),
