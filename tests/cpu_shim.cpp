@@ -225,9 +225,10 @@ void run_lpw(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
     // second launch: the lanes that touch an end of the input
     const StreamView TS = direct_view(a);
     alignas(16) uint8_t ring[80];
-    for (uint32_t k = 0; k < redo[0]; ++k) {
+    const int64_t sub = lane_bytes >= 64 ? lane_bytes / 64 : 1, sub_bytes = lane_bytes >= 64 ? 64 : lane_bytes;
+    for (int64_t k = 0; k < (int64_t)redo[0] * sub; ++k) {
         DirectLane L;
-        stream_direct_lane<0>(a, TS, h.n_cls, (int64_t)redo[1 + k], lane_bytes, ring, 0, L, status);
+        stream_direct_lane<0>(a, TS, h.n_cls, (int64_t)redo[1 + k / sub] * sub + k % sub, sub_bytes, ring, 0, L, status);
     }
 }
 

@@ -613,11 +613,14 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_redo(ScanArgs a, int6
     const StreamView T = direct_stage<kLdsEnt>(a, smem);
     const uint32_t n_cls = reinterpret_cast<const StreamBlobHeader*>(a.blob)->n_cls;
     uint8_t* ring = smem + 256 + kDirectEntBytes + threadIdx.x * kRingStride;
-    const uint32_t n = a.redo[0];
+    // every listed lane is split into 64-byte sub-lanes (same ownership rule, same positional
+    // output) so that the few redone lanes do not serialise a whole sub-range each
+    const int64_t sub = lane_bytes / 64;
+    const int64_t n = (int64_t)a.redo[0] * sub;
     uint32_t st = 0;
-    for (uint32_t k = blockIdx.x * kDirectThreads + threadIdx.x; k < n; k += gridDim.x * kDirectThreads) {
+    for (int64_t k = (int64_t)blockIdx.x * kDirectThreads + threadIdx.x; k < n; k += (int64_t)gridDim.x * kDirectThreads) {
         DirectLane L;
-        stream_direct_lane<0>(a, T, n_cls, (int64_t)a.redo[1 + k], lane_bytes, ring, 0, L, st);
+        stream_direct_lane<0>(a, T, n_cls, (int64_t)a.redo[1 + k / sub] * sub + k % sub, 64, ring, 0, L, st);
     }
     if (st) atomicOr(a.status, st);
 }
@@ -635,8 +638,8 @@ void launch_lpw_kernel(bool ent_in_lds, bool direct_ent_in_lds, const ScanArgs& 
         else hipLaunchKernelGGL((k_stream_lpw<false>), grid, dim3(kLpwThreads), 0, s, a, lane_bytes);
     }
     const bool ring_lds = reinterpret_cast<const void*>(a.blob) != nullptr && direct_ent_in_lds;
-    if (ring_lds) hipLaunchKernelGGL((k_stream_redo<true>), dim3(16), dim3(kDirectThreads), kDirectLds, s, a, lane_bytes);
-    else hipLaunchKernelGGL((k_stream_redo<false>), dim3(16), dim3(kDirectThreads), kDirectLds, s, a, lane_bytes);
+    if (ring_lds) hipLaunchKernelGGL((k_stream_redo<true>), dim3(64), dim3(kDirectThreads), kDirectLds, s, a, lane_bytes);
+    else hipLaunchKernelGGL((k_stream_redo<false>), dim3(64), dim3(kDirectThreads), kDirectLds, s, a, lane_bytes);
 }
 
 template <int kMode>
