@@ -158,3 +158,21 @@ def test_random_patterns_against_oracle():
                 assert got == want, (pat, eng, fam, data)
                 checked += 1
     assert checked > 200
+
+
+def test_dictionary_config_through_the_fold():
+    """BASELINE config 5 in miniature: a seeded key:value dictionary.  Both engines fold into the
+    stream table (the NFT one has far more than 64 CONS states) and match the oracle."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import dictgen
+    keys, vals = dictgen.make_dictionary(120)
+    pat = dictgen.pattern(keys, vals)
+    data = dictgen.corpus(keys, 30000) + dictgen.corpus_fast(keys, 20000)
+    for eng in ("dft", "nft"):
+        p = trre_amd.Program(pat, eng)
+        assert p.info.stream_states > 100 and p.info.kernel == trre_amd.KERNEL_STREAM_GEN
+        want = Oracle(pat, eng).scan(data)
+        for fam in shim_families(p):
+            assert shim_lib.scan_like_runtime(p, data, geo=0, family=fam) == want, (eng, fam)
+            assert shim_lib.scan_like_runtime(p, data, geo=1, family=fam) == want, (eng, fam)

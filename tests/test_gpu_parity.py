@@ -159,3 +159,20 @@ def test_full_size_properties_1gib_uppercase():
     cut = int((data[: 8 << 20] == 10).nonzero()[-1]) + 1
     host = data[:cut].cpu().numpy().tobytes()
     assert out[:cut].cpu().numpy().tobytes() == Oracle("[a:A-z:Z]", "dft").scan(host)
+
+
+def test_dictionary_config_on_gpu():
+    """BASELINE config 5 shape: the seeded 1000-entry key:value dictionary, both engines (the NFT
+    engine has 5555 CONS states and runs through the folded stream table)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import dictgen
+    keys, vals = dictgen.make_dictionary(1000)
+    pat = dictgen.pattern(keys, vals)
+    data = dictgen.corpus_fast(keys, 3 << 20)
+    for eng in ("dft", "nft"):
+        p = prog(pat, eng)
+        want = Oracle(pat, eng).scan(data[: 1 << 18] if eng == "nft" else data)   # the NFT oracle is ~0.2 MB/s here
+        got = gpu_scan(p, data[: 1 << 18] if eng == "nft" else data)
+        assert got == want, eng

@@ -51,6 +51,8 @@ public:
     virtual ~AttemptModel() {}
     virtual Outcome attempt(const std::string& w, bool at_eol) const = 0;
     virtual bool tries_empty_tail() const = 0;   // the NFT's extra attempt at end of line
+    // bytes the automaton can consume at all; every other byte behaves like any other such byte
+    virtual void alphabet(bool (&used)[256]) const = 0;
 };
 
 // ---- deterministic engine: infer_dft, trre_dft.c:1110-1196 --------------------------------
@@ -77,6 +79,12 @@ public:
         return r;
     }
     bool tries_empty_tail() const override { return false; }   // never accepts: the start state is not final
+    void alphabet(bool (&used)[256]) const override {
+        for (int c = 0; c < 256; ++c) used[c] = false;
+        for (const DftState& st : d_.st)
+            for (int c = 0; c < 256; ++c)
+                if (st.edge[c].to >= 0) used[c] = true;
+    }
 
 private:
     const Dft& d_;
@@ -85,7 +93,10 @@ private:
 // ---- backtracking engine: infer_backtrack, trre_nft.c:593-657 ------------------------------
 class NftModel : public AttemptModel {
 public:
-    explicit NftModel(const Nft& n) : n_(n) {}
+    explicit NftModel(const Nft& n) : n_(n) {
+        // whole-build search budget: grows with the automaton (a 1000-key dictionary needs ~5e8 steps)
+        budget_ = std::min<uint64_t>(1500000000ull, std::max<uint64_t>(30000000ull, 60000ull * n.st.size()));
+    }
     Outcome attempt(const std::string& w, bool at_eol) const override {
         struct Item { int32_t s; size_t i, o; };
         std::vector<Item> stack;
@@ -94,7 +105,7 @@ public:
         int32_t s = n_.start;
         size_t i = 0, o = 0, steps = 0;
         while (!stack.empty() || s >= 0) {
-            if (++steps > 2000000 || ++work_ > 30000000) throw GiveUp();   // per-attempt and whole-build budgets
+            if (++steps > 2000000 || ++work_ > budget_) throw GiveUp();   // per-attempt and whole-build budgets
             if (s < 0) {
                 s = stack.back().s; i = stack.back().i; o = stack.back().o;
                 stack.pop_back();
@@ -143,10 +154,16 @@ public:
         return r;
     }
     bool tries_empty_tail() const override { return true; }
+    void alphabet(bool (&used)[256]) const override {
+        for (int c = 0; c < 256; ++c) used[c] = false;
+        for (const NState& st : n_.st)
+            if (st.kind == NKind::Cons) used[st.val] = true;
+    }
 
 private:
     const Nft& n_;
     mutable uint64_t work_ = 0;
+    uint64_t budget_ = 30000000ull;
 };
 
 class StreamBuilder {
@@ -155,6 +172,7 @@ public:
 
     StreamTables run() {
         StreamTables t;
+        m_.alphabet(used_);
         intern("");                       // 0 = root
         skip_ = (uint32_t)names_.size();  // 1 = SKIP: swallow the rest of the record (after a NUL; also a
         names_.push_back(std::string("\0skip", 5));   //     lane's state before its first line start)
@@ -173,7 +191,17 @@ public:
                 continue;
             }
             const std::string w = names_[s];
-            for (int c = 0; c < 256; ++c) rows_[s][c] = transition(w, c);
+            // a byte no state can consume ends every pending attempt and is copied raw: all such
+            // bytes share one transition (its output ends with the byte itself -> copy flag)
+            int other = -1;
+            for (int c = 0; c < 256; ++c) {
+                if (c != 0 && c != '\n' && !used_[c]) {
+                    if (other < 0) { other = c; rows_[s][c] = transition(w, c); }
+                    else rows_[s][c] = rows_[s][other];
+                } else {
+                    rows_[s][c] = transition(w, c);
+                }
+            }
         }
         return pack(t);
     }
@@ -350,6 +378,7 @@ private:
     std::vector<std::vector<Cell>> rows_;
     std::unordered_map<std::string, uint32_t> index_;
     uint32_t skip_ = 1, done_ = 2;
+    bool used_[256];
 };
 
 StreamTables build(const AttemptModel& m, const StreamLimits& lim) {
