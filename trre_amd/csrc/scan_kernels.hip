@@ -399,8 +399,8 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_direct(ScanArgs a, in
 // ------------------------------------------------------------------------------------------
 // memoryless byte map: out[v] = map[in[v]], 16 bytes per lane per step
 constexpr int kMapThreads = 256;
-constexpr int kMapUnroll = 4;
 
+template <int kUnroll, bool kNonTemporal>
 __global__ __launch_bounds__(kMapThreads) void k_bytemap(ScanArgs a, int64_t nvec) {
     __shared__ uint8_t map[256];
     const DftBlobHeader& h = *reinterpret_cast<const DftBlobHeader*>(a.blob);
@@ -409,19 +409,37 @@ __global__ __launch_bounds__(kMapThreads) void k_bytemap(ScanArgs a, int64_t nve
     const bool aligned = (reinterpret_cast<uintptr_t>(a.out_v0) & 15u) == 0;
     const int64_t vfirst = a.vbeg & ~(int64_t)15;
     uint32_t zero = 0;
-    const int64_t stride = (int64_t)gridDim.x * kMapThreads * kMapUnroll;
-    for (int64_t base = (int64_t)blockIdx.x * kMapThreads * kMapUnroll; base < nvec; base += stride) {
-        U128 w[kMapUnroll];
+    const int64_t stride = (int64_t)gridDim.x * kMapThreads * kUnroll;
+    for (int64_t base = (int64_t)blockIdx.x * kMapThreads * kUnroll; base < nvec; base += stride) {
+        U128 w[kUnroll];
 #pragma unroll
-        for (int u = 0; u < kMapUnroll; ++u) {
+        for (int u = 0; u < kUnroll; ++u) {
             const int64_t k = base + u * kMapThreads + threadIdx.x;
-            if (k < nvec) w[u] = *reinterpret_cast<const U128*>(a.in_v0 + vfirst + k * 16);
+            if (k < nvec) {
+                const U128* src = reinterpret_cast<const U128*>(a.in_v0 + vfirst + k * 16);
+                if (kNonTemporal) {
+                    w[u].x = __builtin_nontemporal_load(&src->x); w[u].y = __builtin_nontemporal_load(&src->y);
+                    w[u].z = __builtin_nontemporal_load(&src->z); w[u].w = __builtin_nontemporal_load(&src->w);
+                } else {
+                    w[u] = *src;
+                }
+            }
         }
 #pragma unroll
-        for (int u = 0; u < kMapUnroll; ++u) {
+        for (int u = 0; u < kUnroll; ++u) {
             const int64_t k = base + u * kMapThreads + threadIdx.x;
             if (k >= nvec) continue;
-            bytemap_vec(a, map, w[u], vfirst + k * 16, aligned, zero);
+            const int64_t v = vfirst + k * 16;
+            if (kNonTemporal && aligned && v >= a.vbeg && v + 16 <= a.vend - 1) {
+                U128 r;
+                r.x = map4(map, w[u].x); r.y = map4(map, w[u].y); r.z = map4(map, w[u].z); r.w = map4(map, w[u].w);
+                zero |= has_zero_byte(w[u].x) | has_zero_byte(w[u].y) | has_zero_byte(w[u].z) | has_zero_byte(w[u].w);
+                U128* dst = reinterpret_cast<U128*>(a.out_v0 + v);
+                __builtin_nontemporal_store(r.x, &dst->x); __builtin_nontemporal_store(r.y, &dst->y);
+                __builtin_nontemporal_store(r.z, &dst->z); __builtin_nontemporal_store(r.w, &dst->w);
+                continue;
+            }
+            bytemap_vec(a, map, w[u], v, aligned, zero);
         }
     }
     if (zero) atomicOr(a.status, kStNul);
@@ -672,12 +690,28 @@ void launch_chunk_scan(const uint64_t* total, uint64_t* base, int64_t n_chunks, 
 void launch_bytemap(const ScanArgs& a, void* stream) {
     const int64_t vfirst = a.vbeg & ~(int64_t)15;
     const int64_t nvec = (a.vend - vfirst + 15) / 16;
-    const int64_t per_block = (int64_t)kMapThreads * kMapUnroll;
+    // tuning knobs for A/B runs: TRRE_MAP_UNROLL (2|4|8), TRRE_MAP_NT (0|1), TRRE_MAP_WGS (workgroups per CU, 0 = one pass).
+    // Measured on 1 GiB (ms per launch): unroll 4 / non-temporal / one pass 0.361; unroll 4 / plain / 16 per CU 0.399;
+    // unroll 8 and unroll 2 are slower in every combination.
+    static const int unroll = getenv("TRRE_MAP_UNROLL") ? atoi(getenv("TRRE_MAP_UNROLL")) : 4;
+    static const int nt = getenv("TRRE_MAP_NT") ? atoi(getenv("TRRE_MAP_NT")) : 1;
+    static const int wgs = getenv("TRRE_MAP_WGS") ? atoi(getenv("TRRE_MAP_WGS")) : 0;
+    const int64_t per_block = (int64_t)kMapThreads * unroll;
     int64_t blocks = (nvec + per_block - 1) / per_block;
-    const int64_t cap = 256 * 16;                     // 256 CUs x 16 resident workgroups, grid-stride beyond
+    const int64_t cap = wgs > 0 ? 256 * (int64_t)wgs : blocks;      // grid-stride beyond `cap` workgroups
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_bytemap, dim3((unsigned)blocks), dim3(kMapThreads), 0, static_cast<hipStream_t>(stream), a, nvec);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 g((unsigned)blocks), b(kMapThreads);
+    if (nt) {
+        if (unroll == 2) hipLaunchKernelGGL((k_bytemap<2, true>), g, b, 0, s, a, nvec);
+        else if (unroll == 8) hipLaunchKernelGGL((k_bytemap<8, true>), g, b, 0, s, a, nvec);
+        else hipLaunchKernelGGL((k_bytemap<4, true>), g, b, 0, s, a, nvec);
+    } else {
+        if (unroll == 2) hipLaunchKernelGGL((k_bytemap<2, false>), g, b, 0, s, a, nvec);
+        else if (unroll == 8) hipLaunchKernelGGL((k_bytemap<8, false>), g, b, 0, s, a, nvec);
+        else hipLaunchKernelGGL((k_bytemap<4, false>), g, b, 0, s, a, nvec);
+    }
 }
 
 }  // namespace trre
