@@ -131,7 +131,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
@@ -194,8 +194,9 @@ def main():
         "dtype": "u8",
         "data": "synthetic",
         "config": {
-            "workload": "'%s' %s scan over %.3f GiB synthetic ASCII lines per GPU (BASELINE.json configs[1])"
-                        % (args.pattern, args.engine.upper(), n / 2**30),
+            "workload": "'%s' %s scan over %.3f GiB synthetic ASCII lines per GPU%s"
+                        % (args.pattern, args.engine.upper(), n / 2**30,
+                           " (BASELINE.json configs[1])" if (args.pattern, args.engine, n) == ("[a:A-z:Z]", "dft", 1 << 30) else ""),
             "pattern": args.pattern, "engine": args.engine, "bytes_per_gpu": n, "output_bytes_per_gpu": m,
             "kernel": trre_amd.KERNEL_NAMES[info.kernel], "table_rows": info.table_rows,
             "parallelism": "line-sharded x%d, no collective" % world,

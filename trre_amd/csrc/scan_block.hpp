@@ -423,7 +423,9 @@ TRRE_HD int64_t line_start_global(const ScanArgs& a, int64_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #define TRRE_WAVE_ANY(x) __any(x)
 #define TRRE_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)   // keep the scheduler from interleaving blocks
+#define TRRE_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
 #else
+#define TRRE_NT_STORE(v, p) (*(p) = (v))
 #define TRRE_WAVE_ANY(x) (x)
 #define TRRE_SCHED_FENCE() ((void)0)
 #endif
@@ -943,8 +945,16 @@ TRRE_HD void stream_lpw_lane(const ScanArgs& a, const LpwView& T, uint32_t n_cls
                 if (!full) { lpw_store_partial(L.out, L.rv - 16, outq, L.rfs, L.rend); stored = true; }
             }
             if (!stored) {
+                if (a.ablate & 32u) {                         // experiment: non-temporal piece stores
 #pragma unroll
-                for (int q = 0; q < 4; ++q) *reinterpret_cast<U128*>(L.out + L.rv - 16 + 16 * q) = outq[q];
+                    for (int q = 0; q < 4; ++q) {
+                        uint32_t* d = reinterpret_cast<uint32_t*>(L.out + L.rv - 16 + 16 * q);
+                        TRRE_NT_STORE(outq[q].x, d); TRRE_NT_STORE(outq[q].y, d + 1); TRRE_NT_STORE(outq[q].z, d + 2); TRRE_NT_STORE(outq[q].w, d + 3);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<U128*>(L.out + L.rv - 16 + 16 * q) = outq[q];
+                }
             }
         }
         L.advance();
