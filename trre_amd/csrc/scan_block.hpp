@@ -682,7 +682,7 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint8_t c = (uint8_t)(w >> (8 * j));
-                const uint64_t e = T.ent[row + kk[j]];
+                const uint64_t e = str_entry(T, row + kk[j]);
                 const uint32_t elo = (uint32_t)e, ehi = (uint32_t)(e >> 32);
                 const uint32_t ol = str_olen(elo), cc = (elo >> 27) & 1u;
                 uint32_t n = ol + cc;

@@ -333,8 +333,10 @@ __global__ __launch_bounds__(G::THREADS) void k_stream_emit(ScanArgs a) {
 // ------------------------------------------------------------------------------------------
 // Direct stream kernels: no tile, one long sub-range per lane (see stream_direct_lane).
 constexpr int kDirectThreads = 256;
-constexpr int kDirectEntBytes = 2048;      // table rows in LDS when they fit
+constexpr int kDirectEntBytes = 2048;      // table rows in LDS when they all fit
+constexpr int kDirectHotBytes = 12288;     // otherwise: the shallow states' rows
 constexpr int kDirectLds = 256 + kDirectEntBytes + kDirectThreads * kRingStride + 64;
+constexpr int kDirectLdsHot = 256 + kDirectHotBytes + kDirectThreads * kRingStride + 64;
 
 template <bool kLdsEnt>
 __device__ __forceinline__ StreamView direct_stage(const ScanArgs& a, uint8_t* smem) {
@@ -345,11 +347,23 @@ __device__ __forceinline__ StreamView direct_stage(const ScanArgs& a, uint8_t* s
         uint64_t* d = reinterpret_cast<uint64_t*>(smem + 256);
         for (int k = threadIdx.x; k < (int)(h.ent_bytes / 8); k += kDirectThreads) d[k] = e[k];
     }
-    __syncthreads();
+    const int tab = kLdsEnt ? kDirectEntBytes : kDirectHotBytes;
     StreamView T;
+    if (!kLdsEnt) {
+        const uint64_t* e = reinterpret_cast<const uint64_t*>(a.blob + h.off_ent);
+        uint64_t* d = reinterpret_cast<uint64_t*>(smem + 256);
+        const int rows = kDirectHotBytes / 8 / (int)h.n_cls;        // whole rows only
+        int n = rows * (int)h.n_cls;
+        if (n > (int)(h.ent_bytes / 8)) n = (int)(h.ent_bytes / 8);
+        for (int k = threadIdx.x; k < n; k += kDirectThreads) d[k] = e[k];
+        T.ent_hot = d;
+        T.hot_limit = (uint32_t)n;
+    }
+    __syncthreads();
     T.cls = smem;
     T.ent = kLdsEnt ? reinterpret_cast<const uint64_t*>(smem + 256) : reinterpret_cast<const uint64_t*>(a.blob + h.off_ent);
     T.pool = a.blob + h.off_pool;
+    (void)tab;
     return T;
 }
 
@@ -358,14 +372,16 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_direct(ScanArgs a, in
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const StreamView T = direct_stage<kLdsEnt>(a, smem);
     const uint32_t n_cls = reinterpret_cast<const StreamBlobHeader*>(a.blob)->n_cls;
-    uint8_t* ring = smem + 256 + kDirectEntBytes + threadIdx.x * kRingStride;
+    constexpr int kTab = kLdsEnt ? kDirectEntBytes : kDirectHotBytes;
+    constexpr int kLds = kLdsEnt ? kDirectLds : kDirectLdsHot;
+    uint8_t* ring = smem + 256 + kTab + threadIdx.x * kRingStride;
     const int64_t lane = (int64_t)blockIdx.x * kDirectThreads + threadIdx.x;
     DirectLane L;
     uint32_t st = 0;
     uint64_t base = 0;
     if (kMode == 2) {
         // lane offsets: workgroup-wide exclusive scan of the counts from the count launch
-        uint32_t* wpart = reinterpret_cast<uint32_t*>(smem + kDirectLds - 64);
+        uint32_t* wpart = reinterpret_cast<uint32_t*>(smem + kLds - 64);
         const uint32_t mine = a.lane_counts[lane];
         const uint32_t incl = wave_scan_incl(mine);
         if ((threadIdx.x & (kWave - 1)) == kWave - 1) wpart[threadIdx.x / kWave] = incl;
@@ -380,7 +396,7 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_direct(ScanArgs a, in
     }
     stream_direct_lane<kMode>(a, T, n_cls, lane, lane_bytes, ring, base, L, st);
     if (kMode == 1) {
-        uint64_t* part = reinterpret_cast<uint64_t*>(smem + kDirectLds - 64);
+        uint64_t* part = reinterpret_cast<uint64_t*>(smem + kLds - 64);
         if (L.count > 0xffffffffull) { st |= kStCapacity; L.count = 0xffffffffull; }
         a.lane_counts[lane] = (uint32_t)L.count;
         const uint64_t wsum = wave_sum(L.count);
@@ -630,7 +646,7 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_redo(ScanArgs a, int6
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const StreamView T = direct_stage<kLdsEnt>(a, smem);
     const uint32_t n_cls = reinterpret_cast<const StreamBlobHeader*>(a.blob)->n_cls;
-    uint8_t* ring = smem + 256 + kDirectEntBytes + threadIdx.x * kRingStride;
+    uint8_t* ring = smem + 256 + (kLdsEnt ? kDirectEntBytes : kDirectHotBytes) + threadIdx.x * kRingStride;
     // every listed lane is split into 64-byte sub-lanes (same ownership rule, same positional
     // output) so that the few redone lanes do not serialise a whole sub-range each
     const int64_t sub = lane_bytes / 64;
@@ -657,13 +673,13 @@ void launch_lpw_kernel(bool ent_in_lds, bool direct_ent_in_lds, const ScanArgs& 
     }
     const bool ring_lds = reinterpret_cast<const void*>(a.blob) != nullptr && direct_ent_in_lds;
     if (ring_lds) hipLaunchKernelGGL((k_stream_redo<true>), dim3(64), dim3(kDirectThreads), kDirectLds, s, a, lane_bytes);
-    else hipLaunchKernelGGL((k_stream_redo<false>), dim3(64), dim3(kDirectThreads), kDirectLds, s, a, lane_bytes);
+    else hipLaunchKernelGGL((k_stream_redo<false>), dim3(64), dim3(kDirectThreads), kDirectLdsHot, s, a, lane_bytes);
 }
 
 template <int kMode>
 void launch_direct_t(bool ent_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, hipStream_t s) {
     if (ent_lds) hipLaunchKernelGGL((k_stream_direct<kMode, true>), dim3((unsigned)n_blocks), dim3(kDirectThreads), kDirectLds, s, a, lane_bytes);
-    else hipLaunchKernelGGL((k_stream_direct<kMode, false>), dim3((unsigned)n_blocks), dim3(kDirectThreads), kDirectLds, s, a, lane_bytes);
+    else hipLaunchKernelGGL((k_stream_direct<kMode, false>), dim3((unsigned)n_blocks), dim3(kDirectThreads), kDirectLdsHot, s, a, lane_bytes);
 }
 int direct_ent_lds_bytes() { return kDirectEntBytes; }
 int direct_block_threads() { return kDirectThreads; }
