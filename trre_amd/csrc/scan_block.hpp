@@ -698,14 +698,21 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
                                 for (uint32_t i = 1; i < ol; ++i) { ring[(o + i) & 63u] = (uint8_t)x; x >>= 8; }
                                 if (cc) ring[(o + ol) & 63u] = c;
                             } else {
-                                // long replacement text: empty the ring, then write straight to HBM
-                                direct_flush<true>(obase, ring, of, o);
                                 const uint8_t* r = T.pool + ehi;
                                 const uint32_t len = str_pool_len(T, ehi);
-                                for (uint32_t i = 0; i < len; ++i) obase[o + i] = r[4 + i];
-                                if (cc) obase[o + len] = c;
+                                if (len <= 40u) {
+                                    // replacement text of ordinary length goes through the ring like any output
+                                    if (o - of + len + 1u > 60u) direct_flush<false>(obase, ring, of, o);
+                                    for (uint32_t i = 0; i < len; ++i) ring[(o + i) & 63u] = r[4 + i];
+                                    if (cc) ring[(o + len) & 63u] = c;
+                                } else {
+                                    // very long replacement text: empty the ring, then write straight to HBM
+                                    direct_flush<true>(obase, ring, of, o);
+                                    for (uint32_t i = 0; i < len; ++i) obase[o + i] = r[4 + i];
+                                    if (cc) obase[o + len] = c;
+                                    of = o + len + cc;
+                                }
                                 n = len + cc;
-                                of = o + n;
                             }
                         }
                     }
