@@ -703,7 +703,11 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
                                 if (len <= 40u) {
                                     // replacement text of ordinary length goes through the ring like any output
                                     if (o - of + len + 1u > 60u) direct_flush<false>(obase, ring, of, o);
-                                    for (uint32_t i = 0; i < len; ++i) ring[(o + i) & 63u] = r[4 + i];
+                                    for (uint32_t i = 0; i < len; i += 4) {                  // dword reads from the pool record
+                                        uint32_t x = *reinterpret_cast<const uint32_t*>(r + 4 + i);
+                                        const uint32_t m = len - i < 4u ? len - i : 4u;
+                                        for (uint32_t b2 = 0; b2 < m; ++b2) { ring[(o + i + b2) & 63u] = (uint8_t)x; x >>= 8; }
+                                    }
                                     if (cc) ring[(o + len) & 63u] = c;
                                 } else {
                                     // very long replacement text: empty the ring, then write straight to HBM

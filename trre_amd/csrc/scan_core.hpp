@@ -204,8 +204,7 @@ constexpr uint32_t kStrCopyC = 1u << 27, kStrEol = 1u << 28;
 TRRE_HD uint32_t str_olen(uint32_t lo) { return (lo >> 24) & 7u; }
 TRRE_HD uint32_t str_next(uint32_t lo) { return lo & 0xffffffu; }
 TRRE_HD uint32_t str_pool_len(const StreamView& T, uint32_t hi) {
-    const uint8_t* r = T.pool + hi;
-    return (uint32_t)r[0] | (uint32_t)r[1] << 8 | (uint32_t)r[2] << 16 | (uint32_t)r[3] << 24;
+    return *reinterpret_cast<const uint32_t*>(T.pool + hi);      // records are 4-byte aligned: {u32 len, bytes}
 }
 // number of bytes one transition emits
 TRRE_HD uint32_t str_count(const StreamView& T, uint32_t lo, uint32_t hi) {

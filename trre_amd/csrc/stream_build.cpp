@@ -333,6 +333,8 @@ private:
                 }
             }
         }
+        while (t.pool.size() % 4) t.pool.push_back(0);
+        for (int k = 0; k < 4; ++k) t.pool.push_back(0);   // dword reads of a record's tail stay inside the pool
         t.ok = true;
         if (lp) build_window_form(t, rep);
         if (lp) t.flags |= kFlagLengthPreserving;
