@@ -800,20 +800,19 @@ TRRE_HD void lpw_redo(const ScanArgs& a, int64_t lane) {
     a.redo[1 + k] = (uint32_t)lane;
 }
 
-// slow path of the piece store: only offsets in [fs, end) belong to this lane
-TRRE_HD void store_dword_partial(uint8_t* out, int32_t pos, uint32_t w, int32_t fs, int32_t end) {
+// head of a lane's first piece: blocks below the first line start are not this lane's, the block
+// that contains it is written bytewise from there on
+TRRE_HD void lpw_store_block_from(uint8_t* out, int32_t r0, const U128& q, int32_t fs, bool aligned) {
+    if (r0 + 16 <= fs) return;
+    if (r0 >= fs && aligned) { *reinterpret_cast<U128*>(out + r0) = q; return; }
+    const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (pos + k >= fs && pos + k < end) out[pos + k] = (uint8_t)(w >> (8 * k));
+    for (int i = 0; i < 16; ++i)
+        if (r0 + i >= fs) out[r0 + i] = (uint8_t)(wd[i >> 2] >> (8 * (i & 3)));
 }
-TRRE_HD void lpw_store_partial(uint8_t* out, int32_t r0, const U128 (&outq)[4], int32_t fs, int32_t end) {
+TRRE_HD void lpw_store_partial(uint8_t* out, int32_t r0, const U128 (&outq)[4], int32_t fs, bool aligned) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        store_dword_partial(out, r0 + 16 * q, outq[q].x, fs, end);
-        store_dword_partial(out, r0 + 16 * q + 4, outq[q].y, fs, end);
-        store_dword_partial(out, r0 + 16 * q + 8, outq[q].z, fs, end);
-        store_dword_partial(out, r0 + 16 * q + 12, outq[q].w, fs, end);
-    }
+    for (int q = 0; q < 4; ++q) lpw_store_block_from(out, r0 + 16 * q, outq[q], fs, aligned);
 }
 
 // Positions inside the hot loop are 32-bit offsets from the lane's sub-range start.
@@ -837,11 +836,13 @@ TRRE_HD void lpw_block(const LpwView& T, const U128& cur, int32_t rv, int32_t rh
             row = e.x;
             seen |= e.y;
             if (kCheckEnd) {
-                // a record end at or beyond the end of the sub-range finishes the lane (branch-free)
+                // The first record end at or beyond the end of the sub-range is where the lane's own lines
+                // end (branch-free).  The automaton simply keeps going to the end of the piece: what it
+                // emits there is the head of the next lane's first line, byte for byte what that lane
+                // writes itself, so the last piece can be stored whole.
                 const int32_t p1 = rv + 4 * d + j + 1;
                 const uint32_t hit = ((e.y >> 5) & 1u) & (uint32_t)(p1 >= rhi) & (done ^ 1u);
                 rend = hit ? p1 : rend;
-                row = hit ? done_row : row;
                 done |= hit;
             }
             w >>= 8;
@@ -924,7 +925,7 @@ struct LpwLane {
         if (rv > rlimit) { lpw_redo(a, lane); active = false; return false; }   // a very long last line: hand over
         if (rv + 64 < rhi) lpw_piece<false>(T, cur, rv, rhi, done_row, D, row, win, seen, Rprev, carry, outq, done, rend);
         else lpw_piece<true>(T, cur, rv, rhi, done_row, D, row, win, seen, Rprev, carry, outq, done, rend);
-        full = aligned && rv - 16 >= rfs && rv + 48 <= rend;
+        full = aligned && rv - 16 >= rfs;                        // only the head of the first piece is not this lane's
         return true;
     }
     // after the piece's output has been stored
@@ -943,25 +944,25 @@ TRRE_HD void stream_lpw_lane(const ScanArgs& a, const LpwView& T, uint32_t n_cls
 #pragma unroll
     for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const U128*>(L.in + L.rv + 16 * q);
     while (L.active) {
-        if (L.rv <= L.rlimit) {
+        // unconditional prefetch (the offset is clamped instead of predicated, so that the wait the
+        // compiler places before the first use of `cur` can leave these four loads outstanding)
+        const int32_t rp = L.rv <= L.rlimit ? L.rv + 64 : L.rlimit + 64;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) nxt[q] = *reinterpret_cast<const U128*>(L.in + L.rv + 64 + 16 * q);
-        }
+        for (int q = 0; q < 4; ++q) nxt[q] = *reinterpret_cast<const U128*>(L.in + rp + 16 * q);
         U128 outq[4];
         bool full;
         if (!L.piece(a, T, lane, cur, outq, full)) break;
         if (!(a.ablate & 1u)) {
             bool stored = false;
             if (TRRE_WAVE_ANY(!full)) {
-                if (!full) { lpw_store_partial(L.out, L.rv - 16, outq, L.rfs, L.rend); stored = true; }
+                if (!full) { if (!(a.ablate & 64u)) lpw_store_partial(L.out, L.rv - 16, outq, L.rfs, L.aligned); stored = true; }
             }
             if (!stored) {
-                if (a.ablate & 32u) {                         // experiment: non-temporal piece stores
+                if (a.ablate & 8u) {                          // experiment (timing only): coalesced alias addresses
+                    const int64_t wave_lo = (lane & ~(int64_t)63) * lane_bytes;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        uint32_t* d = reinterpret_cast<uint32_t*>(L.out + L.rv - 16 + 16 * q);
-                        TRRE_NT_STORE(outq[q].x, d); TRRE_NT_STORE(outq[q].y, d + 1); TRRE_NT_STORE(outq[q].z, d + 2); TRRE_NT_STORE(outq[q].w, d + 3);
-                    }
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<U128*>(a.out_v0 + wave_lo + ((int64_t)(L.rv >> 6) * 4 + q) * 1024 + (lane & 63) * 16) = outq[q];
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) *reinterpret_cast<U128*>(L.out + L.rv - 16 + 16 * q) = outq[q];

@@ -589,7 +589,7 @@ __global__ __launch_bounds__(kLpwThreads) void k_stream_lpw_coop(ScanArgs a, int
         // ---- C. transposed store of the pieces that are entirely their lane's; the others store bytewise
         {
             const bool coop = ok && full && !(a.ablate & 1u);
-            if (ok && !full && !(a.ablate & 1u)) lpw_store_partial(L.out, L.rv - 16, outq, L.rfs, L.rend);
+            if (ok && !full && !(a.ablate & 1u)) lpw_store_partial(L.out, L.rv - 16, outq, L.rfs, L.aligned);
             *reinterpret_cast<uint64_t*>(my_row + 64) = coop ? reinterpret_cast<uint64_t>(L.out + L.rv - 16) : 0ull;
             if (coop) {
 #pragma unroll
