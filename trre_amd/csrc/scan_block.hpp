@@ -424,8 +424,10 @@ TRRE_HD int64_t line_start_global(const ScanArgs& a, int64_t v) {
 #define TRRE_WAVE_ANY(x) __any(x)
 #define TRRE_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)   // keep the scheduler from interleaving blocks
 #define TRRE_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
+#define TRRE_TOUCH(x) asm volatile("" ::"v"(x))                // force x to be materialised here
 #else
 #define TRRE_NT_STORE(v, p) (*(p) = (v))
+#define TRRE_TOUCH(x) ((void)(x))
 #define TRRE_WAVE_ANY(x) (x)
 #define TRRE_SCHED_FENCE() ((void)0)
 #endif
@@ -943,6 +945,15 @@ TRRE_HD void stream_lpw_lane(const ScanArgs& a, const LpwView& T, uint32_t n_cls
     U128 cur[4], nxt[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const U128*>(L.in + L.rv + 16 * q);
+    {
+        // Wait for the first piece HERE, outside the loop.  Otherwise the compiler's wait for `cur`
+        // sits at its first use inside the loop, after the prefetch loads have been issued, and
+        // (the counter being in order) also drains the previous iteration's stores every time round.
+        uint32_t t = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t ^= cur[q].x ^ cur[q].y ^ cur[q].z ^ cur[q].w;
+        TRRE_TOUCH(t);
+    }
     while (L.active) {
         // unconditional prefetch (the offset is clamped instead of predicated, so that the wait the
         // compiler places before the first use of `cur` can leave these four loads outstanding)
