@@ -15,7 +15,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtrre_mi355x.so")
+LIB_PATH = os.environ.get("TRRE_LIB_PATH") or os.path.join(_HERE, "lib", "libtrre_mi355x.so")   # override: A/B builds only
 
 ENGINE_NFT, ENGINE_DFT = 0, 1
 _ENGINES = {"nft": ENGINE_NFT, "dft": ENGINE_DFT, ENGINE_NFT: ENGINE_NFT, ENGINE_DFT: ENGINE_DFT}

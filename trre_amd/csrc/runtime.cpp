@@ -281,7 +281,9 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
     //     form, direct walker otherwise
     static const int stream_impl = getenv("TRRE_STREAM_IMPL") ? atoi(getenv("TRRE_STREAM_IMPL")) : 2;
     static const int64_t lane_bytes_env = getenv("TRRE_LANE_BYTES") ? atoll(getenv("TRRE_LANE_BYTES")) : 0;
-    const int64_t lane_bytes = lane_bytes_env > 0 ? (lane_bytes_env + 63) / 64 * 64 : (family == TRRE_KERNEL_STREAM_LP ? 1024 : 2048);
+    const bool window = is_stream(family) && stream_impl == 2 && family == TRRE_KERNEL_STREAM_LP && p->stt.lpw_ok;
+    const int64_t lane_bytes = lane_bytes_env > 0 ? (lane_bytes_env + 127) / 128 * 128
+                                                  : (family == TRRE_KERNEL_STREAM_LP && !window ? 1024 : 2048);
     const bool direct = is_stream(family) && stream_impl >= 1;
     const bool direct_ent_lds = p->stt.ok && p->stt.ent.size() * 8 <= (size_t)direct_ent_lds_bytes();
     if (direct) n_chunks = (args.vend + lane_bytes * direct_block_threads() - 1) / (lane_bytes * direct_block_threads());
@@ -303,7 +305,7 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
         launch_bytemap(args, stream);
     } else if (family == TRRE_KERNEL_TILE_LP) {
         launch_tile_kernel(0, p->engine, p->mask_bytes, args, n_chunks, stream);
-    } else if (is_stream(family) && stream_impl == 2 && family == TRRE_KERNEL_STREAM_LP && p->stt.lpw_ok) {
+    } else if (window) {
         const int64_t n_lanes = (args.vend + lane_bytes - 1) / lane_bytes;
         if (st->redo_lanes < n_lanes) {
             if (st->d_redo) (void)hipFree(st->d_redo);

@@ -28,6 +28,10 @@ namespace trre {
 
 struct alignas(16) U128 { uint32_t x, y, z, w; };
 
+#ifndef TRRE_LPW_BLOCKS
+#define TRRE_LPW_BLOCKS 8
+#endif
+
 template <int THREADS_, int CHUNK_, int HALO_>
 struct Geometry {
     static constexpr int THREADS = THREADS_;
@@ -812,11 +816,6 @@ TRRE_HD void lpw_store_block_from(uint8_t* out, int32_t r0, const U128& q, int32
     for (int i = 0; i < 16; ++i)
         if (r0 + i >= fs) out[r0 + i] = (uint8_t)(wd[i >> 2] >> (8 * (i & 3)));
 }
-TRRE_HD void lpw_store_partial(uint8_t* out, int32_t r0, const U128 (&outq)[4], int32_t fs, bool aligned) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) lpw_store_block_from(out, r0 + 16 * q, outq[q], fs, aligned);
-}
-
 // Positions inside the hot loop are 32-bit offsets from the lane's sub-range start.
 template <bool kCheckEnd>
 TRRE_HD void lpw_block(const LpwView& T, const U128& cur, int32_t rv, int32_t rhi, uint32_t done_row, uint32_t& row, uint32_t& win,
@@ -854,24 +853,27 @@ TRRE_HD void lpw_block(const LpwView& T, const U128& cur, int32_t rv, int32_t rh
     }
 }
 
+constexpr int kLpwBlocks = TRRE_LPW_BLOCKS;       // 16-byte blocks per piece (4 = 64-byte pieces, 8 = whole 128-byte lines)
+constexpr int kLpwPiece = 16 * kLpwBlocks;
+
 template <bool kCheckEnd>
-TRRE_HD void lpw_piece(const LpwView& T, const U128 (&cur)[4], int32_t rv, int32_t rhi, uint32_t done_row, uint32_t D, uint32_t& row,
-                       uint32_t& win, uint32_t& seen, uint32_t& Rprev, U128& carry, U128 (&outq)[4], uint32_t& done, int32_t& rend) {
-    // outq[0] = block rv-16 (needs this piece's first released dword), outq[1..3] = blocks rv, rv+16, rv+32;
-    // block rv+48 stays in `carry` until the next piece
+TRRE_HD void lpw_piece(const LpwView& T, const U128 (&cur)[kLpwBlocks], int32_t rv, int32_t rhi, uint32_t done_row, uint32_t D, uint32_t& row,
+                       uint32_t& win, uint32_t& seen, uint32_t& Rprev, U128& carry, U128 (&outq)[kLpwBlocks], uint32_t& done, int32_t& rend) {
+    // outq[0] = block rv-16 (needs this piece's first released dword), outq[1..] = blocks rv, rv+16, ...;
+    // the piece's last block stays in `carry` until the next piece
     uint32_t Rm[4];
     lpw_block<kCheckEnd>(T, cur[0], rv, rhi, done_row, row, win, seen, Rm, done, rend);
     outq[0] = carry;
     outq[0].w = alignbyte_b32(Rm[0], Rprev, D);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < kLpwBlocks; ++q) {
         U128 o;
         o.x = alignbyte_b32(Rm[1], Rm[0], D);
         o.y = alignbyte_b32(Rm[2], Rm[1], D);
         o.z = alignbyte_b32(Rm[3], Rm[2], D);
         o.w = 0;
         const uint32_t r3 = Rm[3];
-        if (q < 3) {
+        if (q < kLpwBlocks - 1) {
             lpw_block<kCheckEnd>(T, cur[q + 1], rv + 16 * (q + 1), rhi, done_row, row, win, seen, Rm, done, rend);
             o.w = alignbyte_b32(Rm[0], r3, D);
             outq[q + 1] = o;
@@ -882,7 +884,7 @@ TRRE_HD void lpw_piece(const LpwView& T, const U128 (&cur)[4], int32_t rv, int32
     }
 }
 
-// Per-lane state of the window walk, split from its I/O so that the kernel can move the 64-byte
+// Per-lane state of the window walk, split from its I/O so that the kernel can move the
 // pieces cooperatively (transposed through LDS: adjacent lanes touch adjacent 16-byte blocks) while
 // the host shim and the fallback use plain per-lane loads and stores.
 struct LpwLane {
@@ -896,12 +898,12 @@ struct LpwLane {
     TRRE_HD void init(const ScanArgs& a, const LpwView& T, uint32_t n_cls, int64_t lane, int64_t lane_bytes) {
         active = false;
         seen = 0;
-        const int64_t lo = lane * lane_bytes;            // lane_bytes is a multiple of 64
+        const int64_t lo = lane * lane_bytes;            // lane_bytes is a multiple of the piece size
         int64_t hi = lo + lane_bytes;
         if (hi > a.vend) hi = a.vend;
         if (lo >= hi) return;
         // keep slack to both ends of the input; lanes that need the edge fix-ups are redone
-        if (lo < a.vbeg + 64 || hi + 192 > a.vend) { lpw_redo(a, lane); return; }
+        if (lo < a.vbeg + kLpwPiece || hi + 3 * kLpwPiece > a.vend) { lpw_redo(a, lane); return; }
         const int64_t fs = first_line_start_global(a, lo, hi);
         if (fs >= hi) return;                                     // no line starts in this sub-range
         D = T.delay & 3u;
@@ -911,78 +913,75 @@ struct LpwLane {
         out = a.out_v0 + lo;
         rhi = (int32_t)(hi - lo);
         rfs = (int32_t)(fs - lo);
-        const int64_t room = a.vend - lo - 192;                   // never run into the end of the input,
+        const int64_t room = a.vend - lo - 3 * kLpwPiece;         // never run into the end of the input,
         rlimit = room < 0x40000000 ? (int32_t)room : 0x40000000;  // and keep 32-bit offsets exact
-        rv = rfs & ~63;
+        rv = rfs & ~(kLpwPiece - 1);
         row = rv == rfs ? 0u : kSkipState * n_cls * 16u;          // the byte before fs is '\n': SKIP reaches root exactly at fs
         win = 0; Rprev = 0; done = 0;
         rend = 0x7fffffff;
         carry = U128{};
         active = true;
     }
-    // one 64-byte piece at offset rv: outq = output for offsets [rv - 16, rv + 48), of which only
-    // [rfs, rend) is this lane's (`full` = all of it, 16-byte aligned).  Returns false when the lane
-    // must stop without storing (handed over to the redo launch).
-    TRRE_HD bool piece(const ScanArgs& a, const LpwView& T, int64_t lane, const U128 (&cur)[4], U128 (&outq)[4], bool& full) {
+    // one piece at offset rv: outq = output for offsets [rv - 16, rv + piece - 16), of which only those
+    // at or above rfs are this lane's (`full` = all of them, 16-byte aligned).  Returns false when the
+    // lane must stop without storing (handed over to the redo launch).
+    TRRE_HD bool piece(const ScanArgs& a, const LpwView& T, int64_t lane, const U128 (&cur)[kLpwBlocks], U128 (&outq)[kLpwBlocks], bool& full) {
         if (rv > rlimit) { lpw_redo(a, lane); active = false; return false; }   // a very long last line: hand over
-        if (rv + 64 < rhi) lpw_piece<false>(T, cur, rv, rhi, done_row, D, row, win, seen, Rprev, carry, outq, done, rend);
+        if (rv + kLpwPiece < rhi) lpw_piece<false>(T, cur, rv, rhi, done_row, D, row, win, seen, Rprev, carry, outq, done, rend);
         else lpw_piece<true>(T, cur, rv, rhi, done_row, D, row, win, seen, Rprev, carry, outq, done, rend);
         full = aligned && rv - 16 >= rfs;                        // only the head of the first piece is not this lane's
         return true;
     }
     // after the piece's output has been stored
     TRRE_HD void advance() {
-        if (done && rend <= rv + 48) active = false;              // every offset below `rend` has been stored
-        else rv += 64;
+        if (done && rend <= rv + kLpwPiece - 16) active = false;  // every offset below `rend` has been stored
+        else rv += kLpwPiece;
     }
 };
 
-// plain per-lane I/O (host shim; also the non-cooperative device path)
+// plain per-lane I/O (host shim; also the default device path)
 TRRE_HD void stream_lpw_lane(const ScanArgs& a, const LpwView& T, uint32_t n_cls, int64_t lane, int64_t lane_bytes, uint32_t& status) {
     LpwLane L;
     L.init(a, T, n_cls, lane, lane_bytes);
     if (!L.active) return;
-    U128 cur[4], nxt[4];
+    U128 cur[kLpwBlocks], nxt[kLpwBlocks];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const U128*>(L.in + L.rv + 16 * q);
+    for (int q = 0; q < kLpwBlocks; ++q) cur[q] = *reinterpret_cast<const U128*>(L.in + L.rv + 16 * q);
     {
         // Wait for the first piece HERE, outside the loop.  Otherwise the compiler's wait for `cur`
         // sits at its first use inside the loop, after the prefetch loads have been issued, and
         // (the counter being in order) also drains the previous iteration's stores every time round.
         uint32_t t = 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) t ^= cur[q].x ^ cur[q].y ^ cur[q].z ^ cur[q].w;
+        for (int q = 0; q < kLpwBlocks; ++q) t ^= cur[q].x ^ cur[q].y ^ cur[q].z ^ cur[q].w;
         TRRE_TOUCH(t);
     }
     while (L.active) {
         // unconditional prefetch (the offset is clamped instead of predicated, so that the wait the
-        // compiler places before the first use of `cur` can leave these four loads outstanding)
-        const int32_t rp = L.rv <= L.rlimit ? L.rv + 64 : L.rlimit + 64;
+        // compiler places before the first use of `cur` can leave these loads outstanding)
+        const int32_t rp = L.rv <= L.rlimit ? L.rv + kLpwPiece : L.rlimit + kLpwPiece;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) nxt[q] = *reinterpret_cast<const U128*>(L.in + rp + 16 * q);
-        U128 outq[4];
+        for (int q = 0; q < kLpwBlocks; ++q) nxt[q] = *reinterpret_cast<const U128*>(L.in + rp + 16 * q);
+        U128 outq[kLpwBlocks];
         bool full;
         if (!L.piece(a, T, lane, cur, outq, full)) break;
         if (!(a.ablate & 1u)) {
             bool stored = false;
             if (TRRE_WAVE_ANY(!full)) {
-                if (!full) { if (!(a.ablate & 64u)) lpw_store_partial(L.out, L.rv - 16, outq, L.rfs, L.aligned); stored = true; }
+                if (!full) {
+#pragma unroll
+                    for (int q = 0; q < kLpwBlocks; ++q) lpw_store_block_from(L.out, L.rv - 16 + 16 * q, outq[q], L.rfs, L.aligned);
+                    stored = true;
+                }
             }
             if (!stored) {
-                if (a.ablate & 8u) {                          // experiment (timing only): coalesced alias addresses
-                    const int64_t wave_lo = (lane & ~(int64_t)63) * lane_bytes;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        *reinterpret_cast<U128*>(a.out_v0 + wave_lo + ((int64_t)(L.rv >> 6) * 4 + q) * 1024 + (lane & 63) * 16) = outq[q];
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) *reinterpret_cast<U128*>(L.out + L.rv - 16 + 16 * q) = outq[q];
-                }
+                for (int q = 0; q < kLpwBlocks; ++q) *reinterpret_cast<U128*>(L.out + L.rv - 16 + 16 * q) = outq[q];
             }
         }
         L.advance();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+        for (int q = 0; q < kLpwBlocks; ++q) cur[q] = nxt[q];
     }
     if (L.seen & kLpwNul) status |= kStNul;
 }

@@ -533,6 +533,7 @@ void launch_stream_t(int which, const ScanArgs& a, int64_t n_chunks, hipStream_t
 // positional-window kernel (length-preserving stream tables in window form)
 constexpr int kLpwThreads = 256;
 constexpr int kLpwEntBytes = 8192;
+#if TRRE_LPW_BLOCKS == 4
 // Cooperative piece I/O of the window kernel.  Each lane works on its own 64-byte piece, but the
 // pieces of a wave's 64 lanes lie lane_bytes apart, so per-lane 16-byte accesses would be 64
 // separate cache lines per instruction.  Instead every lane publishes the address of its piece in
@@ -589,7 +590,10 @@ __global__ __launch_bounds__(kLpwThreads) void k_stream_lpw_coop(ScanArgs a, int
         // ---- C. transposed store of the pieces that are entirely their lane's; the others store bytewise
         {
             const bool coop = ok && full && !(a.ablate & 1u);
-            if (ok && !full && !(a.ablate & 1u)) lpw_store_partial(L.out, L.rv - 16, outq, L.rfs, L.aligned);
+            if (ok && !full && !(a.ablate & 1u)) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) lpw_store_block_from(L.out, L.rv - 16 + 16 * q, outq[q], L.rfs, L.aligned);
+            }
             *reinterpret_cast<uint64_t*>(my_row + 64) = coop ? reinterpret_cast<uint64_t>(L.out + L.rv - 16) : 0ull;
             if (coop) {
 #pragma unroll
@@ -617,6 +621,8 @@ __global__ __launch_bounds__(kLpwThreads) void k_stream_lpw_coop(ScanArgs a, int
     uint32_t st = (L.seen & kLpwNul) ? kStNul : 0u;
     if (st) atomicOr(a.status, st);
 }
+
+#endif  // TRRE_LPW_BLOCKS == 4
 
 // plain per-lane piece I/O (four 16-byte loads / stores per lane per piece)
 template <bool kLdsEnt>
@@ -664,10 +670,13 @@ void launch_lpw_kernel(bool ent_in_lds, bool direct_ent_in_lds, const ScanArgs& 
     const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
     const dim3 grid((unsigned)((n_lanes + kLpwThreads - 1) / kLpwThreads));
     static const bool coop = getenv("TRRE_LPW_COOP") && atoi(getenv("TRRE_LPW_COOP")) != 0;
+#if TRRE_LPW_BLOCKS == 4
     if (coop) {
         if (ent_in_lds) hipLaunchKernelGGL((k_stream_lpw_coop<true>), grid, dim3(kLpwThreads), 0, s, a, lane_bytes);
         else hipLaunchKernelGGL((k_stream_lpw_coop<false>), grid, dim3(kLpwThreads), 0, s, a, lane_bytes);
-    } else {
+    } else
+#endif
+    {
         if (ent_in_lds) hipLaunchKernelGGL((k_stream_lpw<true>), grid, dim3(kLpwThreads), 0, s, a, lane_bytes);
         else hipLaunchKernelGGL((k_stream_lpw<false>), grid, dim3(kLpwThreads), 0, s, a, lane_bytes);
     }
