@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Run by tests/test_gpu_parity.py in a subprocess with TRRE_STREAM_IMPL / TRRE_LPW_COOP /
+"""Run by tests/test_gpu_parity.py in a subprocess with TRRE_STREAM_IMPL /
 TRRE_LANE_BYTES set: checks the alternative implementations of the stream kernel families
 against the oracle (the environment is read once per process by the library)."""
 import os

@@ -429,9 +429,11 @@ TRRE_HD int64_t line_start_global(const ScanArgs& a, int64_t v) {
 #define TRRE_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)   // keep the scheduler from interleaving blocks
 #define TRRE_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
 #define TRRE_TOUCH(x) asm volatile("" ::"v"(x))                // force x to be materialised here
+#define TRRE_PIN(x) asm volatile("" : "+v"(x))                 // x is computed by here (stops reassociation into late trees)
 #else
 #define TRRE_NT_STORE(v, p) (*(p) = (v))
 #define TRRE_TOUCH(x) ((void)(x))
+#define TRRE_PIN(x) ((void)0)
 #define TRRE_WAVE_ANY(x) (x)
 #define TRRE_SCHED_FENCE() ((void)0)
 #endif
@@ -985,6 +987,198 @@ TRRE_HD void stream_lpw_lane(const ScanArgs& a, const LpwView& T, uint32_t n_cls
     }
     if (L.seen & kLpwNul) status |= kStNul;
 }
+
+// =============================================================================================
+// Wave-tiled window kernel.
+//
+// Same walk as above (one lane per sub-range, one 16-byte table entry per input byte), but a lane
+// never touches global memory for its pieces.  Per-lane 16-byte accesses are one L2 request each
+// (the lanes of a wave are lane_bytes apart), and a lane's output line was written 16 bytes at a
+// time, with its 64-byte sectors completed by different instructions: the store path, not the walk,
+// was the limit.  Here the wave moves the 64-byte pieces of its 64 lanes together as 4 KiB tiles:
+// four adjacent lanes cover one piece, so a wave instruction touches 16 rows x 64 contiguous,
+// 64-byte aligned bytes.  The input tile goes straight from global memory to LDS
+// (global_load_lds_dwordx4: no staging registers); every lane takes its row into registers, at
+// which point the next tile is already requested into the same buffer.  Output blocks are
+// collected in a second tile whose rows are the aligned 64 bytes BEHIND the lane's position (the
+// output lags the input by the window delay, so the last block of a row is only known after the
+// first block of the next piece) and the wave stores that tile the way the input was loaded.
+//
+// Tile layout: row r (= lane r of the wave) at r * 64; logical block b of the row sits in physical
+// 16-byte slot b ^ ((r >> 1) & 3), which makes both the row-wise accesses of 8 consecutive lanes
+// and the slot-linear accesses of the tile moves conflict-free.  The LDS side of a direct load is
+// linear in the lane id, so the permutation is applied to the global address instead.
+// =============================================================================================
+constexpr int kWtBlocks = 4;
+constexpr int kWtPiece = 16 * kWtBlocks;
+constexpr int kWtTile = 64 * kWtPiece;             // one piece of every lane of a wave
+
+// byte classes of one dword
+TRRE_HD void lpw_classes(const LpwView& T, uint32_t w, uint32_t (&kk)[4]) {
+    kk[0] = T.cls[w & 0xffu]; kk[1] = T.cls[(w >> 8) & 0xffu]; kk[2] = T.cls[(w >> 16) & 0xffu]; kk[3] = T.cls[w >> 24];
+}
+
+// One 16-byte block like lpw_block, with the class lookups taken off the row chain: kk holds the
+// classes of the block's first dword on entry and those of next_w on return.
+template <bool kCheckEnd>
+TRRE_HD void wt_block(const LpwView& T, const U128& cur, uint32_t next_w, uint32_t (&kk)[4], int32_t rv, int32_t rhi, uint32_t& row,
+                      uint32_t& win, uint32_t& seen, uint32_t (&Rm)[4], uint32_t& done, int32_t& rend) {
+    const uint32_t wd[5] = {cur.x, cur.y, cur.z, cur.w, next_w};
+    uint32_t R = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        uint32_t w = wd[d];
+        const uint32_t kc[4] = {kk[0], kk[1], kk[2], kk[3]};
+        lpw_classes(T, wd[d + 1], kk);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const U128 e = *reinterpret_cast<const U128*>(reinterpret_cast<const uint8_t*>(T.ent) + row + (kc[j] << 4));
+            const uint32_t seq = perm_b32(w, e.z, e.w);
+            win |= seq << (e.y & 31u);
+            R = alignbit_b32(win, R, 8);
+            win >>= 8;
+            row = e.x;
+            seen |= e.y;
+            if (kCheckEnd) {      // see lpw_block
+                const int32_t p1 = rv + 4 * d + j + 1;
+                const uint32_t hit = ((e.y >> 5) & 1u) & (uint32_t)(p1 >= rhi) & (done ^ 1u);
+                rend = hit ? p1 : rend;
+                done |= hit;
+            }
+            w >>= 8;
+        }
+        Rm[d] = R;
+        // the running flags are not needed before the end of the piece; left alone the compiler turns
+        // their chains into trees evaluated there, with every entry's meta word live until then
+        TRRE_PIN(seen);
+        if (kCheckEnd) { TRRE_PIN(done); TRRE_PIN(rend); }
+        TRRE_SCHED_FENCE();
+    }
+}
+
+// a lane's row of a tile
+struct WtRow {
+    uint8_t* row;        // tile + r * 64
+    uint32_t swz16;      // ((r >> 1) & 3) << 4
+    TRRE_HD U128 load(int b) const { return *reinterpret_cast<const U128*>(row + ((uint32_t)(b << 4) ^ swz16)); }
+    TRRE_HD void store(int b, const U128& v) const { *reinterpret_cast<U128*>(row + ((uint32_t)(b << 4) ^ swz16)) = v; }
+};
+
+struct WtLane {
+    int64_t lo;
+    int32_t rhi, rfs, rlimit, rv, rend;
+    uint32_t D, row, win, seen, Rprev, done;
+    uint32_t kk[4];
+    U128 carry;          // the output block being assembled (its last dword needs the next block)
+    bool active;
+
+    TRRE_HD void init(const ScanArgs& a, const LpwView& T, uint32_t n_cls, int64_t lane, int64_t lane_bytes) {
+        active = false;
+        seen = 0; rv = 0; rfs = 0;
+        lo = lane * lane_bytes;                          // lane_bytes is a multiple of the piece size
+        int64_t hi = lo + lane_bytes;
+        if (hi > a.vend) hi = a.vend;
+        if (lo >= hi) return;
+        // keep slack to both ends of the input; lanes that need the edge fix-ups are redone
+        if (lo < a.vbeg + kWtPiece || hi + 3 * kWtPiece > a.vend) { lpw_redo(a, lane); return; }
+        const int64_t fs = first_line_start_global(a, lo, hi);
+        if (fs >= hi) return;                                     // no line starts in this sub-range
+        D = T.delay & 3u;
+        rhi = (int32_t)(hi - lo);
+        rfs = (int32_t)(fs - lo);
+        const int64_t room = a.vend - lo - 3 * kWtPiece;          // pieces are fetched one ahead: never run into
+        rlimit = room < 0x40000000 ? (int32_t)room : 0x40000000;  // the end of the input; keep 32-bit offsets exact
+        rv = rfs & ~(kWtPiece - 1);
+        row = rv == rfs ? 0u : kSkipState * n_cls * 16u;          // the byte before fs is '\n': SKIP reaches root exactly at fs
+        win = 0; Rprev = 0; done = 0;
+        rend = 0x7fffffff;
+        carry = U128{};
+        active = true;
+    }
+    // top of an iteration: a very long last line is handed over before the lane would read beyond its slack
+    TRRE_HD void check(const ScanArgs& a, int64_t lane) {
+        if (active && rv > rlimit) { lpw_redo(a, lane); active = false; }
+    }
+    // 0: one of the lane's first two pieces (may hold offsets below its first line start)
+    // 1: a piece well inside the sub-range   2: a piece in which the lane's last line may end
+    TRRE_HD int mode(int64_t k) const { return k < 2 ? 0 : (rv + kWtPiece < rhi ? 1 : 2); }
+
+    // The output block `carry` = offsets [r0, r0 + 16) is complete: it goes to slot `b` of the lane's
+    // output row.  kHead: the block that contains the lane's first line start is written to memory
+    // from here, bytewise from that offset (the tile store skips it; blocks below are nobody's).
+    template <bool kHead>
+    TRRE_HD void emit(const WtRow& orow, int b, int32_t r0, uint8_t* out_v0) {
+        orow.store(b, carry);
+        if (kHead && r0 < rfs && r0 + 16 > rfs) {
+            const uint32_t wd[4] = {carry.x, carry.y, carry.z, carry.w};
+            for (int i = 0; i < 16; ++i)
+                if (r0 + i >= rfs) out_v0[lo + r0 + i] = (uint8_t)(wd[i >> 2] >> (8 * (i & 3)));
+        }
+    }
+    template <bool kCheckEnd, bool kHead>
+    TRRE_HD void step(const LpwView& T, const U128& blk, uint32_t next_w, int q, const WtRow& orow, uint8_t* out_v0) {
+        uint32_t Rm[4];
+        wt_block<kCheckEnd>(T, blk, next_w, kk, rv + 16 * q, rhi, row, win, seen, Rm, done, rend);
+        carry.w = alignbyte_b32(Rm[0], Rprev, D);
+        emit<kHead>(orow, (q + 3) & 3, rv - 16 + 16 * q, out_v0);
+        carry.x = alignbyte_b32(Rm[1], Rm[0], D);
+        carry.y = alignbyte_b32(Rm[2], Rm[1], D);
+        carry.z = alignbyte_b32(Rm[3], Rm[2], D);
+        Rprev = Rm[3];
+    }
+    // First block of the piece at rv: completes the output row [rv - 64, rv) (slot 3).
+    TRRE_HD void front(const LpwView& T, int md, const U128& b0, uint32_t next_w, const WtRow& orow, uint8_t* out_v0) {
+        lpw_classes(T, b0.x, kk);
+        if (md == 0) step<true, true>(T, b0, next_w, 0, orow, out_v0);
+        else if (md == 1) step<false, false>(T, b0, next_w, 0, orow, out_v0);
+        else step<true, false>(T, b0, next_w, 0, orow, out_v0);
+    }
+    // The other three: slots 0..2 of the output row [rv, rv + 64).
+    template <bool kCheckEnd, bool kHead>
+    TRRE_HD void back_t(const LpwView& T, const U128& b1, const U128& b2, const U128& b3, const WtRow& orow, uint8_t* out_v0) {
+        step<kCheckEnd, kHead>(T, b1, b2.x, 1, orow, out_v0);
+        step<kCheckEnd, kHead>(T, b2, b3.x, 2, orow, out_v0);
+        step<kCheckEnd, kHead>(T, b3, 0u, 3, orow, out_v0);
+    }
+    TRRE_HD void back(const LpwView& T, int md, const U128& b1, const U128& b2, const U128& b3, const WtRow& orow, uint8_t* out_v0) {
+        if (md == 0) back_t<true, true>(T, b1, b2, b3, orow, out_v0);
+        else if (md == 1) back_t<false, false>(T, b1, b2, b3, orow, out_v0);
+        else back_t<true, false>(T, b1, b2, b3, orow, out_v0);
+        // The lane's own lines end at the first record end at or beyond the end of its sub-range; the
+        // automaton has simply kept going to the end of the piece, where what it emits is the head of
+        // the next lane's first line, byte for byte what that lane writes itself: whole blocks are stored.
+        if (done && rend <= rv + kWtPiece - 16) active = false;   // every offset below `rend` is in slots 0..2
+        else rv += kWtPiece;
+    }
+};
+
+// What lane `lid` of a wave needs to move tiles: in tile instruction i (0..3) it handles logical block
+// b = (lid & 3) ^ ((lid >> 3) & 3) of row 16 i + (lid >> 2).
+struct WtMover {
+    int64_t src[4];       // v-space offset of that block in the row's piece 0
+    int32_t head[4];      // the block of output row k - 1 is the row's to store iff 64 (k - 1) >= head
+    int b;
+    TRRE_HD static int row_of(int lid, int i) { return 16 * i + (lid >> 2); }
+    TRRE_HD static int block_of(int lid) { return (lid & 3) ^ ((lid >> 3) & 3); }
+    // rv0 / rfs of the row's lane
+    TRRE_HD void set(int lid, int i, int64_t row_lo, int32_t row_rv0, int32_t row_rfs) {
+        b = block_of(lid);
+        src[i] = row_lo + row_rv0 + 16 * b;
+        head[i] = row_rfs - row_rv0 - 16 * b;             // block offset rv0 + 64 (k - 1) + 16 b >= rfs
+    }
+    // where to fetch the block of piece k from (rows that are not walking get any readable address)
+    TRRE_HD int64_t load_off(int i, int64_t k, int64_t vhi) const {
+        const int64_t v = src[i] + k * kWtPiece;
+        return v < vhi ? v : vhi;
+    }
+    // Iteration k stores the output rows [rv - 64, rv): slots 0..2 were written in iteration k - 1,
+    // slot 3 in this one (rows / rows_prev: the lanes that walked then).
+    TRRE_HD bool stores(int i, int64_t k, uint64_t rows, uint64_t rows_prev, int lid) const {
+        const uint64_t m = b == 3 ? rows : rows_prev;
+        return ((m >> row_of(lid, i)) & 1u) && (k - 1) * kWtPiece >= head[i];
+    }
+    TRRE_HD int64_t store_off(int i, int64_t k) const { return src[i] + (k - 1) * kWtPiece; }
+};
 
 // =============================================================================================
 // Memoryless tables: out[v] = map[in[v]] for one 16-byte vector at v.

@@ -533,98 +533,7 @@ void launch_stream_t(int which, const ScanArgs& a, int64_t n_chunks, hipStream_t
 // positional-window kernel (length-preserving stream tables in window form)
 constexpr int kLpwThreads = 256;
 constexpr int kLpwEntBytes = 8192;
-#if TRRE_LPW_BLOCKS == 4
-// Cooperative piece I/O of the window kernel.  Each lane works on its own 64-byte piece, but the
-// pieces of a wave's 64 lanes lie lane_bytes apart, so per-lane 16-byte accesses would be 64
-// separate cache lines per instruction.  Instead every lane publishes the address of its piece in
-// a per-wave LDS table and the wave moves the 64 pieces transposed: in access i lane L handles
-// quarter (L & 3) of the piece of lane 16 i + (L >> 2), i.e. four adjacent lanes cover one
-// contiguous 64-byte piece.  Rows are 80 bytes: 64 data + address + flag.
-constexpr int kLpwRow = 80;
-constexpr int kLpwWaveLds = 64 * kLpwRow;
-constexpr int kLpwWaves = kLpwThreads / kWave;
-
-template <bool kLdsEnt>
-__global__ __launch_bounds__(kLpwThreads) void k_stream_lpw_coop(ScanArgs a, int64_t lane_bytes) {
-    __shared__ __attribute__((aligned(16))) uint8_t smem[256 + (kLdsEnt ? kLpwEntBytes : 16) + kLpwWaves * kLpwWaveLds];
-    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
-    for (int k = threadIdx.x; k < 256; k += kLpwThreads) smem[k] = a.blob[h.off_cls + k];
-    if (kLdsEnt) {
-        const U128* e = reinterpret_cast<const U128*>(a.blob + h.off_lpw);
-        U128* d = reinterpret_cast<U128*>(smem + 256);
-        for (int k = threadIdx.x; k < (int)(h.lpw_bytes / 16); k += kLpwThreads) d[k] = e[k];
-    }
-    __syncthreads();
-    LpwView T;
-    T.cls = smem;
-    T.ent = kLdsEnt ? reinterpret_cast<const U128*>(smem + 256) : reinterpret_cast<const U128*>(a.blob + h.off_lpw);
-    T.delay = h.lpw_delay;
-    const int lid = threadIdx.x & (kWave - 1);
-    uint8_t* wave_lds = smem + 256 + (kLdsEnt ? kLpwEntBytes : 16) + (threadIdx.x / kWave) * kLpwWaveLds;
-    uint8_t* my_row = wave_lds + lid * kLpwRow;
-    const int64_t lane = (int64_t)blockIdx.x * kLpwThreads + threadIdx.x;
-
-    LpwLane L;
-    L.init(a, T, h.n_cls, lane, lane_bytes);
-    U128 cur[4] = {}, tmp[4] = {};
-    if (L.active) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const U128*>(L.in + L.rv + 16 * q);
-    }
-    while (__any(L.active)) {
-        // ---- A. transposed prefetch of every lane's next piece (into tmp, lands during the compute)
-        {
-            const bool want = L.active && L.rv <= L.rlimit;
-            *reinterpret_cast<uint64_t*>(my_row + 64) = want ? reinterpret_cast<uint64_t>(L.in + L.rv + 64) : 0ull;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint8_t* r = wave_lds + (16 * i + (lid >> 2)) * kLpwRow;
-                const uint64_t src = *reinterpret_cast<const uint64_t*>(r + 64);
-                if (src) tmp[i] = *reinterpret_cast<const U128*>(reinterpret_cast<const uint8_t*>(src) + 16 * (lid & 3));
-            }
-        }
-        // ---- B. compute
-        U128 outq[4];
-        bool full = false, ok = false;
-        if (L.active) ok = L.piece(a, T, lane, cur, outq, full);
-        // ---- C. transposed store of the pieces that are entirely their lane's; the others store bytewise
-        {
-            const bool coop = ok && full && !(a.ablate & 1u);
-            if (ok && !full && !(a.ablate & 1u)) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) lpw_store_block_from(L.out, L.rv - 16 + 16 * q, outq[q], L.rfs, L.aligned);
-            }
-            *reinterpret_cast<uint64_t*>(my_row + 64) = coop ? reinterpret_cast<uint64_t>(L.out + L.rv - 16) : 0ull;
-            if (coop) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) *reinterpret_cast<U128*>(my_row + 16 * q) = outq[q];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint8_t* r = wave_lds + (16 * i + (lid >> 2)) * kLpwRow;
-                const uint64_t dst = *reinterpret_cast<const uint64_t*>(r + 64);
-                if (dst) *reinterpret_cast<U128*>(reinterpret_cast<uint8_t*>(dst) + 16 * (lid & 3)) = *reinterpret_cast<const U128*>(r + 16 * (lid & 3));
-            }
-        }
-        if (ok) L.advance();
-        // ---- D. the prefetched pieces: back through LDS to their owners
-        {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uint8_t* r = wave_lds + (16 * i + (lid >> 2)) * kLpwRow;
-                *reinterpret_cast<U128*>(r + 16 * (lid & 3)) = tmp[i];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const U128*>(my_row + 16 * q);
-        }
-    }
-    uint32_t st = (L.seen & kLpwNul) ? kStNul : 0u;
-    if (st) atomicOr(a.status, st);
-}
-
-#endif  // TRRE_LPW_BLOCKS == 4
-
-// plain per-lane piece I/O (four 16-byte loads / stores per lane per piece)
+// per-lane piece I/O: whole 128-byte lines, 16 bytes per load / store
 template <bool kLdsEnt>
 __global__ __launch_bounds__(kLpwThreads) void k_stream_lpw(ScanArgs a, int64_t lane_bytes) {
     __shared__ __attribute__((aligned(16))) uint8_t smem[256 + (kLdsEnt ? kLpwEntBytes : 16)];
@@ -643,6 +552,105 @@ __global__ __launch_bounds__(kLpwThreads) void k_stream_lpw(ScanArgs a, int64_t 
     uint32_t st = 0;
     stream_lpw_lane(a, T, h.n_cls, (int64_t)blockIdx.x * kLpwThreads + threadIdx.x, lane_bytes, st);
     if (st) atomicOr(a.status, st);
+}
+
+// ---- wave-tiled window kernel (see scan_block.hpp) -------------------------------------------
+constexpr int kWtThreads = 256;
+constexpr int kWtWaves = kWtThreads / kWave;
+constexpr int kWtEntMax = 32768;          // larger window tables stay in global memory (L1/L2)
+
+// 16 bytes per lane from global memory straight into LDS at lds_dst + 16 * lane id (lds_dst: wave-uniform
+// LDS byte address).  The compiler neither counts this load nor knows that it writes LDS: the waits
+// around it are explicit.
+__device__ __forceinline__ void wt_glds16(const uint8_t* gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ uint32_t wt_lds_addr(const uint8_t* p) {
+    return (uint32_t)reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) uint8_t*)p);
+}
+#define TRRE_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define TRRE_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <bool kLdsEnt>
+__global__ __launch_bounds__(kWtThreads) void k_stream_lpwt(ScanArgs a, int64_t lane_bytes, int ent_room) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];    // cls[256] | entries[ent_room] | tiles[waves][in, out][4 KiB]
+    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
+    for (int k = threadIdx.x; k < 256; k += kWtThreads) smem[k] = a.blob[h.off_cls + k];
+    if (kLdsEnt) {
+        const U128* e = reinterpret_cast<const U128*>(a.blob + h.off_lpw);
+        U128* d = reinterpret_cast<U128*>(smem + 256);
+        for (int k = threadIdx.x; k < (int)(h.lpw_bytes / 16); k += kWtThreads) d[k] = e[k];
+    }
+    __syncthreads();
+    LpwView T;
+    T.cls = smem;
+    T.ent = kLdsEnt ? reinterpret_cast<const U128*>(smem + 256) : reinterpret_cast<const U128*>(a.blob + h.off_lpw);
+    T.delay = h.lpw_delay;
+    const int lid = threadIdx.x & (kWave - 1);
+    uint8_t* tin = smem + 256 + ent_room + (threadIdx.x / kWave) * 2 * kWtTile;
+    uint8_t* tout = tin + kWtTile;
+    const int64_t lane = (int64_t)blockIdx.x * kWtThreads + threadIdx.x;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+    WtLane L;
+    L.init(a, T, h.n_cls, lane, lane_bytes);
+    WtMover M;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = WtMover::row_of(lid, i);
+        M.set(lid, i, (lane - lid + r) * lane_bytes, __shfl(L.rv, r), __shfl(L.rfs, r));
+    }
+    const int64_t vhi = (a.vend - 16) & ~(int64_t)15;
+    const WtRow irow{tin + lid * kWtPiece, (uint32_t)((lid >> 1) & 3) << 4};
+    const WtRow orow{tout + lid * kWtPiece, (uint32_t)((lid >> 1) & 3) << 4};
+    uint64_t rows_prev = 0;
+    if (__ballot(L.active)) {
+        const uint32_t t0 = __builtin_amdgcn_readfirstlane(wt_lds_addr(tin));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wt_glds16(a.in_v0 + M.load_off(i, 0, vhi), t0 + i * 1024);
+        bool st1 = false;                     // the previous iteration issued all four tile stores, unconditionally
+        for (int64_t k = 0;; ++k) {
+            L.check(a, lane);
+            const uint64_t rows = __ballot(L.active);
+            if (!rows && !rows_prev) break;
+            // Input tile k must have landed.  The memory counter retires in order and the only operations
+            // issued after the tile's loads are the previous iteration's stores, which count only when
+            // they were certainly issued (an all-lanes-off store may be branched over).
+            if (st1) TRRE_WAIT_VM(4);
+            else TRRE_WAIT_VM(0);
+            const U128 b0 = irow.load(0), b1 = irow.load(1), b2 = irow.load(2), b3 = irow.load(3);
+            TRRE_WAIT_LGKM0();                // the rows are in registers: the buffer can take tile k + 1
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wt_glds16(a.in_v0 + M.load_off(i, k + 1, vhi), t0 + i * 1024);
+            const int md = L.mode(k);
+            if (L.active) L.front(T, md, b0, b1.x, orow, a.out_v0);
+            // the output rows [rv - 64, rv) are complete
+            {
+                const uint8_t* slot = tout + lid * 16;
+                const u32x4 ov0 = *reinterpret_cast<const u32x4*>(slot), ov1 = *reinterpret_cast<const u32x4*>(slot + 1024),
+                            ov2 = *reinterpret_cast<const u32x4*>(slot + 2048), ov3 = *reinterpret_cast<const u32x4*>(slot + 3072);
+                const bool steady = rows == ~0ull && rows_prev == ~0ull && k >= 3;
+                if (steady) {
+                    *reinterpret_cast<u32x4*>(a.out_v0 + M.store_off(0, k)) = ov0;
+                    *reinterpret_cast<u32x4*>(a.out_v0 + M.store_off(1, k)) = ov1;
+                    *reinterpret_cast<u32x4*>(a.out_v0 + M.store_off(2, k)) = ov2;
+                    *reinterpret_cast<u32x4*>(a.out_v0 + M.store_off(3, k)) = ov3;
+                } else {
+                    if (M.stores(0, k, rows, rows_prev, lid)) *reinterpret_cast<u32x4*>(a.out_v0 + M.store_off(0, k)) = ov0;
+                    if (M.stores(1, k, rows, rows_prev, lid)) *reinterpret_cast<u32x4*>(a.out_v0 + M.store_off(1, k)) = ov1;
+                    if (M.stores(2, k, rows, rows_prev, lid)) *reinterpret_cast<u32x4*>(a.out_v0 + M.store_off(2, k)) = ov2;
+                    if (M.stores(3, k, rows, rows_prev, lid)) *reinterpret_cast<u32x4*>(a.out_v0 + M.store_off(3, k)) = ov3;
+                }
+                st1 = steady;
+            }
+            if (L.active) L.back(T, md, b1, b2, b3, orow, a.out_v0);
+            rows_prev = rows;
+        }
+        TRRE_WAIT_VM(0);                      // no load may still be writing LDS when the wave ends
+    }
+    if (L.seen & kLpwNul) atomicOr(a.status, kStNul);
 }
 
 // second launch of the window path: the few lanes that touch an end of the input, redone by the
@@ -665,21 +673,29 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_redo(ScanArgs a, int6
     if (st) atomicOr(a.status, st);
 }
 int lpw_ent_lds_bytes() { return kLpwEntBytes; }
+void launch_lpwt_kernel(int ent_bytes, bool direct_ent_in_lds, const ScanArgs& a, int64_t lane_bytes, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
+    const dim3 grid((unsigned)((n_lanes + kWtThreads - 1) / kWtThreads));
+    const bool ent_in_lds = ent_bytes <= kWtEntMax;
+    const int ent_room = ent_in_lds ? (ent_bytes + 15) / 16 * 16 : 0;
+    const int lds = 256 + ent_room + kWtWaves * 2 * kWtTile;
+    if (ent_in_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_lpwt<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((k_stream_lpwt<true>), grid, dim3(kWtThreads), lds, s, a, lane_bytes, ent_room);
+    } else {
+        hipLaunchKernelGGL((k_stream_lpwt<false>), grid, dim3(kWtThreads), lds, s, a, lane_bytes, ent_room);
+    }
+    const bool ring_lds = reinterpret_cast<const void*>(a.blob) != nullptr && direct_ent_in_lds;
+    if (ring_lds) hipLaunchKernelGGL((k_stream_redo<true>), dim3(64), dim3(kDirectThreads), kDirectLds, s, a, lane_bytes);
+    else hipLaunchKernelGGL((k_stream_redo<false>), dim3(64), dim3(kDirectThreads), kDirectLdsHot, s, a, lane_bytes);
+}
 void launch_lpw_kernel(bool ent_in_lds, bool direct_ent_in_lds, const ScanArgs& a, int64_t lane_bytes, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
     const dim3 grid((unsigned)((n_lanes + kLpwThreads - 1) / kLpwThreads));
-    static const bool coop = getenv("TRRE_LPW_COOP") && atoi(getenv("TRRE_LPW_COOP")) != 0;
-#if TRRE_LPW_BLOCKS == 4
-    if (coop) {
-        if (ent_in_lds) hipLaunchKernelGGL((k_stream_lpw_coop<true>), grid, dim3(kLpwThreads), 0, s, a, lane_bytes);
-        else hipLaunchKernelGGL((k_stream_lpw_coop<false>), grid, dim3(kLpwThreads), 0, s, a, lane_bytes);
-    } else
-#endif
-    {
-        if (ent_in_lds) hipLaunchKernelGGL((k_stream_lpw<true>), grid, dim3(kLpwThreads), 0, s, a, lane_bytes);
-        else hipLaunchKernelGGL((k_stream_lpw<false>), grid, dim3(kLpwThreads), 0, s, a, lane_bytes);
-    }
+    if (ent_in_lds) hipLaunchKernelGGL((k_stream_lpw<true>), grid, dim3(kLpwThreads), 0, s, a, lane_bytes);
+    else hipLaunchKernelGGL((k_stream_lpw<false>), grid, dim3(kLpwThreads), 0, s, a, lane_bytes);
     const bool ring_lds = reinterpret_cast<const void*>(a.blob) != nullptr && direct_ent_in_lds;
     if (ring_lds) hipLaunchKernelGGL((k_stream_redo<true>), dim3(64), dim3(kDirectThreads), kDirectLds, s, a, lane_bytes);
     else hipLaunchKernelGGL((k_stream_redo<false>), dim3(64), dim3(kDirectThreads), kDirectLdsHot, s, a, lane_bytes);
