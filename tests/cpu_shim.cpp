@@ -211,30 +211,9 @@ void run_direct_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uin
     }
 }
 
-void run_lpw(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
-    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
-    LpwView T;
-    T.cls = a.blob + h.off_cls;
-    T.ent = reinterpret_cast<const U128*>(a.blob + h.off_lpw);
-    T.delay = h.lpw_delay;
-    const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
-    std::vector<uint32_t> redo(n_lanes + 1, 0);
-    ScanArgs b = a;
-    b.redo = redo.data();
-    for (int64_t lane = n_lanes - 1; lane >= 0; --lane) stream_lpw_lane(b, T, h.n_cls, lane, lane_bytes, status);
-    // second launch: the lanes that touch an end of the input
-    const StreamView TS = direct_view(a);
-    alignas(16) uint8_t ring[80];
-    const int64_t sub = lane_bytes >= 64 ? lane_bytes / 64 : 1, sub_bytes = lane_bytes >= 64 ? 64 : lane_bytes;
-    for (int64_t k = 0; k < (int64_t)redo[0] * sub; ++k) {
-        DirectLane L;
-        stream_direct_lane<0>(a, TS, h.n_cls, (int64_t)redo[1 + k / sub] * sub + k % sub, sub_bytes, ring, 0, L, status);
-    }
-}
-
-// Host emulation of the wave-tiled window kernel (k_stream_lpwt): 64 lanes in lockstep over an
+// Host emulation of the window kernel (k_stream_lpw): 64 lanes in lockstep over an
 // emulated pair of LDS tiles, the same lane / mover code as the device.
-void run_lpwt(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
+void run_lpw(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
     LpwView T;
     T.cls = a.blob + h.off_cls;
@@ -253,20 +232,21 @@ void run_lpwt(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
         const int64_t lane0 = wv * 64;
         for (int lid = 0; lid < 64; ++lid) L[lid].init(b, T, h.n_cls, lane0 + lid, lane_bytes);
         for (int lid = 0; lid < 64; ++lid)
-            for (int i = 0; i < 4; ++i) {
-                const int r = WtMover::row_of(lid, i);
-                M[lid].set(lid, i, (lane0 + r) * lane_bytes, L[r].rv, L[r].rfs);
-            }
+            for (int i = 0; i < 4; ++i) M[lid].set(lid, i, lane_bytes, L[WtMover::row_of(lid, i)].rv);
+        const int64_t wave_lo = lane0 * lane_bytes;
+        const uint8_t* win_in = a.in_v0 + wave_lo;
+        uint8_t* win_out = a.out_v0 + wave_lo;
+        const int64_t room0 = vhi - wave_lo;
         auto ballot = [&]() { uint64_t m = 0; for (int lid = 0; lid < 64; ++lid) if (L[lid].active) m |= 1ull << lid; return m; };
-        auto fetch = [&](int64_t k) {
+        auto fetch = [&](int32_t k64) {
             for (int lid = 0; lid < 64; ++lid)
-                for (int i = 0; i < 4; ++i) std::memcpy(tin + i * 1024 + lid * 16, a.in_v0 + M[lid].load_off(i, k, vhi), 16);
+                for (int i = 0; i < 4; ++i) std::memcpy(tin + i * 1024 + lid * 16, win_in + M[lid].load_off(i, k64, room0), 16);
         };
         if (!ballot()) continue;
         std::memset(tout, 0xEE, sizeof(tout));
         fetch(0);
         uint64_t rows_prev = 0;
-        for (int64_t k = 0;; ++k) {
+        for (int32_t k64 = 0;; k64 += kWtPiece) {
             for (int lid = 0; lid < 64; ++lid) L[lid].check(b, lane0 + lid);
             const uint64_t rows = ballot();
             if (!rows && !rows_prev) break;
@@ -276,15 +256,16 @@ void run_lpwt(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
                 const WtRow irow{tin + lid * kWtPiece, (uint32_t)((lid >> 1) & 3) << 4};
                 for (int q = 0; q < 4; ++q) blk[lid][q] = irow.load(q);
             }
-            fetch(k + 1);
+            fetch(k64 + kWtPiece);
             for (int lid = 0; lid < 64; ++lid) {
                 const WtRow orow{tout + lid * kWtPiece, (uint32_t)((lid >> 1) & 3) << 4};
-                md[lid] = L[lid].mode(k);
+                md[lid] = L[lid].mode(k64);
                 if (L[lid].active) L[lid].front(T, md[lid], blk[lid][0], blk[lid][1].x, orow, a.out_v0);
             }
             for (int lid = 0; lid < 64; ++lid)
                 for (int i = 0; i < 4; ++i)
-                    if (M[lid].stores(i, k, rows, rows_prev, lid)) std::memcpy(a.out_v0 + M[lid].store_off(i, k), tout + i * 1024 + lid * 16, 16);
+                    if (WtMover::stores(i, k64, rows, rows_prev, lid, L[WtMover::row_of(lid, i)].rfs))
+                        std::memcpy(win_out + M[lid].store_off(i, k64), tout + i * 1024 + lid * 16, 16);
             for (int lid = 0; lid < 64; ++lid) {
                 const WtRow orow{tout + lid * kWtPiece, (uint32_t)((lid >> 1) & 3) << 4};
                 if (L[lid].active) L[lid].back(T, md[lid], blk[lid][1], blk[lid][2], blk[lid][3], orow, a.out_v0);
@@ -331,7 +312,7 @@ int run_family(int family, ScanArgs& a, uint32_t& status, uint64_t& total) {
 extern "C" {
 
 // family: 1 bytemap, 2 tile LP, 3 tile general, 4 stream LP (in place), 5 stream general.
-// 8 wave-tiled positional-window stream LP, 9 the same with per-lane piece I/O, 6 direct stream LP, 7 direct stream general (geo: 0 -> 2048-byte lanes, 1 -> 48-byte lanes).
+// 8 positional-window stream LP, 6 direct stream LP, 7 direct stream general (geo: 0 -> 2048-byte lanes, 1 -> 48-byte lanes).
 // geo: 0 production, 1 tiny.
 // in_mis/out_mis: address misalignment (0..15) to give the staged buffers.
 // want_scratch: pass a mask scratch to the NFT long-line path.
@@ -361,13 +342,7 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
         if (reinterpret_cast<const StreamBlobHeader*>(blob)->lpw_bytes == 0) return -5;
         // like the runtime: buffers that are not congruent mod 16 go to the direct walker
         if (reinterpret_cast<uintptr_t>(a.out_v0) & 15u) run_direct_lp(a, geo == 0 ? 2048 : 48, status);
-        else run_lpwt(a, geo == 0 ? 2048 : 64, status);
-        total = n;
-    }
-    else if (family == 9) {          // window kernel with per-lane piece I/O
-        if (reinterpret_cast<const StreamBlobHeader*>(blob)->lpw_bytes == 0) return -5;
-        if (reinterpret_cast<uintptr_t>(a.out_v0) & 15u) run_direct_lp(a, geo == 0 ? 2048 : 48, status);
-        else run_lpw(a, geo == 0 ? 2048 : 128, status);
+        else run_lpw(a, geo == 0 ? 2048 : 64, status);
         total = n;
     }
     else if (family == 6) { run_direct_lp(a, geo == 0 ? 2048 : 48, status); total = n; }

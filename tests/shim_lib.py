@@ -63,16 +63,16 @@ def scan_like_runtime(prog, data, geo=1, family=None, in_mis=0, out_mis=0):
     """Mirror of runtime.cpp's policy (finish()): auto family, NUL -> general family."""
     info = prog.info
     fam = family if family else info.kernel
-    blob = prog.export_stream_tables() if fam in (4, 5, 6, 7, 8, 9) else prog.export_tables()
+    blob = prog.export_stream_tables() if fam in (4, 5, 6, 7, 8) else prog.export_tables()
     out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
-    if out is None:                         # family 8 / 9 without a window form: nothing to run
+    if out is None:                         # family 8 without a window form: nothing to run
         fam = 6
         out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
     assert not st & ST_MISMATCH, "count and emit passes disagree"
     if st & ST_DIVERGE:
         raise RuntimeError("diverges")
     if fam not in (3, 5, 7) and st & ST_NUL:
-        gen = (7 if fam in (6, 8, 9) else 5) if info.stream_states else 3
+        gen = (7 if fam in (6, 8) else 5) if info.stream_states else 3
         blob = prog.export_stream_tables() if gen in (5, 7) else prog.export_tables()
         out, st = shim_scan(blob, info.engine, gen, data, geo, in_mis, out_mis)
         assert not st & ST_MISMATCH

@@ -68,7 +68,7 @@ def shim_families(p):
     """kernel families to run through the shim: the ABI's plus the direct (no-tile) stream walkers"""
     fams = list(p.allowed_kernels())
     if 4 in fams:
-        fams += [6, 8, 9]
+        fams += [6, 8]
     if 5 in fams:
         fams.append(7)
     return fams

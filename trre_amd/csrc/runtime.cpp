@@ -267,8 +267,6 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
     args.status = st->d_status;
     args.cap = cap;
     args.gscratch = st->d_scratch;
-    static const uint32_t ablate = getenv("TRRE_ABLATE") ? (uint32_t)atoi(getenv("TRRE_ABLATE")) : 0u;
-    args.ablate = ablate;
     const int chunk = is_stream(family) ? stream_chunk_bytes(family == TRRE_KERNEL_STREAM_LP ? 0 : 1)
                                         : chunk_bytes(p->engine, p->mask_bytes);
     const int threads = is_stream(family) ? stream_block_threads(family == TRRE_KERNEL_STREAM_LP ? 0 : 1)
@@ -277,11 +275,11 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
     const bool ent_lds = p->stt.ok && p->stt.ent.size() * 8 <= (size_t)StreamEngine::kLdsEntBytes;
     // stream families have three implementations (TRRE_STREAM_IMPL, for A/B measurements):
     //   0 LDS tile (k_stream_lp / k_stream_count+emit)      1 direct walker with an LDS output ring
-    //   2 (default) wave-tiled positional-window kernel for length-preserving tables that have the
-    //     window form, direct walker otherwise            3 window kernel with per-lane piece I/O
+    //   2 (default) positional-window kernel (wave-tiled I/O) for length-preserving tables that have
+    //     the window form, direct walker otherwise
     static const int stream_impl = getenv("TRRE_STREAM_IMPL") ? atoi(getenv("TRRE_STREAM_IMPL")) : 2;
     static const int64_t lane_bytes_env = getenv("TRRE_LANE_BYTES") ? atoll(getenv("TRRE_LANE_BYTES")) : 0;
-    const bool window = is_stream(family) && stream_impl >= 2 && family == TRRE_KERNEL_STREAM_LP && p->stt.lpw_ok &&
+    const bool window = is_stream(family) && stream_impl == 2 && family == TRRE_KERNEL_STREAM_LP && p->stt.lpw_ok &&
                         (reinterpret_cast<uintptr_t>(args.out_v0) & 15u) == 0;   // its 16-byte stores need in and out congruent mod 16
     const int64_t lane_bytes = lane_bytes_env > 0 ? (lane_bytes_env + 127) / 128 * 128
                                                   : (family == TRRE_KERNEL_STREAM_LP && !window ? 1024 : 2048);
@@ -316,8 +314,7 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
         }
         HIP_TRY(hipMemsetAsync(st->d_redo, 0, 4, stream));
         args.redo = st->d_redo;
-        if (stream_impl == 3) launch_lpw_kernel(p->stt.lpw.size() * 4 <= (size_t)lpw_ent_lds_bytes(), direct_ent_lds, args, lane_bytes, stream);
-        else launch_lpwt_kernel((int)(p->stt.lpw.size() * 4), direct_ent_lds, args, lane_bytes, stream);
+        launch_lpw_kernel((int)(p->stt.lpw.size() * 4), direct_ent_lds, args, lane_bytes, stream);
     } else if (direct && family == TRRE_KERNEL_STREAM_LP) {
         launch_direct_kernel(0, direct_ent_lds, args, lane_bytes, n_chunks, stream);
     } else if (direct) {

@@ -28,9 +28,6 @@ namespace trre {
 
 struct alignas(16) U128 { uint32_t x, y, z, w; };
 
-#ifndef TRRE_LPW_BLOCKS
-#define TRRE_LPW_BLOCKS 8
-#endif
 
 template <int THREADS_, int CHUNK_, int HALO_>
 struct Geometry {
@@ -56,7 +53,6 @@ struct ScanArgs {
     uint64_t* chunk_base;    // [n_chunks + 1] exclusive scan of chunk_total; [n_chunks] = total
     uint64_t cap;            // capacity of out
     uint8_t* gscratch;       // NFT long-line mask scratch (or null)
-    uint32_t ablate;         // experiments only (TRRE_ABLATE): 1 no stores
     uint32_t* redo;          // window kernel: [0] = count, [1..] = lanes to redo with the general direct walker
 };
 
@@ -760,10 +756,9 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
 //   win >>= 8 ; row = entry.next
 //
 // Output position == input position, so released bytes are packed into aligned
-// dwords statically and leave as one 16-byte store per 16 input bytes straight
-// from registers (no LDS staging at all).  Each lane streams a long sub-range of
-// the input from HBM/L2 (lane_bytes); it starts at its first line start and runs
-// to the end of its last line.
+// dwords statically, 16 bytes at a time.  Each lane walks a long sub-range of the
+// input (lane_bytes); it starts at its first line start and runs to the end of its
+// last line.
 // =============================================================================================
 struct LpwView {
     const uint8_t* cls;      // [256]
@@ -808,201 +803,20 @@ TRRE_HD void lpw_redo(const ScanArgs& a, int64_t lane) {
     a.redo[1 + k] = (uint32_t)lane;
 }
 
-// head of a lane's first piece: blocks below the first line start are not this lane's, the block
-// that contains it is written bytewise from there on
-TRRE_HD void lpw_store_block_from(uint8_t* out, int32_t r0, const U128& q, int32_t fs, bool aligned) {
-    if (r0 + 16 <= fs) return;
-    if (r0 >= fs && aligned) { *reinterpret_cast<U128*>(out + r0) = q; return; }
-    const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-        if (r0 + i >= fs) out[r0 + i] = (uint8_t)(wd[i >> 2] >> (8 * (i & 3)));
-}
-// Positions inside the hot loop are 32-bit offsets from the lane's sub-range start.
-template <bool kCheckEnd>
-TRRE_HD void lpw_block(const LpwView& T, const U128& cur, int32_t rv, int32_t rhi, uint32_t done_row, uint32_t& row, uint32_t& win,
-                       uint32_t& seen, uint32_t (&Rm)[4], uint32_t& done, int32_t& rend) {
-    const uint32_t wd[4] = {cur.x, cur.y, cur.z, cur.w};
-    uint32_t R = 0;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        uint32_t w = wd[d];
-        const uint32_t k0 = T.cls[w & 0xffu], k1 = T.cls[(w >> 8) & 0xffu], k2 = T.cls[(w >> 16) & 0xffu], k3 = T.cls[w >> 24];
-        const uint32_t kk[4] = {k0, k1, k2, k3};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const U128 e = *reinterpret_cast<const U128*>(reinterpret_cast<const uint8_t*>(T.ent) + row + (kk[j] << 4));
-            const uint32_t seq = perm_b32(w, e.z, e.w);
-            win |= seq << (e.y & 31u);
-            R = alignbit_b32(win, R, 8);
-            win >>= 8;
-            row = e.x;
-            seen |= e.y;
-            if (kCheckEnd) {
-                // The first record end at or beyond the end of the sub-range is where the lane's own lines
-                // end (branch-free).  The automaton simply keeps going to the end of the piece: what it
-                // emits there is the head of the next lane's first line, byte for byte what that lane
-                // writes itself, so the last piece can be stored whole.
-                const int32_t p1 = rv + 4 * d + j + 1;
-                const uint32_t hit = ((e.y >> 5) & 1u) & (uint32_t)(p1 >= rhi) & (done ^ 1u);
-                rend = hit ? p1 : rend;
-                done |= hit;
-            }
-            w >>= 8;
-        }
-        Rm[d] = R;
-        TRRE_SCHED_FENCE();
-    }
-}
-
-constexpr int kLpwBlocks = TRRE_LPW_BLOCKS;       // 16-byte blocks per piece (4 = 64-byte pieces, 8 = whole 128-byte lines)
-constexpr int kLpwPiece = 16 * kLpwBlocks;
-
-template <bool kCheckEnd>
-TRRE_HD void lpw_piece(const LpwView& T, const U128 (&cur)[kLpwBlocks], int32_t rv, int32_t rhi, uint32_t done_row, uint32_t D, uint32_t& row,
-                       uint32_t& win, uint32_t& seen, uint32_t& Rprev, U128& carry, U128 (&outq)[kLpwBlocks], uint32_t& done, int32_t& rend) {
-    // outq[0] = block rv-16 (needs this piece's first released dword), outq[1..] = blocks rv, rv+16, ...;
-    // the piece's last block stays in `carry` until the next piece
-    uint32_t Rm[4];
-    lpw_block<kCheckEnd>(T, cur[0], rv, rhi, done_row, row, win, seen, Rm, done, rend);
-    outq[0] = carry;
-    outq[0].w = alignbyte_b32(Rm[0], Rprev, D);
-#pragma unroll
-    for (int q = 0; q < kLpwBlocks; ++q) {
-        U128 o;
-        o.x = alignbyte_b32(Rm[1], Rm[0], D);
-        o.y = alignbyte_b32(Rm[2], Rm[1], D);
-        o.z = alignbyte_b32(Rm[3], Rm[2], D);
-        o.w = 0;
-        const uint32_t r3 = Rm[3];
-        if (q < kLpwBlocks - 1) {
-            lpw_block<kCheckEnd>(T, cur[q + 1], rv + 16 * (q + 1), rhi, done_row, row, win, seen, Rm, done, rend);
-            o.w = alignbyte_b32(Rm[0], r3, D);
-            outq[q + 1] = o;
-        } else {
-            carry = o;
-            Rprev = r3;
-        }
-    }
-}
-
-// Per-lane state of the window walk, split from its I/O so that the kernel can move the
-// pieces cooperatively (transposed through LDS: adjacent lanes touch adjacent 16-byte blocks) while
-// the host shim and the fallback use plain per-lane loads and stores.
-struct LpwLane {
-    const uint8_t* in;     // a.in_v0 + lo
-    uint8_t* out;          // a.out_v0 + lo
-    int32_t rhi, rfs, rlimit, rv, rend;
-    uint32_t D, done_row, row, win, seen, Rprev, done;
-    U128 carry;
-    bool active, aligned;
-
-    TRRE_HD void init(const ScanArgs& a, const LpwView& T, uint32_t n_cls, int64_t lane, int64_t lane_bytes) {
-        active = false;
-        seen = 0;
-        const int64_t lo = lane * lane_bytes;            // lane_bytes is a multiple of the piece size
-        int64_t hi = lo + lane_bytes;
-        if (hi > a.vend) hi = a.vend;
-        if (lo >= hi) return;
-        // keep slack to both ends of the input; lanes that need the edge fix-ups are redone
-        if (lo < a.vbeg + kLpwPiece || hi + 3 * kLpwPiece > a.vend) { lpw_redo(a, lane); return; }
-        const int64_t fs = first_line_start_global(a, lo, hi);
-        if (fs >= hi) return;                                     // no line starts in this sub-range
-        D = T.delay & 3u;
-        done_row = kDoneState * n_cls * 16u;
-        aligned = (reinterpret_cast<uintptr_t>(a.out_v0) & 15u) == 0;
-        in = a.in_v0 + lo;
-        out = a.out_v0 + lo;
-        rhi = (int32_t)(hi - lo);
-        rfs = (int32_t)(fs - lo);
-        const int64_t room = a.vend - lo - 3 * kLpwPiece;         // never run into the end of the input,
-        rlimit = room < 0x40000000 ? (int32_t)room : 0x40000000;  // and keep 32-bit offsets exact
-        rv = rfs & ~(kLpwPiece - 1);
-        row = rv == rfs ? 0u : kSkipState * n_cls * 16u;          // the byte before fs is '\n': SKIP reaches root exactly at fs
-        win = 0; Rprev = 0; done = 0;
-        rend = 0x7fffffff;
-        carry = U128{};
-        active = true;
-    }
-    // one piece at offset rv: outq = output for offsets [rv - 16, rv + piece - 16), of which only those
-    // at or above rfs are this lane's (`full` = all of them, 16-byte aligned).  Returns false when the
-    // lane must stop without storing (handed over to the redo launch).
-    TRRE_HD bool piece(const ScanArgs& a, const LpwView& T, int64_t lane, const U128 (&cur)[kLpwBlocks], U128 (&outq)[kLpwBlocks], bool& full) {
-        if (rv > rlimit) { lpw_redo(a, lane); active = false; return false; }   // a very long last line: hand over
-        if (rv + kLpwPiece < rhi) lpw_piece<false>(T, cur, rv, rhi, done_row, D, row, win, seen, Rprev, carry, outq, done, rend);
-        else lpw_piece<true>(T, cur, rv, rhi, done_row, D, row, win, seen, Rprev, carry, outq, done, rend);
-        full = aligned && rv - 16 >= rfs;                        // only the head of the first piece is not this lane's
-        return true;
-    }
-    // after the piece's output has been stored
-    TRRE_HD void advance() {
-        if (done && rend <= rv + kLpwPiece - 16) active = false;  // every offset below `rend` has been stored
-        else rv += kLpwPiece;
-    }
-};
-
-// plain per-lane I/O (host shim; also the default device path)
-TRRE_HD void stream_lpw_lane(const ScanArgs& a, const LpwView& T, uint32_t n_cls, int64_t lane, int64_t lane_bytes, uint32_t& status) {
-    LpwLane L;
-    L.init(a, T, n_cls, lane, lane_bytes);
-    if (!L.active) return;
-    U128 cur[kLpwBlocks], nxt[kLpwBlocks];
-#pragma unroll
-    for (int q = 0; q < kLpwBlocks; ++q) cur[q] = *reinterpret_cast<const U128*>(L.in + L.rv + 16 * q);
-    {
-        // Wait for the first piece HERE, outside the loop.  Otherwise the compiler's wait for `cur`
-        // sits at its first use inside the loop, after the prefetch loads have been issued, and
-        // (the counter being in order) also drains the previous iteration's stores every time round.
-        uint32_t t = 0;
-#pragma unroll
-        for (int q = 0; q < kLpwBlocks; ++q) t ^= cur[q].x ^ cur[q].y ^ cur[q].z ^ cur[q].w;
-        TRRE_TOUCH(t);
-    }
-    while (L.active) {
-        // unconditional prefetch (the offset is clamped instead of predicated, so that the wait the
-        // compiler places before the first use of `cur` can leave these loads outstanding)
-        const int32_t rp = L.rv <= L.rlimit ? L.rv + kLpwPiece : L.rlimit + kLpwPiece;
-#pragma unroll
-        for (int q = 0; q < kLpwBlocks; ++q) nxt[q] = *reinterpret_cast<const U128*>(L.in + rp + 16 * q);
-        U128 outq[kLpwBlocks];
-        bool full;
-        if (!L.piece(a, T, lane, cur, outq, full)) break;
-        if (!(a.ablate & 1u)) {
-            bool stored = false;
-            if (TRRE_WAVE_ANY(!full)) {
-                if (!full) {
-#pragma unroll
-                    for (int q = 0; q < kLpwBlocks; ++q) lpw_store_block_from(L.out, L.rv - 16 + 16 * q, outq[q], L.rfs, L.aligned);
-                    stored = true;
-                }
-            }
-            if (!stored) {
-#pragma unroll
-                for (int q = 0; q < kLpwBlocks; ++q) *reinterpret_cast<U128*>(L.out + L.rv - 16 + 16 * q) = outq[q];
-            }
-        }
-        L.advance();
-#pragma unroll
-        for (int q = 0; q < kLpwBlocks; ++q) cur[q] = nxt[q];
-    }
-    if (L.seen & kLpwNul) status |= kStNul;
-}
-
 // =============================================================================================
-// Wave-tiled window kernel.
+// How the window walk gets its bytes: wave tiles.
 //
-// Same walk as above (one lane per sub-range, one 16-byte table entry per input byte), but a lane
-// never touches global memory for its pieces.  Per-lane 16-byte accesses are one L2 request each
-// (the lanes of a wave are lane_bytes apart), and a lane's output line was written 16 bytes at a
-// time, with its 64-byte sectors completed by different instructions: the store path, not the walk,
-// was the limit.  Here the wave moves the 64-byte pieces of its 64 lanes together as 4 KiB tiles:
-// four adjacent lanes cover one piece, so a wave instruction touches 16 rows x 64 contiguous,
-// 64-byte aligned bytes.  The input tile goes straight from global memory to LDS
-// (global_load_lds_dwordx4: no staging registers); every lane takes its row into registers, at
-// which point the next tile is already requested into the same buffer.  Output blocks are
-// collected in a second tile whose rows are the aligned 64 bytes BEHIND the lane's position (the
-// output lags the input by the window delay, so the last block of a row is only known after the
-// first block of the next piece) and the wave stores that tile the way the input was loaded.
+// A lane never touches global memory for its pieces.  Per-lane 16-byte accesses are one L2 request
+// each (the lanes of a wave are lane_bytes apart) and complete a line's 64-byte sectors piecemeal;
+// measured that way the store path, not the walk, set the pace.  Instead the wave moves the
+// 64-byte pieces of its 64 lanes together as 4 KiB tiles: four adjacent lanes cover one piece, so
+// a wave instruction touches 16 rows x 64 contiguous, 64-byte aligned bytes.  The input tile goes
+// straight from global memory to LDS (global_load_lds_dwordx4: no staging registers); every lane
+// takes its row into registers, at which point the next tile is already requested into the same
+// buffer.  Output blocks are collected in a second tile whose rows are the aligned 64 bytes BEHIND
+// the lane's position (the output lags the input by the window delay, so the last block of a row
+// is only known after the first block of the next piece) and the wave stores that tile the way
+// the input was loaded.
 //
 // Tile layout: row r (= lane r of the wave) at r * 64; logical block b of the row sits in physical
 // 16-byte slot b ^ ((r >> 1) & 3), which makes both the row-wise accesses of 8 consecutive lanes
@@ -1018,8 +832,9 @@ TRRE_HD void lpw_classes(const LpwView& T, uint32_t w, uint32_t (&kk)[4]) {
     kk[0] = T.cls[w & 0xffu]; kk[1] = T.cls[(w >> 8) & 0xffu]; kk[2] = T.cls[(w >> 16) & 0xffu]; kk[3] = T.cls[w >> 24];
 }
 
-// One 16-byte block like lpw_block, with the class lookups taken off the row chain: kk holds the
-// classes of the block's first dword on entry and those of next_w on return.
+// One 16-byte block of the walk.  The class lookups are taken off the row chain: kk holds the
+// classes of the block's first dword on entry and those of next_w on return.  rv: the block's offset
+// in the lane's sub-range, rhi: the sub-range's length.
 template <bool kCheckEnd>
 TRRE_HD void wt_block(const LpwView& T, const U128& cur, uint32_t next_w, uint32_t (&kk)[4], int32_t rv, int32_t rhi, uint32_t& row,
                       uint32_t& win, uint32_t& seen, uint32_t (&Rm)[4], uint32_t& done, int32_t& rend) {
@@ -1039,7 +854,9 @@ TRRE_HD void wt_block(const LpwView& T, const U128& cur, uint32_t next_w, uint32
             win >>= 8;
             row = e.x;
             seen |= e.y;
-            if (kCheckEnd) {      // see lpw_block
+            if (kCheckEnd) {
+                // the first record end at or beyond the end of the sub-range is where the lane's own lines end
+                // (branch-free; the walk itself simply goes on to the end of the piece)
                 const int32_t p1 = rv + 4 * d + j + 1;
                 const uint32_t hit = ((e.y >> 5) & 1u) & (uint32_t)(p1 >= rhi) & (done ^ 1u);
                 rend = hit ? p1 : rend;
@@ -1101,7 +918,7 @@ struct WtLane {
     }
     // 0: one of the lane's first two pieces (may hold offsets below its first line start)
     // 1: a piece well inside the sub-range   2: a piece in which the lane's last line may end
-    TRRE_HD int mode(int64_t k) const { return k < 2 ? 0 : (rv + kWtPiece < rhi ? 1 : 2); }
+    TRRE_HD int mode(int32_t k64) const { return k64 < 2 * kWtPiece ? 0 : (rv + kWtPiece < rhi ? 1 : 2); }
 
     // The output block `carry` = offsets [r0, r0 + 16) is complete: it goes to slot `b` of the lane's
     // output row.  kHead: the block that contains the lane's first line start is written to memory
@@ -1110,9 +927,10 @@ struct WtLane {
     TRRE_HD void emit(const WtRow& orow, int b, int32_t r0, uint8_t* out_v0) {
         orow.store(b, carry);
         if (kHead && r0 < rfs && r0 + 16 > rfs) {
-            const uint32_t wd[4] = {carry.x, carry.y, carry.z, carry.w};
-            for (int i = 0; i < 16; ++i)
-                if (r0 + i >= rfs) out_v0[lo + r0 + i] = (uint8_t)(wd[i >> 2] >> (8 * (i & 3)));
+            // (a real loop over the bytes just put in the tile: this runs once per lane, keep it small)
+            const uint8_t* blk = orow.row + ((uint32_t)(b << 4) ^ orow.swz16);
+#pragma clang loop unroll(disable)
+            for (int i = rfs - r0; i < 16; ++i) out_v0[lo + r0 + i] = blk[i];
         }
     }
     template <bool kCheckEnd, bool kHead>
@@ -1153,31 +971,32 @@ struct WtLane {
 };
 
 // What lane `lid` of a wave needs to move tiles: in tile instruction i (0..3) it handles logical block
-// b = (lid & 3) ^ ((lid >> 3) & 3) of row 16 i + (lid >> 2).
+// b = (lid & 3) ^ ((lid >> 3) & 3) of row 16 i + (lid >> 2).  Offsets are relative to the start of the
+// wave's first sub-range (a wave spans 64 * lane_bytes < 2^31 bytes).
 struct WtMover {
-    int64_t src[4];       // v-space offset of that block in the row's piece 0
-    int32_t head[4];      // the block of output row k - 1 is the row's to store iff 64 (k - 1) >= head
-    int b;
+    int32_t src[4];       // offset of that block in the row's piece 0
     TRRE_HD static int row_of(int lid, int i) { return 16 * i + (lid >> 2); }
     TRRE_HD static int block_of(int lid) { return (lid & 3) ^ ((lid >> 3) & 3); }
-    // rv0 / rfs of the row's lane
-    TRRE_HD void set(int lid, int i, int64_t row_lo, int32_t row_rv0, int32_t row_rfs) {
-        b = block_of(lid);
-        src[i] = row_lo + row_rv0 + 16 * b;
-        head[i] = row_rfs - row_rv0 - 16 * b;             // block offset rv0 + 64 (k - 1) + 16 b >= rfs
+    // row_rv0: the piece-aligned offset at which the row's lane starts walking
+    TRRE_HD void set(int lid, int i, int64_t lane_bytes, int32_t row_rv0) {
+        src[i] = (int32_t)(row_of(lid, i) * lane_bytes) + row_rv0 + 16 * block_of(lid);
     }
-    // where to fetch the block of piece k from (rows that are not walking get any readable address)
-    TRRE_HD int64_t load_off(int i, int64_t k, int64_t vhi) const {
-        const int64_t v = src[i] + k * kWtPiece;
-        return v < vhi ? v : vhi;
+    // where to fetch the block of piece k from (rows that are not walking get any readable address);
+    // room = offset of the last readable 16 bytes, relative like src
+    TRRE_HD int32_t load_off(int i, int32_t k64, int64_t room) const {
+        const int64_t v = (int64_t)src[i] + k64;
+        return (int32_t)(v < room ? v : room);
     }
     // Iteration k stores the output rows [rv - 64, rv): slots 0..2 were written in iteration k - 1,
-    // slot 3 in this one (rows / rows_prev: the lanes that walked then).
-    TRRE_HD bool stores(int i, int64_t k, uint64_t rows, uint64_t rows_prev, int lid) const {
+    // slot 3 in this one (rows / rows_prev: the lanes that walked then).  Blocks below the row's first
+    // line start (row_rfs, relative to its sub-range) are nobody's; the one containing it is written
+    // by the row's lane itself.
+    TRRE_HD static bool stores(int i, int32_t k64, uint64_t rows, uint64_t rows_prev, int lid, int32_t row_rfs) {
+        const int b = block_of(lid);
         const uint64_t m = b == 3 ? rows : rows_prev;
-        return ((m >> row_of(lid, i)) & 1u) && (k - 1) * kWtPiece >= head[i];
+        return ((m >> row_of(lid, i)) & 1u) && k64 - kWtPiece + 16 * b >= (row_rfs & (kWtPiece - 1));
     }
-    TRRE_HD int64_t store_off(int i, int64_t k) const { return src[i] + (k - 1) * kWtPiece; }
+    TRRE_HD int32_t store_off(int i, int32_t k64) const { return src[i] + k64 - kWtPiece; }
 };
 
 // =============================================================================================

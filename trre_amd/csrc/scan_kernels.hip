@@ -530,31 +530,7 @@ void launch_stream_t(int which, const ScanArgs& a, int64_t n_chunks, hipStream_t
     else hipLaunchKernelGGL((k_stream_emit<GG, kLdsEnt>), grid, dim3(GG::THREADS), StreamCarve<GG>::kBytesTwoTiles, s, a);
 }
 
-// positional-window kernel (length-preserving stream tables in window form)
-constexpr int kLpwThreads = 256;
-constexpr int kLpwEntBytes = 8192;
-// per-lane piece I/O: whole 128-byte lines, 16 bytes per load / store
-template <bool kLdsEnt>
-__global__ __launch_bounds__(kLpwThreads) void k_stream_lpw(ScanArgs a, int64_t lane_bytes) {
-    __shared__ __attribute__((aligned(16))) uint8_t smem[256 + (kLdsEnt ? kLpwEntBytes : 16)];
-    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
-    for (int k = threadIdx.x; k < 256; k += kLpwThreads) smem[k] = a.blob[h.off_cls + k];
-    if (kLdsEnt) {
-        const U128* e = reinterpret_cast<const U128*>(a.blob + h.off_lpw);
-        U128* d = reinterpret_cast<U128*>(smem + 256);
-        for (int k = threadIdx.x; k < (int)(h.lpw_bytes / 16); k += kLpwThreads) d[k] = e[k];
-    }
-    __syncthreads();
-    LpwView T;
-    T.cls = smem;
-    T.ent = kLdsEnt ? reinterpret_cast<const U128*>(smem + 256) : reinterpret_cast<const U128*>(a.blob + h.off_lpw);
-    T.delay = h.lpw_delay;
-    uint32_t st = 0;
-    stream_lpw_lane(a, T, h.n_cls, (int64_t)blockIdx.x * kLpwThreads + threadIdx.x, lane_bytes, st);
-    if (st) atomicOr(a.status, st);
-}
-
-// ---- wave-tiled window kernel (see scan_block.hpp) -------------------------------------------
+// ---- positional-window kernel for length-preserving stream tables in window form, wave-tiled I/O (see scan_block.hpp)
 constexpr int kWtThreads = 256;
 constexpr int kWtWaves = kWtThreads / kWave;
 constexpr int kWtEntMax = 32768;          // larger window tables stay in global memory (L1/L2)
@@ -574,7 +550,7 @@ __device__ __forceinline__ uint32_t wt_lds_addr(const uint8_t* p) {
 #define TRRE_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 template <bool kLdsEnt>
-__global__ __launch_bounds__(kWtThreads) void k_stream_lpwt(ScanArgs a, int64_t lane_bytes, int ent_room) {
+__global__ __launch_bounds__(kWtThreads) void k_stream_lpw(ScanArgs a, int64_t lane_bytes, int ent_room) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];    // cls[256] | entries[ent_room] | tiles[waves][in, out][4 KiB]
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
     for (int k = threadIdx.x; k < 256; k += kWtThreads) smem[k] = a.blob[h.off_cls + k];
@@ -598,20 +574,21 @@ __global__ __launch_bounds__(kWtThreads) void k_stream_lpwt(ScanArgs a, int64_t 
     L.init(a, T, h.n_cls, lane, lane_bytes);
     WtMover M;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = WtMover::row_of(lid, i);
-        M.set(lid, i, (lane - lid + r) * lane_bytes, __shfl(L.rv, r), __shfl(L.rfs, r));
-    }
-    const int64_t vhi = (a.vend - 16) & ~(int64_t)15;
+    for (int i = 0; i < 4; ++i) M.set(lid, i, lane_bytes, __shfl(L.rv, WtMover::row_of(lid, i)));
+    // the wave's window of the buffers (uniform) and how far a fetch may reach in it
+    const int64_t wave_lo = (lane - lid) * lane_bytes;
+    const uint8_t* win_in = a.in_v0 + wave_lo;
+    uint8_t* win_out = a.out_v0 + wave_lo;
+    const int64_t room0 = ((a.vend - 16) & ~(int64_t)15) - wave_lo;
     const WtRow irow{tin + lid * kWtPiece, (uint32_t)((lid >> 1) & 3) << 4};
     const WtRow orow{tout + lid * kWtPiece, (uint32_t)((lid >> 1) & 3) << 4};
     uint64_t rows_prev = 0;
     if (__ballot(L.active)) {
         const uint32_t t0 = __builtin_amdgcn_readfirstlane(wt_lds_addr(tin));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wt_glds16(a.in_v0 + M.load_off(i, 0, vhi), t0 + i * 1024);
+        for (int i = 0; i < 4; ++i) wt_glds16(win_in + M.load_off(i, 0, room0), t0 + i * 1024);
         bool st1 = false;                     // the previous iteration issued all four tile stores, unconditionally
-        for (int64_t k = 0;; ++k) {
+        for (int32_t k64 = 0;; k64 += kWtPiece) {       // 64 k (a sub-range never walks 2^31 bytes: see rlimit)
             L.check(a, lane);
             const uint64_t rows = __ballot(L.active);
             if (!rows && !rows_prev) break;
@@ -623,25 +600,30 @@ __global__ __launch_bounds__(kWtThreads) void k_stream_lpwt(ScanArgs a, int64_t 
             const U128 b0 = irow.load(0), b1 = irow.load(1), b2 = irow.load(2), b3 = irow.load(3);
             TRRE_WAIT_LGKM0();                // the rows are in registers: the buffer can take tile k + 1
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wt_glds16(a.in_v0 + M.load_off(i, k + 1, vhi), t0 + i * 1024);
-            const int md = L.mode(k);
+            for (int i = 0; i < 4; ++i) wt_glds16(win_in + M.load_off(i, k64 + kWtPiece, room0), t0 + i * 1024);
+            const int md = L.mode(k64);
             if (L.active) L.front(T, md, b0, b1.x, orow, a.out_v0);
             // the output rows [rv - 64, rv) are complete
             {
                 const uint8_t* slot = tout + lid * 16;
                 const u32x4 ov0 = *reinterpret_cast<const u32x4*>(slot), ov1 = *reinterpret_cast<const u32x4*>(slot + 1024),
                             ov2 = *reinterpret_cast<const u32x4*>(slot + 2048), ov3 = *reinterpret_cast<const u32x4*>(slot + 3072);
-                const bool steady = rows == ~0ull && rows_prev == ~0ull && k >= 3;
+                const bool steady = rows == ~0ull && rows_prev == ~0ull && k64 >= 3 * kWtPiece;
                 if (steady) {
-                    *reinterpret_cast<u32x4*>(a.out_v0 + M.store_off(0, k)) = ov0;
-                    *reinterpret_cast<u32x4*>(a.out_v0 + M.store_off(1, k)) = ov1;
-                    *reinterpret_cast<u32x4*>(a.out_v0 + M.store_off(2, k)) = ov2;
-                    *reinterpret_cast<u32x4*>(a.out_v0 + M.store_off(3, k)) = ov3;
+                    *reinterpret_cast<u32x4*>(win_out + M.store_off(0, k64)) = ov0;
+                    *reinterpret_cast<u32x4*>(win_out + M.store_off(1, k64)) = ov1;
+                    *reinterpret_cast<u32x4*>(win_out + M.store_off(2, k64)) = ov2;
+                    *reinterpret_cast<u32x4*>(win_out + M.store_off(3, k64)) = ov3;
                 } else {
-                    if (M.stores(0, k, rows, rows_prev, lid)) *reinterpret_cast<u32x4*>(a.out_v0 + M.store_off(0, k)) = ov0;
-                    if (M.stores(1, k, rows, rows_prev, lid)) *reinterpret_cast<u32x4*>(a.out_v0 + M.store_off(1, k)) = ov1;
-                    if (M.stores(2, k, rows, rows_prev, lid)) *reinterpret_cast<u32x4*>(a.out_v0 + M.store_off(2, k)) = ov2;
-                    if (M.stores(3, k, rows, rows_prev, lid)) *reinterpret_cast<u32x4*>(a.out_v0 + M.store_off(3, k)) = ov3;
+                    // (the first pieces and the tail: which blocks are whose is worked out on the spot)
+                    if (WtMover::stores(0, k64, rows, rows_prev, lid, __shfl(L.rfs, WtMover::row_of(lid, 0))))
+                        *reinterpret_cast<u32x4*>(win_out + M.store_off(0, k64)) = ov0;
+                    if (WtMover::stores(1, k64, rows, rows_prev, lid, __shfl(L.rfs, WtMover::row_of(lid, 1))))
+                        *reinterpret_cast<u32x4*>(win_out + M.store_off(1, k64)) = ov1;
+                    if (WtMover::stores(2, k64, rows, rows_prev, lid, __shfl(L.rfs, WtMover::row_of(lid, 2))))
+                        *reinterpret_cast<u32x4*>(win_out + M.store_off(2, k64)) = ov2;
+                    if (WtMover::stores(3, k64, rows, rows_prev, lid, __shfl(L.rfs, WtMover::row_of(lid, 3))))
+                        *reinterpret_cast<u32x4*>(win_out + M.store_off(3, k64)) = ov3;
                 }
                 st1 = steady;
             }
@@ -672,8 +654,7 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_redo(ScanArgs a, int6
     }
     if (st) atomicOr(a.status, st);
 }
-int lpw_ent_lds_bytes() { return kLpwEntBytes; }
-void launch_lpwt_kernel(int ent_bytes, bool direct_ent_in_lds, const ScanArgs& a, int64_t lane_bytes, void* stream) {
+void launch_lpw_kernel(int ent_bytes, bool direct_ent_in_lds, const ScanArgs& a, int64_t lane_bytes, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
     const dim3 grid((unsigned)((n_lanes + kWtThreads - 1) / kWtThreads));
@@ -681,26 +662,15 @@ void launch_lpwt_kernel(int ent_bytes, bool direct_ent_in_lds, const ScanArgs& a
     const int ent_room = ent_in_lds ? (ent_bytes + 15) / 16 * 16 : 0;
     const int lds = 256 + ent_room + kWtWaves * 2 * kWtTile;
     if (ent_in_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_lpwt<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL((k_stream_lpwt<true>), grid, dim3(kWtThreads), lds, s, a, lane_bytes, ent_room);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_lpw<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((k_stream_lpw<true>), grid, dim3(kWtThreads), lds, s, a, lane_bytes, ent_room);
     } else {
-        hipLaunchKernelGGL((k_stream_lpwt<false>), grid, dim3(kWtThreads), lds, s, a, lane_bytes, ent_room);
+        hipLaunchKernelGGL((k_stream_lpw<false>), grid, dim3(kWtThreads), lds, s, a, lane_bytes, ent_room);
     }
     const bool ring_lds = reinterpret_cast<const void*>(a.blob) != nullptr && direct_ent_in_lds;
     if (ring_lds) hipLaunchKernelGGL((k_stream_redo<true>), dim3(64), dim3(kDirectThreads), kDirectLds, s, a, lane_bytes);
     else hipLaunchKernelGGL((k_stream_redo<false>), dim3(64), dim3(kDirectThreads), kDirectLdsHot, s, a, lane_bytes);
 }
-void launch_lpw_kernel(bool ent_in_lds, bool direct_ent_in_lds, const ScanArgs& a, int64_t lane_bytes, void* stream) {
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
-    const dim3 grid((unsigned)((n_lanes + kLpwThreads - 1) / kLpwThreads));
-    if (ent_in_lds) hipLaunchKernelGGL((k_stream_lpw<true>), grid, dim3(kLpwThreads), 0, s, a, lane_bytes);
-    else hipLaunchKernelGGL((k_stream_lpw<false>), grid, dim3(kLpwThreads), 0, s, a, lane_bytes);
-    const bool ring_lds = reinterpret_cast<const void*>(a.blob) != nullptr && direct_ent_in_lds;
-    if (ring_lds) hipLaunchKernelGGL((k_stream_redo<true>), dim3(64), dim3(kDirectThreads), kDirectLds, s, a, lane_bytes);
-    else hipLaunchKernelGGL((k_stream_redo<false>), dim3(64), dim3(kDirectThreads), kDirectLdsHot, s, a, lane_bytes);
-}
-
 template <int kMode>
 void launch_direct_t(bool ent_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, hipStream_t s) {
     if (ent_lds) hipLaunchKernelGGL((k_stream_direct<kMode, true>), dim3((unsigned)n_blocks), dim3(kDirectThreads), kDirectLds, s, a, lane_bytes);
