@@ -183,7 +183,7 @@ void run_direct_lp(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
     const StreamView T = direct_view(a);
     const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
-    alignas(16) uint8_t ring[80];
+    alignas(16) uint8_t ring[kRingStride];
     for (int64_t lane = n_lanes - 1; lane >= 0; --lane) {      // any order: lanes write disjoint bytes
         DirectLane L;
         stream_direct_lane<0>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
@@ -193,7 +193,7 @@ void run_direct_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uin
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
     const StreamView T = direct_view(a);
     const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
-    alignas(16) uint8_t ring[80];
+    alignas(16) uint8_t ring[kRingStride];
     std::vector<uint64_t> cnt(n_lanes);
     for (int64_t lane = 0; lane < n_lanes; ++lane) {
         DirectLane L;
@@ -277,7 +277,7 @@ void run_lpw(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
     }
     // second launch: the lanes that touch an end of the input
     const StreamView TS = direct_view(a);
-    alignas(16) uint8_t ring[80];
+    alignas(16) uint8_t ring[kRingStride];
     const int64_t sub = lane_bytes / 64;
     for (int64_t k = 0; k < (int64_t)redo[0] * sub; ++k) {
         DirectLane L;

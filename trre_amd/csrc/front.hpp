@@ -132,8 +132,9 @@ DftTables flatten_dft(const Dft& dft);
 // Stream tables: the scan line loop folded into one deterministic transducer over
 // the raw byte stream (stream_build.cpp).  Entry (64 bit):
 //   [23:0]  next state's row offset (state * n_cls)
-//   [26:24] olen   0..4 bytes held inline in [63:32]; 7 = pooled: [63:32] is the
-//                  offset of a {u32 len, bytes} record in the pool
+//   [26:24] olen   0..4 bytes held inline in [63:32]; 7 = pooled: [55:32] is the
+//                  offset / 4 of a {u32 len, bytes} record in the pool and [63:56]
+//                  min(len, 255) (255: read the record's length)
 //   [27]    after those bytes, also emit the input byte itself
 //   [28]    this byte ends the record ('\n')
 struct StreamLimits {

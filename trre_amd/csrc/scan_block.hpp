@@ -602,7 +602,7 @@ TRRE_HD void stream_lane_gen(const ScanArgs& a, const StreamView& T, uint32_t n_
 // ring and leave as aligned 16-byte stores.
 //   kMode 0: length-preserving (output address = input address), 1: count, 2: emit
 // =============================================================================================
-constexpr int kRingStride = 68;                       // bytes per lane: 17 dwords (odd) -> conflict-free byte writes
+constexpr int kRingStride = 96;                       // bytes per lane (16-byte aligned)
 
 struct DirectLane {
     uint64_t count = 0;        // kMode 1: bytes this lane emits
@@ -642,6 +642,69 @@ TRRE_HD void direct_flush(uint8_t* obase, const uint8_t* ring, uint32_t& of, uin
     if (kAll) while (of < o) { obase[of] = ring[of & 63u]; ++of; }
 }
 
+// ---- output staging of the emit pass ---------------------------------------------------------------
+// A lane's output is a contiguous run of the output buffer that starts at an arbitrary byte.  It is
+// assembled in a small linear LDS buffer whose byte 0 corresponds to a 16-byte aligned output address:
+// every transition appends with ONE unaligned 8-byte LDS store (its up-to-4 inline bytes; bytes beyond
+// the count are overwritten by the next append) plus one byte store for the input byte it may copy, so
+// appending has no branch and no per-byte loop.  After every eight input bytes the complete 16-byte
+// chunks leave as aligned 16-byte stores and the remainder (< 16 bytes) moves to the front
+// (15 + 8 * (8 + 1) bytes plus the reach of the last 8-byte store fit the lane's kRingStride).
+struct Stage {
+    uint8_t* buf;        // kRingStride bytes, 16-byte aligned
+    uint8_t* gq;         // 16-byte aligned output address of buf[0]
+    uint32_t fill;       // buf[skip .. fill) is output not yet stored
+    uint32_t skip;       // leading bytes of buf[0..16) that belong to whoever wrote before this lane's first byte
+};
+TRRE_HD void stage_begin(Stage& s, uint8_t* buf, uint8_t* first_out_byte) {
+    const uintptr_t start = reinterpret_cast<uintptr_t>(first_out_byte);
+    s.buf = buf;
+    s.gq = reinterpret_cast<uint8_t*>(start & ~(uintptr_t)15);
+    s.skip = s.fill = (uint32_t)(start & 15u);
+}
+TRRE_HD void stage_put8(Stage& s, uint32_t at, uint64_t v) { __builtin_memcpy(s.buf + at, &v, 8); }
+// exactly len (1..8) bytes of v at `at`
+TRRE_HD void stage_put_exact(Stage& s, uint32_t at, uint64_t v, uint32_t len) {
+    if (len >= 4u) {
+        const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> (8u * (len - 4u)));
+        __builtin_memcpy(s.buf + at, &lo, 4);
+        __builtin_memcpy(s.buf + at + len - 4u, &hi, 4);
+    } else {
+        for (uint32_t i = 0; i < len; ++i) s.buf[at + i] = (uint8_t)(v >> (8u * i));
+    }
+}
+TRRE_HD void stage_store_chunk(Stage& s, uint32_t c) {
+    if (c == 0 && s.skip) {
+        for (uint32_t i = s.skip; i < 16u; ++i) s.gq[i] = s.buf[i];      // once per lane: the chunk it shares with its predecessor
+    } else {
+        *reinterpret_cast<U128*>(s.gq + 16u * c) = *reinterpret_cast<const U128*>(s.buf + 16u * c);
+    }
+}
+template <bool kAll>
+TRRE_HD void stage_flush(Stage& s) {
+    const uint32_t k = s.fill >> 4;                    // complete chunks (at most 5 between flushes)
+    if (TRRE_WAVE_ANY(k > 0u)) {
+        if (k > 0u) stage_store_chunk(s, 0);
+        if (TRRE_WAVE_ANY(k > 1u)) {
+            if (k > 1u) stage_store_chunk(s, 1);
+            if (TRRE_WAVE_ANY(k > 2u)) {
+                for (uint32_t c = 2; c < k; ++c) stage_store_chunk(s, c);
+            }
+        }
+        if (k > 0u) {
+            const U128 rest = *reinterpret_cast<const U128*>(s.buf + 16u * k);
+            *reinterpret_cast<U128*>(s.buf) = rest;
+            s.gq += 16u * k;
+            s.fill -= 16u * k;
+            s.skip = 0;
+        }
+    }
+    if (kAll) {
+        for (uint32_t i = s.skip; i < s.fill; ++i) s.gq[i] = s.buf[i];
+        s.skip = s.fill;
+    }
+}
+
 template <int kMode>
 TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, int64_t lane, int64_t lane_bytes,
                                 uint8_t* ring, uint64_t out_base, DirectLane& L, uint32_t& status) {
@@ -653,20 +716,18 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
     else if (lo < a.vbeg) row = kSkipState * n_cls;                  // filler then '\n' right before the input
     else row = (lo == a.vbeg || a.in_v0[lo - 1] == (uint8_t)'\n') ? 0u : kSkipState * n_cls;
 
-    // output cursor as a 32-bit offset from a 64-byte aligned base address
-    uint8_t* obase;
-    uint32_t o;
+    // kMode 0: output cursor as a 32-bit offset from a 64-byte aligned base address, through a 64-byte ring
+    uint8_t* obase = nullptr;
+    uint32_t o = 0;
     if (kMode == 0) {
         const uintptr_t start = reinterpret_cast<uintptr_t>(a.out_v0 + lo);
-        obase = reinterpret_cast<uint8_t*>(start & ~(uintptr_t)63);
-        o = (uint32_t)(start & 63u);
-    } else {
-        const uintptr_t start = reinterpret_cast<uintptr_t>(a.out) + out_base;
         obase = reinterpret_cast<uint8_t*>(start & ~(uintptr_t)63);
         o = (uint32_t)(start & 63u);
     }
     const uint32_t o_of_lo = o;           // kMode 0: offset that corresponds to position lo
     uint32_t of = o;                      // everything below `of` has left the ring
+    Stage S{};                            // kMode 2
+    if (kMode == 2) stage_begin(S, ring, a.out + out_base);
     uint64_t cnt = 0;
     uint32_t seen = 0;
 
@@ -680,20 +741,53 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
         for (int d = 0; d < 4; ++d) {
             const uint32_t w = wd[d];
             const uint8_t kk[4] = {T.cls[w & 0xffu], T.cls[(w >> 8) & 0xffu], T.cls[(w >> 16) & 0xffu], T.cls[w >> 24]};
-            if (kMode == 2) {                         // expanding programs can fill the ring inside a block
-                if (TRRE_WAVE_ANY(o - of >= 32u)) direct_flush<false>(obase, ring, of, o);
-            }
+            // kMode 2: pooled texts of up to 8 bytes are fetched when met and put in place after the dword
+            // (their length is in the entry, so the cursor moves on without waiting for the text)
+            uint64_t ptext[4] = {0, 0, 0, 0};
+            uint32_t pat[4] = {0, 0, 0, 0}, plen[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint8_t c = (uint8_t)(w >> (8 * j));
                 const uint64_t e = str_entry(T, row + kk[j]);
                 const uint32_t elo = (uint32_t)e, ehi = (uint32_t)(e >> 32);
                 const uint32_t ol = str_olen(elo), cc = (elo >> 27) & 1u;
-                uint32_t n = ol + cc;
                 if (kMode == 1) {
-                    if (TRRE_WAVE_ANY(ol == 7u)) { if (ol == 7u) n = str_count(T, elo, ehi); }
+                    uint32_t n = (ol == 7u ? ehi >> 24 : ol) + cc;
+                    if (TRRE_WAVE_ANY(ol == 7u && n - cc == 255u)) { if (ol == 7u && n - cc == 255u) n = str_pool_len(T, ehi) + cc; }
                     cnt += n;
+                } else if (kMode == 2) {
+                    uint32_t len = ol;
+                    stage_put8(S, S.fill, (uint64_t)ehi);                 // inline bytes (harmless for a pooled entry)
+                    if (TRRE_WAVE_ANY(ol == 7u)) {
+                        if (ol == 7u) {
+                            len = ehi >> 24;
+                            const uint8_t* r = T.pool + str_pool_off(ehi);
+                            if (len <= 8u) {
+                                __builtin_memcpy(&ptext[j], r + 4, 8);
+                                pat[j] = S.fill;
+                                plen[j] = len;
+                            } else {
+                                // long replacement text: empty the staging buffer (texts still on their way
+                                // first), then write straight to memory
+                                if (len == 255u) len = str_pool_len(T, ehi);
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    if (plen[q]) stage_put_exact(S, pat[q], ptext[q], plen[q]);
+                                    plen[q] = 0;
+                                }
+                                stage_flush<false>(S);
+                                stage_flush<true>(S);
+                                uint8_t* g = S.gq + S.fill;
+                                for (uint32_t i = 0; i < len; ++i) g[i] = r[4 + i];
+                                stage_begin(S, S.buf, g + len);
+                                len = 0;
+                            }
+                        }
+                    }
+                    S.buf[S.fill + len] = c;                              // (overwritten by the next append unless copied)
+                    S.fill += len + cc;
                 } else {
+                    uint32_t n = ol + cc;
                     if (n) ring[o & 63u] = ol ? (uint8_t)ehi : c;
                     if (TRRE_WAVE_ANY(n >= 2u)) {
                         if (n >= 2u) {
@@ -702,7 +796,7 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
                                 for (uint32_t i = 1; i < ol; ++i) { ring[(o + i) & 63u] = (uint8_t)x; x >>= 8; }
                                 if (cc) ring[(o + ol) & 63u] = c;
                             } else {
-                                const uint8_t* r = T.pool + ehi;
+                                const uint8_t* r = T.pool + str_pool_off(ehi);
                                 const uint32_t len = str_pool_len(T, ehi);
                                 if (len <= 40u) {
                                     // replacement text of ordinary length goes through the ring like any output
@@ -737,10 +831,19 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
                     if (p1 >= hi) row = done_row;
                 }
             }
+            if (kMode == 2) {
+                if (TRRE_WAVE_ANY((plen[0] | plen[1] | plen[2] | plen[3]) != 0u)) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (plen[j]) stage_put_exact(S, pat[j], ptext[j], plen[j]);
+                }
+                if (d & 1) stage_flush<false>(S);
+            }
         }
-        if (kMode != 1) direct_flush<false>(obase, ring, of, o);
+        if (kMode == 0) direct_flush<false>(obase, ring, of, o);
     }
-    if (kMode != 1) direct_flush<true>(obase, ring, of, o);
+    if (kMode == 0) direct_flush<true>(obase, ring, of, o);
+    if (kMode == 2) stage_flush<true>(S);
     if (kMode == 0 && (seen & kStrNul)) status |= kStNul;
     L.count = cnt;
 }

@@ -203,8 +203,10 @@ constexpr uint32_t kStrCopyC = 1u << 27, kStrEol = 1u << 28;
 
 TRRE_HD uint32_t str_olen(uint32_t lo) { return (lo >> 24) & 7u; }
 TRRE_HD uint32_t str_next(uint32_t lo) { return lo & 0xffffffu; }
+TRRE_HD uint32_t str_pool_off(uint32_t hi) { return (hi & 0xffffffu) << 2; }   // records are 4-byte aligned: {u32 len, bytes}
 TRRE_HD uint32_t str_pool_len(const StreamView& T, uint32_t hi) {
-    return *reinterpret_cast<const uint32_t*>(T.pool + hi);      // records are 4-byte aligned: {u32 len, bytes}
+    const uint32_t l = hi >> 24;
+    return l != 255u ? l : *reinterpret_cast<const uint32_t*>(T.pool + str_pool_off(hi));
 }
 // number of bytes one transition emits
 TRRE_HD uint32_t str_count(const StreamView& T, uint32_t lo, uint32_t hi) {
@@ -225,7 +227,7 @@ TRRE_HD int64_t str_emit(const StreamView& T, uint8_t* dst, int64_t o, uint32_t 
         }
         return o + n;
     }
-    const uint8_t* r = T.pool + hi;
+    const uint8_t* r = T.pool + str_pool_off(hi);
     const uint32_t len = str_pool_len(T, hi);
     for (uint32_t k = 0; k < len; ++k) dst[o + k] = r[4 + k];
     if (cc) dst[o + len] = c;

@@ -312,7 +312,8 @@ private:
                         for (int b = 0; b < 4; ++b) t.pool.push_back((uint8_t)(len >> (8 * b)));
                         t.pool.insert(t.pool.end(), x.out.begin(), x.out.end());
                     }
-                    hi = hit->second;
+                    if (hit->second >= (1u << 26)) throw GiveUp();
+                    hi = (uint64_t)(hit->second >> 2) | (uint64_t)std::min<size_t>(x.out.size(), 255) << 24;
                 }
                 if (x.copy_c) lo |= 1ull << 27;
                 if (x.eol) lo |= 1ull << 28;
@@ -334,7 +335,7 @@ private:
             }
         }
         while (t.pool.size() % 4) t.pool.push_back(0);
-        for (int k = 0; k < 4; ++k) t.pool.push_back(0);   // dword reads of a record's tail stay inside the pool
+        for (int k = 0; k < 8; ++k) t.pool.push_back(0);   // 8-byte reads of a record's text stay inside the pool
         t.ok = true;
         if (lp) build_window_form(t, rep);
         if (lp) t.flags |= kFlagLengthPreserving;
