@@ -24,13 +24,18 @@ for c in FETCH_SIZE WRITE_SIZE; do
     run pmc_$c --pmc $c -d gpurun_out/raw/pmc_$c -o p -- python bench.py --steps 4 --warmup 1 --no-cpu --no-extras
     python tools/rocpd_summary.py gpurun_out/raw/pmc_$c/p_results.db trre > $out/${tag}_bench_pmc_$c.txt
 done
-# 3. the general kernels on the cfg4 pattern (NFT) and an expanding pattern
-for spec in "cfg4_nft|(cat:dog|dog:cat)|nft" "expand_dft|a:xyz|dft"; do
-    IFS='|' read -r name pat1 pat2 eng <<< "$spec"
-    if [ -z "$eng" ]; then eng=$pat2; pat=$pat1; else pat="$pat1|$pat2"; fi
-    run st_$name --kernel-trace --stats -d gpurun_out/raw/st_$name -o s -- python tools/kbench.py --pattern "$pat" --engine $eng --steps 5
+# 3. the stream kernels: the cfg4 pattern (NFT, window kernel), an expanding pattern and the cfg5-style
+#    dictionary (count + emit passes)
+for spec in "cfg4_nft|--pattern (cat:dog|dog:cat) --engine nft" "expand_dft|--pattern a:xyz --engine dft" "dict1000_dft|--dict 1000 --engine dft"; do
+    name=${spec%%|*}; kargs=${spec#*|}
+    run st_$name --kernel-trace --stats -d gpurun_out/raw/st_$name -o s -- python tools/kbench.py $kargs --steps 5
     python tools/rocpd_summary.py gpurun_out/raw/st_$name/s_results.db trre > $out/${tag}_${name}_kernel_stats.txt
     grep '^pattern' gpurun_out/raw/st_$name.log >> $out/${tag}_${name}_kernel_stats.txt
+done
+# 4. HBM traffic of the window kernel on the cfg4 pattern
+for c in FETCH_SIZE WRITE_SIZE; do
+    run pmcw_$c --pmc $c -d gpurun_out/raw/pmcw_$c -o p -- python tools/kbench.py --pattern "(cat:dog|dog:cat)" --engine nft --steps 3
+    python tools/rocpd_summary.py gpurun_out/raw/pmcw_$c/p_results.db k_stream_lpw > $out/${tag}_cfg4_nft_pmc_$c.txt
 done
 rm -rf gpurun_out/raw
 ls -la $out

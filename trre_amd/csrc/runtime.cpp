@@ -60,6 +60,7 @@ struct Pending {
     bool launched = false;
     bool timed = false;
     int count = 0;          // launches in the current batch
+    const uint64_t* total_at = nullptr;   // general families: where the launch leaves its output size
 };
 
 template <class T>
@@ -321,23 +322,23 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
         launch_direct_kernel(1, direct_ent_lds, args, lane_bytes, n_chunks, stream);
         launch_chunk_scan(st->d_chunk_total, st->d_chunk_base, n_chunks, stream);
         launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream);
-        HIP_TRY(hipMemcpyAsync(st->h_status + 2, st->d_chunk_base + n_chunks, 8, hipMemcpyDeviceToHost, stream));
+        pd.total_at = st->d_chunk_base + n_chunks;
     } else if (family == TRRE_KERNEL_STREAM_LP) {
         launch_stream_kernel(0, ent_lds, args, n_chunks, stream);
     } else if (family == TRRE_KERNEL_STREAM_GEN) {
         launch_stream_kernel(1, ent_lds, args, n_chunks, stream);
         launch_chunk_scan(st->d_chunk_total, st->d_chunk_base, n_chunks, stream);
         launch_stream_kernel(2, ent_lds, args, n_chunks, stream);
-        HIP_TRY(hipMemcpyAsync(st->h_status + 2, st->d_chunk_base + n_chunks, 8, hipMemcpyDeviceToHost, stream));
+        pd.total_at = st->d_chunk_base + n_chunks;
     } else {
         launch_tile_kernel(1, p->engine, p->mask_bytes, args, n_chunks, stream);
         launch_chunk_scan(st->d_chunk_total, st->d_chunk_base, n_chunks, stream);
         launch_tile_kernel(2, p->engine, p->mask_bytes, args, n_chunks, stream);
-        HIP_TRY(hipMemcpyAsync(st->h_status + 2, st->d_chunk_base + n_chunks, 8, hipMemcpyDeviceToHost, stream));
+        pd.total_at = st->d_chunk_base + n_chunks;
     }
     HIP_TRY(hipGetLastError());
-    if (p->profiling) HIP_TRY(hipEventRecord(st->ev1, stream));
-    HIP_TRY(hipMemcpyAsync(st->h_status, st->d_status, 4, hipMemcpyDeviceToHost, stream));
+    // (the status word, the output size and the closing timing event are fetched by finish(): nothing
+    // sits between the kernels of back-to-back launches)
     pd.launched = true;
     pd.count += 1;
     return TRRE_OK;
@@ -354,6 +355,9 @@ int finish(trre_prog* p, size_t* out_len) {
         return fail(TRRE_E_CAPACITY, "error: output buffer too small");
     }
     DeviceState* st = &p->dev[pd.device];
+    if (pd.timed) HIP_TRY(hipEventRecord(st->ev1, pd.stream));
+    HIP_TRY(hipMemcpyAsync(st->h_status, st->d_status, 4, hipMemcpyDeviceToHost, pd.stream));
+    if (pd.total_at) HIP_TRY(hipMemcpyAsync(st->h_status + 2, pd.total_at, 8, hipMemcpyDeviceToHost, pd.stream));
     HIP_TRY(hipStreamSynchronize(pd.stream));
     if (pd.timed) {
         float ms = 0;
