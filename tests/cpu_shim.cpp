@@ -177,6 +177,7 @@ StreamView direct_view(const ScanArgs& a) {
     T.cls = a.blob + h.off_cls;
     T.ent = reinterpret_cast<const uint64_t*>(a.blob + h.off_ent);
     T.pool = a.blob + h.off_pool;
+    T.long_pool = h.max_out >= 255u;
     return T;
 }
 void run_direct_lp(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {

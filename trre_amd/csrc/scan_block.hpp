@@ -602,7 +602,7 @@ TRRE_HD void stream_lane_gen(const ScanArgs& a, const StreamView& T, uint32_t n_
 // ring and leave as aligned 16-byte stores.
 //   kMode 0: length-preserving (output address = input address), 1: count, 2: emit
 // =============================================================================================
-constexpr int kRingStride = 96;                       // bytes per lane (16-byte aligned)
+constexpr int kRingStride = 100;                      // bytes per lane: 25 dwords (odd), so the lanes' accesses at equal offsets hit distinct banks
 
 struct DirectLane {
     uint64_t count = 0;        // kMode 1: bytes this lane emits
@@ -650,8 +650,19 @@ TRRE_HD void direct_flush(uint8_t* obase, const uint8_t* ring, uint32_t& of, uin
 // appending has no branch and no per-byte loop.  After every eight input bytes the complete 16-byte
 // chunks leave as aligned 16-byte stores and the remainder (< 16 bytes) moves to the front
 // (15 + 8 * (8 + 1) bytes plus the reach of the last 8-byte store fit the lane's kRingStride).
+// Lanes are an odd number of dwords apart and the chunk moves are done in dwords.
+TRRE_HD U128 lds_ld16(const uint8_t* p) {              // 4-byte aligned
+    U128 q;
+    q.x = *reinterpret_cast<const uint32_t*>(p); q.y = *reinterpret_cast<const uint32_t*>(p + 4);
+    q.z = *reinterpret_cast<const uint32_t*>(p + 8); q.w = *reinterpret_cast<const uint32_t*>(p + 12);
+    return q;
+}
+TRRE_HD void lds_st16(uint8_t* p, const U128& q) {
+    *reinterpret_cast<uint32_t*>(p) = q.x; *reinterpret_cast<uint32_t*>(p + 4) = q.y;
+    *reinterpret_cast<uint32_t*>(p + 8) = q.z; *reinterpret_cast<uint32_t*>(p + 12) = q.w;
+}
 struct Stage {
-    uint8_t* buf;        // kRingStride bytes, 16-byte aligned
+    uint8_t* buf;        // kRingStride bytes, 4-byte aligned
     uint8_t* gq;         // 16-byte aligned output address of buf[0]
     uint32_t fill;       // buf[skip .. fill) is output not yet stored
     uint32_t skip;       // leading bytes of buf[0..16) that belong to whoever wrote before this lane's first byte
@@ -677,7 +688,7 @@ TRRE_HD void stage_store_chunk(Stage& s, uint32_t c) {
     if (c == 0 && s.skip) {
         for (uint32_t i = s.skip; i < 16u; ++i) s.gq[i] = s.buf[i];      // once per lane: the chunk it shares with its predecessor
     } else {
-        *reinterpret_cast<U128*>(s.gq + 16u * c) = *reinterpret_cast<const U128*>(s.buf + 16u * c);
+        *reinterpret_cast<U128*>(s.gq + 16u * c) = lds_ld16(s.buf + 16u * c);
     }
 }
 template <bool kAll>
@@ -692,8 +703,8 @@ TRRE_HD void stage_flush(Stage& s) {
             }
         }
         if (k > 0u) {
-            const U128 rest = *reinterpret_cast<const U128*>(s.buf + 16u * k);
-            *reinterpret_cast<U128*>(s.buf) = rest;
+            const U128 rest = lds_ld16(s.buf + 16u * k);
+            lds_st16(s.buf, rest);
             s.gq += 16u * k;
             s.fill -= 16u * k;
             s.skip = 0;
@@ -705,12 +716,15 @@ TRRE_HD void stage_flush(Stage& s) {
     }
 }
 
-template <int kMode>
+// kHot: part of the table is mirrored in LDS (StreamView::ent_hot); otherwise every entry comes from T.ent
+template <int kMode, bool kHot = true>
 TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, int64_t lane, int64_t lane_bytes,
                                 uint8_t* ring, uint64_t out_base, DirectLane& L, uint32_t& status) {
     const uint32_t done_row = kDoneState * n_cls;
     int64_t lo = lane * lane_bytes, hi = lo + lane_bytes;
     if (hi > a.vend) hi = a.vend;
+    // end of the lane's sub-range as a 32-bit offset from lo (the count and emit passes stop branch-free)
+    const uint32_t rhi = (uint32_t)(hi > lo ? hi - lo : 0);
     uint32_t row;
     if (lo >= hi) row = done_row;
     else if (lo < a.vbeg) row = kSkipState * n_cls;                  // filler then '\n' right before the input
@@ -731,11 +745,17 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
     uint64_t cnt = 0;
     uint32_t seen = 0;
 
-    U128 blk = direct_load(a, lo), nxt = direct_load(a, lo + 16);
-    for (int64_t v = lo; TRRE_WAVE_ANY(row != done_row); v += 16) {
-        const U128 cur = blk;
-        blk = nxt;
-        nxt = direct_load(a, v + 32);
+    const int64_t vlast = (a.vend - 1) & ~(int64_t)15;        // the last readable aligned block
+    // One 16-byte block at a time from two alternating register buffers: a buffer is refilled right after
+    // its block has been walked and used one block later, so the load has a whole block of walking to
+    // land and no register copies (which would wait for it) are needed.  Away from the two ends of the
+    // input a refill is a bare load; only waves that reach an end take the version that patches bytes.
+    auto fetch = [&](int64_t vn) -> U128 {
+        U128 q = *reinterpret_cast<const U128*>(a.in_v0 + (vn < vlast ? vn : vlast));
+        if (TRRE_WAVE_ANY(vn < a.vbeg || vn + 16 > a.vend - 1)) q = direct_load(a, vn);
+        return q;
+    };
+    auto walk = [&](const U128& cur, const int64_t v) {
         const uint32_t wd[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
@@ -748,16 +768,19 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint8_t c = (uint8_t)(w >> (8 * j));
-                const uint64_t e = str_entry(T, row + kk[j]);
+                const uint64_t e = kHot ? str_entry(T, row + kk[j]) : T.ent[row + kk[j]];
                 const uint32_t elo = (uint32_t)e, ehi = (uint32_t)(e >> 32);
                 const uint32_t ol = str_olen(elo), cc = (elo >> 27) & 1u;
                 if (kMode == 1) {
                     uint32_t n = (ol == 7u ? ehi >> 24 : ol) + cc;
-                    if (TRRE_WAVE_ANY(ol == 7u && n - cc == 255u)) { if (ol == 7u && n - cc == 255u) n = str_pool_len(T, ehi) + cc; }
+                    if (T.long_pool) {
+                        if (TRRE_WAVE_ANY(ol == 7u && n - cc == 255u)) { if (ol == 7u && n - cc == 255u) n = str_pool_len(T, ehi) + cc; }
+                    }
                     cnt += n;
                 } else if (kMode == 2) {
                     uint32_t len = ol;
-                    stage_put8(S, S.fill, (uint64_t)ehi);                 // inline bytes (harmless for a pooled entry)
+                    // inline bytes (an unaligned LDS store is expensive per active lane: only the lanes that have some)
+                    if (TRRE_WAVE_ANY(ol != 0u)) { if (ol != 0u) stage_put8(S, S.fill, (uint64_t)ehi); }
                     if (TRRE_WAVE_ANY(ol == 7u)) {
                         if (ol == 7u) {
                             len = ehi >> 24;
@@ -822,13 +845,18 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
                 }
                 row = str_next(elo);
                 seen |= elo;
-                if (elo & kStrEol) {
-                    const int64_t p1 = v + 4 * d + j + 1;
-                    if (kMode == 0) {
+                if (kMode == 0) {
+                    if (elo & kStrEol) {
+                        const int64_t p1 = v + 4 * d + j + 1;
                         const uint32_t sync = o_of_lo + (uint32_t)(p1 - lo);
                         if (o != sync) { o = sync; of = sync; }       // leaving SKIP (or after a NUL: launch is void)
+                        if (p1 >= hi) row = done_row;
                     }
-                    if (p1 >= hi) row = done_row;
+                } else {
+                    // a record end at or beyond the end of the sub-range ends the lane (a lane walks far less
+                    // than 4 GiB: its sub-range plus the rest of one line, or it stops at the end of the input)
+                    const uint32_t p1 = (uint32_t)(v - lo) + 4u * d + j + 1u;
+                    row = ((elo & kStrEol) && p1 >= rhi) ? done_row : row;
                 }
             }
             if (kMode == 2) {
@@ -841,6 +869,14 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
             }
         }
         if (kMode == 0) direct_flush<false>(obase, ring, of, o);
+    };
+    U128 blk0 = direct_load(a, lo), blk1 = direct_load(a, lo + 16);
+    for (int64_t v = lo; TRRE_WAVE_ANY(row != done_row); v += 32) {
+        walk(blk0, v);
+        blk0 = fetch(v + 32);
+        if (!TRRE_WAVE_ANY(row != done_row)) break;
+        walk(blk1, v + 16);
+        blk1 = fetch(v + 48);
     }
     if (kMode == 0) direct_flush<true>(obase, ring, of, o);
     if (kMode == 2) stage_flush<true>(S);

@@ -194,6 +194,7 @@ struct StreamView {
     // also kept in LDS; deeper states are read through L2
     const uint64_t* ent_hot = nullptr;
     uint32_t hot_limit = 0;
+    uint32_t long_pool = 1;  // 0: no pooled text reaches 255 bytes, i.e. every pooled entry carries its exact length
 };
 TRRE_HD uint64_t str_entry(const StreamView& T, uint32_t idx) {
     if (idx < T.hot_limit) return T.ent_hot[idx];

@@ -332,6 +332,9 @@ __global__ __launch_bounds__(G::THREADS) void k_stream_emit(ScanArgs a) {
 
 // ------------------------------------------------------------------------------------------
 // Direct stream kernels: no tile, one long sub-range per lane (see stream_direct_lane).
+#ifndef TRRE_DIRECT_HOT
+#define TRRE_DIRECT_HOT 1
+#endif
 constexpr int kDirectThreads = 256;
 constexpr int kDirectEntBytes = 2048;      // table rows in LDS when they all fit
 constexpr int kDirectHotBytes = 12288;     // otherwise: the shallow states' rows
@@ -363,6 +366,7 @@ __device__ __forceinline__ StreamView direct_stage(const ScanArgs& a, uint8_t* s
     T.cls = smem;
     T.ent = kLdsEnt ? reinterpret_cast<const uint64_t*>(smem + 256) : reinterpret_cast<const uint64_t*>(a.blob + h.off_ent);
     T.pool = a.blob + h.off_pool;
+    T.long_pool = h.max_out >= 255u;
     (void)tab;
     return T;
 }
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_direct(ScanArgs a, in
             return;
         }
     }
-    stream_direct_lane<kMode>(a, T, n_cls, lane, lane_bytes, ring, base, L, st);
+    stream_direct_lane<kMode, !kLdsEnt && TRRE_DIRECT_HOT>(a, T, n_cls, lane, lane_bytes, ring, base, L, st);
     if (kMode == 1) {
         uint64_t* part = reinterpret_cast<uint64_t*>(smem + kLds - 64);
         if (L.count > 0xffffffffull) { st |= kStCapacity; L.count = 0xffffffffull; }
