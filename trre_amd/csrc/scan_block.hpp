@@ -602,7 +602,7 @@ TRRE_HD void stream_lane_gen(const ScanArgs& a, const StreamView& T, uint32_t n_
 // ring and leave as aligned 16-byte stores.
 //   kMode 0: length-preserving (output address = input address), 1: count, 2: emit
 // =============================================================================================
-constexpr int kRingStride = 100;                      // bytes per lane: 25 dwords (odd), so the lanes' accesses at equal offsets hit distinct banks
+constexpr int kRingStride = 116;                      // bytes per lane: 29 dwords (odd), so the lanes' accesses at equal offsets hit distinct banks
 
 struct DirectLane {
     uint64_t count = 0;        // kMode 1: bytes this lane emits
@@ -644,13 +644,15 @@ TRRE_HD void direct_flush(uint8_t* obase, const uint8_t* ring, uint32_t& of, uin
 
 // ---- output staging of the emit pass ---------------------------------------------------------------
 // A lane's output is a contiguous run of the output buffer that starts at an arbitrary byte.  It is
-// assembled in a small linear LDS buffer whose byte 0 corresponds to a 16-byte aligned output address:
-// every transition appends with ONE unaligned 8-byte LDS store (its up-to-4 inline bytes; bytes beyond
-// the count are overwritten by the next append) plus one byte store for the input byte it may copy, so
-// appending has no branch and no per-byte loop.  After every eight input bytes the complete 16-byte
-// chunks leave as aligned 16-byte stores and the remainder (< 16 bytes) moves to the front
-// (15 + 8 * (8 + 1) bytes plus the reach of the last 8-byte store fit the lane's kRingStride).
-// Lanes are an odd number of dwords apart and the chunk moves are done in dwords.
+// assembled in a small linear LDS buffer whose byte 0 corresponds to a 16-byte aligned output address.
+// Appending is branch-free: the bytes of the dword being filled live in a 64-bit register window `acc`;
+// a transition ORs its up-to-5 bytes (at most 4 inline bytes and the input byte it may copy) in at the
+// fill position, the window's two dwords are stored (aligned) over the buffer, and the window moves on
+// by as many dwords as were completed.  After every eight input bytes the complete 32-byte sectors leave
+// as pairs of aligned 16-byte stores (whole sectors: a 16-byte store on its own is a partial-sector
+// write, measured at 2.2x write amplification) and the remainder (< 32 bytes) moves to the front.
+// 31 + 8 * 9 bytes plus the reach of the window fit the lane's kRingStride; lanes are an odd number of
+// dwords apart (equal offsets of different lanes hit distinct banks) and the moves are done in dwords.
 TRRE_HD U128 lds_ld16(const uint8_t* p) {              // 4-byte aligned
     U128 q;
     q.x = *reinterpret_cast<const uint32_t*>(p); q.y = *reinterpret_cast<const uint32_t*>(p + 4);
@@ -663,19 +665,36 @@ TRRE_HD void lds_st16(uint8_t* p, const U128& q) {
 }
 struct Stage {
     uint8_t* buf;        // kRingStride bytes, 4-byte aligned
-    uint8_t* gq;         // 16-byte aligned output address of buf[0]
-    uint32_t fill;       // buf[skip .. fill) is output not yet stored
-    uint32_t skip;       // leading bytes of buf[0..16) that belong to whoever wrote before this lane's first byte
+    uint8_t* gq;         // 32-byte aligned output address of buf[0]
+    uint64_t acc;        // bytes [wp, wp + pb) of the buffer (and zeros above them)
+    uint32_t wp;         // offset of the dword being filled (multiple of 4)
+    uint32_t pb;         // bytes of it that are filled (0..3)
+    uint32_t skip;       // leading bytes of buf[0..32) that belong to whoever wrote before this lane's first byte
+    TRRE_HD uint32_t fill() const { return wp + pb; }
 };
+// start (or restart) at an arbitrary output address; bytes below it in its 16-byte chunk are not ours
 TRRE_HD void stage_begin(Stage& s, uint8_t* buf, uint8_t* first_out_byte) {
     const uintptr_t start = reinterpret_cast<uintptr_t>(first_out_byte);
     s.buf = buf;
-    s.gq = reinterpret_cast<uint8_t*>(start & ~(uintptr_t)15);
-    s.skip = s.fill = (uint32_t)(start & 15u);
+    s.gq = reinterpret_cast<uint8_t*>(start & ~(uintptr_t)31);
+    s.skip = (uint32_t)(start & 31u);
+    s.wp = s.skip & ~3u;
+    s.pb = s.skip & 3u;
+    s.acc = 0;
 }
-TRRE_HD void stage_put8(Stage& s, uint32_t at, uint64_t v) { __builtin_memcpy(s.buf + at, &v, 8); }
-// exactly len (1..8) bytes of v at `at`
-TRRE_HD void stage_put_exact(Stage& s, uint32_t at, uint64_t v, uint32_t len) {
+// append the low n (0..5) bytes of v; the bytes of v above n must be zero
+TRRE_HD void stage_append(Stage& s, uint64_t v, uint32_t n) {
+    s.acc |= v << (8u * s.pb);
+    *reinterpret_cast<uint32_t*>(s.buf + s.wp) = (uint32_t)s.acc;
+    *reinterpret_cast<uint32_t*>(s.buf + s.wp + 4) = (uint32_t)(s.acc >> 32);
+    const uint32_t t = s.pb + n, adv = t >> 2;          // 0..2 dwords completed
+    s.pb = t & 3u;
+    s.wp += 4u * adv;
+    s.acc = adv == 0u ? s.acc : (adv == 1u ? s.acc >> 32 : 0ull);
+}
+// exactly len (1..8) bytes of v at the fill position, written to the buffer directly (rare path)
+TRRE_HD void stage_append_text(Stage& s, uint64_t v, uint32_t len) {
+    const uint32_t at = s.fill();
     if (len >= 4u) {
         const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> (8u * (len - 4u)));
         __builtin_memcpy(s.buf + at, &lo, 4);
@@ -683,41 +702,46 @@ TRRE_HD void stage_put_exact(Stage& s, uint32_t at, uint64_t v, uint32_t len) {
     } else {
         for (uint32_t i = 0; i < len; ++i) s.buf[at + i] = (uint8_t)(v >> (8u * i));
     }
+    const uint32_t f = at + len;
+    s.wp = f & ~3u;
+    s.pb = f & 3u;
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(s.buf + s.wp);      // the window again, from the buffer
+    s.acc = s.pb ? (uint64_t)(w & (0xffffffffu >> (32u - 8u * s.pb))) : 0ull;
 }
-TRRE_HD void stage_store_chunk(Stage& s, uint32_t c) {
+TRRE_HD void stage_store_sector(Stage& s, uint32_t c) {
     if (c == 0 && s.skip) {
-        for (uint32_t i = s.skip; i < 16u; ++i) s.gq[i] = s.buf[i];      // once per lane: the chunk it shares with its predecessor
+        for (uint32_t i = s.skip; i < 32u; ++i) s.gq[i] = s.buf[i];      // once per lane: the sector it shares with its predecessor
     } else {
-        *reinterpret_cast<U128*>(s.gq + 16u * c) = lds_ld16(s.buf + 16u * c);
+        const U128 q0 = lds_ld16(s.buf + 32u * c), q1 = lds_ld16(s.buf + 32u * c + 16u);
+        *reinterpret_cast<U128*>(s.gq + 32u * c) = q0;
+        *reinterpret_cast<U128*>(s.gq + 32u * c + 16u) = q1;
     }
 }
 template <bool kAll>
 TRRE_HD void stage_flush(Stage& s) {
-    const uint32_t k = s.fill >> 4;                    // complete chunks (at most 5 between flushes)
+    const uint32_t k = s.wp >> 5;                      // complete sectors (at most 3 between flushes)
     if (TRRE_WAVE_ANY(k > 0u)) {
-        if (k > 0u) stage_store_chunk(s, 0);
+        if (k > 0u) stage_store_sector(s, 0);
         if (TRRE_WAVE_ANY(k > 1u)) {
-            if (k > 1u) stage_store_chunk(s, 1);
-            if (TRRE_WAVE_ANY(k > 2u)) {
-                for (uint32_t c = 2; c < k; ++c) stage_store_chunk(s, c);
-            }
+            for (uint32_t c = 1; c < k; ++c) stage_store_sector(s, c);
         }
         if (k > 0u) {
-            const U128 rest = lds_ld16(s.buf + 16u * k);
-            lds_st16(s.buf, rest);
-            s.gq += 16u * k;
-            s.fill -= 16u * k;
+            const U128 r0 = lds_ld16(s.buf + 32u * k), r1 = lds_ld16(s.buf + 32u * k + 16u);
+            lds_st16(s.buf, r0);
+            lds_st16(s.buf + 16, r1);
+            s.gq += 32u * k;
+            s.wp -= 32u * k;
             s.skip = 0;
         }
     }
     if (kAll) {
-        for (uint32_t i = s.skip; i < s.fill; ++i) s.gq[i] = s.buf[i];
-        s.skip = s.fill;
+        const uint32_t f = s.fill();                   // (the window is in the buffer: every append stores it)
+        for (uint32_t i = s.skip; i < f; ++i) s.gq[i] = s.buf[i];
+        s.skip = f;
     }
 }
 
-// kHot: part of the table is mirrored in LDS (StreamView::ent_hot); otherwise every entry comes from T.ent
-template <int kMode, bool kHot = true>
+template <int kMode>
 TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, int64_t lane, int64_t lane_bytes,
                                 uint8_t* ring, uint64_t out_base, DirectLane& L, uint32_t& status) {
     const uint32_t done_row = kDoneState * n_cls;
@@ -761,14 +785,10 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
         for (int d = 0; d < 4; ++d) {
             const uint32_t w = wd[d];
             const uint8_t kk[4] = {T.cls[w & 0xffu], T.cls[(w >> 8) & 0xffu], T.cls[(w >> 16) & 0xffu], T.cls[w >> 24]};
-            // kMode 2: pooled texts of up to 8 bytes are fetched when met and put in place after the dword
-            // (their length is in the entry, so the cursor moves on without waiting for the text)
-            uint64_t ptext[4] = {0, 0, 0, 0};
-            uint32_t pat[4] = {0, 0, 0, 0}, plen[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint8_t c = (uint8_t)(w >> (8 * j));
-                const uint64_t e = kHot ? str_entry(T, row + kk[j]) : T.ent[row + kk[j]];
+                const uint64_t e = T.ent[row + kk[j]];
                 const uint32_t elo = (uint32_t)e, ehi = (uint32_t)(e >> 32);
                 const uint32_t ol = str_olen(elo), cc = (elo >> 27) & 1u;
                 if (kMode == 1) {
@@ -778,37 +798,32 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
                     }
                     cnt += n;
                 } else if (kMode == 2) {
-                    uint32_t len = ol;
-                    // inline bytes (an unaligned LDS store is expensive per active lane: only the lanes that have some)
-                    if (TRRE_WAVE_ANY(ol != 0u)) { if (ol != 0u) stage_put8(S, S.fill, (uint64_t)ehi); }
-                    if (TRRE_WAVE_ANY(ol == 7u)) {
-                        if (ol == 7u) {
-                            len = ehi >> 24;
-                            const uint8_t* r = T.pool + str_pool_off(ehi);
+                    // the common transition: at most 4 inline bytes, then maybe the input byte
+                    const bool pooled = ol == 7u;
+                    const uint32_t il = pooled ? 0u : ol;
+                    const uint64_t v = (uint64_t)(pooled ? 0u : ehi) | (uint64_t)(cc && !pooled ? c : 0u) << (8u * il);
+                    stage_append(S, v, pooled ? 0u : ol + cc);
+                    if (TRRE_WAVE_ANY(pooled)) {
+                        if (pooled) {
+                            uint32_t len = ehi >> 24;
                             if (len <= 8u) {
-                                __builtin_memcpy(&ptext[j], r + 4, 8);
-                                pat[j] = S.fill;
-                                plen[j] = len;
+                                uint64_t text;
+                                if (T.pool_fast) __builtin_memcpy(&text, T.pool_fast + str_pool_off(ehi) + 4, 8);
+                                else __builtin_memcpy(&text, T.pool + str_pool_off(ehi) + 4, 8);
+                                stage_append_text(S, text, len);
                             } else {
-                                // long replacement text: empty the staging buffer (texts still on their way
-                                // first), then write straight to memory
+                                // long replacement text: empty the staging buffer, write straight to memory
+                                const uint8_t* r = T.pool + str_pool_off(ehi);
                                 if (len == 255u) len = str_pool_len(T, ehi);
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    if (plen[q]) stage_put_exact(S, pat[q], ptext[q], plen[q]);
-                                    plen[q] = 0;
-                                }
                                 stage_flush<false>(S);
                                 stage_flush<true>(S);
-                                uint8_t* g = S.gq + S.fill;
+                                uint8_t* g = S.gq + S.fill();
                                 for (uint32_t i = 0; i < len; ++i) g[i] = r[4 + i];
                                 stage_begin(S, S.buf, g + len);
-                                len = 0;
                             }
+                            stage_append(S, (uint64_t)(cc ? c : 0u), cc);
                         }
                     }
-                    S.buf[S.fill + len] = c;                              // (overwritten by the next append unless copied)
-                    S.fill += len + cc;
                 } else {
                     uint32_t n = ol + cc;
                     if (n) ring[o & 63u] = ol ? (uint8_t)ehi : c;
@@ -859,14 +874,7 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
                     row = ((elo & kStrEol) && p1 >= rhi) ? done_row : row;
                 }
             }
-            if (kMode == 2) {
-                if (TRRE_WAVE_ANY((plen[0] | plen[1] | plen[2] | plen[3]) != 0u)) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (plen[j]) stage_put_exact(S, pat[j], ptext[j], plen[j]);
-                }
-                if (d & 1) stage_flush<false>(S);
-            }
+            if (kMode == 2 && (d & 1)) stage_flush<false>(S);
         }
         if (kMode == 0) direct_flush<false>(obase, ring, of, o);
     };

@@ -190,16 +190,10 @@ struct StreamView {
     const uint8_t* cls;     // [256]
     const uint64_t* ent;    // [n_states][n_cls]
     const uint8_t* pool;
-    // large tables: the first `hot_limit` entries (the shallow states, in breadth-first order) are
-    // also kept in LDS; deeper states are read through L2
-    const uint64_t* ent_hot = nullptr;
-    uint32_t hot_limit = 0;
+    const uint8_t* pool_fast = nullptr;   // a copy of the pool in LDS when it fits (emit pass), else null
     uint32_t long_pool = 1;  // 0: no pooled text reaches 255 bytes, i.e. every pooled entry carries its exact length
 };
-TRRE_HD uint64_t str_entry(const StreamView& T, uint32_t idx) {
-    if (idx < T.hot_limit) return T.ent_hot[idx];
-    return T.ent[idx];
-}
+TRRE_HD uint64_t str_entry(const StreamView& T, uint32_t idx) { return T.ent[idx]; }
 constexpr uint32_t kStrCopyC = 1u << 27, kStrEol = 1u << 28;
 
 TRRE_HD uint32_t str_olen(uint32_t lo) { return (lo >> 24) & 7u; }

@@ -332,14 +332,13 @@ __global__ __launch_bounds__(G::THREADS) void k_stream_emit(ScanArgs a) {
 
 // ------------------------------------------------------------------------------------------
 // Direct stream kernels: no tile, one long sub-range per lane (see stream_direct_lane).
-#ifndef TRRE_DIRECT_HOT
-#define TRRE_DIRECT_HOT 1
-#endif
 constexpr int kDirectThreads = 256;
-constexpr int kDirectEntBytes = 2048;      // table rows in LDS when they all fit
-constexpr int kDirectHotBytes = 12288;     // otherwise: the shallow states' rows
-constexpr int kDirectLds = 256 + kDirectEntBytes + kDirectThreads * kRingStride + 64;
-constexpr int kDirectLdsHot = 256 + kDirectHotBytes + kDirectThreads * kRingStride + 64;
+constexpr int kDirectEntBytes = 2048;      // table rows in LDS when they all fit ...
+constexpr int kDirectPoolSmall = 2048;     // ... next to this much of pooled text
+constexpr int kDirectPoolBytes = 4096;     // larger tables stay in global memory (L1/L2); LDS takes their pooled texts when small
+constexpr int kDirectTabSmall = kDirectEntBytes + kDirectPoolSmall;
+constexpr int kDirectLds = 256 + kDirectTabSmall + kDirectThreads * kRingStride + 64;
+constexpr int kDirectLdsHot = 256 + kDirectPoolBytes + kDirectThreads * kRingStride + 64;
 
 template <bool kLdsEnt>
 __device__ __forceinline__ StreamView direct_stage(const ScanArgs& a, uint8_t* smem) {
@@ -350,24 +349,20 @@ __device__ __forceinline__ StreamView direct_stage(const ScanArgs& a, uint8_t* s
         uint64_t* d = reinterpret_cast<uint64_t*>(smem + 256);
         for (int k = threadIdx.x; k < (int)(h.ent_bytes / 8); k += kDirectThreads) d[k] = e[k];
     }
-    const int tab = kLdsEnt ? kDirectEntBytes : kDirectHotBytes;
     StreamView T;
-    if (!kLdsEnt) {
-        const uint64_t* e = reinterpret_cast<const uint64_t*>(a.blob + h.off_ent);
-        uint64_t* d = reinterpret_cast<uint64_t*>(smem + 256);
-        const int rows = kDirectHotBytes / 8 / (int)h.n_cls;        // whole rows only
-        int n = rows * (int)h.n_cls;
-        if (n > (int)(h.ent_bytes / 8)) n = (int)(h.ent_bytes / 8);
-        for (int k = threadIdx.x; k < n; k += kDirectThreads) d[k] = e[k];
-        T.ent_hot = d;
-        T.hot_limit = (uint32_t)n;
+    // pooled replacement texts next to the table (the pool is a multiple of 4 bytes)
+    uint8_t* pool_lds = smem + 256 + (kLdsEnt ? kDirectEntBytes : 0);
+    if ((int)h.pool_bytes <= (kLdsEnt ? kDirectPoolSmall : kDirectPoolBytes)) {
+        const uint32_t* e = reinterpret_cast<const uint32_t*>(a.blob + h.off_pool);
+        uint32_t* d = reinterpret_cast<uint32_t*>(pool_lds);
+        for (int k = threadIdx.x; k < (int)(h.pool_bytes / 4); k += kDirectThreads) d[k] = e[k];
+        T.pool_fast = pool_lds;
     }
     __syncthreads();
     T.cls = smem;
     T.ent = kLdsEnt ? reinterpret_cast<const uint64_t*>(smem + 256) : reinterpret_cast<const uint64_t*>(a.blob + h.off_ent);
     T.pool = a.blob + h.off_pool;
     T.long_pool = h.max_out >= 255u;
-    (void)tab;
     return T;
 }
 
@@ -376,7 +371,7 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_direct(ScanArgs a, in
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const StreamView T = direct_stage<kLdsEnt>(a, smem);
     const uint32_t n_cls = reinterpret_cast<const StreamBlobHeader*>(a.blob)->n_cls;
-    constexpr int kTab = kLdsEnt ? kDirectEntBytes : kDirectHotBytes;
+    constexpr int kTab = kLdsEnt ? kDirectTabSmall : kDirectPoolBytes;
     constexpr int kLds = kLdsEnt ? kDirectLds : kDirectLdsHot;
     uint8_t* ring = smem + 256 + kTab + threadIdx.x * kRingStride;
     const int64_t lane = (int64_t)blockIdx.x * kDirectThreads + threadIdx.x;
@@ -398,7 +393,7 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_direct(ScanArgs a, in
             return;
         }
     }
-    stream_direct_lane<kMode, !kLdsEnt && TRRE_DIRECT_HOT>(a, T, n_cls, lane, lane_bytes, ring, base, L, st);
+    stream_direct_lane<kMode>(a, T, n_cls, lane, lane_bytes, ring, base, L, st);
     if (kMode == 1) {
         uint64_t* part = reinterpret_cast<uint64_t*>(smem + kLds - 64);
         if (L.count > 0xffffffffull) { st |= kStCapacity; L.count = 0xffffffffull; }
@@ -646,7 +641,7 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_redo(ScanArgs a, int6
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const StreamView T = direct_stage<kLdsEnt>(a, smem);
     const uint32_t n_cls = reinterpret_cast<const StreamBlobHeader*>(a.blob)->n_cls;
-    uint8_t* ring = smem + 256 + (kLdsEnt ? kDirectEntBytes : kDirectHotBytes) + threadIdx.x * kRingStride;
+    uint8_t* ring = smem + 256 + (kLdsEnt ? kDirectTabSmall : kDirectPoolBytes) + threadIdx.x * kRingStride;
     // every listed lane is split into 64-byte sub-lanes (same ownership rule, same positional
     // output) so that the few redone lanes do not serialise a whole sub-range each
     const int64_t sub = lane_bytes / 64;
