@@ -602,24 +602,65 @@ TRRE_HD void stream_lane_gen(const ScanArgs& a, const StreamView& T, uint32_t n_
 // ring and leave as aligned 16-byte stores.
 //   kMode 0: length-preserving (output address = input address), 1: count, 2: emit
 // =============================================================================================
+// ---- device-only: direct global -> LDS loads and explicit waits ------------------------------------
+#if defined(__HIPCC__)
+// 16 bytes per lane from global memory straight into LDS at lds_dst + 16 * lane id (lds_dst: wave-uniform
+// LDS byte address).  The compiler neither counts this load nor knows that it writes LDS: the waits
+// around it are explicit.
+__device__ __forceinline__ void wt_glds16(const uint8_t* gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ uint32_t wt_lds_addr(const uint8_t* p) {
+    return (uint32_t)reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) uint8_t*)p);
+}
+#define TRRE_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define TRRE_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
+
+// a lane's row of a wave tile (64 rows x 64 bytes; see "wave tiles" below)
+struct WtRow {
+    uint8_t* row;        // tile + r * 64
+    uint32_t swz16;      // ((r >> 1) & 3) << 4
+    TRRE_HD U128 load(int b) const { return *reinterpret_cast<const U128*>(row + ((uint32_t)(b << 4) ^ swz16)); }
+    TRRE_HD void store(int b, const U128& v) const { *reinterpret_cast<U128*>(row + ((uint32_t)(b << 4) ^ swz16)) = v; }
+};
 constexpr int kRingStride = 116;                      // bytes per lane: 29 dwords (odd), so the lanes' accesses at equal offsets hit distinct banks
 
 struct DirectLane {
     uint64_t count = 0;        // kMode 1: bytes this lane emits
 };
 
+// 16 input bytes at v (16-byte aligned in v-space) as the walkers see them: bytes from the last one of
+// the input on read as '\n' (every record ends in '\n', Q1), the byte right before the input as '\n'
+// and anything before that as filler.  Word-wise, so that inlining it several times stays cheap.
 TRRE_HD U128 direct_load(const ScanArgs& a, int64_t v) {
     const uint32_t nl4 = 0x0a0a0a0au;
     U128 w;
     if (v >= a.vend) { w.x = w.y = w.z = w.w = nl4; return w; }
     w = *reinterpret_cast<const U128*>(a.in_v0 + v);
     if (v < a.vbeg || v + 16 > a.vend - 1) {
-        uint8_t* b = reinterpret_cast<uint8_t*>(&w);
-        for (int k = 0; k < 16; ++k) {
-            const int64_t vv = v + k;
-            if (vv >= a.vend - 1) b[k] = (uint8_t)'\n';
-            else if (vv < a.vbeg) b[k] = vv == a.vbeg - 1 ? (uint8_t)'\n' : (uint8_t)'x';
+        uint32_t wd[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int64_t p = v + 4 * d;
+            // bytes at positions >= vend - 1: the top n_hi bytes of the dword
+            int64_t n_hi = p + 4 - (a.vend - 1);
+            n_hi = n_hi < 0 ? 0 : (n_hi > 4 ? 4 : n_hi);
+            const uint32_t m_hi = n_hi >= 4 ? 0xffffffffu : ~(0xffffffffu >> (8 * (int)n_hi));
+            // bytes at positions < vbeg: the low n_lo bytes; the last of them (position vbeg - 1) is '\n'
+            int64_t n_lo = a.vbeg - p;
+            n_lo = n_lo < 0 ? 0 : (n_lo > 4 ? 4 : n_lo);
+            const uint32_t m_lo = n_lo >= 4 ? 0xffffffffu : ~(0xffffffffu << (8 * (int)n_lo));
+            uint32_t fill_lo = 0x78787878u;
+            if (a.vbeg - 1 >= p && a.vbeg - 1 < p + 4) fill_lo = (fill_lo & ~(0xffu << (8 * (int)(a.vbeg - 1 - p)))) | (0x0au << (8 * (int)(a.vbeg - 1 - p)));
+            uint32_t x = wd[d];
+            x = (x & ~m_lo) | (fill_lo & m_lo);
+            x = (x & ~m_hi) | (nl4 & m_hi);
+            wd[d] = x;
         }
+        w.x = wd[0]; w.y = wd[1]; w.z = wd[2]; w.w = wd[3];
     }
     return w;
 }
@@ -875,16 +916,47 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
                 }
             }
             if (kMode == 2 && (d & 1)) stage_flush<false>(S);
+            if (kMode != 0) {
+                // one dword at a time: interleaving the walks of several blocks only costs registers, and left
+                // alone the compiler turns the running sums into trees evaluated at the end of the piece
+                TRRE_PIN(seen);
+                if (kMode == 1) TRRE_PIN(cnt);
+                TRRE_SCHED_FENCE();
+            }
         }
         if (kMode == 0) direct_flush<false>(obase, ring, of, o);
     };
-    U128 blk0 = direct_load(a, lo), blk1 = direct_load(a, lo + 16);
-    for (int64_t v = lo; TRRE_WAVE_ANY(row != done_row); v += 32) {
-        walk(blk0, v);
-        blk0 = fetch(v + 32);
-        if (!TRRE_WAVE_ANY(row != done_row)) break;
-        walk(blk1, v + 16);
-        blk1 = fetch(v + 48);
+    if (kMode != 0) {
+        // Count and emit passes: 64 bytes at a time.  A lane's four 16-byte loads of a piece are issued
+        // together, one piece ahead: per-lane 16-byte loads spread over time fetch every 64-byte sector
+        // four times (the lanes of a wave lie lane_bytes apart; measured 4.3 bytes of HBM reads per
+        // input byte), four back-to-back loads of one sector fetch it once.
+        U128 cur[4], nxt[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] = direct_load(a, lo + 16 * q);
+        for (int64_t v = lo;; v += 64) {
+            if (!TRRE_WAVE_ANY(row != done_row)) break;
+            const int64_t vn = v + 64;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int64_t x = vn + 16 * q; nxt[q] = *reinterpret_cast<const U128*>(a.in_v0 + (x < vlast ? x : vlast)); }
+            if (TRRE_WAVE_ANY(vn < a.vbeg || vn + 64 > a.vend - 1)) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) nxt[q] = direct_load(a, vn + 16 * q);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) walk(cur[q], v + 16 * q);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+        }
+    } else {
+        U128 blk0 = direct_load(a, lo), blk1 = direct_load(a, lo + 16);
+        for (int64_t v = lo; TRRE_WAVE_ANY(row != done_row); v += 32) {
+            walk(blk0, v);
+            blk0 = fetch(v + 32);
+            if (!TRRE_WAVE_ANY(row != done_row)) break;
+            walk(blk1, v + 16);
+            blk1 = fetch(v + 48);
+        }
     }
     if (kMode == 0) direct_flush<true>(obase, ring, of, o);
     if (kMode == 2) stage_flush<true>(S);
@@ -1019,14 +1091,6 @@ TRRE_HD void wt_block(const LpwView& T, const U128& cur, uint32_t next_w, uint32
         TRRE_SCHED_FENCE();
     }
 }
-
-// a lane's row of a tile
-struct WtRow {
-    uint8_t* row;        // tile + r * 64
-    uint32_t swz16;      // ((r >> 1) & 3) << 4
-    TRRE_HD U128 load(int b) const { return *reinterpret_cast<const U128*>(row + ((uint32_t)(b << 4) ^ swz16)); }
-    TRRE_HD void store(int b, const U128& v) const { *reinterpret_cast<U128*>(row + ((uint32_t)(b << 4) ^ swz16)) = v; }
-};
 
 struct WtLane {
     int64_t lo;

@@ -534,20 +534,6 @@ constexpr int kWtThreads = 256;
 constexpr int kWtWaves = kWtThreads / kWave;
 constexpr int kWtEntMax = 32768;          // larger window tables stay in global memory (L1/L2)
 
-// 16 bytes per lane from global memory straight into LDS at lds_dst + 16 * lane id (lds_dst: wave-uniform
-// LDS byte address).  The compiler neither counts this load nor knows that it writes LDS: the waits
-// around it are explicit.
-__device__ __forceinline__ void wt_glds16(const uint8_t* gsrc, uint32_t lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ uint32_t wt_lds_addr(const uint8_t* p) {
-    return (uint32_t)reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) uint8_t*)p);
-}
-#define TRRE_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-#define TRRE_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-
 template <bool kLdsEnt>
 __global__ __launch_bounds__(kWtThreads) void k_stream_lpw(ScanArgs a, int64_t lane_bytes, int ent_room) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];    // cls[256] | entries[ent_room] | tiles[waves][in, out][4 KiB]
