@@ -178,6 +178,7 @@ StreamView direct_view(const ScanArgs& a) {
     T.ent = reinterpret_cast<const uint64_t*>(a.blob + h.off_ent);
     T.pool = a.blob + h.off_pool;
     T.long_pool = h.max_out >= 255u;
+    if (h.g16_bytes) T.g16 = a.blob + h.off_g16;
     return T;
 }
 void run_direct_lp(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
@@ -190,7 +191,8 @@ void run_direct_lp(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
         stream_direct_lane<0>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
     }
 }
-void run_direct_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64_t& total_out) {
+// g16: walk the 16-byte entries (when the tables have them), like k_stream_g16
+void run_direct_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64_t& total_out, bool g16) {
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
     const StreamView T = direct_view(a);
     const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
@@ -198,7 +200,8 @@ void run_direct_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uin
     std::vector<uint64_t> cnt(n_lanes);
     for (int64_t lane = 0; lane < n_lanes; ++lane) {
         DirectLane L;
-        stream_direct_lane<1>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
+        if (g16) stream_direct_lane<1, true>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
+        else stream_direct_lane<1>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
         cnt[lane] = L.count;
     }
     uint64_t run = 0;
@@ -208,7 +211,8 @@ void run_direct_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uin
     if (run > a.cap) { status |= kStCapacity; return; }
     for (int64_t lane = n_lanes - 1; lane >= 0; --lane) {
         DirectLane L;
-        stream_direct_lane<2>(a, T, h.n_cls, lane, lane_bytes, ring, base[lane], L, status);
+        if (g16) stream_direct_lane<2, true>(a, T, h.n_cls, lane, lane_bytes, ring, base[lane], L, status);
+        else stream_direct_lane<2>(a, T, h.n_cls, lane, lane_bytes, ring, base[lane], L, status);
     }
 }
 
@@ -313,7 +317,7 @@ int run_family(int family, ScanArgs& a, uint32_t& status, uint64_t& total) {
 extern "C" {
 
 // family: 1 bytemap, 2 tile LP, 3 tile general, 4 stream LP (in place), 5 stream general.
-// 8 positional-window stream LP, 6 direct stream LP, 7 direct stream general (geo: 0 -> 2048-byte lanes, 1 -> 48-byte lanes).
+// 8 positional-window stream LP, 9 direct stream general on the 8-byte entries (7 prefers the 16-byte ones), 6 direct stream LP, 7 direct stream general (geo: 0 -> 2048-byte lanes, 1 -> 48-byte lanes).
 // geo: 0 production, 1 tiny.
 // in_mis/out_mis: address misalignment (0..15) to give the staged buffers.
 // want_scratch: pass a mask scratch to the NFT long-line path.
@@ -337,7 +341,7 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
     a.gscratch = want_scratch ? scratch.data() : nullptr;
     uint32_t status = 0;
     uint64_t total = 0;
-    if (family != 3 && family != 5 && family != 7 && cap < n) return -9;
+    if (family != 3 && family != 5 && family != 7 && family != 9 && cap < n) return -9;
     if (family == 1) { run_bytemap(a, status); total = n; }
     else if (family == 8) {
         if (reinterpret_cast<const StreamBlobHeader*>(blob)->lpw_bytes == 0) return -5;
@@ -347,7 +351,10 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
         total = n;
     }
     else if (family == 6) { run_direct_lp(a, geo == 0 ? 2048 : 48, status); total = n; }
-    else if (family == 7) { run_direct_gen(a, geo == 0 ? 2048 : 48, status, total); }
+    else if (family == 7 || family == 9) {
+        const bool g16 = family == 7 && reinterpret_cast<const StreamBlobHeader*>(blob)->g16_bytes != 0;
+        run_direct_gen(a, geo == 0 ? 2048 : 48, status, total, g16);
+    }
     else if (family == 4) {
         if (geo == 0) run_stream_lp<GeoStream>(a, status); else run_stream_lp<GeoTinyStream>(a, status);
         total = n;

@@ -46,7 +46,7 @@ def mask_bytes_of(blob, engine):
 def shim_scan(blob, engine, family, data, geo=1, in_mis=0, out_mis=0, scratch=True, cap=None):
     """Run one kernel family of the device code on the host.  Returns (output bytes, status)."""
     if cap is None:
-        cap = len(data) * 8 + 64 if family in (3, 5, 7) else len(data)
+        cap = len(data) * 8 + 64 if family in (3, 5, 7, 9) else len(data)
     out = ctypes.create_string_buffer(max(cap, 1))
     m = ctypes.c_size_t()
     st = ctypes.c_uint32()
@@ -63,7 +63,7 @@ def scan_like_runtime(prog, data, geo=1, family=None, in_mis=0, out_mis=0):
     """Mirror of runtime.cpp's policy (finish()): auto family, NUL -> general family."""
     info = prog.info
     fam = family if family else info.kernel
-    blob = prog.export_stream_tables() if fam in (4, 5, 6, 7, 8) else prog.export_tables()
+    blob = prog.export_stream_tables() if fam in (4, 5, 6, 7, 8, 9) else prog.export_tables()
     out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
     if out is None:                         # family 8 without a window form: nothing to run
         fam = 6
@@ -71,7 +71,7 @@ def scan_like_runtime(prog, data, geo=1, family=None, in_mis=0, out_mis=0):
     assert not st & ST_MISMATCH, "count and emit passes disagree"
     if st & ST_DIVERGE:
         raise RuntimeError("diverges")
-    if fam not in (3, 5, 7) and st & ST_NUL:
+    if fam not in (3, 5, 7, 9) and st & ST_NUL:
         gen = (7 if fam in (6, 8) else 5) if info.stream_states else 3
         blob = prog.export_stream_tables() if gen in (5, 7) else prog.export_tables()
         out, st = shim_scan(blob, info.engine, gen, data, geo, in_mis, out_mis)

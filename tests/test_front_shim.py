@@ -70,7 +70,7 @@ def shim_families(p):
     if 4 in fams:
         fams += [6, 8]
     if 5 in fams:
-        fams.append(7)
+        fams += [7, 9]
     return fams
 
 

@@ -42,7 +42,7 @@ struct StreamBlobHeader {
     uint32_t off_pool, pool_bytes;
     uint32_t total_bytes, max_out;
     uint32_t off_lpw, lpw_bytes, lpw_delay;   // window form (0 bytes when not available)
-    uint32_t pad[2];
+    uint32_t off_g16, g16_bytes;              // 16-byte count / emit entries (0 bytes when not available)
 };
 static_assert(sizeof(StreamBlobHeader) == 64, "header layout");
 

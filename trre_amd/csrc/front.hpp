@@ -158,6 +158,12 @@ struct StreamTables {
     bool lpw_ok = false;
     uint32_t lpw_delay = 0;                 // max pending length
     std::vector<uint32_t> lpw;              // [n_states][n_cls][4]
+    // 16-byte entries for the count / emit passes of small tables (any output length): like the window
+    // form without the shift, {next row offset, meta, inline bytes, v_perm selector}; meta [2:0] = bytes
+    // the transition appends (inline bytes, then maybe the input byte), [5] record end, [7] "slow":
+    // more than 4 bytes or pooled text — handled from the 8-byte entry
+    bool g16_ok = false;
+    std::vector<uint32_t> g16;              // [n_states][n_cls][4]
 };
 StreamTables build_stream_dft(const Dft& dft, const StreamLimits& lim = StreamLimits());
 StreamTables build_stream_nft(const Nft& nft, const StreamLimits& lim = StreamLimits());

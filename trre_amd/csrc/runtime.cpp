@@ -165,6 +165,8 @@ void serialize_stream(trre_prog& p) {
     h.off_pool = (uint32_t)off; h.pool_bytes = (uint32_t)t.pool.size(); off += t.pool.size();
     off = align_up(off, 16);
     h.off_lpw = (uint32_t)off; h.lpw_bytes = (uint32_t)(t.lpw.size() * 4); h.lpw_delay = t.lpw_delay; off += t.lpw.size() * 4;
+    off = align_up(off, 16);
+    h.off_g16 = (uint32_t)off; h.g16_bytes = (uint32_t)(t.g16.size() * 4); off += t.g16.size() * 4;
     off = align_up(off + 16, 16);
     h.total_bytes = (uint32_t)off;
     std::vector<uint8_t>& b = p.sblob;
@@ -174,6 +176,7 @@ void serialize_stream(trre_prog& p) {
     put(b, h.off_ent, t.ent.data(), t.ent.size());
     put(b, h.off_pool, t.pool.data(), t.pool.size());
     put(b, h.off_lpw, t.lpw.data(), t.lpw.size());
+    put(b, h.off_g16, t.g16.data(), t.g16.size());
 }
 
 bool is_stream(int fam) { return fam == TRRE_KERNEL_STREAM_LP || fam == TRRE_KERNEL_STREAM_GEN; }
@@ -319,9 +322,11 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
     } else if (direct && family == TRRE_KERNEL_STREAM_LP) {
         launch_direct_kernel(0, direct_ent_lds, args, lane_bytes, n_chunks, stream);
     } else if (direct) {
-        launch_direct_kernel(1, direct_ent_lds, args, lane_bytes, n_chunks, stream);
+        static const bool no_g16 = getenv("TRRE_NO_G16") != nullptr;          // A/B: the 8-byte entries
+        const int g16 = p->stt.g16_ok && !no_g16 ? (int)(p->stt.g16.size() * 4) : 0;
+        launch_direct_kernel(1, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16);
         launch_chunk_scan(st->d_chunk_total, st->d_chunk_base, n_chunks, stream);
-        launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream);
+        launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16);
         pd.total_at = st->d_chunk_base + n_chunks;
     } else if (family == TRRE_KERNEL_STREAM_LP) {
         launch_stream_kernel(0, ent_lds, args, n_chunks, stream);

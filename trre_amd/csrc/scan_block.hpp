@@ -733,6 +733,8 @@ TRRE_HD void stage_append(Stage& s, uint64_t v, uint32_t n) {
     s.wp += 4u * adv;
     s.acc = adv == 0u ? s.acc : (adv == 1u ? s.acc >> 32 : 0ull);
 }
+// the same for at most 4 bytes
+TRRE_HD void stage_append4(Stage& s, uint32_t v, uint32_t n) { stage_append(s, (uint64_t)v, n); }
 // exactly len (1..8) bytes of v at the fill position, written to the buffer directly (rare path)
 TRRE_HD void stage_append_text(Stage& s, uint64_t v, uint32_t len) {
     const uint32_t at = s.fill();
@@ -782,18 +784,21 @@ TRRE_HD void stage_flush(Stage& s) {
     }
 }
 
-template <int kMode>
+// kG16 (count and emit passes of small tables): the walk uses the 16-byte entries T.g16 (front.hpp) —
+// bytes to append and their count come ready-made (v_perm selector, count field), rows are byte offsets.
+template <int kMode, bool kG16 = false>
 TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, int64_t lane, int64_t lane_bytes,
                                 uint8_t* ring, uint64_t out_base, DirectLane& L, uint32_t& status) {
-    const uint32_t done_row = kDoneState * n_cls;
+    const uint32_t rs = kG16 ? 16u : 1u;                              // row unit
+    const uint32_t done_row = kDoneState * n_cls * rs;
     int64_t lo = lane * lane_bytes, hi = lo + lane_bytes;
     if (hi > a.vend) hi = a.vend;
     // end of the lane's sub-range as a 32-bit offset from lo (the count and emit passes stop branch-free)
     const uint32_t rhi = (uint32_t)(hi > lo ? hi - lo : 0);
     uint32_t row;
     if (lo >= hi) row = done_row;
-    else if (lo < a.vbeg) row = kSkipState * n_cls;                  // filler then '\n' right before the input
-    else row = (lo == a.vbeg || a.in_v0[lo - 1] == (uint8_t)'\n') ? 0u : kSkipState * n_cls;
+    else if (lo < a.vbeg) row = kSkipState * n_cls * rs;             // filler then '\n' right before the input
+    else row = (lo == a.vbeg || a.in_v0[lo - 1] == (uint8_t)'\n') ? 0u : kSkipState * n_cls * rs;
 
     // kMode 0: output cursor as a 32-bit offset from a 64-byte aligned base address, through a 64-byte ring
     uint8_t* obase = nullptr;
@@ -820,15 +825,52 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
         if (TRRE_WAVE_ANY(vn < a.vbeg || vn + 16 > a.vend - 1)) q = direct_load(a, vn);
         return q;
     };
-    auto walk = [&](const U128& cur, const int64_t v) {
-        const uint32_t wd[4] = {cur.x, cur.y, cur.z, cur.w};
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const uint32_t w = wd[d];
+    // one dword (4 input bytes) at position v + 4 d of the block at v
+    auto walk_dword = [&](const uint32_t w, const int64_t v, const int d) {
+        {
             const uint8_t kk[4] = {T.cls[w & 0xffu], T.cls[(w >> 8) & 0xffu], T.cls[(w >> 16) & 0xffu], T.cls[w >> 24]};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint8_t c = (uint8_t)(w >> (8 * j));
+                if (kG16) {
+                    const U128 g = *reinterpret_cast<const U128*>(T.g16 + row + ((uint32_t)kk[j] << 4));
+                    const uint32_t n = g.y & 7u;
+                    if (kMode == 1) cnt += n;
+                    else stage_append4(S, perm_b32(w >> (8 * j), g.z, g.w), n);
+                    if (TRRE_WAVE_ANY(g.y & 128u)) {
+                        if (g.y & 128u) {
+                            // more than four bytes, or pooled text: from the 8-byte entry
+                            const uint64_t e = T.ent[(row >> 4) + kk[j]];
+                            const uint32_t elo = (uint32_t)e, ehi = (uint32_t)(e >> 32);
+                            const uint32_t ol = str_olen(elo), cc = (elo >> 27) & 1u;
+                            if (kMode == 1) {
+                                cnt += (ol == 7u ? str_pool_len(T, ehi) : ol) + cc;
+                            } else if (ol != 7u) {
+                                stage_append(S, (uint64_t)ehi | (uint64_t)(cc ? c : 0u) << (8u * ol), ol + cc);
+                            } else {
+                                uint32_t len = ehi >> 24;
+                                if (len <= 8u) {
+                                    uint64_t text;
+                                    if (T.pool_fast) __builtin_memcpy(&text, T.pool_fast + str_pool_off(ehi) + 4, 8);
+                                    else __builtin_memcpy(&text, T.pool + str_pool_off(ehi) + 4, 8);
+                                    stage_append_text(S, text, len);
+                                } else {
+                                    const uint8_t* r = T.pool + str_pool_off(ehi);
+                                    if (len == 255u) len = str_pool_len(T, ehi);
+                                    stage_flush<false>(S);
+                                    stage_flush<true>(S);
+                                    uint8_t* gp = S.gq + S.fill();
+                                    for (uint32_t i = 0; i < len; ++i) gp[i] = r[4 + i];
+                                    stage_begin(S, S.buf, gp + len);
+                                }
+                                stage_append(S, (uint64_t)(cc ? c : 0u), cc);
+                            }
+                        }
+                    }
+                    const uint32_t p1 = (uint32_t)(v - lo) + 4u * d + j + 1u;
+                    row = ((g.y & 32u) && p1 >= rhi) ? done_row : g.x;
+                    continue;
+                }
                 const uint64_t e = T.ent[row + kk[j]];
                 const uint32_t elo = (uint32_t)e, ehi = (uint32_t)(e >> 32);
                 const uint32_t ol = str_olen(elo), cc = (elo >> 27) & 1u;
@@ -917,12 +959,26 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
             }
             if (kMode == 2 && (d & 1)) stage_flush<false>(S);
             if (kMode != 0) {
-                // one dword at a time: interleaving the walks of several blocks only costs registers, and left
+                // one dword at a time: interleaving the walks of several dwords only costs registers, and left
                 // alone the compiler turns the running sums into trees evaluated at the end of the piece
                 TRRE_PIN(seen);
                 if (kMode == 1) TRRE_PIN(cnt);
                 TRRE_SCHED_FENCE();
             }
+        }
+    };
+    // One 16-byte block.  The emit pass walks its dwords (and a piece's blocks) with real loops: fully
+    // unrolled, a piece was 19 000 instructions, several times the instruction cache; the count pass is
+    // small enough to keep its dwords unrolled.
+    auto walk = [&](const U128& cur, const int64_t v) {
+        if (kMode == 2) {
+#pragma clang loop unroll(disable)
+            for (int d = 0; d < 4; ++d) walk_dword(d == 0 ? cur.x : (d == 1 ? cur.y : (d == 2 ? cur.z : cur.w)), v, d);
+        } else {
+            walk_dword(cur.x, v, 0);
+            walk_dword(cur.y, v, 1);
+            walk_dword(cur.z, v, 2);
+            walk_dword(cur.w, v, 3);
         }
         if (kMode == 0) direct_flush<false>(obase, ring, of, o);
     };
@@ -931,22 +987,28 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
         // together, one piece ahead: per-lane 16-byte loads spread over time fetch every 64-byte sector
         // four times (the lanes of a wave lie lane_bytes apart; measured 4.3 bytes of HBM reads per
         // input byte), four back-to-back loads of one sector fetch it once.
-        U128 cur[4], nxt[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) cur[q] = direct_load(a, lo + 16 * q);
+        // (named registers, selected by compares: an indexed array would be kept in scratch memory)
+        U128 c0 = direct_load(a, lo), c1 = direct_load(a, lo + 16), c2 = direct_load(a, lo + 32), c3 = direct_load(a, lo + 48);
         for (int64_t v = lo;; v += 64) {
             if (!TRRE_WAVE_ANY(row != done_row)) break;
             const int64_t vn = v + 64;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { const int64_t x = vn + 16 * q; nxt[q] = *reinterpret_cast<const U128*>(a.in_v0 + (x < vlast ? x : vlast)); }
+            const int64_t x0 = vn < vlast ? vn : vlast, x1 = vn + 16 < vlast ? vn + 16 : vlast,
+                          x2 = vn + 32 < vlast ? vn + 32 : vlast, x3 = vn + 48 < vlast ? vn + 48 : vlast;
+            U128 n0 = *reinterpret_cast<const U128*>(a.in_v0 + x0), n1 = *reinterpret_cast<const U128*>(a.in_v0 + x1),
+                 n2 = *reinterpret_cast<const U128*>(a.in_v0 + x2), n3 = *reinterpret_cast<const U128*>(a.in_v0 + x3);
             if (TRRE_WAVE_ANY(vn < a.vbeg || vn + 64 > a.vend - 1)) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) nxt[q] = direct_load(a, vn + 16 * q);
+                n0 = direct_load(a, vn); n1 = direct_load(a, vn + 16); n2 = direct_load(a, vn + 32); n3 = direct_load(a, vn + 48);
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) walk(cur[q], v + 16 * q);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+#pragma clang loop unroll(disable)
+            for (int q = 0; q < 4; ++q) {
+                U128 b;
+                b.x = q == 0 ? c0.x : (q == 1 ? c1.x : (q == 2 ? c2.x : c3.x));
+                b.y = q == 0 ? c0.y : (q == 1 ? c1.y : (q == 2 ? c2.y : c3.y));
+                b.z = q == 0 ? c0.z : (q == 1 ? c1.z : (q == 2 ? c2.z : c3.z));
+                b.w = q == 0 ? c0.w : (q == 1 ? c1.w : (q == 2 ? c2.w : c3.w));
+                walk(b, v + 16 * q);
+            }
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         }
     } else {
         U128 blk0 = direct_load(a, lo), blk1 = direct_load(a, lo + 16);

@@ -411,6 +411,70 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_direct(ScanArgs a, in
     if (st && (threadIdx.x & (kWave - 1)) == 0) atomicOr(a.status, st);
 }
 
+// Count / emit passes over the 16-byte entries of a small table (front.hpp): the whole table in LDS.
+//   smem: cls[256] | g16[g16_room] | pooled text (2 KiB, when the pool fits) | staging[threads] | 64
+template <int kMode>
+__global__ __launch_bounds__(kDirectThreads) void k_stream_g16(ScanArgs a, int64_t lane_bytes, int g16_room) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
+    for (int k = threadIdx.x; k < 256; k += kDirectThreads) smem[k] = a.blob[h.off_cls + k];
+    {
+        const U128* e = reinterpret_cast<const U128*>(a.blob + h.off_g16);
+        U128* d = reinterpret_cast<U128*>(smem + 256);
+        for (int k = threadIdx.x; k < (int)(h.g16_bytes / 16); k += kDirectThreads) d[k] = e[k];
+    }
+    StreamView T;
+    uint8_t* pool_lds = smem + 256 + g16_room;
+    if ((int)h.pool_bytes <= kDirectPoolSmall) {
+        const uint32_t* e = reinterpret_cast<const uint32_t*>(a.blob + h.off_pool);
+        uint32_t* d = reinterpret_cast<uint32_t*>(pool_lds);
+        for (int k = threadIdx.x; k < (int)(h.pool_bytes / 4); k += kDirectThreads) d[k] = e[k];
+        T.pool_fast = pool_lds;
+    }
+    __syncthreads();
+    T.cls = smem;
+    T.g16 = smem + 256;
+    T.ent = reinterpret_cast<const uint64_t*>(a.blob + h.off_ent);
+    T.pool = a.blob + h.off_pool;
+    T.long_pool = h.max_out >= 255u;
+    uint8_t* ring = pool_lds + kDirectPoolSmall + threadIdx.x * kRingStride;
+    uint8_t* tail = pool_lds + kDirectPoolSmall + kDirectThreads * kRingStride;       // 64 bytes
+    const int64_t lane = (int64_t)blockIdx.x * kDirectThreads + threadIdx.x;
+    DirectLane L;
+    uint32_t st = 0;
+    uint64_t base = 0;
+    if (kMode == 2) {
+        uint32_t* wpart = reinterpret_cast<uint32_t*>(tail);
+        const uint32_t mine = a.lane_counts[lane];
+        const uint32_t incl = wave_scan_incl(mine);
+        if ((threadIdx.x & (kWave - 1)) == kWave - 1) wpart[threadIdx.x / kWave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (int w = 0; w < (int)threadIdx.x / kWave; ++w) wbase += wpart[w];
+        base = a.chunk_base[blockIdx.x] + wbase + incl - mine;
+        if (a.chunk_base[blockIdx.x] + a.chunk_total[blockIdx.x] > a.cap) {
+            if (threadIdx.x == 0) atomicOr(a.status, kStCapacity);
+            return;
+        }
+    }
+    stream_direct_lane<kMode, true>(a, T, h.n_cls, lane, lane_bytes, ring, base, L, st);
+    if (kMode == 1) {
+        uint64_t* part = reinterpret_cast<uint64_t*>(tail);
+        if (L.count > 0xffffffffull) { st |= kStCapacity; L.count = 0xffffffffull; }
+        a.lane_counts[lane] = (uint32_t)L.count;
+        const uint64_t wsum = wave_sum(L.count);
+        if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = wsum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t t = 0;
+            for (int w = 0; w < kDirectThreads / kWave; ++w) t += part[w];
+            a.chunk_total[blockIdx.x] = t;
+        }
+    }
+    st = wave_or(st);
+    if (st && (threadIdx.x & (kWave - 1)) == 0) atomicOr(a.status, st);
+}
+
 // ------------------------------------------------------------------------------------------
 // memoryless byte map: out[v] = map[in[v]], 16 bytes per lane per step
 constexpr int kMapThreads = 256;
@@ -663,8 +727,17 @@ void launch_direct_t(bool ent_lds, const ScanArgs& a, int64_t lane_bytes, int64_
 }
 int direct_ent_lds_bytes() { return kDirectEntBytes; }
 int direct_block_threads() { return kDirectThreads; }
-void launch_direct_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, void* stream) {
+void launch_direct_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, void* stream, int g16_bytes) {
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (g16_bytes > 0 && which != 0) {
+        const int room = (g16_bytes + 15) / 16 * 16;
+        const int lds = 256 + room + kDirectPoolSmall + kDirectThreads * kRingStride + 64;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_g16<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_g16<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (which == 1) hipLaunchKernelGGL((k_stream_g16<1>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds, s, a, lane_bytes, room);
+        else hipLaunchKernelGGL((k_stream_g16<2>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds, s, a, lane_bytes, room);
+        return;
+    }
     if (which == 0) launch_direct_t<0>(ent_in_lds, a, lane_bytes, n_blocks, s);
     else if (which == 1) launch_direct_t<1>(ent_in_lds, a, lane_bytes, n_blocks, s);
     else launch_direct_t<2>(ent_in_lds, a, lane_bytes, n_blocks, s);

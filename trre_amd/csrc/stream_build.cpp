@@ -338,6 +338,7 @@ private:
         for (int k = 0; k < 8; ++k) t.pool.push_back(0);   // 8-byte reads of a record's text stay inside the pool
         t.ok = true;
         if (lp) build_window_form(t, rep);
+        build_gen16(t, rep);
         if (lp) t.flags |= kFlagLengthPreserving;
         if (lp && inplace_ok) t.flags |= kFlagNoOverrun;    // the in-place kernel may run
         return t;
@@ -373,6 +374,36 @@ private:
         t.lpw = std::move(v);
         t.lpw_delay = delay;
         t.lpw_ok = true;
+    }
+
+    // 16-byte entries for the count and emit passes (see front.hpp); small tables only (they live in LDS)
+    void build_gen16(StreamTables& t, const std::vector<int>& rep) {
+        if ((size_t)t.n_states * t.n_cls > 2048) return;
+        std::vector<uint32_t> v((size_t)t.n_states * t.n_cls * 4, 0);
+        for (uint32_t s = 0; s < t.n_states; ++s) {
+            for (uint32_t k = 0; k < t.n_cls; ++k) {
+                const Cell& x = rows_[s][rep[k]];
+                const size_t n = x.out.size() + (x.copy_c ? 1 : 0);
+                const bool slow = n > 4;
+                uint32_t* e = &v[((size_t)s * t.n_cls + k) * 4];
+                e[0] = x.next * t.n_cls * 16u;
+                e[1] = (slow ? 128u : (uint32_t)n) | (x.eol ? 32u : 0u);
+                uint32_t bytes = 0, sel = 0x0c0c0c0cu;                       // constant 0x00 everywhere
+                if (!slow) {
+                    sel = 0;
+                    for (size_t b = 0; b < 4; ++b) {
+                        uint32_t pick = 0x0cu;
+                        if (b < x.out.size()) { bytes |= (uint32_t)(uint8_t)x.out[b] << (8 * b); pick = (uint32_t)b; }
+                        else if (b == x.out.size() && x.copy_c) pick = 4u;   // byte 0 of the input register
+                        sel |= pick << (8 * b);
+                    }
+                }
+                e[2] = bytes;
+                e[3] = sel;
+            }
+        }
+        t.g16 = std::move(v);
+        t.g16_ok = true;
     }
 
     const AttemptModel& m_;
