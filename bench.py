@@ -206,7 +206,7 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "traffic": pmc_traffic("k_bytemap") if (info.kernel == 1 and n == 1 << 30) else None,
             "kernel": {"bytemap": "k_bytemap", "tile_lp": "k_scan_lp", "tile_gen": "k_scan_emit", "stream_lp": "k_stream_lpw",
-                       "stream_gen": "k_stream_direct<emit>"}[trre_amd.KERNEL_NAMES[info.kernel]],
+                       "stream_gen": "k_stream_g16<emit> (small tables) / k_stream_direct<emit>"}[trre_amd.KERNEL_NAMES[info.kernel]],
             "kernel_ms": round(kernel_ms, 4),
             "algorithmic_bytes_per_launch": n,
             "achieved_read_plus_write": round((n + m) / (kernel_ms * 1e-3) / 1e9, 1),

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run by tests/test_gpu_parity.py in a subprocess with TRRE_STREAM_IMPL /
-TRRE_LANE_BYTES set: checks the alternative implementations of the stream kernel families
+TRRE_LANE_BYTES / TRRE_NO_G16 set: checks the alternative implementations of the stream kernel families
 against the oracle (the environment is read once per process by the library)."""
 import os
 import random
@@ -24,7 +24,9 @@ def main():
     clean = data.replace(b"\0", b" ")
     bad = 0
     for pat, eng in [("[a:A-z:Z]", "dft"), ("(cat:dog|dog:cat)", "nft"), ("(cat:dog|dog:cat)", "dft"), ("cat:dog", "nft"),
-                     ("a:xyz", "dft"), ("[aie]:", "nft"), ("abc:2|ab:1", "nft"), ("abc:2|ab:1", "dft")]:
+                     ("a:xyz", "dft"), ("[aie]:", "nft"), ("abc:2|ab:1", "nft"), ("abc:2|ab:1", "dft"),
+                     ("(cat:elephant|dog:a-replacement-text-of-more-than-forty-bytes-0123456789|do:12345)", "dft"),
+                     ("(cat:elephant|dog:a-replacement-text-of-more-than-forty-bytes-0123456789|do:12345)", "nft")]:
         p = trre_amd.Program(pat, eng)
         for fam in [f for f in p.allowed_kernels() if f in (trre_amd.KERNEL_STREAM_LP, trre_amd.KERNEL_STREAM_GEN)]:
             p.set_kernel(fam)
