@@ -115,6 +115,17 @@ def test_alternative_stream_implementations(env):
     assert r.returncode == 0, r.stdout.decode("latin-1")[-2000:]
 
 
+def test_mask_scratch_grows_with_the_input():
+    """NFT tile kernels need a mask scratch for lines longer than the LDS tile; one left by a smaller
+    scan must not be reused for a larger one (found by tools/gpu_fuzz.py)"""
+    p = prog("c", "nft")
+    o = Oracle("c", "nft")
+    for n_lines in (3, 40):
+        data = b"".join(b"abcxy" * 9000 + b"\n" + b"cab\n" for _ in range(n_lines))
+        for fam in (trre_amd.KERNEL_TILE_LP, trre_amd.KERNEL_TILE_GEN):
+            assert gpu_scan(p, data, fam) == o.scan(data), (n_lines, fam)
+
+
 def test_capacity_error_reports_needed_size():
     import ctypes
     import torch

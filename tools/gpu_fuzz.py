@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Randomized differential check of the GPU path (C ABI, every kernel family a pattern admits)
+against the oracle.  Run on the GPU box:   python tools/gpu_fuzz.py --seconds 120 --seed 1
+
+Random patterns (the generator of tests/fuzz_oracle.py over the alphabet abcxy), random inputs over
+the same alphabet with lines of very different lengths (empty lines, lines longer than a lane's
+sub-range, NULs now and then, with and without a final newline), random buffer sizes and random
+misalignment of the input and output tensors."""
+import argparse
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+
+import trre_amd  # noqa: E402
+from fuzz_oracle import gen_expr  # noqa: E402
+from oracle_lib import Oracle, OracleError  # noqa: E402
+
+ALPHA = b"abcxy"
+
+
+def gen_input(rng, n):
+    out = bytearray()
+    while len(out) < n:
+        r = rng.random()
+        if r < 0.05:
+            ln = 0
+        elif r < 0.85:
+            ln = rng.randint(1, 160)
+        elif r < 0.97:
+            ln = rng.randint(1000, 6000)          # longer than a lane's sub-range
+        else:
+            ln = rng.randint(20000, 70000)        # longer than an LDS tile
+        line = bytes(rng.choice(ALPHA) for _ in range(min(ln, 64)))
+        line = (line * (ln // max(len(line), 1) + 1))[:ln]
+        if rng.random() < 0.01 and ln:
+            k = rng.randrange(ln)
+            line = line[:k] + b"\0" + line[k + 1:]
+        out += line + b"\n"
+    out = bytes(out[:n])
+    if rng.random() < 0.5 and not out.endswith(b"\n"):
+        out = out[:-1] + b"\n"
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=60)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--verbose", action="store_true", help="print every case before it runs (to find a crashing one)")
+    a = ap.parse_args()
+    rng = random.Random(a.seed)
+    t_end = time.time() + a.seconds
+    n_pat = n_run = n_skip = bad = 0
+    fams = {}
+    while time.time() < t_end:
+        pat = gen_expr(rng).decode("latin-1")
+        eng = rng.choice(["dft", "nft"])
+        try:
+            o = Oracle(pat, eng)
+            p = trre_amd.Program(pat, eng)
+        except (OracleError, trre_amd.TrreError):
+            n_skip += 1
+            continue
+        n_pat += 1
+        for _ in range(2):
+            n = rng.choice([1, 7, 100, 5000, 70000, 300000, 1500000])
+            data = gen_input(rng, n)
+            try:
+                want = o.scan(data)
+            except OracleError:
+                n_skip += 1
+                continue
+            mis_in, mis_out = rng.choice([0, 0, 1, 5, 16, 33]), rng.choice([0, 0, 1, 5, 16, 33])
+            buf = torch.zeros(len(data) + 64, dtype=torch.uint8, device="cuda")
+            buf[mis_in:mis_in + len(data)] = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+            tin = buf[mis_in:mis_in + len(data)]
+            for fam in p.allowed_kernels():
+                p.set_kernel(fam)
+                if a.verbose:
+                    print("case pat=%r eng=%s fam=%d n=%d mis=(%d,%d)" % (pat, eng, fam, len(data), mis_in, mis_out), flush=True)
+                cap = max(len(want), len(data)) + 64
+                obuf = torch.empty(cap + 64, dtype=torch.uint8, device="cuda")
+                tout = obuf[mis_out:mis_out + cap]
+                try:
+                    m = p.scan_tensor(tin, out=tout)
+                    got = m.cpu().numpy().tobytes() if hasattr(m, "cpu") else bytes(tout[:m].cpu().numpy())
+                except trre_amd.TrreError as e:
+                    got = ("ERR " + str(e)).encode()
+                n_run += 1
+                fams[fam] = fams.get(fam, 0) + 1
+                if got != want:
+                    bad += 1
+                    print("MISMATCH pat=%r eng=%s fam=%d n=%d mis=(%d,%d) got=%d want=%d" % (pat, eng, fam, len(data), mis_in, mis_out, len(got), len(want)), flush=True)
+                    if bad > 20:
+                        return 1
+    print("gpu fuzz: %d patterns, %d scans (%s), %d skipped, %d mismatches" % (n_pat, n_run, fams, n_skip, bad))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

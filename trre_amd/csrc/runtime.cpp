@@ -270,7 +270,8 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
     args.blob = is_stream(family) ? st->d_sblob : st->d_blob;
     args.status = st->d_status;
     args.cap = cap;
-    args.gscratch = st->d_scratch;
+    // a mask scratch left by an earlier, smaller scan must not be used: the kernel asks for one again
+    args.gscratch = st->scratch_bytes >= (n + 32) * (size_t)p->mask_bytes ? st->d_scratch : nullptr;
     const int chunk = is_stream(family) ? stream_chunk_bytes(family == TRRE_KERNEL_STREAM_LP ? 0 : 1)
                                         : chunk_bytes(p->engine, p->mask_bytes);
     const int threads = is_stream(family) ? stream_block_threads(family == TRRE_KERNEL_STREAM_LP ? 0 : 1)
