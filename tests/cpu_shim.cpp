@@ -229,15 +229,17 @@ void run_lpw(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
     std::vector<uint32_t> redo(n_waves * 64 + 1, 0);
     ScanArgs b = a;
     b.redo = redo.data();
-    alignas(16) static uint8_t tin[kWtTile], tout[kWtTile];
+    alignas(16) static uint8_t tin[kWtTile], tout[kWtOutTile];
     const int64_t vhi = (a.vend - 16) & ~(int64_t)15;
     for (int64_t wv = n_waves - 1; wv >= 0; --wv) {
         WtLane L[64];
         WtMover M[64];
         const int64_t lane0 = wv * 64;
         for (int lid = 0; lid < 64; ++lid) L[lid].init(b, T, h.n_cls, lane0 + lid, lane_bytes);
-        for (int lid = 0; lid < 64; ++lid)
+        for (int lid = 0; lid < 64; ++lid) {
             for (int i = 0; i < 4; ++i) M[lid].set(lid, i, lane_bytes, L[WtMover::row_of(lid, i)].rv);
+            for (int i = 0; i < 8; ++i) M[lid].set_out(lid, i, lane_bytes, L[WtMover::out_row_of(lid, i)].rv);
+        }
         const int64_t wave_lo = lane0 * lane_bytes;
         const uint8_t* win_in = a.in_v0 + wave_lo;
         uint8_t* win_out = a.out_v0 + wave_lo;
@@ -250,11 +252,11 @@ void run_lpw(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
         if (!ballot()) continue;
         std::memset(tout, 0xEE, sizeof(tout));
         fetch(0);
-        uint64_t rows_prev = 0;
+        uint64_t rows1 = 0, rows2 = 0;
         for (int32_t k64 = 0;; k64 += kWtPiece) {
             for (int lid = 0; lid < 64; ++lid) L[lid].check(b, lane0 + lid);
             const uint64_t rows = ballot();
-            if (!rows && !rows_prev) break;
+            if (!rows && !rows1 && !rows2) break;
             U128 blk[64][4];
             int md[64];
             for (int lid = 0; lid < 64; ++lid) {
@@ -263,19 +265,22 @@ void run_lpw(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
             }
             fetch(k64 + kWtPiece);
             for (int lid = 0; lid < 64; ++lid) {
-                const WtRow orow{tout + lid * kWtPiece, (uint32_t)((lid >> 1) & 3) << 4};
+                const WtOutRow orow{tout + lid * kWtOutRow, (uint32_t)(lid & 7) << 4};
                 md[lid] = L[lid].mode(k64);
                 if (L[lid].active) L[lid].front(T, md[lid], blk[lid][0], blk[lid][1].x, orow, a.out_v0);
             }
-            for (int lid = 0; lid < 64; ++lid)
-                for (int i = 0; i < 4; ++i)
-                    if (WtMover::stores(i, k64, rows, rows_prev, lid, L[WtMover::row_of(lid, i)].rfs))
-                        std::memcpy(win_out + M[lid].store_off(i, k64), tout + i * 1024 + lid * 16, 16);
+            if ((k64 & (kWtOutRow - 1)) == 0) {
+                for (int lid = 0; lid < 64; ++lid)
+                    for (int i = 0; i < 8; ++i)
+                        if (WtMover::stores(i, k64, rows, rows1, rows2, lid, L[WtMover::out_row_of(lid, i)].rfs))
+                            std::memcpy(win_out + M[lid].store_off(i, k64), tout + i * 1024 + lid * 16, 16);
+            }
             for (int lid = 0; lid < 64; ++lid) {
-                const WtRow orow{tout + lid * kWtPiece, (uint32_t)((lid >> 1) & 3) << 4};
+                const WtOutRow orow{tout + lid * kWtOutRow, (uint32_t)(lid & 7) << 4};
                 if (L[lid].active) L[lid].back(T, md[lid], blk[lid][1], blk[lid][2], blk[lid][3], orow, a.out_v0);
             }
-            rows_prev = rows;
+            rows2 = rows1;
+            rows1 = rows;
         }
         for (int lid = 0; lid < 64; ++lid)
             if (L[lid].seen & kLpwNul) status |= kStNul;

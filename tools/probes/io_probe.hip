@@ -57,6 +57,51 @@ __global__ void k_io(const uint8_t* in, uint8_t* out, int64_t n, int64_t lane_by
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+// mixed: 64-byte input rows every iteration, 128-byte output rows every second iteration
+__global__ void k_io_mixed(const uint8_t* in, uint8_t* out, int64_t n, int64_t lane_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lid = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint8_t* tin = smem + wv * 12288;
+    uint8_t* tout = tin + 4096;
+    const uint32_t t0 = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) uint8_t*)tin));
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + wv;
+    const int64_t wave_lo = wave * 64 * lane_bytes;
+    if (wave_lo + 64 * lane_bytes > n) return;
+    int32_t src[4], dst[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) src[i] = (int32_t)((16 * i + lid / 4) * lane_bytes) + 16 * (lid % 4);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[i] = (int32_t)((8 * i + lid / 8) * lane_bytes) + 16 * (lid % 8);
+    const uint8_t* wi = in + wave_lo;
+    uint8_t* wo = out + wave_lo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(wi + src[i], t0 + i * 1024);
+    bool stored = false;
+    for (int32_t k = 0; k < lane_bytes; k += 64) {
+        if (stored) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        u32x4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const u32x4*>(tin + i * 1024 + lid * 16);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (k + 64 < lane_bytes) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) glds16(wi + src[i] + k + 64, t0 + i * 1024);
+        }
+        // each lane puts its 64 bytes into its 128-byte output row (half k/64 & 1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(tout + lid * 128 + ((k >> 6) & 1) * 64 + i * 16) = v[i];
+        stored = false;
+        if ((k >> 6) & 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const u32x4 o = *reinterpret_cast<const u32x4*>(tout + i * 1024 + lid * 16);
+                *reinterpret_cast<u32x4*>(wo + dst[i] + k - 64) = o;
+            }
+            stored = true;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 int main(int argc, char** argv) {
     const int rowb = argc > 1 ? atoi(argv[1]) : 64;
     const int64_t lane_bytes = argc > 2 ? atoll(argv[2]) : 2048;
@@ -73,7 +118,8 @@ int main(int argc, char** argv) {
     float best = 1e9;
     for (int it = 0; it < 6; ++it) {
         hipEventRecord(e0);
-        if (rowb == 64) hipLaunchKernelGGL(k_io<64>, dim3(grid), dim3(waves * 64), lds, 0, in, out, n, lane_bytes, mode);
+        if (rowb == 0) hipLaunchKernelGGL(k_io_mixed, dim3(grid), dim3(waves * 64), waves * 12288, 0, in, out, n, lane_bytes);
+        else if (rowb == 64) hipLaunchKernelGGL(k_io<64>, dim3(grid), dim3(waves * 64), lds, 0, in, out, n, lane_bytes, mode);
         else if (rowb == 128) hipLaunchKernelGGL(k_io<128>, dim3(grid), dim3(waves * 64), lds, 0, in, out, n, lane_bytes, mode);
         else hipLaunchKernelGGL(k_io<256>, dim3(grid), dim3(waves * 64), lds, 0, in, out, n, lane_bytes, mode);
         hipEventRecord(e1); hipEventSynchronize(e1);

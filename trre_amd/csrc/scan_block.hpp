@@ -1094,19 +1094,32 @@ TRRE_HD void lpw_redo(const ScanArgs& a, int64_t lane) {
 // a wave instruction touches 16 rows x 64 contiguous, 64-byte aligned bytes.  The input tile goes
 // straight from global memory to LDS (global_load_lds_dwordx4: no staging registers); every lane
 // takes its row into registers, at which point the next tile is already requested into the same
-// buffer.  Output blocks are collected in a second tile whose rows are the aligned 64 bytes BEHIND
-// the lane's position (the output lags the input by the window delay, so the last block of a row
-// is only known after the first block of the next piece) and the wave stores that tile the way
-// the input was loaded.
+// buffer.  Output blocks are collected in a second tile of 128-byte rows, the aligned 128 bytes
+// BEHIND the lane's position (the output lags the input by the window delay, so the last block of
+// a row is only known after the first block of the piece after it), and every second iteration the
+// wave stores that tile as whole 128-byte lines, eight adjacent lanes per line (the compute-free
+// probe tools/probes/io_probe: 64-byte rows both ways 1.83 TB/s, 64-byte loads with 128-byte
+// stores 2.47 TB/s, 128-byte rows both ways 2.52 TB/s).  All lanes start walking at a multiple of
+// 128 bytes (in SKIP state up to their first line start), so their lines complete in step.
 //
-// Tile layout: row r (= lane r of the wave) at r * 64; logical block b of the row sits in physical
-// 16-byte slot b ^ ((r >> 1) & 3), which makes both the row-wise accesses of 8 consecutive lanes
-// and the slot-linear accesses of the tile moves conflict-free.  The LDS side of a direct load is
-// linear in the lane id, so the permutation is applied to the global address instead.
+// Tile layouts: input row r (= lane r of the wave) at r * 64, logical block b in physical 16-byte
+// slot b ^ ((r >> 1) & 3); output row r at r * 128, block b in slot b ^ (r & 7).  That makes both
+// the row-wise accesses of 8 consecutive lanes and the slot-linear accesses of the tile moves
+// conflict-free.  The LDS side of a direct load is linear in the lane id, so the permutation is
+// applied to the global address instead.
 // =============================================================================================
 constexpr int kWtBlocks = 4;
 constexpr int kWtPiece = 16 * kWtBlocks;
 constexpr int kWtTile = 64 * kWtPiece;             // one piece of every lane of a wave
+constexpr int kWtOutRow = 128;                     // output rows: whole cache lines
+constexpr int kWtOutTile = 64 * kWtOutRow;
+
+// a lane's row of the output tile
+struct WtOutRow {
+    uint8_t* row;        // tile + r * 128
+    uint32_t swz16;      // (r & 7) << 4
+    TRRE_HD uint8_t* slot(int b) const { return row + ((uint32_t)(b << 4) ^ swz16); }
+};
 
 // byte classes of one dword
 TRRE_HD void lpw_classes(const LpwView& T, uint32_t w, uint32_t (&kk)[4]) {
@@ -1178,7 +1191,7 @@ struct WtLane {
         rfs = (int32_t)(fs - lo);
         const int64_t room = a.vend - lo - 3 * kWtPiece;          // pieces are fetched one ahead: never run into
         rlimit = room < 0x40000000 ? (int32_t)room : 0x40000000;  // the end of the input; keep 32-bit offsets exact
-        rv = rfs & ~(kWtPiece - 1);
+        rv = rfs & ~(kWtOutRow - 1);                              // (output rows of all lanes complete in step)
         row = rv == rfs ? 0u : kSkipState * n_cls * 16u;          // the byte before fs is '\n': SKIP reaches root exactly at fs
         win = 0; Rprev = 0; done = 0;
         rend = 0x7fffffff;
@@ -1189,70 +1202,79 @@ struct WtLane {
     TRRE_HD void check(const ScanArgs& a, int64_t lane) {
         if (active && rv > rlimit) { lpw_redo(a, lane); active = false; }
     }
-    // 0: one of the lane's first two pieces (may hold offsets below its first line start)
+    // 0: one of the lane's first three pieces (may hold offsets below its first line start)
     // 1: a piece well inside the sub-range   2: a piece in which the lane's last line may end
-    TRRE_HD int mode(int32_t k64) const { return k64 < 2 * kWtPiece ? 0 : (rv + kWtPiece < rhi ? 1 : 2); }
+    TRRE_HD int mode(int32_t k64) const { return k64 < 3 * kWtPiece ? 0 : (rv + kWtPiece < rhi ? 1 : 2); }
 
-    // The output block `carry` = offsets [r0, r0 + 16) is complete: it goes to slot `b` of the lane's
+    // The output block `carry` = offsets [r0, r0 + 16) is complete: it goes to its slot of the lane's
     // output row.  kHead: the block that contains the lane's first line start is written to memory
     // from here, bytewise from that offset (the tile store skips it; blocks below are nobody's).
     template <bool kHead>
-    TRRE_HD void emit(const WtRow& orow, int b, int32_t r0, uint8_t* out_v0) {
-        orow.store(b, carry);
+    TRRE_HD void emit(const WtOutRow& orow, int32_t r0, uint8_t* out_v0) {
+        uint8_t* blk = orow.slot((r0 >> 4) & 7);
+        *reinterpret_cast<U128*>(blk) = carry;
         if (kHead && r0 < rfs && r0 + 16 > rfs) {
             // (a real loop over the bytes just put in the tile: this runs once per lane, keep it small)
-            const uint8_t* blk = orow.row + ((uint32_t)(b << 4) ^ orow.swz16);
 #pragma clang loop unroll(disable)
             for (int i = rfs - r0; i < 16; ++i) out_v0[lo + r0 + i] = blk[i];
         }
     }
     template <bool kCheckEnd, bool kHead>
-    TRRE_HD void step(const LpwView& T, const U128& blk, uint32_t next_w, int q, const WtRow& orow, uint8_t* out_v0) {
+    TRRE_HD void step(const LpwView& T, const U128& blk, uint32_t next_w, int q, const WtOutRow& orow, uint8_t* out_v0) {
         uint32_t Rm[4];
         wt_block<kCheckEnd>(T, blk, next_w, kk, rv + 16 * q, rhi, row, win, seen, Rm, done, rend);
         carry.w = alignbyte_b32(Rm[0], Rprev, D);
-        emit<kHead>(orow, (q + 3) & 3, rv - 16 + 16 * q, out_v0);
+        emit<kHead>(orow, rv - 16 + 16 * q, out_v0);
         carry.x = alignbyte_b32(Rm[1], Rm[0], D);
         carry.y = alignbyte_b32(Rm[2], Rm[1], D);
         carry.z = alignbyte_b32(Rm[3], Rm[2], D);
         Rprev = Rm[3];
     }
-    // First block of the piece at rv: completes the output row [rv - 64, rv) (slot 3).
-    TRRE_HD void front(const LpwView& T, int md, const U128& b0, uint32_t next_w, const WtRow& orow, uint8_t* out_v0) {
+    // First block of the piece at rv: the output block below rv (in every second piece it completes an output row).
+    TRRE_HD void front(const LpwView& T, int md, const U128& b0, uint32_t next_w, const WtOutRow& orow, uint8_t* out_v0) {
         lpw_classes(T, b0.x, kk);
         if (md == 0) step<true, true>(T, b0, next_w, 0, orow, out_v0);
         else if (md == 1) step<false, false>(T, b0, next_w, 0, orow, out_v0);
         else step<true, false>(T, b0, next_w, 0, orow, out_v0);
     }
-    // The other three: slots 0..2 of the output row [rv, rv + 64).
+    // The other three: the output blocks [rv, rv + 48).
     template <bool kCheckEnd, bool kHead>
-    TRRE_HD void back_t(const LpwView& T, const U128& b1, const U128& b2, const U128& b3, const WtRow& orow, uint8_t* out_v0) {
+    TRRE_HD void back_t(const LpwView& T, const U128& b1, const U128& b2, const U128& b3, const WtOutRow& orow, uint8_t* out_v0) {
         step<kCheckEnd, kHead>(T, b1, b2.x, 1, orow, out_v0);
         step<kCheckEnd, kHead>(T, b2, b3.x, 2, orow, out_v0);
         step<kCheckEnd, kHead>(T, b3, 0u, 3, orow, out_v0);
     }
-    TRRE_HD void back(const LpwView& T, int md, const U128& b1, const U128& b2, const U128& b3, const WtRow& orow, uint8_t* out_v0) {
+    TRRE_HD void back(const LpwView& T, int md, const U128& b1, const U128& b2, const U128& b3, const WtOutRow& orow, uint8_t* out_v0) {
         if (md == 0) back_t<true, true>(T, b1, b2, b3, orow, out_v0);
         else if (md == 1) back_t<false, false>(T, b1, b2, b3, orow, out_v0);
         else back_t<true, false>(T, b1, b2, b3, orow, out_v0);
         // The lane's own lines end at the first record end at or beyond the end of its sub-range; the
         // automaton has simply kept going to the end of the piece, where what it emits is the head of
         // the next lane's first line, byte for byte what that lane writes itself: whole blocks are stored.
-        if (done && rend <= rv + kWtPiece - 16) active = false;   // every offset below `rend` is in slots 0..2
+        if (done && rend <= rv + kWtPiece - 16) active = false;   // every offset below `rend` is in the output tile
         else rv += kWtPiece;
     }
 };
 
-// What lane `lid` of a wave needs to move tiles: in tile instruction i (0..3) it handles logical block
-// b = (lid & 3) ^ ((lid >> 3) & 3) of row 16 i + (lid >> 2).  Offsets are relative to the start of the
-// wave's first sub-range (a wave spans 64 * lane_bytes < 2^31 bytes).
+// What lane `lid` of a wave needs to move tiles.  Offsets are relative to the start of the wave's first
+// sub-range (a wave spans 64 * lane_bytes < 2^31 bytes).
+//   input  (4 instructions of 16 rows x 64 bytes): instruction i, logical block (lid & 3) ^ ((lid >> 3) & 3)
+//          of row 16 i + (lid >> 2)
+//   output (8 instructions of 8 rows x 128 bytes): instruction i, logical block (lid & 7) ^ ((lid >> 3) & 7)
+//          of row 8 i + (lid >> 3)
 struct WtMover {
-    int32_t src[4];       // offset of that block in the row's piece 0
+    int32_t src[4];       // input: offset of that block in the row's piece 0
+    int32_t dst[8];       // output: offset of that block in the row's output row 0 (= [rv0, rv0 + 128))
     TRRE_HD static int row_of(int lid, int i) { return 16 * i + (lid >> 2); }
     TRRE_HD static int block_of(int lid) { return (lid & 3) ^ ((lid >> 3) & 3); }
-    // row_rv0: the piece-aligned offset at which the row's lane starts walking
+    TRRE_HD static int out_row_of(int lid, int i) { return 8 * i + (lid >> 3); }
+    TRRE_HD static int out_block_of(int lid) { return (lid & 7) ^ ((lid >> 3) & 7); }
+    // row_rv0: the 128-aligned offset at which the row's lane starts walking
     TRRE_HD void set(int lid, int i, int64_t lane_bytes, int32_t row_rv0) {
         src[i] = (int32_t)(row_of(lid, i) * lane_bytes) + row_rv0 + 16 * block_of(lid);
+    }
+    TRRE_HD void set_out(int lid, int i, int64_t lane_bytes, int32_t row_rv0) {
+        dst[i] = (int32_t)(out_row_of(lid, i) * lane_bytes) + row_rv0 + 16 * out_block_of(lid);
     }
     // where to fetch the block of piece k from (rows that are not walking get any readable address);
     // room = offset of the last readable 16 bytes, relative like src
@@ -1260,16 +1282,16 @@ struct WtMover {
         const int64_t v = (int64_t)src[i] + k64;
         return (int32_t)(v < room ? v : room);
     }
-    // Iteration k stores the output rows [rv - 64, rv): slots 0..2 were written in iteration k - 1,
-    // slot 3 in this one (rows / rows_prev: the lanes that walked then).  Blocks below the row's first
-    // line start (row_rfs, relative to its sub-range) are nobody's; the one containing it is written
-    // by the row's lane itself.
-    TRRE_HD static bool stores(int i, int32_t k64, uint64_t rows, uint64_t rows_prev, int lid, int32_t row_rfs) {
-        const int b = block_of(lid);
-        const uint64_t m = b == 3 ? rows : rows_prev;
-        return ((m >> row_of(lid, i)) & 1u) && k64 - kWtPiece + 16 * b >= (row_rfs & (kWtPiece - 1));
+    // An iteration with k64 a multiple of 128 stores the output rows [rv - 128, rv): blocks 0..2 were
+    // written two iterations ago, 3..6 in the previous one, 7 in this one (rows2 / rows1 / rows: the
+    // lanes that walked then).  Blocks below the row's first line start (row_rfs, relative to its
+    // sub-range) are nobody's; the one containing it is written by the row's lane itself.
+    TRRE_HD static bool stores(int i, int32_t k64, uint64_t rows, uint64_t rows1, uint64_t rows2, int lid, int32_t row_rfs) {
+        const int b = out_block_of(lid);
+        const uint64_t m = b == 7 ? rows : (b >= 3 ? rows1 : rows2);
+        return ((m >> out_row_of(lid, i)) & 1u) && k64 - kWtOutRow + 16 * b >= (row_rfs & (kWtOutRow - 1));
     }
-    TRRE_HD int32_t store_off(int i, int32_t k64) const { return src[i] + k64 - kWtPiece; }
+    TRRE_HD int32_t store_off(int i, int32_t k64) const { return dst[i] + k64 - kWtOutRow; }
 };
 
 // =============================================================================================

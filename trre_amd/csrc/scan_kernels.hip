@@ -600,7 +600,7 @@ constexpr int kWtEntMax = 32768;          // larger window tables stay in global
 
 template <bool kLdsEnt>
 __global__ __launch_bounds__(kWtThreads) void k_stream_lpw(ScanArgs a, int64_t lane_bytes, int ent_room) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];    // cls[256] | entries[ent_room] | tiles[waves][in, out][4 KiB]
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];    // cls[256] | entries[ent_room] | tiles[waves][in 4 KiB, out 8 KiB]
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
     for (int k = threadIdx.x; k < 256; k += kWtThreads) smem[k] = a.blob[h.off_cls + k];
     if (kLdsEnt) {
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(kWtThreads) void k_stream_lpw(ScanArgs a, int64_t l
     T.ent = kLdsEnt ? reinterpret_cast<const U128*>(smem + 256) : reinterpret_cast<const U128*>(a.blob + h.off_lpw);
     T.delay = h.lpw_delay;
     const int lid = threadIdx.x & (kWave - 1);
-    uint8_t* tin = smem + 256 + ent_room + (threadIdx.x / kWave) * 2 * kWtTile;
+    uint8_t* tin = smem + 256 + ent_room + (threadIdx.x / kWave) * (kWtTile + kWtOutTile);
     uint8_t* tout = tin + kWtTile;
     const int64_t lane = (int64_t)blockIdx.x * kWtThreads + threadIdx.x;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -624,27 +624,29 @@ __global__ __launch_bounds__(kWtThreads) void k_stream_lpw(ScanArgs a, int64_t l
     WtMover M;
 #pragma unroll
     for (int i = 0; i < 4; ++i) M.set(lid, i, lane_bytes, __shfl(L.rv, WtMover::row_of(lid, i)));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) M.set_out(lid, i, lane_bytes, __shfl(L.rv, WtMover::out_row_of(lid, i)));
     // the wave's window of the buffers (uniform) and how far a fetch may reach in it
     const int64_t wave_lo = (lane - lid) * lane_bytes;
     const uint8_t* win_in = a.in_v0 + wave_lo;
     uint8_t* win_out = a.out_v0 + wave_lo;
     const int64_t room0 = ((a.vend - 16) & ~(int64_t)15) - wave_lo;
     const WtRow irow{tin + lid * kWtPiece, (uint32_t)((lid >> 1) & 3) << 4};
-    const WtRow orow{tout + lid * kWtPiece, (uint32_t)((lid >> 1) & 3) << 4};
-    uint64_t rows_prev = 0;
+    const WtOutRow orow{tout + lid * kWtOutRow, (uint32_t)(lid & 7) << 4};
+    uint64_t rows1 = 0, rows2 = 0;            // the lanes that walked in the previous iteration / the one before
     if (__ballot(L.active)) {
         const uint32_t t0 = __builtin_amdgcn_readfirstlane(wt_lds_addr(tin));
 #pragma unroll
         for (int i = 0; i < 4; ++i) wt_glds16(win_in + M.load_off(i, 0, room0), t0 + i * 1024);
-        bool st1 = false;                     // the previous iteration issued all four tile stores, unconditionally
+        bool st1 = false;                     // the previous iteration issued all eight tile stores, unconditionally
         for (int32_t k64 = 0;; k64 += kWtPiece) {       // 64 k (a sub-range never walks 2^31 bytes: see rlimit)
             L.check(a, lane);
             const uint64_t rows = __ballot(L.active);
-            if (!rows && !rows_prev) break;
+            if (!rows && !rows1 && !rows2) break;
             // Input tile k must have landed.  The memory counter retires in order and the only operations
             // issued after the tile's loads are the previous iteration's stores, which count only when
             // they were certainly issued (an all-lanes-off store may be branched over).
-            if (st1) TRRE_WAIT_VM(4);
+            if (st1) TRRE_WAIT_VM(8);
             else TRRE_WAIT_VM(0);
             const U128 b0 = irow.load(0), b1 = irow.load(1), b2 = irow.load(2), b3 = irow.load(3);
             TRRE_WAIT_LGKM0();                // the rows are in registers: the buffer can take tile k + 1
@@ -652,32 +654,37 @@ __global__ __launch_bounds__(kWtThreads) void k_stream_lpw(ScanArgs a, int64_t l
             for (int i = 0; i < 4; ++i) wt_glds16(win_in + M.load_off(i, k64 + kWtPiece, room0), t0 + i * 1024);
             const int md = L.mode(k64);
             if (L.active) L.front(T, md, b0, b1.x, orow, a.out_v0);
-            // the output rows [rv - 64, rv) are complete
-            {
-                const uint8_t* slot = tout + lid * 16;
-                const u32x4 ov0 = *reinterpret_cast<const u32x4*>(slot), ov1 = *reinterpret_cast<const u32x4*>(slot + 1024),
-                            ov2 = *reinterpret_cast<const u32x4*>(slot + 2048), ov3 = *reinterpret_cast<const u32x4*>(slot + 3072);
-                const bool steady = rows == ~0ull && rows_prev == ~0ull && k64 >= 3 * kWtPiece;
-                if (steady) {
-                    *reinterpret_cast<u32x4*>(win_out + M.store_off(0, k64)) = ov0;
-                    *reinterpret_cast<u32x4*>(win_out + M.store_off(1, k64)) = ov1;
-                    *reinterpret_cast<u32x4*>(win_out + M.store_off(2, k64)) = ov2;
-                    *reinterpret_cast<u32x4*>(win_out + M.store_off(3, k64)) = ov3;
-                } else {
-                    // (the first pieces and the tail: which blocks are whose is worked out on the spot)
-                    if (WtMover::stores(0, k64, rows, rows_prev, lid, __shfl(L.rfs, WtMover::row_of(lid, 0))))
-                        *reinterpret_cast<u32x4*>(win_out + M.store_off(0, k64)) = ov0;
-                    if (WtMover::stores(1, k64, rows, rows_prev, lid, __shfl(L.rfs, WtMover::row_of(lid, 1))))
-                        *reinterpret_cast<u32x4*>(win_out + M.store_off(1, k64)) = ov1;
-                    if (WtMover::stores(2, k64, rows, rows_prev, lid, __shfl(L.rfs, WtMover::row_of(lid, 2))))
-                        *reinterpret_cast<u32x4*>(win_out + M.store_off(2, k64)) = ov2;
-                    if (WtMover::stores(3, k64, rows, rows_prev, lid, __shfl(L.rfs, WtMover::row_of(lid, 3))))
-                        *reinterpret_cast<u32x4*>(win_out + M.store_off(3, k64)) = ov3;
+            st1 = false;
+            if ((k64 & (kWtOutRow - 1)) == 0) {
+                // the output rows [rv - 128, rv) are complete: out they go, eight lanes per 128-byte line
+                const bool steady = (rows & rows1 & rows2) == ~0ull && k64 >= 2 * kWtOutRow;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const uint8_t* slot = tout + hf * 4096 + lid * 16;
+                    const u32x4 ov0 = *reinterpret_cast<const u32x4*>(slot), ov1 = *reinterpret_cast<const u32x4*>(slot + 1024),
+                                ov2 = *reinterpret_cast<const u32x4*>(slot + 2048), ov3 = *reinterpret_cast<const u32x4*>(slot + 3072);
+                    if (steady) {
+                        *reinterpret_cast<u32x4*>(win_out + M.store_off(4 * hf + 0, k64)) = ov0;
+                        *reinterpret_cast<u32x4*>(win_out + M.store_off(4 * hf + 1, k64)) = ov1;
+                        *reinterpret_cast<u32x4*>(win_out + M.store_off(4 * hf + 2, k64)) = ov2;
+                        *reinterpret_cast<u32x4*>(win_out + M.store_off(4 * hf + 3, k64)) = ov3;
+                    } else {
+                        // (the first pieces and the tail: which blocks are whose is worked out on the spot)
+                        if (WtMover::stores(4 * hf + 0, k64, rows, rows1, rows2, lid, __shfl(L.rfs, WtMover::out_row_of(lid, 4 * hf + 0))))
+                            *reinterpret_cast<u32x4*>(win_out + M.store_off(4 * hf + 0, k64)) = ov0;
+                        if (WtMover::stores(4 * hf + 1, k64, rows, rows1, rows2, lid, __shfl(L.rfs, WtMover::out_row_of(lid, 4 * hf + 1))))
+                            *reinterpret_cast<u32x4*>(win_out + M.store_off(4 * hf + 1, k64)) = ov1;
+                        if (WtMover::stores(4 * hf + 2, k64, rows, rows1, rows2, lid, __shfl(L.rfs, WtMover::out_row_of(lid, 4 * hf + 2))))
+                            *reinterpret_cast<u32x4*>(win_out + M.store_off(4 * hf + 2, k64)) = ov2;
+                        if (WtMover::stores(4 * hf + 3, k64, rows, rows1, rows2, lid, __shfl(L.rfs, WtMover::out_row_of(lid, 4 * hf + 3))))
+                            *reinterpret_cast<u32x4*>(win_out + M.store_off(4 * hf + 3, k64)) = ov3;
+                    }
                 }
                 st1 = steady;
             }
             if (L.active) L.back(T, md, b1, b2, b3, orow, a.out_v0);
-            rows_prev = rows;
+            rows2 = rows1;
+            rows1 = rows;
         }
         TRRE_WAIT_VM(0);                      // no load may still be writing LDS when the wave ends
     }
@@ -709,7 +716,7 @@ void launch_lpw_kernel(int ent_bytes, bool direct_ent_in_lds, const ScanArgs& a,
     const dim3 grid((unsigned)((n_lanes + kWtThreads - 1) / kWtThreads));
     const bool ent_in_lds = ent_bytes <= kWtEntMax;
     const int ent_room = ent_in_lds ? (ent_bytes + 15) / 16 * 16 : 0;
-    const int lds = 256 + ent_room + kWtWaves * 2 * kWtTile;
+    const int lds = 256 + ent_room + kWtWaves * (kWtTile + kWtOutTile);
     if (ent_in_lds) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_lpw<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL((k_stream_lpw<true>), grid, dim3(kWtThreads), lds, s, a, lane_bytes, ent_room);
