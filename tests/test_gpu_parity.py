@@ -188,3 +188,15 @@ def test_dictionary_config_on_gpu():
         want = Oracle(pat, eng).scan(data[: 1 << 18] if eng == "nft" else data)   # the NFT oracle is ~0.2 MB/s here
         got = gpu_scan(p, data[: 1 << 18] if eng == "nft" else data)
         assert got == want, eng
+
+
+def test_random_patterns_against_the_oracle():
+    """a short run of the differential fuzz (tools/gpu_fuzz.py): random patterns and inputs, every kernel
+    family each pattern admits, misaligned buffers"""
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gpu_fuzz.py")
+    r = subprocess.run([sys.executable, script, "--seconds", "12", "--seed", "20250926"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = r.stdout.decode("latin-1")
+    assert r.returncode == 0 and "0 mismatches" in out, out[-2000:]
