@@ -190,6 +190,27 @@ def test_dictionary_config_on_gpu():
         assert got == want, eng
 
 
+def test_host_buffers_in_chunks():
+    """trre_scan_host pipelines inputs larger than 64 MiB in line-aligned chunks; a too small output
+    buffer reports the size needed"""
+    import ctypes
+    rng = random.Random(77)
+    block = corpus.word_soup(rng, 3 << 20) + b"a line without cats\n"
+    data = block * 50                                        # ~150 MiB, three chunks
+    for pat, eng in [("(cat:dog|dog:cat)", "nft"), ("a:xyz", "dft"), ("[a:A-z:Z]", "dft")]:
+        p = prog(pat, eng)
+        want_block = Oracle(pat, eng).scan(block)
+        got = p.scan(data)
+        assert len(got) == len(want_block) * 50, (pat, eng)
+        assert got[:len(want_block)] == want_block and got[-len(want_block):] == want_block, (pat, eng)
+        assert got == want_block * 50, (pat, eng)
+    p = prog("a:xyz", "dft")
+    small = ctypes.create_string_buffer(1 << 20)
+    m = ctypes.c_size_t()
+    rc = trre_amd.api.lib().trre_scan_host(p._h, data, len(data), small, len(small), ctypes.byref(m), 0)
+    assert rc == trre_amd.api.E_CAPACITY and m.value == len(Oracle("a:xyz", "dft").scan(block)) * 50
+
+
 def test_random_patterns_against_the_oracle():
     """a short run of the differential fuzz (tools/gpu_fuzz.py): random patterns and inputs, every kernel
     family each pattern admits, misaligned buffers"""

@@ -174,17 +174,18 @@ class Program:
 
     def scan(self, data, device=0):
         """bytes in -> bytes out through trre_scan_host (H2D, GPU scan, D2H)."""
+        import numpy as np
         data = _bytes(data)
         cap = len(data) + 64
         for _ in range(2):
-            out = ctypes.create_string_buffer(cap)
+            out = np.empty(cap, dtype=np.uint8)              # (not zero-filled: the library writes what it reports)
             m = ctypes.c_size_t()
-            rc = lib().trre_scan_host(self._h, data, len(data), out, cap, ctypes.byref(m), device)
+            rc = lib().trre_scan_host(self._h, data, len(data), out.ctypes.data_as(ctypes.c_char_p), cap, ctypes.byref(m), device)
             if rc == E_CAPACITY:
                 cap = m.value + 64
                 continue
             _check(rc)
-            return out.raw[:m.value]
+            return out[:m.value].tobytes()
         _check(rc)
 
     def set_profiling(self, on=True):

@@ -47,6 +47,12 @@ struct DeviceState {
     uint32_t* d_redo = nullptr;       // window kernel redo list
     int64_t redo_lanes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // trre_scan_host: two sets of pinned staging + device buffers and two streams (chunks alternate)
+    struct HostSlot {
+        uint8_t *pin_in = nullptr, *pin_out = nullptr, *d_in = nullptr, *d_out = nullptr;
+        size_t in_cap = 0, out_cap = 0;
+        hipStream_t stream = nullptr;
+    } slot[2];
 };
 
 struct Pending {
@@ -477,6 +483,13 @@ void trre_free(trre_prog* p) {
         (void)hipFree(st.d_redo);
         if (st.ev0) (void)hipEventDestroy(st.ev0);
         if (st.ev1) (void)hipEventDestroy(st.ev1);
+        for (auto& hs : st.slot) {
+            if (hs.pin_in) (void)hipHostFree(hs.pin_in);
+            if (hs.pin_out) (void)hipHostFree(hs.pin_out);
+            (void)hipFree(hs.d_in);
+            (void)hipFree(hs.d_out);
+            if (hs.stream) (void)hipStreamDestroy(hs.stream);
+        }
     }
     delete p;
 }
@@ -543,23 +556,92 @@ int trre_scan_device(trre_prog* p, const uint8_t* d_in, size_t n, uint8_t* d_out
     return trre_scan_finish(p, out_len);
 }
 
+namespace {
+// grow one direction of a host slot (pinned staging + device buffer)
+int slot_reserve(DeviceState::HostSlot& hs, bool input, size_t bytes) {
+    uint8_t*& pin = input ? hs.pin_in : hs.pin_out;
+    uint8_t*& dev = input ? hs.d_in : hs.d_out;
+    size_t& have = input ? hs.in_cap : hs.out_cap;
+    if (have >= bytes) return TRRE_OK;
+    if (pin) (void)hipHostFree(pin);
+    if (dev) (void)hipFree(dev);
+    pin = nullptr; dev = nullptr; have = 0;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&pin), bytes + 64, hipHostMallocDefault));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), bytes + 64));
+    have = bytes;
+    return TRRE_OK;
+}
+constexpr size_t kHostChunk = (size_t)64 << 20;
+}  // namespace
+
+// Host buffers: the input goes through in chunks cut at line ends (lines are independent, so the chunks'
+// outputs simply concatenate), two chunks in flight: while one is on the device the next is staged into
+// pinned memory and the previous one's output is copied out.
 int trre_scan_host(trre_prog* p, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_len, int device) {
-    if (!p || (n && !in)) return fail(TRRE_E_ARG, "error: null argument");
+    if (!p || (n && !in) || (cap && !out)) return fail(TRRE_E_ARG, "error: null argument");
+    if (out_len) *out_len = 0;
+    if (n == 0) return TRRE_OK;
     HIP_TRY(hipSetDevice(device));
-    uint8_t *d_in = nullptr, *d_out = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_in), n + 16));
-    if (hipMalloc(reinterpret_cast<void**>(&d_out), cap + 16) != hipSuccess) {
-        (void)hipFree(d_in);
-        return fail(TRRE_E_DEVICE, "hip: out of device memory");
+    DeviceState* st;
+    int rc = device_state(p, device, &st);
+    if (rc) return rc;
+    for (auto& hs : st->slot)
+        if (!hs.stream) HIP_TRY(hipStreamCreateWithFlags(&hs.stream, hipStreamNonBlocking));
+    const int fam = p->forced_family ? p->forced_family : auto_family(*p);
+    const bool fixed_len = !is_gen(fam);              // output size == input size (unless a NUL forces the general family)
+
+    size_t off = 0, total = 0;                        // input consumed, output produced (or needed)
+    bool overflow = false;                            // the caller's buffer is too small: keep counting only
+    struct Out { size_t at = 0, len = 0; bool live = false; } pend[2];
+    auto drain = [&](int b) -> int {                  // chunk output: pinned -> caller, once its D2H has finished
+        if (!pend[b].live) return TRRE_OK;
+        HIP_TRY(hipStreamSynchronize(st->slot[b].stream));
+        std::memcpy(out + pend[b].at, st->slot[b].pin_out, pend[b].len);
+        pend[b].live = false;
+        return TRRE_OK;
+    };
+    for (int k = 0; off < n; ++k) {
+        const int b = k & 1;
+        DeviceState::HostSlot& hs = st->slot[b];
+        // this chunk: up to kHostChunk bytes, extended to the end of its last line
+        size_t len = n - off;
+        if (len > kHostChunk) {
+            const void* nl = std::memchr(in + off + kHostChunk - 1, '\n', n - off - (kHostChunk - 1));
+            len = nl ? (size_t)(static_cast<const uint8_t*>(nl) - (in + off)) + 1 : n - off;
+        }
+        rc = drain(b);                                // the slot's previous output must have left its staging buffer
+        if (rc) return rc;
+        rc = slot_reserve(hs, true, len);
+        if (rc) return rc;
+        std::memcpy(hs.pin_in, in + off, len);
+        HIP_TRY(hipMemcpyAsync(hs.d_in, hs.pin_in, len, hipMemcpyHostToDevice, hs.stream));
+        size_t want = fixed_len ? len : len + len / 2 + 4096;
+        size_t m = 0;
+        for (;;) {
+            rc = slot_reserve(hs, false, want);
+            if (rc) return rc;
+            rc = enqueue(p, fam, hs.d_in, len, hs.d_out, hs.out_cap, hs.stream);
+            if (!rc) rc = finish(p, &m);
+            if (rc != TRRE_E_CAPACITY) break;
+            want = m + 4096;                          // the general families report the size they need
+        }
+        if (rc) return rc;
+        if (!overflow && total + m > cap) overflow = true;
+        if (!overflow && m) {
+            HIP_TRY(hipMemcpyAsync(hs.pin_out, hs.d_out, m, hipMemcpyDeviceToHost, hs.stream));
+            pend[b].at = total; pend[b].len = m; pend[b].live = true;
+        }
+        total += m;
+        off += len;
+        if (!overflow) {                              // meanwhile: the other slot's output
+            rc = drain(b ^ 1);
+            if (rc) return rc;
+        }
     }
-    int rc = TRRE_OK;
-    size_t m = 0;
-    if (hipMemcpy(d_in, in, n, hipMemcpyHostToDevice) != hipSuccess) rc = fail(TRRE_E_DEVICE, "hip: H2D copy failed");
-    if (!rc) rc = trre_scan_device(p, d_in, n, d_out, cap, &m, nullptr);
-    if (out_len) *out_len = m;
-    if (!rc && m && hipMemcpy(out, d_out, m, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(TRRE_E_DEVICE, "hip: D2H copy failed");
-    (void)hipFree(d_in);
-    (void)hipFree(d_out);
+    if (out_len) *out_len = total;
+    if (overflow) return fail(TRRE_E_CAPACITY, "error: output buffer too small");
+    rc = drain(0);
+    if (!rc) rc = drain(1);
     return rc;
 }
 
