@@ -735,21 +735,12 @@ TRRE_HD void stage_append(Stage& s, uint64_t v, uint32_t n) {
 }
 // the same for at most 4 bytes
 TRRE_HD void stage_append4(Stage& s, uint32_t v, uint32_t n) { stage_append(s, (uint64_t)v, n); }
-// exactly len (1..8) bytes of v at the fill position, written to the buffer directly (rare path)
-TRRE_HD void stage_append_text(Stage& s, uint64_t v, uint32_t len) {
-    const uint32_t at = s.fill();
-    if (len >= 4u) {
-        const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> (8u * (len - 4u)));
-        __builtin_memcpy(s.buf + at, &lo, 4);
-        __builtin_memcpy(s.buf + at + len - 4u, &hi, 4);
-    } else {
-        for (uint32_t i = 0; i < len; ++i) s.buf[at + i] = (uint8_t)(v >> (8u * i));
-    }
-    const uint32_t f = at + len;
-    s.wp = f & ~3u;
-    s.pb = f & 3u;
-    const uint32_t w = *reinterpret_cast<const uint32_t*>(s.buf + s.wp);      // the window again, from the buffer
-    s.acc = s.pb ? (uint64_t)(w & (0xffffffffu >> (32u - 8u * s.pb))) : 0ull;
+// a pooled text of 5..8 bytes, then maybe the input byte c: two appends through the window (no LDS round trip)
+TRRE_HD void stage_append_text_c(Stage& s, uint64_t text, uint32_t len, uint32_t c, uint32_t cc) {
+    stage_append(s, (uint64_t)(uint32_t)text, 4u);
+    const uint32_t rest = len - 4u;                                     // 1..4 bytes
+    const uint64_t hi = (text >> 32) & (0xffffffffull >> (32u - 8u * rest));
+    stage_append(s, hi | (uint64_t)(cc ? c : 0u) << (8u * rest), rest + cc);
 }
 TRRE_HD void stage_store_sector(Stage& s, uint32_t c) {
     if (c == 0 && s.skip) {
@@ -853,7 +844,7 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
                                     uint64_t text;
                                     if (T.pool_fast) __builtin_memcpy(&text, T.pool_fast + str_pool_off(ehi) + 4, 8);
                                     else __builtin_memcpy(&text, T.pool + str_pool_off(ehi) + 4, 8);
-                                    stage_append_text(S, text, len);
+                                    stage_append_text_c(S, text, len, c, cc);
                                 } else {
                                     const uint8_t* r = T.pool + str_pool_off(ehi);
                                     if (len == 255u) len = str_pool_len(T, ehi);
@@ -862,8 +853,8 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
                                     uint8_t* gp = S.gq + S.fill();
                                     for (uint32_t i = 0; i < len; ++i) gp[i] = r[4 + i];
                                     stage_begin(S, S.buf, gp + len);
+                                    stage_append(S, (uint64_t)(cc ? c : 0u), cc);
                                 }
-                                stage_append(S, (uint64_t)(cc ? c : 0u), cc);
                             }
                         }
                     }
@@ -890,10 +881,11 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
                         if (pooled) {
                             uint32_t len = ehi >> 24;
                             if (len <= 8u) {
+                                // (pooled texts are longer than the 4 bytes an entry holds inline)
                                 uint64_t text;
                                 if (T.pool_fast) __builtin_memcpy(&text, T.pool_fast + str_pool_off(ehi) + 4, 8);
                                 else __builtin_memcpy(&text, T.pool + str_pool_off(ehi) + 4, 8);
-                                stage_append_text(S, text, len);
+                                stage_append_text_c(S, text, len, c, cc);
                             } else {
                                 // long replacement text: empty the staging buffer, write straight to memory
                                 const uint8_t* r = T.pool + str_pool_off(ehi);
@@ -903,8 +895,8 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
                                 uint8_t* g = S.gq + S.fill();
                                 for (uint32_t i = 0; i < len; ++i) g[i] = r[4 + i];
                                 stage_begin(S, S.buf, g + len);
+                                stage_append(S, (uint64_t)(cc ? c : 0u), cc);
                             }
-                            stage_append(S, (uint64_t)(cc ? c : 0u), cc);
                         }
                     }
                 } else {
