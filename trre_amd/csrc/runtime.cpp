@@ -292,8 +292,13 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
     static const int64_t lane_bytes_env = getenv("TRRE_LANE_BYTES") ? atoll(getenv("TRRE_LANE_BYTES")) : 0;
     const bool window = is_stream(family) && stream_impl == 2 && family == TRRE_KERNEL_STREAM_LP && p->stt.lpw_ok &&
                         (reinterpret_cast<uintptr_t>(args.out_v0) & 15u) == 0;   // its 16-byte stores need in and out congruent mod 16
-    const int64_t lane_bytes = lane_bytes_env > 0 ? (lane_bytes_env + 127) / 128 * 128
-                                                  : (family == TRRE_KERNEL_STREAM_LP && !window ? 1024 : 2048);
+    // sub-range per lane: 2 KiB, growing with the input so that about half a million lanes (8192 waves)
+    // walk it — per-lane costs (the skipped head, the tail beyond the sub-range, the wave waiting for its
+    // slowest lane) shrink with longer lanes: cfg 4 at 8 GiB 1.72 TB/s with 2 KiB lanes, 2.06 with 16 KiB
+    int64_t lane_auto = family == TRRE_KERNEL_STREAM_LP && !window ? 1024 : 2048;
+    if (window)
+        while (lane_auto < 16384 && (int64_t)n / (lane_auto * 2) >= 524288) lane_auto *= 2;
+    const int64_t lane_bytes = lane_bytes_env > 0 ? (lane_bytes_env + 127) / 128 * 128 : lane_auto;
     const bool direct = is_stream(family) && stream_impl >= 1;
     const bool direct_ent_lds = p->stt.ok && p->stt.ent.size() * 8 <= (size_t)direct_ent_lds_bytes();
     if (direct) n_chunks = (args.vend + lane_bytes * direct_block_threads() - 1) / (lane_bytes * direct_block_threads());
