@@ -425,7 +425,7 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_g16(ScanArgs a, int64
     }
     StreamView T;
     uint8_t* pool_lds = smem + 256 + g16_room;
-    if ((int)h.pool_bytes <= kDirectPoolSmall) {
+    if (kMode != 1 && (int)h.pool_bytes <= kDirectPoolSmall) {
         const uint32_t* e = reinterpret_cast<const uint32_t*>(a.blob + h.off_pool);
         uint32_t* d = reinterpret_cast<uint32_t*>(pool_lds);
         for (int k = threadIdx.x; k < (int)(h.pool_bytes / 4); k += kDirectThreads) d[k] = e[k];
@@ -437,8 +437,11 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_g16(ScanArgs a, int64
     T.ent = reinterpret_cast<const uint64_t*>(a.blob + h.off_ent);
     T.pool = a.blob + h.off_pool;
     T.long_pool = h.max_out >= 255u;
-    uint8_t* ring = pool_lds + kDirectPoolSmall + threadIdx.x * kRingStride;
-    uint8_t* tail = pool_lds + kDirectPoolSmall + kDirectThreads * kRingStride;       // 64 bytes
+    // (the count pass has neither pooled texts nor staging buffers in LDS: more resident waves.  With a
+    // large table in global memory that does not pay: k_stream_direct's count pass is fastest at the
+    // 16 waves per CU its emit-sized LDS allows — 1.63 ms against 1.9 ms at 8 or 28 waves: cache capacity)
+    uint8_t* ring = kMode == 1 ? pool_lds : pool_lds + kDirectPoolSmall + threadIdx.x * kRingStride;
+    uint8_t* tail = kMode == 1 ? pool_lds : pool_lds + kDirectPoolSmall + kDirectThreads * kRingStride;       // 64 bytes
     const int64_t lane = (int64_t)blockIdx.x * kDirectThreads + threadIdx.x;
     DirectLane L;
     uint32_t st = 0;
@@ -739,9 +742,10 @@ void launch_direct_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t
     if (g16_bytes > 0 && which != 0) {
         const int room = (g16_bytes + 15) / 16 * 16;
         const int lds = 256 + room + kDirectPoolSmall + kDirectThreads * kRingStride + 64;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_g16<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        const int lds_count = 256 + room + 64;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_g16<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_count);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_g16<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (which == 1) hipLaunchKernelGGL((k_stream_g16<1>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds, s, a, lane_bytes, room);
+        if (which == 1) hipLaunchKernelGGL((k_stream_g16<1>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds_count, s, a, lane_bytes, room);
         else hipLaunchKernelGGL((k_stream_g16<2>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds, s, a, lane_bytes, room);
         return;
     }
