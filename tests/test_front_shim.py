@@ -176,3 +176,36 @@ def test_dictionary_config_through_the_fold():
         for fam in shim_families(p):
             assert shim_lib.scan_like_runtime(p, data, geo=0, family=fam) == want, (eng, fam)
             assert shim_lib.scan_like_runtime(p, data, geo=1, family=fam) == want, (eng, fam)
+
+
+def test_random_replacement_lists():
+    """alternations of literal key:value pairs with values of 0..12 bytes and keys that overlap, share
+    prefixes and end lines: long outputs (inline, split over two transitions, pooled), all stream families"""
+    rng = random.Random(99)
+    alpha = b"abc"
+    checked = 0
+    for it in range(60):
+        n_keys = rng.randint(1, 6)
+        pairs = []
+        for _ in range(n_keys):
+            k = bytes(rng.choice(alpha) for _ in range(rng.randint(1, 4)))
+            v = bytes(rng.choice(b"xyzXYZ01") for _ in range(rng.choice([0, 1, 3, 4, 5, 6, 7, 8, 9, 12])))
+            pairs.append(k + b":" + v)
+        pat = b"|".join(pairs)
+        if rng.random() < 0.5:
+            pat = b"(" + pat + b")"
+        lines = []
+        for _ in range(rng.randint(5, 60)):
+            lines.append(bytes(rng.choice(alpha + b" ") for _ in range(rng.randint(0, 40))))
+        data = b"\n".join(lines) + (b"\n" if rng.random() < 0.7 else b"")
+        for eng in ("dft", "nft"):
+            try:
+                want = Oracle(pat, eng).scan(data)
+                p = trre_amd.Program(pat, eng)
+            except (OracleError, trre_amd.TrreError):
+                continue
+            for fam in shim_families(p):
+                for geo in (0, 1):
+                    assert shim_lib.scan_like_runtime(p, data, geo=geo, family=fam) == want, (pat, eng, fam, geo, data)
+                    checked += 1
+    assert checked > 300

@@ -48,6 +48,17 @@ def gen_input(rng, n):
     return out
 
 
+def gen_replacement_list(rng):
+    """alternation of literal key:value pairs, values of 0..12 bytes (inline, split and pooled outputs)"""
+    pairs = []
+    for _ in range(rng.randint(1, 6)):
+        k = bytes(rng.choice(ALPHA) for _ in range(rng.randint(1, 4)))
+        v = bytes(rng.choice(b"xyzXYZ01") for _ in range(rng.choice([0, 1, 3, 4, 5, 6, 7, 8, 9, 12])))
+        pairs.append(k + b":" + v)
+    pat = b"|".join(pairs)
+    return b"(" + pat + b")" if rng.random() < 0.5 else pat
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60)
@@ -59,7 +70,7 @@ def main():
     n_pat = n_run = n_skip = bad = 0
     fams = {}
     while time.time() < t_end:
-        pat = gen_expr(rng).decode("latin-1")
+        pat = (gen_replacement_list(rng) if rng.random() < 0.3 else gen_expr(rng)).decode("latin-1")
         eng = rng.choice(["dft", "nft"])
         try:
             o = Oracle(pat, eng)
