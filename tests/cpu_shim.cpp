@@ -218,7 +218,8 @@ void run_direct_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uin
 
 // Host emulation of the window kernel (k_stream_lpw): 64 lanes in lockstep over an
 // emulated pair of LDS tiles, the same lane / mover code as the device.
-void run_lpw(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
+template <bool kWide>
+void run_lpw_t(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
     LpwView T;
     T.cls = a.blob + h.off_cls;
@@ -232,7 +233,7 @@ void run_lpw(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
     alignas(16) static uint8_t tin[kWtTile], tout[kWtOutTile];
     const int64_t vhi = (a.vend - 16) & ~(int64_t)15;
     for (int64_t wv = n_waves - 1; wv >= 0; --wv) {
-        WtLane L[64];
+        WtLane<kWide> L[64];
         WtMover M[64];
         const int64_t lane0 = wv * 64;
         for (int lid = 0; lid < 64; ++lid) L[lid].init(b, T, h.n_cls, lane0 + lid, lane_bytes);
@@ -293,6 +294,11 @@ void run_lpw(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
         DirectLane L;
         stream_direct_lane<0>(a, TS, h.n_cls, (int64_t)redo[1 + k / sub] * sub + k % sub, 64, ring, 0, L, status);
     }
+}
+
+void run_lpw(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
+    if (reinterpret_cast<const StreamBlobHeader*>(a.blob)->lpw_delay > 3) run_lpw_t<true>(a, lane_bytes, status);
+    else run_lpw_t<false>(a, lane_bytes, status);
 }
 
 void run_bytemap(const ScanArgs& a, uint32_t& status) {

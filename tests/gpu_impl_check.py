@@ -18,13 +18,14 @@ from oracle_lib import Oracle  # noqa: E402
 
 def main():
     rng = random.Random(31)
-    long_line = b"cat dog ca do " * 700
+    long_line = b"cat dog ca do there hello world abcdefgh abcdefg " * 300
     data = (corpus.word_soup(rng, 400000) + b"short cat\n" + long_line + b"\n" + corpus.printable_lines(rng, 300000)
             + b"nul\0cat dog\n" + b"tail cat without newline")
     clean = data.replace(b"\0", b" ")
     bad = 0
     for pat, eng in [("[a:A-z:Z]", "dft"), ("(cat:dog|dog:cat)", "nft"), ("(cat:dog|dog:cat)", "dft"), ("cat:dog", "nft"),
                      ("a:xyz", "dft"), ("[aie]:", "nft"), ("abc:2|ab:1", "nft"), ("abc:2|ab:1", "dft"),
+                     ("there:THERE|cat:dog", "dft"), ("(hello:world|world:hello)", "nft"), ("abcdefgh:ABCDEFGH|dog:cat", "dft"),
                      ("(cat:elephant|dog:a-replacement-text-of-more-than-forty-bytes-0123456789|do:12345)", "dft"),
                      ("(cat:elephant|dog:a-replacement-text-of-more-than-forty-bytes-0123456789|do:12345)", "nft")]:
         p = trre_amd.Program(pat, eng)

@@ -209,3 +209,30 @@ def test_random_replacement_lists():
                     assert shim_lib.scan_like_runtime(p, data, geo=geo, family=fam) == want, (pat, eng, fam, geo, data)
                     checked += 1
     assert checked > 300
+
+
+def test_wide_window_form():
+    """length-preserving substitutions with keys of 5..8 bytes: the 64-bit window form (32-byte entries);
+    9-byte keys have no window form and take the direct walker"""
+    import struct
+    rng = random.Random(4)
+    words = [b"there", b"hello", b"world", b"ther", b"the", b"abcdefgh", b"abcdefg", b"abcdefghi", b"hell", b"worldly"]
+    lines = []
+    for _ in range(1500):
+        ln = bytearray()
+        for _ in range(rng.randint(0, 12)):
+            ln += rng.choice(words) if rng.random() < 0.5 else bytes(rng.choice(b"abcdefghtlworxyz") for _ in range(rng.randint(1, 9)))
+            ln += rng.choice([b" ", b"", b",", b"  "])
+        lines.append(bytes(ln))
+    data = b"\n".join(lines) + b"\ntail there"
+    for pat, eng, delay in [("there:THERE", "dft", 4), ("there:THERE", "nft", 4), ("hello:world|world:hello", "dft", 4),
+                            ("(hello:world|world:hello)", "nft", 4), ("abcdefgh:ABCDEFGH", "dft", 7),
+                            ("abcdefg:GFEDCBA|hell:HELL", "nft", 6), ("abcdefghi:ABCDEFGHI", "dft", 0)]:
+        p = trre_amd.Program(pat, eng)
+        h = struct.unpack_from("<16I", p.export_stream_tables(), 0)
+        assert h[13] == delay and (h[12] != 0) == (delay != 0), (pat, eng, h[12], h[13])
+        want = Oracle(pat, eng).scan(data)
+        for fam in shim_families(p):
+            for geo in (0, 1):
+                for mis in (0, 3):
+                    assert shim_lib.scan_like_runtime(p, data, geo=geo, family=fam, in_mis=mis, out_mis=mis) == want, (pat, eng, fam, geo, mis)

@@ -51,9 +51,11 @@ def gen_input(rng, n):
 def gen_replacement_list(rng):
     """alternation of literal key:value pairs, values of 0..12 bytes (inline, split and pooled outputs)"""
     pairs = []
+    same_len = rng.random() < 0.4                      # length-preserving lists: the window kernels (keys up to 8 bytes)
     for _ in range(rng.randint(1, 6)):
-        k = bytes(rng.choice(ALPHA) for _ in range(rng.randint(1, 4)))
-        v = bytes(rng.choice(b"xyzXYZ01") for _ in range(rng.choice([0, 1, 3, 4, 5, 6, 7, 8, 9, 12])))
+        k = bytes(rng.choice(ALPHA) for _ in range(rng.randint(1, 8 if same_len else 4)))
+        n = len(k) if same_len else rng.choice([0, 1, 3, 4, 5, 6, 7, 8, 9, 12])
+        v = bytes(rng.choice(b"xyzXYZ01") for _ in range(n))
         pairs.append(k + b":" + v)
     pat = b"|".join(pairs)
     return b"(" + pat + b")" if rng.random() < 0.5 else pat

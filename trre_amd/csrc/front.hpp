@@ -149,15 +149,17 @@ struct StreamTables {
     std::vector<uint64_t> ent;              // [n_states][n_cls]
     std::vector<uint8_t> pool;
     std::vector<uint32_t> pending_len;      // bytes consumed but not yet emitted, per state
-    // "window" form for length-preserving programs whose pending string never exceeds 3 bytes
-    // and whose transitions emit at most 4 bytes: 16 bytes per entry
-    //   x  byte offset of the next state's row (state * n_cls * 16)
-    //   y  [4:0] insert shift = 8 * (delay - pending(source state)), [5] record end, [6] NUL
+    // "window" form for length-preserving programs whose pending string never exceeds 7 bytes.
+    // Up to 3 pending (transitions emit at most 4 bytes): 16 bytes per entry
+    //   x  byte offset of the next state's row (state * n_cls * entry size)
+    //   y  [5:0] insert shift = 8 * (delay - pending(source state)), [6] record end, [7] NUL
     //   z  up to four inline output bytes
     //   w  v_perm_b32 selector that builds the emitted byte sequence from {input byte, z}
+    // 4..7 pending (at most 8 bytes): 32 bytes per entry, the same followed by a second {z, w} pair for
+    // bytes 4..7 and two unused words; the kernel keeps a 64-bit window
     bool lpw_ok = false;
     uint32_t lpw_delay = 0;                 // max pending length
-    std::vector<uint32_t> lpw;              // [n_states][n_cls][4]
+    std::vector<uint32_t> lpw;              // [n_states][n_cls][4 or 8]
     // 16-byte entries for the count / emit passes of small tables (any output length): like the window
     // form without the shift, {next row offset, meta, inline bytes, v_perm selector}; meta [2:0] = bytes
     // the transition appends (inline bytes, then maybe the input byte), [5] record end, [7] "slow":

@@ -22,7 +22,7 @@ void launch_stream_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t
 int direct_ent_lds_bytes();
 int direct_block_threads();
 void launch_direct_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, void* stream, int g16_bytes = 0);
-void launch_lpw_kernel(int ent_bytes, bool direct_ent_in_lds, const ScanArgs& a, int64_t lane_bytes, void* stream);
+void launch_lpw_kernel(int ent_bytes, bool wide, bool direct_ent_in_lds, const ScanArgs& a, int64_t lane_bytes, void* stream);
 void launch_chunk_scan(const uint64_t* total, uint64_t* base, int64_t n_chunks, void* stream);
 void launch_bytemap(const ScanArgs& a, void* stream);
 

@@ -330,7 +330,7 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
         }
         HIP_TRY(hipMemsetAsync(st->d_redo, 0, 4, stream));
         args.redo = st->d_redo;
-        launch_lpw_kernel((int)(p->stt.lpw.size() * 4), direct_ent_lds, args, lane_bytes, stream);
+        launch_lpw_kernel((int)(p->stt.lpw.size() * 4), p->stt.lpw_delay > 3, direct_ent_lds, args, lane_bytes, stream);
     } else if (direct && family == TRRE_KERNEL_STREAM_LP) {
         launch_direct_kernel(0, direct_ent_lds, args, lane_bytes, n_chunks, stream);
     } else if (direct) {

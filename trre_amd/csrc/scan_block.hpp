@@ -1028,6 +1028,9 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
 //   R    = alignbit(win, R, 8)       the byte for position p - delay is final: release it
 //   win >>= 8 ; row = entry.next
 //
+// With 4..7 bytes pending (keys of 5..8 bytes) the window is 64 bits wide and an entry carries a
+// second {bytes, selector} pair for the bytes 4..7 of its sequence (kWide).
+//
 // Output position == input position, so released bytes are packed into aligned
 // dwords statically, 16 bytes at a time.  Each lane walks a long sub-range of the
 // input (lane_bytes); it starts at its first line start and runs to the end of its
@@ -1035,10 +1038,10 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
 // =============================================================================================
 struct LpwView {
     const uint8_t* cls;      // [256]
-    const U128* ent;         // [n_states][n_cls]
+    const U128* ent;         // [n_states][n_cls] entries of 16 bytes (delay <= 3) or 32 bytes
     uint32_t delay;
 };
-constexpr uint32_t kLpwEol = 32u, kLpwNul = 64u;
+constexpr uint32_t kLpwEol = 64u, kLpwNul = 128u;
 
 // position after the first '\n' at or after lo - 1 (the lane's first line start); >= hi: none
 TRRE_HD int64_t first_line_start_global(const ScanArgs& a, int64_t lo, int64_t hi) {
@@ -1121,9 +1124,9 @@ TRRE_HD void lpw_classes(const LpwView& T, uint32_t w, uint32_t (&kk)[4]) {
 // One 16-byte block of the walk.  The class lookups are taken off the row chain: kk holds the
 // classes of the block's first dword on entry and those of next_w on return.  rv: the block's offset
 // in the lane's sub-range, rhi: the sub-range's length.
-template <bool kCheckEnd>
+template <bool kCheckEnd, bool kWide>
 TRRE_HD void wt_block(const LpwView& T, const U128& cur, uint32_t next_w, uint32_t (&kk)[4], int32_t rv, int32_t rhi, uint32_t& row,
-                      uint32_t& win, uint32_t& seen, uint32_t (&Rm)[4], uint32_t& done, int32_t& rend) {
+                      uint32_t& win, uint32_t& win_hi, uint32_t& seen, uint32_t (&Rm)[4], uint32_t& done, int32_t& rend) {
     const uint32_t wd[5] = {cur.x, cur.y, cur.z, cur.w, next_w};
     uint32_t R = 0;
 #pragma unroll
@@ -1133,18 +1136,30 @@ TRRE_HD void wt_block(const LpwView& T, const U128& cur, uint32_t next_w, uint32
         lpw_classes(T, wd[d + 1], kk);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const U128 e = *reinterpret_cast<const U128*>(reinterpret_cast<const uint8_t*>(T.ent) + row + (kc[j] << 4));
+            const uint8_t* ep = reinterpret_cast<const uint8_t*>(T.ent) + row + (kc[j] << (kWide ? 5 : 4));
+            const U128 e = *reinterpret_cast<const U128*>(ep);
             const uint32_t seq = perm_b32(w, e.z, e.w);
-            win |= seq << (e.y & 31u);
-            R = alignbit_b32(win, R, 8);
-            win >>= 8;
+            if (!kWide) {
+                win |= seq << (e.y & 63u);
+                R = alignbit_b32(win, R, 8);
+                win >>= 8;
+            } else {
+                const uint64_t e2 = *reinterpret_cast<const uint64_t*>(ep + 16);       // bytes 4..7: {bytes, selector}
+                const uint32_t seq2 = perm_b32(w, (uint32_t)e2, (uint32_t)(e2 >> 32));
+                uint64_t w64 = (uint64_t)win_hi << 32 | win;
+                w64 |= ((uint64_t)seq2 << 32 | seq) << (e.y & 63u);
+                R = alignbit_b32((uint32_t)w64, R, 8);
+                w64 >>= 8;
+                win = (uint32_t)w64;
+                win_hi = (uint32_t)(w64 >> 32);
+            }
             row = e.x;
             seen |= e.y;
             if (kCheckEnd) {
                 // the first record end at or beyond the end of the sub-range is where the lane's own lines end
                 // (branch-free; the walk itself simply goes on to the end of the piece)
                 const int32_t p1 = rv + 4 * d + j + 1;
-                const uint32_t hit = ((e.y >> 5) & 1u) & (uint32_t)(p1 >= rhi) & (done ^ 1u);
+                const uint32_t hit = ((e.y >> 6) & 1u) & (uint32_t)(p1 >= rhi) & (done ^ 1u);
                 rend = hit ? p1 : rend;
                 done |= hit;
             }
@@ -1159,10 +1174,11 @@ TRRE_HD void wt_block(const LpwView& T, const U128& cur, uint32_t next_w, uint32
     }
 }
 
+template <bool kWide>
 struct WtLane {
     int64_t lo;
     int32_t rhi, rfs, rlimit, rv, rend;
-    uint32_t D, row, win, seen, Rprev, done;
+    uint32_t D, row, win, win_hi, seen, Rprev, done;
     uint32_t kk[4];
     U128 carry;          // the output block being assembled (its last dword needs the next block)
     bool active;
@@ -1184,8 +1200,8 @@ struct WtLane {
         const int64_t room = a.vend - lo - 3 * kWtPiece;          // pieces are fetched one ahead: never run into
         rlimit = room < 0x40000000 ? (int32_t)room : 0x40000000;  // the end of the input; keep 32-bit offsets exact
         rv = rfs & ~(kWtOutRow - 1);                              // (output rows of all lanes complete in step)
-        row = rv == rfs ? 0u : kSkipState * n_cls * 16u;          // the byte before fs is '\n': SKIP reaches root exactly at fs
-        win = 0; Rprev = 0; done = 0;
+        row = rv == rfs ? 0u : kSkipState * n_cls * (kWide ? 32u : 16u);   // the byte before fs is '\n': SKIP reaches root exactly at fs
+        win = 0; win_hi = 0; Rprev = 0; done = 0;
         rend = 0x7fffffff;
         carry = U128{};
         active = true;
@@ -1211,15 +1227,27 @@ struct WtLane {
             for (int i = rfs - r0; i < 16; ++i) out_v0[lo + r0 + i] = blk[i];
         }
     }
+    // One input block.  The released bytes lag the input by `delay` bytes: the output block below this one
+    // is complete after this block's first dword (delay <= 3) or its first two (delay 4..7).
     template <bool kCheckEnd, bool kHead>
     TRRE_HD void step(const LpwView& T, const U128& blk, uint32_t next_w, int q, const WtOutRow& orow, uint8_t* out_v0) {
         uint32_t Rm[4];
-        wt_block<kCheckEnd>(T, blk, next_w, kk, rv + 16 * q, rhi, row, win, seen, Rm, done, rend);
-        carry.w = alignbyte_b32(Rm[0], Rprev, D);
+        wt_block<kCheckEnd, kWide>(T, blk, next_w, kk, rv + 16 * q, rhi, row, win, win_hi, seen, Rm, done, rend);
+        if (!kWide) {
+            carry.w = alignbyte_b32(Rm[0], Rprev, D);
+        } else {
+            carry.z = alignbyte_b32(Rm[0], Rprev, D);
+            carry.w = alignbyte_b32(Rm[1], Rm[0], D);
+        }
         emit<kHead>(orow, rv - 16 + 16 * q, out_v0);
-        carry.x = alignbyte_b32(Rm[1], Rm[0], D);
-        carry.y = alignbyte_b32(Rm[2], Rm[1], D);
-        carry.z = alignbyte_b32(Rm[3], Rm[2], D);
+        if (!kWide) {
+            carry.x = alignbyte_b32(Rm[1], Rm[0], D);
+            carry.y = alignbyte_b32(Rm[2], Rm[1], D);
+            carry.z = alignbyte_b32(Rm[3], Rm[2], D);
+        } else {
+            carry.x = alignbyte_b32(Rm[2], Rm[1], D);
+            carry.y = alignbyte_b32(Rm[3], Rm[2], D);
+        }
         Rprev = Rm[3];
     }
     // First block of the piece at rv: the output block below rv (in every second piece it completes an output row).

@@ -601,7 +601,7 @@ constexpr int kWtThreads = 256;
 constexpr int kWtWaves = kWtThreads / kWave;
 constexpr int kWtEntMax = 32768;          // larger window tables stay in global memory (L1/L2)
 
-template <bool kLdsEnt>
+template <bool kLdsEnt, bool kWide>
 __global__ __launch_bounds__(kWtThreads) void k_stream_lpw(ScanArgs a, int64_t lane_bytes, int ent_room) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];    // cls[256] | entries[ent_room] | tiles[waves][in 4 KiB, out 8 KiB]
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(kWtThreads) void k_stream_lpw(ScanArgs a, int64_t l
     const int64_t lane = (int64_t)blockIdx.x * kWtThreads + threadIdx.x;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-    WtLane L;
+    WtLane<kWide> L;
     L.init(a, T, h.n_cls, lane, lane_bytes);
     WtMover M;
 #pragma unroll
@@ -713,18 +713,23 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_redo(ScanArgs a, int6
     }
     if (st) atomicOr(a.status, st);
 }
-void launch_lpw_kernel(int ent_bytes, bool direct_ent_in_lds, const ScanArgs& a, int64_t lane_bytes, void* stream) {
+void launch_lpw_kernel(int ent_bytes, bool wide, bool direct_ent_in_lds, const ScanArgs& a, int64_t lane_bytes, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
     const dim3 grid((unsigned)((n_lanes + kWtThreads - 1) / kWtThreads));
     const bool ent_in_lds = ent_bytes <= kWtEntMax;
     const int ent_room = ent_in_lds ? (ent_bytes + 15) / 16 * 16 : 0;
     const int lds = 256 + ent_room + kWtWaves * (kWtTile + kWtOutTile);
-    if (ent_in_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_lpw<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL((k_stream_lpw<true>), grid, dim3(kWtThreads), lds, s, a, lane_bytes, ent_room);
+    if (ent_in_lds && wide) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_lpw<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((k_stream_lpw<true, true>), grid, dim3(kWtThreads), lds, s, a, lane_bytes, ent_room);
+    } else if (ent_in_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_lpw<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((k_stream_lpw<true, false>), grid, dim3(kWtThreads), lds, s, a, lane_bytes, ent_room);
+    } else if (wide) {
+        hipLaunchKernelGGL((k_stream_lpw<false, true>), grid, dim3(kWtThreads), lds, s, a, lane_bytes, ent_room);
     } else {
-        hipLaunchKernelGGL((k_stream_lpw<false>), grid, dim3(kWtThreads), lds, s, a, lane_bytes, ent_room);
+        hipLaunchKernelGGL((k_stream_lpw<false, false>), grid, dim3(kWtThreads), lds, s, a, lane_bytes, ent_room);
     }
     const bool ring_lds = reinterpret_cast<const void*>(a.blob) != nullptr && direct_ent_in_lds;
     if (ring_lds) hipLaunchKernelGGL((k_stream_redo<true>), dim3(64), dim3(kDirectThreads), kDirectLds, s, a, lane_bytes);

@@ -378,31 +378,39 @@ private:
         return t;
     }
 
-    // 16-byte entries for the positional-window kernel (see front.hpp)
+    // entries for the positional-window kernel (see front.hpp): 16 bytes when no state has more than
+    // 3 bytes pending (at most 4 bytes per transition, 32-bit window), 32 bytes up to 7 pending
+    // (at most 8 bytes per transition, 64-bit window)
     void build_window_form(StreamTables& t, const std::vector<int>& rep) {
         uint32_t delay = 0;
         for (uint32_t s = 0; s < t.n_states; ++s) delay = std::max(delay, t.pending_len[s]);
-        if (delay > 3) return;
-        std::vector<uint32_t> v((size_t)t.n_states * t.n_cls * 4, 0);
+        if (delay > 7) return;
+        const bool wide = delay > 3;
+        const uint32_t words = wide ? 8u : 4u;
+        if ((size_t)t.n_states * t.n_cls * words * 4 > 32768) return;    // the table lives in LDS
+        std::vector<uint32_t> v((size_t)t.n_states * t.n_cls * words, 0);
         for (uint32_t s = 0; s < t.n_states; ++s) {
             for (uint32_t k = 0; k < t.n_cls; ++k) {
                 const Cell& x = rows_[s][rep[k]];
                 const size_t n = x.out.size() + (x.copy_c ? 1 : 0);
-                if (n > 4) return;                       // (a NUL flushes pending + '\n': at most delay + 1 <= 4)
-                uint32_t* e = &v[((size_t)s * t.n_cls + k) * 4];
-                e[0] = x.next * t.n_cls * 16u;
+                if (n > (wide ? 8u : 4u)) return;        // (a NUL flushes pending + '\n': at most delay + 1)
+                uint32_t* e = &v[((size_t)s * t.n_cls + k) * words];
+                e[0] = x.next * t.n_cls * words * 4u;
                 const bool silent = s == skip_ || s == done_;
-                e[1] = (silent ? 0u : 8u * (delay - t.pending_len[s])) | (x.eol ? 32u : 0u) |
-                       ((rep[k] == 0 && !silent) ? 64u : 0u);
-                uint32_t bytes = 0, sel = 0;
-                for (size_t b = 0; b < 4; ++b) {
-                    uint32_t pick = 0x0cu;                                   // constant 0x00
-                    if (b < x.out.size()) { bytes |= (uint32_t)(uint8_t)x.out[b] << (8 * b); pick = (uint32_t)b; }
-                    else if (b == x.out.size() && x.copy_c) pick = 4u;       // byte 0 of the input register
-                    sel |= pick << (8 * b);
+                e[1] = (silent ? 0u : 8u * (delay - t.pending_len[s])) | (x.eol ? 64u : 0u) |
+                       ((rep[k] == 0 && !silent) ? 128u : 0u);
+                for (uint32_t half = 0; half < words / 4; ++half) {
+                    uint32_t bytes = 0, sel = 0;
+                    for (size_t b = 0; b < 4; ++b) {
+                        const size_t pos = 4 * half + b;
+                        uint32_t pick = 0x0cu;                                   // constant 0x00
+                        if (pos < x.out.size()) { bytes |= (uint32_t)(uint8_t)x.out[pos] << (8 * b); pick = (uint32_t)b; }
+                        else if (pos == x.out.size() && x.copy_c) pick = 4u;     // byte 0 of the input register
+                        sel |= pick << (8 * b);
+                    }
+                    e[2 + 2 * half] = bytes;
+                    e[3 + 2 * half] = sel;
                 }
-                e[2] = bytes;
-                e[3] = sel;
             }
         }
         t.lpw = std::move(v);
