@@ -9,7 +9,7 @@ SRC = os.path.join(HERE, "cpu_shim.cpp")
 SO = os.path.join(HERE, "_shim", "libcpu_shim.so")
 CSRC = os.path.join(os.path.dirname(HERE), "trre_amd", "csrc")
 
-ST_NUL, ST_DIVERGE, ST_CAPACITY, ST_LONGLINE, ST_NEEDSCRATCH, ST_MISMATCH = 1, 2, 4, 8, 16, 1 << 30
+ST_NUL, ST_DIVERGE, ST_CAPACITY, ST_LONGLINE, ST_NEEDSCRATCH, ST_OVERFLOW, ST_MISMATCH = 1, 2, 4, 8, 16, 32, 1 << 30
 
 
 def build():
@@ -67,6 +67,10 @@ def scan_like_runtime(prog, data, geo=1, family=None, in_mis=0, out_mis=0):
     out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
     if out is None:                         # family 8 without a window form: nothing to run
         fam = 6
+        out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
+    if fam in (5, 7, 9) and st & ST_OVERFLOW:           # bounded stream table: the tile kernels take over
+        fam = 3
+        blob = prog.export_tables()
         out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
     assert not st & ST_MISMATCH, "count and emit passes disagree"
     if st & ST_DIVERGE:

@@ -117,8 +117,11 @@ def test_static_properties_of_config_tables():
     assert (i.nft_states, i.nft_cons_states) == (15, 6) and i.kernel == trre_amd.KERNEL_STREAM_LP
     i = prog("a:xyz", "dft").info
     assert i.kernel == trre_amd.KERNEL_STREAM_GEN and not i.flags & 1
-    # attempts that need unbounded look-ahead do not fold: the tile kernels run them
+    # attempts with unbounded look-ahead fold up to 64 pending bytes (longer runs void the launch and the
+    # tile kernels take over); where the pending strings branch the fold gives up: tile kernels only
     i = prog("a*b:x", "nft").info
+    assert i.stream_states == 67 and i.kernel == trre_amd.KERNEL_STREAM_GEN
+    i = prog("(a|b)*c:x", "nft").info
     assert i.stream_states == 0 and i.kernel == trre_amd.KERNEL_TILE_GEN
 
 
@@ -236,3 +239,25 @@ def test_wide_window_form():
             for geo in (0, 1):
                 for mis in (0, 3):
                     assert shim_lib.scan_like_runtime(p, data, geo=geo, family=fam, in_mis=mis, out_mis=mis) == want, (pat, eng, fam, geo, mis)
+
+
+def test_bounded_fold_and_its_fallback():
+    """greedy loops: runs of up to 64 bytes go through the stream tables, longer ones make the launch
+    void (overflow mark) and the tile kernels produce the result"""
+    short = b"a  b   c,  d ,e\naab aaab b\n" * 40 + b"x" + b" " * 60 + b"y\n"
+    long_run = short + b"p" + b" " * 200 + b"q aaaa" + b"a" * 100 + b"b\n" + short
+    for pat in (" +: ", "a+:b", "a*b:x", " *, *:,", "(ab)+:x"):
+        for eng in ("nft", "dft"):
+            p = prog(pat, eng)
+            o = Oracle(pat, eng)
+            for data in (short, long_run):
+                want = o.scan(data)
+                for fam in shim_families(p):
+                    for geo in (0, 1):
+                        assert shim_lib.scan_like_runtime(p, data, geo=geo, family=fam) == want, (pat, eng, fam, geo, len(data))
+    # the mark really is met on the long input
+    p = prog(" +: ", "nft")
+    _, st = shim_lib.shim_scan(p.export_stream_tables(), p.info.engine, 7, long_run, 0)
+    assert st & shim_lib.ST_OVERFLOW
+    _, st = shim_lib.shim_scan(p.export_stream_tables(), p.info.engine, 7, short, 0)
+    assert not st & shim_lib.ST_OVERFLOW

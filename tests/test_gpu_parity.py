@@ -190,6 +190,20 @@ def test_dictionary_config_on_gpu():
         assert got == want, eng
 
 
+def test_bounded_fold_falls_back_to_the_tile_kernels():
+    """greedy loops fold into stream tables for runs of up to 64 bytes; a longer run voids the launch
+    (overflow mark) and the tile kernels produce the result"""
+    rng = random.Random(12)
+    base = corpus.word_soup(rng, 200000).replace(b" ", b"  ")
+    long_run = base + b"p" + b" " * 300 + b"q aaaa" + b"a" * 150 + b"b\n" + base
+    for pat in (" +: ", "a+:b", "a*b:x", " *, *:,"):
+        for eng in ("nft", "dft"):
+            p = prog(pat, eng)
+            o = Oracle(pat, eng)
+            for data in (base, long_run):
+                assert gpu_scan(p, data) == o.scan(data), (pat, eng, len(data))
+
+
 def test_host_buffers_in_chunks():
     """trre_scan_host pipelines inputs larger than 64 MiB in line-aligned chunks; a too small output
     buffer reports the size needed"""

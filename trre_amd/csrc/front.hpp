@@ -137,6 +137,8 @@ DftTables flatten_dft(const Dft& dft);
 //                  min(len, 255) (255: read the record's length)
 //   [27]    after those bytes, also emit the input byte itself
 //   [28]    this byte ends the record ('\n')
+//   [30]    the undecided attempt outgrew max_pending: the table does not know how it ends.  A launch
+//           that meets such a transition reports it and the runtime runs the tile kernels instead
 struct StreamLimits {
     size_t max_states = 4096;
     size_t max_pending = 64;
@@ -144,6 +146,7 @@ struct StreamLimits {
 };
 struct StreamTables {
     bool ok = false;
+    bool bounded = false;                   // some transitions carry the overflow mark (entry bit 30)
     uint32_t n_states = 0, n_cls = 0, flags = 0, max_out = 0;
     std::array<uint8_t, 256> cls{};
     std::vector<uint64_t> ent;              // [n_states][n_cls]

@@ -398,6 +398,12 @@ int finish(trre_prog* p, size_t* out_len) {
         if (rc) return rc;
         return finish(p, out_len);
     }
+    if (is_stream(pd.family) && (status & kStOverflow)) {
+        // an undecided attempt outgrew the stream table (bounded fold): the tile kernels take the buffer
+        int rc = enqueue(p, TRRE_KERNEL_TILE_GEN, pd.d_in, pd.n, pd.d_out, pd.cap, pd.stream);
+        if (rc) return rc;
+        return finish(p, out_len);
+    }
     if (!is_gen(pd.family)) {
         if (status & kStNul) {
             // a NUL cuts its line short, so output positions no longer equal input
@@ -447,7 +453,8 @@ int compile_impl(const std::string& pattern, int engine, trre_prog** out) {
                 deferred.reset(new Error(e));            // too many CONS states for the bitmask kernels
             }
             p->stt = build_stream_nft(nft);
-            if (!p->stt.ok && deferred) throw *deferred;  // neither kernel family can run this pattern
+            // neither kernel family can run this pattern (a bounded stream table needs the tile kernels behind it)
+            if (deferred && (!p->stt.ok || p->stt.bounded)) throw *deferred;
         }
         if (p->stt.ok) serialize_stream(*p);
         *out = p.release();

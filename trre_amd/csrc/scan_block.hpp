@@ -398,10 +398,10 @@ TRRE_HD void stream_line_lp_global(const ScanArgs& a, const StreamView& T, int64
     if (o != p) status |= kStNul;
 }
 template <class Sink>
-TRRE_HD void stream_line_gen_global(const ScanArgs& a, const StreamView& T, Sink& sink, int64_t v) {
+TRRE_HD uint32_t stream_line_gen_global(const ScanArgs& a, const StreamView& T, Sink& sink, int64_t v) {
     GlobalIn in{a.in_v0, a.vend - 1};
     int64_t p = v;
-    uint32_t row = 0;
+    uint32_t row = 0, seen = 0;
     for (;;) {
         const uint8_t c = in(p);
         const uint64_t e = T.ent[row + T.cls[c]];
@@ -409,9 +409,11 @@ TRRE_HD void stream_line_gen_global(const ScanArgs& a, const StreamView& T, Sink
         if constexpr (Sink::kCountOnly) sink.add(str_count(T, lo, hi));
         else sink.n = (uint64_t)str_emit(T, sink.o, (int64_t)sink.n, lo, hi, c);
         row = str_next(lo);
+        seen |= lo;
         ++p;
         if (lo & kStrEol) break;
     }
+    return seen;                                  // (entry flags met: the caller looks for kStrOvf)
 }
 
 // start of the line that contains position v (HBM, slow path only)
@@ -548,6 +550,7 @@ TRRE_HD void stream_lane_gen(const ScanArgs& a, const StreamView& T, uint32_t n_
     const uint32_t done_row = kDoneState * n_cls;
     int ls = row == 0u ? lo : -1;
     bool over = false;
+    uint32_t seen = 0;
     uint64_t mark = sink.n;                   // sink position at the start of the current line
     const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tin);
     StreamPipe q;
@@ -579,6 +582,7 @@ TRRE_HD void stream_lane_gen(const ScanArgs& a, const StreamView& T, uint32_t n_
                 sink.n += n;
             }
             row = str_next(elo);
+            seen |= elo;
             if (elo & kStrEol) {
                 const int p1 = p + j + 1;
                 if (p1 <= G::TILE) { ls = p1; mark = sink.n; } else over = true;
@@ -586,10 +590,11 @@ TRRE_HD void stream_lane_gen(const ScanArgs& a, const StreamView& T, uint32_t n_
             }
         }
     }
+    if (seen & kStrOvf) status |= kStOverflow;
     if (over && ls >= 0) {                    // the line that starts at ls leaves the tile: redo it from HBM
         status |= kStLongLine;
         sink.n = mark;
-        stream_line_gen_global(a, T, sink, v0 + ls);
+        if (stream_line_gen_global(a, T, sink, v0 + ls) & kStrOvf) status |= kStOverflow;
     }
 }
 
@@ -826,7 +831,7 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
                 if (kG16) {
                     const U128 g = *reinterpret_cast<const U128*>(T.g16 + row + ((uint32_t)kk[j] << 4));
                     const uint32_t n = g.y & 7u;
-                    if (kMode == 1) cnt += n;
+                    if (kMode == 1) { cnt += n; seen |= g.y; }
                     else stage_append4(S, perm_b32(w >> (8 * j), g.z, g.w), n);
                     if (TRRE_WAVE_ANY(g.y & 128u)) {
                         if (g.y & 128u) {
@@ -1015,6 +1020,7 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
     if (kMode == 0) direct_flush<true>(obase, ring, of, o);
     if (kMode == 2) stage_flush<true>(S);
     if (kMode == 0 && (seen & kStrNul)) status |= kStNul;
+    if (kMode == 1 && (seen & (kG16 ? 64u : kStrOvf))) status |= kStOverflow;     // bounded fold: the launch is void
     L.count = cnt;
 }
 

@@ -23,7 +23,8 @@ enum : uint32_t {
     kStNul = 1u << 0,        // a NUL byte was seen (length-preserving launch is void)
     kStDiverge = 1u << 1,    // non-deterministic search would not terminate (reference hangs)
     kStCapacity = 1u << 2,   // output does not fit the caller's buffer
-    kStLongLine = 1u << 3    // informational: a line left the LDS tile (slow path taken)
+    kStLongLine = 1u << 3,   // informational: a line left the LDS tile (slow path taken)
+    kStOverflow = 1u << 5    // a stream table met an attempt longer than it was built for: the launch is void
 };
 
 // ---- deterministic tables as the kernel sees them --------------------------------
@@ -196,6 +197,7 @@ struct StreamView {
 };
 TRRE_HD uint64_t str_entry(const StreamView& T, uint32_t idx) { return T.ent[idx]; }
 constexpr uint32_t kStrCopyC = 1u << 27, kStrEol = 1u << 28;
+constexpr uint32_t kStrOvf = 1u << 30;      // the attempt outgrew the table (bounded fold): the result is void, see kStOverflow
 
 TRRE_HD uint32_t str_olen(uint32_t lo) { return (lo >> 24) & 7u; }
 TRRE_HD uint32_t str_next(uint32_t lo) { return lo & 0xffffffu; }

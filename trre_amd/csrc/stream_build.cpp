@@ -213,12 +213,14 @@ private:
         std::string out;     // bytes emitted before the optional copy of the input byte
         bool copy_c = false;
         bool eol = false;
+        bool ovf = false;    // the attempt outgrew max_pending: target SKIP, result void
     };
 
     uint32_t intern(const std::string& w) {
         auto hit = index_.find(w);
         if (hit != index_.end()) return hit->second;
-        if (names_.size() >= lim_.max_states || w.size() > lim_.max_pending) throw GiveUp();
+        if (w.size() > lim_.max_pending) return kOverflow;     // bounded fold: the caller marks the transition
+        if (names_.size() >= lim_.max_states) throw GiveUp();
         uint32_t id = (uint32_t)names_.size();
         names_.push_back(w);
         rows_.emplace_back();
@@ -258,6 +260,16 @@ private:
         }
         std::string rest = resolve(w + (char)c, false, cell.out);
         cell.next = intern(rest);
+        if (cell.next == kOverflow) {
+            // An attempt that is still undecided after max_pending bytes (a long run under a greedy loop).
+            // The table stops following it: the transition swallows the rest of the record and is marked,
+            // a launch that takes it is void and the runtime falls back to the tile kernels.
+            cell.next = skip_;
+            cell.out.clear();
+            cell.ovf = true;
+            bounded_ = true;
+            return cell;
+        }
         // express "... then the input byte itself" through the copy flag so that
         // bytes the pattern never mentions share one column
         // (an exact re-encoding of this cell: the last emitted byte equals the byte read)
@@ -314,7 +326,7 @@ private:
             key.reserve(n);
             for (uint32_t s = 0; s < n; ++s) {
                 const Cell& x = rows_[s][c];
-                key.push_back(std::to_string(x.next) + (x.copy_c ? "C" : "-") + (x.eol ? "E" : "-") + x.out);
+                key.push_back(std::to_string(x.next) + (x.copy_c ? "C" : "-") + (x.eol ? "E" : "-") + (x.ovf ? "O" : "-") + x.out);
             }
             auto hit = col_index.find(key);
             if (hit == col_index.end()) {
@@ -351,6 +363,7 @@ private:
                 }
                 if (x.copy_c) lo |= 1ull << 27;
                 if (x.eol) lo |= 1ull << 28;
+                if (x.ovf) lo |= 1ull << 30;
                 if (rep[k] == 0 && s != skip_ && s != done_) lo |= 1ull << 29;   // a NUL cut a line short
                 // in-place safety: an emitted '\n' may only be the last byte of a record-end transition
                 if (rep[k] != 0) {   // (a NUL voids the in-place launch anyway: kStNul)
@@ -371,6 +384,8 @@ private:
         while (t.pool.size() % 4) t.pool.push_back(0);
         for (int k = 0; k < 8; ++k) t.pool.push_back(0);   // 8-byte reads of a record's text stay inside the pool
         t.ok = true;
+        t.bounded = bounded_;
+        if (bounded_) lp = false;           // (a void launch must be noticed: only the count pass reports it)
         if (lp) build_window_form(t, rep);
         build_gen16(t, rep);
         if (lp) t.flags |= kFlagLengthPreserving;
@@ -429,7 +444,7 @@ private:
                 const bool slow = n > 4;
                 uint32_t* e = &v[((size_t)s * t.n_cls + k) * 4];
                 e[0] = x.next * t.n_cls * 16u;
-                e[1] = (slow ? 128u : (uint32_t)n) | (x.eol ? 32u : 0u);
+                e[1] = (slow ? 128u : (uint32_t)n) | (x.eol ? 32u : 0u) | (x.ovf ? 64u : 0u);
                 uint32_t bytes = 0, sel = 0x0c0c0c0cu;                       // constant 0x00 everywhere
                 if (!slow) {
                     sel = 0;
@@ -454,6 +469,8 @@ private:
     std::vector<std::vector<Cell>> rows_;
     std::unordered_map<std::string, uint32_t> index_;
     uint32_t skip_ = 1, done_ = 2;
+    static constexpr uint32_t kOverflow = 0xffffffffu;
+    bool bounded_ = false;
     bool used_[256];
 };
 
