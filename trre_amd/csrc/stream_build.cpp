@@ -281,32 +281,33 @@ private:
     }
 
     // An entry holds 4 output bytes inline; longer outputs are pooled and cost the kernels a slow path
-    // (with a dictionary, one lane or another of a wave takes it on most steps).  A transition that
-    // emits 5..8 literal bytes is therefore split: it emits the first 4 and enters a copy of its target
-    // state whose every transition first emits the rest.  The copy counts the owed bytes as pending, so
-    // the length bookkeeping of pack() still holds; transitions that end a record or copy the input byte
-    // are left alone (a record's output must be complete when it ends).
+    // (with a dictionary, one lane or another of a wave takes it on most steps), and texts of more than
+    // 8 bytes a very slow one.  A completed match that emits 5..12 literal bytes is therefore split: it
+    // emits the first 4 and enters a copy of the root state whose every transition first emits the rest
+    // (at most 8 bytes: what the kernels append without leaving their fast paths).  The copy counts the
+    // owed bytes as pending, so the length bookkeeping of pack() still holds; transitions that end a
+    // record or copy the input byte are left alone (a record's output must be complete when it ends),
+    // and so are flushes of a long failed prefix (one per deep state and byte, rare at run time).
     void spread_long_outputs() {
-        std::map<std::pair<uint32_t, std::string>, uint32_t> made;
-        const uint32_t n0 = (uint32_t)names_.size();
-        for (uint32_t s = 0; s < n0; ++s) {
+        std::map<std::string, uint32_t> made;
+        for (uint32_t s = 0; s < (uint32_t)names_.size(); ++s) {       // (the copies are visited too: they may owe again)
             if (s == skip_ || s == done_) continue;
             for (int c = 0; c < 256; ++c) {
-                Cell& x = rows_[s][c];
-                // (only completed matches, which return to the root: flushes of a long failed prefix are many
-                // — one per deep state and byte — and rare at run time)
-                if (x.out.size() < 5 || x.out.size() > 8 || x.copy_c || x.eol || x.next != 0u) continue;
-                const std::string rest = x.out.substr(4);
-                auto key = std::make_pair(x.next, rest);
-                auto hit = made.find(key);
+                if (rows_[s][c].out.size() < 5 || rows_[s][c].out.size() > 12 || rows_[s][c].copy_c || rows_[s][c].eol ||
+                    rows_[s][c].next != 0u)
+                    continue;
+                const std::string rest = rows_[s][c].out.substr(4);
+                auto hit = made.find(rest);
                 if (hit == made.end()) {
                     if (names_.size() >= 2 * lim_.max_states) return;      // no room: the remaining ones stay pooled
                     const uint32_t id = (uint32_t)names_.size();
-                    names_.push_back(names_[x.next] + rest);                // (only its length is used from here on)
-                    rows_.emplace_back(rows_[x.next]);
-                    for (Cell& y : rows_.back()) y.out = rest + y.out;
-                    hit = made.emplace(key, id).first;
+                    names_.push_back(rest);                                 // (only its length is used from here on)
+                    std::vector<Cell> row = rows_[0];
+                    for (Cell& y : row) y.out = rest + y.out;
+                    rows_.push_back(std::move(row));
+                    hit = made.emplace(rest, id).first;
                 }
+                Cell& x = rows_[s][c];
                 x.out.resize(4);
                 x.next = hit->second;
             }
