@@ -103,7 +103,11 @@ int trre_scan_device(trre_prog* p, const uint8_t* d_in, size_t n, uint8_t* d_out
 int trre_scan_enqueue(trre_prog* p, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, void* stream);
 int trre_scan_finish(trre_prog* p, size_t* out_len);
 
-/* Host-buffer convenience: H2D copy, scan, D2H copy on `device`. */
+/* Host buffers on `device`: what the scan branch of the reference's main() does with a FILE* (the
+ * getline loop of trre_nft.c:776-790 / trre_dft.c:1272-1286).  The input goes through in 64 MiB chunks
+ * cut at line ends, two in flight (pinned staging, H2D copy, scan, D2H copy overlap); records are
+ * independent, so the chunks' outputs concatenate to exactly the output of one scan.  On
+ * TRRE_E_CAPACITY *out_len is the size the whole output needs. */
 int trre_scan_host(trre_prog* p, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_len, int device);
 
 /* Kernel timing for the last finished scan on this prog (HIP events recorded on
