@@ -599,12 +599,13 @@ TRRE_HD void stream_lane_gen(const ScanArgs& a, const StreamView& T, uint32_t n_
 }
 
 // =============================================================================================
-// Direct stream walk: no LDS tile.  Each lane streams a long contiguous sub-range
-// (lane_bytes, a few KiB) straight from HBM/L2 with 16-byte loads held in
-// registers, so a wave can keep all 8 wave slots of a SIMD busy (no LDS capacity
-// limit) and a lane's tail — the part of its last line beyond its sub-range — is
-// small against its sub-range.  Output bytes go through a 64-byte per-lane LDS
-// ring and leave as aligned 16-byte stores.
+// Direct stream walk: no LDS tile.  Each lane walks a long contiguous sub-range (lane_bytes, a few
+// KiB) of the input straight from HBM/L2, 16-byte loads held in registers, so a lane's tail — the
+// part of its last line beyond its sub-range — is small against its sub-range.  The count and emit
+// passes fetch 64 bytes at a time (one sector, once) and the emit pass assembles the lane's output in
+// a per-lane LDS staging buffer behind a 64-bit register window (see Stage); the in-place walk
+// (kMode 0: tables without a window form, and the window kernel's edge lanes) keeps a 64-byte LDS
+// ring per lane and stores aligned 16-byte chunks.
 //   kMode 0: length-preserving (output address = input address), 1: count, 2: emit
 // =============================================================================================
 // ---- device-only: direct global -> LDS loads and explicit waits ------------------------------------
