@@ -53,6 +53,10 @@ QUIRK_PATTERNS = [
     "(a|b)*c", "(ab)+:x", "a?b", "a??b", "[abc]:x", "[a-c][x-z]",
     "(a:x)*b", "((a:x)|(a:y))c", ".", "...:x", ":x", "a|:x",
     "\\[a\\]", "\xe9:e", "[\xe0:a-\xe5:a]",
+    # classes of tables the kernels treat differently: keys of 5..8 bytes (64-bit window), replacement
+    # texts of 5..12 and more bytes (split / pooled outputs), greedy loops (bounded fold)
+    "hello:world|world:hello", "little:LITTLE", "(quick:slow|brown:red|fox:elephant)", "cat:elephants!",
+    "dog:a-replacement-of-more-than-forty-bytes-0123456789", " +: ", "a*b:x", "o+:0",
 ]
 
 WORDS = ["cat", "dog", "ca", "do", "cadog", "catdog", "lamb", "Mary", "had", "a", "little", "the", "quick",
