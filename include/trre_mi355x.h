@@ -39,7 +39,7 @@ extern "C" {
 #define TRRE_E_UNDEFINED (-2)   /* the reference reads outside its buffers on this pattern */
 #define TRRE_E_EPS_CYCLE (-3)   /* epsilon cycle: the reference recurses without bound (DFT) */
 #define TRRE_E_TOO_BIG (-4)     /* determinisation exceeds the state/residual caps */
-#define TRRE_E_UNSUPPORTED (-5) /* legal pattern, outside this engine's GPU limits (e.g. >64 CONS states, NFT) */
+#define TRRE_E_UNSUPPORTED (-5) /* legal pattern, outside this engine's GPU limits (NFT: backward DFA > 256 states and > 64 nodes) */
 #define TRRE_E_DEVICE (-6)      /* HIP runtime failure / no GPU */
 #define TRRE_E_ARG (-7)
 #define TRRE_E_DIVERGES (-8)    /* the reference would not terminate on this input (NFT epsilon cycle entered) */
@@ -52,6 +52,8 @@ extern "C" {
 #define TRRE_KERNEL_TILE_GEN 3  /* any tables: count + scan + emit */
 #define TRRE_KERNEL_STREAM_LP 4 /* scan loop folded into the tables, length-preserving: in-place, single launch */
 #define TRRE_KERNEL_STREAM_GEN 5 /* scan loop folded into the tables, any output length: count + scan + emit */
+#define TRRE_KERNEL_GUIDED_LP 6  /* NFT engine, any pattern: backward DFA sweep (one symbol per byte) + guided forward transducer, in place */
+#define TRRE_KERNEL_GUIDED_GEN 7 /* the same, any output length: backward sweep, count + scan + emit */
 
 typedef struct trre_prog trre_prog;
 
@@ -68,6 +70,9 @@ typedef struct trre_info {
     uint32_t chunk_bytes;      /* input bytes owned by one workgroup */
     uint32_t stream_states;    /* states of the folded scan transducer (0 = pattern does not fold) */
     uint32_t stream_classes;
+    uint32_t nft_nodes;         /* consuming nodes of the NFT engine's tables (a byte range is one node) */
+    uint32_t guided_rev_states; /* states of the backward DFA of the guided families (0 = not available) */
+    uint32_t guided_fwd_states;
 } trre_info;
 
 /* Replaces parse() + create_nft() (trre_nft.c:752-754) and, for the DFT engine,
@@ -85,6 +90,7 @@ int trre_set_kernel(trre_prog* p, int kernel_family); /* force a family (benchma
  * tests).  Returns the blob size; copies min(size, cap) bytes. */
 size_t trre_export_tables(const trre_prog* p, void* buf, size_t cap);
 size_t trre_export_stream_tables(const trre_prog* p, void* buf, size_t cap); /* 0 if the pattern does not fold */
+size_t trre_export_guided_tables(const trre_prog* p, int which, void* buf, size_t cap); /* which: 0 backward DFA, 1 forward tables; 0 if none */
 
 /* Replaces the scan branch of main() (trre_nft.c:775-790 / trre_dft.c:1272-1286)
  * for a whole buffer that is already resident in HBM.

@@ -181,6 +181,7 @@ StreamView direct_view(const ScanArgs& a) {
     if (h.g16_bytes) T.g16 = a.blob + h.off_g16;
     return T;
 }
+template <bool kSym = false>
 void run_direct_lp(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
     const StreamView T = direct_view(a);
@@ -188,10 +189,19 @@ void run_direct_lp(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
     alignas(16) uint8_t ring[kRingStride];
     for (int64_t lane = n_lanes - 1; lane >= 0; --lane) {      // any order: lanes write disjoint bytes
         DirectLane L;
-        stream_direct_lane<0>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
+        stream_direct_lane<0, false, kSym>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
     }
 }
+// backward pass of the guided families, lane by lane (any order: lanes write disjoint symbols)
+void run_rev_sweep(const ScanArgs& a, int64_t lane_bytes) {
+    const RevBlobHeader& h = *reinterpret_cast<const RevBlobHeader*>(a.rblob);
+    const RevView T{a.rblob + h.off_cls, a.rblob + h.off_tab, h.n_cls};
+    const int64_t vtop = (a.vend + 63) & ~(int64_t)63;
+    const int64_t n_lanes = (vtop + lane_bytes - 1) / lane_bytes;
+    for (int64_t lane = 0; lane < n_lanes; ++lane) rev_sweep_lane(a, T, lane, lane_bytes);
+}
 // g16: walk the 16-byte entries (when the tables have them), like k_stream_g16
+template <bool kSym = false>
 void run_direct_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64_t& total_out, bool g16) {
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
     const StreamView T = direct_view(a);
@@ -200,8 +210,8 @@ void run_direct_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uin
     std::vector<uint64_t> cnt(n_lanes);
     for (int64_t lane = 0; lane < n_lanes; ++lane) {
         DirectLane L;
-        if (g16) stream_direct_lane<1, true>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
-        else stream_direct_lane<1>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
+        if (g16) stream_direct_lane<1, true, kSym>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
+        else stream_direct_lane<1, false, kSym>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
         cnt[lane] = L.count;
     }
     uint64_t run = 0;
@@ -211,8 +221,8 @@ void run_direct_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uin
     if (run > a.cap) { status |= kStCapacity; return; }
     for (int64_t lane = n_lanes - 1; lane >= 0; --lane) {
         DirectLane L;
-        if (g16) stream_direct_lane<2, true>(a, T, h.n_cls, lane, lane_bytes, ring, base[lane], L, status);
-        else stream_direct_lane<2>(a, T, h.n_cls, lane, lane_bytes, ring, base[lane], L, status);
+        if (g16) stream_direct_lane<2, true, kSym>(a, T, h.n_cls, lane, lane_bytes, ring, base[lane], L, status);
+        else stream_direct_lane<2, false, kSym>(a, T, h.n_cls, lane, lane_bytes, ring, base[lane], L, status);
     }
 }
 
@@ -357,14 +367,14 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
     else if (family == 8) {
         if (reinterpret_cast<const StreamBlobHeader*>(blob)->lpw_bytes == 0) return -5;
         // like the runtime: buffers that are not congruent mod 16 go to the direct walker
-        if (reinterpret_cast<uintptr_t>(a.out_v0) & 15u) run_direct_lp(a, geo == 0 ? 2048 : 48, status);
+        if (reinterpret_cast<uintptr_t>(a.out_v0) & 15u) run_direct_lp<>(a, geo == 0 ? 2048 : 48, status);
         else run_lpw(a, geo == 0 ? 2048 : 64, status);
         total = n;
     }
-    else if (family == 6) { run_direct_lp(a, geo == 0 ? 2048 : 48, status); total = n; }
+    else if (family == 6) { run_direct_lp<>(a, geo == 0 ? 2048 : 48, status); total = n; }
     else if (family == 7 || family == 9) {
         const bool g16 = family == 7 && reinterpret_cast<const StreamBlobHeader*>(blob)->g16_bytes != 0;
-        run_direct_gen(a, geo == 0 ? 2048 : 48, status, total, g16);
+        run_direct_gen<>(a, geo == 0 ? 2048 : 48, status, total, g16);
     }
     else if (family == 4) {
         if (geo == 0) run_stream_lp<GeoStream>(a, status); else run_stream_lp<GeoTinyStream>(a, status);
@@ -387,6 +397,44 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
     } else {
         if (geo == 0) run_family<GeoNft64, NftEngine<uint64_t>>(family, a, status, total);
         else run_family<GeoTiny, NftEngine<uint64_t>>(family, a, status, total);
+    }
+    *status_out = status;
+    *m = (size_t)total;
+    if (total <= cap) std::memcpy(out, oa, (size_t)total);
+    return 0;
+}
+
+// Guided families (backward DFA sweep + forward transducer over its symbols).
+// family: 10 length-preserving (in place), 11 general on the 16-byte entries when the tables have them,
+// 12 general on the 8-byte entries.  geo: 0 -> 2048-byte lanes, 1 -> 64-byte lanes.
+int shim_scan_guided(const uint8_t* rblob, const uint8_t* gblob, int family, int geo, const uint8_t* in, size_t n, int in_mis,
+                     uint8_t* out, size_t cap, int out_mis, size_t* m, uint32_t* status_out) {
+    if (n == 0) { *m = 0; *status_out = 0; return 0; }
+    std::vector<uint8_t> ibuf(n + 64, 0xAA), obuf(cap + 64, 0xEE);
+    uint8_t* ia = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(ibuf.data()) + 15) & ~(uintptr_t)15) + in_mis;
+    uint8_t* oa = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(obuf.data()) + 15) & ~(uintptr_t)15) + out_mis;
+    std::memcpy(ia, in, n);
+    ScanArgs a{};
+    const int64_t al = (int64_t)(reinterpret_cast<uintptr_t>(ia) & 15u);
+    a.in_v0 = ia - al;
+    a.out_v0 = oa - al;
+    a.out = oa;
+    a.vbeg = al;
+    a.vend = al + (int64_t)n;
+    a.blob = gblob;
+    a.rblob = rblob;
+    a.cap = cap;
+    std::vector<uint8_t> sym(n + 512, 0xDD);        // poison: every symbol the forward pass walks must have been written
+    a.sym_v0 = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(sym.data()) + 63) & ~(uintptr_t)63);
+    uint32_t status = 0;
+    uint64_t total = 0;
+    const int64_t lane_bytes = geo == 0 ? 2048 : 64;
+    if (family == 10 && cap < n) return -9;
+    run_rev_sweep(a, lane_bytes);
+    if (family == 10) { run_direct_lp<true>(a, lane_bytes, status); total = n; }
+    else {
+        const bool g16 = family == 11 && reinterpret_cast<const StreamBlobHeader*>(gblob)->g16_bytes != 0;
+        run_direct_gen<true>(a, lane_bytes, status, total, g16);
     }
     *status_out = status;
     *m = (size_t)total;

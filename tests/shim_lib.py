@@ -32,6 +32,9 @@ def lib():
                                 ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
                                 ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t),
                                 ctypes.POINTER(ctypes.c_uint32)]
+        L.shim_scan_guided.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p,
+                                       ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                       ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_uint32)]
         _lib = L
     return _lib
 
@@ -59,16 +62,52 @@ def shim_scan(blob, engine, family, data, geo=1, in_mis=0, out_mis=0, scratch=Tr
     return out.raw[:m.value], st.value
 
 
+GUIDED_LP, GUIDED_GEN, GUIDED_GEN8 = 10, 11, 12     # shim ids of the guided families (ABI ids 6, 7; 12 = 7 on the 8-byte entries)
+
+
+def shim_scan_guided(prog, family, data, geo=1, in_mis=0, out_mis=0):
+    rblob, gblob = prog.export_guided_tables()
+    assert rblob and gblob
+    cap = len(data) * 8 + 64 if family != GUIDED_LP else len(data)
+    out = ctypes.create_string_buffer(max(cap, 1))
+    m = ctypes.c_size_t()
+    st = ctypes.c_uint32()
+    rc = lib().shim_scan_guided(rblob, gblob, family, geo, data, len(data), in_mis, out, cap, out_mis, ctypes.byref(m),
+                                ctypes.byref(st))
+    if rc:
+        raise RuntimeError("shim rc %d" % rc)
+    return out.raw[:m.value], st.value
+
+
+def scan_guided_like_runtime(prog, data, geo=1, family=GUIDED_LP, in_mis=0, out_mis=0):
+    out, st = shim_scan_guided(prog, family, data, geo, in_mis, out_mis)
+    assert not st & ST_MISMATCH, "count and emit passes disagree"
+    if st & ST_DIVERGE:
+        raise RuntimeError("diverges")
+    if family == GUIDED_LP and st & ST_NUL:
+        out, st = shim_scan_guided(prog, GUIDED_GEN, data, geo, in_mis, out_mis)
+        assert not st & ST_MISMATCH
+        if st & ST_DIVERGE:
+            raise RuntimeError("diverges")
+    return out
+
+
 def scan_like_runtime(prog, data, geo=1, family=None, in_mis=0, out_mis=0):
     """Mirror of runtime.cpp's policy (finish()): auto family, NUL -> general family."""
     info = prog.info
-    fam = family if family else info.kernel
+    fam = family
+    if not fam:                       # ABI ids -> shim ids (the shim's 6..9 are the direct walkers of the stream families)
+        fam = {6: GUIDED_LP, 7: GUIDED_GEN}.get(info.kernel, info.kernel)
+    if fam in (GUIDED_LP, GUIDED_GEN, GUIDED_GEN8):
+        return scan_guided_like_runtime(prog, data, geo, fam, in_mis, out_mis)
     blob = prog.export_stream_tables() if fam in (4, 5, 6, 7, 8, 9) else prog.export_tables()
     out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
     if out is None:                         # family 8 without a window form: nothing to run
         fam = 6
         out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
-    if fam in (5, 7, 9) and st & ST_OVERFLOW:           # bounded stream table: the tile kernels take over
+    if fam in (5, 7, 9) and st & ST_OVERFLOW:           # bounded stream table: the guided (or the tile) kernels take over
+        if info.guided_rev_states:
+            return scan_guided_like_runtime(prog, data, geo, GUIDED_GEN, in_mis, out_mis)
         fam = 3
         blob = prog.export_tables()
         out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)

@@ -40,9 +40,16 @@ def test_engine_limits_are_errors_not_fallbacks():
     p = trre_amd.Program(big, "nft")                        # but the scan loop folds into a stream table
     assert p.info.kernel == trre_amd.KERNEL_STREAM_GEN and trre_amd.KERNEL_TILE_GEN not in p.allowed_kernels()
     assert trre_amd.Program(big, "dft").info.table_rows == 7   # start, w, w0, w00..w03 (trie)
-    with pytest.raises(trre_amd.TrreError) as e:            # unbounded look-ahead AND > 64 CONS states
-        trre_amd.Program("(" + big.replace(":x", "") + ")*z:y", "nft")
+    # unbounded look-ahead and > 64 CONS states: round 1 refused it, the guided families run it
+    p = trre_amd.Program("(" + big.replace(":x", "") + ")*z:y", "nft")
+    assert p.info.kernel == trre_amd.KERNEL_GUIDED_GEN and p.info.nft_nodes == 161
+    # what is still refused: the backward DFA of the guided families explodes (which of the next ten bytes is a
+    # 'c': > 256 states), the fold explodes (8^9 pending strings) and there are more nodes than mask bits
+    with pytest.raises(trre_amd.TrreError) as e:
+        trre_amd.Program("a(a|b|c|d|e|f|g|h){9}c:x", "nft")
     assert e.value.code == api.E_UNSUPPORTED
+    p = trre_amd.Program("a(a|b|c){9}c:x", "nft")            # the same with 29 nodes: the bitmask tile kernels
+    assert p.info.kernel == trre_amd.KERNEL_TILE_GEN and p.info.guided_rev_states == 0
     with pytest.raises(trre_amd.TrreError) as e:
         trre_amd.Program("(a*)*", "dft")
     assert e.value.code == api.E_EPS_CYCLE

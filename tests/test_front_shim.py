@@ -26,21 +26,42 @@ def prog(pat, eng):
     return _progs[key]
 
 
+# golden (pattern, engine) pairs the product may refuse to compile.  Empty: every vector generated from the
+# compiled reference runs (round 1 refused the NFT patterns with more than 64 CONS states, e.g. '.').
+REFUSED_GOLDEN = set()
+
+
 def test_golden_vectors_tiny_geometry():
-    """every golden case through the auto-selected kernel family, 64-byte chunks"""
-    n = 0
+    """every golden case through the auto-selected kernel family, 64-byte chunks; NFT cases also through
+    every guided family the pattern admits"""
+    n = n_guided = 0
     for pat, name, data, engine, exp in golden_lib.cases():
         p = prog(pat, engine)
         if isinstance(p, trre_amd.TrreError):
-            # the only patterns the product may refuse: engine limits it documents
-            assert p.code in (trre_amd.api.E_UNSUPPORTED, trre_amd.api.E_EPS_CYCLE, trre_amd.api.E_TOO_BIG), (pat, engine, p)
+            assert (pat, engine) in REFUSED_GOLDEN, (pat, engine, p)
             continue
+        assert (pat, engine) not in REFUSED_GOLDEN
         if len(data) > 20000:
             continue                      # the 100 kB line runs in the production-geometry test
         assert exp is not None
         assert shim_lib.scan_like_runtime(p, data, geo=1) == exp, (pat, name, engine)
         n += 1
-    assert n > 600
+        if engine == "nft":
+            assert p.info.guided_rev_states, (pat, "no guided tables")
+            for fam in guided_families(p):
+                assert shim_lib.scan_like_runtime(p, data, geo=1, family=fam) == exp, (pat, name, fam)
+                n_guided += 1
+    assert n > 850 and n_guided > 1000
+
+
+def guided_families(p):
+    allowed = p.allowed_kernels()
+    fams = []
+    if trre_amd.KERNEL_GUIDED_LP in allowed:
+        fams.append(shim_lib.GUIDED_LP)
+    if trre_amd.KERNEL_GUIDED_GEN in allowed:
+        fams += [shim_lib.GUIDED_GEN, shim_lib.GUIDED_GEN8]
+    return fams
 
 
 def test_golden_vectors_production_geometry():
@@ -66,12 +87,13 @@ def test_every_family_agrees():
 
 def shim_families(p):
     """kernel families to run through the shim: the ABI's plus the direct (no-tile) stream walkers"""
-    fams = list(p.allowed_kernels())
+    allowed = list(p.allowed_kernels())
+    fams = [f for f in allowed if f <= 5]
     if 4 in fams:
-        fams += [6, 8]
+        fams += [6, 8]         # (shim ids: 6/8 direct and window walkers of the stream LP family, 7/9 of the general one)
     if 5 in fams:
         fams += [7, 9]
-    return fams
+    return fams + guided_families(p)
 
 
 def test_unaligned_buffers():
@@ -122,7 +144,42 @@ def test_static_properties_of_config_tables():
     i = prog("a*b:x", "nft").info
     assert i.stream_states == 67 and i.kernel == trre_amd.KERNEL_STREAM_GEN
     i = prog("(a|b)*c:x", "nft").info
-    assert i.stream_states == 0 and i.kernel == trre_amd.KERNEL_TILE_GEN
+    assert i.stream_states == 0 and i.kernel == trre_amd.KERNEL_GUIDED_GEN
+    assert (i.nft_nodes, i.guided_rev_states, i.guided_fwd_states) == (3, 6, 6)
+    # a byte range is one node: '.' is 256 CONS states in the reference (trre_nft.c:215-221, 426-435)
+    i = prog("(.:x)*.*", "nft").info
+    assert i.nft_cons_states == 512 and i.nft_nodes == 2 and i.guided_rev_states > 0
+    i = prog("[0-9]+:N", "nft").info
+    assert i.nft_nodes == 1 and i.kernel == trre_amd.KERNEL_GUIDED_GEN
+
+
+def test_reference_scan_rows_that_need_many_cons_states():
+    """test.sh:114,115,129-132 and the DFT-quirk probes: '.' and wide ranges with the NFT engine (round 1 refused them)"""
+    rows = [("(.:x)*.*", b"abc\n", b"xxx\n"), ("(.:x)*?.*", b"abc\n", b"abc\n"), ("<(.:)*>", b"<abc>\n", b"<>\n"),
+            ("<(.:)*?>", b"<abc>\n", b"<>\n"), ("<(.:)+>", b"<abc>\n", b"<>\n"), ("<(.:)+?>", b"<abc>\n", b"<>\n")]
+    for pat, data, _ in rows + [("a.c:X", b"abc aXc a\n", None), ("x.*:y", b"xab x\n", None), ("...:x", b"abcdefgh\n", None)]:
+        p = prog(pat, "nft")
+        want = Oracle(pat, "nft").scan(data)
+        for fam in shim_families(p):
+            for geo in (0, 1):
+                assert shim_lib.scan_like_runtime(p, data, geo=geo, family=fam) == want, (pat, fam, geo)
+
+
+def test_epsilon_cycles_are_reported_like_the_reference():
+    """the reference's search enters an epsilon cycle and exits 1 with 'stack max capacity reached'
+    (verified against the compiled binary): the guided families report it, on exactly those inputs"""
+    for pat, data, diverges in [("a:*", b"a\n", True), ("a:*", b"b\n", False), ("a(:y)*", b"a\n", True), ("a(:y)*", b"xx\n", False),
+                                ("a(b*)*c|ad", b"ad\n", True), ("a(b*)*c|ad", b"abc\n", True), ("a(b*)*c|ad", b"xyz\nzz\n", False)]:
+        p = prog(pat, "nft")
+        assert trre_amd.KERNEL_TILE_GEN not in p.allowed_kernels()      # the two-valued mask sweep cannot see it
+        for fam in guided_families(p):
+            if diverges:
+                with pytest.raises(RuntimeError, match="diverges"):
+                    shim_lib.scan_like_runtime(p, data, geo=1, family=fam)
+                with pytest.raises(OracleError):
+                    Oracle(pat, "nft").scan(data)
+            else:
+                assert shim_lib.scan_like_runtime(p, data, geo=1, family=fam) == Oracle(pat, "nft").scan(data), (pat, fam)
 
 
 def test_random_patterns_against_oracle():

@@ -21,7 +21,9 @@ ENGINE_NFT, ENGINE_DFT = 0, 1
 _ENGINES = {"nft": ENGINE_NFT, "dft": ENGINE_DFT, ENGINE_NFT: ENGINE_NFT, ENGINE_DFT: ENGINE_DFT}
 
 KERNEL_AUTO, KERNEL_BYTEMAP, KERNEL_TILE_LP, KERNEL_TILE_GEN, KERNEL_STREAM_LP, KERNEL_STREAM_GEN = 0, 1, 2, 3, 4, 5
-KERNEL_NAMES = {0: "auto", 1: "bytemap", 2: "tile_lp", 3: "tile_gen", 4: "stream_lp", 5: "stream_gen"}
+KERNEL_GUIDED_LP, KERNEL_GUIDED_GEN = 6, 7
+KERNEL_NAMES = {0: "auto", 1: "bytemap", 2: "tile_lp", 3: "tile_gen", 4: "stream_lp", 5: "stream_gen", 6: "guided_lp",
+                7: "guided_gen"}
 
 FLAG_LENGTH_PRESERVING, FLAG_MEMORYLESS, FLAG_NO_OVERRUN = 1, 2, 4
 
@@ -44,7 +46,9 @@ class Info(ctypes.Structure):
                 ("nft_cons_states", ctypes.c_uint32), ("dft_states", ctypes.c_uint32),
                 ("table_rows", ctypes.c_uint32), ("table_classes", ctypes.c_uint32),
                 ("table_bytes", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("chunk_bytes", ctypes.c_uint32),
-                ("stream_states", ctypes.c_uint32), ("stream_classes", ctypes.c_uint32)]
+                ("stream_states", ctypes.c_uint32), ("stream_classes", ctypes.c_uint32),
+                ("nft_nodes", ctypes.c_uint32), ("guided_rev_states", ctypes.c_uint32),
+                ("guided_fwd_states", ctypes.c_uint32)]
 
 
 def build_library(force=False):
@@ -79,6 +83,8 @@ def lib():
         L.trre_export_tables.restype = sz
         L.trre_export_stream_tables.argtypes = [vp, vp, sz]
         L.trre_export_stream_tables.restype = sz
+        L.trre_export_guided_tables.argtypes = [vp, ctypes.c_int, vp, sz]
+        L.trre_export_guided_tables.restype = sz
         L.trre_scan_device.argtypes = [vp, vp, sz, vp, sz, ctypes.POINTER(sz), vp]
         L.trre_scan_enqueue.argtypes = [vp, vp, sz, vp, sz, vp]
         L.trre_scan_finish.argtypes = [vp, ctypes.POINTER(sz)]
@@ -136,9 +142,20 @@ class Program:
         lib().trre_export_stream_tables(self._h, buf, n)
         return buf.raw[:n]
 
+    def export_guided_tables(self):
+        """(backward DFA blob, forward tables blob) of the guided families, or (b"", b"")"""
+        blobs = []
+        for which in (0, 1):
+            n = lib().trre_export_guided_tables(self._h, which, None, 0)
+            buf = ctypes.create_string_buffer(max(n, 1))
+            lib().trre_export_guided_tables(self._h, which, buf, n)
+            blobs.append(buf.raw[:n])
+        return tuple(blobs)
+
     def allowed_kernels(self):
         ok = []
-        for fam in (KERNEL_BYTEMAP, KERNEL_TILE_LP, KERNEL_TILE_GEN, KERNEL_STREAM_LP, KERNEL_STREAM_GEN):
+        for fam in (KERNEL_BYTEMAP, KERNEL_TILE_LP, KERNEL_TILE_GEN, KERNEL_STREAM_LP, KERNEL_STREAM_GEN, KERNEL_GUIDED_LP,
+                    KERNEL_GUIDED_GEN):
             if lib().trre_set_kernel(self._h, fam) == 0:
                 ok.append(fam)
         lib().trre_set_kernel(self._h, KERNEL_AUTO)

@@ -46,4 +46,14 @@ struct StreamBlobHeader {
 };
 static_assert(sizeof(StreamBlobHeader) == 64, "header layout");
 
+// backward pass of the guided families (guided_build.cpp): a DFA read right to left
+constexpr uint32_t kMagicRev = 0x31525254u;   // "TRR1"
+struct RevBlobHeader {
+    uint32_t magic, n_rev, n_cls;
+    uint32_t off_cls;        // u8[256] byte -> class
+    uint32_t off_tab;        // u8[n_rev][n_cls] next state (= the symbol left at the byte's position)
+    uint32_t tab_bytes, total_bytes, pad;
+};
+static_assert(sizeof(RevBlobHeader) == 32, "header layout");
+
 }  // namespace trre

@@ -60,8 +60,20 @@ struct NState {
     int32_t a = -1;   // primary successor ("nexta")
     int32_t b = -1;   // secondary successor of a split ("nextb")
 };
+// A byte range outside ':' ("[a-z]", ".") or on its left side is a chain of SPLITNG states with one
+// CONS branch per byte (trre_nft.c:426-435).  The branches read distinct bytes, are entered only through
+// the chain's head and all continue at the same JOIN, so the table builders treat the whole chain as ONE
+// consuming node with a byte set (`echo`: each CONS is followed by a PROD of the same byte — copy mode).
+struct NGroup {
+    int32_t head = -1;              // first SPLITNG of the chain
+    int32_t join = -1;              // where every branch continues
+    uint8_t lo = 0, hi = 0;         // bytes lo..hi
+    bool echo = false;
+    std::vector<int32_t> members;   // the CONS states, lowest byte first
+};
 struct Nft {
     std::vector<NState> st;
+    std::vector<NGroup> groups;
     int32_t start = -1;
     int32_t n_cons = 0;
     int32_t add(NKind k, int32_t a = -1, int32_t b = -1, uint8_t val = 0) {
@@ -173,31 +185,76 @@ struct StreamTables {
 StreamTables build_stream_dft(const Dft& dft, const StreamLimits& lim = StreamLimits());
 StreamTables build_stream_nft(const Nft& nft, const StreamLimits& lim = StreamLimits());
 
-// Non-deterministic engine (priority-exact).  Only CONS states (and FINAL) are
-// materialised; for each CONS state s (and for the start) `follow` lists, in the
-// reference's depth-first priority order, the CONS/FINAL states reachable from
-// s's successor through epsilon states, each with the bytes produced on the way.
-// A list stops at its first FINAL (which always accepts in scan mode,
-// trre_nft.c:643-648) or with a Diverge marker where the reference's search
-// would run around an epsilon cycle for ever.
+// Non-deterministic engine (priority-exact).  Only consuming NODES (a CONS state, or a whole byte-range
+// chain: NGroup) and FINAL are materialised; for each node s (and for the start) `follow` lists, in the
+// reference's depth-first priority order, the nodes / FINAL reachable from s's successor through epsilon
+// states, each with the bytes produced on the way.  A list stops at its first FINAL (which always accepts
+// in scan mode, trre_nft.c:643-648) or with a Diverge marker where the reference's search would run
+// around an epsilon cycle for ever ("stack max capacity reached", trre_nft.c:551-553).
+constexpr uint32_t kNodeFinal = 0xFFFFFFFFu, kNodeDiverge = 0xFFFFFFFEu;
+struct NodeFollow {
+    uint32_t target = 0;   // node index, kNodeFinal or kNodeDiverge
+    bool mute = false;     // the bytes produced on the way contain a NUL: `out` stops before it and the
+                           // rest of the attempt's output is invisible (fputs, trre_nft.c:645)
+    std::string out;
+};
+struct NftNodes {
+    struct Node {
+        std::array<uint64_t, 4> bytes{};   // the bytes it reads
+        bool echo = false;                 // copy mode: reading a byte also produces it
+        bool reads(uint8_t c) const { return (bytes[c >> 6] >> (c & 63)) & 1u; }
+    };
+    std::vector<Node> node;
+    std::vector<std::vector<NodeFollow>> follow;   // [n_nodes + 1]; the last one is the start's
+    bool has_diverge = false;
+    uint32_t n_states = 0;                         // states of the NFT they were made from
+};
+NftNodes build_nft_nodes(const Nft& nft);
+
+// Tables of the bitmask tile kernels: at most 64 nodes, no Diverge marker (their backward sweep is
+// two-valued; patterns with epsilon cycles need the guided tables below).
 constexpr uint8_t kTgtFinal = 0xFF, kTgtDiverge = 0xFE;
+constexpr uint8_t kFollowMute = 1, kFollowEcho = 2;
 struct NftFollow {
-    uint8_t target;        // CONS index 0..n_cons-1, kTgtFinal or kTgtDiverge
-    uint8_t mute;          // output contains a NUL: emit up to it, then mute the attempt (fputs)
+    uint8_t target;        // node index 0..n_cons-1 or kTgtFinal
+    uint8_t flags;         // kFollowMute: output contained a NUL (emit up to it, then mute the attempt);
+                           // kFollowEcho: the target also produces the byte it reads
     uint16_t out_len;
     uint32_t out_off;      // into pool
 };
 struct NftTables {
-    uint32_t n_cons = 0;                    // <= 64
-    std::array<uint64_t, 256> cons_mask{};  // CONS states that read byte c
-    std::vector<uint64_t> pred;             // [n_cons]: CONS states whose follow list holds t
-    uint64_t to_final = 0;                  // CONS states whose follow list holds FINAL
+    uint32_t n_cons = 0;                    // nodes, <= 64
+    std::array<uint64_t, 256> cons_mask{};  // nodes that read byte c
+    std::vector<uint64_t> pred;             // [n_cons]: nodes whose follow list holds t
+    uint64_t to_final = 0;                  // nodes whose follow list holds FINAL
     std::vector<uint32_t> follow_off;       // [n_cons + 2]; index n_cons = start
     std::vector<NftFollow> follow;
     std::vector<uint8_t> pool;
     uint32_t flags = 0;                     // kFlagLengthPreserving
     uint32_t n_states = 0;
 };
-NftTables build_nft_tables(const Nft& nft);
+NftTables build_nft_tables(const NftNodes& nodes);
+
+// Guided tables ("bimachine"): the backtracking search of trre_nft.c:593-657 as two deterministic passes.
+//   backward  a DFA over the input read right to left whose state at position i is, for every node, what
+//             the reference's search from that node at i would end in (fail / accept / run for ever);
+//             it leaves one symbol per input byte (its state id);
+//   forward   a transducer over (symbol, byte) pairs in stream-table form whose state is the node the
+//             first accepting path is in: at every step it takes the first follow entry that does not fail.
+// '\n' and NUL reset the backward DFA (symbols kSymEol / kSymNul); symbol 0 is "nothing alive".
+constexpr uint32_t kSymDead = 0, kSymEol = 1, kSymNul = 2;
+struct GuidedLimits {
+    size_t max_rev_states = 256;      // symbols are bytes
+    size_t max_fwd_states = 4096;
+    size_t max_out = 4096;
+};
+struct GuidedTables {
+    bool ok = false;
+    uint32_t n_rev = 0, n_cls = 0;          // backward DFA: states (= symbols) x byte classes
+    std::array<uint8_t, 256> cls{};         // byte -> class; class 0 = '\n', class 1 = NUL
+    std::vector<uint8_t> rev;               // [n_rev][n_cls] next state
+    StreamTables fwd;                       // columns = symbols (fwd.cls is unused)
+};
+GuidedTables build_guided_nft(const NftNodes& nodes, const GuidedLimits& lim = GuidedLimits());
 
 }  // namespace trre

@@ -108,11 +108,17 @@ private:
         int32_t chain = -1;
         if (lo.type == 'c' && hi.type == 'c') {
             int32_t join = nft_.add(NKind::Join);
+            NGroup g;
             for (int c = hi.val; c >= (int)lo.val; --c) {
                 Frag f = byte((uint8_t)c, side);
                 int32_t fork = nft_.add(NKind::SplitNg, f.head, chain);
                 connect(f.tail, join);
                 chain = fork;
+                if (side != 2) g.members.insert(g.members.begin(), f.head);
+            }
+            if (g.members.size() >= 2) {
+                g.head = chain; g.join = join; g.lo = lo.val; g.hi = hi.val; g.echo = side == 0;
+                nft_.groups.push_back(std::move(g));
             }
             return Frag{chain, join};
         }

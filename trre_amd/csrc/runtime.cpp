@@ -36,6 +36,10 @@ int fail(int code, const std::string& msg) {
 struct DeviceState {
     uint8_t* d_blob = nullptr;
     uint8_t* d_sblob = nullptr;       // stream tables
+    uint8_t* d_gblob = nullptr;       // guided families: forward tables (stream form) ...
+    uint8_t* d_rblob = nullptr;       // ... and the backward DFA
+    uint8_t* d_sym = nullptr;         // guided families: one symbol per input byte
+    size_t sym_bytes = 0;
     uint32_t* d_status = nullptr;     // [4]
     uint32_t* h_status = nullptr;     // pinned mirror: [0] status bits; [2..3] total (u64)
     uint32_t* d_lane_counts = nullptr;
@@ -85,9 +89,12 @@ struct trre_prog {
     trre::DftTables dt;
     trre::NftTables nt;
     trre::StreamTables stt;
-    bool has_engine_tables = false;   // tile kernels available (always for DFT; NFT: <= 64 CONS states)
+    trre::GuidedTables gt;
+    uint32_t nft_nodes = 0;
+    bool has_engine_tables = false;   // tile kernels available (always for DFT; NFT: <= 64 nodes, no epsilon cycle)
     std::vector<uint8_t> blob;
     std::vector<uint8_t> sblob;
+    std::vector<uint8_t> gblob, rblob;
     int mask_bytes = 0;
     bool profiling = false;
     float last_ms = -1.f;
@@ -156,9 +163,8 @@ void serialize_nft(trre_prog& p) {
     put(b, h.off_pool, t.pool.data(), t.pool.size());
 }
 
-void serialize_stream(trre_prog& p) {
+void serialize_stream(const trre::StreamTables& t, std::vector<uint8_t>& b) {
     using namespace trre;
-    const StreamTables& t = p.stt;
     StreamBlobHeader h{};
     h.magic = kMagicStream;
     h.n_states = t.n_states;
@@ -175,7 +181,6 @@ void serialize_stream(trre_prog& p) {
     h.off_g16 = (uint32_t)off; h.g16_bytes = (uint32_t)(t.g16.size() * 4); off += t.g16.size() * 4;
     off = align_up(off + 16, 16);
     h.total_bytes = (uint32_t)off;
-    std::vector<uint8_t>& b = p.sblob;
     b.assign(off, 0);
     put(b, 0, &h, 1);
     put(b, h.off_cls, t.cls.data(), 256);
@@ -185,14 +190,39 @@ void serialize_stream(trre_prog& p) {
     put(b, h.off_g16, t.g16.data(), t.g16.size());
 }
 
+void serialize_rev(const trre::GuidedTables& g, std::vector<uint8_t>& b) {
+    using namespace trre;
+    RevBlobHeader h{};
+    h.magic = kMagicRev;
+    h.n_rev = g.n_rev;
+    h.n_cls = g.n_cls;
+    size_t off = sizeof h;
+    h.off_cls = (uint32_t)off; off += 256;
+    h.off_tab = (uint32_t)off; h.tab_bytes = (uint32_t)align_up(g.rev.size(), 4); off += h.tab_bytes;
+    off = align_up(off + 16, 16);
+    h.total_bytes = (uint32_t)off;
+    b.assign(off, 0);
+    put(b, 0, &h, 1);
+    put(b, h.off_cls, g.cls.data(), 256);
+    put(b, h.off_tab, g.rev.data(), g.rev.size());
+}
+
 bool is_stream(int fam) { return fam == TRRE_KERNEL_STREAM_LP || fam == TRRE_KERNEL_STREAM_GEN; }
-bool is_gen(int fam) { return fam == TRRE_KERNEL_TILE_GEN || fam == TRRE_KERNEL_STREAM_GEN; }
+bool is_guided(int fam) { return fam == TRRE_KERNEL_GUIDED_LP || fam == TRRE_KERNEL_GUIDED_GEN; }
+bool is_gen(int fam) { return fam == TRRE_KERNEL_TILE_GEN || fam == TRRE_KERNEL_STREAM_GEN || fam == TRRE_KERNEL_GUIDED_GEN; }
+bool lp_inplace(uint32_t flags) { return (flags & trre::kFlagLengthPreserving) && (flags & trre::kFlagNoOverrun); }
+// the family that takes over when a length-preserving launch met a NUL, or a bounded stream table a long run
+int general_family(const trre_prog& p, bool stream_ok) {
+    if (stream_ok && p.stt.ok) return TRRE_KERNEL_STREAM_GEN;
+    if (p.gt.ok) return TRRE_KERNEL_GUIDED_GEN;
+    return TRRE_KERNEL_TILE_GEN;
+}
 
 int auto_family(const trre_prog& p) {
     using namespace trre;
     if (p.engine == TRRE_ENGINE_DFT && (p.dt.flags & kFlagMemoryless)) return TRRE_KERNEL_BYTEMAP;
-    if (p.stt.ok)
-        return ((p.stt.flags & kFlagLengthPreserving) && (p.stt.flags & kFlagNoOverrun)) ? TRRE_KERNEL_STREAM_LP : TRRE_KERNEL_STREAM_GEN;
+    if (p.stt.ok) return lp_inplace(p.stt.flags) ? TRRE_KERNEL_STREAM_LP : TRRE_KERNEL_STREAM_GEN;
+    if (p.gt.ok) return lp_inplace(p.gt.fwd.flags) ? TRRE_KERNEL_GUIDED_LP : TRRE_KERNEL_GUIDED_GEN;
     if (p.engine == TRRE_ENGINE_DFT) {
         if ((p.dt.flags & kFlagLengthPreserving) && (p.dt.flags & kFlagNoOverrun)) return TRRE_KERNEL_TILE_LP;
         return TRRE_KERNEL_TILE_GEN;
@@ -203,7 +233,9 @@ int auto_family(const trre_prog& p) {
 bool family_allowed(const trre_prog& p, int fam) {
     using namespace trre;
     if (fam == TRRE_KERNEL_STREAM_GEN) return p.stt.ok;
-    if (fam == TRRE_KERNEL_STREAM_LP) return p.stt.ok && (p.stt.flags & kFlagLengthPreserving) && (p.stt.flags & kFlagNoOverrun);
+    if (fam == TRRE_KERNEL_STREAM_LP) return p.stt.ok && lp_inplace(p.stt.flags);
+    if (fam == TRRE_KERNEL_GUIDED_GEN) return p.gt.ok;
+    if (fam == TRRE_KERNEL_GUIDED_LP) return p.gt.ok && lp_inplace(p.gt.fwd.flags);
     if (!p.has_engine_tables) return false;
     if (fam == TRRE_KERNEL_TILE_GEN) return true;
     if (p.engine == TRRE_ENGINE_DFT) {
@@ -225,6 +257,12 @@ int device_state(trre_prog* p, int dev, DeviceState** out) {
         if (!p->sblob.empty()) {
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st.d_sblob), p->sblob.size()));
             HIP_TRY(hipMemcpy(st.d_sblob, p->sblob.data(), p->sblob.size(), hipMemcpyHostToDevice));
+        }
+        if (!p->gblob.empty()) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st.d_gblob), p->gblob.size()));
+            HIP_TRY(hipMemcpy(st.d_gblob, p->gblob.data(), p->gblob.size(), hipMemcpyHostToDevice));
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st.d_rblob), p->rblob.size()));
+            HIP_TRY(hipMemcpy(st.d_rblob, p->rblob.data(), p->rblob.size(), hipMemcpyHostToDevice));
         }
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st.d_status), 16));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&st.h_status), 16, hipHostMallocDefault));
@@ -273,17 +311,19 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
     args.out = d_out;
     args.vbeg = a;
     args.vend = a + (int64_t)n;
-    args.blob = is_stream(family) ? st->d_sblob : st->d_blob;
+    args.blob = is_stream(family) ? st->d_sblob : (is_guided(family) ? st->d_gblob : st->d_blob);
+    const trre::StreamTables& stt = is_guided(family) ? p->gt.fwd : p->stt;       // the stream-form tables this launch walks
     args.status = st->d_status;
     args.cap = cap;
     // a mask scratch left by an earlier, smaller scan must not be used: the kernel asks for one again
     args.gscratch = st->scratch_bytes >= (n + 32) * (size_t)p->mask_bytes ? st->d_scratch : nullptr;
+    const bool streamish = is_stream(family) || is_guided(family);
     const int chunk = is_stream(family) ? stream_chunk_bytes(family == TRRE_KERNEL_STREAM_LP ? 0 : 1)
                                         : chunk_bytes(p->engine, p->mask_bytes);
     const int threads = is_stream(family) ? stream_block_threads(family == TRRE_KERNEL_STREAM_LP ? 0 : 1)
                                           : block_threads(p->engine, p->mask_bytes);
     int64_t n_chunks = (args.vend + chunk - 1) / chunk;
-    const bool ent_lds = p->stt.ok && p->stt.ent.size() * 8 <= (size_t)StreamEngine::kLdsEntBytes;
+    const bool ent_lds = stt.ok && stt.ent.size() * 8 <= (size_t)StreamEngine::kLdsEntBytes;
     // stream families have three implementations (TRRE_STREAM_IMPL, for A/B measurements):
     //   0 LDS tile (k_stream_lp / k_stream_count+emit)      1 direct walker with an LDS output ring
     //   2 (default) positional-window kernel (wave-tiled I/O) for length-preserving tables that have
@@ -295,12 +335,12 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
     // sub-range per lane: 2 KiB, growing with the input so that about half a million lanes (8192 waves)
     // walk it — per-lane costs (the skipped head, the tail beyond the sub-range, the wave waiting for its
     // slowest lane) shrink with longer lanes: cfg 4 at 8 GiB 1.72 TB/s with 2 KiB lanes, 2.06 with 16 KiB
-    int64_t lane_auto = family == TRRE_KERNEL_STREAM_LP && !window ? 1024 : 2048;
+    int64_t lane_auto = !is_gen(family) && streamish && !window ? 1024 : 2048;
     if (window)
         while (lane_auto < 16384 && (int64_t)n / (lane_auto * 2) >= 524288) lane_auto *= 2;
     const int64_t lane_bytes = lane_bytes_env > 0 ? (lane_bytes_env + 127) / 128 * 128 : lane_auto;
-    const bool direct = is_stream(family) && stream_impl >= 1;
-    const bool direct_ent_lds = p->stt.ok && p->stt.ent.size() * 8 <= (size_t)direct_ent_lds_bytes();
+    const bool direct = (is_stream(family) && stream_impl >= 1) || is_guided(family);
+    const bool direct_ent_lds = stt.ok && stt.ent.size() * 8 <= (size_t)direct_ent_lds_bytes();
     if (direct) n_chunks = (args.vend + lane_bytes * direct_block_threads() - 1) / (lane_bytes * direct_block_threads());
 
     if (!is_gen(family) && cap < n) return TRRE_OK;   // finish() reports the capacity error
@@ -310,6 +350,18 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
         args.lane_counts = st->d_lane_counts;
         args.chunk_total = st->d_chunk_total;
         args.chunk_base = st->d_chunk_base;
+    }
+    if (is_guided(family)) {
+        // one symbol per input byte, written by the backward pass (whole 64-byte pieces) and read by the forward pass
+        const size_t need = (size_t)((args.vend + 63) & ~(int64_t)63) + 256;
+        if (st->sym_bytes < need) {
+            if (st->d_sym) (void)hipFree(st->d_sym);
+            st->d_sym = nullptr; st->sym_bytes = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st->d_sym), need));
+            st->sym_bytes = need;
+        }
+        args.rblob = st->d_rblob;
+        args.sym_v0 = st->d_sym;
     }
     if (!batch) {
         HIP_TRY(hipMemsetAsync(st->d_status, 0, 16, stream));
@@ -331,14 +383,16 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
         HIP_TRY(hipMemsetAsync(st->d_redo, 0, 4, stream));
         args.redo = st->d_redo;
         launch_lpw_kernel((int)(p->stt.lpw.size() * 4), p->stt.lpw_delay > 3, direct_ent_lds, args, lane_bytes, stream);
-    } else if (direct && family == TRRE_KERNEL_STREAM_LP) {
-        launch_direct_kernel(0, direct_ent_lds, args, lane_bytes, n_chunks, stream);
+    } else if (direct && !is_gen(family)) {
+        if (is_guided(family)) launch_rev_sweep(args, (int)align_up(p->gt.rev.size(), 4), lane_bytes, stream);
+        launch_direct_kernel(0, direct_ent_lds, args, lane_bytes, n_chunks, stream, 0, is_guided(family));
     } else if (direct) {
         static const bool no_g16 = getenv("TRRE_NO_G16") != nullptr;          // A/B: the 8-byte entries
-        const int g16 = p->stt.g16_ok && !no_g16 ? (int)(p->stt.g16.size() * 4) : 0;
-        launch_direct_kernel(1, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16);
+        const int g16 = stt.g16_ok && !no_g16 ? (int)(stt.g16.size() * 4) : 0;
+        if (is_guided(family)) launch_rev_sweep(args, (int)align_up(p->gt.rev.size(), 4), lane_bytes, stream);
+        launch_direct_kernel(1, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, is_guided(family));
         launch_chunk_scan(st->d_chunk_total, st->d_chunk_base, n_chunks, stream);
-        launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16);
+        launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, is_guided(family));
         pd.total_at = st->d_chunk_base + n_chunks;
     } else if (family == TRRE_KERNEL_STREAM_LP) {
         launch_stream_kernel(0, ent_lds, args, n_chunks, stream);
@@ -399,8 +453,8 @@ int finish(trre_prog* p, size_t* out_len) {
         return finish(p, out_len);
     }
     if (is_stream(pd.family) && (status & kStOverflow)) {
-        // an undecided attempt outgrew the stream table (bounded fold): the tile kernels take the buffer
-        int rc = enqueue(p, TRRE_KERNEL_TILE_GEN, pd.d_in, pd.n, pd.d_out, pd.cap, pd.stream);
+        // an undecided attempt outgrew the stream table (bounded fold): the guided (or the tile) kernels take the buffer
+        int rc = enqueue(p, general_family(*p, false), pd.d_in, pd.n, pd.d_out, pd.cap, pd.stream);
         if (rc) return rc;
         return finish(p, out_len);
     }
@@ -408,7 +462,7 @@ int finish(trre_prog* p, size_t* out_len) {
         if (status & kStNul) {
             // a NUL cuts its line short, so output positions no longer equal input
             // positions: redo with the general family
-            const int gen = p->stt.ok ? TRRE_KERNEL_STREAM_GEN : TRRE_KERNEL_TILE_GEN;
+            const int gen = general_family(*p, !is_guided(pd.family));
             int rc = enqueue(p, gen, pd.d_in, pd.n, pd.d_out, pd.cap, pd.stream);
             if (rc) return rc;
             return finish(p, out_len);
@@ -442,21 +496,25 @@ int compile_impl(const std::string& pattern, int engine, trre_prog** out) {
             p->has_engine_tables = true;
             p->stt = build_stream_dft(dft);
         } else {
+            const NftNodes nodes = build_nft_nodes(nft);
+            p->nft_nodes = (uint32_t)nodes.node.size();
             std::unique_ptr<Error> deferred;
             try {
-                p->nt = build_nft_tables(nft);
+                p->nt = build_nft_tables(nodes);
                 p->mask_bytes = p->nt.n_cons <= 8 ? 1 : p->nt.n_cons <= 16 ? 2 : p->nt.n_cons <= 32 ? 4 : 8;
                 serialize_nft(*p);
                 p->has_engine_tables = true;
             } catch (const Error& e) {
                 if (e.code != kErrUnsupported) throw;
-                deferred.reset(new Error(e));            // too many CONS states for the bitmask kernels
+                deferred.reset(new Error(e));            // too many nodes (or an epsilon cycle) for the bitmask kernels
             }
             p->stt = build_stream_nft(nft);
-            // neither kernel family can run this pattern (a bounded stream table needs the tile kernels behind it)
-            if (deferred && (!p->stt.ok || p->stt.bounded)) throw *deferred;
+            p->gt = build_guided_nft(nodes);
+            // no kernel family can run this pattern (a bounded stream table needs general kernels behind it)
+            if (deferred && !p->gt.ok && (!p->stt.ok || p->stt.bounded)) throw *deferred;
         }
-        if (p->stt.ok) serialize_stream(*p);
+        if (p->stt.ok) serialize_stream(p->stt, p->sblob);
+        if (p->gt.ok) { serialize_stream(p->gt.fwd, p->gblob); serialize_rev(p->gt, p->rblob); }
         *out = p.release();
         return TRRE_OK;
     } catch (const Error& e) {
@@ -486,6 +544,9 @@ void trre_free(trre_prog* p) {
         DeviceState& st = kv.second;
         (void)hipFree(st.d_blob);
         (void)hipFree(st.d_sblob);
+        (void)hipFree(st.d_gblob);
+        (void)hipFree(st.d_rblob);
+        (void)hipFree(st.d_sym);
         (void)hipFree(st.d_status);
         (void)hipHostFree(st.h_status);
         (void)hipFree(st.d_lane_counts);
@@ -524,9 +585,11 @@ int trre_get_info(const trre_prog* p, trre_info* info) {
         info->table_rows = p->nt.n_cons;
         info->flags = p->nt.flags;
     }
-    info->table_bytes = (uint32_t)(p->blob.size() + p->sblob.size());
+    info->table_bytes = (uint32_t)(p->blob.size() + p->sblob.size() + p->gblob.size() + p->rblob.size());
     info->chunk_bytes = (uint32_t)trre::chunk_bytes(p->engine, p->mask_bytes);
     if (p->stt.ok) { info->stream_states = p->stt.n_states; info->stream_classes = p->stt.n_cls; }
+    info->nft_nodes = p->nft_nodes;
+    if (p->gt.ok) { info->guided_rev_states = p->gt.n_rev; info->guided_fwd_states = p->gt.fwd.n_states; }
     return TRRE_OK;
 }
 
@@ -548,6 +611,13 @@ size_t trre_export_stream_tables(const trre_prog* p, void* buf, size_t cap) {
     if (!p) return 0;
     if (buf && cap) std::memcpy(buf, p->sblob.data(), cap < p->sblob.size() ? cap : p->sblob.size());
     return p->sblob.size();
+}
+
+size_t trre_export_guided_tables(const trre_prog* p, int which, void* buf, size_t cap) {
+    if (!p) return 0;
+    const std::vector<uint8_t>& b = which == 0 ? p->rblob : p->gblob;
+    if (buf && cap) std::memcpy(buf, b.data(), cap < b.size() ? cap : b.size());
+    return b.size();
 }
 
 int trre_scan_enqueue(trre_prog* p, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, void* stream) {

@@ -54,6 +54,9 @@ struct ScanArgs {
     uint64_t cap;            // capacity of out
     uint8_t* gscratch;       // NFT long-line mask scratch (or null)
     uint32_t* redo;          // window kernel: [0] = count, [1..] = lanes to redo with the general direct walker
+    const uint8_t* rblob;    // guided families: tables of the backward pass (RevBlobHeader)
+    uint8_t* sym_v0;         // guided families: one symbol per input byte, indexed like in_v0 (v-space); the
+                             // backward pass fills [0, round_up(vend, 64)), the forward pass reads it
 };
 
 // ---- phase: stage the tile -------------------------------------------------------------
@@ -437,6 +440,7 @@ TRRE_HD int64_t line_start_global(const ScanArgs& a, int64_t v) {
 #endif
 
 constexpr uint32_t kStrNul = 1u << 29;
+constexpr uint32_t kStrDiv = 1u << 31;       // guided tables: the reference's search would not terminate on this input
 constexpr uint32_t kSkipState = 1, kDoneState = 2;
 
 // Lane start for the synchronous walks.  Every lane of a wave reads byte
@@ -783,7 +787,9 @@ TRRE_HD void stage_flush(Stage& s) {
 
 // kG16 (count and emit passes of small tables): the walk uses the 16-byte entries T.g16 (front.hpp) —
 // bytes to append and their count come ready-made (v_perm selector, count field), rows are byte offsets.
-template <int kMode, bool kG16 = false>
+// kSym (guided families): a transition's column is the symbol the backward pass left at the byte's position
+// (a.sym_v0) instead of the byte's class.
+template <int kMode, bool kG16 = false, bool kSym = false>
 TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, int64_t lane, int64_t lane_bytes,
                                 uint8_t* ring, uint64_t out_base, DirectLane& L, uint32_t& status) {
     const uint32_t rs = kG16 ? 16u : 1u;                              // row unit
@@ -813,6 +819,11 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
     uint32_t seen = 0;
 
     const int64_t vlast = (a.vend - 1) & ~(int64_t)15;        // the last readable aligned block
+    const int64_t slast = ((a.vend + 63) & ~(int64_t)63) - 16;   // the last block of symbols
+    auto sym_at = [&](int64_t vn) -> U128 {
+        if (!kSym) return U128{};
+        return *reinterpret_cast<const U128*>(a.sym_v0 + (vn < slast ? vn : slast));
+    };
     // One 16-byte block at a time from two alternating register buffers: a buffer is refilled right after
     // its block has been walked and used one block later, so the load has a whole block of walking to
     // land and no register copies (which would wait for it) are needed.  Away from the two ends of the
@@ -823,9 +834,10 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
         return q;
     };
     // one dword (4 input bytes) at position v + 4 d of the block at v
-    auto walk_dword = [&](const uint32_t w, const int64_t v, const int d) {
+    auto walk_dword = [&](const uint32_t w, const uint32_t sw, const int64_t v, const int d) {
         {
-            const uint8_t kk[4] = {T.cls[w & 0xffu], T.cls[(w >> 8) & 0xffu], T.cls[(w >> 16) & 0xffu], T.cls[w >> 24]};
+            const uint8_t kk[4] = {kSym ? (uint8_t)sw : T.cls[w & 0xffu], kSym ? (uint8_t)(sw >> 8) : T.cls[(w >> 8) & 0xffu],
+                                   kSym ? (uint8_t)(sw >> 16) : T.cls[(w >> 16) & 0xffu], kSym ? (uint8_t)(sw >> 24) : T.cls[w >> 24]};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint8_t c = (uint8_t)(w >> (8 * j));
@@ -968,15 +980,16 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
     // One 16-byte block.  The emit pass walks its dwords (and a piece's blocks) with real loops: fully
     // unrolled, a piece was 19 000 instructions, several times the instruction cache; the count pass is
     // small enough to keep its dwords unrolled.
-    auto walk = [&](const U128& cur, const int64_t v) {
+    auto walk = [&](const U128& cur, const U128& sy, const int64_t v) {
         if (kMode == 2) {
 #pragma clang loop unroll(disable)
-            for (int d = 0; d < 4; ++d) walk_dword(d == 0 ? cur.x : (d == 1 ? cur.y : (d == 2 ? cur.z : cur.w)), v, d);
+            for (int d = 0; d < 4; ++d)
+                walk_dword(d == 0 ? cur.x : (d == 1 ? cur.y : (d == 2 ? cur.z : cur.w)), d == 0 ? sy.x : (d == 1 ? sy.y : (d == 2 ? sy.z : sy.w)), v, d);
         } else {
-            walk_dword(cur.x, v, 0);
-            walk_dword(cur.y, v, 1);
-            walk_dword(cur.z, v, 2);
-            walk_dword(cur.w, v, 3);
+            walk_dword(cur.x, sy.x, v, 0);
+            walk_dword(cur.y, sy.y, v, 1);
+            walk_dword(cur.z, sy.z, v, 2);
+            walk_dword(cur.w, sy.w, v, 3);
         }
         if (kMode == 0) direct_flush<false>(obase, ring, of, o);
     };
@@ -987,6 +1000,7 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
         // input byte), four back-to-back loads of one sector fetch it once.
         // (named registers, selected by compares: an indexed array would be kept in scratch memory)
         U128 c0 = direct_load(a, lo), c1 = direct_load(a, lo + 16), c2 = direct_load(a, lo + 32), c3 = direct_load(a, lo + 48);
+        U128 s0 = sym_at(lo), s1 = sym_at(lo + 16), s2 = sym_at(lo + 32), s3 = sym_at(lo + 48);
         for (int64_t v = lo;; v += 64) {
             if (!TRRE_WAVE_ANY(row != done_row)) break;
             const int64_t vn = v + 64;
@@ -997,31 +1011,43 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
             if (TRRE_WAVE_ANY(vn < a.vbeg || vn + 64 > a.vend - 1)) {
                 n0 = direct_load(a, vn); n1 = direct_load(a, vn + 16); n2 = direct_load(a, vn + 32); n3 = direct_load(a, vn + 48);
             }
+            const U128 t0 = sym_at(vn), t1 = sym_at(vn + 16), t2 = sym_at(vn + 32), t3 = sym_at(vn + 48);
 #pragma clang loop unroll(disable)
             for (int q = 0; q < 4; ++q) {
-                U128 b;
+                U128 b, y{};
                 b.x = q == 0 ? c0.x : (q == 1 ? c1.x : (q == 2 ? c2.x : c3.x));
                 b.y = q == 0 ? c0.y : (q == 1 ? c1.y : (q == 2 ? c2.y : c3.y));
                 b.z = q == 0 ? c0.z : (q == 1 ? c1.z : (q == 2 ? c2.z : c3.z));
                 b.w = q == 0 ? c0.w : (q == 1 ? c1.w : (q == 2 ? c2.w : c3.w));
-                walk(b, v + 16 * q);
+                if (kSym) {
+                    y.x = q == 0 ? s0.x : (q == 1 ? s1.x : (q == 2 ? s2.x : s3.x));
+                    y.y = q == 0 ? s0.y : (q == 1 ? s1.y : (q == 2 ? s2.y : s3.y));
+                    y.z = q == 0 ? s0.z : (q == 1 ? s1.z : (q == 2 ? s2.z : s3.z));
+                    y.w = q == 0 ? s0.w : (q == 1 ? s1.w : (q == 2 ? s2.w : s3.w));
+                }
+                walk(b, y, v + 16 * q);
             }
             c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            if (kSym) { s0 = t0; s1 = t1; s2 = t2; s3 = t3; }
         }
     } else {
         U128 blk0 = direct_load(a, lo), blk1 = direct_load(a, lo + 16);
+        U128 sy0 = sym_at(lo), sy1 = sym_at(lo + 16);
         for (int64_t v = lo; TRRE_WAVE_ANY(row != done_row); v += 32) {
-            walk(blk0, v);
+            walk(blk0, sy0, v);
             blk0 = fetch(v + 32);
+            sy0 = sym_at(v + 32);
             if (!TRRE_WAVE_ANY(row != done_row)) break;
-            walk(blk1, v + 16);
+            walk(blk1, sy1, v + 16);
             blk1 = fetch(v + 48);
+            sy1 = sym_at(v + 48);
         }
     }
     if (kMode == 0) direct_flush<true>(obase, ring, of, o);
     if (kMode == 2) stage_flush<true>(S);
     if (kMode == 0 && (seen & kStrNul)) status |= kStNul;
     if (kMode == 1 && (seen & (kG16 ? 64u : kStrOvf))) status |= kStOverflow;     // bounded fold: the launch is void
+    if (kMode != 2 && (seen & (kG16 ? 16u : kStrDiv))) status |= kStDiverge;      // guided tables: the reference's search never returns
     L.count = cnt;
 }
 
@@ -1320,6 +1346,80 @@ struct WtMover {
     }
     TRRE_HD int32_t store_off(int i, int32_t k64) const { return dst[i] + k64 - kWtOutRow; }
 };
+
+// =============================================================================================
+// Backward pass of the guided families (tables: guided_build.cpp).  A DFA reads the input right to
+// left, '\n' resets it, and its state after byte p — what the reference's backtracking search would
+// find on the rest of the line — is stored as the symbol of position p.  Lane `lane` produces the
+// symbols of exactly the positions [lane * lane_bytes, (lane + 1) * lane_bytes) (lane_bytes: a multiple
+// of 64): it first runs, without storing, from the end of the line that crosses the end of its
+// sub-range, then walks its own bytes, 64 at a time, highest first.  Positions outside the input get
+// symbols too (they read as the walkers see them: direct_load), up to the next multiple of 64.
+// =============================================================================================
+struct RevView {
+    const uint8_t* cls;      // [256]
+    const uint8_t* tab;      // [n_rev][n_cls]
+    uint32_t n_cls;
+};
+TRRE_HD uint32_t rev_step4(const RevView& T, uint32_t& r, uint32_t w) {
+    // bytes 3, 2, 1, 0 of w in that order; returns their four symbols packed like w
+    const uint32_t k3 = T.cls[w >> 24], k2 = T.cls[(w >> 16) & 0xffu], k1 = T.cls[(w >> 8) & 0xffu], k0 = T.cls[w & 0xffu];
+    uint32_t y;
+    r = T.tab[r * T.n_cls + k3]; y = r << 24;
+    r = T.tab[r * T.n_cls + k2]; y |= r << 16;
+    r = T.tab[r * T.n_cls + k1]; y |= r << 8;
+    r = T.tab[r * T.n_cls + k0]; y |= r;
+    return y;
+}
+TRRE_HD void rev_sweep_lane(const ScanArgs& a, const RevView& T, int64_t lane, int64_t lane_bytes) {
+    const int64_t lo = lane * lane_bytes;
+    const int64_t vtop = (a.vend + 63) & ~(int64_t)63;
+    int64_t hi = lo + lane_bytes;
+    if (hi > vtop) hi = vtop;
+    if (lo >= hi) return;
+    uint32_t r = 0;            // "nothing alive": the state right of a '\n' (every byte from vend - 1 on reads as '\n')
+    if (hi < a.vend - 1) {
+        // the line that crosses hi: find its end e (first '\n' at or after hi), then run e - 1 .. hi
+        int64_t e = hi;        // hi is a multiple of 16
+        for (;; e += 16) {
+            const U128 q = direct_load(a, e);
+            const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+            int found = -1;
+            for (int d = 0; d < 4 && found < 0; ++d) {
+                const uint32_t x = wd[d] ^ 0x0a0a0a0au;
+                const uint32_t m = (x - 0x01010101u) & ~x & 0x80808080u;   // the lowest flag is exact
+                if (m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                    found = 4 * d + ((__ffs((int)m) - 1) >> 3);
+#else
+                    found = 4 * d + (__builtin_ctz(m) >> 3);
+#endif
+                }
+            }
+            if (found >= 0) { e += found; break; }
+        }
+        // blocks from the one holding e - 1 down to hi; bytes at or beyond e are skipped
+        for (int64_t v = (e - 1) & ~(int64_t)15; v >= hi && e > hi; v -= 16) {
+            const U128 q = direct_load(a, v);
+            const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+            for (int d = 3; d >= 0; --d)
+                for (int j = 3; j >= 0; --j) {
+                    const int64_t p = v + 4 * d + j;
+                    if (p < e) r = T.tab[r * T.n_cls + T.cls[(wd[d] >> (8 * j)) & 0xffu]];
+                }
+        }
+    }
+    for (int64_t v = hi - 64; v >= lo; v -= 64) {
+        const U128 b0 = direct_load(a, v), b1 = direct_load(a, v + 16), b2 = direct_load(a, v + 32), b3 = direct_load(a, v + 48);
+        U128 y0, y1, y2, y3;
+        y3.w = rev_step4(T, r, b3.w); y3.z = rev_step4(T, r, b3.z); y3.y = rev_step4(T, r, b3.y); y3.x = rev_step4(T, r, b3.x);
+        y2.w = rev_step4(T, r, b2.w); y2.z = rev_step4(T, r, b2.z); y2.y = rev_step4(T, r, b2.y); y2.x = rev_step4(T, r, b2.x);
+        y1.w = rev_step4(T, r, b1.w); y1.z = rev_step4(T, r, b1.z); y1.y = rev_step4(T, r, b1.y); y1.x = rev_step4(T, r, b1.x);
+        y0.w = rev_step4(T, r, b0.w); y0.z = rev_step4(T, r, b0.z); y0.y = rev_step4(T, r, b0.y); y0.x = rev_step4(T, r, b0.x);
+        U128* dst = reinterpret_cast<U128*>(a.sym_v0 + v);
+        dst[0] = y0; dst[1] = y1; dst[2] = y2; dst[3] = y3;
+    }
+}
 
 // =============================================================================================
 // Memoryless tables: out[v] = map[in[v]] for one 16-byte vector at v.

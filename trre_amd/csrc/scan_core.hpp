@@ -263,8 +263,8 @@ TRRE_HD uint32_t alignbyte_b32(uint32_t hi, uint32_t lo, uint32_t sh) {
 }
 
 // ---- non-deterministic tables as the kernel sees them ---------------------------------
-struct NftFollowDev {      // mirrors trre::NftFollow
-    uint8_t target, mute;
+struct NftFollowDev {      // mirrors trre::NftFollow (flags: 1 mute, 2 the target echoes the byte it reads)
+    uint8_t target, flags;
     uint16_t out_len;
     uint32_t out_off;
 };
@@ -319,16 +319,18 @@ TRRE_HD void nft_line(const NftView& T, In in, GMask G, Sink& sink, int64_t p, i
             bool moved = false;
             for (; k < k_end; ++k) {
                 const NftFollowDev f = T.follow[k];
-                if (f.target == 0xFEu) { status |= kStDiverge; break; }
                 const bool fin = f.target == 0xFFu;
                 if (fin || (alive >> f.target & 1ull)) {
                     if (!muted) {
                         if (Sink::kCountOnly) sink.add(f.out_len);
                         else for (uint32_t b = 0; b < f.out_len; ++b) sink.put(T.pool[f.out_off + b]);
                     }
-                    if (f.mute) muted = true;
+                    if (f.flags & 1u) muted = true;
                     if (fin) accepted = true;
-                    else { s = f.target; ++i; }
+                    else {
+                        if ((f.flags & 2u) && !muted) sink.put(in(i));     // a byte range in copy mode
+                        s = f.target; ++i;
+                    }
                     moved = true;
                     break;
                 }

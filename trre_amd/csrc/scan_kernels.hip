@@ -366,7 +366,7 @@ __device__ __forceinline__ StreamView direct_stage(const ScanArgs& a, uint8_t* s
     return T;
 }
 
-template <int kMode, bool kLdsEnt>
+template <int kMode, bool kLdsEnt, bool kSym>
 __global__ __launch_bounds__(kDirectThreads) void k_stream_direct(ScanArgs a, int64_t lane_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const StreamView T = direct_stage<kLdsEnt>(a, smem);
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_direct(ScanArgs a, in
             return;
         }
     }
-    stream_direct_lane<kMode>(a, T, n_cls, lane, lane_bytes, ring, base, L, st);
+    stream_direct_lane<kMode, false, kSym>(a, T, n_cls, lane, lane_bytes, ring, base, L, st);
     if (kMode == 1) {
         uint64_t* part = reinterpret_cast<uint64_t*>(smem + kLds - 64);
         if (L.count > 0xffffffffull) { st |= kStCapacity; L.count = 0xffffffffull; }
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_direct(ScanArgs a, in
 
 // Count / emit passes over the 16-byte entries of a small table (front.hpp): the whole table in LDS.
 //   smem: cls[256] | g16[g16_room] | pooled text (2 KiB, when the pool fits) | staging[threads] | 64
-template <int kMode>
+template <int kMode, bool kSym>
 __global__ __launch_bounds__(kDirectThreads) void k_stream_g16(ScanArgs a, int64_t lane_bytes, int g16_room) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_g16(ScanArgs a, int64
             return;
         }
     }
-    stream_direct_lane<kMode, true>(a, T, h.n_cls, lane, lane_bytes, ring, base, L, st);
+    stream_direct_lane<kMode, true, kSym>(a, T, h.n_cls, lane, lane_bytes, ring, base, L, st);
     if (kMode == 1) {
         uint64_t* part = reinterpret_cast<uint64_t*>(tail);
         if (L.count > 0xffffffffull) { st |= kStCapacity; L.count = 0xffffffffull; }
@@ -735,28 +735,65 @@ void launch_lpw_kernel(int ent_bytes, bool wide, bool direct_ent_in_lds, const S
     if (ring_lds) hipLaunchKernelGGL((k_stream_redo<true>), dim3(64), dim3(kDirectThreads), kDirectLds, s, a, lane_bytes);
     else hipLaunchKernelGGL((k_stream_redo<false>), dim3(64), dim3(kDirectThreads), kDirectLdsHot, s, a, lane_bytes);
 }
-template <int kMode>
+template <int kMode, bool kSym>
 void launch_direct_t(bool ent_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, hipStream_t s) {
-    if (ent_lds) hipLaunchKernelGGL((k_stream_direct<kMode, true>), dim3((unsigned)n_blocks), dim3(kDirectThreads), kDirectLds, s, a, lane_bytes);
-    else hipLaunchKernelGGL((k_stream_direct<kMode, false>), dim3((unsigned)n_blocks), dim3(kDirectThreads), kDirectLdsHot, s, a, lane_bytes);
+    if (ent_lds) hipLaunchKernelGGL((k_stream_direct<kMode, true, kSym>), dim3((unsigned)n_blocks), dim3(kDirectThreads), kDirectLds, s, a, lane_bytes);
+    else hipLaunchKernelGGL((k_stream_direct<kMode, false, kSym>), dim3((unsigned)n_blocks), dim3(kDirectThreads), kDirectLdsHot, s, a, lane_bytes);
 }
 int direct_ent_lds_bytes() { return kDirectEntBytes; }
 int direct_block_threads() { return kDirectThreads; }
-void launch_direct_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, void* stream, int g16_bytes) {
-    hipStream_t s = static_cast<hipStream_t>(stream);
+template <bool kSym>
+void launch_direct_sym(int which, bool ent_in_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, hipStream_t s, int g16_bytes) {
     if (g16_bytes > 0 && which != 0) {
         const int room = (g16_bytes + 15) / 16 * 16;
         const int lds = 256 + room + kDirectPoolSmall + kDirectThreads * kRingStride + 64;
         const int lds_count = 256 + room + 64;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_g16<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_count);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_g16<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (which == 1) hipLaunchKernelGGL((k_stream_g16<1>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds_count, s, a, lane_bytes, room);
-        else hipLaunchKernelGGL((k_stream_g16<2>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds, s, a, lane_bytes, room);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_g16<1, kSym>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_count);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_g16<2, kSym>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (which == 1) hipLaunchKernelGGL((k_stream_g16<1, kSym>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds_count, s, a, lane_bytes, room);
+        else hipLaunchKernelGGL((k_stream_g16<2, kSym>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds, s, a, lane_bytes, room);
         return;
     }
-    if (which == 0) launch_direct_t<0>(ent_in_lds, a, lane_bytes, n_blocks, s);
-    else if (which == 1) launch_direct_t<1>(ent_in_lds, a, lane_bytes, n_blocks, s);
-    else launch_direct_t<2>(ent_in_lds, a, lane_bytes, n_blocks, s);
+    if (which == 0) launch_direct_t<0, kSym>(ent_in_lds, a, lane_bytes, n_blocks, s);
+    else if (which == 1) launch_direct_t<1, kSym>(ent_in_lds, a, lane_bytes, n_blocks, s);
+    else launch_direct_t<2, kSym>(ent_in_lds, a, lane_bytes, n_blocks, s);
+}
+void launch_direct_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, void* stream, int g16_bytes, bool sym) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (sym) launch_direct_sym<true>(which, ent_in_lds, a, lane_bytes, n_blocks, s, g16_bytes);
+    else launch_direct_sym<false>(which, ent_in_lds, a, lane_bytes, n_blocks, s, g16_bytes);
+}
+
+// ---- backward pass of the guided families: one symbol per input byte (rev_sweep_lane) -------------------
+constexpr int kRevThreads = 256;
+constexpr int kRevTabLds = 65536;          // larger tables are read through L1/L2
+
+template <bool kLdsTab>
+__global__ __launch_bounds__(kRevThreads) void k_rev_sweep(ScanArgs a, int64_t lane_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];    // cls[256] | tab
+    const RevBlobHeader& h = *reinterpret_cast<const RevBlobHeader*>(a.rblob);
+    for (int k = threadIdx.x; k < 256; k += kRevThreads) smem[k] = a.rblob[h.off_cls + k];
+    if (kLdsTab) {
+        const uint32_t* e = reinterpret_cast<const uint32_t*>(a.rblob + h.off_tab);
+        uint32_t* d = reinterpret_cast<uint32_t*>(smem + 256);
+        for (int k = threadIdx.x; k < (int)(h.tab_bytes / 4); k += kRevThreads) d[k] = e[k];
+    }
+    __syncthreads();
+    const RevView T{smem, kLdsTab ? smem + 256 : a.rblob + h.off_tab, h.n_cls};
+    rev_sweep_lane(a, T, (int64_t)blockIdx.x * kRevThreads + threadIdx.x, lane_bytes);
+}
+void launch_rev_sweep(const ScanArgs& a, int tab_bytes, int64_t lane_bytes, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t vtop = (a.vend + 63) & ~(int64_t)63;
+    const int64_t n_lanes = (vtop + lane_bytes - 1) / lane_bytes;
+    const dim3 grid((unsigned)((n_lanes + kRevThreads - 1) / kRevThreads));
+    if (tab_bytes <= kRevTabLds) {
+        const int lds = 256 + (tab_bytes + 15) / 16 * 16;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rev_sweep<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((k_rev_sweep<true>), grid, dim3(kRevThreads), lds, s, a, lane_bytes);
+    } else {
+        hipLaunchKernelGGL((k_rev_sweep<false>), grid, dim3(kRevThreads), 256, s, a, lane_bytes);
+    }
 }
 
 int stream_chunk_bytes(int which) { return which == 0 ? GeoStream::CHUNK : GeoStreamGen::CHUNK; }

@@ -30,10 +30,12 @@
 // (loops before a decision) make the state set infinite; the builder then gives
 // up and the launcher uses the general tile kernels instead.
 #include <algorithm>
+#include <array>
 #include <map>
 #include <unordered_map>
 
 #include "front.hpp"
+#include "stream_pack.hpp"
 
 namespace trre {
 namespace {
@@ -44,7 +46,7 @@ struct Outcome {
     size_t consumed = 0;
 };
 
-struct GiveUp {};   // the pattern does not fold into a bounded stream table
+using GiveUp = StreamGiveUp;   // the pattern does not fold into a bounded stream table
 
 class AttemptModel {
 public:
@@ -171,7 +173,6 @@ public:
     StreamBuilder(const AttemptModel& m, const StreamLimits& lim) : m_(m), lim_(lim) {}
 
     StreamTables run() {
-        StreamTables t;
         m_.alphabet(used_);
         intern("");                       // 0 = root
         skip_ = (uint32_t)names_.size();  // 1 = SKIP: swallow the rest of the record (after a NUL; also a
@@ -204,17 +205,11 @@ public:
             }
         }
         spread_long_outputs();
-        return pack(t);
+        return pack();
     }
 
 private:
-    struct Cell {
-        uint32_t next = 0;
-        std::string out;     // bytes emitted before the optional copy of the input byte
-        bool copy_c = false;
-        bool eol = false;
-        bool ovf = false;    // the attempt outgrew max_pending: target SKIP, result void
-    };
+    using Cell = StreamCell;
 
     uint32_t intern(const std::string& w) {
         auto hit = index_.find(w);
@@ -314,14 +309,15 @@ private:
         }
     }
 
-    StreamTables pack(StreamTables& t) {
+    // byte classes (identical columns over all states), then the generic packer
+    StreamTables pack() {
         const uint32_t n = (uint32_t)names_.size();
-        t.n_states = n;
-        t.pending_len.resize(n);
-        for (uint32_t s = 0; s < n; ++s) t.pending_len[s] = (s == skip_ || s == done_) ? 0 : (uint32_t)names_[s].size();
-        // byte classes: identical columns over all states
+        StreamPackInput in;
+        in.pending_len.resize(n);
+        for (uint32_t s = 0; s < n; ++s) in.pending_len[s] = (s == skip_ || s == done_) ? 0 : (uint32_t)names_[s].size();
         std::map<std::vector<std::string>, uint32_t> col_index;
         std::vector<int> rep;
+        std::array<uint8_t, 256> cls{};
         for (int c = 0; c < 256; ++c) {
             std::vector<std::string> key;
             key.reserve(n);
@@ -334,134 +330,20 @@ private:
                 hit = col_index.emplace(std::move(key), (uint32_t)rep.size()).first;
                 rep.push_back(c);
             }
-            t.cls[c] = (uint8_t)hit->second;
+            cls[c] = (uint8_t)hit->second;
         }
-        t.n_cls = (uint32_t)rep.size();
-        if ((uint64_t)n * t.n_cls >= (1u << 24)) throw GiveUp();
-        t.ent.resize((size_t)n * t.n_cls);
-        std::unordered_map<std::string, uint32_t> pooled;
-        bool lp = true, inplace_ok = true;
+        in.rows.resize(n);
         for (uint32_t s = 0; s < n; ++s) {
-            for (uint32_t k = 0; k < t.n_cls; ++k) {
-                const Cell& x = rows_[s][rep[k]];
-                uint64_t lo = (uint64_t)x.next * t.n_cls;
-                uint64_t hi = 0;
-                if (x.out.size() <= 4) {
-                    lo |= (uint64_t)x.out.size() << 24;
-                    for (size_t b = 0; b < x.out.size(); ++b) hi |= (uint64_t)(uint8_t)x.out[b] << (8 * b);
-                } else {
-                    lo |= 7ull << 24;
-                    auto hit = pooled.find(x.out);
-                    if (hit == pooled.end()) {
-                        while (t.pool.size() % 4) t.pool.push_back(0);
-                        hit = pooled.emplace(x.out, (uint32_t)t.pool.size()).first;
-                        uint32_t len = (uint32_t)x.out.size();
-                        for (int b = 0; b < 4; ++b) t.pool.push_back((uint8_t)(len >> (8 * b)));
-                        t.pool.insert(t.pool.end(), x.out.begin(), x.out.end());
-                    }
-                    if (hit->second >= (1u << 26)) throw GiveUp();
-                    hi = (uint64_t)(hit->second >> 2) | (uint64_t)std::min<size_t>(x.out.size(), 255) << 24;
-                }
-                if (x.copy_c) lo |= 1ull << 27;
-                if (x.eol) lo |= 1ull << 28;
-                if (x.ovf) lo |= 1ull << 30;
-                if (rep[k] == 0 && s != skip_ && s != done_) lo |= 1ull << 29;   // a NUL cut a line short
-                // in-place safety: an emitted '\n' may only be the last byte of a record-end transition
-                if (rep[k] != 0) {   // (a NUL voids the in-place launch anyway: kStNul)
-                    const size_t nl = x.out.find('\n');
-                    if (nl != std::string::npos && !(x.eol && nl + 1 == x.out.size())) inplace_ok = false;
-                    if (x.copy_c && rep[k] == '\n') inplace_ok = false;
-                }
-                t.ent[(size_t)s * t.n_cls + k] = lo | hi << 32;
-                t.max_out = std::max<uint32_t>(t.max_out, (uint32_t)x.out.size() + (x.copy_c ? 1 : 0));
-                // length-preserving: bytes emitted = pending released + the byte read
-                if (s != skip_ && s != done_ && rep[k] != 0) {
-                    const int64_t emitted = (int64_t)x.out.size() + (x.copy_c ? 1 : 0);
-                    const int64_t expect = (int64_t)t.pending_len[s] + 1 - (int64_t)t.pending_len[x.next];
-                    if (emitted != expect) lp = false;
-                }
-            }
+            in.rows[s].reserve(rep.size());
+            for (int c : rep) in.rows[s].push_back(rows_[s][c]);
         }
-        while (t.pool.size() % 4) t.pool.push_back(0);
-        for (int k = 0; k < 8; ++k) t.pool.push_back(0);   // 8-byte reads of a record's text stay inside the pool
-        t.ok = true;
-        t.bounded = bounded_;
-        if (bounded_) lp = false;           // (a void launch must be noticed: only the count pass reports it)
-        if (lp) build_window_form(t, rep);
-        build_gen16(t, rep);
-        if (lp) t.flags |= kFlagLengthPreserving;
-        if (lp && inplace_ok) t.flags |= kFlagNoOverrun;    // the in-place kernel may run
+        for (int c : rep) in.col_kind.push_back(c == 0 ? kColNul : (c == '\n' ? kColNewline : kColPlain));
+        in.skip = skip_;
+        in.done = done_;
+        in.bounded = bounded_;
+        StreamTables t = pack_stream_tables(in);
+        t.cls = cls;
         return t;
-    }
-
-    // entries for the positional-window kernel (see front.hpp): 16 bytes when no state has more than
-    // 3 bytes pending (at most 4 bytes per transition, 32-bit window), 32 bytes up to 7 pending
-    // (at most 8 bytes per transition, 64-bit window)
-    void build_window_form(StreamTables& t, const std::vector<int>& rep) {
-        uint32_t delay = 0;
-        for (uint32_t s = 0; s < t.n_states; ++s) delay = std::max(delay, t.pending_len[s]);
-        if (delay > 7) return;
-        const bool wide = delay > 3;
-        const uint32_t words = wide ? 8u : 4u;
-        if ((size_t)t.n_states * t.n_cls * words * 4 > 32768) return;    // the table lives in LDS
-        std::vector<uint32_t> v((size_t)t.n_states * t.n_cls * words, 0);
-        for (uint32_t s = 0; s < t.n_states; ++s) {
-            for (uint32_t k = 0; k < t.n_cls; ++k) {
-                const Cell& x = rows_[s][rep[k]];
-                const size_t n = x.out.size() + (x.copy_c ? 1 : 0);
-                if (n > (wide ? 8u : 4u)) return;        // (a NUL flushes pending + '\n': at most delay + 1)
-                uint32_t* e = &v[((size_t)s * t.n_cls + k) * words];
-                e[0] = x.next * t.n_cls * words * 4u;
-                const bool silent = s == skip_ || s == done_;
-                e[1] = (silent ? 0u : 8u * (delay - t.pending_len[s])) | (x.eol ? 64u : 0u) |
-                       ((rep[k] == 0 && !silent) ? 128u : 0u);
-                for (uint32_t half = 0; half < words / 4; ++half) {
-                    uint32_t bytes = 0, sel = 0;
-                    for (size_t b = 0; b < 4; ++b) {
-                        const size_t pos = 4 * half + b;
-                        uint32_t pick = 0x0cu;                                   // constant 0x00
-                        if (pos < x.out.size()) { bytes |= (uint32_t)(uint8_t)x.out[pos] << (8 * b); pick = (uint32_t)b; }
-                        else if (pos == x.out.size() && x.copy_c) pick = 4u;     // byte 0 of the input register
-                        sel |= pick << (8 * b);
-                    }
-                    e[2 + 2 * half] = bytes;
-                    e[3 + 2 * half] = sel;
-                }
-            }
-        }
-        t.lpw = std::move(v);
-        t.lpw_delay = delay;
-        t.lpw_ok = true;
-    }
-
-    // 16-byte entries for the count and emit passes (see front.hpp); small tables only (they live in LDS)
-    void build_gen16(StreamTables& t, const std::vector<int>& rep) {
-        if ((size_t)t.n_states * t.n_cls > 2048) return;
-        std::vector<uint32_t> v((size_t)t.n_states * t.n_cls * 4, 0);
-        for (uint32_t s = 0; s < t.n_states; ++s) {
-            for (uint32_t k = 0; k < t.n_cls; ++k) {
-                const Cell& x = rows_[s][rep[k]];
-                const size_t n = x.out.size() + (x.copy_c ? 1 : 0);
-                const bool slow = n > 4;
-                uint32_t* e = &v[((size_t)s * t.n_cls + k) * 4];
-                e[0] = x.next * t.n_cls * 16u;
-                e[1] = (slow ? 128u : (uint32_t)n) | (x.eol ? 32u : 0u) | (x.ovf ? 64u : 0u);
-                uint32_t bytes = 0, sel = 0x0c0c0c0cu;                       // constant 0x00 everywhere
-                if (!slow) {
-                    sel = 0;
-                    for (size_t b = 0; b < 4; ++b) {
-                        uint32_t pick = 0x0cu;
-                        if (b < x.out.size()) { bytes |= (uint32_t)(uint8_t)x.out[b] << (8 * b); pick = (uint32_t)b; }
-                        else if (b == x.out.size() && x.copy_c) pick = 4u;   // byte 0 of the input register
-                        sel |= pick << (8 * b);
-                    }
-                }
-                e[2] = bytes;
-                e[3] = sel;
-            }
-        }
-        t.g16 = std::move(v);
-        t.g16_ok = true;
     }
 
     const AttemptModel& m_;

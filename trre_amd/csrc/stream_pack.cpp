@@ -1,0 +1,147 @@
+// stream_pack.cpp — see stream_pack.hpp.  Entry formats are documented in front.hpp (StreamTables).
+#include "stream_pack.hpp"
+
+#include <algorithm>
+#include <unordered_map>
+
+namespace trre {
+namespace {
+
+// entries for the positional-window kernel (see front.hpp): 16 bytes when no state has more than
+// 3 bytes pending (at most 4 bytes per transition, 32-bit window), 32 bytes up to 7 pending
+// (at most 8 bytes per transition, 64-bit window)
+void build_window_form(StreamTables& t, const StreamPackInput& in) {
+    uint32_t delay = 0;
+    for (uint32_t s = 0; s < t.n_states; ++s) delay = std::max(delay, t.pending_len[s]);
+    if (delay > 7) return;
+    const bool wide = delay > 3;
+    const uint32_t words = wide ? 8u : 4u;
+    if ((size_t)t.n_states * t.n_cls * words * 4 > 32768) return;    // the table lives in LDS
+    std::vector<uint32_t> v((size_t)t.n_states * t.n_cls * words, 0);
+    for (uint32_t s = 0; s < t.n_states; ++s) {
+        for (uint32_t k = 0; k < t.n_cls; ++k) {
+            const StreamCell& x = in.rows[s][k];
+            const size_t n = x.out.size() + (x.copy_c ? 1 : 0);
+            if (n > (wide ? 8u : 4u)) return;        // (a NUL flushes pending + '\n': at most delay + 1)
+            uint32_t* e = &v[((size_t)s * t.n_cls + k) * words];
+            e[0] = x.next * t.n_cls * words * 4u;
+            const bool silent = s == in.skip || s == in.done;
+            e[1] = (silent ? 0u : 8u * (delay - t.pending_len[s])) | (x.eol ? 64u : 0u) |
+                   ((in.col_kind[k] == kColNul && !silent) ? 128u : 0u) | (x.diverge ? 256u : 0u);
+            for (uint32_t half = 0; half < words / 4; ++half) {
+                uint32_t bytes = 0, sel = 0;
+                for (size_t b = 0; b < 4; ++b) {
+                    const size_t pos = 4 * half + b;
+                    uint32_t pick = 0x0cu;                                   // constant 0x00
+                    if (pos < x.out.size()) { bytes |= (uint32_t)(uint8_t)x.out[pos] << (8 * b); pick = (uint32_t)b; }
+                    else if (pos == x.out.size() && x.copy_c) pick = 4u;     // byte 0 of the input register
+                    sel |= pick << (8 * b);
+                }
+                e[2 + 2 * half] = bytes;
+                e[3 + 2 * half] = sel;
+            }
+        }
+    }
+    t.lpw = std::move(v);
+    t.lpw_delay = delay;
+    t.lpw_ok = true;
+}
+
+// 16-byte entries for the count and emit passes (see front.hpp); small tables only (they live in LDS)
+void build_gen16(StreamTables& t, const StreamPackInput& in) {
+    if ((size_t)t.n_states * t.n_cls > 2048) return;
+    std::vector<uint32_t> v((size_t)t.n_states * t.n_cls * 4, 0);
+    for (uint32_t s = 0; s < t.n_states; ++s) {
+        for (uint32_t k = 0; k < t.n_cls; ++k) {
+            const StreamCell& x = in.rows[s][k];
+            const size_t n = x.out.size() + (x.copy_c ? 1 : 0);
+            const bool slow = n > 4;
+            uint32_t* e = &v[((size_t)s * t.n_cls + k) * 4];
+            e[0] = x.next * t.n_cls * 16u;
+            e[1] = (slow ? 128u : (uint32_t)n) | (x.eol ? 32u : 0u) | (x.ovf ? 64u : 0u) | (x.diverge ? 16u : 0u);
+            uint32_t bytes = 0, sel = 0x0c0c0c0cu;                       // constant 0x00 everywhere
+            if (!slow) {
+                sel = 0;
+                for (size_t b = 0; b < 4; ++b) {
+                    uint32_t pick = 0x0cu;
+                    if (b < x.out.size()) { bytes |= (uint32_t)(uint8_t)x.out[b] << (8 * b); pick = (uint32_t)b; }
+                    else if (b == x.out.size() && x.copy_c) pick = 4u;   // byte 0 of the input register
+                    sel |= pick << (8 * b);
+                }
+            }
+            e[2] = bytes;
+            e[3] = sel;
+        }
+    }
+    t.g16 = std::move(v);
+    t.g16_ok = true;
+}
+
+}  // namespace
+
+StreamTables pack_stream_tables(const StreamPackInput& in) {
+    StreamTables t;
+    const uint32_t n = (uint32_t)in.rows.size();
+    t.n_states = n;
+    t.pending_len = in.pending_len;
+    t.n_cls = (uint32_t)in.col_kind.size();
+    if (t.n_cls > 256 || (uint64_t)n * t.n_cls >= (1u << 24)) throw StreamGiveUp();
+    t.ent.resize((size_t)n * t.n_cls);
+    std::unordered_map<std::string, uint32_t> pooled;
+    bool lp = !in.never_lp, inplace_ok = true;
+    for (uint32_t s = 0; s < n; ++s) {
+        for (uint32_t k = 0; k < t.n_cls; ++k) {
+            const StreamCell& x = in.rows[s][k];
+            const bool nul_col = in.col_kind[k] == kColNul;
+            uint64_t lo = (uint64_t)x.next * t.n_cls;
+            uint64_t hi = 0;
+            if (x.out.size() <= 4) {
+                lo |= (uint64_t)x.out.size() << 24;
+                for (size_t b = 0; b < x.out.size(); ++b) hi |= (uint64_t)(uint8_t)x.out[b] << (8 * b);
+            } else {
+                lo |= 7ull << 24;
+                auto hit = pooled.find(x.out);
+                if (hit == pooled.end()) {
+                    while (t.pool.size() % 4) t.pool.push_back(0);
+                    hit = pooled.emplace(x.out, (uint32_t)t.pool.size()).first;
+                    uint32_t len = (uint32_t)x.out.size();
+                    for (int b = 0; b < 4; ++b) t.pool.push_back((uint8_t)(len >> (8 * b)));
+                    t.pool.insert(t.pool.end(), x.out.begin(), x.out.end());
+                }
+                if (hit->second >= (1u << 26)) throw StreamGiveUp();
+                hi = (uint64_t)(hit->second >> 2) | (uint64_t)std::min<size_t>(x.out.size(), 255) << 24;
+            }
+            if (x.copy_c) lo |= 1ull << 27;
+            if (x.eol) lo |= 1ull << 28;
+            if (x.ovf) lo |= 1ull << 30;
+            if (x.diverge) lo |= 1ull << 31;
+            if (nul_col && s != in.skip && s != in.done) lo |= 1ull << 29;   // a NUL cut a line short
+            // in-place safety: an emitted '\n' may only be the last byte of a record-end transition
+            if (!nul_col) {   // (a NUL voids the in-place launch anyway: kStNul)
+                const size_t nl = x.out.find('\n');
+                if (nl != std::string::npos && !(x.eol && nl + 1 == x.out.size())) inplace_ok = false;
+                if (x.copy_c && in.col_kind[k] == kColNewline) inplace_ok = false;
+            }
+            t.ent[(size_t)s * t.n_cls + k] = lo | hi << 32;
+            t.max_out = std::max<uint32_t>(t.max_out, (uint32_t)x.out.size() + (x.copy_c ? 1 : 0));
+            // length-preserving: bytes emitted = pending released + the byte read
+            if (s != in.skip && s != in.done && !nul_col && !x.diverge) {
+                const int64_t emitted = (int64_t)x.out.size() + (x.copy_c ? 1 : 0);
+                const int64_t expect = (int64_t)t.pending_len[s] + 1 - (int64_t)t.pending_len[x.next];
+                if (emitted != expect) lp = false;
+            }
+        }
+    }
+    while (t.pool.size() % 4) t.pool.push_back(0);
+    for (int k = 0; k < 8; ++k) t.pool.push_back(0);   // 8-byte reads of a record's text stay inside the pool
+    t.ok = true;
+    t.bounded = in.bounded;
+    if (in.bounded) lp = false;         // (a void launch must be noticed: only the count pass reports it)
+    if (lp) build_window_form(t, in);
+    build_gen16(t, in);
+    if (lp) t.flags |= kFlagLengthPreserving;
+    if (lp && inplace_ok) t.flags |= kFlagNoOverrun;    // the in-place kernel may run
+    return t;
+}
+
+}  // namespace trre
