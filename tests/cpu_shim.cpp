@@ -192,10 +192,24 @@ void run_direct_lp(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
         stream_direct_lane<0, false, kSym>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
     }
 }
+// length-preserving as the runtime launches it: the emit pass alone, lanes writing their lines in place
+template <bool kSym = false>
+void run_direct_lp_emit(ScanArgs a, int64_t lane_bytes, uint32_t& status, bool g16) {
+    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
+    const StreamView T = direct_view(a);
+    const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
+    alignas(16) uint8_t ring[kRingStride];
+    a.lp_emit = 1;
+    for (int64_t lane = n_lanes - 1; lane >= 0; --lane) {
+        DirectLane L;
+        if (g16) stream_direct_lane<2, true, kSym>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
+        else stream_direct_lane<2, false, kSym>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
+    }
+}
 // backward pass of the guided families, lane by lane (any order: lanes write disjoint symbols)
 void run_rev_sweep(const ScanArgs& a, int64_t lane_bytes) {
     const RevBlobHeader& h = *reinterpret_cast<const RevBlobHeader*>(a.rblob);
-    const RevView T{a.rblob + h.off_cls, a.rblob + h.off_tab, h.n_cls};
+    const RevView T{a.rblob + h.off_wide};
     const int64_t vtop = (a.vend + 63) & ~(int64_t)63;
     const int64_t n_lanes = (vtop + lane_bytes - 1) / lane_bytes;
     for (int64_t lane = 0; lane < n_lanes; ++lane) rev_sweep_lane(a, T, lane, lane_bytes);
@@ -338,6 +352,7 @@ int run_family(int family, ScanArgs& a, uint32_t& status, uint64_t& total) {
 extern "C" {
 
 // family: 1 bytemap, 2 tile LP, 3 tile general, 4 stream LP (in place), 5 stream general.
+// 20 / 21 stream LP by the emit pass alone (16-byte / 8-byte entries),
 // 8 positional-window stream LP, 9 direct stream general on the 8-byte entries (7 prefers the 16-byte ones), 6 direct stream LP, 7 direct stream general (geo: 0 -> 2048-byte lanes, 1 -> 48-byte lanes).
 // geo: 0 production, 1 tiny.
 // in_mis/out_mis: address misalignment (0..15) to give the staged buffers.
@@ -372,6 +387,11 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
         total = n;
     }
     else if (family == 6) { run_direct_lp<>(a, geo == 0 ? 2048 : 48, status); total = n; }
+    else if (family == 20 || family == 21) {          // stream LP as the runtime launches it without a window form: emit pass alone
+        const bool g16 = family == 20 && reinterpret_cast<const StreamBlobHeader*>(blob)->g16_bytes != 0;
+        run_direct_lp_emit<>(a, geo == 0 ? 2048 : 64, status, g16);
+        total = n;
+    }
     else if (family == 7 || family == 9) {
         const bool g16 = family == 7 && reinterpret_cast<const StreamBlobHeader*>(blob)->g16_bytes != 0;
         run_direct_gen<>(a, geo == 0 ? 2048 : 48, status, total, g16);
@@ -405,8 +425,8 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
 }
 
 // Guided families (backward DFA sweep + forward transducer over its symbols).
-// family: 10 length-preserving (in place), 11 general on the 16-byte entries when the tables have them,
-// 12 general on the 8-byte entries.  geo: 0 -> 2048-byte lanes, 1 -> 64-byte lanes.
+// family: 10 length-preserving (emit pass alone; 14: on the 8-byte entries; 13: the LDS-ring walker),
+// 11 general on the 16-byte entries when the tables have them, 12 general on the 8-byte entries.  geo: 0 -> 2048-byte lanes, 1 -> 64-byte lanes.
 int shim_scan_guided(const uint8_t* rblob, const uint8_t* gblob, int family, int geo, const uint8_t* in, size_t n, int in_mis,
                      uint8_t* out, size_t cap, int out_mis, size_t* m, uint32_t* status_out) {
     if (n == 0) { *m = 0; *status_out = 0; return 0; }
@@ -429,9 +449,14 @@ int shim_scan_guided(const uint8_t* rblob, const uint8_t* gblob, int family, int
     uint32_t status = 0;
     uint64_t total = 0;
     const int64_t lane_bytes = geo == 0 ? 2048 : 64;
-    if (family == 10 && cap < n) return -9;
+    if ((family == 10 || family == 13 || family == 14) && cap < n) return -9;
     run_rev_sweep(a, lane_bytes);
-    if (family == 10) { run_direct_lp<true>(a, lane_bytes, status); total = n; }
+    if (family == 10 || family == 13 || family == 14) {
+        const bool g16 = reinterpret_cast<const StreamBlobHeader*>(gblob)->g16_bytes != 0;
+        if (family == 13) run_direct_lp<true>(a, lane_bytes, status);              // the LDS-ring walker (A/B variant)
+        else run_direct_lp_emit<true>(a, lane_bytes, status, family == 10 && g16);  // 14: on the 8-byte entries
+        total = n;
+    }
     else {
         const bool g16 = family == 11 && reinterpret_cast<const StreamBlobHeader*>(gblob)->g16_bytes != 0;
         run_direct_gen<true>(a, lane_bytes, status, total, g16);

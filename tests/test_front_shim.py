@@ -58,7 +58,7 @@ def guided_families(p):
     allowed = p.allowed_kernels()
     fams = []
     if trre_amd.KERNEL_GUIDED_LP in allowed:
-        fams.append(shim_lib.GUIDED_LP)
+        fams += list(shim_lib.GUIDED_LP_ALL)
     if trre_amd.KERNEL_GUIDED_GEN in allowed:
         fams += [shim_lib.GUIDED_GEN, shim_lib.GUIDED_GEN8]
     return fams
@@ -89,8 +89,8 @@ def shim_families(p):
     """kernel families to run through the shim: the ABI's plus the direct (no-tile) stream walkers"""
     allowed = list(p.allowed_kernels())
     fams = [f for f in allowed if f <= 5]
-    if 4 in fams:
-        fams += [6, 8]         # (shim ids: 6/8 direct and window walkers of the stream LP family, 7/9 of the general one)
+    if 4 in fams:             # (shim ids: 6/8 LDS-ring and window walkers of the stream LP family, 20/21 its emit-only form,
+        fams += [6, 8, shim_lib.STREAM_LP_EMIT, shim_lib.STREAM_LP_EMIT8]      # 7/9 direct walkers of the general one)
     if 5 in fams:
         fams += [7, 9]
     return fams + guided_families(p)

@@ -2,7 +2,7 @@
 """Run one kernel family on one corpus a few times (for rocprofv3 / quick A-B).
     python tools/kbench.py --pattern '(cat:dog|dog:cat)' --engine nft --corpus catdog --bytes $((1<<30))
     python tools/kbench.py --dict 1000 --engine dft             # cfg 5 shape
-Several --case 'pattern|engine|corpus|kernel' run back to back in one process."""
+Several --case 'pattern;;engine;;corpus;;kernel' run back to back in one process."""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -20,10 +20,10 @@ ap.add_argument("--corpus", default="printable", help="printable | catdog | dict
 ap.add_argument("--bytes", type=int, default=1 << 30)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--dict", type=int, default=0, help="use the seeded N-entry key:value dictionary pattern and corpus (config 5)")
-ap.add_argument("--case", action="append", default=[], help="pattern|engine|corpus|kernel (repeatable)")
+ap.add_argument("--case", action="append", default=[], help="pattern;;engine;;corpus;;kernel (repeatable)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
-cases = [c.split("|") for c in a.case]
+cases = [c.split(";;") for c in a.case]
 if not cases:
     if a.dict:
         cases = [["@dict%d" % a.dict, a.engine, "dict%d" % a.dict, a.kernel]]

@@ -50,9 +50,10 @@ static_assert(sizeof(StreamBlobHeader) == 64, "header layout");
 constexpr uint32_t kMagicRev = 0x31525254u;   // "TRR1"
 struct RevBlobHeader {
     uint32_t magic, n_rev, n_cls;
-    uint32_t off_cls;        // u8[256] byte -> class
-    uint32_t off_tab;        // u8[n_rev][n_cls] next state (= the symbol left at the byte's position)
-    uint32_t tab_bytes, total_bytes, pad;
+    uint32_t off_cls;        // u8[256] byte -> class            } the compact form (inspection, host tests)
+    uint32_t off_tab;        // u8[n_rev][n_cls] next state      }
+    uint32_t off_wide;       // u8[n_rev][256] next state by raw byte (= the symbol left at the byte's position): what the kernel walks
+    uint32_t total_bytes, pad;
 };
 static_assert(sizeof(RevBlobHeader) == 32, "header layout");
 

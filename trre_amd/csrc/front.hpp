@@ -177,7 +177,8 @@ struct StreamTables {
     std::vector<uint32_t> lpw;              // [n_states][n_cls][4 or 8]
     // 16-byte entries for the count / emit passes of small tables (any output length): like the window
     // form without the shift, {next row offset, meta, inline bytes, v_perm selector}; meta [2:0] = bytes
-    // the transition appends (inline bytes, then maybe the input byte), [5] record end, [7] "slow":
+    // the transition appends (inline bytes, then maybe the input byte), [3] a NUL cut a line short, [4] the
+    // reference's search diverges (guided tables), [5] record end, [6] bounded-fold overflow, [7] "slow":
     // more than 4 bytes or pooled text — handled from the 8-byte entry
     bool g16_ok = false;
     std::vector<uint32_t> g16;              // [n_states][n_cls][4]

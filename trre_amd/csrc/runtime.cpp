@@ -198,13 +198,18 @@ void serialize_rev(const trre::GuidedTables& g, std::vector<uint8_t>& b) {
     h.n_cls = g.n_cls;
     size_t off = sizeof h;
     h.off_cls = (uint32_t)off; off += 256;
-    h.off_tab = (uint32_t)off; h.tab_bytes = (uint32_t)align_up(g.rev.size(), 4); off += h.tab_bytes;
+    h.off_tab = (uint32_t)off; off += align_up(g.rev.size(), 16);
+    h.off_wide = (uint32_t)off; off += (size_t)g.n_rev * 256;
     off = align_up(off + 16, 16);
     h.total_bytes = (uint32_t)off;
     b.assign(off, 0);
+    std::vector<uint8_t> wide((size_t)g.n_rev * 256);
+    for (uint32_t r = 0; r < g.n_rev; ++r)
+        for (int c = 0; c < 256; ++c) wide[(size_t)r * 256 + c] = g.rev[(size_t)r * g.n_cls + g.cls[c]];
     put(b, 0, &h, 1);
     put(b, h.off_cls, g.cls.data(), 256);
     put(b, h.off_tab, g.rev.data(), g.rev.size());
+    put(b, h.off_wide, wide.data(), wide.size());
 }
 
 bool is_stream(int fam) { return fam == TRRE_KERNEL_STREAM_LP || fam == TRRE_KERNEL_STREAM_GEN; }
@@ -335,7 +340,7 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
     // sub-range per lane: 2 KiB, growing with the input so that about half a million lanes (8192 waves)
     // walk it — per-lane costs (the skipped head, the tail beyond the sub-range, the wave waiting for its
     // slowest lane) shrink with longer lanes: cfg 4 at 8 GiB 1.72 TB/s with 2 KiB lanes, 2.06 with 16 KiB
-    int64_t lane_auto = !is_gen(family) && streamish && !window ? 1024 : 2048;
+    int64_t lane_auto = 2048;
     if (window)
         while (lane_auto < 16384 && (int64_t)n / (lane_auto * 2) >= 524288) lane_auto *= 2;
     const int64_t lane_bytes = lane_bytes_env > 0 ? (lane_bytes_env + 127) / 128 * 128 : lane_auto;
@@ -384,12 +389,22 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
         args.redo = st->d_redo;
         launch_lpw_kernel((int)(p->stt.lpw.size() * 4), p->stt.lpw_delay > 3, direct_ent_lds, args, lane_bytes, stream);
     } else if (direct && !is_gen(family)) {
-        if (is_guided(family)) launch_rev_sweep(args, (int)align_up(p->gt.rev.size(), 4), lane_bytes, stream);
-        launch_direct_kernel(0, direct_ent_lds, args, lane_bytes, n_chunks, stream, 0, is_guided(family));
+        // length-preserving without a window form: the emit pass alone, every lane writing its lines where it read
+        // them (TRRE_LP_RING=1: the older in-place walker with an LDS ring, 2.3x slower; kept for A/B runs)
+        static const bool lp_ring = getenv("TRRE_LP_RING") != nullptr;
+        static const bool no_g16 = getenv("TRRE_NO_G16") != nullptr;
+        const int g16 = stt.g16_ok && !no_g16 ? (int)(stt.g16.size() * 4) : 0;
+        if (is_guided(family)) launch_rev_sweep(args, (int)p->gt.n_rev * 256, lane_bytes, stream);
+        if (lp_ring) {
+            launch_direct_kernel(0, direct_ent_lds, args, lane_bytes, n_chunks, stream, 0, is_guided(family));
+        } else {
+            args.lp_emit = 1;
+            launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, is_guided(family));
+        }
     } else if (direct) {
         static const bool no_g16 = getenv("TRRE_NO_G16") != nullptr;          // A/B: the 8-byte entries
         const int g16 = stt.g16_ok && !no_g16 ? (int)(stt.g16.size() * 4) : 0;
-        if (is_guided(family)) launch_rev_sweep(args, (int)align_up(p->gt.rev.size(), 4), lane_bytes, stream);
+        if (is_guided(family)) launch_rev_sweep(args, (int)p->gt.n_rev * 256, lane_bytes, stream);
         launch_direct_kernel(1, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, is_guided(family));
         launch_chunk_scan(st->d_chunk_total, st->d_chunk_base, n_chunks, stream);
         launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, is_guided(family));

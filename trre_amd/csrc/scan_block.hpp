@@ -55,6 +55,8 @@ struct ScanArgs {
     uint8_t* gscratch;       // NFT long-line mask scratch (or null)
     uint32_t* redo;          // window kernel: [0] = count, [1..] = lanes to redo with the general direct walker
     const uint8_t* rblob;    // guided families: tables of the backward pass (RevBlobHeader)
+    uint32_t lp_emit;        // emit pass of a length-preserving program without a count pass: a lane's output starts at
+                             // the position of its first line start (output position == input position at line starts)
     uint8_t* sym_v0;         // guided families: one symbol per input byte, indexed like in_v0 (v-space); the
                              // backward pass fills [0, round_up(vend, 64)), the forward pass reads it
 };
@@ -785,6 +787,19 @@ TRRE_HD void stage_flush(Stage& s) {
     }
 }
 
+// position after the first '\n' at or after lo - 1, anywhere in the input (reads through direct_load); >= hi: none
+TRRE_HD int64_t first_line_start_safe(const ScanArgs& a, int64_t lo, int64_t hi) {
+    if (lo <= a.vbeg) return a.vbeg;
+    for (int64_t v = (lo - 1) & ~(int64_t)15; v < hi; v += 16) {
+        const U128 q = direct_load(a, v);
+        const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+#pragma clang loop unroll(disable)
+        for (int k = 0; k < 16; ++k)
+            if (v + k >= lo - 1 && ((wd[k >> 2] >> (8 * (k & 3))) & 0xffu) == 0x0au) return v + k + 1;
+    }
+    return hi;
+}
+
 // kG16 (count and emit passes of small tables): the walk uses the 16-byte entries T.g16 (front.hpp) —
 // bytes to append and their count come ready-made (v_perm selector, count field), rows are byte offsets.
 // kSym (guided families): a transition's column is the symbol the backward pass left at the byte's position
@@ -814,7 +829,16 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
     const uint32_t o_of_lo = o;           // kMode 0: offset that corresponds to position lo
     uint32_t of = o;                      // everything below `of` has left the ring
     Stage S{};                            // kMode 2
-    if (kMode == 2) stage_begin(S, ring, a.out + out_base);
+    if (kMode == 2) {
+        if (a.lp_emit) {
+            // no count pass: this lane's lines are written where they were read
+            const int64_t fs = row == done_row ? hi : first_line_start_safe(a, lo, hi);
+            if (fs >= hi) row = done_row;
+            stage_begin(S, ring, a.out_v0 + fs);
+        } else {
+            stage_begin(S, ring, a.out + out_base);
+        }
+    }
     uint64_t cnt = 0;
     uint32_t seen = 0;
 
@@ -845,7 +869,7 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
                     const U128 g = *reinterpret_cast<const U128*>(T.g16 + row + ((uint32_t)kk[j] << 4));
                     const uint32_t n = g.y & 7u;
                     if (kMode == 1) { cnt += n; seen |= g.y; }
-                    else stage_append4(S, perm_b32(w >> (8 * j), g.z, g.w), n);
+                    else { stage_append4(S, perm_b32(w >> (8 * j), g.z, g.w), n); seen |= g.y; }
                     if (TRRE_WAVE_ANY(g.y & 128u)) {
                         if (g.y & 128u) {
                             // more than four bytes, or pooled text: from the 8-byte entry
@@ -1045,9 +1069,9 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
     }
     if (kMode == 0) direct_flush<true>(obase, ring, of, o);
     if (kMode == 2) stage_flush<true>(S);
-    if (kMode == 0 && (seen & kStrNul)) status |= kStNul;
+    if ((kMode == 0 || (kMode == 2 && a.lp_emit)) && (seen & (kG16 ? 8u : kStrNul))) status |= kStNul;
     if (kMode == 1 && (seen & (kG16 ? 64u : kStrOvf))) status |= kStOverflow;     // bounded fold: the launch is void
-    if (kMode != 2 && (seen & (kG16 ? 16u : kStrDiv))) status |= kStDiverge;      // guided tables: the reference's search never returns
+    if ((kMode != 2 || a.lp_emit) && (seen & (kG16 ? 16u : kStrDiv))) status |= kStDiverge;      // guided tables: the reference's search never returns
     L.count = cnt;
 }
 
@@ -1357,18 +1381,15 @@ struct WtMover {
 // symbols too (they read as the walkers see them: direct_load), up to the next multiple of 64.
 // =============================================================================================
 struct RevView {
-    const uint8_t* cls;      // [256]
-    const uint8_t* tab;      // [n_rev][n_cls]
-    uint32_t n_cls;
+    const uint8_t* tab;      // [n_rev][256] next state by raw byte (the class-compressed table expanded: one lookup per byte)
 };
 TRRE_HD uint32_t rev_step4(const RevView& T, uint32_t& r, uint32_t w) {
     // bytes 3, 2, 1, 0 of w in that order; returns their four symbols packed like w
-    const uint32_t k3 = T.cls[w >> 24], k2 = T.cls[(w >> 16) & 0xffu], k1 = T.cls[(w >> 8) & 0xffu], k0 = T.cls[w & 0xffu];
     uint32_t y;
-    r = T.tab[r * T.n_cls + k3]; y = r << 24;
-    r = T.tab[r * T.n_cls + k2]; y |= r << 16;
-    r = T.tab[r * T.n_cls + k1]; y |= r << 8;
-    r = T.tab[r * T.n_cls + k0]; y |= r;
+    r = T.tab[(r << 8) | (w >> 24)]; y = r << 24;
+    r = T.tab[(r << 8) | ((w >> 16) & 0xffu)]; y |= r << 16;
+    r = T.tab[(r << 8) | ((w >> 8) & 0xffu)]; y |= r << 8;
+    r = T.tab[(r << 8) | (w & 0xffu)]; y |= r;
     return y;
 }
 TRRE_HD void rev_sweep_lane(const ScanArgs& a, const RevView& T, int64_t lane, int64_t lane_bytes) {
@@ -1402,15 +1423,28 @@ TRRE_HD void rev_sweep_lane(const ScanArgs& a, const RevView& T, int64_t lane, i
         for (int64_t v = (e - 1) & ~(int64_t)15; v >= hi && e > hi; v -= 16) {
             const U128 q = direct_load(a, v);
             const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
-            for (int d = 3; d >= 0; --d)
-                for (int j = 3; j >= 0; --j) {
-                    const int64_t p = v + 4 * d + j;
-                    if (p < e) r = T.tab[r * T.n_cls + T.cls[(wd[d] >> (8 * j)) & 0xffu]];
-                }
+#pragma clang loop unroll(disable)
+            for (int k = 15; k >= 0; --k) {
+                const int64_t p = v + k;
+                if (p < e) r = T.tab[(r << 8) | ((wd[k >> 2] >> (8 * (k & 3))) & 0xffu)];
+            }
         }
     }
+    // the lane's own pieces, highest first; the piece below is requested before this one is walked
+    auto fetch = [&](int64_t v, U128& b0, U128& b1, U128& b2, U128& b3) {
+        const int64_t vv = v >= lo ? v : lo;              // (the fetch below the lane's first piece is not used)
+        const U128* src = reinterpret_cast<const U128*>(a.in_v0 + vv);
+        if (TRRE_WAVE_ANY(vv < a.vbeg || vv + 64 > a.vend - 1)) {
+            b0 = direct_load(a, vv); b1 = direct_load(a, vv + 16); b2 = direct_load(a, vv + 32); b3 = direct_load(a, vv + 48);
+        } else {
+            b0 = src[0]; b1 = src[1]; b2 = src[2]; b3 = src[3];
+        }
+    };
+    U128 b0, b1, b2, b3;
+    fetch(hi - 64, b0, b1, b2, b3);
     for (int64_t v = hi - 64; v >= lo; v -= 64) {
-        const U128 b0 = direct_load(a, v), b1 = direct_load(a, v + 16), b2 = direct_load(a, v + 32), b3 = direct_load(a, v + 48);
+        U128 n0, n1, n2, n3;
+        fetch(v - 64, n0, n1, n2, n3);
         U128 y0, y1, y2, y3;
         y3.w = rev_step4(T, r, b3.w); y3.z = rev_step4(T, r, b3.z); y3.y = rev_step4(T, r, b3.y); y3.x = rev_step4(T, r, b3.x);
         y2.w = rev_step4(T, r, b2.w); y2.z = rev_step4(T, r, b2.z); y2.y = rev_step4(T, r, b2.y); y2.x = rev_step4(T, r, b2.x);
@@ -1418,6 +1452,7 @@ TRRE_HD void rev_sweep_lane(const ScanArgs& a, const RevView& T, int64_t lane, i
         y0.w = rev_step4(T, r, b0.w); y0.z = rev_step4(T, r, b0.z); y0.y = rev_step4(T, r, b0.y); y0.x = rev_step4(T, r, b0.x);
         U128* dst = reinterpret_cast<U128*>(a.sym_v0 + v);
         dst[0] = y0; dst[1] = y1; dst[2] = y2; dst[3] = y3;
+        b0 = n0; b1 = n1; b2 = n2; b3 = n3;
     }
 }
 

@@ -378,7 +378,7 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_direct(ScanArgs a, in
     DirectLane L;
     uint32_t st = 0;
     uint64_t base = 0;
-    if (kMode == 2) {
+    if (kMode == 2 && !a.lp_emit) {
         // lane offsets: workgroup-wide exclusive scan of the counts from the count launch
         uint32_t* wpart = reinterpret_cast<uint32_t*>(smem + kLds - 64);
         const uint32_t mine = a.lane_counts[lane];
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_g16(ScanArgs a, int64
     DirectLane L;
     uint32_t st = 0;
     uint64_t base = 0;
-    if (kMode == 2) {
+    if (kMode == 2 && !a.lp_emit) {
         uint32_t* wpart = reinterpret_cast<uint32_t*>(tail);
         const uint32_t mine = a.lane_counts[lane];
         const uint32_t incl = wave_scan_incl(mine);
@@ -766,20 +766,15 @@ void launch_direct_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t
 
 // ---- backward pass of the guided families: one symbol per input byte (rev_sweep_lane) -------------------
 constexpr int kRevThreads = 256;
-constexpr int kRevTabLds = 65536;          // larger tables are read through L1/L2
 
-template <bool kLdsTab>
 __global__ __launch_bounds__(kRevThreads) void k_rev_sweep(ScanArgs a, int64_t lane_bytes) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];    // cls[256] | tab
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];    // tab[n_rev][256]: at most 64 KiB
     const RevBlobHeader& h = *reinterpret_cast<const RevBlobHeader*>(a.rblob);
-    for (int k = threadIdx.x; k < 256; k += kRevThreads) smem[k] = a.rblob[h.off_cls + k];
-    if (kLdsTab) {
-        const uint32_t* e = reinterpret_cast<const uint32_t*>(a.rblob + h.off_tab);
-        uint32_t* d = reinterpret_cast<uint32_t*>(smem + 256);
-        for (int k = threadIdx.x; k < (int)(h.tab_bytes / 4); k += kRevThreads) d[k] = e[k];
-    }
+    const U128* e = reinterpret_cast<const U128*>(a.rblob + h.off_wide);
+    U128* d = reinterpret_cast<U128*>(smem);
+    for (int k = threadIdx.x; k < (int)h.n_rev * 16; k += kRevThreads) d[k] = e[k];
     __syncthreads();
-    const RevView T{smem, kLdsTab ? smem + 256 : a.rblob + h.off_tab, h.n_cls};
+    const RevView T{smem};
     rev_sweep_lane(a, T, (int64_t)blockIdx.x * kRevThreads + threadIdx.x, lane_bytes);
 }
 void launch_rev_sweep(const ScanArgs& a, int tab_bytes, int64_t lane_bytes, void* stream) {
@@ -787,13 +782,8 @@ void launch_rev_sweep(const ScanArgs& a, int tab_bytes, int64_t lane_bytes, void
     const int64_t vtop = (a.vend + 63) & ~(int64_t)63;
     const int64_t n_lanes = (vtop + lane_bytes - 1) / lane_bytes;
     const dim3 grid((unsigned)((n_lanes + kRevThreads - 1) / kRevThreads));
-    if (tab_bytes <= kRevTabLds) {
-        const int lds = 256 + (tab_bytes + 15) / 16 * 16;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rev_sweep<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL((k_rev_sweep<true>), grid, dim3(kRevThreads), lds, s, a, lane_bytes);
-    } else {
-        hipLaunchKernelGGL((k_rev_sweep<false>), grid, dim3(kRevThreads), 256, s, a, lane_bytes);
-    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rev_sweep), hipFuncAttributeMaxDynamicSharedMemorySize, tab_bytes);
+    hipLaunchKernelGGL(k_rev_sweep, grid, dim3(kRevThreads), tab_bytes, s, a, lane_bytes);
 }
 
 int stream_chunk_bytes(int which) { return which == 0 ? GeoStream::CHUNK : GeoStreamGen::CHUNK; }

@@ -58,7 +58,9 @@ void build_gen16(StreamTables& t, const StreamPackInput& in) {
             const bool slow = n > 4;
             uint32_t* e = &v[((size_t)s * t.n_cls + k) * 4];
             e[0] = x.next * t.n_cls * 16u;
-            e[1] = (slow ? 128u : (uint32_t)n) | (x.eol ? 32u : 0u) | (x.ovf ? 64u : 0u) | (x.diverge ? 16u : 0u);
+            const bool silent = s == in.skip || s == in.done;
+            e[1] = (slow ? 128u : (uint32_t)n) | (x.eol ? 32u : 0u) | (x.ovf ? 64u : 0u) | (x.diverge ? 16u : 0u) |
+                   ((in.col_kind[k] == kColNul && !silent) ? 8u : 0u);
             uint32_t bytes = 0, sel = 0x0c0c0c0cu;                       // constant 0x00 everywhere
             if (!slow) {
                 sel = 0;
