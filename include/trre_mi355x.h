@@ -104,17 +104,32 @@ size_t trre_export_guided_tables(const trre_prog* p, int which, void* buf, size_
 int trre_scan_device(trre_prog* p, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, size_t* out_len,
                      void* stream);
 
-/* Split form for back-to-back launches: enqueue only (no host sync), then
- * collect status/size once.  One scan may be in flight per (prog, device). */
+/* Split form for back-to-back launches: enqueue only (no host sync), then collect status/size once.
+ * One scan may be in flight per (prog, device); enqueues repeated before the finish must be the same
+ * scan (same buffers, size and stream: a benchmark loop) — anything else returns TRRE_E_ARG.  The split
+ * form uses the calling thread's current device and is not serialised against other threads. */
 int trre_scan_enqueue(trre_prog* p, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, void* stream);
 int trre_scan_finish(trre_prog* p, size_t* out_len);
 
 /* Host buffers on `device`: what the scan branch of the reference's main() does with a FILE* (the
  * getline loop of trre_nft.c:776-790 / trre_dft.c:1272-1286).  The input goes through in 64 MiB chunks
- * cut at line ends, two in flight (pinned staging, H2D copy, scan, D2H copy overlap); records are
- * independent, so the chunks' outputs concatenate to exactly the output of one scan.  On
- * TRRE_E_CAPACITY *out_len is the size the whole output needs. */
+ * cut at line ends, three in flight on their own streams (staging copy, H2D, scan, D2H and the copy out
+ * overlap); records are independent, so the chunks' outputs concatenate to exactly the output of one scan.
+ * On TRRE_E_CAPACITY *out_len is the size the whole output needs (cap 0 / out NULL: a size query).  The
+ * caller's current device is left as it was. */
 int trre_scan_host(trre_prog* p, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_len, int device);
+
+/* The same over several GPUs of this node, line-sharded: the input is cut at line ends into one contiguous
+ * shard per selected device (trre_shard_bounds), each shard runs trre_scan_host on its device from a host
+ * thread of its own, the outputs are concatenated in shard order (an exclusive sum of the shard sizes on
+ * the host — the path has no exchange step, hence no collective).  device_mask: bit d selects visible
+ * device d; 0 selects all of them.
+ *
+ * Threading: a compiled program may be used from several host threads at once; calls that target the same
+ * device are serialised per (prog, device), calls on different devices run in parallel.  Compilation
+ * (trre_compile) is single-threaded host work and trre_last_error() is per thread. */
+int trre_scan_host_multi(trre_prog* p, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_len,
+                         uint32_t device_mask);
 
 /* Kernel timing for the last finished scan on this prog (HIP events recorded on
  * the launch stream around the scan kernels).  Enable first. */

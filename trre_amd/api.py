@@ -89,6 +89,7 @@ def lib():
         L.trre_scan_enqueue.argtypes = [vp, vp, sz, vp, sz, vp]
         L.trre_scan_finish.argtypes = [vp, ctypes.POINTER(sz)]
         L.trre_scan_host.argtypes = [vp, ctypes.c_char_p, sz, vp, sz, ctypes.POINTER(sz), ctypes.c_int]
+        L.trre_scan_host_multi.argtypes = [vp, ctypes.c_char_p, sz, vp, sz, ctypes.POINTER(sz), ctypes.c_uint32]
         L.trre_set_profiling.argtypes = [vp, ctypes.c_int]
         L.trre_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         L.trre_shard_bounds.argtypes = [ctypes.c_char_p, sz, ctypes.c_int, ctypes.POINTER(sz)]
@@ -189,15 +190,20 @@ class Program:
         _check(lib().trre_scan_finish(self._h, ctypes.byref(m)))
         return m.value
 
-    def scan(self, data, device=0):
-        """bytes in -> bytes out through trre_scan_host (H2D, GPU scan, D2H)."""
+    def scan(self, data, device=0, device_mask=None):
+        """bytes in -> bytes out through trre_scan_host (H2D, GPU scan, D2H); with device_mask (0 = every
+        visible GPU) through trre_scan_host_multi, line-sharded over the selected GPUs."""
         import numpy as np
         data = _bytes(data)
         cap = len(data) + 64
         for _ in range(2):
             out = np.empty(cap, dtype=np.uint8)              # (not zero-filled: the library writes what it reports)
             m = ctypes.c_size_t()
-            rc = lib().trre_scan_host(self._h, data, len(data), out.ctypes.data_as(ctypes.c_char_p), cap, ctypes.byref(m), device)
+            if device_mask is None:
+                rc = lib().trre_scan_host(self._h, data, len(data), out.ctypes.data_as(ctypes.c_char_p), cap, ctypes.byref(m), device)
+            else:
+                rc = lib().trre_scan_host_multi(self._h, data, len(data), out.ctypes.data_as(ctypes.c_char_p), cap, ctypes.byref(m),
+                                                device_mask)
             if rc == E_CAPACITY:
                 cap = m.value + 64
                 continue

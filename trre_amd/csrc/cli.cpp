@@ -5,10 +5,17 @@
 // errors go to stderr as "error: ..." with exit status 1.  Only scan mode runs
 // here — it is the GPU hot path; -m / -a / -d belong to the reference's CPU
 // binaries and are refused rather than emulated on the host.
+//
+// Like the reference's getline loop the input is streamed: it is read in blocks
+// of up to 256 MiB, every block is cut after its last '\n' (the rest is carried
+// into the next block), scanned line-sharded on all visible GPUs
+// (trre_scan_host_multi) and written out, so neither the input nor the output
+// has to fit in host memory.  TRRE_DEVICES=<mask> restricts the GPUs used.
 #include <unistd.h>
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../../include/trre_mi355x.h"
@@ -47,22 +54,43 @@ int main(int argc, char** argv) {
             return EXIT_FAILURE;
         }
     }
-    std::vector<uint8_t> in;
-    uint8_t buf[1 << 16];
-    size_t k;
-    while ((k = std::fread(buf, 1, sizeof buf, fp)) > 0) in.insert(in.end(), buf, buf + k);
-    std::vector<uint8_t> out(in.size() + 64);
-    size_t m = 0;
-    int rc = trre_scan_host(prog, in.data(), in.size(), out.data(), out.size(), &m, 0);
-    if (rc == TRRE_E_CAPACITY) {
-        out.resize(m + 64);
-        rc = trre_scan_host(prog, in.data(), in.size(), out.data(), out.size(), &m, 0);
+    const uint32_t mask = std::getenv("TRRE_DEVICES") ? (uint32_t)std::strtoul(std::getenv("TRRE_DEVICES"), nullptr, 0) : 0u;
+    const size_t block = std::getenv("TRRE_CLI_BLOCK") ? (size_t)std::strtoull(std::getenv("TRRE_CLI_BLOCK"), nullptr, 0) : (size_t)256 << 20;
+    std::vector<uint8_t> in, out;
+    size_t have = 0;                   // bytes of `in` that are filled (a carried partial line first)
+    bool eof = false;
+    while (!eof) {
+        if (in.size() < have + block) in.resize(have + block);
+        size_t k;
+        while (have < in.size() && (k = std::fread(in.data() + have, 1, in.size() - have, fp)) > 0) have += k;
+        eof = have < in.size();
+        // scan up to the last record end; the very last block goes as it is (a final record without '\n'
+        // loses its last byte, like every record: trre_nft.c:777)
+        size_t n = have;
+        if (!eof) {
+            while (n > 0 && in[n - 1] != '\n') --n;
+            if (n == 0) continue;      // one line longer than the block: keep reading
+        }
+        if (n) {
+            if (out.size() < n + 64) out.resize(n + 64);
+            size_t m = 0;
+            int rc = trre_scan_host_multi(prog, in.data(), n, out.data(), out.size(), &m, mask);
+            if (rc == TRRE_E_CAPACITY) {
+                out.resize(m + 64);
+                rc = trre_scan_host_multi(prog, in.data(), n, out.data(), out.size(), &m, mask);
+            }
+            if (rc != TRRE_OK) {
+                std::fprintf(stderr, "%s\n", trre_last_error());
+                return EXIT_FAILURE;
+            }
+            if (std::fwrite(out.data(), 1, m, stdout) != m) {
+                std::fprintf(stderr, "error: write failed\n");
+                return EXIT_FAILURE;
+            }
+        }
+        std::memmove(in.data(), in.data() + n, have - n);
+        have -= n;
     }
-    if (rc != TRRE_OK) {
-        std::fprintf(stderr, "%s\n", trre_last_error());
-        return EXIT_FAILURE;
-    }
-    std::fwrite(out.data(), 1, m, stdout);
     trre_free(prog);
     return 0;
 }

@@ -6,9 +6,15 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/trre_mi355x.h"
@@ -33,35 +39,8 @@ int fail(int code, const std::string& msg) {
             return fail(TRRE_E_DEVICE, std::string("hip: ") + hipGetErrorString(e_) + " at " #expr); \
     } while (0)
 
-struct DeviceState {
-    uint8_t* d_blob = nullptr;
-    uint8_t* d_sblob = nullptr;       // stream tables
-    uint8_t* d_gblob = nullptr;       // guided families: forward tables (stream form) ...
-    uint8_t* d_rblob = nullptr;       // ... and the backward DFA
-    uint8_t* d_sym = nullptr;         // guided families: one symbol per input byte
-    size_t sym_bytes = 0;
-    uint32_t* d_status = nullptr;     // [4]
-    uint32_t* h_status = nullptr;     // pinned mirror: [0] status bits; [2..3] total (u64)
-    uint32_t* d_lane_counts = nullptr;
-    uint64_t* d_chunk_total = nullptr;
-    uint64_t* d_chunk_base = nullptr;
-    int64_t ws_chunks = 0;
-    uint8_t* d_scratch = nullptr;
-    size_t scratch_bytes = 0;
-    uint32_t* d_redo = nullptr;       // window kernel redo list
-    int64_t redo_lanes = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // trre_scan_host: two sets of pinned staging + device buffers and two streams (chunks alternate)
-    struct HostSlot {
-        uint8_t *pin_in = nullptr, *pin_out = nullptr, *d_in = nullptr, *d_out = nullptr;
-        size_t in_cap = 0, out_cap = 0;
-        hipStream_t stream = nullptr;
-    } slot[2];
-};
-
 struct Pending {
     bool active = false;
-    int device = 0;
     int family = 0;
     const uint8_t* d_in = nullptr;
     uint8_t* d_out = nullptr;
@@ -71,6 +50,44 @@ struct Pending {
     bool timed = false;
     int count = 0;          // launches in the current batch
     const uint64_t* total_at = nullptr;   // general families: where the launch leaves its output size
+};
+
+// Everything ONE in-flight scan needs on a device besides the tables: status words, the workspaces of the
+// general families, scratch buffers, timing events.  trre_scan_device / enqueue+finish use the device's own
+// context; trre_scan_host keeps several chunks in flight, each with the context of its slot.
+struct ScanCtx {
+    uint32_t* d_status = nullptr;     // [4]
+    uint32_t* h_status = nullptr;     // pinned mirror: [0] status bits; [2..3] total (u64)
+    uint32_t* d_lane_counts = nullptr;
+    uint64_t* d_chunk_total = nullptr;
+    uint64_t* d_chunk_base = nullptr;
+    int64_t ws_chunks = 0;
+    uint8_t* d_scratch = nullptr;     // NFT tile kernels: mask scratch for lines longer than the LDS tile
+    size_t scratch_bytes = 0;
+    uint32_t* d_redo = nullptr;       // window kernel redo list
+    int64_t redo_lanes = 0;
+    uint8_t* d_sym = nullptr;         // guided families: one symbol per input byte
+    size_t sym_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    Pending pend;
+};
+
+constexpr int kHostSlots = 3;         // chunks in flight in trre_scan_host: staging in, on the device, staging out
+
+struct DeviceState {
+    std::mutex mu;                    // one scan call at a time per (prog, device): trre_scan_device, trre_scan_host
+    int device = 0;
+    uint8_t* d_blob = nullptr;
+    uint8_t* d_sblob = nullptr;       // stream tables
+    uint8_t* d_gblob = nullptr;       // guided families: forward tables (stream form) ...
+    uint8_t* d_rblob = nullptr;       // ... and the backward DFA
+    ScanCtx ctx;
+    struct HostSlot {
+        uint8_t *pin_in = nullptr, *pin_out = nullptr, *d_in = nullptr, *d_out = nullptr;
+        size_t in_cap = 0, out_cap = 0;
+        hipStream_t stream = nullptr;
+        ScanCtx ctx;
+    } slot[kHostSlots];
 };
 
 template <class T>
@@ -97,9 +114,9 @@ struct trre_prog {
     std::vector<uint8_t> gblob, rblob;
     int mask_bytes = 0;
     bool profiling = false;
-    float last_ms = -1.f;
-    std::map<int, DeviceState> dev;
-    Pending pend;
+    std::atomic<float> last_ms{-1.f};
+    std::mutex dev_mu;                                  // guards the map (not the states)
+    std::map<int, std::unique_ptr<DeviceState>> dev;
 };
 
 namespace {
@@ -251,63 +268,85 @@ bool family_allowed(const trre_prog& p, int fam) {
     return (p.nt.flags & kFlagLengthPreserving) != 0;
 }
 
+int ctx_init(ScanCtx& c) {
+    if (c.d_status) return TRRE_OK;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c.d_status), 16));
+    HIP_TRY(hipMemset(c.d_status, 0, 16));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c.h_status), 16, hipHostMallocDefault));
+    HIP_TRY(hipEventCreate(&c.ev0));
+    HIP_TRY(hipEventCreate(&c.ev1));
+    return TRRE_OK;
+}
+void ctx_free(ScanCtx& c) {
+    (void)hipFree(c.d_status);
+    if (c.h_status) (void)hipHostFree(c.h_status);
+    (void)hipFree(c.d_lane_counts);
+    (void)hipFree(c.d_chunk_total);
+    (void)hipFree(c.d_chunk_base);
+    (void)hipFree(c.d_scratch);
+    (void)hipFree(c.d_redo);
+    (void)hipFree(c.d_sym);
+    if (c.ev0) (void)hipEventDestroy(c.ev0);
+    if (c.ev1) (void)hipEventDestroy(c.ev1);
+    c = ScanCtx();
+}
+
+// the prog's state on device `dev` (tables uploaded on first use); the calling thread's current device must be `dev`
 int device_state(trre_prog* p, int dev, DeviceState** out) {
+    std::lock_guard<std::mutex> lock(p->dev_mu);
     auto it = p->dev.find(dev);
     if (it == p->dev.end()) {
-        DeviceState st;
-        if (!p->blob.empty()) {
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st.d_blob), p->blob.size()));
-            HIP_TRY(hipMemcpy(st.d_blob, p->blob.data(), p->blob.size(), hipMemcpyHostToDevice));
-        }
-        if (!p->sblob.empty()) {
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st.d_sblob), p->sblob.size()));
-            HIP_TRY(hipMemcpy(st.d_sblob, p->sblob.data(), p->sblob.size(), hipMemcpyHostToDevice));
-        }
-        if (!p->gblob.empty()) {
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st.d_gblob), p->gblob.size()));
-            HIP_TRY(hipMemcpy(st.d_gblob, p->gblob.data(), p->gblob.size(), hipMemcpyHostToDevice));
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st.d_rblob), p->rblob.size()));
-            HIP_TRY(hipMemcpy(st.d_rblob, p->rblob.data(), p->rblob.size(), hipMemcpyHostToDevice));
-        }
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st.d_status), 16));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&st.h_status), 16, hipHostMallocDefault));
-        HIP_TRY(hipEventCreate(&st.ev0));
-        HIP_TRY(hipEventCreate(&st.ev1));
-        it = p->dev.emplace(dev, st).first;
+        std::unique_ptr<DeviceState> st(new DeviceState);
+        st->device = dev;
+        auto upload = [&](const std::vector<uint8_t>& b, uint8_t** d) -> int {
+            if (b.empty()) return TRRE_OK;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(d), b.size()));
+            HIP_TRY(hipMemcpy(*d, b.data(), b.size(), hipMemcpyHostToDevice));
+            return TRRE_OK;
+        };
+        int rc = upload(p->blob, &st->d_blob);
+        if (!rc) rc = upload(p->sblob, &st->d_sblob);
+        if (!rc) rc = upload(p->gblob, &st->d_gblob);
+        if (!rc) rc = upload(p->rblob, &st->d_rblob);
+        if (!rc) rc = ctx_init(st->ctx);
+        if (rc) return rc;
+        it = p->dev.emplace(dev, std::move(st)).first;
     }
-    *out = &it->second;
+    *out = it->second.get();
     return TRRE_OK;
 }
 
-int ensure_workspace(trre_prog* p, DeviceState* st, int64_t n_chunks, int threads) {
+int ensure_workspace(ScanCtx* c, int64_t n_chunks, int threads) {
     n_chunks = n_chunks * ((threads + 255) / 256);      // sized in units of 256-lane chunks
-    if (n_chunks <= st->ws_chunks) return TRRE_OK;
-    if (st->d_lane_counts) { (void)hipFree(st->d_lane_counts); (void)hipFree(st->d_chunk_total); (void)hipFree(st->d_chunk_base); }
-    st->ws_chunks = 0;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st->d_lane_counts), (size_t)n_chunks * 256 * 4));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st->d_chunk_total), (size_t)n_chunks * 8));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st->d_chunk_base), (size_t)(n_chunks + 1) * 8));
-    st->ws_chunks = n_chunks;
+    if (n_chunks <= c->ws_chunks) return TRRE_OK;
+    if (c->d_lane_counts) { (void)hipFree(c->d_lane_counts); (void)hipFree(c->d_chunk_total); (void)hipFree(c->d_chunk_base); }
+    c->d_lane_counts = nullptr; c->d_chunk_total = nullptr; c->d_chunk_base = nullptr;
+    c->ws_chunks = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_lane_counts), (size_t)n_chunks * 256 * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_chunk_total), (size_t)n_chunks * 8));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_chunk_base), (size_t)(n_chunks + 1) * 8));
+    c->ws_chunks = n_chunks;
     return TRRE_OK;
 }
 
-int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, hipStream_t stream) {
+int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap,
+            hipStream_t stream) {
     using namespace trre;
-    Pending& pd = p->pend;
-    // back-to-back enqueues without a finish() in between form one batch: status
-    // bits accumulate and the timing events bracket the whole batch
+    Pending& pd = cx->pend;
+    // Back-to-back enqueues without a finish() in between form one batch: status bits accumulate, the
+    // timing events bracket the whole batch and finish() speaks for the last launch — so every launch of
+    // a batch must be the same scan (benchmark loops); anything else has to be finished first.
     const bool batch = pd.active && pd.launched;
+    if (pd.active && (pd.family != family || pd.d_in != d_in || pd.d_out != d_out || pd.n != n || pd.cap != cap || pd.stream != stream))
+        return fail(TRRE_E_ARG, "error: a different scan is still in flight on this device: call trre_scan_finish first");
     const int batch_count = batch ? pd.count : 0;
     pd = Pending();
     pd.active = true;
     pd.count = batch_count;
     pd.family = family;
     pd.d_in = d_in; pd.d_out = d_out; pd.n = n; pd.cap = cap; pd.stream = stream;
-    HIP_TRY(hipGetDevice(&pd.device));
     if (n == 0) return TRRE_OK;
-    DeviceState* st;
-    int rc = device_state(p, pd.device, &st);
-    if (rc) return rc;
+    int rc;
 
     const int64_t a = (int64_t)(reinterpret_cast<uintptr_t>(d_in) & 15u);
     ScanArgs args{};
@@ -318,11 +357,10 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
     args.vend = a + (int64_t)n;
     args.blob = is_stream(family) ? st->d_sblob : (is_guided(family) ? st->d_gblob : st->d_blob);
     const trre::StreamTables& stt = is_guided(family) ? p->gt.fwd : p->stt;       // the stream-form tables this launch walks
-    args.status = st->d_status;
+    args.status = cx->d_status;
     args.cap = cap;
     // a mask scratch left by an earlier, smaller scan must not be used: the kernel asks for one again
-    args.gscratch = st->scratch_bytes >= (n + 32) * (size_t)p->mask_bytes ? st->d_scratch : nullptr;
-    const bool streamish = is_stream(family) || is_guided(family);
+    args.gscratch = cx->scratch_bytes >= (n + 32) * (size_t)p->mask_bytes ? cx->d_scratch : nullptr;
     const int chunk = is_stream(family) ? stream_chunk_bytes(family == TRRE_KERNEL_STREAM_LP ? 0 : 1)
                                         : chunk_bytes(p->engine, p->mask_bytes);
     const int threads = is_stream(family) ? stream_block_threads(family == TRRE_KERNEL_STREAM_LP ? 0 : 1)
@@ -330,9 +368,9 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
     int64_t n_chunks = (args.vend + chunk - 1) / chunk;
     const bool ent_lds = stt.ok && stt.ent.size() * 8 <= (size_t)StreamEngine::kLdsEntBytes;
     // stream families have three implementations (TRRE_STREAM_IMPL, for A/B measurements):
-    //   0 LDS tile (k_stream_lp / k_stream_count+emit)      1 direct walker with an LDS output ring
+    //   0 LDS tile (k_stream_lp / k_stream_count+emit)      1 direct walkers only
     //   2 (default) positional-window kernel (wave-tiled I/O) for length-preserving tables that have
-    //     the window form, direct walker otherwise
+    //     the window form, direct walkers otherwise
     static const int stream_impl = getenv("TRRE_STREAM_IMPL") ? atoi(getenv("TRRE_STREAM_IMPL")) : 2;
     static const int64_t lane_bytes_env = getenv("TRRE_LANE_BYTES") ? atoll(getenv("TRRE_LANE_BYTES")) : 0;
     const bool window = is_stream(family) && stream_impl == 2 && family == TRRE_KERNEL_STREAM_LP && p->stt.lpw_ok &&
@@ -350,27 +388,27 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
 
     if (!is_gen(family) && cap < n) return TRRE_OK;   // finish() reports the capacity error
     if (is_gen(family)) {
-        rc = ensure_workspace(p, st, n_chunks, direct ? direct_block_threads() : threads);
+        rc = ensure_workspace(cx, n_chunks, direct ? direct_block_threads() : threads);
         if (rc) return rc;
-        args.lane_counts = st->d_lane_counts;
-        args.chunk_total = st->d_chunk_total;
-        args.chunk_base = st->d_chunk_base;
+        args.lane_counts = cx->d_lane_counts;
+        args.chunk_total = cx->d_chunk_total;
+        args.chunk_base = cx->d_chunk_base;
     }
     if (is_guided(family)) {
         // one symbol per input byte, written by the backward pass (whole 64-byte pieces) and read by the forward pass
         const size_t need = (size_t)((args.vend + 63) & ~(int64_t)63) + 256;
-        if (st->sym_bytes < need) {
-            if (st->d_sym) (void)hipFree(st->d_sym);
-            st->d_sym = nullptr; st->sym_bytes = 0;
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st->d_sym), need));
-            st->sym_bytes = need;
+        if (cx->sym_bytes < need) {
+            if (cx->d_sym) (void)hipFree(cx->d_sym);
+            cx->d_sym = nullptr; cx->sym_bytes = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&cx->d_sym), need));
+            cx->sym_bytes = need;
         }
         args.rblob = st->d_rblob;
-        args.sym_v0 = st->d_sym;
+        args.sym_v0 = cx->d_sym;
     }
     if (!batch) {
-        HIP_TRY(hipMemsetAsync(st->d_status, 0, 16, stream));
-        if (p->profiling) HIP_TRY(hipEventRecord(st->ev0, stream));
+        HIP_TRY(hipMemsetAsync(cx->d_status, 0, 16, stream));
+        if (p->profiling) HIP_TRY(hipEventRecord(cx->ev0, stream));
     }
     pd.timed = p->profiling;
     if (family == TRRE_KERNEL_BYTEMAP) {
@@ -379,14 +417,14 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
         launch_tile_kernel(0, p->engine, p->mask_bytes, args, n_chunks, stream);
     } else if (window) {
         const int64_t n_lanes = (args.vend + lane_bytes - 1) / lane_bytes;
-        if (st->redo_lanes < n_lanes) {
-            if (st->d_redo) (void)hipFree(st->d_redo);
-            st->d_redo = nullptr; st->redo_lanes = 0;
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st->d_redo), (size_t)(n_lanes + 1) * 4));
-            st->redo_lanes = n_lanes;
+        if (cx->redo_lanes < n_lanes) {
+            if (cx->d_redo) (void)hipFree(cx->d_redo);
+            cx->d_redo = nullptr; cx->redo_lanes = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&cx->d_redo), (size_t)(n_lanes + 1) * 4));
+            cx->redo_lanes = n_lanes;
         }
-        HIP_TRY(hipMemsetAsync(st->d_redo, 0, 4, stream));
-        args.redo = st->d_redo;
+        HIP_TRY(hipMemsetAsync(cx->d_redo, 0, 4, stream));
+        args.redo = cx->d_redo;
         launch_lpw_kernel((int)(p->stt.lpw.size() * 4), p->stt.lpw_delay > 3, direct_ent_lds, args, lane_bytes, stream);
     } else if (direct && !is_gen(family)) {
         // length-preserving without a window form: the emit pass alone, every lane writing its lines where it read
@@ -395,7 +433,9 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
         static const bool no_g16 = getenv("TRRE_NO_G16") != nullptr;
         const int g16 = stt.g16_ok && !no_g16 ? (int)(stt.g16.size() * 4) : 0;
         if (is_guided(family)) launch_rev_sweep(args, (int)p->gt.n_rev * 256, lane_bytes, stream);
-        if (lp_ring) {
+        static const bool rev_only = getenv("TRRE_REV_DBG") != nullptr;       // experiments on the backward pass alone (its output may be void)
+        if (is_guided(family) && rev_only) {
+        } else if (lp_ring) {
             launch_direct_kernel(0, direct_ent_lds, args, lane_bytes, n_chunks, stream, 0, is_guided(family));
         } else {
             args.lp_emit = 1;
@@ -406,21 +446,21 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
         const int g16 = stt.g16_ok && !no_g16 ? (int)(stt.g16.size() * 4) : 0;
         if (is_guided(family)) launch_rev_sweep(args, (int)p->gt.n_rev * 256, lane_bytes, stream);
         launch_direct_kernel(1, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, is_guided(family));
-        launch_chunk_scan(st->d_chunk_total, st->d_chunk_base, n_chunks, stream);
+        launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);
         launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, is_guided(family));
-        pd.total_at = st->d_chunk_base + n_chunks;
+        pd.total_at = cx->d_chunk_base + n_chunks;
     } else if (family == TRRE_KERNEL_STREAM_LP) {
         launch_stream_kernel(0, ent_lds, args, n_chunks, stream);
     } else if (family == TRRE_KERNEL_STREAM_GEN) {
         launch_stream_kernel(1, ent_lds, args, n_chunks, stream);
-        launch_chunk_scan(st->d_chunk_total, st->d_chunk_base, n_chunks, stream);
+        launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);
         launch_stream_kernel(2, ent_lds, args, n_chunks, stream);
-        pd.total_at = st->d_chunk_base + n_chunks;
+        pd.total_at = cx->d_chunk_base + n_chunks;
     } else {
         launch_tile_kernel(1, p->engine, p->mask_bytes, args, n_chunks, stream);
-        launch_chunk_scan(st->d_chunk_total, st->d_chunk_base, n_chunks, stream);
+        launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);
         launch_tile_kernel(2, p->engine, p->mask_bytes, args, n_chunks, stream);
-        pd.total_at = st->d_chunk_base + n_chunks;
+        pd.total_at = cx->d_chunk_base + n_chunks;
     }
     HIP_TRY(hipGetLastError());
     // (the status word, the output size and the closing timing event are fetched by finish(): nothing
@@ -430,65 +470,58 @@ int enqueue(trre_prog* p, int family, const uint8_t* d_in, size_t n, uint8_t* d_
     return TRRE_OK;
 }
 
-int finish(trre_prog* p, size_t* out_len) {
+int finish(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
     using namespace trre;
-    Pending& pd = p->pend;
+    Pending& pd = cx->pend;
     if (!pd.active) return fail(TRRE_E_ARG, "error: no scan in flight");
-    pd.active = false;
-    if (pd.n == 0) { if (out_len) *out_len = 0; return TRRE_OK; }
-    if (!pd.launched) {                                  // length-preserving family, buffer too small
-        if (out_len) *out_len = pd.n;
+    const Pending was = pd;
+    pd = Pending();
+    if (was.n == 0) { if (out_len) *out_len = 0; return TRRE_OK; }
+    if (!was.launched) {                                 // length-preserving family, buffer too small
+        if (out_len) *out_len = was.n;
         return fail(TRRE_E_CAPACITY, "error: output buffer too small");
     }
-    DeviceState* st = &p->dev[pd.device];
-    if (pd.timed) HIP_TRY(hipEventRecord(st->ev1, pd.stream));
-    HIP_TRY(hipMemcpyAsync(st->h_status, st->d_status, 4, hipMemcpyDeviceToHost, pd.stream));
-    if (pd.total_at) HIP_TRY(hipMemcpyAsync(st->h_status + 2, pd.total_at, 8, hipMemcpyDeviceToHost, pd.stream));
-    HIP_TRY(hipStreamSynchronize(pd.stream));
-    if (pd.timed) {
+    if (was.timed) HIP_TRY(hipEventRecord(cx->ev1, was.stream));
+    HIP_TRY(hipMemcpyAsync(cx->h_status, cx->d_status, 4, hipMemcpyDeviceToHost, was.stream));
+    if (was.total_at) HIP_TRY(hipMemcpyAsync(cx->h_status + 2, was.total_at, 8, hipMemcpyDeviceToHost, was.stream));
+    HIP_TRY(hipStreamSynchronize(was.stream));
+    if (was.timed) {
         float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, st->ev0, st->ev1));
-        p->last_ms = ms / (float)(pd.count > 0 ? pd.count : 1);   // average per launch of the batch
+        HIP_TRY(hipEventElapsedTime(&ms, cx->ev0, cx->ev1));
+        p->last_ms = ms / (float)(was.count > 0 ? was.count : 1);   // average per launch of the batch
     }
-    const uint32_t status = st->h_status[0];
+    const uint32_t status = cx->h_status[0];
+    auto again = [&](int family) -> int {
+        int rc = enqueue(p, st, cx, family, was.d_in, was.n, was.d_out, was.cap, was.stream);
+        if (rc) return rc;
+        return finish(p, st, cx, out_len);
+    };
     if (status & kStDiverge)
         return fail(TRRE_E_DIVERGES, "error: stack max capacity reached (the reference's search does not terminate on this input)");
     if (status & kStNeedScratch) {
         // a line longer than the LDS tile met the non-deterministic engine: give it
         // a mask scratch (one mask per input byte) and run again
-        const size_t need = (pd.n + 32) * (size_t)p->mask_bytes;
-        if (st->scratch_bytes < need) {
-            if (st->d_scratch) (void)hipFree(st->d_scratch);
-            st->d_scratch = nullptr; st->scratch_bytes = 0;
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st->d_scratch), need));
-            st->scratch_bytes = need;
+        const size_t need = (was.n + 32) * (size_t)p->mask_bytes;
+        if (cx->scratch_bytes < need) {
+            if (cx->d_scratch) (void)hipFree(cx->d_scratch);
+            cx->d_scratch = nullptr; cx->scratch_bytes = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&cx->d_scratch), need));
+            cx->scratch_bytes = need;
         }
-        int rc = enqueue(p, pd.family, pd.d_in, pd.n, pd.d_out, pd.cap, pd.stream);
-        if (rc) return rc;
-        return finish(p, out_len);
+        return again(was.family);
     }
-    if (is_stream(pd.family) && (status & kStOverflow)) {
-        // an undecided attempt outgrew the stream table (bounded fold): the guided (or the tile) kernels take the buffer
-        int rc = enqueue(p, general_family(*p, false), pd.d_in, pd.n, pd.d_out, pd.cap, pd.stream);
-        if (rc) return rc;
-        return finish(p, out_len);
-    }
-    if (!is_gen(pd.family)) {
-        if (status & kStNul) {
-            // a NUL cuts its line short, so output positions no longer equal input
-            // positions: redo with the general family
-            const int gen = general_family(*p, !is_guided(pd.family));
-            int rc = enqueue(p, gen, pd.d_in, pd.n, pd.d_out, pd.cap, pd.stream);
-            if (rc) return rc;
-            return finish(p, out_len);
-        }
-        if (out_len) *out_len = pd.n;
+    // an undecided attempt outgrew the stream table (bounded fold): the guided (or the tile) kernels take the buffer
+    if (is_stream(was.family) && (status & kStOverflow)) return again(general_family(*p, false));
+    if (!is_gen(was.family)) {
+        // a NUL cuts its line short, so output positions no longer equal input positions: redo with a general family
+        if (status & kStNul) return again(general_family(*p, !is_guided(was.family)));
+        if (out_len) *out_len = was.n;
         return TRRE_OK;
     }
     uint64_t total;
-    std::memcpy(&total, st->h_status + 2, 8);
+    std::memcpy(&total, cx->h_status + 2, 8);
     if (out_len) *out_len = (size_t)total;
-    if ((status & kStCapacity) || total > pd.cap) return fail(TRRE_E_CAPACITY, "error: output buffer too small");
+    if ((status & kStCapacity) || total > was.cap) return fail(TRRE_E_CAPACITY, "error: output buffer too small");
     return TRRE_OK;
 }
 
@@ -555,30 +588,26 @@ int trre_compile_bytes(const uint8_t* pattern, size_t len, int engine, trre_prog
 
 void trre_free(trre_prog* p) {
     if (!p) return;
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
     for (auto& kv : p->dev) {
-        DeviceState& st = kv.second;
+        DeviceState& st = *kv.second;
+        (void)hipSetDevice(st.device);
         (void)hipFree(st.d_blob);
         (void)hipFree(st.d_sblob);
         (void)hipFree(st.d_gblob);
         (void)hipFree(st.d_rblob);
-        (void)hipFree(st.d_sym);
-        (void)hipFree(st.d_status);
-        (void)hipHostFree(st.h_status);
-        (void)hipFree(st.d_lane_counts);
-        (void)hipFree(st.d_chunk_total);
-        (void)hipFree(st.d_chunk_base);
-        (void)hipFree(st.d_scratch);
-        (void)hipFree(st.d_redo);
-        if (st.ev0) (void)hipEventDestroy(st.ev0);
-        if (st.ev1) (void)hipEventDestroy(st.ev1);
+        ctx_free(st.ctx);
         for (auto& hs : st.slot) {
             if (hs.pin_in) (void)hipHostFree(hs.pin_in);
             if (hs.pin_out) (void)hipHostFree(hs.pin_out);
             (void)hipFree(hs.d_in);
             (void)hipFree(hs.d_out);
             if (hs.stream) (void)hipStreamDestroy(hs.stream);
+            ctx_free(hs.ctx);
         }
     }
+    if (have_cur) (void)hipSetDevice(cur);
     delete p;
 }
 
@@ -635,22 +664,41 @@ size_t trre_export_guided_tables(const trre_prog* p, int which, void* buf, size_
     return b.size();
 }
 
+// the prog's state on the calling thread's current device
+static int current_state(trre_prog* p, DeviceState** st) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    return device_state(p, dev, st);
+}
+
 int trre_scan_enqueue(trre_prog* p, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, void* stream) {
     if (!p || (n && (!d_in || !d_out))) return fail(TRRE_E_ARG, "error: null argument");
+    DeviceState* st;
+    int rc = current_state(p, &st);
+    if (rc) return rc;
     const int fam = p->forced_family ? p->forced_family : auto_family(*p);
-    return enqueue(p, fam, d_in, n, d_out, cap, static_cast<hipStream_t>(stream));
+    return enqueue(p, st, &st->ctx, fam, d_in, n, d_out, cap, static_cast<hipStream_t>(stream));
 }
 
 int trre_scan_finish(trre_prog* p, size_t* out_len) {
     if (!p) return fail(TRRE_E_ARG, "error: null argument");
-    return finish(p, out_len);
+    DeviceState* st;
+    int rc = current_state(p, &st);
+    if (rc) return rc;
+    return finish(p, st, &st->ctx, out_len);
 }
 
 int trre_scan_device(trre_prog* p, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, size_t* out_len,
                      void* stream) {
-    int rc = trre_scan_enqueue(p, d_in, n, d_out, cap, stream);
+    if (!p || (n && (!d_in || !d_out))) return fail(TRRE_E_ARG, "error: null argument");
+    DeviceState* st;
+    int rc = current_state(p, &st);
     if (rc) return rc;
-    return trre_scan_finish(p, out_len);
+    std::lock_guard<std::mutex> lock(st->mu);        // one scan call at a time per (prog, device); other devices run in parallel
+    const int fam = p->forced_family ? p->forced_family : auto_family(*p);
+    rc = enqueue(p, st, &st->ctx, fam, d_in, n, d_out, cap, static_cast<hipStream_t>(stream));
+    if (rc) { st->ctx.pend = Pending(); return rc; }
+    return finish(p, st, &st->ctx, out_len);
 }
 
 namespace {
@@ -663,83 +711,263 @@ int slot_reserve(DeviceState::HostSlot& hs, bool input, size_t bytes) {
     if (pin) (void)hipHostFree(pin);
     if (dev) (void)hipFree(dev);
     pin = nullptr; dev = nullptr; have = 0;
+    bytes += bytes / 8;                                   // (head room: the next chunk is rarely the same size)
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&pin), bytes + 64, hipHostMallocDefault));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), bytes + 64));
     have = bytes;
     return TRRE_OK;
 }
 constexpr size_t kHostChunk = (size_t)64 << 20;
-}  // namespace
 
-// Host buffers: the input goes through in chunks cut at line ends (lines are independent, so the chunks'
-// outputs simply concatenate), two chunks in flight: while one is on the device the next is staged into
-// pinned memory and the previous one's output is copied out.
-int trre_scan_host(trre_prog* p, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_len, int device) {
-    if (!p || (n && !in) || (cap && !out)) return fail(TRRE_E_ARG, "error: null argument");
-    if (out_len) *out_len = 0;
-    if (n == 0) return TRRE_OK;
-    HIP_TRY(hipSetDevice(device));
-    DeviceState* st;
-    int rc = device_state(p, device, &st);
-    if (rc) return rc;
-    for (auto& hs : st->slot)
+// Staging copies between the caller's pageable buffers and pinned memory are spread over a few threads:
+// one thread moves ~10 GB/s, a PCIe 5 x16 link ~55 GB/s each way.
+class CopyPool {
+public:
+    static CopyPool& get() { static CopyPool pool; return pool; }
+    // copies n bytes with up to `ways` workers; returns when done
+    void copy(void* dst, const void* src, size_t n, int ways) {
+        if (n < ((size_t)4 << 20) || ways <= 1) { std::memcpy(dst, src, n); return; }
+        const size_t piece = (n / (size_t)ways + 4095) & ~(size_t)4095;
+        Job job;
+        std::unique_lock<std::mutex> lk(mu_);
+        for (size_t off = 0; off < n; off += piece) {
+            queue_.push_back(Piece{&job, static_cast<uint8_t*>(dst) + off, static_cast<const uint8_t*>(src) + off, std::min(piece, n - off)});
+            ++job.left;
+        }
+        cv_.notify_all();
+        done_.wait(lk, [&] { return job.left == 0; });
+    }
+
+private:
+    struct Job { int left = 0; };
+    struct Piece { Job* job; uint8_t* dst; const uint8_t* src; size_t n; };
+    CopyPool() {
+        unsigned hw = std::thread::hardware_concurrency();
+        const unsigned n = hw >= 32 ? 16 : (hw >= 8 ? hw / 2 : 2);
+        for (unsigned i = 0; i < n; ++i) workers_.emplace_back([this] { run(); });
+    }
+    ~CopyPool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& w : workers_) w.join();
+    }
+    void run() {
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            cv_.wait(lk, [&] { return stop_ || !queue_.empty(); });
+            if (stop_) return;
+            Piece pc = queue_.back();
+            queue_.pop_back();
+            lk.unlock();
+            std::memcpy(pc.dst, pc.src, pc.n);
+            lk.lock();
+            if (--pc.job->left == 0) done_.notify_all();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    std::vector<Piece> queue_;
+    std::vector<std::thread> workers_;
+    bool stop_ = false;
+};
+constexpr int kCopyWays = 8;
+
+// Host buffers on one device.  The input goes through in chunks cut at line ends (lines are independent, so
+// the chunks' outputs simply concatenate), kHostSlots chunks in flight, each on its slot's stream: while one
+// chunk is scanned the next is staged into pinned memory and copied up, and the previous one's output comes
+// down and is copied out.  `out` may be null when cap == 0 (size query).
+int scan_host_on(trre_prog* p, DeviceState* st, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_len) {
+    for (auto& hs : st->slot) {
         if (!hs.stream) HIP_TRY(hipStreamCreateWithFlags(&hs.stream, hipStreamNonBlocking));
+        int rc = ctx_init(hs.ctx);
+        if (rc) return rc;
+    }
     const int fam = p->forced_family ? p->forced_family : auto_family(*p);
-    const bool fixed_len = !is_gen(fam);              // output size == input size (unless a NUL forces the general family)
+    const bool fixed_len = !is_gen(fam);              // output size == input size (unless a NUL forces a general family)
 
+    struct Chunk { size_t off = 0, len = 0, out_at = 0, m = 0; bool submitted = false, copying = false; };
+    Chunk ch[kHostSlots];
     size_t off = 0, total = 0;                        // input consumed, output produced (or needed)
     bool overflow = false;                            // the caller's buffer is too small: keep counting only
-    struct Out { size_t at = 0, len = 0; bool live = false; } pend[2];
-    auto drain = [&](int b) -> int {                  // chunk output: pinned -> caller, once its D2H has finished
-        if (!pend[b].live) return TRRE_OK;
-        HIP_TRY(hipStreamSynchronize(st->slot[b].stream));
-        std::memcpy(out + pend[b].at, st->slot[b].pin_out, pend[b].len);
-        pend[b].live = false;
-        return TRRE_OK;
+    int rc = TRRE_OK;
+    auto abandon = [&](int code) -> int {             // leave nothing queued behind an error
+        for (auto& hs : st->slot) { (void)hipStreamSynchronize(hs.stream); hs.ctx.pend = Pending(); }
+        return code;
     };
-    for (int k = 0; off < n; ++k) {
-        const int b = k & 1;
+    // stage chunk k in and queue its upload + scan
+    auto submit = [&](int b, size_t at, size_t len) -> int {
         DeviceState::HostSlot& hs = st->slot[b];
-        // this chunk: up to kHostChunk bytes, extended to the end of its last line
-        size_t len = n - off;
-        if (len > kHostChunk) {
-            const void* nl = std::memchr(in + off + kHostChunk - 1, '\n', n - off - (kHostChunk - 1));
-            len = nl ? (size_t)(static_cast<const uint8_t*>(nl) - (in + off)) + 1 : n - off;
-        }
-        rc = drain(b);                                // the slot's previous output must have left its staging buffer
-        if (rc) return rc;
-        rc = slot_reserve(hs, true, len);
-        if (rc) return rc;
-        std::memcpy(hs.pin_in, in + off, len);
+        int r = slot_reserve(hs, true, len);
+        if (r) return r;
+        r = slot_reserve(hs, false, fixed_len ? len : len + len / 2 + 4096);
+        if (r) return r;
+        CopyPool::get().copy(hs.pin_in, in + at, len, kCopyWays);
         HIP_TRY(hipMemcpyAsync(hs.d_in, hs.pin_in, len, hipMemcpyHostToDevice, hs.stream));
-        size_t want = fixed_len ? len : len + len / 2 + 4096;
+        ch[b] = Chunk();
+        ch[b].off = at; ch[b].len = len; ch[b].submitted = true;
+        return enqueue(p, st, &hs.ctx, fam, hs.d_in, len, hs.d_out, hs.out_cap, hs.stream);
+    };
+    // wait for chunk b's scan, learn its output size, queue the download
+    auto complete = [&](int b) -> int {
+        DeviceState::HostSlot& hs = st->slot[b];
         size_t m = 0;
-        for (;;) {
-            rc = slot_reserve(hs, false, want);
-            if (rc) return rc;
-            rc = enqueue(p, fam, hs.d_in, len, hs.d_out, hs.out_cap, hs.stream);
-            if (!rc) rc = finish(p, &m);
-            if (rc != TRRE_E_CAPACITY) break;
-            want = m + 4096;                          // the general families report the size they need
+        int r = finish(p, st, &hs.ctx, &m);
+        while (r == TRRE_E_CAPACITY) {                // the general families report the size they need
+            r = slot_reserve(hs, false, m + 4096);
+            if (r) return r;
+            r = enqueue(p, st, &hs.ctx, fam, hs.d_in, ch[b].len, hs.d_out, hs.out_cap, hs.stream);
+            if (!r) r = finish(p, st, &hs.ctx, &m);
         }
-        if (rc) return rc;
+        if (r) return r;
+        ch[b].m = m;
+        ch[b].out_at = total;
         if (!overflow && total + m > cap) overflow = true;
         if (!overflow && m) {
             HIP_TRY(hipMemcpyAsync(hs.pin_out, hs.d_out, m, hipMemcpyDeviceToHost, hs.stream));
-            pend[b].at = total; pend[b].len = m; pend[b].live = true;
+            ch[b].copying = true;
         }
         total += m;
-        off += len;
-        if (!overflow) {                              // meanwhile: the other slot's output
-            rc = drain(b ^ 1);
-            if (rc) return rc;
+        ch[b].submitted = false;
+        return TRRE_OK;
+    };
+    auto drain = [&](int b) -> int {                  // chunk output: pinned -> caller, once its download has finished
+        if (!ch[b].copying) return TRRE_OK;
+        HIP_TRY(hipStreamSynchronize(st->slot[b].stream));
+        CopyPool::get().copy(out + ch[b].out_at, st->slot[b].pin_out, ch[b].m, kCopyWays);
+        ch[b].copying = false;
+        return TRRE_OK;
+    };
+    // software pipeline: submit(k) | complete(k-1) | drain(k-2)
+    for (int64_t k = 0;; ++k) {
+        const bool more = off < n;
+        if (more) {
+            const int b = (int)(k % kHostSlots);
+            rc = drain(b);                            // the slot's previous output must have left its staging buffer
+            if (rc) return abandon(rc);
+            size_t len = n - off;                     // this chunk: up to kHostChunk bytes, extended to the end of its last line
+            if (len > kHostChunk) {
+                const void* nl = std::memchr(in + off + kHostChunk - 1, '\n', n - off - (kHostChunk - 1));
+                len = nl ? (size_t)(static_cast<const uint8_t*>(nl) - (in + off)) + 1 : n - off;
+            }
+            rc = submit(b, off, len);
+            if (rc) return abandon(rc);
+            off += len;
+        }
+        if (k >= 1) {
+            const int b1 = (int)((k - 1) % kHostSlots);
+            if (ch[b1].submitted) { rc = complete(b1); if (rc) return abandon(rc); }
+        }
+        if (k >= 2) { rc = drain((int)((k - 2) % kHostSlots)); if (rc) return abandon(rc); }
+        if (!more) {
+            bool busy = false;
+            for (const Chunk& c : ch) busy = busy || c.submitted || c.copying;
+            if (!busy) break;
         }
     }
     if (out_len) *out_len = total;
     if (overflow) return fail(TRRE_E_CAPACITY, "error: output buffer too small");
-    rc = drain(0);
-    if (!rc) rc = drain(1);
-    return rc;
+    return TRRE_OK;
+}
+
+// RAII: make `device` current for the calling thread, restore the previous one on return
+struct DeviceScope {
+    int prev = -1;
+    hipError_t err;
+    explicit DeviceScope(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess) err = hipSetDevice(device);
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+}  // namespace
+
+int trre_scan_host(trre_prog* p, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_len, int device) {
+    if (!p || (n && !in) || (cap && !out)) return fail(TRRE_E_ARG, "error: null argument");
+    if (out_len) *out_len = 0;
+    if (n == 0) return TRRE_OK;
+    DeviceScope scope(device);
+    HIP_TRY(scope.err);
+    DeviceState* st;
+    int rc = device_state(p, device, &st);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(st->mu);
+    return scan_host_on(p, st, in, n, out, cap, out_len);
+}
+
+// Host buffers, line-sharded over several GPUs of this node: the reference's scan has no exchange step
+// (a line's output depends on that line and the read-only program, trre_nft.c:776-790), so the input is
+// cut at line ends into one contiguous shard per device (trre_shard_bounds), every device scans its shard on
+// its own host thread and streams, and the outputs are concatenated in shard order — an exclusive sum of G
+// sizes on the host, no collective.
+int trre_scan_host_multi(trre_prog* p, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_len, uint32_t device_mask) {
+    if (!p || (n && !in) || (cap && !out)) return fail(TRRE_E_ARG, "error: null argument");
+    if (out_len) *out_len = 0;
+    int n_dev = 0;
+    HIP_TRY(hipGetDeviceCount(&n_dev));
+    std::vector<int> devs;
+    for (int d = 0; d < n_dev && d < 32; ++d)
+        if (device_mask == 0 || (device_mask >> d & 1u)) devs.push_back(d);
+    if (devs.empty()) return fail(TRRE_E_ARG, "error: device_mask selects no visible device");
+    if (n == 0) return TRRE_OK;
+    // TRRE_SHARDS_PER_DEVICE=k (tests): k shards per selected device, so that the sharding, the per-shard threads and
+    // the reassembly run on a box with a single GPU (shards on one device take turns: calls are serialised per device)
+    static const int per_dev = getenv("TRRE_SHARDS_PER_DEVICE") ? atoi(getenv("TRRE_SHARDS_PER_DEVICE")) : 1;
+    if (per_dev > 1) {
+        std::vector<int> rep;
+        for (int d : devs) rep.insert(rep.end(), (size_t)per_dev, d);
+        devs.swap(rep);
+    }
+    const int G = (int)devs.size();
+    if (G == 1) return trre_scan_host(p, in, n, out, cap, out_len, devs[0]);
+    std::vector<size_t> bounds(G + 1);
+    int rc = trre_shard_bounds(in, n, G, bounds.data());
+    if (rc) return rc;
+    const int fam = p->forced_family ? p->forced_family : auto_family(*p);
+    const bool fixed_len = !is_gen(fam);
+    // A length-preserving program writes every shard straight to its place (output offset == input offset);
+    // otherwise a shard's offset is known only when the shards before it are done: each goes to a buffer of its
+    // own and is moved into place afterwards.
+    struct Shard { int rc = TRRE_OK; size_t m = 0; std::string err; std::vector<uint8_t> buf; bool own = false; };
+    std::vector<Shard> sh(G);
+    std::vector<std::thread> th;
+    for (int g = 0; g < G; ++g) {
+        th.emplace_back([&, g] {
+            Shard& s = sh[g];
+            const size_t lo = bounds[g], len = bounds[g + 1] - lo;
+            if (len == 0) return;
+            const bool direct = fixed_len && lo + len <= cap;
+            uint8_t* dst = nullptr;
+            size_t room = 0;
+            if (direct) { dst = out + lo; room = len; }
+            else if (!fixed_len || cap >= n) { s.buf.resize(len + len / 2 + 4096); s.own = true; dst = s.buf.data(); room = s.buf.size(); }
+            s.rc = trre_scan_host(p, in + lo, len, dst, room, &s.m, devs[g]);
+            if (s.rc == TRRE_E_CAPACITY && s.own) {          // the shard needs s.m bytes
+                s.buf.resize(s.m + 64);
+                s.rc = trre_scan_host(p, in + lo, len, s.buf.data(), s.buf.size(), &s.m, devs[g]);
+            } else if (s.rc == TRRE_E_CAPACITY && direct) {  // a NUL made it a general scan with another size: cannot happen
+                s.rc = TRRE_E_CAPACITY;                      // (a NUL only shortens), kept for symmetry
+            }
+            if (s.rc && s.rc != TRRE_E_CAPACITY) s.err = trre_last_error();
+        });
+    }
+    for (auto& t : th) t.join();
+    size_t total = 0;
+    bool short_cap = false;
+    for (int g = 0; g < G; ++g) {
+        if (sh[g].rc && sh[g].rc != TRRE_E_CAPACITY) return fail(sh[g].rc, sh[g].err);
+        if (sh[g].rc == TRRE_E_CAPACITY) short_cap = true;
+        total += sh[g].m;
+    }
+    if (out_len) *out_len = total;
+    if (short_cap || total > cap) return fail(TRRE_E_CAPACITY, "error: output buffer too small");
+    // move the shards into place, in order (a direct shard that came out shorter — NUL bytes — moves down)
+    size_t at = 0;
+    for (int g = 0; g < G; ++g) {
+        const uint8_t* src = sh[g].own ? sh[g].buf.data() : out + bounds[g];
+        if (sh[g].m && src != out + at) std::memmove(out + at, src, sh[g].m);
+        at += sh[g].m;
+    }
+    return TRRE_OK;
 }
 
 int trre_set_profiling(trre_prog* p, int on) {
@@ -750,8 +978,8 @@ int trre_set_profiling(trre_prog* p, int on) {
 
 int trre_last_kernel_ms(trre_prog* p, float* ms) {
     if (!p || !ms) return fail(TRRE_E_ARG, "error: null argument");
-    *ms = p->last_ms;
-    return p->last_ms < 0 ? TRRE_E_ARG : TRRE_OK;
+    *ms = p->last_ms.load();
+    return *ms < 0 ? TRRE_E_ARG : TRRE_OK;
 }
 
 int trre_shard_bounds(const uint8_t* in, size_t n, int nshards, size_t* bounds) {

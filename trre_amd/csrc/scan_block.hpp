@@ -1392,6 +1392,7 @@ TRRE_HD uint32_t rev_step4(const RevView& T, uint32_t& r, uint32_t w) {
     r = T.tab[(r << 8) | (w & 0xffu)]; y |= r;
     return y;
 }
+template <int kDbg = 0>
 TRRE_HD void rev_sweep_lane(const ScanArgs& a, const RevView& T, int64_t lane, int64_t lane_bytes) {
     const int64_t lo = lane * lane_bytes;
     const int64_t vtop = (a.vend + 63) & ~(int64_t)63;
@@ -1446,12 +1447,16 @@ TRRE_HD void rev_sweep_lane(const ScanArgs& a, const RevView& T, int64_t lane, i
         U128 n0, n1, n2, n3;
         fetch(v - 64, n0, n1, n2, n3);
         U128 y0, y1, y2, y3;
+        if (kDbg != 2) {
         y3.w = rev_step4(T, r, b3.w); y3.z = rev_step4(T, r, b3.z); y3.y = rev_step4(T, r, b3.y); y3.x = rev_step4(T, r, b3.x);
         y2.w = rev_step4(T, r, b2.w); y2.z = rev_step4(T, r, b2.z); y2.y = rev_step4(T, r, b2.y); y2.x = rev_step4(T, r, b2.x);
         y1.w = rev_step4(T, r, b1.w); y1.z = rev_step4(T, r, b1.z); y1.y = rev_step4(T, r, b1.y); y1.x = rev_step4(T, r, b1.x);
         y0.w = rev_step4(T, r, b0.w); y0.z = rev_step4(T, r, b0.z); y0.y = rev_step4(T, r, b0.y); y0.x = rev_step4(T, r, b0.x);
+        }
         U128* dst = reinterpret_cast<U128*>(a.sym_v0 + v);
-        dst[0] = y0; dst[1] = y1; dst[2] = y2; dst[3] = y3;
+        if (kDbg == 1) { if (y0.x == 0x12345678u && y3.w == 0x9abcdef0u) dst[0] = y1; }      // experiment: no stores
+        else if (kDbg == 2) { dst[0] = b0; dst[1] = b1; dst[2] = b2; dst[3] = b3; }               // experiment: no walk
+        else { dst[0] = y0; dst[1] = y1; dst[2] = y2; dst[3] = y3; }
         b0 = n0; b1 = n1; b2 = n2; b3 = n3;
     }
 }

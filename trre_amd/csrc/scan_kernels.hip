@@ -767,6 +767,7 @@ void launch_direct_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t
 // ---- backward pass of the guided families: one symbol per input byte (rev_sweep_lane) -------------------
 constexpr int kRevThreads = 256;
 
+template <int kDbg>
 __global__ __launch_bounds__(kRevThreads) void k_rev_sweep(ScanArgs a, int64_t lane_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];    // tab[n_rev][256]: at most 64 KiB
     const RevBlobHeader& h = *reinterpret_cast<const RevBlobHeader*>(a.rblob);
@@ -775,15 +776,18 @@ __global__ __launch_bounds__(kRevThreads) void k_rev_sweep(ScanArgs a, int64_t l
     for (int k = threadIdx.x; k < (int)h.n_rev * 16; k += kRevThreads) d[k] = e[k];
     __syncthreads();
     const RevView T{smem};
-    rev_sweep_lane(a, T, (int64_t)blockIdx.x * kRevThreads + threadIdx.x, lane_bytes);
+    rev_sweep_lane<kDbg>(a, T, (int64_t)blockIdx.x * kRevThreads + threadIdx.x, lane_bytes);
 }
 void launch_rev_sweep(const ScanArgs& a, int tab_bytes, int64_t lane_bytes, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t vtop = (a.vend + 63) & ~(int64_t)63;
     const int64_t n_lanes = (vtop + lane_bytes - 1) / lane_bytes;
     const dim3 grid((unsigned)((n_lanes + kRevThreads - 1) / kRevThreads));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rev_sweep), hipFuncAttributeMaxDynamicSharedMemorySize, tab_bytes);
-    hipLaunchKernelGGL(k_rev_sweep, grid, dim3(kRevThreads), tab_bytes, s, a, lane_bytes);
+    static const int dbg = getenv("TRRE_REV_DBG") ? atoi(getenv("TRRE_REV_DBG")) : 0;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rev_sweep<0>), hipFuncAttributeMaxDynamicSharedMemorySize, tab_bytes);
+    if (dbg == 1) hipLaunchKernelGGL(k_rev_sweep<1>, grid, dim3(kRevThreads), tab_bytes, s, a, lane_bytes);
+    else if (dbg == 2) hipLaunchKernelGGL(k_rev_sweep<2>, grid, dim3(kRevThreads), tab_bytes, s, a, lane_bytes);
+    else hipLaunchKernelGGL(k_rev_sweep<0>, grid, dim3(kRevThreads), tab_bytes, s, a, lane_bytes);
 }
 
 int stream_chunk_bytes(int which) { return which == 0 ? GeoStream::CHUNK : GeoStreamGen::CHUNK; }
