@@ -19,6 +19,7 @@ using namespace trre;
 
 namespace {
 
+constexpr uint32_t kFlagG16SlowBit = 1u << 3;    // front.hpp: kFlagG16Slow
 using GeoTiny = Geometry<4, 64, 32>;
 using GeoTinyStream = Geometry<4, 4 * 20, 32>;   // SUB = 20 bytes = 5 dwords (odd), like the production stream geometry
 
@@ -202,7 +203,8 @@ void run_direct_lp_emit(ScanArgs a, int64_t lane_bytes, uint32_t& status, bool g
     a.lp_emit = 1;
     for (int64_t lane = n_lanes - 1; lane >= 0; --lane) {
         DirectLane L;
-        if (g16) stream_direct_lane<2, true, kSym>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
+        if (g16 && (h.flags & kFlagG16SlowBit)) g16_lane<2, kSym, true>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
+        else if (g16) g16_lane<2, kSym, false>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
         else stream_direct_lane<2, false, kSym>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
     }
 }
@@ -224,7 +226,8 @@ void run_direct_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uin
     std::vector<uint64_t> cnt(n_lanes);
     for (int64_t lane = 0; lane < n_lanes; ++lane) {
         DirectLane L;
-        if (g16) stream_direct_lane<1, true, kSym>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
+        if (g16 && (h.flags & kFlagG16SlowBit)) g16_lane<1, kSym, true>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
+        else if (g16) g16_lane<1, kSym, false>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
         else stream_direct_lane<1, false, kSym>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
         cnt[lane] = L.count;
     }
@@ -235,7 +238,8 @@ void run_direct_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uin
     if (run > a.cap) { status |= kStCapacity; return; }
     for (int64_t lane = n_lanes - 1; lane >= 0; --lane) {
         DirectLane L;
-        if (g16) stream_direct_lane<2, true, kSym>(a, T, h.n_cls, lane, lane_bytes, ring, base[lane], L, status);
+        if (g16 && (h.flags & kFlagG16SlowBit)) g16_lane<2, kSym, true>(a, T, h.n_cls, lane, lane_bytes, ring, base[lane], L, status);
+        else if (g16) g16_lane<2, kSym, false>(a, T, h.n_cls, lane, lane_bytes, ring, base[lane], L, status);
         else stream_direct_lane<2, false, kSym>(a, T, h.n_cls, lane, lane_bytes, ring, base[lane], L, status);
     }
 }

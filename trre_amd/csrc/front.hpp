@@ -128,7 +128,8 @@ constexpr uint32_t kClassEol = 0;      // '\n' and NUL: never inside a line
 enum : uint32_t {
     kFlagLengthPreserving = 1u << 0,   // every accepted attempt emits exactly what it consumed
     kFlagMemoryless = 1u << 1,         // every start edge is dead or accepts with one output byte
-    kFlagNoOverrun = 1u << 2           // pending output never exceeds consumed input inside an attempt
+    kFlagNoOverrun = 1u << 2,          // pending output never exceeds consumed input inside an attempt
+    kFlagG16Slow = 1u << 3             // stream tables: some 16-byte entry is "slow" (more than 4 bytes or pooled text)
 };
 
 struct DftTables {

@@ -23,7 +23,7 @@ int direct_ent_lds_bytes();
 int direct_block_threads();
 // sym: guided families — columns are the symbols of the backward pass (a.sym_v0)
 void launch_direct_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, void* stream, int g16_bytes = 0,
-                          bool sym = false);
+                          bool sym = false, bool g16_slow = true);
 // backward pass of the guided families: fills a.sym_v0[0 .. round_up(a.vend, 64))
 void launch_rev_sweep(const ScanArgs& a, int tab_bytes, int64_t lane_bytes, void* stream);
 void launch_lpw_kernel(int ent_bytes, bool wide, bool direct_ent_in_lds, const ScanArgs& a, int64_t lane_bytes, void* stream);

@@ -384,6 +384,7 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
     const int64_t lane_bytes = lane_bytes_env > 0 ? (lane_bytes_env + 127) / 128 * 128 : lane_auto;
     const bool direct = (is_stream(family) && stream_impl >= 1) || is_guided(family);
     const bool direct_ent_lds = stt.ok && stt.ent.size() * 8 <= (size_t)direct_ent_lds_bytes();
+    const bool g16_slow = (stt.flags & kFlagG16Slow) != 0;
     if (direct) n_chunks = (args.vend + lane_bytes * direct_block_threads() - 1) / (lane_bytes * direct_block_threads());
 
     if (!is_gen(family) && cap < n) return TRRE_OK;   // finish() reports the capacity error
@@ -439,15 +440,15 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
             launch_direct_kernel(0, direct_ent_lds, args, lane_bytes, n_chunks, stream, 0, is_guided(family));
         } else {
             args.lp_emit = 1;
-            launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, is_guided(family));
+            launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, is_guided(family), g16_slow);
         }
     } else if (direct) {
         static const bool no_g16 = getenv("TRRE_NO_G16") != nullptr;          // A/B: the 8-byte entries
         const int g16 = stt.g16_ok && !no_g16 ? (int)(stt.g16.size() * 4) : 0;
         if (is_guided(family)) launch_rev_sweep(args, (int)p->gt.n_rev * 256, lane_bytes, stream);
-        launch_direct_kernel(1, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, is_guided(family));
+        launch_direct_kernel(1, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, is_guided(family), g16_slow);
         launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);
-        launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, is_guided(family));
+        launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, is_guided(family), g16_slow);
         pd.total_at = cx->d_chunk_base + n_chunks;
     } else if (family == TRRE_KERNEL_STREAM_LP) {
         launch_stream_kernel(0, ent_lds, args, n_chunks, stream);

@@ -20,6 +20,7 @@
 // tests/cpu_shim.cpp runs them thread by thread on the host.
 #pragma once
 #include <cstdint>
+#include <type_traits>
 
 #include "device_blob.hpp"
 #include "scan_core.hpp"
@@ -429,6 +430,7 @@ TRRE_HD int64_t line_start_global(const ScanArgs& a, int64_t v) {
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define TRRE_WAVE_ANY(x) __any(x)
+#define TRRE_WAVE_ALL(x) __all(x)
 #define TRRE_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)   // keep the scheduler from interleaving blocks
 #define TRRE_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
 #define TRRE_TOUCH(x) asm volatile("" ::"v"(x))                // force x to be materialised here
@@ -438,6 +440,7 @@ TRRE_HD int64_t line_start_global(const ScanArgs& a, int64_t v) {
 #define TRRE_TOUCH(x) ((void)(x))
 #define TRRE_PIN(x) ((void)0)
 #define TRRE_WAVE_ANY(x) (x)
+#define TRRE_WAVE_ALL(x) (x)
 #define TRRE_SCHED_FENCE() ((void)0)
 #endif
 
@@ -1072,6 +1075,214 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
     if ((kMode == 0 || (kMode == 2 && a.lp_emit)) && (seen & (kG16 ? 8u : kStrNul))) status |= kStNul;
     if (kMode == 1 && (seen & (kG16 ? 64u : kStrOvf))) status |= kStOverflow;     // bounded fold: the launch is void
     if ((kMode != 2 || a.lp_emit) && (seen & (kG16 ? 16u : kStrDiv))) status |= kStDiverge;      // guided tables: the reference's search never returns
+    L.count = cnt;
+}
+
+// =============================================================================================
+// Small tables (16-byte entries, whole table in LDS): the count and emit passes written for instruction
+// count — these passes are bound by VALU issue (a wave64 integer instruction occupies its SIMD for 4
+// cycles), not by memory.  Differences from stream_direct_lane<.., kG16>:
+//   * pieces that lie wholly inside the lane's sub-range are walked without any end-of-lane test (no lane
+//     of the wave can finish there); only the pieces of the tail — the rest of the lane's last line —
+//     carry it;
+//   * the count pass sums the entries' byte counts per dword in 32 bits and looks at the "slow" flag once
+//     per dword (a dword that met one is simply counted again the careful way);
+//   * the emit pass appends through a 64-bit window that moves on by at most one dword per transition
+//     (an entry of this form emits at most 4 bytes): OR, store, one variable 64-bit shift, no selects;
+//   * tables without slow entries (kHasSlow = false: no transition emits more than 4 bytes) have no slow
+//     path at all.
+// =============================================================================================
+TRRE_HD void stage_append_n4(Stage& s, uint32_t v, uint32_t n) {      // n <= 4; the bytes of v above n are zero
+    s.acc |= (uint64_t)v << (8u * s.pb);
+    *reinterpret_cast<uint32_t*>(s.buf + s.wp) = (uint32_t)s.acc;
+    *reinterpret_cast<uint32_t*>(s.buf + s.wp + 4) = (uint32_t)(s.acc >> 32);
+    const uint32_t t = s.pb + n;          // <= 7
+    const uint32_t adv = t >> 2;          // 0 or 1 dword completed
+    s.pb = t & 3u;
+    s.wp += 4u * adv;
+    s.acc >>= 32u * adv;
+}
+
+template <int kMode, bool kSym, bool kHasSlow>
+TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, int64_t lane, int64_t lane_bytes, uint8_t* ring,
+                      uint64_t out_base, DirectLane& L, uint32_t& status) {
+    static_assert(kMode == 1 || kMode == 2, "count or emit");
+    const uint32_t done_row = kDoneState * n_cls * 16u;
+    const int64_t lo = lane * lane_bytes;
+    int64_t hi = lo + lane_bytes;
+    if (hi > a.vend) hi = a.vend;
+    const uint32_t rhi = (uint32_t)(hi > lo ? hi - lo : 0);
+    uint32_t row;
+    if (lo >= hi) row = done_row;
+    else if (lo < a.vbeg) row = kSkipState * n_cls * 16u;             // filler then '\n' right before the input
+    else row = (lo == a.vbeg || a.in_v0[lo - 1] == (uint8_t)'\n') ? 0u : kSkipState * n_cls * 16u;
+    Stage S{};
+    if (kMode == 2) {
+        if (a.lp_emit) {
+            // no count pass: this lane's lines are written where they were read
+            const int64_t fs = row == done_row ? hi : first_line_start_safe(a, lo, hi);
+            if (fs >= hi) row = done_row;
+            stage_begin(S, ring, a.out_v0 + fs);
+        } else {
+            stage_begin(S, ring, a.out + out_base);
+        }
+    }
+    uint64_t cnt = 0;
+    uint32_t seen = 0;
+    const int64_t vlast = (a.vend - 1) & ~(int64_t)15;               // the last readable aligned block
+    const int64_t slast = ((a.vend + 63) & ~(int64_t)63) - 16;       // the last block of symbols
+    auto sym_at = [&](int64_t vn) -> U128 {
+        if (!kSym) return U128{};
+        return *reinterpret_cast<const U128*>(a.sym_v0 + (vn < slast ? vn : slast));
+    };
+    // the careful version of one transition (a "slow" entry: more than 4 bytes or pooled text, from the 8-byte entry)
+    auto slow_count = [&](uint32_t r, uint32_t k) -> uint32_t {
+        const uint64_t e = T.ent[(r >> 4) + k];
+        const uint32_t elo = (uint32_t)e, ehi = (uint32_t)(e >> 32);
+        const uint32_t ol = str_olen(elo);
+        return (ol == 7u ? str_pool_len(T, ehi) : ol) + ((elo >> 27) & 1u);
+    };
+    auto slow_emit = [&](uint32_t r, uint32_t k, uint8_t c) {
+        const uint64_t e = T.ent[(r >> 4) + k];
+        const uint32_t elo = (uint32_t)e, ehi = (uint32_t)(e >> 32);
+        const uint32_t ol = str_olen(elo), cc = (elo >> 27) & 1u;
+        if (ol != 7u) {
+            stage_append(S, (uint64_t)ehi | (uint64_t)(cc ? c : 0u) << (8u * ol), ol + cc);
+            return;
+        }
+        uint32_t len = ehi >> 24;
+        if (len <= 8u) {
+            uint64_t text;
+            if (T.pool_fast) __builtin_memcpy(&text, T.pool_fast + str_pool_off(ehi) + 4, 8);
+            else __builtin_memcpy(&text, T.pool + str_pool_off(ehi) + 4, 8);
+            stage_append_text_c(S, text, len, c, cc);
+            return;
+        }
+        // long replacement text: empty the staging buffer, write straight to memory
+        const uint8_t* rec = T.pool + str_pool_off(ehi);
+        if (len == 255u) len = str_pool_len(T, ehi);
+        stage_flush<false>(S);
+        stage_flush<true>(S);
+        uint8_t* gp = S.gq + S.fill();
+        for (uint32_t i = 0; i < len; ++i) gp[i] = rec[4 + i];
+        stage_begin(S, S.buf, gp + len);
+        stage_append(S, (uint64_t)(cc ? c : 0u), cc);
+    };
+    // one dword (4 input bytes) whose first byte lies rp bytes into the sub-range; kEnd: a lane may finish in it
+    auto dword = [&](auto end_tag, const uint32_t w, const uint32_t sw, const uint32_t rp) {
+        constexpr bool kEnd = decltype(end_tag)::value;
+        const uint32_t kk[4] = {kSym ? (sw & 0xffu) : (uint32_t)T.cls[w & 0xffu], kSym ? ((sw >> 8) & 0xffu) : (uint32_t)T.cls[(w >> 8) & 0xffu],
+                                kSym ? ((sw >> 16) & 0xffu) : (uint32_t)T.cls[(w >> 16) & 0xffu], kSym ? (sw >> 24) : (uint32_t)T.cls[w >> 24]};
+        if (kMode == 1) {
+            const uint32_t row0 = row;
+            uint32_t c = 0, fl = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint64_t g = *reinterpret_cast<const uint64_t*>(T.g16 + row + (kk[j] << 4));       // {next row, meta}
+                const uint32_t meta = (uint32_t)(g >> 32);
+                c += meta & 7u;
+                fl |= meta;
+                row = (kEnd && (meta & 32u) && rp + (uint32_t)j + 1u >= rhi) ? done_row : (uint32_t)g;
+            }
+            if (kHasSlow) {
+                if (TRRE_WAVE_ANY(fl & 128u)) {
+                    if (fl & 128u) {              // count this dword again, slow entries from their 8-byte form
+                        row = row0;
+                        c = 0;
+                        for (int j = 0; j < 4; ++j) {
+                            const uint64_t g = *reinterpret_cast<const uint64_t*>(T.g16 + row + (kk[j] << 4));
+                            const uint32_t meta = (uint32_t)(g >> 32);
+                            c += (meta & 128u) ? slow_count(row, kk[j]) : (meta & 7u);
+                            row = (kEnd && (meta & 32u) && rp + (uint32_t)j + 1u >= rhi) ? done_row : (uint32_t)g;
+                        }
+                    }
+                }
+            }
+            seen |= fl;
+            cnt += c;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const U128 g = *reinterpret_cast<const U128*>(T.g16 + row + (kk[j] << 4));
+                stage_append_n4(S, perm_b32(w >> (8 * j), g.z, g.w), g.y & 7u);
+                seen |= g.y;
+                if (kHasSlow) {
+                    if (TRRE_WAVE_ANY(g.y & 128u)) {
+                        if (g.y & 128u) slow_emit(row, kk[j], (uint8_t)(w >> (8 * j)));
+                    }
+                }
+                row = (kEnd && (g.y & 32u) && rp + (uint32_t)j + 1u >= rhi) ? done_row : g.x;
+            }
+        }
+    };
+    auto block = [&](auto end_tag, const U128& b, const U128& y, const uint32_t rp) {
+        dword(end_tag, b.x, y.x, rp);
+        dword(end_tag, b.y, y.y, rp + 4u);
+        if (kMode == 2) stage_flush<false>(S);
+        dword(end_tag, b.z, y.z, rp + 8u);
+        dword(end_tag, b.w, y.w, rp + 12u);
+        if (kMode == 2) stage_flush<false>(S);
+        TRRE_PIN(seen);
+        if (kMode == 1) TRRE_PIN(cnt);
+        TRRE_SCHED_FENCE();
+    };
+    // 64 bytes at a time; a lane's four 16-byte loads of a piece are issued together, one piece ahead
+    U128 c0 = direct_load(a, lo), c1 = direct_load(a, lo + 16), c2 = direct_load(a, lo + 32), c3 = direct_load(a, lo + 48);
+    U128 s0 = sym_at(lo), s1 = sym_at(lo + 16), s2 = sym_at(lo + 32), s3 = sym_at(lo + 48);
+    for (int64_t v = lo;; v += 64) {
+        if (!TRRE_WAVE_ANY(row != done_row)) break;
+        const int64_t vn = v + 64;
+        const int64_t x0 = vn < vlast ? vn : vlast, x1 = vn + 16 < vlast ? vn + 16 : vlast,
+                      x2 = vn + 32 < vlast ? vn + 32 : vlast, x3 = vn + 48 < vlast ? vn + 48 : vlast;
+        U128 n0 = *reinterpret_cast<const U128*>(a.in_v0 + x0), n1 = *reinterpret_cast<const U128*>(a.in_v0 + x1),
+             n2 = *reinterpret_cast<const U128*>(a.in_v0 + x2), n3 = *reinterpret_cast<const U128*>(a.in_v0 + x3);
+        if (TRRE_WAVE_ANY(vn < a.vbeg || vn + 64 > a.vend - 1)) {
+            n0 = direct_load(a, vn); n1 = direct_load(a, vn + 16); n2 = direct_load(a, vn + 32); n3 = direct_load(a, vn + 48);
+        }
+        const U128 t0 = sym_at(vn), t1 = sym_at(vn + 16), t2 = sym_at(vn + 32), t3 = sym_at(vn + 48);
+        const uint32_t rp = (uint32_t)(v - lo);
+        if (TRRE_WAVE_ALL(rp + 64u < rhi)) {
+            // interior piece: a lane finishes at the first record end whose '\n' is the last byte of its sub-range or lies
+            // beyond it, and every byte of this piece lies before that last byte
+#pragma clang loop unroll(disable)
+            for (int q = 0; q < 4; ++q) {
+                U128 b, y{};
+                b.x = q == 0 ? c0.x : (q == 1 ? c1.x : (q == 2 ? c2.x : c3.x));
+                b.y = q == 0 ? c0.y : (q == 1 ? c1.y : (q == 2 ? c2.y : c3.y));
+                b.z = q == 0 ? c0.z : (q == 1 ? c1.z : (q == 2 ? c2.z : c3.z));
+                b.w = q == 0 ? c0.w : (q == 1 ? c1.w : (q == 2 ? c2.w : c3.w));
+                if (kSym) {
+                    y.x = q == 0 ? s0.x : (q == 1 ? s1.x : (q == 2 ? s2.x : s3.x));
+                    y.y = q == 0 ? s0.y : (q == 1 ? s1.y : (q == 2 ? s2.y : s3.y));
+                    y.z = q == 0 ? s0.z : (q == 1 ? s1.z : (q == 2 ? s2.z : s3.z));
+                    y.w = q == 0 ? s0.w : (q == 1 ? s1.w : (q == 2 ? s2.w : s3.w));
+                }
+                block(std::false_type{}, b, y, rp + 16u * (uint32_t)q);
+            }
+        } else {
+#pragma clang loop unroll(disable)
+            for (int q = 0; q < 4; ++q) {
+                U128 b, y{};
+                b.x = q == 0 ? c0.x : (q == 1 ? c1.x : (q == 2 ? c2.x : c3.x));
+                b.y = q == 0 ? c0.y : (q == 1 ? c1.y : (q == 2 ? c2.y : c3.y));
+                b.z = q == 0 ? c0.z : (q == 1 ? c1.z : (q == 2 ? c2.z : c3.z));
+                b.w = q == 0 ? c0.w : (q == 1 ? c1.w : (q == 2 ? c2.w : c3.w));
+                if (kSym) {
+                    y.x = q == 0 ? s0.x : (q == 1 ? s1.x : (q == 2 ? s2.x : s3.x));
+                    y.y = q == 0 ? s0.y : (q == 1 ? s1.y : (q == 2 ? s2.y : s3.y));
+                    y.z = q == 0 ? s0.z : (q == 1 ? s1.z : (q == 2 ? s2.z : s3.z));
+                    y.w = q == 0 ? s0.w : (q == 1 ? s1.w : (q == 2 ? s2.w : s3.w));
+                }
+                block(std::true_type{}, b, y, rp + 16u * (uint32_t)q);
+            }
+        }
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        if (kSym) { s0 = t0; s1 = t1; s2 = t2; s3 = t3; }
+    }
+    if (kMode == 2) stage_flush<true>(S);
+    if (kMode == 2 && a.lp_emit && (seen & 8u)) status |= kStNul;
+    if (kMode == 1 && (seen & 64u)) status |= kStOverflow;            // bounded fold: the launch is void
+    if ((kMode == 1 || a.lp_emit) && (seen & 16u)) status |= kStDiverge;   // guided tables: the reference's search never returns
     L.count = cnt;
 }
 

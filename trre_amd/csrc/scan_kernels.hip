@@ -413,7 +413,7 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_direct(ScanArgs a, in
 
 // Count / emit passes over the 16-byte entries of a small table (front.hpp): the whole table in LDS.
 //   smem: cls[256] | g16[g16_room] | pooled text (2 KiB, when the pool fits) | staging[threads] | 64
-template <int kMode, bool kSym>
+template <int kMode, bool kSym, bool kHasSlow>
 __global__ __launch_bounds__(kDirectThreads) void k_stream_g16(ScanArgs a, int64_t lane_bytes, int g16_room) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_g16(ScanArgs a, int64
             return;
         }
     }
-    stream_direct_lane<kMode, true, kSym>(a, T, h.n_cls, lane, lane_bytes, ring, base, L, st);
+    g16_lane<kMode, kSym, kHasSlow>(a, T, h.n_cls, lane, lane_bytes, ring, base, L, st);
     if (kMode == 1) {
         uint64_t* part = reinterpret_cast<uint64_t*>(tail);
         if (L.count > 0xffffffffull) { st |= kStCapacity; L.count = 0xffffffffull; }
@@ -742,26 +742,32 @@ void launch_direct_t(bool ent_lds, const ScanArgs& a, int64_t lane_bytes, int64_
 }
 int direct_ent_lds_bytes() { return kDirectEntBytes; }
 int direct_block_threads() { return kDirectThreads; }
+template <bool kSym, bool kHasSlow>
+void launch_g16(int which, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, hipStream_t s, int g16_bytes) {
+    const int room = (g16_bytes + 15) / 16 * 16;
+    const int lds = 256 + room + kDirectPoolSmall + kDirectThreads * kRingStride + 64;
+    const int lds_count = 256 + room + 64;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_g16<1, kSym, kHasSlow>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_count);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_g16<2, kSym, kHasSlow>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (which == 1) hipLaunchKernelGGL((k_stream_g16<1, kSym, kHasSlow>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds_count, s, a, lane_bytes, room);
+    else hipLaunchKernelGGL((k_stream_g16<2, kSym, kHasSlow>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds, s, a, lane_bytes, room);
+}
 template <bool kSym>
-void launch_direct_sym(int which, bool ent_in_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, hipStream_t s, int g16_bytes) {
+void launch_direct_sym(int which, bool ent_in_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, hipStream_t s, int g16_bytes, bool g16_slow) {
     if (g16_bytes > 0 && which != 0) {
-        const int room = (g16_bytes + 15) / 16 * 16;
-        const int lds = 256 + room + kDirectPoolSmall + kDirectThreads * kRingStride + 64;
-        const int lds_count = 256 + room + 64;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_g16<1, kSym>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_count);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_g16<2, kSym>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (which == 1) hipLaunchKernelGGL((k_stream_g16<1, kSym>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds_count, s, a, lane_bytes, room);
-        else hipLaunchKernelGGL((k_stream_g16<2, kSym>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds, s, a, lane_bytes, room);
+        if (g16_slow) launch_g16<kSym, true>(which, a, lane_bytes, n_blocks, s, g16_bytes);
+        else launch_g16<kSym, false>(which, a, lane_bytes, n_blocks, s, g16_bytes);
         return;
     }
     if (which == 0) launch_direct_t<0, kSym>(ent_in_lds, a, lane_bytes, n_blocks, s);
     else if (which == 1) launch_direct_t<1, kSym>(ent_in_lds, a, lane_bytes, n_blocks, s);
     else launch_direct_t<2, kSym>(ent_in_lds, a, lane_bytes, n_blocks, s);
 }
-void launch_direct_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, void* stream, int g16_bytes, bool sym) {
+void launch_direct_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, void* stream, int g16_bytes, bool sym,
+                          bool g16_slow) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (sym) launch_direct_sym<true>(which, ent_in_lds, a, lane_bytes, n_blocks, s, g16_bytes);
-    else launch_direct_sym<false>(which, ent_in_lds, a, lane_bytes, n_blocks, s, g16_bytes);
+    if (sym) launch_direct_sym<true>(which, ent_in_lds, a, lane_bytes, n_blocks, s, g16_bytes, g16_slow);
+    else launch_direct_sym<false>(which, ent_in_lds, a, lane_bytes, n_blocks, s, g16_bytes, g16_slow);
 }
 
 // ---- backward pass of the guided families: one symbol per input byte (rev_sweep_lane) -------------------

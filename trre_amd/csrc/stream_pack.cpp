@@ -56,6 +56,7 @@ void build_gen16(StreamTables& t, const StreamPackInput& in) {
             const StreamCell& x = in.rows[s][k];
             const size_t n = x.out.size() + (x.copy_c ? 1 : 0);
             const bool slow = n > 4;
+            if (slow) t.flags |= kFlagG16Slow;
             uint32_t* e = &v[((size_t)s * t.n_cls + k) * 4];
             e[0] = x.next * t.n_cls * 16u;
             const bool silent = s == in.skip || s == in.done;
