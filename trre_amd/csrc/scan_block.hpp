@@ -641,7 +641,6 @@ struct WtRow {
     TRRE_HD U128 load(int b) const { return *reinterpret_cast<const U128*>(row + ((uint32_t)(b << 4) ^ swz16)); }
     TRRE_HD void store(int b, const U128& v) const { *reinterpret_cast<U128*>(row + ((uint32_t)(b << 4) ^ swz16)) = v; }
 };
-constexpr int kRingStride = 116;                      // bytes per lane: 29 dwords (odd), so the lanes' accesses at equal offsets hit distinct banks
 
 struct DirectLane {
     uint64_t count = 0;        // kMode 1: bytes this lane emits
@@ -699,94 +698,91 @@ TRRE_HD void direct_flush(uint8_t* obase, const uint8_t* ring, uint32_t& of, uin
 }
 
 // ---- output staging of the emit pass ---------------------------------------------------------------
-// A lane's output is a contiguous run of the output buffer that starts at an arbitrary byte.  It is
-// assembled in a small linear LDS buffer whose byte 0 corresponds to a 16-byte aligned output address.
-// Appending is branch-free: the bytes of the dword being filled live in a 64-bit register window `acc`;
-// a transition ORs its up-to-5 bytes (at most 4 inline bytes and the input byte it may copy) in at the
-// fill position, the window's two dwords are stored (aligned) over the buffer, and the window moves on
-// by as many dwords as were completed.  After every eight input bytes the complete 32-byte sectors leave
-// as pairs of aligned 16-byte stores (whole sectors: a 16-byte store on its own is a partial-sector
-// write, measured at 2.2x write amplification) and the remainder (< 32 bytes) moves to the front.
-// 31 + 8 * 9 bytes plus the reach of the window fit the lane's kRingStride; lanes are an odd number of
-// dwords apart (equal offsets of different lanes hit distinct banks) and the moves are done in dwords.
-TRRE_HD U128 lds_ld16(const uint8_t* p) {              // 4-byte aligned
-    U128 q;
-    q.x = *reinterpret_cast<const uint32_t*>(p); q.y = *reinterpret_cast<const uint32_t*>(p + 4);
-    q.z = *reinterpret_cast<const uint32_t*>(p + 8); q.w = *reinterpret_cast<const uint32_t*>(p + 12);
-    return q;
-}
-TRRE_HD void lds_st16(uint8_t* p, const U128& q) {
-    *reinterpret_cast<uint32_t*>(p) = q.x; *reinterpret_cast<uint32_t*>(p + 4) = q.y;
-    *reinterpret_cast<uint32_t*>(p + 8) = q.z; *reinterpret_cast<uint32_t*>(p + 12) = q.w;
-}
+// A lane's output is a contiguous run of the output buffer that starts at an arbitrary byte.  The dword
+// being filled lives in a 64-bit register window `acc`; a transition ORs its bytes in at the fill position
+// and only a COMPLETED dword goes to the lane's 128-byte LDS ring (one aligned ds_write_b32, and only the
+// lanes that completed one take part).  After every eight input bytes the complete 32-byte sectors leave
+// the ring as pairs of aligned 16-byte loads and stores (whole sectors: a 16-byte store on its own is a
+// partial-sector write, measured at 2.2x write amplification); nothing is ever moved inside the ring.
+// (The first version stored the window's two dwords on every transition and moved the remainder to the front
+// of a linear buffer at every flush: PMC showed the LDS array busy 63 % of the kernel's time, a third of
+// it bank conflicts — lanes sit at unrelated offsets of their buffers — and the VALU waiting for it.)
+// Stream offsets count from the 32-byte aligned output address g0 at or below the lane's first byte; the
+// ring holds offsets [fp, wp), 31 + 8 * 9 bytes at most between two flushes.  Rings are 132 bytes apart
+// (33 dwords, odd: lanes that run in step — one byte out per byte in — store to distinct banks), so a
+// ring is only 4-byte aligned and a sector leaves it as eight dword reads.
+constexpr int kRingStride = 132;
+constexpr uint32_t kRingBytes = 128;
 struct Stage {
-    uint8_t* buf;        // kRingStride bytes, 4-byte aligned
-    uint8_t* gq;         // 32-byte aligned output address of buf[0]
-    uint64_t acc;        // bytes [wp, wp + pb) of the buffer (and zeros above them)
-    uint32_t wp;         // offset of the dword being filled (multiple of 4)
+    uint8_t* buf;        // the lane's ring: kRingBytes, 4-byte aligned
+    uint8_t* g0;         // 32-byte aligned output address of stream offset 0
+    uint64_t acc;        // bytes [wp, wp + pb) of the stream (and whatever spills beyond while appending)
+    uint32_t wp;         // stream offset of the dword being filled (multiple of 4)
     uint32_t pb;         // bytes of it that are filled (0..3)
-    uint32_t skip;       // leading bytes of buf[0..32) that belong to whoever wrote before this lane's first byte
-    TRRE_HD uint32_t fill() const { return wp + pb; }
+    uint32_t fp;         // everything below this stream offset has left for memory (multiple of 32)
+    uint32_t skip;       // leading bytes of sector 0 that belong to whoever wrote before this lane's first byte
 };
-// start (or restart) at an arbitrary output address; bytes below it in its 16-byte chunk are not ours
+// start (or restart) at an arbitrary output address; bytes below it in its 32-byte sector are not ours
 TRRE_HD void stage_begin(Stage& s, uint8_t* buf, uint8_t* first_out_byte) {
     const uintptr_t start = reinterpret_cast<uintptr_t>(first_out_byte);
     s.buf = buf;
-    s.gq = reinterpret_cast<uint8_t*>(start & ~(uintptr_t)31);
+    s.g0 = reinterpret_cast<uint8_t*>(start & ~(uintptr_t)31);
     s.skip = (uint32_t)(start & 31u);
     s.wp = s.skip & ~3u;
     s.pb = s.skip & 3u;
+    s.fp = 0;
     s.acc = 0;
 }
-// append the low n (0..5) bytes of v; the bytes of v above n must be zero
-TRRE_HD void stage_append(Stage& s, uint64_t v, uint32_t n) {
-    s.acc |= v << (8u * s.pb);
-    *reinterpret_cast<uint32_t*>(s.buf + s.wp) = (uint32_t)s.acc;
-    *reinterpret_cast<uint32_t*>(s.buf + s.wp + 4) = (uint32_t)(s.acc >> 32);
-    const uint32_t t = s.pb + n, adv = t >> 2;          // 0..2 dwords completed
-    s.pb = t & 3u;
-    s.wp += 4u * adv;
-    s.acc = adv == 0u ? s.acc : (adv == 1u ? s.acc >> 32 : 0ull);
-}
-// the same for at most 4 bytes
-TRRE_HD void stage_append4(Stage& s, uint32_t v, uint32_t n) { stage_append(s, (uint64_t)v, n); }
-// a pooled text of 5..8 bytes, then maybe the input byte c: two appends through the window (no LDS round trip)
-TRRE_HD void stage_append_text_c(Stage& s, uint64_t text, uint32_t len, uint32_t c, uint32_t cc) {
-    stage_append(s, (uint64_t)(uint32_t)text, 4u);
-    const uint32_t rest = len - 4u;                                     // 1..4 bytes
-    const uint64_t hi = (text >> 32) & (0xffffffffull >> (32u - 8u * rest));
-    stage_append(s, hi | (uint64_t)(cc ? c : 0u) << (8u * rest), rest + cc);
-}
-TRRE_HD void stage_store_sector(Stage& s, uint32_t c) {
-    if (c == 0 && s.skip) {
-        for (uint32_t i = s.skip; i < 32u; ++i) s.gq[i] = s.buf[i];      // once per lane: the sector it shares with its predecessor
-    } else {
-        const U128 q0 = lds_ld16(s.buf + 32u * c), q1 = lds_ld16(s.buf + 32u * c + 16u);
-        *reinterpret_cast<U128*>(s.gq + 32u * c) = q0;
-        *reinterpret_cast<U128*>(s.gq + 32u * c + 16u) = q1;
+TRRE_HD uint8_t* stage_out_ptr(const Stage& s) { return s.g0 + s.wp + s.pb; }      // where the next byte goes
+// append the low n (0..4) bytes of v; the bytes of v above n must be zero
+TRRE_HD void stage_append_n4(Stage& s, uint32_t v, uint32_t n) {
+    s.acc |= (uint64_t)v << (8u * s.pb);
+    const uint32_t t = s.pb + n;          // <= 7: at most one dword completed
+    if (t >= 4u) {
+        *reinterpret_cast<uint32_t*>(s.buf + (s.wp & (kRingBytes - 1u))) = (uint32_t)s.acc;
+        s.acc >>= 32;
+        s.wp += 4u;
     }
+    s.pb = t & 3u;
+}
+TRRE_HD void stage_append4(Stage& s, uint32_t v, uint32_t n) { stage_append_n4(s, v, n); }
+// the same for up to 8 bytes
+TRRE_HD void stage_append(Stage& s, uint64_t v, uint32_t n) {
+    const uint32_t n1 = n < 4u ? n : 4u;
+    stage_append_n4(s, n < 4u ? (uint32_t)v : (uint32_t)v, n1);
+    stage_append_n4(s, (uint32_t)(v >> 32), n - n1);
+}
+// a pooled text of 5..8 bytes, then maybe the input byte c
+TRRE_HD void stage_append_text_c(Stage& s, uint64_t text, uint32_t len, uint32_t c, uint32_t cc) {
+    stage_append_n4(s, (uint32_t)text, 4u);
+    const uint32_t rest = len - 4u;                                     // 1..4 bytes
+    const uint32_t hi = (uint32_t)(text >> 32) & (0xffffffffu >> (32u - 8u * rest));
+    stage_append_n4(s, hi, rest);
+    stage_append_n4(s, cc ? c : 0u, cc);
+}
+TRRE_HD void stage_store_sector(Stage& s) {        // the sector at stream offset fp is complete
+    const uint8_t* src = s.buf + (s.fp & (kRingBytes - 1u));
+    if (s.fp == 0 && s.skip) {
+        for (uint32_t i = s.skip; i < 32u; ++i) s.g0[i] = src[i];        // once per lane: the sector it shares with its predecessor
+    } else {
+        const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src);
+        const U128 q0{s32[0], s32[1], s32[2], s32[3]}, q1{s32[4], s32[5], s32[6], s32[7]};
+        *reinterpret_cast<U128*>(s.g0 + s.fp) = q0;
+        *reinterpret_cast<U128*>(s.g0 + s.fp + 16u) = q1;
+    }
+    s.fp += 32u;
 }
 template <bool kAll>
 TRRE_HD void stage_flush(Stage& s) {
-    const uint32_t k = s.wp >> 5;                      // complete sectors (at most 3 between flushes)
-    if (TRRE_WAVE_ANY(k > 0u)) {
-        if (k > 0u) stage_store_sector(s, 0);
-        if (TRRE_WAVE_ANY(k > 1u)) {
-            for (uint32_t c = 1; c < k; ++c) stage_store_sector(s, c);
-        }
-        if (k > 0u) {
-            const U128 r0 = lds_ld16(s.buf + 32u * k), r1 = lds_ld16(s.buf + 32u * k + 16u);
-            lds_st16(s.buf, r0);
-            lds_st16(s.buf + 16, r1);
-            s.gq += 32u * k;
-            s.wp -= 32u * k;
-            s.skip = 0;
-        }
+    while (TRRE_WAVE_ANY(s.wp - s.fp >= 32u)) {
+        if (s.wp - s.fp >= 32u) stage_store_sector(s);
     }
     if (kAll) {
-        const uint32_t f = s.fill();                   // (the window is in the buffer: every append stores it)
-        for (uint32_t i = s.skip; i < f; ++i) s.gq[i] = s.buf[i];
-        s.skip = f;
+        // the rest, byte by byte: what is in the ring and the partial dword of the window
+        *reinterpret_cast<uint32_t*>(s.buf + (s.wp & (kRingBytes - 1u))) = (uint32_t)s.acc;
+        const uint32_t end = s.wp + s.pb;
+        for (uint32_t i = (s.fp == 0 ? s.skip : s.fp); i < end; ++i) s.g0[i] = s.buf[i & (kRingBytes - 1u)];
+        s.skip = end & 31u;                 // (a caller that goes on restarts with stage_begin at stage_out_ptr)
     }
 }
 
@@ -895,7 +891,7 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
                                     if (len == 255u) len = str_pool_len(T, ehi);
                                     stage_flush<false>(S);
                                     stage_flush<true>(S);
-                                    uint8_t* gp = S.gq + S.fill();
+                                    uint8_t* gp = stage_out_ptr(S);
                                     for (uint32_t i = 0; i < len; ++i) gp[i] = r[4 + i];
                                     stage_begin(S, S.buf, gp + len);
                                     stage_append(S, (uint64_t)(cc ? c : 0u), cc);
@@ -937,7 +933,7 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
                                 if (len == 255u) len = str_pool_len(T, ehi);
                                 stage_flush<false>(S);
                                 stage_flush<true>(S);
-                                uint8_t* g = S.gq + S.fill();
+                                uint8_t* g = stage_out_ptr(S);
                                 for (uint32_t i = 0; i < len; ++i) g[i] = r[4 + i];
                                 stage_begin(S, S.buf, g + len);
                                 stage_append(S, (uint64_t)(cc ? c : 0u), cc);
@@ -1092,17 +1088,6 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
 //   * tables without slow entries (kHasSlow = false: no transition emits more than 4 bytes) have no slow
 //     path at all.
 // =============================================================================================
-TRRE_HD void stage_append_n4(Stage& s, uint32_t v, uint32_t n) {      // n <= 4; the bytes of v above n are zero
-    s.acc |= (uint64_t)v << (8u * s.pb);
-    *reinterpret_cast<uint32_t*>(s.buf + s.wp) = (uint32_t)s.acc;
-    *reinterpret_cast<uint32_t*>(s.buf + s.wp + 4) = (uint32_t)(s.acc >> 32);
-    const uint32_t t = s.pb + n;          // <= 7
-    const uint32_t adv = t >> 2;          // 0 or 1 dword completed
-    s.pb = t & 3u;
-    s.wp += 4u * adv;
-    s.acc >>= 32u * adv;
-}
-
 template <int kMode, bool kSym, bool kHasSlow>
 TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, int64_t lane, int64_t lane_bytes, uint8_t* ring,
                       uint64_t out_base, DirectLane& L, uint32_t& status) {
@@ -1163,7 +1148,7 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
         if (len == 255u) len = str_pool_len(T, ehi);
         stage_flush<false>(S);
         stage_flush<true>(S);
-        uint8_t* gp = S.gq + S.fill();
+        uint8_t* gp = stage_out_ptr(S);
         for (uint32_t i = 0; i < len; ++i) gp[i] = rec[4 + i];
         stage_begin(S, S.buf, gp + len);
         stage_append(S, (uint64_t)(cc ? c : 0u), cc);
