@@ -311,8 +311,10 @@ void run_lpw_t(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
             rows2 = rows1;
             rows1 = rows;
         }
-        for (int lid = 0; lid < 64; ++lid)
+        for (int lid = 0; lid < 64; ++lid) {
             if (L[lid].seen & kLpwNul) status |= kStNul;
+            if (L[lid].seen & kLpwDiv) status |= kStDiverge;
+        }
     }
     // second launch: the lanes that touch an end of the input
     const StreamView TS = direct_view(a);

@@ -19,7 +19,9 @@ import zlib
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
 import corpus  # noqa: E402
+import dictgen  # noqa: E402
 from oracle_lib import REF_DIR, build_oracle  # noqa: E402
 
 
@@ -52,6 +54,22 @@ def main():
             cases.append({"pattern": pat, "input": name})
     for pat in corpus.QUIRK_PATTERNS + sorted({c[1] for c in corpus.REF_S_CASES}):
         for name in small:
+            cases.append({"pattern": pat, "input": name})
+    # 2. BASELINE config 5: the seeded 1000-entry dictionary (prefix-free keys: both engines agree) on a slice of its
+    #    corpus, and a small dictionary whose keys overlap as prefixes and suffixes (the engines differ: Q9)
+    keys, vals = dictgen.make_dictionary(1000)
+    inputs["dict1000_slice"] = dictgen.corpus(keys, 60000, seed=7)
+    cases.append({"pattern": dictgen.pattern(keys, vals), "input": "dict1000_slice"})
+    import random
+    rng = random.Random(11)
+    inputs["abcd_soup"] = b"".join(bytes(rng.choice(b"abcd ") for _ in range(rng.randint(0, 70))) + b"\n" for _ in range(600))
+    cases.append({"pattern": "ab:1|abc:2|abcd:3|b:4|bc:5|cab:6|ca:7|dab:8", "input": "abcd_soup"})
+    cases.append({"pattern": "(abcd:3|abc:2|ab:1|dab:8|cab:6|ca:7|bc:5|b:4)", "input": "abcd_soup"})
+    # 3. epsilon cycles: the NFT engine's search runs round them for ever on some inputs ("stack max capacity
+    #    reached", exit 1 -> "fail") and never meets them on others
+    inputs.update({"eps_no_a": b"b\nxx\nzz\n", "eps_with_a": b"b\nca\n", "eps_ad": b"ad\n", "eps_abc": b"xyz\nabc\n"})
+    for pat in ("a:*", "a(:y)*", "a(b*)*c|ad"):
+        for name in ("eps_no_a", "eps_with_a", "eps_ad", "eps_abc"):
             cases.append({"pattern": pat, "input": name})
     out_cases = []
     with tempfile.TemporaryDirectory() as td:

@@ -50,9 +50,9 @@ def test_engine_limits_are_errors_not_fallbacks():
     assert e.value.code == api.E_UNSUPPORTED
     p = trre_amd.Program("a(a|b|c){9}c:x", "nft")            # the same with 29 nodes: the bitmask tile kernels
     assert p.info.kernel == trre_amd.KERNEL_TILE_GEN and p.info.guided_rev_states == 0
-    with pytest.raises(trre_amd.TrreError) as e:
-        trre_amd.Program("(a*)*", "dft")
-    assert e.value.code == api.E_EPS_CYCLE
+    # an epsilon cycle is not a compile error: like the reference's lazy tables, the scan fails (TRRE_E_DIVERGES) only
+    # on an input that makes it explore the cycle (tests/test_front_shim.py, golden 'eps_*' inputs)
+    assert trre_amd.Program("(a*)*", "dft").info.dft_states >= 1
 
 
 def test_info_and_table_export():

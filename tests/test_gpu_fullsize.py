@@ -1,0 +1,100 @@
+"""BASELINE.json's full sizes on the GPU: 8 GiB buffers, i.e. byte offsets beyond 2^32 through every kernel
+family that accepts the pattern.  No full-size CPU run is possible (the reference does ~0.1 GB/s), so the
+checks are size-independent properties and oracle-checked slices — at the head, right above the 4 GiB
+mark and at the tail of the buffer — as tests/test_gpu_parity.py does at 1 GiB for configs[1]."""
+import os
+import sys
+
+import pytest
+
+import trre_amd
+from oracle_lib import Oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+N = 8 << 30
+SLICE = 2 << 20
+LP_FAMILIES = (trre_amd.KERNEL_BYTEMAP, trre_amd.KERNEL_TILE_LP, trre_amd.KERNEL_STREAM_LP, trre_amd.KERNEL_GUIDED_LP)
+
+
+def line_start(inp, pos):
+    if pos <= 0:
+        return 0
+    nl = (inp[pos - 1: pos - 1 + (1 << 20)] == 10).nonzero()
+    return pos + int(nl[0]) if nl.numel() else inp.numel()
+
+
+def check_slices(p, oracle, inp, out, m, fam):
+    """length-preserving families: output offset == input offset at line starts, so slices compare directly;
+    general families: a slice of the input is scanned on its own and must reappear in the full output at the
+    offset the scan of everything before it produces — checked for the two halves around the 4 GiB mark"""
+    import torch
+    n = inp.numel()
+    cut = line_start(inp, (4 << 30) + 777)
+    if fam in LP_FAMILIES:
+        assert m == n
+        for s in (0, line_start(inp, (4 << 30) - SLICE), cut, line_start(inp, n - SLICE)):
+            e = min(n, line_start(inp, min(n, s + SLICE)))
+            want = oracle.scan(inp[s:e].cpu().numpy().tobytes())
+            assert out[s:e].cpu().numpy().tobytes() == want, (fam, s)
+        return
+    tmp = torch.empty(inp.numel() // 2 + inp.numel() // 8 + (4 << 20), dtype=torch.uint8, device="cuda")
+    at = 0
+    for lo, hi in ((0, cut), (cut, n)):
+        part = p.scan_tensor(inp[lo:hi], out=tmp)
+        k = part.numel()
+        assert torch.equal(out[at:at + k], part), (fam, lo)
+        e = line_start(inp, lo + SLICE)
+        want = oracle.scan(inp[lo:e].cpu().numpy().tobytes())
+        assert part[:len(want)].cpu().numpy().tobytes() == want, (fam, lo)
+        at += k
+    assert at == m
+
+
+def test_caesar_8gib_all_families():
+    """BASELINE configs[2]: '[a:b-y:zz:a]' DFT over 8 GiB; the whole output against an independent torch byte map"""
+    import torch
+    import corpora
+    inp = corpora.printable_lines(N, corpora.SEED0 + 3, "cuda")
+    want = torch.where((inp >= 97) & (inp <= 121), inp + 1, torch.where(inp == 122, torch.full_like(inp, 97), inp))
+    p = trre_amd.Program("[a:b-y:zz:a]", "dft")
+    out = torch.empty(N + N // 8, dtype=torch.uint8, device="cuda")
+    for fam in [trre_amd.KERNEL_AUTO] + p.allowed_kernels():
+        if fam == trre_amd.KERNEL_TILE_GEN:
+            continue                       # (40 GB/s class and two more 8 GiB workspaces: covered at 1 GiB)
+        p.set_kernel(fam)
+        got = p.scan_tensor(inp, out=out)
+        assert got.numel() == N and torch.equal(got, want), fam
+    p.set_kernel(trre_amd.KERNEL_AUTO)
+
+
+def test_cfg4_8gib_all_families():
+    """BASELINE configs[3]: '(cat:dog|dog:cat)' NFT over 8 GiB of its own corpus (word soup, ~10 % cat/dog tokens and
+    near-misses, > 64 M lines), every family the pattern admits, oracle-checked slices around the 4 GiB mark"""
+    import torch
+    import corpora
+    inp = corpora.cat_dog_soup(N, corpora.SEED0 + 4, "cuda")
+    assert int((inp == 10).sum()) >= 64 << 20
+    p = trre_amd.Program("(cat:dog|dog:cat)", "nft")
+    oracle = Oracle("(cat:dog|dog:cat)", "nft")
+    out = torch.empty(N + N // 8, dtype=torch.uint8, device="cuda")
+    fams = [trre_amd.KERNEL_AUTO] + [f for f in p.allowed_kernels() if f != trre_amd.KERNEL_TILE_GEN]
+    for fam in fams:
+        p.set_kernel(fam)
+        got = p.scan_tensor(inp, out=out)
+        check_slices(p, oracle, inp, out, got.numel(), p.info.kernel)
+    p.set_kernel(trre_amd.KERNEL_AUTO)
+
+
+def test_general_families_8gib():
+    """variable-length output beyond 2^32 bytes: an expanding DFT pattern (stream family) and an NFT pattern that
+    only the guided family runs"""
+    import torch
+    import corpora
+    inp = corpora.printable_lines(N, corpora.SEED0 + 2, "cuda")
+    out = torch.empty(N + N // 4, dtype=torch.uint8, device="cuda")
+    for pat, eng in (("a:xyz", "dft"), ("(a|b)*c:x", "nft")):
+        p = trre_amd.Program(pat, eng)
+        got = p.scan_tensor(inp, out=out)
+        check_slices(p, Oracle(pat, eng), inp, out, got.numel(), p.info.kernel)

@@ -48,17 +48,24 @@ def test_gpu_present_and_native_library_loaded():
         assert "libtrre_mi355x.so" in f.read()
 
 
-# golden (pattern, engine) pairs the product may refuse: none.  All 870 vectors generated from the compiled
-# reference run on the GPU (round 1 refused 60 of them: NFT patterns with '.' or wide ranges).
+# golden (pattern, engine) pairs the product may refuse: none.  All 900 vectors generated from the compiled
+# reference run on the GPU (round 1 refused 60 of its 870: NFT patterns with '.' or wide ranges); 18 of them are
+# runs on which the reference itself exits 1 (an epsilon cycle entered) and the scan reports TRRE_E_DIVERGES.
 REFUSED_GOLDEN = set()
 
 
 def test_golden_vectors_on_gpu():
-    n = n_guided = 0
+    n = n_guided = n_fail = 0
     for pat, name, data, engine, exp in golden_lib.cases():
         p = prog(pat, engine)
         if isinstance(p, trre_amd.TrreError):
             assert (pat, engine) in REFUSED_GOLDEN, (pat, engine, p)
+            continue
+        if exp is None:                     # the reference exits 1 here (epsilon cycle entered): so must the scan
+            with pytest.raises(trre_amd.TrreError) as e:
+                gpu_scan(p, data)
+            assert e.value.code == trre_amd.api.E_DIVERGES, (pat, name, engine)
+            n_fail += 1
             continue
         assert gpu_scan(p, data) == exp, (pat, name, engine)
         n += 1
@@ -68,7 +75,7 @@ def test_golden_vectors_on_gpu():
                 if fam in allowed(p):
                     assert gpu_scan(p, data, fam) == exp, (pat, name, fam)
                     n_guided += 1
-    assert n == 870 and n_guided > 500
+    assert n == 882 and n_fail == 18 and n_guided > 500
 
 
 _allowed = {}

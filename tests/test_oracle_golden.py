@@ -61,3 +61,19 @@ def test_oracle_equals_compiled_reference_on_fresh_inputs():
     for pat in corpus.CONFIG_PATTERNS + ["a:xyz", "[aie]:", "abc:2|ab:1"]:
         for eng in ("nft", "dft"):
             assert Oracle(pat, eng).scan(data) == ref_scan(pat, eng, data), (pat, eng)
+
+
+def test_inverted_bounds_are_the_lower_bound_only():
+    """'{2,1}' (upper bound below the lower one): the reference unrolls the two mandatory copies and no optional one
+    (trre_nft.c:458-485), i.e. 'x{2,1}' is 'xx'.  A fuzz run (tests/fuzz_oracle.py --seed 777) met '.{2,1}' inside a
+    large DFT pattern on which the compiled reference needs minutes and gigabytes (256-way branches squared) — slow,
+    not non-terminating — so the oracle and the product answer it; the error promise of DESIGN.md §2 is for real
+    non-termination only (epsilon cycles), which the 'eps_*' golden vectors pin."""
+    from oracle_lib import Oracle
+    import trre_amd
+    data = b"axyb ab axb axyzb\naxxb\n\naxyb"
+    for eng in ("nft", "dft"):
+        for a, b in (("a.{2,1}b:x", "a..b:x"), ("(c{2,1}:y|ab)", "(cc:y|ab)"), ("[ab]{3,2}:z", "[ab][ab][ab]:z")):
+            want = Oracle(b, eng).scan(data)
+            assert Oracle(a, eng).scan(data) == want, (a, eng)
+            assert trre_amd.Program(a, eng).info.nft_states == trre_amd.Program(b, eng).info.nft_states + 2   # (the iteration's two JOINs)

@@ -52,7 +52,7 @@ public:
         index_.emplace(init, 0);
         dft_.st.emplace_back();                           // start: finality is never evaluated
         for (size_t cur = 0; cur < lists_.size(); ++cur) {
-            if (dft_.st[cur].final) continue;             // left at once, its edges are never used
+            if (dft_.st[cur].final || dft_.st[cur].diverges) continue;   // left at once / never entered: its edges are never used
             expand((int32_t)cur);
         }
         return std::move(dft_);
@@ -136,7 +136,16 @@ private:
         // answers the probe too (the "." quirk) and the FIRST item's residual is
         // the final output
         ItemList probe;
-        step(l, 0, probe);
+        try {
+            step(l, 0, probe);
+        } catch (const Error& e) {
+            if (e.code != kErrEpsCycle) throw;
+            // The reference creates the state and then probes its finality (trre_dft.c:1148-1174): with an epsilon
+            // cycle behind one of its items that probe recurses for ever.  Reaching this state is what fails.
+            std::fill(mark_.begin(), mark_.end(), 0);
+            dft_.st[id].diverges = true;
+            return id;
+        }
         if (!probe.empty()) {
             dft_.st[id].final = true;
             dft_.st[id].final_out = probe[0].res;
@@ -148,11 +157,21 @@ private:
         for (int c = 1; c < 256; ++c) {
             if (c == '\n') continue;      // a line never holds NUL or '\n' (getline + C string)
             ItemList next;
-            step(lists_[id], c, next);    // lists_ may reallocate inside intern(): index, don't hold refs
+            try {
+                step(lists_[id], c, next);    // lists_ may reallocate inside intern(): index, don't hold refs
+            } catch (const Error& e) {
+                if (e.code != kErrEpsCycle) throw;
+                // the closure of this very step runs round an epsilon cycle: a table miss here never returns in the
+                // reference (the lazy construction only gets here when the input makes it take this edge)
+                std::fill(mark_.begin(), mark_.end(), 0);
+                dft_.st[id].edge[c].to = kEdgeDiverge;
+                continue;
+            }
             if (next.empty()) continue;   // dead edge
             std::string prefix = strip_common_prefix(next);
             const int32_t to = intern(next);
             DftEdge& e = dft_.st[id].edge[c];
+            if (dft_.st[to].diverges) { e.to = kEdgeDiverge; continue; }
             e.to = to;
             e.out = std::move(prefix);
         }
@@ -216,7 +235,7 @@ DftTables flatten_dft(const Dft& dft) {
     std::vector<int32_t> row_of(dft.st.size(), -1);
     std::vector<int32_t> state_of_row;
     for (size_t s = 0; s < dft.st.size(); ++s)
-        if (!dft.st[s].final) { row_of[s] = (int32_t)state_of_row.size(); state_of_row.push_back((int32_t)s); }
+        if (!dft.st[s].final && !dft.st[s].diverges) { row_of[s] = (int32_t)state_of_row.size(); state_of_row.push_back((int32_t)s); }
     t.n_rows = (uint32_t)state_of_row.size();
     if (t.n_rows >= (1u << 27)) throw Error(kErrTooBig, "error: too many table rows");
 
@@ -227,6 +246,7 @@ DftTables flatten_dft(const Dft& dft) {
         const DftState& s = dft.st[state_of_row[r]];
         for (int c = 0; c < 256; ++c) {
             const DftEdge& e = s.edge[c];
+            if (e.to == kEdgeDiverge) { full[r][c] = kEntDiverge; continue; }
             if (e.to < 0) { full[r][c] = kEntDead; continue; }
             const DftState& tgt = dft.st[e.to];
             if (tgt.final) full[r][c] = encode(kEntAccept, 0, e.out + tgt.final_out, pool);
@@ -282,7 +302,7 @@ DftTables flatten_dft(const Dft& dft) {
         for (uint32_t k = 0; k < t.n_cls && lp; ++k) {
             const uint64_t e = t.ent[(size_t)r * t.n_cls + k];
             const uint32_t kind = (uint32_t)e & 3u;
-            if (kind == kEntDead) continue;
+            if (kind == kEntDead || kind == kEntDiverge) continue;
             const int64_t d = delta[r] + out_len(e) - 1;
             if (d > 0) no_overrun = false;
             if (kind == kEntAccept) {
@@ -299,6 +319,7 @@ DftTables flatten_dft(const Dft& dft) {
         const uint64_t e = t.ent[t.cls[c]];
         const uint32_t kind = (uint32_t)e & 3u;
         if (kind == kEntDead) continue;
+        if (kind == kEntDiverge) { memoryless = false; continue; }
         if (kind == kEntAccept && ((e >> 2) & 7u) == 1) t.bytemap[c] = (uint8_t)(e >> 32);
         else memoryless = false;
     }

@@ -91,12 +91,15 @@ struct Nft {
 Nft build_nft(const Ast& ast, bool with_initial_join);
 
 // ---- deterministic transducer (eager subset construction) ---------------------
+constexpr int32_t kEdgeDead = -1, kEdgeDiverge = -2;
 struct DftEdge {
-    int32_t to = -1;          // -1 = dead
+    int32_t to = -1;          // -1 = dead; -2 = exploring this edge runs into an epsilon cycle: the reference's closure
+                              // recursion (trre_dft.c:874-907) never returns
     std::string out;          // output factored onto the edge (longest common prefix)
 };
 struct DftState {
     bool final = false;
+    bool diverges = false;           // its finality probe runs into an epsilon cycle: every edge into it diverges
     std::string final_out;
     std::array<DftEdge, 256> edge;   // only filled for non-final states
     bool expanded = false;
@@ -116,12 +119,12 @@ Dft determinize(const Nft& nft, const DftLimits& lim = DftLimits());
 // left immediately: shortest match, trre_dft.c:1120-1125).  Bytes with identical
 // columns share a class.  Entry (64 bit):
 //   [1:0]   kind      0 dead, 1 goto, 2 accept (edge output already includes the
-//                     target's final_out)
+//                     target's final_out), 3 the reference does not return from this edge (epsilon cycle)
 //   [4:2]   ilen      0..4 output bytes held inline in [63:32]; 7 = pooled:
 //                     [63:32] is a byte offset into the pool of a record
 //                     {u32 len, bytes...} (4-byte aligned)
 //   [31:5]  next row  (goto only)
-constexpr uint32_t kEntDead = 0, kEntGoto = 1, kEntAccept = 2;
+constexpr uint32_t kEntDead = 0, kEntGoto = 1, kEntAccept = 2, kEntDiverge = 3;
 constexpr uint32_t kIlenPooled = 7;
 constexpr uint32_t kClassEol = 0;      // '\n' and NUL: never inside a line
 

@@ -359,6 +359,8 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
     const trre::StreamTables& stt = is_guided(family) ? p->gt.fwd : p->stt;       // the stream-form tables this launch walks
     args.status = cx->d_status;
     args.cap = cap;
+    static const uint32_t emit_dbg = getenv("TRRE_EMIT_DBG") ? (uint32_t)atoi(getenv("TRRE_EMIT_DBG")) : 0u;
+    args.dbg = emit_dbg;
     // a mask scratch left by an earlier, smaller scan must not be used: the kernel asks for one again
     args.gscratch = cx->scratch_bytes >= (n + 32) * (size_t)p->mask_bytes ? cx->d_scratch : nullptr;
     const int chunk = is_stream(family) ? stream_chunk_bytes(family == TRRE_KERNEL_STREAM_LP ? 0 : 1)

@@ -56,6 +56,7 @@ struct ScanArgs {
     uint8_t* gscratch;       // NFT long-line mask scratch (or null)
     uint32_t* redo;          // window kernel: [0] = count, [1..] = lanes to redo with the general direct walker
     const uint8_t* rblob;    // guided families: tables of the backward pass (RevBlobHeader)
+    uint32_t dbg;            // experiments (TRRE_EMIT_DBG): 1 no global stores in the emit pass, 2 no ring writes; the output is void
     uint32_t lp_emit;        // emit pass of a length-preserving program without a count pass: a lane's output starts at
                              // the position of its first line start (output position == input position at line starts)
     uint8_t* sym_v0;         // guided families: one symbol per input byte, indexed like in_v0 (v-space); the
@@ -238,12 +239,12 @@ struct DftEngine {
         dft_line_lp(T, GlobalIn{a.in_v0, a.vend - 1}, PosOut{a.out_v0}, v, st);
     }
     template <class Sink>
-    TRRE_HD static int64_t line_gen_tile(const View& T, Lane&, const uint8_t* tin, Sink& s, int64_t q, int64_t, uint32_t&) {
-        return dft_line_gen(T, TileIn{tin}, s, q);
+    TRRE_HD static int64_t line_gen_tile(const View& T, Lane&, const uint8_t* tin, Sink& s, int64_t q, int64_t, uint32_t& st) {
+        return dft_line_gen(T, TileIn{tin}, s, q, st);
     }
     template <class Sink>
-    TRRE_HD static void line_gen_global(const View& T, Lane&, const ScanArgs& a, Sink& s, int64_t v, uint32_t&) {
-        dft_line_gen(T, GlobalIn{a.in_v0, a.vend - 1}, s, v);
+    TRRE_HD static void line_gen_global(const View& T, Lane&, const ScanArgs& a, Sink& s, int64_t v, uint32_t& st) {
+        dft_line_gen(T, GlobalIn{a.in_v0, a.vend - 1}, s, v, st);
     }
 };
 
@@ -541,6 +542,7 @@ TRRE_HD void stream_lane_lp(const ScanArgs& a, const StreamView& T, uint32_t n_c
         }
     }
     if (seen & kStrNul) status |= kStNul;
+    if (seen & kStrDiv) status |= kStDiverge;
     first = fs;
     last = ls;
     if (over && ls >= 0) {                    // the line that starts at ls leaves the tile: redo it from HBM
@@ -600,6 +602,7 @@ TRRE_HD void stream_lane_gen(const ScanArgs& a, const StreamView& T, uint32_t n_
         }
     }
     if (seen & kStrOvf) status |= kStOverflow;
+    if (seen & kStrDiv) status |= kStDiverge;
     if (over && ls >= 0) {                    // the line that starts at ls leaves the tile: redo it from HBM
         status |= kStLongLine;
         sink.n = mark;
@@ -721,6 +724,7 @@ struct Stage {
     uint32_t pb;         // bytes of it that are filled (0..3)
     uint32_t fp;         // everything below this stream offset has left for memory (multiple of 32)
     uint32_t skip;       // leading bytes of sector 0 that belong to whoever wrote before this lane's first byte
+    uint32_t dbg;
 };
 // start (or restart) at an arbitrary output address; bytes below it in its 32-byte sector are not ours
 TRRE_HD void stage_begin(Stage& s, uint8_t* buf, uint8_t* first_out_byte) {
@@ -739,7 +743,7 @@ TRRE_HD void stage_append_n4(Stage& s, uint32_t v, uint32_t n) {
     s.acc |= (uint64_t)v << (8u * s.pb);
     const uint32_t t = s.pb + n;          // <= 7: at most one dword completed
     if (t >= 4u) {
-        *reinterpret_cast<uint32_t*>(s.buf + (s.wp & (kRingBytes - 1u))) = (uint32_t)s.acc;
+        if (!(s.dbg & 2u)) *reinterpret_cast<uint32_t*>(s.buf + (s.wp & (kRingBytes - 1u))) = (uint32_t)s.acc;
         s.acc >>= 32;
         s.wp += 4u;
     }
@@ -767,8 +771,12 @@ TRRE_HD void stage_store_sector(Stage& s) {        // the sector at stream offse
     } else {
         const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src);
         const U128 q0{s32[0], s32[1], s32[2], s32[3]}, q1{s32[4], s32[5], s32[6], s32[7]};
-        *reinterpret_cast<U128*>(s.g0 + s.fp) = q0;
-        *reinterpret_cast<U128*>(s.g0 + s.fp + 16u) = q1;
+        if (!(s.dbg & 1u)) {
+            *reinterpret_cast<U128*>(s.g0 + s.fp) = q0;
+            *reinterpret_cast<U128*>(s.g0 + s.fp + 16u) = q1;
+        } else if (q0.x == 0x12345678u && q1.w == 0x9abcdef0u) {
+            *reinterpret_cast<U128*>(s.g0 + s.fp) = q0;
+        }
     }
     s.fp += 32u;
 }
@@ -828,6 +836,7 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
     const uint32_t o_of_lo = o;           // kMode 0: offset that corresponds to position lo
     uint32_t of = o;                      // everything below `of` has left the ring
     Stage S{};                            // kMode 2
+    S.dbg = a.dbg;
     if (kMode == 2) {
         if (a.lp_emit) {
             // no count pass: this lane's lines are written where they were read
@@ -1102,6 +1111,7 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
     else if (lo < a.vbeg) row = kSkipState * n_cls * 16u;             // filler then '\n' right before the input
     else row = (lo == a.vbeg || a.in_v0[lo - 1] == (uint8_t)'\n') ? 0u : kSkipState * n_cls * 16u;
     Stage S{};
+    S.dbg = a.dbg;
     if (kMode == 2) {
         if (a.lp_emit) {
             // no count pass: this lane's lines are written where they were read
@@ -1294,7 +1304,7 @@ struct LpwView {
     const U128* ent;         // [n_states][n_cls] entries of 16 bytes (delay <= 3) or 32 bytes
     uint32_t delay;
 };
-constexpr uint32_t kLpwEol = 64u, kLpwNul = 128u;
+constexpr uint32_t kLpwEol = 64u, kLpwNul = 128u, kLpwDiv = 256u;
 
 // position after the first '\n' at or after lo - 1 (the lane's first line start); >= hi: none
 TRRE_HD int64_t first_line_start_global(const ScanArgs& a, int64_t lo, int64_t hi) {

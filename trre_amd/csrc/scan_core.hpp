@@ -37,6 +37,12 @@ struct DftView {
 };
 
 TRRE_HD uint32_t ent_kind(uint64_t e) { return (uint32_t)e & 3u; }
+// kind 3: the reference never returns from this edge (epsilon cycle) — report it and treat the edge as dead
+TRRE_HD uint32_t ent_kind_st(uint64_t e, uint32_t& status) {
+    const uint32_t k = (uint32_t)e & 3u;
+    if (k == 3u) { status |= kStDiverge; return 0u; }
+    return k;
+}
 TRRE_HD uint32_t ent_ilen(uint64_t e) { return ((uint32_t)e >> 2) & 7u; }
 TRRE_HD uint32_t ent_next(uint64_t e) { return ((uint32_t)e >> 5); }
 TRRE_HD uint32_t ent_hi(uint64_t e) { return (uint32_t)(e >> 32); }
@@ -106,7 +112,7 @@ TRRE_HD int64_t dft_line_lp(const DftView& T, In in, Out out, int64_t p, uint32_
     for (;;) {
         const uint8_t c0 = in(p);
         uint64_t e = T.ent0[c0];
-        uint32_t kind = ent_kind(e);
+        uint32_t kind = ent_kind_st(e, status);
         if (kind == 0u) {
             if (c0 == (uint8_t)'\n') { out.put(p, (uint8_t)'\n'); return p; }
             if (c0 == 0) status |= kStNul;
@@ -129,7 +135,7 @@ TRRE_HD int64_t dft_line_lp(const DftView& T, In in, Out out, int64_t p, uint32_
             if (kind == 2u) { p = i; break; }                 // first final state: shortest match
             const uint8_t c = in(i);
             e = T.ent[(uint64_t)ent_next(e) * T.n_cls + T.cls[c]];
-            kind = ent_kind(e);
+            kind = ent_kind_st(e, status);
             if (kind == 0u) { out.put(p, c0); ++p; break; }   // dead (or end of line): copy one raw byte
         }
     }
@@ -143,11 +149,11 @@ TRRE_HD int64_t dft_line_lp(const DftView& T, In in, Out out, int64_t p, uint32_
 // Returns the position of the record's terminating '\n'.
 // -------------------------------------------------------------------------------------
 template <class In, class Sink>
-TRRE_HD int64_t dft_line_gen(const DftView& T, In in, Sink& sink, int64_t p) {
+TRRE_HD int64_t dft_line_gen(const DftView& T, In in, Sink& sink, int64_t p, uint32_t& status) {
     for (;;) {
         const uint8_t c0 = in(p);
         const uint64_t e0 = T.ent0[c0];
-        if (ent_kind(e0) == 0u) {
+        if (ent_kind_st(e0, status) == 0u) {
             if (c0 == (uint8_t)'\n') { sink.put((uint8_t)'\n'); return p; }
             if (c0 == 0) {
                 sink.put((uint8_t)'\n');
@@ -167,7 +173,7 @@ TRRE_HD int64_t dft_line_gen(const DftView& T, In in, Sink& sink, int64_t p) {
             ++i;
             if (ent_kind(e) == 2u) { ok = true; break; }
             e = T.ent[(uint64_t)ent_next(e) * T.n_cls + T.cls[in(i)]];
-            if (ent_kind(e) == 0u) { ok = false; break; }
+            if (ent_kind_st(e, status) == 0u) { ok = false; break; }
         }
         if (!ok) { sink.put(c0); ++p; continue; }
         if (Sink::kCountOnly) {

@@ -692,6 +692,7 @@ __global__ __launch_bounds__(kWtThreads) void k_stream_lpw(ScanArgs a, int64_t l
         TRRE_WAIT_VM(0);                      // no load may still be writing LDS when the wave ends
     }
     if (L.seen & kLpwNul) atomicOr(a.status, kStNul);
+    if (L.seen & kLpwDiv) atomicOr(a.status, kStDiverge);
 }
 
 // second launch of the window path: the few lanes that touch an end of the input, redone by the

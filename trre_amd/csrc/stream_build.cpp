@@ -41,7 +41,7 @@ namespace trre {
 namespace {
 
 struct Outcome {
-    enum Kind { Undecided, Fail, Accept } kind = Fail;
+    enum Kind { Undecided, Fail, Accept, Diverge } kind = Fail;      // Diverge: the reference does not return from this attempt
     std::string out;
     size_t consumed = 0;
 };
@@ -66,6 +66,7 @@ public:
         int32_t s = 0;
         for (size_t i = 0; i < w.size(); ++i) {
             const DftEdge& e = d_.st[s].edge[(uint8_t)w[i]];
+            if (e.to == kEdgeDiverge) { r.kind = Outcome::Diverge; r.out.clear(); return r; }
             if (e.to < 0) { r.kind = Outcome::Fail; r.out.clear(); return r; }
             r.out += e.out;
             s = e.to;
@@ -85,7 +86,7 @@ public:
         for (int c = 0; c < 256; ++c) used[c] = false;
         for (const DftState& st : d_.st)
             for (int c = 0; c < 256; ++c)
-                if (st.edge[c].to >= 0) used[c] = true;
+                if (st.edge[c].to >= 0 || st.edge[c].to == kEdgeDiverge) used[c] = true;
     }
 
 private:
@@ -224,10 +225,11 @@ private:
     }
 
     // resolve pending attempts from the left, exactly like the scan line loop
-    std::string resolve(std::string w, bool at_eol, std::string& out) {
+    std::string resolve(std::string w, bool at_eol, std::string& out, bool& diverges) {
         while (!w.empty()) {
             Outcome r = m_.attempt(w, at_eol);
             if (r.kind == Outcome::Undecided) break;
+            if (r.kind == Outcome::Diverge) { diverges = true; return std::string(); }
             if (r.kind == Outcome::Accept) {
                 out += r.out;
                 if (r.consumed > 0) { w.erase(0, r.consumed); continue; }
@@ -241,8 +243,10 @@ private:
 
     Cell transition(const std::string& w, int c) {
         Cell cell;
+        bool diverges = false;
         if (c == '\n' || c == 0) {
-            std::string rest = resolve(w, true, cell.out);
+            std::string rest = resolve(w, true, cell.out, diverges);
+            if (diverges) { cell.out.clear(); cell.diverge = true; cell.next = skip_; return cell; }
             if (!rest.empty()) throw GiveUp();           // cannot happen: at end of line everything is decided
             if (m_.tries_empty_tail()) {
                 Outcome r = m_.attempt(std::string(), true);
@@ -253,7 +257,8 @@ private:
             cell.eol = c == '\n';          // record end (a NUL only ends the line's content)
             return cell;
         }
-        std::string rest = resolve(w + (char)c, false, cell.out);
+        std::string rest = resolve(w + (char)c, false, cell.out, diverges);
+        if (diverges) { cell.out.clear(); cell.diverge = true; cell.next = skip_; return cell; }
         cell.next = intern(rest);
         if (cell.next == kOverflow) {
             // An attempt that is still undecided after max_pending bytes (a long run under a greedy loop).
@@ -323,7 +328,7 @@ private:
             key.reserve(n);
             for (uint32_t s = 0; s < n; ++s) {
                 const Cell& x = rows_[s][c];
-                key.push_back(std::to_string(x.next) + (x.copy_c ? "C" : "-") + (x.eol ? "E" : "-") + (x.ovf ? "O" : "-") + x.out);
+                key.push_back(std::to_string(x.next) + (x.copy_c ? "C" : "-") + (x.eol ? "E" : "-") + (x.ovf ? "O" : "-") + (x.diverge ? "D" : "-") + x.out);
             }
             auto hit = col_index.find(key);
             if (hit == col_index.end()) {
