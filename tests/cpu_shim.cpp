@@ -182,7 +182,7 @@ StreamView direct_view(const ScanArgs& a) {
     if (h.g16_bytes) T.g16 = a.blob + h.off_g16;
     return T;
 }
-template <bool kSym = false>
+template <int kSym = 0>
 void run_direct_lp(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
     const StreamView T = direct_view(a);
@@ -190,11 +190,11 @@ void run_direct_lp(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
     alignas(16) uint8_t ring[kRingStride];
     for (int64_t lane = n_lanes - 1; lane >= 0; --lane) {      // any order: lanes write disjoint bytes
         DirectLane L;
-        stream_direct_lane<0, false, kSym>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
+        stream_direct_lane<0, false, (kSym != 0)>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
     }
 }
 // length-preserving as the runtime launches it: the emit pass alone, lanes writing their lines in place
-template <bool kSym = false>
+template <int kSym = 0>
 void run_direct_lp_emit(ScanArgs a, int64_t lane_bytes, uint32_t& status, bool g16) {
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
     const StreamView T = direct_view(a);
@@ -205,19 +205,22 @@ void run_direct_lp_emit(ScanArgs a, int64_t lane_bytes, uint32_t& status, bool g
         DirectLane L;
         if (g16 && (h.flags & kFlagG16SlowBit)) g16_lane<2, kSym, true>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
         else if (g16) g16_lane<2, kSym, false>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
-        else stream_direct_lane<2, false, kSym>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
+        else stream_direct_lane<2, false, (kSym != 0)>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
     }
 }
 // backward pass of the guided families, lane by lane (any order: lanes write disjoint symbols)
-void run_rev_sweep(const ScanArgs& a, int64_t lane_bytes) {
+void run_rev_sweep(const ScanArgs& a, int64_t lane_bytes, bool packed) {
     const RevBlobHeader& h = *reinterpret_cast<const RevBlobHeader*>(a.rblob);
     const RevView T{a.rblob + h.off_wide};
-    const int64_t vtop = (a.vend + 63) & ~(int64_t)63;
+    const int64_t vtop = packed ? (a.vend + 127) & ~(int64_t)127 : (a.vend + 63) & ~(int64_t)63;
     const int64_t n_lanes = (vtop + lane_bytes - 1) / lane_bytes;
-    for (int64_t lane = 0; lane < n_lanes; ++lane) rev_sweep_lane(a, T, lane, lane_bytes);
+    for (int64_t lane = 0; lane < n_lanes; ++lane) {
+        if (packed) rev_sweep_lane<0, true>(a, T, lane, lane_bytes);
+        else rev_sweep_lane<0, false>(a, T, lane, lane_bytes);
+    }
 }
 // g16: walk the 16-byte entries (when the tables have them), like k_stream_g16
-template <bool kSym = false>
+template <int kSym = 0>
 void run_direct_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64_t& total_out, bool g16) {
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
     const StreamView T = direct_view(a);
@@ -228,7 +231,7 @@ void run_direct_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uin
         DirectLane L;
         if (g16 && (h.flags & kFlagG16SlowBit)) g16_lane<1, kSym, true>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
         else if (g16) g16_lane<1, kSym, false>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
-        else stream_direct_lane<1, false, kSym>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
+        else stream_direct_lane<1, false, (kSym != 0)>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
         cnt[lane] = L.count;
     }
     uint64_t run = 0;
@@ -240,7 +243,7 @@ void run_direct_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uin
         DirectLane L;
         if (g16 && (h.flags & kFlagG16SlowBit)) g16_lane<2, kSym, true>(a, T, h.n_cls, lane, lane_bytes, ring, base[lane], L, status);
         else if (g16) g16_lane<2, kSym, false>(a, T, h.n_cls, lane, lane_bytes, ring, base[lane], L, status);
-        else stream_direct_lane<2, false, kSym>(a, T, h.n_cls, lane, lane_bytes, ring, base[lane], L, status);
+        else stream_direct_lane<2, false, (kSym != 0)>(a, T, h.n_cls, lane, lane_bytes, ring, base[lane], L, status);
     }
 }
 
@@ -454,19 +457,20 @@ int shim_scan_guided(const uint8_t* rblob, const uint8_t* gblob, int family, int
     a.sym_v0 = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(sym.data()) + 63) & ~(uintptr_t)63);
     uint32_t status = 0;
     uint64_t total = 0;
-    const int64_t lane_bytes = geo == 0 ? 2048 : 64;
+    const int64_t lane_bytes = geo == 0 ? 2048 : 128;
     if ((family == 10 || family == 13 || family == 14) && cap < n) return -9;
-    run_rev_sweep(a, lane_bytes);
+    // like the runtime: symbols are packed two per byte when the backward DFA allows it and the walk uses the 16-byte entries
+    const bool has_g16 = reinterpret_cast<const StreamBlobHeader*>(gblob)->g16_bytes != 0;
+    const bool packed = reinterpret_cast<const RevBlobHeader*>(rblob)->sym_bits == 4 && has_g16 && (family == 10 || family == 11);
+    run_rev_sweep(a, lane_bytes, packed);
     if (family == 10 || family == 13 || family == 14) {
-        const bool g16 = reinterpret_cast<const StreamBlobHeader*>(gblob)->g16_bytes != 0;
-        if (family == 13) run_direct_lp<true>(a, lane_bytes, status);              // the LDS-ring walker (A/B variant)
-        else run_direct_lp_emit<true>(a, lane_bytes, status, family == 10 && g16);  // 14: on the 8-byte entries
+        if (family == 13) run_direct_lp<1>(a, lane_bytes, status);                  // the LDS-ring walker (A/B variant)
+        else if (packed) run_direct_lp_emit<2>(a, lane_bytes, status, true);
+        else run_direct_lp_emit<1>(a, lane_bytes, status, family == 10 && has_g16);  // 14: on the 8-byte entries
         total = n;
     }
-    else {
-        const bool g16 = family == 11 && reinterpret_cast<const StreamBlobHeader*>(gblob)->g16_bytes != 0;
-        run_direct_gen<true>(a, lane_bytes, status, total, g16);
-    }
+    else if (packed) run_direct_gen<2>(a, lane_bytes, status, total, true);
+    else run_direct_gen<1>(a, lane_bytes, status, total, family == 11 && has_g16);
     *status_out = status;
     *m = (size_t)total;
     if (total <= cap) std::memcpy(out, oa, (size_t)total);

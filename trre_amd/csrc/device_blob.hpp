@@ -53,7 +53,8 @@ struct RevBlobHeader {
     uint32_t off_cls;        // u8[256] byte -> class            } the compact form (inspection, host tests)
     uint32_t off_tab;        // u8[n_rev][n_cls] next state      }
     uint32_t off_wide;       // u8[n_rev][256] next state by raw byte (= the symbol left at the byte's position): what the kernel walks
-    uint32_t total_bytes, pad;
+    uint32_t total_bytes;
+    uint32_t sym_bits;       // 8: one symbol per input byte; 4: two per byte (n_rev <= 16)
 };
 static_assert(sizeof(RevBlobHeader) == 32, "header layout");
 

@@ -256,6 +256,7 @@ struct GuidedLimits {
 struct GuidedTables {
     bool ok = false;
     uint32_t n_rev = 0, n_cls = 0;          // backward DFA: states (= symbols) x byte classes
+    uint32_t sym_bits = 8;                  // 4: at most 16 states and a small forward table — symbols are stored two per byte
     std::array<uint8_t, 256> cls{};         // byte -> class; class 0 = '\n', class 1 = NUL
     std::vector<uint8_t> rev;               // [n_rev][n_cls] next state
     StreamTables fwd;                       // columns = symbols (fwd.cls is unused)

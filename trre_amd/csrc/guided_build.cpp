@@ -59,6 +59,7 @@ public:
         byte_classes(g);
         backward(g);
         forward(g);
+        g.sym_bits = (g.n_rev <= 16 && g.fwd.g16_ok) ? 4 : 8;
         g.ok = true;
         return g;
     }

@@ -21,11 +21,12 @@ void launch_stream_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t
 // direct stream kernels (no LDS tile); which: 0 length-preserving, 1 count, 2 emit
 int direct_ent_lds_bytes();
 int direct_block_threads();
-// sym: guided families — columns are the symbols of the backward pass (a.sym_v0)
+// sym: guided families — columns are the symbols of the backward pass (a.sym_v0): 1 one per byte, 2 packed two per byte
+// (16-byte entries only)
 void launch_direct_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, void* stream, int g16_bytes = 0,
-                          bool sym = false, bool g16_slow = true);
-// backward pass of the guided families: fills a.sym_v0[0 .. round_up(a.vend, 64))
-void launch_rev_sweep(const ScanArgs& a, int tab_bytes, int64_t lane_bytes, void* stream);
+                          int sym = 0, bool g16_slow = true);
+// backward pass of the guided families: fills a.sym_v0 for positions [0 .. round_up(a.vend, 64)) (packed: round_up(.., 128), two per byte)
+void launch_rev_sweep(const ScanArgs& a, int tab_bytes, int64_t lane_bytes, void* stream, bool packed);
 void launch_lpw_kernel(int ent_bytes, bool wide, bool direct_ent_in_lds, const ScanArgs& a, int64_t lane_bytes, void* stream);
 void launch_chunk_scan(const uint64_t* total, uint64_t* base, int64_t n_chunks, void* stream);
 void launch_bytemap(const ScanArgs& a, void* stream);

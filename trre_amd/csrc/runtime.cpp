@@ -213,6 +213,7 @@ void serialize_rev(const trre::GuidedTables& g, std::vector<uint8_t>& b) {
     h.magic = kMagicRev;
     h.n_rev = g.n_rev;
     h.n_cls = g.n_cls;
+    h.sym_bits = g.sym_bits;
     size_t off = sizeof h;
     h.off_cls = (uint32_t)off; off += 256;
     h.off_tab = (uint32_t)off; off += align_up(g.rev.size(), 16);
@@ -387,6 +388,8 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
     const bool direct = (is_stream(family) && stream_impl >= 1) || is_guided(family);
     const bool direct_ent_lds = stt.ok && stt.ent.size() * 8 <= (size_t)direct_ent_lds_bytes();
     const bool g16_slow = (stt.flags & kFlagG16Slow) != 0;
+    static const bool no_nib = getenv("TRRE_NO_NIBBLES") != nullptr;      // A/B: one symbol per byte
+    const int sym_mode = !is_guided(family) ? 0 : (p->gt.sym_bits == 4 && !no_nib && !getenv("TRRE_NO_G16") ? 2 : 1);
     if (direct) n_chunks = (args.vend + lane_bytes * direct_block_threads() - 1) / (lane_bytes * direct_block_threads());
 
     if (!is_gen(family) && cap < n) return TRRE_OK;   // finish() reports the capacity error
@@ -435,22 +438,22 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
         static const bool lp_ring = getenv("TRRE_LP_RING") != nullptr;
         static const bool no_g16 = getenv("TRRE_NO_G16") != nullptr;
         const int g16 = stt.g16_ok && !no_g16 ? (int)(stt.g16.size() * 4) : 0;
-        if (is_guided(family)) launch_rev_sweep(args, (int)p->gt.n_rev * 256, lane_bytes, stream);
+        if (is_guided(family)) launch_rev_sweep(args, (int)p->gt.n_rev * 256, lane_bytes, stream, sym_mode == 2);
         static const bool rev_only = getenv("TRRE_REV_DBG") != nullptr;       // experiments on the backward pass alone (its output may be void)
         if (is_guided(family) && rev_only) {
         } else if (lp_ring) {
-            launch_direct_kernel(0, direct_ent_lds, args, lane_bytes, n_chunks, stream, 0, is_guided(family));
+            launch_direct_kernel(0, direct_ent_lds, args, lane_bytes, n_chunks, stream, 0, sym_mode);
         } else {
             args.lp_emit = 1;
-            launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, is_guided(family), g16_slow);
+            launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, sym_mode, g16_slow);
         }
     } else if (direct) {
         static const bool no_g16 = getenv("TRRE_NO_G16") != nullptr;          // A/B: the 8-byte entries
         const int g16 = stt.g16_ok && !no_g16 ? (int)(stt.g16.size() * 4) : 0;
-        if (is_guided(family)) launch_rev_sweep(args, (int)p->gt.n_rev * 256, lane_bytes, stream);
-        launch_direct_kernel(1, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, is_guided(family), g16_slow);
+        if (is_guided(family)) launch_rev_sweep(args, (int)p->gt.n_rev * 256, lane_bytes, stream, sym_mode == 2);
+        launch_direct_kernel(1, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, sym_mode, g16_slow);
         launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);
-        launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, is_guided(family), g16_slow);
+        launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, sym_mode, g16_slow);
         pd.total_at = cx->d_chunk_base + n_chunks;
     } else if (family == TRRE_KERNEL_STREAM_LP) {
         launch_stream_kernel(0, ent_lds, args, n_chunks, stream);
@@ -720,29 +723,38 @@ int slot_reserve(DeviceState::HostSlot& hs, bool input, size_t bytes) {
     have = bytes;
     return TRRE_OK;
 }
-constexpr size_t kHostChunk = (size_t)64 << 20;
+constexpr size_t kHostChunk = (size_t)32 << 20;
 
 // Staging copies between the caller's pageable buffers and pinned memory are spread over a few threads:
 // one thread moves ~10 GB/s, a PCIe 5 x16 link ~55 GB/s each way.
 class CopyPool {
 public:
     static CopyPool& get() { static CopyPool pool; return pool; }
+    struct Job { int left = 0; };
     // copies n bytes with up to `ways` workers; returns when done
     void copy(void* dst, const void* src, size_t n, int ways) {
         if (n < ((size_t)4 << 20) || ways <= 1) { std::memcpy(dst, src, n); return; }
-        const size_t piece = (n / (size_t)ways + 4095) & ~(size_t)4095;
         Job job;
-        std::unique_lock<std::mutex> lk(mu_);
+        start(job, dst, src, n, ways);
+        wait(job);
+    }
+    // the same in two halves: queue the pieces, collect later (the job must stay alive until wait() returns)
+    void start(Job& job, void* dst, const void* src, size_t n, int ways) {
+        if (n == 0) return;
+        const size_t piece = std::max<size_t>((n / (size_t)(ways > 0 ? ways : 1) + 4095) & ~(size_t)4095, (size_t)1 << 20);
+        std::lock_guard<std::mutex> lk(mu_);
         for (size_t off = 0; off < n; off += piece) {
             queue_.push_back(Piece{&job, static_cast<uint8_t*>(dst) + off, static_cast<const uint8_t*>(src) + off, std::min(piece, n - off)});
             ++job.left;
         }
         cv_.notify_all();
+    }
+    void wait(Job& job) {
+        std::unique_lock<std::mutex> lk(mu_);
         done_.wait(lk, [&] { return job.left == 0; });
     }
 
 private:
-    struct Job { int left = 0; };
     struct Piece { Job* job; uint8_t* dst; const uint8_t* src; size_t n; };
     CopyPool() {
         unsigned hw = std::thread::hardware_concurrency();
@@ -788,16 +800,19 @@ int scan_host_on(trre_prog* p, DeviceState* st, const uint8_t* in, size_t n, uin
     const int fam = p->forced_family ? p->forced_family : auto_family(*p);
     const bool fixed_len = !is_gen(fam);              // output size == input size (unless a NUL forces a general family)
 
-    struct Chunk { size_t off = 0, len = 0, out_at = 0, m = 0; bool submitted = false, copying = false; };
+    struct Chunk { size_t off = 0, len = 0, out_at = 0, m = 0; bool submitted = false, copying = false, leaving = false, early = false; CopyPool::Job job; };
     Chunk ch[kHostSlots];
     size_t off = 0, total = 0;                        // input consumed, output produced (or needed)
+    size_t total_bound = 0;                           // length-preserving: output of everything submitted so far
     bool overflow = false;                            // the caller's buffer is too small: keep counting only
     int rc = TRRE_OK;
     auto abandon = [&](int code) -> int {             // leave nothing queued behind an error
         for (auto& hs : st->slot) { (void)hipStreamSynchronize(hs.stream); hs.ctx.pend = Pending(); }
+        for (Chunk& c : ch)
+            if (c.leaving) { CopyPool::get().wait(c.job); c.leaving = false; }
         return code;
     };
-    // stage chunk k in and queue its upload + scan
+    // stage chunk k in and queue its upload + scan (and, when the output size is known beforehand, its download)
     auto submit = [&](int b, size_t at, size_t len) -> int {
         DeviceState::HostSlot& hs = st->slot[b];
         int r = slot_reserve(hs, true, len);
@@ -806,47 +821,65 @@ int scan_host_on(trre_prog* p, DeviceState* st, const uint8_t* in, size_t n, uin
         if (r) return r;
         CopyPool::get().copy(hs.pin_in, in + at, len, kCopyWays);
         HIP_TRY(hipMemcpyAsync(hs.d_in, hs.pin_in, len, hipMemcpyHostToDevice, hs.stream));
-        ch[b] = Chunk();
-        ch[b].off = at; ch[b].len = len; ch[b].submitted = true;
-        return enqueue(p, st, &hs.ctx, fam, hs.d_in, len, hs.d_out, hs.out_cap, hs.stream);
+        ch[b].off = at; ch[b].len = len; ch[b].out_at = 0; ch[b].m = 0; ch[b].submitted = true; ch[b].early = false;
+        r = enqueue(p, st, &hs.ctx, fam, hs.d_in, len, hs.d_out, hs.out_cap, hs.stream);
+        if (r) return r;
+        if (fixed_len && !overflow && total_bound + len <= cap) {
+            // length-preserving: the output is `len` bytes unless a NUL turns up (then complete() downloads again)
+            HIP_TRY(hipMemcpyAsync(hs.pin_out, hs.d_out, len, hipMemcpyDeviceToHost, hs.stream));
+            ch[b].early = true;
+        }
+        total_bound += len;
+        return TRRE_OK;
     };
-    // wait for chunk b's scan, learn its output size, queue the download
+    // wait for chunk b's scan, learn its output size, queue the download (unless it is already there)
     auto complete = [&](int b) -> int {
         DeviceState::HostSlot& hs = st->slot[b];
         size_t m = 0;
         int r = finish(p, st, &hs.ctx, &m);
+        bool again = false;
         while (r == TRRE_E_CAPACITY) {                // the general families report the size they need
             r = slot_reserve(hs, false, m + 4096);
             if (r) return r;
             r = enqueue(p, st, &hs.ctx, fam, hs.d_in, ch[b].len, hs.d_out, hs.out_cap, hs.stream);
             if (!r) r = finish(p, st, &hs.ctx, &m);
+            again = true;
         }
         if (r) return r;
         ch[b].m = m;
         ch[b].out_at = total;
         if (!overflow && total + m > cap) overflow = true;
         if (!overflow && m) {
-            HIP_TRY(hipMemcpyAsync(hs.pin_out, hs.d_out, m, hipMemcpyDeviceToHost, hs.stream));
+            if (!(ch[b].early && m == ch[b].len && !again))
+                HIP_TRY(hipMemcpyAsync(hs.pin_out, hs.d_out, m, hipMemcpyDeviceToHost, hs.stream));
             ch[b].copying = true;
         }
         total += m;
         ch[b].submitted = false;
         return TRRE_OK;
     };
-    auto drain = [&](int b) -> int {                  // chunk output: pinned -> caller, once its download has finished
+    // chunk output: pinned -> caller, once its download has finished.  The copy is only started here (it runs on the
+    // pool's threads while this thread stages the next chunk in); settle() waits for it before the slot is used again.
+    auto drain = [&](int b) -> int {
         if (!ch[b].copying) return TRRE_OK;
         HIP_TRY(hipStreamSynchronize(st->slot[b].stream));
-        CopyPool::get().copy(out + ch[b].out_at, st->slot[b].pin_out, ch[b].m, kCopyWays);
+        CopyPool::get().start(ch[b].job, out + ch[b].out_at, st->slot[b].pin_out, ch[b].m, kCopyWays);
         ch[b].copying = false;
+        ch[b].leaving = true;
         return TRRE_OK;
     };
-    // software pipeline: submit(k) | complete(k-1) | drain(k-2)
+    auto settle = [&](int b) {
+        if (ch[b].leaving) { CopyPool::get().wait(ch[b].job); ch[b].leaving = false; }
+    };
+    // software pipeline, per iteration: chunk k is staged in by this thread (while chunk k-1 is on the device and chunk
+    // k-2 is copied out by the pool), uploaded and scanned; then chunk k-1 is collected and its copy-out started
     for (int64_t k = 0;; ++k) {
         const bool more = off < n;
         if (more) {
             const int b = (int)(k % kHostSlots);
             rc = drain(b);                            // the slot's previous output must have left its staging buffer
             if (rc) return abandon(rc);
+            settle(b);
             size_t len = n - off;                     // this chunk: up to kHostChunk bytes, extended to the end of its last line
             if (len > kHostChunk) {
                 const void* nl = std::memchr(in + off + kHostChunk - 1, '\n', n - off - (kHostChunk - 1));
@@ -859,14 +892,16 @@ int scan_host_on(trre_prog* p, DeviceState* st, const uint8_t* in, size_t n, uin
         if (k >= 1) {
             const int b1 = (int)((k - 1) % kHostSlots);
             if (ch[b1].submitted) { rc = complete(b1); if (rc) return abandon(rc); }
+            rc = drain(b1);
+            if (rc) return abandon(rc);
         }
-        if (k >= 2) { rc = drain((int)((k - 2) % kHostSlots)); if (rc) return abandon(rc); }
         if (!more) {
             bool busy = false;
             for (const Chunk& c : ch) busy = busy || c.submitted || c.copying;
             if (!busy) break;
         }
     }
+    for (int b = 0; b < kHostSlots; ++b) settle(b);
     if (out_len) *out_len = total;
     if (overflow) return fail(TRRE_E_CAPACITY, "error: output buffer too small");
     return TRRE_OK;

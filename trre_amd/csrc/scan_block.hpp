@@ -1097,7 +1097,9 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
 //   * tables without slow entries (kHasSlow = false: no transition emits more than 4 bytes) have no slow
 //     path at all.
 // =============================================================================================
-template <int kMode, bool kSym, bool kHasSlow>
+// kSym: 0 columns are byte classes; 1 / 2 (guided families) columns are the symbols the backward pass left, one per
+// byte / packed two per byte (backward DFAs of at most 16 states: half the symbol traffic).
+template <int kMode, int kSym, bool kHasSlow>
 TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, int64_t lane, int64_t lane_bytes, uint8_t* ring,
                       uint64_t out_base, DirectLane& L, uint32_t& status) {
     static_assert(kMode == 1 || kMode == 2, "count or emit");
@@ -1125,10 +1127,12 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
     uint64_t cnt = 0;
     uint32_t seen = 0;
     const int64_t vlast = (a.vend - 1) & ~(int64_t)15;               // the last readable aligned block
-    const int64_t slast = ((a.vend + 63) & ~(int64_t)63) - 16;       // the last block of symbols
+    // symbols: per byte — 16 bytes per 16-byte block; packed — 16 bytes per 32 input bytes (fetched for offsets 0 and 32 of a piece)
+    const int64_t slast = kSym == 2 ? (((a.vend + 127) & ~(int64_t)127) >> 1) - 16 : ((a.vend + 63) & ~(int64_t)63) - 16;
     auto sym_at = [&](int64_t vn) -> U128 {
         if (!kSym) return U128{};
-        return *reinterpret_cast<const U128*>(a.sym_v0 + (vn < slast ? vn : slast));
+        const int64_t at = kSym == 2 ? vn >> 1 : vn;
+        return *reinterpret_cast<const U128*>(a.sym_v0 + (at < slast ? at : slast));
     };
     // the careful version of one transition (a "slow" entry: more than 4 bytes or pooled text, from the 8-byte entry)
     auto slow_count = [&](uint32_t r, uint32_t k) -> uint32_t {
@@ -1166,8 +1170,10 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
     // one dword (4 input bytes) whose first byte lies rp bytes into the sub-range; kEnd: a lane may finish in it
     auto dword = [&](auto end_tag, const uint32_t w, const uint32_t sw, const uint32_t rp) {
         constexpr bool kEnd = decltype(end_tag)::value;
-        const uint32_t kk[4] = {kSym ? (sw & 0xffu) : (uint32_t)T.cls[w & 0xffu], kSym ? ((sw >> 8) & 0xffu) : (uint32_t)T.cls[(w >> 8) & 0xffu],
-                                kSym ? ((sw >> 16) & 0xffu) : (uint32_t)T.cls[(w >> 16) & 0xffu], kSym ? (sw >> 24) : (uint32_t)T.cls[w >> 24]};
+        uint32_t kk[4];
+        if (kSym == 2) { kk[0] = sw & 15u; kk[1] = (sw >> 4) & 15u; kk[2] = (sw >> 8) & 15u; kk[3] = (sw >> 12) & 15u; }
+        else if (kSym == 1) { kk[0] = sw & 0xffu; kk[1] = (sw >> 8) & 0xffu; kk[2] = (sw >> 16) & 0xffu; kk[3] = sw >> 24; }
+        else { kk[0] = T.cls[w & 0xffu]; kk[1] = T.cls[(w >> 8) & 0xffu]; kk[2] = T.cls[(w >> 16) & 0xffu]; kk[3] = T.cls[w >> 24]; }
         if (kMode == 1) {
             const uint32_t row0 = row;
             uint32_t c = 0, fl = 0;
@@ -1210,12 +1216,13 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
             }
         }
     };
+    // one 16-byte block; y: its symbols — four dwords (per byte) or the two dwords x, y (packed)
     auto block = [&](auto end_tag, const U128& b, const U128& y, const uint32_t rp) {
-        dword(end_tag, b.x, y.x, rp);
-        dword(end_tag, b.y, y.y, rp + 4u);
+        dword(end_tag, b.x, kSym == 2 ? (y.x & 0xffffu) : y.x, rp);
+        dword(end_tag, b.y, kSym == 2 ? (y.x >> 16) : y.y, rp + 4u);
         if (kMode == 2) stage_flush<false>(S);
-        dword(end_tag, b.z, y.z, rp + 8u);
-        dword(end_tag, b.w, y.w, rp + 12u);
+        dword(end_tag, b.z, kSym == 2 ? (y.y & 0xffffu) : y.z, rp + 8u);
+        dword(end_tag, b.w, kSym == 2 ? (y.y >> 16) : y.w, rp + 12u);
         if (kMode == 2) stage_flush<false>(S);
         TRRE_PIN(seen);
         if (kMode == 1) TRRE_PIN(cnt);
@@ -1223,7 +1230,22 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
     };
     // 64 bytes at a time; a lane's four 16-byte loads of a piece are issued together, one piece ahead
     U128 c0 = direct_load(a, lo), c1 = direct_load(a, lo + 16), c2 = direct_load(a, lo + 32), c3 = direct_load(a, lo + 48);
-    U128 s0 = sym_at(lo), s1 = sym_at(lo + 16), s2 = sym_at(lo + 32), s3 = sym_at(lo + 48);
+    U128 s0 = sym_at(lo), s1 = kSym == 2 ? sym_at(lo + 32) : sym_at(lo + 16), s2 = kSym == 1 ? sym_at(lo + 32) : U128{},
+         s3 = kSym == 1 ? sym_at(lo + 48) : U128{};
+    // the symbols of block q of the piece
+    auto sym_of = [&](int q) -> U128 {
+        U128 y{};
+        if (kSym == 1) {
+            y.x = q == 0 ? s0.x : (q == 1 ? s1.x : (q == 2 ? s2.x : s3.x));
+            y.y = q == 0 ? s0.y : (q == 1 ? s1.y : (q == 2 ? s2.y : s3.y));
+            y.z = q == 0 ? s0.z : (q == 1 ? s1.z : (q == 2 ? s2.z : s3.z));
+            y.w = q == 0 ? s0.w : (q == 1 ? s1.w : (q == 2 ? s2.w : s3.w));
+        } else if (kSym == 2) {
+            y.x = q == 0 ? s0.x : (q == 1 ? s0.z : (q == 2 ? s1.x : s1.z));
+            y.y = q == 0 ? s0.y : (q == 1 ? s0.w : (q == 2 ? s1.y : s1.w));
+        }
+        return y;
+    };
     for (int64_t v = lo;; v += 64) {
         if (!TRRE_WAVE_ANY(row != done_row)) break;
         const int64_t vn = v + 64;
@@ -1234,41 +1256,30 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
         if (TRRE_WAVE_ANY(vn < a.vbeg || vn + 64 > a.vend - 1)) {
             n0 = direct_load(a, vn); n1 = direct_load(a, vn + 16); n2 = direct_load(a, vn + 32); n3 = direct_load(a, vn + 48);
         }
-        const U128 t0 = sym_at(vn), t1 = sym_at(vn + 16), t2 = sym_at(vn + 32), t3 = sym_at(vn + 48);
+        const U128 t0 = sym_at(vn), t1 = kSym == 2 ? sym_at(vn + 32) : sym_at(vn + 16), t2 = kSym == 1 ? sym_at(vn + 32) : U128{},
+                   t3 = kSym == 1 ? sym_at(vn + 48) : U128{};
         const uint32_t rp = (uint32_t)(v - lo);
         if (TRRE_WAVE_ALL(rp + 64u < rhi)) {
             // interior piece: a lane finishes at the first record end whose '\n' is the last byte of its sub-range or lies
             // beyond it, and every byte of this piece lies before that last byte
 #pragma clang loop unroll(disable)
             for (int q = 0; q < 4; ++q) {
-                U128 b, y{};
+                U128 b;
                 b.x = q == 0 ? c0.x : (q == 1 ? c1.x : (q == 2 ? c2.x : c3.x));
                 b.y = q == 0 ? c0.y : (q == 1 ? c1.y : (q == 2 ? c2.y : c3.y));
                 b.z = q == 0 ? c0.z : (q == 1 ? c1.z : (q == 2 ? c2.z : c3.z));
                 b.w = q == 0 ? c0.w : (q == 1 ? c1.w : (q == 2 ? c2.w : c3.w));
-                if (kSym) {
-                    y.x = q == 0 ? s0.x : (q == 1 ? s1.x : (q == 2 ? s2.x : s3.x));
-                    y.y = q == 0 ? s0.y : (q == 1 ? s1.y : (q == 2 ? s2.y : s3.y));
-                    y.z = q == 0 ? s0.z : (q == 1 ? s1.z : (q == 2 ? s2.z : s3.z));
-                    y.w = q == 0 ? s0.w : (q == 1 ? s1.w : (q == 2 ? s2.w : s3.w));
-                }
-                block(std::false_type{}, b, y, rp + 16u * (uint32_t)q);
+                block(std::false_type{}, b, sym_of(q), rp + 16u * (uint32_t)q);
             }
         } else {
 #pragma clang loop unroll(disable)
             for (int q = 0; q < 4; ++q) {
-                U128 b, y{};
+                U128 b;
                 b.x = q == 0 ? c0.x : (q == 1 ? c1.x : (q == 2 ? c2.x : c3.x));
                 b.y = q == 0 ? c0.y : (q == 1 ? c1.y : (q == 2 ? c2.y : c3.y));
                 b.z = q == 0 ? c0.z : (q == 1 ? c1.z : (q == 2 ? c2.z : c3.z));
                 b.w = q == 0 ? c0.w : (q == 1 ? c1.w : (q == 2 ? c2.w : c3.w));
-                if (kSym) {
-                    y.x = q == 0 ? s0.x : (q == 1 ? s1.x : (q == 2 ? s2.x : s3.x));
-                    y.y = q == 0 ? s0.y : (q == 1 ? s1.y : (q == 2 ? s2.y : s3.y));
-                    y.z = q == 0 ? s0.z : (q == 1 ? s1.z : (q == 2 ? s2.z : s3.z));
-                    y.w = q == 0 ? s0.w : (q == 1 ? s1.w : (q == 2 ? s2.w : s3.w));
-                }
-                block(std::true_type{}, b, y, rp + 16u * (uint32_t)q);
+                block(std::true_type{}, b, sym_of(q), rp + 16u * (uint32_t)q);
             }
         }
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
@@ -1598,10 +1609,25 @@ TRRE_HD uint32_t rev_step4(const RevView& T, uint32_t& r, uint32_t w) {
     r = T.tab[(r << 8) | (w & 0xffu)]; y |= r;
     return y;
 }
-template <int kDbg = 0>
+// four symbols packed into 16 bits (backward DFAs of at most 16 states)
+TRRE_HD uint32_t rev_step4n(const RevView& T, uint32_t& r, uint32_t w) {
+    uint32_t y;
+    r = T.tab[(r << 8) | (w >> 24)]; y = r << 12;
+    r = T.tab[(r << 8) | ((w >> 16) & 0xffu)]; y |= r << 8;
+    r = T.tab[(r << 8) | ((w >> 8) & 0xffu)]; y |= r << 4;
+    r = T.tab[(r << 8) | (w & 0xffu)]; y |= r;
+    return y;
+}
+// symbols of a 16-byte block, packed: dword x = bytes 0..7, dword y = bytes 8..15
+TRRE_HD void rev_block_n(const RevView& T, uint32_t& r, const U128& b, uint32_t& x, uint32_t& y) {
+    const uint32_t h3 = rev_step4n(T, r, b.w), h2 = rev_step4n(T, r, b.z), h1 = rev_step4n(T, r, b.y), h0 = rev_step4n(T, r, b.x);
+    x = h0 | h1 << 16;
+    y = h2 | h3 << 16;
+}
+template <int kDbg = 0, bool kNib = false>
 TRRE_HD void rev_sweep_lane(const ScanArgs& a, const RevView& T, int64_t lane, int64_t lane_bytes) {
     const int64_t lo = lane * lane_bytes;
-    const int64_t vtop = (a.vend + 63) & ~(int64_t)63;
+    const int64_t vtop = kNib ? (a.vend + 127) & ~(int64_t)127 : (a.vend + 63) & ~(int64_t)63;
     int64_t hi = lo + lane_bytes;
     if (hi > vtop) hi = vtop;
     if (lo >= hi) return;
@@ -1637,21 +1663,43 @@ TRRE_HD void rev_sweep_lane(const ScanArgs& a, const RevView& T, int64_t lane, i
             }
         }
     }
-    // the lane's own pieces, highest first; the piece below is requested before this one is walked
-    auto fetch = [&](int64_t v, U128& b0, U128& b1, U128& b2, U128& b3) {
-        const int64_t vv = v >= lo ? v : lo;              // (the fetch below the lane's first piece is not used)
-        const U128* src = reinterpret_cast<const U128*>(a.in_v0 + vv);
-        if (TRRE_WAVE_ANY(vv < a.vbeg || vv + 64 > a.vend - 1)) {
-            b0 = direct_load(a, vv); b1 = direct_load(a, vv + 16); b2 = direct_load(a, vv + 32); b3 = direct_load(a, vv + 48);
-        } else {
-            b0 = src[0]; b1 = src[1]; b2 = src[2]; b3 = src[3];
+    // The lane's own pieces, highest first.  A wave whose 64 sub-ranges lie wholly inside the input takes the loop
+    // whose loads and stores are unconditional — the piece below is requested before this one is walked, and with
+    // a fixed number of memory operations per iteration the wait for it can leave the previous piece's stores in
+    // flight (s_waitcnt vmcnt(N) counts instructions: a conditional one forces vmcnt(0), i.e. every piece would
+    // wait for its own stores).  Waves at an end of the input take the patched loads (direct_load).
+    if (kNib) {
+        // packed symbols: 128 input bytes -> 64 bytes of symbols per piece (lane_bytes is a multiple of 128)
+        auto fetch8 = [&](int64_t v, U128 (&b)[8], bool interior) {
+            const int64_t vv = v >= lo ? v : lo;
+            if (interior) {
+                const U128* src = reinterpret_cast<const U128*>(a.in_v0 + vv);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) b[k] = src[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) b[k] = direct_load(a, vv + 16 * k);
+            }
+        };
+        const bool interior = TRRE_WAVE_ALL(lo >= a.vbeg && lo + lane_bytes + 128 <= a.vend - 1 && hi == lo + lane_bytes);
+        U128 b[8];
+        fetch8(hi - 128, b, interior);
+        for (int64_t v = hi - 128; v >= lo; v -= 128) {
+            U128 nx[8];
+            fetch8(v - 128, nx, interior);
+            U128 y[4];
+            rev_block_n(T, r, b[7], y[3].z, y[3].w); rev_block_n(T, r, b[6], y[3].x, y[3].y);
+            rev_block_n(T, r, b[5], y[2].z, y[2].w); rev_block_n(T, r, b[4], y[2].x, y[2].y);
+            rev_block_n(T, r, b[3], y[1].z, y[1].w); rev_block_n(T, r, b[2], y[1].x, y[1].y);
+            rev_block_n(T, r, b[1], y[0].z, y[0].w); rev_block_n(T, r, b[0], y[0].x, y[0].y);
+            U128* dst = reinterpret_cast<U128*>(a.sym_v0 + (v >> 1));
+            dst[0] = y[0]; dst[1] = y[1]; dst[2] = y[2]; dst[3] = y[3];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) b[k] = nx[k];
         }
-    };
-    U128 b0, b1, b2, b3;
-    fetch(hi - 64, b0, b1, b2, b3);
-    for (int64_t v = hi - 64; v >= lo; v -= 64) {
-        U128 n0, n1, n2, n3;
-        fetch(v - 64, n0, n1, n2, n3);
+        return;
+    }
+    auto walk_piece = [&](const U128& b0, const U128& b1, const U128& b2, const U128& b3, int64_t v) {
         U128 y0, y1, y2, y3;
         if (kDbg != 2) {
         y3.w = rev_step4(T, r, b3.w); y3.z = rev_step4(T, r, b3.z); y3.y = rev_step4(T, r, b3.y); y3.x = rev_step4(T, r, b3.x);
@@ -1663,6 +1711,28 @@ TRRE_HD void rev_sweep_lane(const ScanArgs& a, const RevView& T, int64_t lane, i
         if (kDbg == 1) { if (y0.x == 0x12345678u && y3.w == 0x9abcdef0u) dst[0] = y1; }      // experiment: no stores
         else if (kDbg == 2) { dst[0] = b0; dst[1] = b1; dst[2] = b2; dst[3] = b3; }               // experiment: no walk
         else { dst[0] = y0; dst[1] = y1; dst[2] = y2; dst[3] = y3; }
+    };
+    if (TRRE_WAVE_ALL(lo >= a.vbeg && lo + lane_bytes + 64 <= a.vend - 1 && hi == lo + lane_bytes)) {
+        const U128* src = reinterpret_cast<const U128*>(a.in_v0 + hi - 64);
+        U128 b0 = src[0], b1 = src[1], b2 = src[2], b3 = src[3];
+        for (int64_t v = hi - 64; v >= lo; v -= 64) {
+            const U128* nx = reinterpret_cast<const U128*>(a.in_v0 + (v - 64 >= lo ? v - 64 : lo));     // (the last fetch is not used)
+            const U128 n0 = nx[0], n1 = nx[1], n2 = nx[2], n3 = nx[3];
+            walk_piece(b0, b1, b2, b3, v);
+            b0 = n0; b1 = n1; b2 = n2; b3 = n3;
+        }
+        return;
+    }
+    auto fetch = [&](int64_t v, U128& b0, U128& b1, U128& b2, U128& b3) {
+        const int64_t vv = v >= lo ? v : lo;              // (the fetch below the lane's first piece is not used)
+        b0 = direct_load(a, vv); b1 = direct_load(a, vv + 16); b2 = direct_load(a, vv + 32); b3 = direct_load(a, vv + 48);
+    };
+    U128 b0, b1, b2, b3;
+    fetch(hi - 64, b0, b1, b2, b3);
+    for (int64_t v = hi - 64; v >= lo; v -= 64) {
+        U128 n0, n1, n2, n3;
+        fetch(v - 64, n0, n1, n2, n3);
+        walk_piece(b0, b1, b2, b3, v);
         b0 = n0; b1 = n1; b2 = n2; b3 = n3;
     }
 }

@@ -413,7 +413,7 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_direct(ScanArgs a, in
 
 // Count / emit passes over the 16-byte entries of a small table (front.hpp): the whole table in LDS.
 //   smem: cls[256] | g16[g16_room] | pooled text (2 KiB, when the pool fits) | staging[threads] | 64
-template <int kMode, bool kSym, bool kHasSlow>
+template <int kMode, int kSym, bool kHasSlow>
 __global__ __launch_bounds__(kDirectThreads) void k_stream_g16(ScanArgs a, int64_t lane_bytes, int g16_room) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
@@ -743,7 +743,7 @@ void launch_direct_t(bool ent_lds, const ScanArgs& a, int64_t lane_bytes, int64_
 }
 int direct_ent_lds_bytes() { return kDirectEntBytes; }
 int direct_block_threads() { return kDirectThreads; }
-template <bool kSym, bool kHasSlow>
+template <int kSym, bool kHasSlow>
 void launch_g16(int which, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, hipStream_t s, int g16_bytes) {
     const int room = (g16_bytes + 15) / 16 * 16;
     const int lds = 256 + room + kDirectPoolSmall + kDirectThreads * kRingStride + 64;
@@ -753,28 +753,30 @@ void launch_g16(int which, const ScanArgs& a, int64_t lane_bytes, int64_t n_bloc
     if (which == 1) hipLaunchKernelGGL((k_stream_g16<1, kSym, kHasSlow>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds_count, s, a, lane_bytes, room);
     else hipLaunchKernelGGL((k_stream_g16<2, kSym, kHasSlow>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds, s, a, lane_bytes, room);
 }
-template <bool kSym>
+template <int kSym>
 void launch_direct_sym(int which, bool ent_in_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, hipStream_t s, int g16_bytes, bool g16_slow) {
     if (g16_bytes > 0 && which != 0) {
         if (g16_slow) launch_g16<kSym, true>(which, a, lane_bytes, n_blocks, s, g16_bytes);
         else launch_g16<kSym, false>(which, a, lane_bytes, n_blocks, s, g16_bytes);
         return;
     }
-    if (which == 0) launch_direct_t<0, kSym>(ent_in_lds, a, lane_bytes, n_blocks, s);
-    else if (which == 1) launch_direct_t<1, kSym>(ent_in_lds, a, lane_bytes, n_blocks, s);
-    else launch_direct_t<2, kSym>(ent_in_lds, a, lane_bytes, n_blocks, s);
+    constexpr bool kS = kSym != 0;       // (the 8-byte-entry walkers know one symbol per byte only: the runtime packs symbols for 16-byte tables)
+    if (which == 0) launch_direct_t<0, kS>(ent_in_lds, a, lane_bytes, n_blocks, s);
+    else if (which == 1) launch_direct_t<1, kS>(ent_in_lds, a, lane_bytes, n_blocks, s);
+    else launch_direct_t<2, kS>(ent_in_lds, a, lane_bytes, n_blocks, s);
 }
-void launch_direct_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, void* stream, int g16_bytes, bool sym,
+void launch_direct_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, void* stream, int g16_bytes, int sym,
                           bool g16_slow) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (sym) launch_direct_sym<true>(which, ent_in_lds, a, lane_bytes, n_blocks, s, g16_bytes, g16_slow);
-    else launch_direct_sym<false>(which, ent_in_lds, a, lane_bytes, n_blocks, s, g16_bytes, g16_slow);
+    if (sym == 2 && g16_bytes > 0 && which != 0) launch_direct_sym<2>(which, ent_in_lds, a, lane_bytes, n_blocks, s, g16_bytes, g16_slow);
+    else if (sym) launch_direct_sym<1>(which, ent_in_lds, a, lane_bytes, n_blocks, s, g16_bytes, g16_slow);
+    else launch_direct_sym<0>(which, ent_in_lds, a, lane_bytes, n_blocks, s, g16_bytes, g16_slow);
 }
 
 // ---- backward pass of the guided families: one symbol per input byte (rev_sweep_lane) -------------------
 constexpr int kRevThreads = 256;
 
-template <int kDbg>
+template <int kDbg, bool kNib>
 __global__ __launch_bounds__(kRevThreads) void k_rev_sweep(ScanArgs a, int64_t lane_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];    // tab[n_rev][256]: at most 64 KiB
     const RevBlobHeader& h = *reinterpret_cast<const RevBlobHeader*>(a.rblob);
@@ -783,18 +785,20 @@ __global__ __launch_bounds__(kRevThreads) void k_rev_sweep(ScanArgs a, int64_t l
     for (int k = threadIdx.x; k < (int)h.n_rev * 16; k += kRevThreads) d[k] = e[k];
     __syncthreads();
     const RevView T{smem};
-    rev_sweep_lane<kDbg>(a, T, (int64_t)blockIdx.x * kRevThreads + threadIdx.x, lane_bytes);
+    rev_sweep_lane<kDbg, kNib>(a, T, (int64_t)blockIdx.x * kRevThreads + threadIdx.x, lane_bytes);
 }
-void launch_rev_sweep(const ScanArgs& a, int tab_bytes, int64_t lane_bytes, void* stream) {
+void launch_rev_sweep(const ScanArgs& a, int tab_bytes, int64_t lane_bytes, void* stream, bool packed) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int64_t vtop = (a.vend + 63) & ~(int64_t)63;
+    const int64_t vtop = packed ? (a.vend + 127) & ~(int64_t)127 : (a.vend + 63) & ~(int64_t)63;
     const int64_t n_lanes = (vtop + lane_bytes - 1) / lane_bytes;
     const dim3 grid((unsigned)((n_lanes + kRevThreads - 1) / kRevThreads));
     static const int dbg = getenv("TRRE_REV_DBG") ? atoi(getenv("TRRE_REV_DBG")) : 0;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rev_sweep<0>), hipFuncAttributeMaxDynamicSharedMemorySize, tab_bytes);
-    if (dbg == 1) hipLaunchKernelGGL(k_rev_sweep<1>, grid, dim3(kRevThreads), tab_bytes, s, a, lane_bytes);
-    else if (dbg == 2) hipLaunchKernelGGL(k_rev_sweep<2>, grid, dim3(kRevThreads), tab_bytes, s, a, lane_bytes);
-    else hipLaunchKernelGGL(k_rev_sweep<0>, grid, dim3(kRevThreads), tab_bytes, s, a, lane_bytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rev_sweep<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, tab_bytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rev_sweep<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, tab_bytes);
+    if (packed) hipLaunchKernelGGL((k_rev_sweep<0, true>), grid, dim3(kRevThreads), tab_bytes, s, a, lane_bytes);
+    else if (dbg == 1) hipLaunchKernelGGL((k_rev_sweep<1, false>), grid, dim3(kRevThreads), tab_bytes, s, a, lane_bytes);
+    else if (dbg == 2) hipLaunchKernelGGL((k_rev_sweep<2, false>), grid, dim3(kRevThreads), tab_bytes, s, a, lane_bytes);
+    else hipLaunchKernelGGL((k_rev_sweep<0, false>), grid, dim3(kRevThreads), tab_bytes, s, a, lane_bytes);
 }
 
 int stream_chunk_bytes(int which) { return which == 0 ? GeoStream::CHUNK : GeoStreamGen::CHUNK; }
