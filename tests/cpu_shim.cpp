@@ -247,37 +247,6 @@ void run_direct_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uin
     }
 }
 
-// large tables in sparse form: count, scan, emit — lane by lane
-void run_sparse_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64_t& total_out) {
-    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
-    SparseView T;
-    T.cls = a.blob + h.off_cls;
-    T.rec = reinterpret_cast<const uint64_t*>(a.blob + h.off_sp_rec);
-    T.dense = reinterpret_cast<const uint64_t*>(a.blob + h.off_sp_dense);
-    T.xent = reinterpret_cast<const uint64_t*>(a.blob + h.off_sp_x);
-    T.ppool = reinterpret_cast<const uint64_t*>(a.blob + h.off_sp_p);
-    T.text.pool = a.blob + h.off_pool;
-    T.text.long_pool = h.max_out >= 255u;
-    T.n_dense = h.sp_dense_states;
-    T.n_cls = h.n_cls;
-    const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
-    alignas(16) uint8_t ring[kSparseRing + 8];
-    std::vector<uint64_t> cnt(n_lanes), base(n_lanes);
-    for (int64_t lane = 0; lane < n_lanes; ++lane) {
-        DirectLane L;
-        sparse_lane<1>(a, T, lane, lane_bytes, ring, 0, L, status);
-        cnt[lane] = L.count;
-    }
-    uint64_t run = 0;
-    for (int64_t lane = 0; lane < n_lanes; ++lane) { base[lane] = run; run += cnt[lane]; }
-    total_out = run;
-    if (run > a.cap) { status |= kStCapacity; return; }
-    for (int64_t lane = n_lanes - 1; lane >= 0; --lane) {
-        DirectLane L;
-        sparse_lane<2>(a, T, lane, lane_bytes, ring, base[lane], L, status);
-    }
-}
-
 // Host emulation of the window kernel (k_stream_lpw): 64 lanes in lockstep over an
 // emulated pair of LDS tiles, the same lane / mover code as the device.
 template <bool kWide>
@@ -392,7 +361,6 @@ int run_family(int family, ScanArgs& a, uint32_t& status, uint64_t& total) {
 extern "C" {
 
 // family: 1 bytemap, 2 tile LP, 3 tile general, 4 stream LP (in place), 5 stream general.
-// 22 stream general on the sparse form of a large table (-5 when the tables have none),
 // 20 / 21 stream LP by the emit pass alone (16-byte / 8-byte entries),
 // 8 positional-window stream LP, 9 direct stream general on the 8-byte entries (7 prefers the 16-byte ones), 6 direct stream LP, 7 direct stream general (geo: 0 -> 2048-byte lanes, 1 -> 48-byte lanes).
 // geo: 0 production, 1 tiny.
@@ -418,7 +386,7 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
     a.gscratch = want_scratch ? scratch.data() : nullptr;
     uint32_t status = 0;
     uint64_t total = 0;
-    if (family != 3 && family != 5 && family != 7 && family != 9 && family != 22 && cap < n) return -9;
+    if (family != 3 && family != 5 && family != 7 && family != 9 && cap < n) return -9;
     if (family == 1) { run_bytemap(a, status); total = n; }
     else if (family == 8) {
         if (reinterpret_cast<const StreamBlobHeader*>(blob)->lpw_bytes == 0) return -5;
@@ -426,10 +394,6 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
         if (reinterpret_cast<uintptr_t>(a.out_v0) & 15u) run_direct_lp<>(a, geo == 0 ? 2048 : 48, status);
         else run_lpw(a, geo == 0 ? 2048 : 64, status);
         total = n;
-    }
-    else if (family == 22) {                           // large tables in sparse form
-        if (reinterpret_cast<const StreamBlobHeader*>(blob)->sp_sparse_states == 0) return -5;
-        run_sparse_gen(a, geo == 0 ? 2048 : 48, status, total);
     }
     else if (family == 6) { run_direct_lp<>(a, geo == 0 ? 2048 : 48, status); total = n; }
     else if (family == 20 || family == 21) {          // stream LP as the runtime launches it without a window form: emit pass alone

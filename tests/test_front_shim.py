@@ -52,10 +52,6 @@ def test_golden_vectors_tiny_geometry():
             continue
         assert shim_lib.scan_like_runtime(p, data, geo=1) == exp, (pat, name, engine)
         n += 1
-        if len(pat) > 1000:               # the 1000-key dictionary: the sparse form is what the runtime launches
-            assert has_sparse_form(p)
-            for geo in (0, 1):
-                assert shim_lib.scan_like_runtime(p, data, geo=geo, family=shim_lib.STREAM_SPARSE) == exp, (name, engine, geo)
         if engine == "nft":
             # (the backward DFA of the 1000-key dictionary has more than 256 states: it runs on its folded stream table)
             assert p.info.guided_rev_states or len(pat) > 1000, (pat, "no guided tables")
@@ -104,15 +100,7 @@ def shim_families(p):
         fams += [6, 8, shim_lib.STREAM_LP_EMIT, shim_lib.STREAM_LP_EMIT8]      # 7/9 direct walkers of the general one)
     if 5 in fams:
         fams += [7, 9]
-        if has_sparse_form(p):
-            fams.append(shim_lib.STREAM_SPARSE)
     return fams + guided_families(p)
-
-
-def has_sparse_form(p):
-    import struct
-    blob = p.export_stream_tables()
-    return len(blob) >= 96 and struct.unpack_from("<24I", blob, 0)[17] != 0
 
 
 def test_unaligned_buffers():
@@ -251,7 +239,6 @@ def test_dictionary_config_through_the_fold():
     for eng in ("dft", "nft"):
         p = trre_amd.Program(pat, eng)
         assert p.info.stream_states > 100 and p.info.kernel == trre_amd.KERNEL_STREAM_GEN
-        assert has_sparse_form(p)         # what the runtime launches for a table of this size
         want = Oracle(pat, eng).scan(data)
         for fam in shim_families(p):
             assert shim_lib.scan_like_runtime(p, data, geo=0, family=fam) == want, (eng, fam)

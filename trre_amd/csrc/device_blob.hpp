@@ -43,15 +43,8 @@ struct StreamBlobHeader {
     uint32_t total_bytes, max_out;
     uint32_t off_lpw, lpw_bytes, lpw_delay;   // window form (0 bytes when not available)
     uint32_t off_g16, g16_bytes;              // 16-byte count / emit entries (0 bytes when not available)
-    // sparse form (front.hpp, StreamTables::sp_*): 0 sparse states when not available
-    uint32_t sp_dense_states, sp_sparse_states;
-    uint32_t off_sp_dense;   // u64[sp_dense_states][n_cls]
-    uint32_t off_sp_rec;     // u64[sp_sparse_states]
-    uint32_t off_sp_x, sp_x_count;   // u64[]
-    uint32_t off_sp_p;       // u64[sp_sparse_states]
-    uint32_t pad;
 };
-static_assert(sizeof(StreamBlobHeader) == 96, "header layout");
+static_assert(sizeof(StreamBlobHeader) == 64, "header layout");
 
 // backward pass of the guided families (guided_build.cpp): a DFA read right to left
 constexpr uint32_t kMagicRev = 0x31525254u;   // "TRR1"

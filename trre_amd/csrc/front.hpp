@@ -186,20 +186,6 @@ struct StreamTables {
     // more than 4 bytes or pooled text — handled from the 8-byte entry
     bool g16_ok = false;
     std::vector<uint32_t> g16;              // [n_states][n_cls][4]
-    // Sparse form for large tables (a dictionary: thousands of states, almost all of them deep inside a key with one
-    // or two ways on).  States are renumbered: [0, sp_dense_states) keep their rows of 8-byte entries (`next` = new
-    // state id), every other state s is one 64-bit record
-    //   [12:0] f   [25:13] n1   [38:26] n2   [43:39] k1   [48:44] k2   [52:49] plen   [53] x1   [54] x2
-    // "on class k1 (k2) go to state n1 (n2) without output — or, with x1 (x2), take entry sp_x[n1] (sp_x[n2]); on any
-    // other class emit the plen bytes sp_p[s] and behave as state f on the same byte": the Aho-Corasick shape of the
-    // folded scan loop (a failed attempt flushes its first bytes raw and what is left is a shorter pending string).
-    // The records live in LDS, so only the few shallow rows and the completing entries are fetched through the caches.
-    bool sp_ok = false;
-    uint32_t sp_dense_states = 0;
-    std::vector<uint64_t> sp_dense;         // [sp_dense_states][n_cls]
-    std::vector<uint64_t> sp_rec;           // [n_states - sp_dense_states]
-    std::vector<uint64_t> sp_x;             // entries of exceptions that emit or carry flags
-    std::vector<uint64_t> sp_p;             // [n_states - sp_dense_states] the bytes a fallback emits (at most 8)
 };
 StreamTables build_stream_dft(const Dft& dft, const StreamLimits& lim = StreamLimits());
 StreamTables build_stream_nft(const Nft& nft, const StreamLimits& lim = StreamLimits());

@@ -25,8 +25,6 @@ int direct_block_threads();
 // (16-byte entries only)
 void launch_direct_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, void* stream, int g16_bytes = 0,
                           int sym = 0, bool g16_slow = true);
-// large stream tables in sparse form (StreamTables::sp_*); which: 1 count, 2 emit; n_blocks: 256-lane chunks
-void launch_sparse_kernel(int which, const ScanArgs& a, int n_records, int64_t lane_bytes, int64_t n_blocks, void* stream);
 // backward pass of the guided families: fills a.sym_v0 for positions [0 .. round_up(a.vend, 64)) (packed: round_up(.., 128), two per byte)
 void launch_rev_sweep(const ScanArgs& a, int tab_bytes, int64_t lane_bytes, void* stream, bool packed);
 void launch_lpw_kernel(int ent_bytes, bool wide, bool direct_ent_in_lds, const ScanArgs& a, int64_t lane_bytes, void* stream);

@@ -196,15 +196,6 @@ void serialize_stream(const trre::StreamTables& t, std::vector<uint8_t>& b) {
     h.off_lpw = (uint32_t)off; h.lpw_bytes = (uint32_t)(t.lpw.size() * 4); h.lpw_delay = t.lpw_delay; off += t.lpw.size() * 4;
     off = align_up(off, 16);
     h.off_g16 = (uint32_t)off; h.g16_bytes = (uint32_t)(t.g16.size() * 4); off += t.g16.size() * 4;
-    off = align_up(off, 16);
-    if (t.sp_ok) {
-        h.sp_dense_states = t.sp_dense_states;
-        h.sp_sparse_states = (uint32_t)t.sp_rec.size();
-        h.off_sp_dense = (uint32_t)off; off += t.sp_dense.size() * 8;
-        h.off_sp_rec = (uint32_t)off; off += align_up(t.sp_rec.size() * 8, 16);
-        h.off_sp_x = (uint32_t)off; h.sp_x_count = (uint32_t)t.sp_x.size(); off += t.sp_x.size() * 8;
-        h.off_sp_p = (uint32_t)off; off += t.sp_p.size() * 8;
-    }
     off = align_up(off + 16, 16);
     h.total_bytes = (uint32_t)off;
     b.assign(off, 0);
@@ -214,12 +205,6 @@ void serialize_stream(const trre::StreamTables& t, std::vector<uint8_t>& b) {
     put(b, h.off_pool, t.pool.data(), t.pool.size());
     put(b, h.off_lpw, t.lpw.data(), t.lpw.size());
     put(b, h.off_g16, t.g16.data(), t.g16.size());
-    if (t.sp_ok) {
-        put(b, h.off_sp_dense, t.sp_dense.data(), t.sp_dense.size());
-        put(b, h.off_sp_rec, t.sp_rec.data(), t.sp_rec.size());
-        put(b, h.off_sp_x, t.sp_x.data(), t.sp_x.size());
-        put(b, h.off_sp_p, t.sp_p.data(), t.sp_p.size());
-    }
 }
 
 void serialize_rev(const trre::GuidedTables& g, std::vector<uint8_t>& b) {
@@ -333,7 +318,7 @@ int device_state(trre_prog* p, int dev, DeviceState** out) {
 }
 
 int ensure_workspace(ScanCtx* c, int64_t n_chunks, int threads) {
-    n_chunks = n_chunks * ((threads + 255) / 256) + 2;  // sized in units of 256-lane chunks (+ slack: 512-lane emit workgroups)
+    n_chunks = n_chunks * ((threads + 255) / 256);      // sized in units of 256-lane chunks
     if (n_chunks <= c->ws_chunks) return TRRE_OK;
     if (c->d_lane_counts) { (void)hipFree(c->d_lane_counts); (void)hipFree(c->d_chunk_total); (void)hipFree(c->d_chunk_base); }
     c->d_lane_counts = nullptr; c->d_chunk_total = nullptr; c->d_chunk_base = nullptr;
@@ -464,22 +449,12 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
         }
     } else if (direct) {
         static const bool no_g16 = getenv("TRRE_NO_G16") != nullptr;          // A/B: the 8-byte entries
-        static const bool no_sparse = getenv("TRRE_NO_SPARSE") != nullptr;    // A/B: the dense 8-byte table of a large program
         const int g16 = stt.g16_ok && !no_g16 ? (int)(stt.g16.size() * 4) : 0;
         if (is_guided(family)) launch_rev_sweep(args, (int)p->gt.n_rev * 256, lane_bytes, stream, sym_mode == 2);
-        if (!is_guided(family) && stt.sp_ok && !no_sparse) {
-            // a dictionary-like program: sparse records in LDS (the emit workgroups are 512 lanes: the odd last one needs its counts)
-            if (n_chunks & 1) HIP_TRY(hipMemsetAsync(cx->d_lane_counts + (size_t)n_chunks * 256, 0, 256 * 4, stream));
-            launch_sparse_kernel(1, args, (int)stt.sp_rec.size(), lane_bytes, n_chunks, stream);
-            launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);
-            launch_sparse_kernel(2, args, (int)stt.sp_rec.size(), lane_bytes, n_chunks, stream);
-            pd.total_at = cx->d_chunk_base + n_chunks;
-        } else {
         launch_direct_kernel(1, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, sym_mode, g16_slow);
         launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);
         launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, sym_mode, g16_slow);
         pd.total_at = cx->d_chunk_base + n_chunks;
-        }
     } else if (family == TRRE_KERNEL_STREAM_LP) {
         launch_stream_kernel(0, ent_lds, args, n_chunks, stream);
     } else if (family == TRRE_KERNEL_STREAM_GEN) {

@@ -725,7 +725,6 @@ struct Stage {
     uint32_t fp;         // everything below this stream offset has left for memory (multiple of 32)
     uint32_t skip;       // leading bytes of sector 0 that belong to whoever wrote before this lane's first byte
     uint32_t dbg;
-    uint32_t mask = kRingBytes - 1u;   // ring size - 1 (the sparse walker flushes after every byte and gets by with 64 bytes)
 };
 // start (or restart) at an arbitrary output address; bytes below it in its 32-byte sector are not ours
 TRRE_HD void stage_begin(Stage& s, uint8_t* buf, uint8_t* first_out_byte) {
@@ -744,18 +743,18 @@ TRRE_HD void stage_append_n4(Stage& s, uint32_t v, uint32_t n) {
     s.acc |= (uint64_t)v << (8u * s.pb);
     const uint32_t t = s.pb + n;          // <= 7: at most one dword completed
     if (t >= 4u) {
-        if (!(s.dbg & 2u)) *reinterpret_cast<uint32_t*>(s.buf + (s.wp & s.mask)) = (uint32_t)s.acc;
+        if (!(s.dbg & 2u)) *reinterpret_cast<uint32_t*>(s.buf + (s.wp & (kRingBytes - 1u))) = (uint32_t)s.acc;
         s.acc >>= 32;
         s.wp += 4u;
     }
     s.pb = t & 3u;
 }
 TRRE_HD void stage_append4(Stage& s, uint32_t v, uint32_t n) { stage_append_n4(s, v, n); }
-// the same for up to 8 bytes (the second half only when some lane of the wave has more than 4)
+// the same for up to 8 bytes
 TRRE_HD void stage_append(Stage& s, uint64_t v, uint32_t n) {
     const uint32_t n1 = n < 4u ? n : 4u;
-    stage_append_n4(s, (uint32_t)v, n1);
-    if (TRRE_WAVE_ANY(n > 4u)) stage_append_n4(s, (uint32_t)(v >> 32), n - n1);
+    stage_append_n4(s, n < 4u ? (uint32_t)v : (uint32_t)v, n1);
+    stage_append_n4(s, (uint32_t)(v >> 32), n - n1);
 }
 // a pooled text of 5..8 bytes, then maybe the input byte c
 TRRE_HD void stage_append_text_c(Stage& s, uint64_t text, uint32_t len, uint32_t c, uint32_t cc) {
@@ -766,7 +765,7 @@ TRRE_HD void stage_append_text_c(Stage& s, uint64_t text, uint32_t len, uint32_t
     stage_append_n4(s, cc ? c : 0u, cc);
 }
 TRRE_HD void stage_store_sector(Stage& s) {        // the sector at stream offset fp is complete
-    const uint8_t* src = s.buf + (s.fp & s.mask);
+    const uint8_t* src = s.buf + (s.fp & (kRingBytes - 1u));
     if (s.fp == 0 && s.skip) {
         for (uint32_t i = s.skip; i < 32u; ++i) s.g0[i] = src[i];        // once per lane: the sector it shares with its predecessor
     } else {
@@ -788,9 +787,9 @@ TRRE_HD void stage_flush(Stage& s) {
     }
     if (kAll) {
         // the rest, byte by byte: what is in the ring and the partial dword of the window
-        *reinterpret_cast<uint32_t*>(s.buf + (s.wp & s.mask)) = (uint32_t)s.acc;
+        *reinterpret_cast<uint32_t*>(s.buf + (s.wp & (kRingBytes - 1u))) = (uint32_t)s.acc;
         const uint32_t end = s.wp + s.pb;
-        for (uint32_t i = (s.fp == 0 ? s.skip : s.fp); i < end; ++i) s.g0[i] = s.buf[i & s.mask];
+        for (uint32_t i = (s.fp == 0 ? s.skip : s.fp); i < end; ++i) s.g0[i] = s.buf[i & (kRingBytes - 1u)];
         s.skip = end & 31u;                 // (a caller that goes on restarts with stage_begin at stage_out_ptr)
     }
 }
@@ -1290,149 +1289,6 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
     if (kMode == 2 && a.lp_emit && (seen & 8u)) status |= kStNul;
     if (kMode == 1 && (seen & 64u)) status |= kStOverflow;            // bounded fold: the launch is void
     if ((kMode == 1 || a.lp_emit) && (seen & 16u)) status |= kStDiverge;   // guided tables: the reference's search never returns
-    L.count = cnt;
-}
-
-// =============================================================================================
-// Large tables in sparse form (front.hpp, StreamTables::sp_*): the count and emit passes of a dictionary-like
-// program.  A state is either dense (a row of 8-byte entries, fetched through the caches: the few shallow
-// states) or one 8-byte record in LDS: "on class k1 / k2 go on (silently, or through an entry sp_x[..]), on
-// anything else emit the state's prefix bytes and behave as state f on this same byte".  A lane therefore
-// takes one or more table steps per input byte; the wave loops until all its lanes have consumed theirs.
-// The dense 8-byte table of the same program is ~0.9 MB, a gather through L1/L2 on every byte (PMC: one L2
-// request per four input bytes); here everything a deep state needs is in LDS.
-// The emit pass flushes after every input byte (at most 8 prefix bytes + 8 + 1 from an entry in one step), so a
-// 64-byte ring per lane is enough and a 512-lane workgroup shares one copy of the records.
-// =============================================================================================
-struct SparseView {
-    const uint8_t* cls;        // [256] (LDS)
-    const uint64_t* dense;     // [n_dense][n_cls] (global)
-    const uint64_t* rec;       // [n_sparse] (LDS)
-    const uint64_t* xent;      // (global)
-    const uint64_t* ppool;     // [n_sparse] (global)
-    StreamView text;           // pooled texts of the entries
-    uint32_t n_dense, n_cls;
-};
-constexpr uint32_t kSparseRing = 64;
-
-template <int kMode>
-TRRE_HD void sparse_lane(const ScanArgs& a, const SparseView& T, int64_t lane, int64_t lane_bytes, uint8_t* ring, uint64_t out_base,
-                         DirectLane& L, uint32_t& status) {
-    static_assert(kMode == 1 || kMode == 2, "count or emit");
-    const int64_t lo = lane * lane_bytes;
-    int64_t hi = lo + lane_bytes;
-    if (hi > a.vend) hi = a.vend;
-    const uint32_t rhi = (uint32_t)(hi > lo ? hi - lo : 0);
-    uint32_t st;                                                      // state id
-    if (lo >= hi) st = kDoneState;
-    else if (lo < a.vbeg) st = kSkipState;
-    else st = (lo == a.vbeg || a.in_v0[lo - 1] == (uint8_t)'\n') ? 0u : kSkipState;
-    Stage S{};
-    S.dbg = a.dbg;
-    S.mask = kSparseRing - 1u;
-    if (kMode == 2) stage_begin(S, ring, a.out + out_base);
-    uint64_t cnt = 0;
-    uint32_t seen = 0;
-    const int64_t vlast = (a.vend - 1) & ~(int64_t)15;
-
-    // one input byte c of class k whose successor position lies p1 bytes into the sub-range
-    auto step = [&](const uint32_t c, const uint32_t k, const uint32_t p1) {
-        bool open = st != kDoneState;
-        while (TRRE_WAVE_ANY(open)) {
-            if (open) {
-                uint64_t e = 0;
-                bool have = false;
-                if (st < T.n_dense) {
-                    e = T.dense[st * T.n_cls + k];
-                    have = true;
-                } else {
-                    const uint64_t r = T.rec[st - T.n_dense];
-                    const uint32_t rl = (uint32_t)r, rh = (uint32_t)(r >> 32);
-                    const uint32_t k1 = (rh >> 7) & 31u, k2 = (rh >> 12) & 31u;
-                    if (k == k1 || k == k2) {
-                        const bool second = k != k1;
-                        const uint32_t target = second ? (uint32_t)(r >> 26) & 8191u : (rl >> 13) & 8191u;
-                        const bool x = (rh >> (second ? 22 : 21)) & 1u;
-                        if (x) { e = T.xent[target]; have = true; }
-                        else { st = target; open = false; }           // deeper into a key: nothing to emit
-                    } else {
-                        // not a way on: the first bytes of the pending string are flushed, the rest is a shorter one
-                        const uint32_t plen = (rh >> 17) & 15u;
-                        if (plen) {
-                            if (kMode == 1) cnt += plen;
-                            else stage_append(S, T.ppool[st - T.n_dense], plen);
-                        }
-                        st = rl & 8191u;
-                    }
-                }
-                if (have) {
-                    const uint32_t elo = (uint32_t)e, ehi = (uint32_t)(e >> 32);
-                    const uint32_t ol = str_olen(elo), cc = (elo >> 27) & 1u;
-                    if (kMode == 1) {
-                        cnt += (ol == 7u ? str_pool_len(T.text, ehi) : ol) + cc;
-                    } else if (ol != 7u) {
-                        stage_append(S, (uint64_t)ehi | (uint64_t)(cc ? c : 0u) << (8u * ol), ol + cc);
-                    } else {
-                        uint32_t len = ehi >> 24;
-                        if (len <= 8u) {
-                            uint64_t text;
-                            __builtin_memcpy(&text, T.text.pool + str_pool_off(ehi) + 4, 8);
-                            stage_append_text_c(S, text, len, c, cc);
-                        } else {
-                            // long replacement text: empty the staging buffer, write straight to memory
-                            const uint8_t* rec = T.text.pool + str_pool_off(ehi);
-                            if (len == 255u) len = str_pool_len(T.text, ehi);
-                            stage_flush<false>(S);
-                            stage_flush<true>(S);
-                            uint8_t* gp = stage_out_ptr(S);
-                            for (uint32_t i = 0; i < len; ++i) gp[i] = rec[4 + i];
-                            stage_begin(S, S.buf, gp + len);
-                            stage_append(S, (uint64_t)(cc ? c : 0u), cc);
-                        }
-                    }
-                    seen |= elo;
-                    st = ((elo & kStrEol) && p1 >= rhi) ? kDoneState : (elo & 0xffffffu);
-                    open = false;
-                }
-            }
-        }
-        if (kMode == 2) stage_flush<false>(S);
-    };
-    auto dword = [&](const uint32_t w, const uint32_t rp) {
-        const uint32_t k0 = T.cls[w & 0xffu], k1 = T.cls[(w >> 8) & 0xffu], k2 = T.cls[(w >> 16) & 0xffu], k3 = T.cls[w >> 24];
-        step(w & 0xffu, k0, rp + 1u);
-        step((w >> 8) & 0xffu, k1, rp + 2u);
-        step((w >> 16) & 0xffu, k2, rp + 3u);
-        step(w >> 24, k3, rp + 4u);
-    };
-    U128 c0 = direct_load(a, lo), c1 = direct_load(a, lo + 16), c2 = direct_load(a, lo + 32), c3 = direct_load(a, lo + 48);
-    for (int64_t v = lo;; v += 64) {
-        if (!TRRE_WAVE_ANY(st != kDoneState)) break;
-        const int64_t vn = v + 64;
-        const int64_t x0 = vn < vlast ? vn : vlast, x1 = vn + 16 < vlast ? vn + 16 : vlast,
-                      x2 = vn + 32 < vlast ? vn + 32 : vlast, x3 = vn + 48 < vlast ? vn + 48 : vlast;
-        U128 n0 = *reinterpret_cast<const U128*>(a.in_v0 + x0), n1 = *reinterpret_cast<const U128*>(a.in_v0 + x1),
-             n2 = *reinterpret_cast<const U128*>(a.in_v0 + x2), n3 = *reinterpret_cast<const U128*>(a.in_v0 + x3);
-        if (TRRE_WAVE_ANY(vn < a.vbeg || vn + 64 > a.vend - 1)) {
-            n0 = direct_load(a, vn); n1 = direct_load(a, vn + 16); n2 = direct_load(a, vn + 32); n3 = direct_load(a, vn + 48);
-        }
-        const uint32_t rp = (uint32_t)(v - lo);
-#pragma clang loop unroll(disable)
-        for (int q = 0; q < 4; ++q) {
-            U128 b;
-            b.x = q == 0 ? c0.x : (q == 1 ? c1.x : (q == 2 ? c2.x : c3.x));
-            b.y = q == 0 ? c0.y : (q == 1 ? c1.y : (q == 2 ? c2.y : c3.y));
-            b.z = q == 0 ? c0.z : (q == 1 ? c1.z : (q == 2 ? c2.z : c3.z));
-            b.w = q == 0 ? c0.w : (q == 1 ? c1.w : (q == 2 ? c2.w : c3.w));
-            const uint32_t rq = rp + 16u * (uint32_t)q;
-#pragma clang loop unroll(disable)
-            for (int d = 0; d < 4; ++d) dword(d == 0 ? b.x : (d == 1 ? b.y : (d == 2 ? b.z : b.w)), rq + 4u * (uint32_t)d);
-        }
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    }
-    if (kMode == 2) stage_flush<true>(S);
-    if (kMode == 1 && (seen & kStrOvf)) status |= kStOverflow;
-    if (kMode == 1 && (seen & kStrDiv)) status |= kStDiverge;
     L.count = cnt;
 }
 

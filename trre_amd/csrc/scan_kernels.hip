@@ -773,90 +773,6 @@ void launch_direct_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t
     else launch_direct_sym<0>(which, ent_in_lds, a, lane_bytes, n_blocks, s, g16_bytes, g16_slow);
 }
 
-// ---- large tables in sparse form (sparse_lane): records in LDS, dense rows and completing entries through the caches
-constexpr int kSparseCountThreads = 256, kSparseEmitThreads = 512;
-constexpr int kSparseRingStride = kSparseRing + 4;        // 17 dwords (odd)
-
-template <int kMode>
-__global__ __launch_bounds__(kMode == 1 ? kSparseCountThreads : kSparseEmitThreads) void k_stream_sparse(ScanArgs a, int64_t lane_bytes, int rec_room) {
-    constexpr int kThreads = kMode == 1 ? kSparseCountThreads : kSparseEmitThreads;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];    // cls[256] | records | rings (emit) | 64
-    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
-    for (int k = threadIdx.x; k < 256; k += kThreads) smem[k] = a.blob[h.off_cls + k];
-    {
-        const U128* e = reinterpret_cast<const U128*>(a.blob + h.off_sp_rec);
-        U128* d = reinterpret_cast<U128*>(smem + 256);
-        for (int k = threadIdx.x; k < (int)(h.sp_sparse_states + 1) / 2; k += kThreads) d[k] = e[k];
-    }
-    __syncthreads();
-    SparseView T;
-    T.cls = smem;
-    T.rec = reinterpret_cast<const uint64_t*>(smem + 256);
-    T.dense = reinterpret_cast<const uint64_t*>(a.blob + h.off_sp_dense);
-    T.xent = reinterpret_cast<const uint64_t*>(a.blob + h.off_sp_x);
-    T.ppool = reinterpret_cast<const uint64_t*>(a.blob + h.off_sp_p);
-    T.text.pool = a.blob + h.off_pool;
-    T.text.long_pool = h.max_out >= 255u;
-    T.n_dense = h.sp_dense_states;
-    T.n_cls = h.n_cls;
-    uint8_t* ring = smem + 256 + rec_room + threadIdx.x * kSparseRingStride;
-    uint8_t* tail = smem + 256 + rec_room + (kMode == 2 ? kThreads * kSparseRingStride : 0);      // 64 bytes
-    const int64_t lane = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    DirectLane L;
-    uint32_t st = 0;
-    uint64_t base = 0;
-    if (kMode == 2) {
-        // lane offsets: exclusive scan of the counts of this workgroup's two 256-lane chunks (the count launch's chunks)
-        uint32_t* wpart = reinterpret_cast<uint32_t*>(tail);
-        const uint32_t mine = a.lane_counts[lane];
-        const uint32_t incl = wave_scan_incl(mine);
-        if ((threadIdx.x & (kWave - 1)) == kWave - 1) wpart[threadIdx.x / kWave] = incl;
-        __syncthreads();
-        const int chunk = (int)blockIdx.x * (kThreads / 256) + (int)threadIdx.x / 256;
-        uint32_t wbase = 0;
-        for (int w = ((int)threadIdx.x / 256) * 4; w < (int)threadIdx.x / kWave; ++w) wbase += wpart[w];
-        // (the second half of the last workgroup may lie beyond the input: no chunk of the count launch stands behind it)
-        const bool live = (lane - (threadIdx.x & 255)) * lane_bytes < a.vend;
-        if (live) {
-            base = a.chunk_base[chunk] + wbase + incl - mine;
-            if (a.chunk_base[chunk] + a.chunk_total[chunk] > a.cap) {
-                if ((threadIdx.x & 255) == 0) atomicOr(a.status, kStCapacity);
-                return;                               // (the total exceeds the capacity: every chunk from the first one over returns)
-            }
-        }
-    }
-    sparse_lane<kMode>(a, T, lane, lane_bytes, ring, base, L, st);
-    if (kMode == 1) {
-        uint64_t* part = reinterpret_cast<uint64_t*>(tail);
-        if (L.count > 0xffffffffull) { st |= kStCapacity; L.count = 0xffffffffull; }
-        a.lane_counts[lane] = (uint32_t)L.count;
-        const uint64_t wsum = wave_sum(L.count);
-        if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = wsum;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint64_t t = 0;
-            for (int w = 0; w < kThreads / kWave; ++w) t += part[w];
-            a.chunk_total[blockIdx.x] = t;
-        }
-    }
-    st = wave_or(st);
-    if (st && (threadIdx.x & (kWave - 1)) == 0) atomicOr(a.status, st);
-}
-// which: 1 count (n_blocks workgroups of 256 lanes), 2 emit (half as many of 512)
-void launch_sparse_kernel(int which, const ScanArgs& a, int n_records, int64_t lane_bytes, int64_t n_blocks, void* stream) {
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const int room = ((n_records + 1) / 2) * 16;
-    if (which == 1) {
-        const int lds = 256 + room + 64;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_sparse<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL((k_stream_sparse<1>), dim3((unsigned)n_blocks), dim3(kSparseCountThreads), lds, s, a, lane_bytes, room);
-    } else {
-        const int lds = 256 + room + kSparseEmitThreads * kSparseRingStride + 64;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_sparse<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL((k_stream_sparse<2>), dim3((unsigned)((n_blocks + 1) / 2)), dim3(kSparseEmitThreads), lds, s, a, lane_bytes, room);
-    }
-}
-
 // ---- backward pass of the guided families: one symbol per input byte (rev_sweep_lane) -------------------
 constexpr int kRevThreads = 256;
 

@@ -30,8 +30,6 @@
 // (loops before a decision) make the state set infinite; the builder then gives
 // up and the launcher uses the general tile kernels instead.
 #include <algorithm>
-#include <cstdio>
-#include <cstdlib>
 #include <array>
 #include <map>
 #include <unordered_map>
@@ -207,7 +205,6 @@ public:
                 }
             }
         }
-        first_copy_ = (uint32_t)names_.size();
         spread_long_outputs();
         return pack();
     }
@@ -351,125 +348,7 @@ private:
         in.bounded = bounded_;
         StreamTables t = pack_stream_tables(in);
         t.cls = cls;
-        build_sparse(t, in);
         return t;
-    }
-
-    // sparse form (front.hpp): which states are "f-states" — their row is a fixed prefix P in front of the row of the
-    // state f of a shorter pending string, except on at most two classes — is verified cell by cell, never assumed
-    void build_sparse(StreamTables& t, const StreamPackInput& in) {
-        const uint32_t n = t.n_states, C = t.n_cls;
-        if (t.g16_ok || C > 31 || n > 8191 || bounded_) return;      // small tables have the 16-byte form; 5-bit classes, 13-bit ids
-        for (uint32_t s = 0; s < n; ++s)
-            if (t.pending_len[s] > 8) return;                        // a fallback emits at most 8 bytes
-        struct Plan { bool sparse = false; uint32_t f = 0; std::string P; std::vector<uint32_t> exc; };
-        std::vector<Plan> plan(n);
-        auto same = [](const Cell& a, const Cell& b, const std::string& P) {
-            return a.next == b.next && a.copy_c == b.copy_c && a.eol == b.eol && a.ovf == b.ovf && a.diverge == b.diverge &&
-                   a.out.size() == P.size() + b.out.size() && a.out.compare(0, P.size(), P) == 0 &&
-                   a.out.compare(P.size(), std::string::npos, b.out) == 0;
-        };
-        uint32_t n_sparse = 0;
-        for (uint32_t s = 3; s < n; ++s) {
-            const std::string& w = names_[s];
-            std::vector<std::pair<uint32_t, std::string>> cand;
-            if (s >= first_copy_) {
-                cand.emplace_back(0u, w);                            // an "owed bytes" copy of the root row
-            } else {
-                for (size_t keep = w.size(); keep-- > 0;) {          // longest proper suffix first
-                    auto hit = index_.find(w.substr(w.size() - keep));
-                    if (hit != index_.end() && hit->second != s) cand.emplace_back(hit->second, w.substr(0, w.size() - keep));
-                }
-            }
-            for (auto& fp : cand) {
-                if (fp.second.empty() || fp.second.size() > 8) continue;
-                std::vector<uint32_t> exc;
-                for (uint32_t k = 0; k < C && exc.size() <= kMaxExc; ++k)
-                    if (!same(in.rows[s][k], in.rows[fp.first][k], fp.second)) exc.push_back(k);
-                if (exc.size() > kMaxExc) continue;
-                plan[s].sparse = true;
-                plan[s].f = fp.first;
-                plan[s].P = fp.second;
-                plan[s].exc = exc;
-                ++n_sparse;
-                break;
-            }
-        }
-        if (getenv("TRRE_SPARSE_DEBUG")) {
-            std::map<size_t, int> hist;
-            for (uint32_t s2 = 3; s2 < n; ++s2) {
-                if (plan[s2].sparse) { hist[plan[s2].exc.size()]++; continue; }
-                size_t best = 99;
-                const std::string& w = names_[s2];
-                for (size_t keep = w.size(); keep-- > 0;) {
-                    auto hit = index_.find(w.substr(w.size() - keep));
-                    if (hit == index_.end() || hit->second == s2 || s2 >= first_copy_) continue;
-                    size_t ex = 0;
-                    for (uint32_t k = 0; k < C; ++k) ex += !same(in.rows[s2][k], in.rows[hit->second][k], w.substr(0, w.size() - keep));
-                    best = std::min(best, ex);
-                }
-                hist[100 + best]++;
-            }
-            for (auto& kv : hist) fprintf(stderr, "exc %zu: %d states\n", kv.first, kv.second);
-        }
-        if (n_sparse * 2 < n) return;                                // not that kind of table
-        // renumber: dense states first (root, SKIP, DONE keep 0, 1, 2), then the sparse ones, then the pseudo-states that
-        // carry a state's third to sixth exception (a record holds two: the rest hang off a chain of silent fallbacks)
-        std::vector<uint32_t> id(n);
-        uint32_t nd = 0, ns = 0;
-        for (uint32_t s = 0; s < n; ++s) if (!plan[s].sparse) id[s] = nd++;
-        for (uint32_t s = 0; s < n; ++s) if (plan[s].sparse) id[s] = nd + ns++;
-        uint32_t n_pseudo = 0;
-        for (uint32_t s = 0; s < n; ++s)
-            if (plan[s].sparse && plan[s].exc.size() > 2) n_pseudo += (uint32_t)(plan[s].exc.size() - 1) / 2;
-        if (nd + ns + n_pseudo > 8191) return;
-        auto renum = [&](uint64_t e) -> uint64_t {                   // entry of t.ent with its row offset replaced by the new state id
-            const uint32_t next = (uint32_t)(e & 0xffffffu) / C;
-            return (e & ~0xffffffull) | id[next];
-        };
-        t.sp_dense_states = nd;
-        t.sp_dense.resize((size_t)nd * C);
-        t.sp_rec.assign(ns + n_pseudo, 0);
-        t.sp_p.assign(ns + n_pseudo, 0);
-        uint32_t next_pseudo = nd + ns;
-        for (uint32_t s = 0; s < n; ++s) {
-            if (!plan[s].sparse) {
-                for (uint32_t k = 0; k < C; ++k) t.sp_dense[(size_t)id[s] * C + k] = renum(t.ent[(size_t)s * C + k]);
-                continue;
-            }
-            const Plan& pl = plan[s];
-            uint32_t at = id[s];                                     // the record being filled
-            for (size_t first = 0;; first += 2) {
-                const bool last = first + 2 >= pl.exc.size();
-                // the last record of the chain falls back to f with the prefix; the ones before it silently to the next
-                const uint32_t fb = last ? id[pl.f] : next_pseudo;
-                uint64_t rec = (uint64_t)fb | (uint64_t)(last ? pl.P.size() : 0) << 49 | 31ull << 39 | 31ull << 44;
-                for (size_t i = 0; i < 2 && first + i < pl.exc.size(); ++i) {
-                    const uint32_t k = pl.exc[first + i];
-                    const Cell& x = in.rows[s][k];
-                    const bool plain = x.out.empty() && !x.copy_c && !x.eol && !x.ovf && !x.diverge && in.col_kind[k] == kColPlain;
-                    uint64_t target;
-                    if (plain) {
-                        target = id[x.next];
-                    } else {
-                        target = t.sp_x.size();
-                        if (target > 8191) { t.sp_dense.clear(); t.sp_rec.clear(); t.sp_p.clear(); t.sp_x.clear(); return; }
-                        t.sp_x.push_back(renum(t.ent[(size_t)s * C + k]));
-                    }
-                    rec &= ~(31ull << (i == 0 ? 39 : 44));
-                    rec |= (uint64_t)k << (i == 0 ? 39 : 44) | target << (i == 0 ? 13 : 26) | (plain ? 0ull : 1ull << (i == 0 ? 53 : 54));
-                }
-                t.sp_rec[at - nd] = rec;
-                if (last) {
-                    uint64_t pb = 0;
-                    for (size_t b = 0; b < pl.P.size(); ++b) pb |= (uint64_t)(uint8_t)pl.P[b] << (8 * b);
-                    t.sp_p[at - nd] = pb;
-                    break;
-                }
-                at = next_pseudo++;
-            }
-        }
-        t.sp_ok = true;
     }
 
     const AttemptModel& m_;
@@ -478,8 +357,6 @@ private:
     std::vector<std::vector<Cell>> rows_;
     std::unordered_map<std::string, uint32_t> index_;
     uint32_t skip_ = 1, done_ = 2;
-    static constexpr size_t kMaxExc = 6;
-    uint32_t first_copy_ = 0;         // states from here on are the "owed bytes" copies of the root row (spread_long_outputs)
     static constexpr uint32_t kOverflow = 0xffffffffu;
     bool bounded_ = false;
     bool used_[256];
