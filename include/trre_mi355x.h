@@ -33,6 +33,13 @@ extern "C" {
 #define TRRE_ENGINE_NFT 0 /* ./trre      priority backtracking, trre_nft.c:593-657 */
 #define TRRE_ENGINE_DFT 1 /* ./trre_dft  shortest-match determinised, trre_dft.c:1110-1196 */
 
+/* modes: which branch of the reference's main() to reproduce */
+#define TRRE_MODE_SCAN 0  /* default: every line is scanned for matches, the rest is copied (trre_nft.c:775-790) */
+#define TRRE_MODE_MATCH 1 /* `trre -m`: the whole line must match; its output and '\n' are printed, a line that does not
+                             match prints nothing (trre_nft.c:791-797, 635-642).  NFT engine only: the reference's
+                             trre_dft -m prints an empty line per record (its emit is commented out, trre_dft.c:1185-1190)
+                             and `-a` (all outputs of all paths) is a CPU feature of the reference, not offered here. */
+
 /* return codes */
 #define TRRE_OK 0
 #define TRRE_E_SYNTAX (-1)      /* the reference prints "error: ..." and exits 1 (message kept) */
@@ -81,6 +88,7 @@ typedef struct trre_info {
  * and *out = NULL; trre_last_error() then holds the reference's stderr text. */
 int trre_compile(const char* pattern, int engine, trre_prog** out);
 int trre_compile_bytes(const uint8_t* pattern, size_t len, int engine, trre_prog** out);
+int trre_compile_mode(const uint8_t* pattern, size_t len, int engine, int mode, trre_prog** out);
 void trre_free(trre_prog* p);
 const char* trre_last_error(void); /* thread-local */
 int trre_get_info(const trre_prog* p, trre_info* info);

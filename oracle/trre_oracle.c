@@ -523,7 +523,14 @@ static void bt_push(P *p, int s, size_t i, size_t o)
  * depth-first priority order the attempt's output — cut at its first NUL, as
  * fputs would (nft.c:644-645) — is appended to dst and the consumed count is
  * returned; -1 when every path dies.  nft.c:593-657, scan mode, all=0. */
+static long nft_attempt_mode(P *p, const unsigned char *in, size_t len, bvec *dst, int match);
 static long nft_attempt(P *p, const unsigned char *in, size_t len, bvec *dst)
+{
+    return nft_attempt_mode(p, in, len, dst, 0);
+}
+/* match = 1: `trre -m`, nft.c:635-642 — FINAL accepts only with the whole line consumed (the output is followed by
+ * '\n'); anywhere else the search goes on with the next alternative. */
+static long nft_attempt_mode(P *p, const unsigned char *in, size_t len, bvec *dst, int match)
 {
     size_t i = 0, o = 0;
     int s = p->start;
@@ -556,8 +563,10 @@ static long nft_attempt(P *p, const unsigned char *in, size_t len, bvec *dst)
         case K_JOIN:    s = st->a; break;
         case K_FINAL: {
             size_t k = 0;
+            if (match && i < len) { s = -1; break; }
             while (k < o && out->b[k]) k++;
             bv_append(dst, out->b, k);
+            if (match) bv_push(dst, '\n');
             return (long)i;
         }
         }
@@ -839,6 +848,35 @@ int trre_oracle_scan(trre_oracle_prog *p, const uint8_t *in, size_t n,
         if (z) len = (size_t)(z - (in + pos));         /* C-string walk stops at NUL   */
         if (p->engine == TRRE_ORACLE_DFT) scan_line_dft(p, in + pos, len, dst);
         else scan_line_nft(p, in + pos, len, dst);
+        pos += reclen;
+    }
+    *out = dst->b;
+    *m = dst->n;
+    dst->b = NULL; dst->n = dst->cap = 0;
+    return ORC_OK;
+}
+
+/* `trre -m PATTERN` (nft.c:791-797): one attempt per record over the whole line; a line that does not match
+ * prints nothing.  NFT engine only. */
+int trre_oracle_match(trre_oracle_prog *p, const uint8_t *in, size_t n, uint8_t **out, size_t *m)
+{
+    if (p->engine != TRRE_ORACLE_NFT) return ORC_E_SYNTAX;
+    p->scan_out.b = NULL; p->scan_out.n = p->scan_out.cap = 0;
+    bv_reserve(&p->scan_out, n + 16);
+    if (setjmp(p->jb)) {
+        bv_free(&p->scan_out);
+        *out = NULL; *m = 0;
+        return p->ecode;
+    }
+    bvec *dst = &p->scan_out;
+    size_t pos = 0;
+    while (pos < n) {
+        const unsigned char *nl = memchr(in + pos, '\n', n - pos);
+        size_t reclen = nl ? (size_t)(nl - (in + pos)) + 1 : n - pos;
+        size_t len = reclen - 1;                       /* line[read-1] = '\0', nft.c:793 */
+        const unsigned char *z = memchr(in + pos, 0, len);
+        if (z) len = (size_t)(z - (in + pos));
+        nft_attempt_mode(p, in + pos, len, dst, 1);
         pos += reclen;
     }
     *out = dst->b;

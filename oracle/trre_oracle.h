@@ -42,6 +42,11 @@ int trre_oracle_compile(const char *pattern, int engine, trre_oracle_prog **out,
 int trre_oracle_scan(trre_oracle_prog *p, const uint8_t *in, size_t n,
                      uint8_t **out, size_t *m);
 
+/* `trre -m PATTERN` (match mode, trre_nft.c:791-797 with 635-642): per record one attempt over the whole line,
+ * accepted only at its end; prints the attempt's output and '\n', nothing for a line that does not match.
+ * NFT engine only. */
+int trre_oracle_match(trre_oracle_prog *p, const uint8_t *in, size_t n, uint8_t **out, size_t *m);
+
 /* Line-sharded scan over `threads` host threads (input split at '\n'
  * boundaries, outputs concatenated in order).  Each thread compiles its own
  * program because the lazily grown DFT cache is not thread-safe. */

@@ -23,6 +23,26 @@ REF_S_CASES = [
     ("<cat><dog>", "<(.:)+?>", "<><>"),
 ]
 
+# --- the reference's match-mode table (test.sh:30-126, `M` rows = `trre -ma`): (input, pattern, FIRST expected output
+# or None when nothing matches) — what `trre -m` prints for it, verified against the compiled binary by make_golden.py
+REF_M_CASES = [
+    ("a", "a:x", "x"), ("ab", "ab:xy", "xy"), ("ab", "(a:x)(b:y)", "xy"), ("cat", "cat:dog", "dog"), ("cat", "(cat):(dog)", "dog"),
+    ("cat", "(c:d)(a:o)(t:g)", "dog"), ("mat", "c:da:ot:g", None), ("xor", "(x:)or", "or"), ("or", "(:x)or", "xor"),
+    ("a", "a|b|c", "a"), ("b", "a|b|c", "b"), ("c", "a|b|c", "c"), ("b", "a*", None), ("bbb", "a*", None),
+    ("abab", "(ab)*", "abab"), ("ababa", "(ab)*", None), ("a", "[a-c]", "a"), ("b", "[a-c]", "b"), ("c", "[a-c]", "c"),
+    ("d", "[a-c]", None), ("a", "[a:x]", "x"), ("a", "[a:xb:y]", "x"), ("b", "[a:xb:y]", "y"), ("c", "[a:xb:y]", None),
+    ("a", "[a:x-c:z]", "x"), ("b", "[a:x-c:z]", "y"), ("c", "[a:x-c:z]", "z"), ("d", "[a:x-c:z]", None), ("a", ".", "a"),
+    ("b", ".", "b"), ("abc", "...", "abc"), ("aa", "a{2}", "aa"), ("a", "a{2}", None), ("aaa", "a{2}", None),
+    ("", "a{,2}", ""), ("a", "a{,2}", "a"), ("aa", "a{,2}", "aa"), ("aaa", "a{,2}", None), ("", "a{1,2}", None),
+    ("a", "a{1,2}", "a"), ("aa", "a{1,2}", "aa"), ("aaa", "a{1,2}", None), ("", "a{2,}", None), ("a", "a{2,}", None),
+    ("aa", "a{2,}", "aa"), ("aaa", "a{2,}", "aaa"), ("", ":a{,3}", "aaa"), ("", ":a{,3}?", ""), ("aaa", "(.:x)*.*", "xxx"),
+    ("aaa", "(.:x)*?.*", "aaa"), (".c", "[.]c", ".c"),
+]
+
+# whole-line patterns for match mode on the multi-line inputs
+MATCH_PATTERNS = ["(cat:dog|dog:cat| |[a-z]|[A-Z]|.)*", ".*(cat:dog).*", "(.:x)*?.*", "[a-z ]*", "(a:x|b|c:|d:yy| )*", ".*", "a:*",
+                  "([a-z]:W| :_)*", "\xe9*.*:!"]
+
 # --- README examples with a stated result (README.md:39-44,57-62,123-128,180-203) ---------
 README_CASES = [
     ("cat", "cat:dog", "dog"),

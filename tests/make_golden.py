@@ -29,10 +29,10 @@ def enc(b):
     return base64.b64encode(zlib.compress(b, 9)).decode("ascii")
 
 
-def run_ref(engine, pattern, path):
+def run_ref(engine, pattern, path, flags=()):
     binary = os.path.join(REF_DIR, "trre" if engine == "nft" else "trre_dft")
     try:
-        p = subprocess.run([binary, pattern.encode("latin-1"), path], stdout=subprocess.PIPE,
+        p = subprocess.run([binary] + list(flags) + [pattern.encode("latin-1"), path], stdout=subprocess.PIPE,
                            stderr=subprocess.PIPE, timeout=20)
     except subprocess.TimeoutExpired:
         return None
@@ -86,8 +86,25 @@ def main():
                 want = (c["expect_nft_text"] + "\n").encode("latin-1")
                 assert zlib.decompress(base64.b64decode(c["nft"])) == want, c
             out_cases.append(c)
-    doc = {"about": "scan-mode outputs of the compiled reference (c0stya/trre @ 2025-05-23), see make_golden.py",
-           "inputs": {k: enc(v) for k, v in inputs.items()}, "cases": out_cases}
+        # 4. match mode (`trre -m`, NFT engine): the reference's own match table (test.sh M rows: the input is one line;
+        #    the rows were written for -ma, the FIRST of their outputs is what -m prints) and whole-line patterns on
+        #    the multi-line inputs
+        match_cases = []
+        for k, (inp, pat, first) in enumerate(corpus.REF_M_CASES):
+            name = "refm_%02d" % k
+            inputs[name] = inp.encode("latin-1") + b"\n"
+            paths[name] = os.path.join(td, name)
+            with open(paths[name], "wb") as f:
+                f.write(inputs[name])
+            got = run_ref("nft", pat, paths[name], ["-m"])
+            assert got == ((first + "\n").encode("latin-1") if first is not None else b""), (inp, pat, got)
+            match_cases.append({"pattern": pat, "input": name, "nft_m": enc(got)})
+        for pat in corpus.MATCH_PATTERNS:
+            for name in ("words", "many_short", "embedded_nul", "no_trailing_newline", "only_newlines", "empty", "abcd_soup", "eps_with_a"):
+                got = run_ref("nft", pat, paths[name], ["-m"])
+                match_cases.append({"pattern": pat, "input": name, "nft_m": "fail" if got is None else enc(got)})
+    doc = {"about": "scan-mode (and `-m`) outputs of the compiled reference (c0stya/trre @ 2025-05-23), see make_golden.py",
+           "inputs": {k: enc(v) for k, v in inputs.items()}, "cases": out_cases, "match_cases": match_cases}
     os.makedirs(os.path.join(HERE, "golden"), exist_ok=True)
     path = os.path.join(HERE, "golden", "golden.json")
     with open(path, "w") as f:

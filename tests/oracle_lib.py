@@ -44,6 +44,9 @@ def lib():
         L.trre_oracle_scan.restype = ctypes.c_int
         L.trre_oracle_scan.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t,
                                        ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+        L.trre_oracle_match.restype = ctypes.c_int
+        L.trre_oracle_match.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t,
+                                        ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
         L.trre_oracle_scan_mt.restype = ctypes.c_int
         L.trre_oracle_scan_mt.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p,
                                           ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p),
@@ -82,6 +85,19 @@ class Oracle:
         rc = lib().trre_oracle_scan(self._h, data, len(data), ctypes.byref(out), ctypes.byref(m))
         if rc:
             raise OracleError(rc, "scan failed")
+        try:
+            return ctypes.string_at(out, m.value)
+        finally:
+            lib().trre_oracle_release(out)
+
+    def match(self, data):
+        """`trre -m`: whole-line matches only (NFT engine)"""
+        data = _as_bytes(data)
+        out = ctypes.c_void_p()
+        m = ctypes.c_size_t()
+        rc = lib().trre_oracle_match(self._h, data, len(data), ctypes.byref(out), ctypes.byref(m))
+        if rc:
+            raise OracleError(rc, "match failed")
         try:
             return ctypes.string_at(out, m.value)
         finally:

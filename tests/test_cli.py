@@ -46,10 +46,24 @@ def test_cli_errors_match_the_reference(eng):
 
 @pytest.mark.parametrize("eng", ["nft", "dft"])
 def test_cli_refuses_the_cpu_only_modes(eng):
-    """-d / -m / -a are the reference's CPU features, not the GPU scan path: refused, status 1, nothing on stdout"""
-    for flag in ("-d", "-m", "-a"):
+    """-d / -a (and trre_dft's -m, which only prints empty lines in the reference) are CPU features of the reference,
+    not GPU paths: refused, status 1, nothing on stdout"""
+    for flag in ("-d", "-a") + (("-m",) if eng == "dft" else ()):
         rc, out, err = run(BIN[eng], [flag, "a"])
         assert rc == 1 and out == b"" and err.startswith(b"error: " + flag.encode()), (eng, flag, err)
+
+
+@pytest.mark.gpu
+def test_cli_match_mode():
+    """`trre -m PATTERN`: whole-line matches (the reference's test.sh M rows, first output)"""
+    n = 0
+    for pat, name, data, exp in list(golden_lib.match_cases())[::4]:
+        if exp is None or b"\0" in pat.encode("latin-1"):
+            continue
+        rc, out, err = run(BIN["nft"], ["-m", pat.encode("latin-1")], data)
+        assert (rc, out, err) == (0, exp, b""), (pat, name, err)
+        n += 1
+    assert n > 20
 
 
 def _sample():

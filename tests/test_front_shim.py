@@ -325,3 +325,27 @@ def test_bounded_fold_and_its_fallback():
     assert st & shim_lib.ST_OVERFLOW
     _, st = shim_lib.shim_scan(p.export_stream_tables(), p.info.engine, 7, short, 0)
     assert not st & shim_lib.ST_OVERFLOW
+
+
+def test_match_mode_through_the_guided_families():
+    """`trre -m` (TRRE_MODE_MATCH): one attempt per line, accepted at its end only — golden vectors from the compiled
+    reference (incl. its test.sh match table) through the guided tables in match form"""
+    n = 0
+    progs = {}
+    for pat, name, data, exp in golden_lib.match_cases():
+        if pat not in progs:
+            progs[pat] = trre_amd.Program(pat, "nft", mode="match")
+        p = progs[pat]
+        assert p.info.kernel == trre_amd.KERNEL_GUIDED_GEN
+        for fam in (shim_lib.GUIDED_GEN, shim_lib.GUIDED_GEN8):
+            for geo in (0, 1):
+                if exp is None:
+                    with pytest.raises(RuntimeError, match="diverges"):
+                        shim_lib.scan_like_runtime(p, data, geo=geo, family=fam)
+                else:
+                    assert shim_lib.scan_like_runtime(p, data, geo=geo, family=fam) == exp, (pat, name, fam, geo)
+        n += 1
+    assert n > 100
+    with pytest.raises(trre_amd.TrreError) as e:
+        trre_amd.Program("cat:dog", "dft", mode="match")
+    assert e.value.code == trre_amd.api.E_UNSUPPORTED

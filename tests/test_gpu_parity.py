@@ -282,3 +282,25 @@ def test_random_patterns_against_the_oracle():
     r = subprocess.run([sys.executable, script, "--seconds", "12", "--seed", "20250926"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     out = r.stdout.decode("latin-1")
     assert r.returncode == 0 and "0 mismatches" in out, out[-2000:]
+
+
+def test_match_mode_on_gpu():
+    """`trre -m` through the C ABI (trre_compile_mode, TRRE_MODE_MATCH): golden vectors of the compiled reference,
+    and a larger buffer against the oracle's match mode"""
+    progs = {}
+    n = 0
+    for pat, name, data, exp in golden_lib.match_cases():
+        if pat not in progs:
+            progs[pat] = trre_amd.Program(pat, "nft", mode="match")
+        if exp is None:
+            with pytest.raises(trre_amd.TrreError) as e:
+                gpu_scan(progs[pat], data)
+            assert e.value.code == trre_amd.api.E_DIVERGES
+        else:
+            assert gpu_scan(progs[pat], data) == exp, (pat, name)
+        n += 1
+    assert n > 100
+    rng = random.Random(3)
+    data = corpus.word_soup(rng, 2 << 20, max_len=30) + b"cat\ndog\n\nlast cat"
+    for pat in ("(cat:dog|dog:cat| |[a-z]|[A-Z])*", "[a-z ]*", ".*(cat:dog).*"):
+        assert gpu_scan(trre_amd.Program(pat, "nft", mode="match"), data) == Oracle(pat, "nft").match(data), pat

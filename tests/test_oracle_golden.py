@@ -77,3 +77,20 @@ def test_inverted_bounds_are_the_lower_bound_only():
             want = Oracle(b, eng).scan(data)
             assert Oracle(a, eng).scan(data) == want, (a, eng)
             assert trre_amd.Program(a, eng).info.nft_states == trre_amd.Program(b, eng).info.nft_states + 2   # (the iteration's two JOINs)
+
+
+def test_match_mode_against_the_reference():
+    """`trre -m`: the oracle's match mode (trre_oracle_match) against the outputs of the compiled reference, incl.
+    the reference's own match table (test.sh M rows)"""
+    from oracle_lib import Oracle, OracleError
+    import golden_lib
+    n = 0
+    for pat, name, data, exp in golden_lib.match_cases():
+        o = Oracle(pat, "nft")
+        if exp is None:
+            with pytest.raises(OracleError):
+                o.match(data)
+        else:
+            assert o.match(data) == exp, (pat, name)
+        n += 1
+    assert n > 100

@@ -18,6 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TRRE_LIB_PATH") or os.path.join(_HERE, "lib", "libtrre_mi355x.so")   # override: A/B builds only
 
 ENGINE_NFT, ENGINE_DFT = 0, 1
+MODE_SCAN, MODE_MATCH = 0, 1
 _ENGINES = {"nft": ENGINE_NFT, "dft": ENGINE_DFT, ENGINE_NFT: ENGINE_NFT, ENGINE_DFT: ENGINE_DFT}
 
 KERNEL_AUTO, KERNEL_BYTEMAP, KERNEL_TILE_LP, KERNEL_TILE_GEN, KERNEL_STREAM_LP, KERNEL_STREAM_GEN = 0, 1, 2, 3, 4, 5
@@ -74,6 +75,7 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         vp, sz = ctypes.c_void_p, ctypes.c_size_t
         L.trre_compile_bytes.argtypes = [ctypes.c_char_p, sz, ctypes.c_int, ctypes.POINTER(vp)]
+        L.trre_compile_mode.argtypes = [ctypes.c_char_p, sz, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]
         L.trre_free.argtypes = [vp]
         L.trre_free.restype = None
         L.trre_last_error.restype = ctypes.c_char_p
@@ -109,11 +111,13 @@ def _bytes(x):
 class Program:
     """A compiled pattern bound to one engine."""
 
-    def __init__(self, pattern, engine="nft"):
+    def __init__(self, pattern, engine="nft", mode="scan"):
+        """mode "scan" (default) or "match" (`trre -m`: whole-line matches only, NFT engine)"""
         self.pattern = _bytes(pattern)
         self.engine = _ENGINES[engine]
+        self.mode = {"scan": MODE_SCAN, "match": MODE_MATCH, MODE_SCAN: MODE_SCAN, MODE_MATCH: MODE_MATCH}[mode]
         self._h = ctypes.c_void_p()
-        _check(lib().trre_compile_bytes(self.pattern, len(self.pattern), self.engine, ctypes.byref(self._h)))
+        _check(lib().trre_compile_mode(self.pattern, len(self.pattern), self.engine, self.mode, ctypes.byref(self._h)))
 
     def close(self):
         if getattr(self, "_h", None):

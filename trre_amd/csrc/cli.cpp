@@ -2,9 +2,11 @@
 //
 // Same command line as the reference (trre_nft.c:728-773, trre_dft.c:1217-1270,
 // trre.1:8-28): `trre [-d] [-m] [-a] PATTERN [FILE]`, FILE defaults to stdin,
-// errors go to stderr as "error: ..." with exit status 1.  Only scan mode runs
-// here — it is the GPU hot path; -m / -a / -d belong to the reference's CPU
-// binaries and are refused rather than emulated on the host.
+// errors go to stderr as "error: ..." with exit status 1.  Scan mode (the GPU
+// hot path) and, for the NFT engine, `-m` (whole-line match, first output: trre_nft.c:791-797) run
+// here; -a (all outputs), -d (debug dumps) and trre_dft's -m (which only prints empty lines,
+// trre_dft.c:1185-1190) belong to the reference's CPU binaries and are refused rather than emulated
+// on the host.
 //
 // Like the reference's getline loop the input is streamed: it is read in blocks
 // of up to 256 MiB, every block is cut after its last '\n' (the rest is carried
@@ -26,9 +28,13 @@
 
 int main(int argc, char** argv) {
     int opt;
+    int mode = TRRE_MODE_SCAN;
     while ((opt = getopt(argc, argv, "dma")) != -1) {
         switch (opt) {
-        case 'd': case 'm': case 'a':
+        case 'm':
+            if (TRRE_CLI_ENGINE == TRRE_ENGINE_NFT) { mode = TRRE_MODE_MATCH; break; }
+            /* fall through */
+        case 'd': case 'a':
             std::fprintf(stderr, "error: -%c is not part of the GPU scan path; use the reference binary for it\n", opt);
             return EXIT_FAILURE;
         default:
@@ -42,7 +48,7 @@ int main(int argc, char** argv) {
         return EXIT_FAILURE;
     }
     trre_prog* prog = nullptr;
-    if (trre_compile(argv[optind], TRRE_CLI_ENGINE, &prog) != TRRE_OK) {
+    if (trre_compile_mode(reinterpret_cast<const uint8_t*>(argv[optind]), std::strlen(argv[optind]), TRRE_CLI_ENGINE, mode, &prog) != TRRE_OK) {
         std::fprintf(stderr, "%s\n", trre_last_error());
         return EXIT_FAILURE;
     }

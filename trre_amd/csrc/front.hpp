@@ -212,9 +212,13 @@ struct NftNodes {
     std::vector<Node> node;
     std::vector<std::vector<NodeFollow>> follow;   // [n_nodes + 1]; the last one is the start's
     bool has_diverge = false;
+    bool match_mode = false;
     uint32_t n_states = 0;                         // states of the NFT they were made from
 };
-NftNodes build_nft_nodes(const Nft& nft);
+// match_mode (trre -m): FINAL accepts only at the end of the line and the search goes on past it otherwise
+// (trre_nft.c:635-642), so a list does not stop at its first FINAL (it still holds FINAL at most once: the first
+// occurrence in search order is the one that accepts).
+NftNodes build_nft_nodes(const Nft& nft, bool match_mode = false);
 
 // Tables of the bitmask tile kernels: at most 64 nodes, no Diverge marker (their backward sweep is
 // two-valued; patterns with epsilon cycles need the guided tables below).
@@ -261,6 +265,9 @@ struct GuidedTables {
     std::vector<uint8_t> rev;               // [n_rev][n_cls] next state
     StreamTables fwd;                       // columns = symbols (fwd.cls is unused)
 };
+// With nodes built for match mode the tables compute `trre -m` (trre_nft.c:791-797): one attempt per line from its first
+// byte, accepted only if it ends exactly at the end of the line; an accepted line prints its output and '\n', a
+// rejected one prints nothing.
 GuidedTables build_guided_nft(const NftNodes& nodes, const GuidedLimits& lim = GuidedLimits());
 
 }  // namespace trre

@@ -38,11 +38,12 @@ struct RevSets {
 
 bool has(const std::vector<uint32_t>& v, uint32_t x) { return std::binary_search(v.begin(), v.end(), x); }
 
-// index of the first entry of `list` the search does not get past, or -1 (the search fails)
-int decisive(const std::vector<NodeFollow>& list, const RevSets& r) {
+// index of the first entry of `list` the search does not get past, or -1 (the search fails).  final_ok: FINAL accepts
+// here (always in scan mode; in match mode only when nothing of the line is left)
+int decisive(const std::vector<NodeFollow>& list, const RevSets& r, bool final_ok) {
     for (size_t e = 0; e < list.size(); ++e) {
         const uint32_t t = list[e].target;
-        if (t == kNodeFinal || t == kNodeDiverge || has(r.alive, t)) return (int)e;
+        if (t == kNodeFinal ? final_ok : (t == kNodeDiverge || has(r.alive, t))) return (int)e;
     }
     return -1;
 }
@@ -52,7 +53,8 @@ bool diverges(const NodeFollow& f, const RevSets& r) {
 
 class GuidedBuilder {
 public:
-    GuidedBuilder(const NftNodes& nd, const GuidedLimits& lim) : nd_(nd), lim_(lim), n_nodes_((uint32_t)nd.node.size()) {}
+    GuidedBuilder(const NftNodes& nd, const GuidedLimits& lim)
+        : nd_(nd), lim_(lim), n_nodes_((uint32_t)nd.node.size()), match_(nd.match_mode) {}
 
     GuidedTables run() {
         GuidedTables g;
@@ -105,7 +107,8 @@ private:
 
     void backward(GuidedTables& g) {
         // ids 0..2 all stand for "nothing alive": 0 inside a line, 1 at its '\n', 2 at a NUL (the symbols
-        // differ because the forward pass treats the three positions differently)
+        // differ because the forward pass treats the three positions differently; in match mode FINAL accepts
+        // right of a line's last byte — states 1 and 2 — and nowhere else)
         rev_.assign(3, RevSets());
         rev_index_.emplace(std::vector<uint32_t>{0xffffffffu}, kSymDead);
         std::vector<std::vector<uint8_t>> rows;
@@ -116,7 +119,7 @@ private:
             for (uint32_t k = 2; k < g.n_cls; ++k) {
                 RevSets nx;
                 for (uint32_t t : readers_[k]) {
-                    const int e = decisive(nd_.follow[t], rev_[r]);
+                    const int e = decisive(nd_.follow[t], rev_[r], final_ok(r));
                     if (e < 0) continue;
                     nx.alive.push_back(t);
                     if (diverges(nd_.follow[t][e], rev_[r])) nx.div.push_back(t);
@@ -129,6 +132,8 @@ private:
         g.rev.resize((size_t)g.n_rev * g.n_cls);
         for (uint32_t r = 0; r < g.n_rev; ++r) std::copy(rows[r].begin(), rows[r].end(), g.rev.begin() + (size_t)r * g.n_cls);
     }
+
+    bool final_ok(uint32_t sym) const { return !match_ || sym == kSymEol || sym == kSymNul; }
 
     // forward states: 0 root, 1 SKIP, 2 DONE (the stream kernels' conventions), then (node, muted)
     uint32_t intern_fwd(uint32_t node, bool muted) {
@@ -148,13 +153,14 @@ private:
         if (s == 2) { c.next = 2; return c; }
         const RevSets& r = rev_[y];
         const bool at_end = y == kSymEol || y == kSymNul;
+        if (match_) return match_cell(s, y, r, at_end);
         const std::vector<NodeFollow>& start = nd_.follow[n_nodes_];
         bool fresh = s == 0;
         bool muted = fresh ? false : (fwd_[s] & 1) != 0;
         const std::vector<NodeFollow>* cur = fresh ? &start : &nd_.follow[fwd_[s] / 2];
         bool ended = false;          // the line's attempts are over (at_end only)
         for (;;) {
-            const int e = decisive(*cur, r);
+            const int e = decisive(*cur, r, true);
             if (e < 0) {
                 if (!fresh) {        // cannot happen: a node is only entered when its search does not fail
                     c.diverge = true; c.next = 1; c.out.clear();
@@ -199,6 +205,37 @@ private:
         return c;
     }
 
+    // trre -m (trre_nft.c:791-797, 635-642): ONE attempt per line from its first byte, accepted only at the end of the
+    // line; an accepted line prints its output and '\n', a rejected one nothing at all.  Root is "at the start of a
+    // line"; a rejected line is swallowed by SKIP, whose '\n' transition is silent.
+    StreamCell match_cell(uint32_t s, uint32_t y, const RevSets& r, bool at_end) {
+        StreamCell c;
+        const bool fresh = s == 0;
+        bool muted = fresh ? false : (fwd_[s] & 1) != 0;
+        const std::vector<NodeFollow>& list = fresh ? nd_.follow[n_nodes_] : nd_.follow[fwd_[s] / 2];
+        const int e = decisive(list, r, at_end);
+        if (e < 0) {
+            if (!fresh) { c.diverge = true; c.next = 1; return c; }        // cannot happen: a node is entered only when alive
+            c.next = y == kSymEol ? 0u : 1u;                               // no match: the line prints nothing
+            c.eol = y == kSymEol;
+            return c;
+        }
+        const NodeFollow& f = list[e];
+        if (diverges(f, r)) { c.diverge = true; c.next = 1; return c; }
+        if (!muted) c.out += f.out;
+        if (f.target == kNodeFinal) {                                      // (only at the end of the line)
+            c.out.push_back('\n');
+            c.next = y == kSymNul ? 1u : 0u;
+            c.eol = y == kSymEol;
+        } else {
+            if (f.mute) muted = true;
+            if (nd_.node[f.target].echo && !muted) c.copy_c = true;
+            c.next = intern_fwd(f.target, muted);
+        }
+        if (c.out.size() > lim_.max_out) throw StreamGiveUp();
+        return c;
+    }
+
     void forward(GuidedTables& g) {
         StreamPackInput in;
         fwd_.assign(3, 0);
@@ -229,7 +266,7 @@ private:
                 else if (pend[x.next] != p) lp = false;
             }
         }
-        in.never_lp = !lp;
+        in.never_lp = !lp || match_;
         in.pending_len.assign(n, 0);
         if (lp)
             for (uint32_t s = 0; s < n; ++s) in.pending_len[s] = pend[s] == INT64_MIN || s == 1 || s == 2 ? 0u : (uint32_t)pend[s];
@@ -239,6 +276,7 @@ private:
     const NftNodes& nd_;
     GuidedLimits lim_;
     uint32_t n_nodes_;
+    bool match_;
     std::vector<int> rep_;                          // class -> a representative byte
     std::vector<std::vector<uint32_t>> readers_;    // class -> nodes that read its bytes
     std::vector<RevSets> rev_;

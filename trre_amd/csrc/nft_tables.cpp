@@ -21,8 +21,9 @@
 
 namespace trre {
 
-NftNodes build_nft_nodes(const Nft& nft) {
+NftNodes build_nft_nodes(const Nft& nft, bool match_mode) {
     NftNodes t;
+    t.match_mode = match_mode;
     t.n_states = (uint32_t)nft.st.size();
     if (nft.st.size() > 2000000) throw Error(kErrTooBig, "error: NFT too large for the non-deterministic GPU engine");
 
@@ -62,21 +63,21 @@ NftNodes build_nft_nodes(const Nft& nft) {
         // depth-first, priority order, first occurrence of each target wins,
         // stop at FINAL or when an epsilon cycle closes
         std::vector<uint8_t> seen(n_nodes, 0);
-        bool done = false;
+        bool done = false, seen_final = false;
         std::function<void(int32_t, std::string&)> visit = [&](int32_t s, std::string& out) {
             std::vector<int32_t> entered;
             while (s >= 0 && !done) {
                 const NState& st = nft.st[s];
                 if (node_of[s] >= 0 || st.kind == NKind::Final) {
                     const bool fin = st.kind == NKind::Final;
-                    if (fin || !seen[node_of[s]]) {
+                    if (fin ? !seen_final : !seen[node_of[s]]) {
                         NodeFollow f;
                         f.target = fin ? kNodeFinal : (uint32_t)node_of[s];
                         const size_t nul = out.find('\0');
                         f.out = nul == std::string::npos ? out : out.substr(0, nul);
                         f.mute = nul != std::string::npos;
                         list.push_back(std::move(f));
-                        if (fin) done = true;
+                        if (fin) { seen_final = true; if (!match_mode) done = true; }   // scan mode: FINAL always accepts
                         else seen[node_of[s]] = 1;
                     }
                     break;

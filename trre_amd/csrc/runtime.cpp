@@ -531,11 +531,14 @@ int finish(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
     return TRRE_OK;
 }
 
-int compile_impl(const std::string& pattern, int engine, trre_prog** out) {
+int compile_impl(const std::string& pattern, int engine, trre_prog** out, int mode = TRRE_MODE_SCAN) {
     using namespace trre;
     if (!out) return fail(TRRE_E_ARG, "error: null output handle");
     *out = nullptr;
     if (engine != TRRE_ENGINE_NFT && engine != TRRE_ENGINE_DFT) return fail(TRRE_E_ARG, "error: unknown engine");
+    if (mode != TRRE_MODE_SCAN && mode != TRRE_MODE_MATCH) return fail(TRRE_E_ARG, "error: unknown mode");
+    if (mode == TRRE_MODE_MATCH && engine != TRRE_ENGINE_NFT)
+        return fail(TRRE_E_UNSUPPORTED, "error: match mode is offered for the non-deterministic engine only (trre_dft -m prints empty lines)");
     try {
         std::unique_ptr<trre_prog> p(new trre_prog);
         p->engine = engine;
@@ -549,6 +552,13 @@ int compile_impl(const std::string& pattern, int engine, trre_prog** out) {
             serialize_dft(*p);
             p->has_engine_tables = true;
             p->stt = build_stream_dft(dft);
+        } else if (mode == TRRE_MODE_MATCH) {
+            // trre -m: one attempt per line, accepted at its end only — the guided tables in match form
+            const NftNodes nodes = build_nft_nodes(nft, true);
+            p->nft_nodes = (uint32_t)nodes.node.size();
+            p->gt = build_guided_nft(nodes);
+            if (!p->gt.ok)
+                throw Error(kErrUnsupported, "error: the backward automaton of this pattern has more than 256 states (match mode runs on the guided tables only)");
         } else {
             const NftNodes nodes = build_nft_nodes(nft);
             p->nft_nodes = (uint32_t)nodes.node.size();
@@ -590,6 +600,11 @@ int trre_compile(const char* pattern, int engine, trre_prog** out) {
 int trre_compile_bytes(const uint8_t* pattern, size_t len, int engine, trre_prog** out) {
     if (!pattern) return fail(TRRE_E_ARG, "error: missing trre expression");
     return compile_impl(std::string(reinterpret_cast<const char*>(pattern), len), engine, out);
+}
+
+int trre_compile_mode(const uint8_t* pattern, size_t len, int engine, int mode, trre_prog** out) {
+    if (!pattern) return fail(TRRE_E_ARG, "error: missing trre expression");
+    return compile_impl(std::string(reinterpret_cast<const char*>(pattern), len), engine, out, mode);
 }
 
 void trre_free(trre_prog* p) {

@@ -1631,7 +1631,7 @@ TRRE_HD void rev_sweep_lane(const ScanArgs& a, const RevView& T, int64_t lane, i
     int64_t hi = lo + lane_bytes;
     if (hi > vtop) hi = vtop;
     if (lo >= hi) return;
-    uint32_t r = 0;            // "nothing alive": the state right of a '\n' (every byte from vend - 1 on reads as '\n')
+    uint32_t r = 1;            // kSymEol, the state right of a '\n': nothing alive (every byte from vend - 1 on reads as '\n')
     if (hi < a.vend - 1) {
         // the line that crosses hi: find its end e (first '\n' at or after hi), then run e - 1 .. hi
         int64_t e = hi;        // hi is a multiple of 16
