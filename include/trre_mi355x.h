@@ -49,7 +49,11 @@ extern "C" {
 #define TRRE_E_UNSUPPORTED (-5) /* legal pattern, outside this engine's GPU limits (NFT: backward DFA > 256 states and > 64 nodes) */
 #define TRRE_E_DEVICE (-6)      /* HIP runtime failure / no GPU */
 #define TRRE_E_ARG (-7)
-#define TRRE_E_DIVERGES (-8)    /* the reference would not terminate on this input (NFT epsilon cycle entered) */
+#define TRRE_E_DIVERGES (-8)    /* the reference does not survive this input: an epsilon cycle is entered (NFT: "error: stack max
+                                   capacity reached", exit 1; DFT: unbounded recursion).  The error is for the whole buffer: no
+                                   partial output (the reference has printed the lines before the bad one).  Not modelled: the
+                                   reference's limit of 65 536 live backtrack items in one attempt (a greedy loop over a run of
+                                   65 536 bytes exits 1 there; here it is matched) */
 #define TRRE_E_CAPACITY (-9)    /* output buffer too small; *out_len holds the size needed */
 
 /* kernel families (trre_info.kernel, trre_set_kernel) */
