@@ -9,6 +9,7 @@ misalignment of the input and output tensors."""
 import argparse
 import os
 import random
+import signal
 import sys
 import time
 
@@ -61,7 +62,12 @@ def gen_replacement_list(rng):
     return b"(" + pat + b")" if rng.random() < 0.5 else pat
 
 
+def _alarm(signum, frame):
+    raise TimeoutError()
+
+
 def main():
+    signal.signal(signal.SIGALRM, _alarm)
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60)
     ap.add_argument("--seed", type=int, default=1)
@@ -112,6 +118,31 @@ def main():
                     print("MISMATCH pat=%r eng=%s fam=%d n=%d mis=(%d,%d) got=%d want=%d" % (pat, eng, fam, len(data), mis_in, mis_out, len(got), len(want)), flush=True)
                     if bad > 20:
                         return 1
+        # match mode (`trre -m`, NFT engine): short lines only — the oracle's whole-line search is exponential on some patterns
+        if eng == "nft" and rng.random() < 0.5:
+            try:
+                pm = trre_amd.Program(pat, "nft", mode="match")
+            except trre_amd.TrreError:
+                continue
+            lines = [bytes(rng.choice(ALPHA) for _ in range(rng.randint(0, 14))) for _ in range(rng.randint(1, 400))]
+            data = b"\n".join(lines) + (b"\n" if rng.random() < 0.7 else b"")
+            signal.alarm(5)
+            try:
+                want = o.match(data)
+            except (OracleError, TimeoutError):
+                n_skip += 1
+                continue
+            finally:
+                signal.alarm(0)
+            try:
+                got = pm.scan_tensor(torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()).cpu().numpy().tobytes() if data else b""
+            except trre_amd.TrreError as e:
+                got = ("ERR " + str(e)).encode()
+            n_run += 1
+            fams["match"] = fams.get("match", 0) + 1
+            if got != want:
+                bad += 1
+                print("MISMATCH (match mode) pat=%r n=%d got=%d want=%d" % (pat, len(data), len(got), len(want)), flush=True)
     print("gpu fuzz: %d patterns, %d scans (%s), %d skipped, %d mismatches" % (n_pat, n_run, fams, n_skip, bad))
     return 1 if bad else 0
 
