@@ -180,6 +180,7 @@ StreamView direct_view(const ScanArgs& a) {
     T.pool = a.blob + h.off_pool;
     T.long_pool = h.max_out >= 255u;
     if (h.g16_bytes) T.g16 = a.blob + h.off_g16;
+    if (h.p32_bytes && !getenv("TRRE_NO_PAIRS")) { T.p32 = a.blob + h.off_p32; T.p32_slow = h.p32_slow; }
     return T;
 }
 template <int kSym = 0>

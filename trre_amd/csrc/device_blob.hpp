@@ -43,8 +43,11 @@ struct StreamBlobHeader {
     uint32_t total_bytes, max_out;
     uint32_t off_lpw, lpw_bytes, lpw_delay;   // window form (0 bytes when not available)
     uint32_t off_g16, g16_bytes;              // 16-byte count / emit entries (0 bytes when not available)
+    uint32_t off_p32, p32_bytes;              // pair form (0 bytes when not available)
+    uint32_t p32_slow;                        // some pair entry is "slow"
+    uint32_t pad;
 };
-static_assert(sizeof(StreamBlobHeader) == 64, "header layout");
+static_assert(sizeof(StreamBlobHeader) == 80, "header layout");
 
 // backward pass of the guided families (guided_build.cpp): a DFA read right to left
 constexpr uint32_t kMagicRev = 0x31525254u;   // "TRR1"

@@ -196,6 +196,8 @@ void serialize_stream(const trre::StreamTables& t, std::vector<uint8_t>& b) {
     h.off_lpw = (uint32_t)off; h.lpw_bytes = (uint32_t)(t.lpw.size() * 4); h.lpw_delay = t.lpw_delay; off += t.lpw.size() * 4;
     off = align_up(off, 16);
     h.off_g16 = (uint32_t)off; h.g16_bytes = (uint32_t)(t.g16.size() * 4); off += t.g16.size() * 4;
+    off = align_up(off, 16);
+    h.off_p32 = (uint32_t)off; h.p32_bytes = (uint32_t)(t.p32.size() * 4); h.p32_slow = t.p32_slow ? 1u : 0u; off += t.p32.size() * 4;
     off = align_up(off + 16, 16);
     h.total_bytes = (uint32_t)off;
     b.assign(off, 0);
@@ -205,6 +207,7 @@ void serialize_stream(const trre::StreamTables& t, std::vector<uint8_t>& b) {
     put(b, h.off_pool, t.pool.data(), t.pool.size());
     put(b, h.off_lpw, t.lpw.data(), t.lpw.size());
     put(b, h.off_g16, t.g16.data(), t.g16.size());
+    put(b, h.off_p32, t.p32.data(), t.p32.size());
 }
 
 void serialize_rev(const trre::GuidedTables& g, std::vector<uint8_t>& b) {
@@ -437,7 +440,7 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
         // them (TRRE_LP_RING=1: the older in-place walker with an LDS ring, 2.3x slower; kept for A/B runs)
         static const bool lp_ring = getenv("TRRE_LP_RING") != nullptr;
         static const bool no_g16 = getenv("TRRE_NO_G16") != nullptr;
-        const int g16 = stt.g16_ok && !no_g16 ? (int)(stt.g16.size() * 4) : 0;
+        const int g16 = stt.g16_ok && !no_g16 ? (int)(align_up(stt.g16.size() * 4, 16) + stt.p32.size() * 4) : 0;   // LDS room: 16-byte + pair forms
         if (is_guided(family)) launch_rev_sweep(args, (int)p->gt.n_rev * 256, lane_bytes, stream, sym_mode == 2);
         static const bool rev_only = getenv("TRRE_REV_DBG") != nullptr;       // experiments on the backward pass alone (its output may be void)
         if (is_guided(family) && rev_only) {
@@ -449,7 +452,7 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
         }
     } else if (direct) {
         static const bool no_g16 = getenv("TRRE_NO_G16") != nullptr;          // A/B: the 8-byte entries
-        const int g16 = stt.g16_ok && !no_g16 ? (int)(stt.g16.size() * 4) : 0;
+        const int g16 = stt.g16_ok && !no_g16 ? (int)(align_up(stt.g16.size() * 4, 16) + stt.p32.size() * 4) : 0;   // LDS room: 16-byte + pair forms
         if (is_guided(family)) launch_rev_sweep(args, (int)p->gt.n_rev * 256, lane_bytes, stream, sym_mode == 2);
         launch_direct_kernel(1, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, sym_mode, g16_slow);
         launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);

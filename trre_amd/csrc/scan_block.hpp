@@ -1216,15 +1216,100 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
             }
         }
     };
+    // Interior pieces of tables that have the pair form: two input bytes per table step (half the steps of a pass that is
+    // bound by instruction issue).  A pair whose bytes do not fit its entry ("slow") is walked as two single steps.
+    const uint32_t pair_mul = 2u * n_cls;         // pair row offset = 16-byte row offset * 2 n_cls
+    uint32_t seen2 = 0;                           // metas of pair entries (their flag bits differ from the 16-byte form's)
+    auto single_emit = [&](const uint32_t wj, const uint32_t k) {       // one byte through the 16-byte entries, no end-of-lane test
+        const U128 g = *reinterpret_cast<const U128*>(T.g16 + row + (k << 4));
+        stage_append_n4(S, perm_b32(wj, g.z, g.w), g.y & 7u);
+        seen |= g.y;
+        if (kHasSlow) {
+            if (TRRE_WAVE_ANY(g.y & 128u)) {
+                if (g.y & 128u) slow_emit(row, k, (uint8_t)wj);
+            }
+        }
+        row = g.x;
+    };
+    auto dword_pairs = [&](const uint32_t w, const uint32_t sw) {
+        uint32_t kk[4];
+        if (kSym == 2) { kk[0] = sw & 15u; kk[1] = (sw >> 4) & 15u; kk[2] = (sw >> 8) & 15u; kk[3] = (sw >> 12) & 15u; }
+        else if (kSym == 1) { kk[0] = sw & 0xffu; kk[1] = (sw >> 8) & 0xffu; kk[2] = (sw >> 16) & 0xffu; kk[3] = sw >> 24; }
+        else { kk[0] = T.cls[w & 0xffu]; kk[1] = T.cls[(w >> 8) & 0xffu]; kk[2] = T.cls[(w >> 16) & 0xffu]; kk[3] = T.cls[w >> 24]; }
+        if (kMode == 1) {
+            const uint32_t row0 = row;
+            uint32_t c = 0, fl = 0, r = row;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint64_t g = *reinterpret_cast<const uint64_t*>(T.p32 + r * pair_mul + ((kk[2 * h] * n_cls + kk[2 * h + 1]) << 5));
+                const uint32_t meta = (uint32_t)(g >> 32);
+                c += meta & 15u;
+                fl |= meta;
+                r = (uint32_t)g;
+            }
+            if (T.p32_slow) {
+                if (TRRE_WAVE_ANY(fl & 128u)) {
+                    if (fl & 128u) {              // this dword again, byte by byte
+                        row = row0;
+                        dword(std::false_type{}, w, sw, 0u);
+                        return;
+                    }
+                }
+            }
+            row = r;
+            seen2 |= fl;
+            cnt += c;
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint8_t* ep = T.p32 + row * pair_mul + ((kk[2 * h] * n_cls + kk[2 * h + 1]) << 5);
+                const U128 e = *reinterpret_cast<const U128*>(ep);
+                const uint32_t ws = w >> (16 * h);
+                bool as_pair = true;
+                if (T.p32_slow) {
+                    if (TRRE_WAVE_ANY(e.y & 128u)) {
+                        if (e.y & 128u) {
+                            single_emit(ws, kk[2 * h]);
+                            single_emit(ws >> 8, kk[2 * h + 1]);
+                            as_pair = false;
+                        }
+                    }
+                }
+                if (as_pair) {
+                    const uint32_t n = e.y & 15u;
+                    uint32_t hi4 = 0;
+                    if (TRRE_WAVE_ANY(n > 4u)) {
+                        const uint64_t e2 = *reinterpret_cast<const uint64_t*>(ep + 16);
+                        hi4 = perm_b32(ws, (uint32_t)e2, (uint32_t)(e2 >> 32));
+                    }
+                    stage_append(S, (uint64_t)perm_b32(ws, e.z, e.w) | (uint64_t)hi4 << 32, n);
+                    seen2 |= e.y;
+                    row = e.x;
+                }
+            }
+        }
+    };
     // one 16-byte block; y: its symbols — four dwords (per byte) or the two dwords x, y (packed)
     auto block = [&](auto end_tag, const U128& b, const U128& y, const uint32_t rp) {
-        dword(end_tag, b.x, kSym == 2 ? (y.x & 0xffffu) : y.x, rp);
-        dword(end_tag, b.y, kSym == 2 ? (y.x >> 16) : y.y, rp + 4u);
-        if (kMode == 2) stage_flush<false>(S);
-        dword(end_tag, b.z, kSym == 2 ? (y.y & 0xffffu) : y.z, rp + 8u);
-        dword(end_tag, b.w, kSym == 2 ? (y.y >> 16) : y.w, rp + 12u);
+        constexpr bool kEnd = decltype(end_tag)::value;
+        const uint32_t y0 = kSym == 2 ? (y.x & 0xffffu) : y.x, y1 = kSym == 2 ? (y.x >> 16) : y.y,
+                       y2 = kSym == 2 ? (y.y & 0xffffu) : y.z, y3 = kSym == 2 ? (y.y >> 16) : y.w;
+        if (!kEnd && T.p32) {
+            dword_pairs(b.x, y0);
+            dword_pairs(b.y, y1);
+            if (kMode == 2) stage_flush<false>(S);
+            dword_pairs(b.z, y2);
+            dword_pairs(b.w, y3);
+        } else {
+            dword(end_tag, b.x, y0, rp);
+            dword(end_tag, b.y, y1, rp + 4u);
+            if (kMode == 2) stage_flush<false>(S);
+            dword(end_tag, b.z, y2, rp + 8u);
+            dword(end_tag, b.w, y3, rp + 12u);
+        }
         if (kMode == 2) stage_flush<false>(S);
         TRRE_PIN(seen);
+        TRRE_PIN(seen2);
         if (kMode == 1) TRRE_PIN(cnt);
         TRRE_SCHED_FENCE();
     };
@@ -1286,9 +1371,9 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
         if (kSym) { s0 = t0; s1 = t1; s2 = t2; s3 = t3; }
     }
     if (kMode == 2) stage_flush<true>(S);
-    if (kMode == 2 && a.lp_emit && (seen & 8u)) status |= kStNul;
-    if (kMode == 1 && (seen & 64u)) status |= kStOverflow;            // bounded fold: the launch is void
-    if ((kMode == 1 || a.lp_emit) && (seen & 16u)) status |= kStDiverge;   // guided tables: the reference's search never returns
+    if (kMode == 2 && a.lp_emit && ((seen & 8u) || (seen2 & 256u))) status |= kStNul;
+    if (kMode == 1 && ((seen | seen2) & 64u)) status |= kStOverflow;            // bounded fold: the launch is void
+    if ((kMode == 1 || a.lp_emit) && ((seen | seen2) & 16u)) status |= kStDiverge;   // guided tables: the reference's search never returns
     L.count = cnt;
 }
 

@@ -199,6 +199,8 @@ struct StreamView {
     const uint8_t* pool;
     const uint8_t* pool_fast = nullptr;   // a copy of the pool in LDS when it fits (emit pass), else null
     const uint8_t* g16 = nullptr;         // 16-byte count / emit entries (front.hpp), when the walker uses them
+    const uint8_t* p32 = nullptr;         // pair form of the same table (front.hpp), or null
+    uint32_t p32_slow = 0;                // some pair entry is "slow"
     uint32_t long_pool = 1;  // 0: no pooled text reaches 255 bytes, i.e. every pooled entry carries its exact length
 };
 TRRE_HD uint64_t str_entry(const StreamView& T, uint32_t idx) { return T.ent[idx]; }

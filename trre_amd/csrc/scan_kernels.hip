@@ -423,6 +423,12 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_g16(ScanArgs a, int64
         U128* d = reinterpret_cast<U128*>(smem + 256);
         for (int k = threadIdx.x; k < (int)(h.g16_bytes / 16); k += kDirectThreads) d[k] = e[k];
     }
+    {
+        // (g16_room holds the 16-byte form and, behind it, the pair form when the tables have one)
+        const U128* e = reinterpret_cast<const U128*>(a.blob + h.off_p32);
+        U128* d = reinterpret_cast<U128*>(smem + 256 + ((h.g16_bytes + 15u) & ~15u));
+        for (int k = threadIdx.x; k < (int)(h.p32_bytes / 16); k += kDirectThreads) d[k] = e[k];
+    }
     StreamView T;
     uint8_t* pool_lds = smem + 256 + g16_room;
     if (kMode != 1 && (int)h.pool_bytes <= kDirectPoolSmall) {
@@ -434,6 +440,7 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_g16(ScanArgs a, int64
     __syncthreads();
     T.cls = smem;
     T.g16 = smem + 256;
+    if (h.p32_bytes && !(a.dbg & 4u)) { T.p32 = smem + 256 + ((h.g16_bytes + 15u) & ~15u); T.p32_slow = h.p32_slow; }   // (TRRE_EMIT_DBG=4: A/B without pairs)
     T.ent = reinterpret_cast<const uint64_t*>(a.blob + h.off_ent);
     T.pool = a.blob + h.off_pool;
     T.long_pool = h.max_out >= 255u;

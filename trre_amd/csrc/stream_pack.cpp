@@ -80,6 +80,51 @@ void build_gen16(StreamTables& t, const StreamPackInput& in) {
     t.g16_ok = true;
 }
 
+// pair form (see front.hpp); tables whose 16-byte and pair forms together stay small (they share LDS with the staging rings)
+void build_pairs(StreamTables& t, const StreamPackInput& in) {
+    const size_t C = t.n_cls, n = t.n_states;
+    if (!t.g16_ok || n * C * C * 32 + t.g16.size() * 4 > 12288) return;
+    std::vector<uint32_t> v(n * C * C * 8, 0);
+    for (uint32_t s = 0; s < n; ++s) {
+        for (uint32_t k0 = 0; k0 < C; ++k0) {
+            const StreamCell& a = in.rows[s][k0];
+            for (uint32_t k1 = 0; k1 < C; ++k1) {
+                const StreamCell& b = in.rows[a.next][k1];
+                // the appended bytes: literal, or 0x100 + i for input byte i of the pair
+                std::vector<uint32_t> seq;
+                for (unsigned char ch : a.out) seq.push_back(ch);
+                if (a.copy_c) seq.push_back(0x100);
+                for (unsigned char ch : b.out) seq.push_back(ch);
+                if (b.copy_c) seq.push_back(0x101);
+                const bool silent_a = s == in.skip || s == in.done, silent_b = a.next == in.skip || a.next == in.done;
+                const bool slow = seq.size() > 8;
+                uint32_t* e = &v[((size_t)s * C * C + (size_t)k0 * C + k1) * 8];
+                e[0] = b.next * t.n_cls * 16u;
+                e[1] = (slow ? 128u : (uint32_t)seq.size()) | ((a.diverge || b.diverge) ? 16u : 0u) | ((a.eol || b.eol) ? 32u : 0u) |
+                       ((a.ovf || b.ovf) ? 64u : 0u) |
+                       (((in.col_kind[k0] == kColNul && !silent_a) || (in.col_kind[k1] == kColNul && !silent_b)) ? 256u : 0u);
+                if (slow) t.p32_slow = true;
+                for (int half = 0; half < 2; ++half) {
+                    uint32_t bytes = 0, sel = 0;
+                    for (size_t i = 0; i < 4; ++i) {
+                        const size_t pos = 4 * half + i;
+                        uint32_t pick = 0x0cu;                                   // constant 0x00
+                        if (!slow && pos < seq.size()) {
+                            if (seq[pos] >= 0x100) pick = 4u + (seq[pos] - 0x100);   // input byte 0 / 1 of the pair
+                            else { bytes |= seq[pos] << (8 * i); pick = (uint32_t)i; }
+                        }
+                        sel |= pick << (8 * i);
+                    }
+                    e[2 + 2 * half] = bytes;
+                    e[3 + 2 * half] = sel;
+                }
+            }
+        }
+    }
+    t.p32 = std::move(v);
+    t.p32_ok = true;
+}
+
 }  // namespace
 
 StreamTables pack_stream_tables(const StreamPackInput& in) {
@@ -142,6 +187,7 @@ StreamTables pack_stream_tables(const StreamPackInput& in) {
     if (in.bounded) lp = false;         // (a void launch must be noticed: only the count pass reports it)
     if (lp) build_window_form(t, in);
     build_gen16(t, in);
+    build_pairs(t, in);
     if (lp) t.flags |= kFlagLengthPreserving;
     if (lp && inplace_ok) t.flags |= kFlagNoOverrun;    // the in-place kernel may run
     return t;
