@@ -19,6 +19,7 @@
 // kernels in scan_kernels.hip put barriers and wave reductions between them,
 // tests/cpu_shim.cpp runs them thread by thread on the host.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <type_traits>
 
@@ -704,34 +705,40 @@ TRRE_HD void direct_flush(uint8_t* obase, const uint8_t* ring, uint32_t& of, uin
 // A lane's output is a contiguous run of the output buffer that starts at an arbitrary byte.  The dword
 // being filled lives in a 64-bit register window `acc`; a transition ORs its bytes in at the fill position
 // and only a COMPLETED dword goes to the lane's 128-byte LDS ring (one aligned ds_write_b32, and only the
-// lanes that completed one take part).  After every eight input bytes the complete 32-byte sectors leave
-// the ring as pairs of aligned 16-byte loads and stores (whole sectors: a 16-byte store on its own is a
-// partial-sector write, measured at 2.2x write amplification); nothing is ever moved inside the ring.
-// (The first version stored the window's two dwords on every transition and moved the remainder to the front
-// of a linear buffer at every flush: PMC showed the LDS array busy 63 % of the kernel's time, a third of
-// it bank conflicts — lanes sit at unrelated offsets of their buffers — and the VALU waiting for it.)
-// Stream offsets count from the 32-byte aligned output address g0 at or below the lane's first byte; the
-// ring holds offsets [fp, wp), 31 + 8 * 9 bytes at most between two flushes.  Rings are 132 bytes apart
-// (33 dwords, odd: lanes that run in step — one byte out per byte in — store to distinct banks), so a
-// ring is only 4-byte aligned and a sector leaves it as eight dword reads.
+// lanes that completed one take part); nothing is ever moved inside the ring.  After every eight input
+// bytes the complete 64-byte UNITS leave the ring, and they leave it through the wave: the lanes that have
+// a unit ready post {ring position, output address} in a small per-wave LDS table, and four adjacent lanes
+// store one unit — 16 bytes each, one 64-byte request — sixteen units per store instruction.
+// History: (1) the window's two dwords stored on every transition and the remainder moved to the front of a
+// linear buffer at every flush: PMC showed the LDS array busy 63 % of the kernel's time, a third of it bank
+// conflicts.  (2) Ring, every lane storing its own 32-byte sectors as two 16-byte stores: PMC counted 86 M
+// L2 write requests per GiB of output (13 bytes per request), four fifths of all the kernel's L2 traffic, and
+// 1.38x write amplification in HBM — the pass ran at the pace of those requests, not of its instructions.
+// Stream offsets count from the 64-byte aligned output address g0 at or below the lane's first byte; the
+// ring holds offsets [fp, wp): 63 + 8 * 5 bytes at most between two flushes (tables with slow entries — up
+// to 9 bytes per transition — flush after every four input bytes).  Rings are 132 bytes apart (33 dwords,
+// odd: lanes that run in step store to distinct banks), so a ring is only 4-byte aligned.
 constexpr int kRingStride = 132;
 constexpr uint32_t kRingBytes = 128;
+constexpr uint32_t kUnitBytes = 64;
+constexpr int kWaveScratchBytes = 16 * 16;     // per wave: 16 posted units x {ring position, address lo, address hi, -}
 struct Stage {
     uint8_t* buf;        // the lane's ring: kRingBytes, 4-byte aligned
-    uint8_t* g0;         // 32-byte aligned output address of stream offset 0
+    uint8_t* g0;         // 64-byte aligned output address of stream offset 0
     uint64_t acc;        // bytes [wp, wp + pb) of the stream (and whatever spills beyond while appending)
     uint32_t wp;         // stream offset of the dword being filled (multiple of 4)
     uint32_t pb;         // bytes of it that are filled (0..3)
-    uint32_t fp;         // everything below this stream offset has left for memory (multiple of 32)
-    uint32_t skip;       // leading bytes of sector 0 that belong to whoever wrote before this lane's first byte
+    uint32_t fp;         // everything below this stream offset has left for memory (multiple of 64)
+    uint32_t skip;       // leading bytes of unit 0 that belong to whoever wrote before this lane's first byte
     uint32_t dbg;
+    uint32_t* wsc;       // the wave's posting table (LDS), or null: every lane stores its own units (host shim)
 };
-// start (or restart) at an arbitrary output address; bytes below it in its 32-byte sector are not ours
+// start (or restart) at an arbitrary output address; bytes below it in its 64-byte unit are not ours
 TRRE_HD void stage_begin(Stage& s, uint8_t* buf, uint8_t* first_out_byte) {
     const uintptr_t start = reinterpret_cast<uintptr_t>(first_out_byte);
     s.buf = buf;
-    s.g0 = reinterpret_cast<uint8_t*>(start & ~(uintptr_t)31);
-    s.skip = (uint32_t)(start & 31u);
+    s.g0 = reinterpret_cast<uint8_t*>(start & ~(uintptr_t)(kUnitBytes - 1u));
+    s.skip = (uint32_t)(start & (kUnitBytes - 1u));
     s.wp = s.skip & ~3u;
     s.pb = s.skip & 3u;
     s.fp = 0;
@@ -750,11 +757,11 @@ TRRE_HD void stage_append_n4(Stage& s, uint32_t v, uint32_t n) {
     s.pb = t & 3u;
 }
 TRRE_HD void stage_append4(Stage& s, uint32_t v, uint32_t n) { stage_append_n4(s, v, n); }
-// the same for up to 8 bytes
+// the same for up to 8 bytes (the second half only when some lane of the wave has more than 4)
 TRRE_HD void stage_append(Stage& s, uint64_t v, uint32_t n) {
     const uint32_t n1 = n < 4u ? n : 4u;
-    stage_append_n4(s, n < 4u ? (uint32_t)v : (uint32_t)v, n1);
-    stage_append_n4(s, (uint32_t)(v >> 32), n - n1);
+    stage_append_n4(s, (uint32_t)v, n1);
+    if (TRRE_WAVE_ANY(n > 4u)) stage_append_n4(s, (uint32_t)(v >> 32), n - n1);
 }
 // a pooled text of 5..8 bytes, then maybe the input byte c
 TRRE_HD void stage_append_text_c(Stage& s, uint64_t text, uint32_t len, uint32_t c, uint32_t cc) {
@@ -764,33 +771,80 @@ TRRE_HD void stage_append_text_c(Stage& s, uint64_t text, uint32_t len, uint32_t
     stage_append_n4(s, hi, rest);
     stage_append_n4(s, cc ? c : 0u, cc);
 }
-TRRE_HD void stage_store_sector(Stage& s) {        // the sector at stream offset fp is complete
-    const uint8_t* src = s.buf + (s.fp & (kRingBytes - 1u));
+// stream bytes [from, to) from the ring to memory: single bytes up to a dword boundary, dwords, single bytes
+TRRE_HD void stage_store_span(Stage& s, uint32_t from, uint32_t to) {
+    uint32_t i = from;
+    for (; i < to && (i & 3u); ++i) s.g0[i] = s.buf[i & (kRingBytes - 1u)];
+    for (; i + 4u <= to; i += 4u)
+        *reinterpret_cast<uint32_t*>(s.g0 + i) = *reinterpret_cast<const uint32_t*>(s.buf + (i & (kRingBytes - 1u)));
+    for (; i < to; ++i) s.g0[i] = s.buf[i & (kRingBytes - 1u)];
+}
+TRRE_HD void stage_store_own_unit(Stage& s) {        // the unit at stream offset fp is complete: the lane stores it itself
     if (s.fp == 0 && s.skip) {
-        for (uint32_t i = s.skip; i < 32u; ++i) s.g0[i] = src[i];        // once per lane: the sector it shares with its predecessor
+        stage_store_span(s, s.skip, kUnitBytes);     // once per lane: the unit it shares with its predecessor
     } else {
-        const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src);
-        const U128 q0{s32[0], s32[1], s32[2], s32[3]}, q1{s32[4], s32[5], s32[6], s32[7]};
+        const uint32_t* s32 = reinterpret_cast<const uint32_t*>(s.buf + (s.fp & (kRingBytes - 1u)));
+        U128* dst = reinterpret_cast<U128*>(s.g0 + s.fp);
         if (!(s.dbg & 1u)) {
-            *reinterpret_cast<U128*>(s.g0 + s.fp) = q0;
-            *reinterpret_cast<U128*>(s.g0 + s.fp + 16u) = q1;
-        } else if (q0.x == 0x12345678u && q1.w == 0x9abcdef0u) {
-            *reinterpret_cast<U128*>(s.g0 + s.fp) = q0;
+            dst[0] = U128{s32[0], s32[1], s32[2], s32[3]};
+            dst[1] = U128{s32[4], s32[5], s32[6], s32[7]};
+            dst[2] = U128{s32[8], s32[9], s32[10], s32[11]};
+            dst[3] = U128{s32[12], s32[13], s32[14], s32[15]};
         }
     }
-    s.fp += 32u;
+    s.fp += kUnitBytes;
 }
 template <bool kAll>
 TRRE_HD void stage_flush(Stage& s) {
-    while (TRRE_WAVE_ANY(s.wp - s.fp >= 32u)) {
-        if (s.wp - s.fp >= 32u) stage_store_sector(s);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (s.wsc) {
+        // a lane's first unit may share its 64 bytes with the lane before it: that one it stores itself
+        if (TRRE_WAVE_ANY(s.fp == 0 && s.skip != 0 && s.wp >= kUnitBytes)) {
+            if (s.fp == 0 && s.skip != 0 && s.wp >= kUnitBytes) stage_store_own_unit(s);
+        }
+        const uint32_t lid = __lane_id();
+        uint64_t ready = __ballot(s.wp - s.fp >= kUnitBytes);
+        while (ready) {
+            const bool mine = (ready >> lid) & 1ull;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(ready >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ready, 0u));
+            const bool post = mine && rank < 16u;
+            if (post) {
+                const uintptr_t dst = reinterpret_cast<uintptr_t>(s.g0 + s.fp);
+                uint32_t* slot = s.wsc + 4u * rank;
+                slot[0] = (uint32_t)(int32_t)((s.buf + (s.fp & (kRingBytes - 1u))) - reinterpret_cast<uint8_t*>(s.wsc));
+                slot[1] = (uint32_t)dst;
+                slot[2] = (uint32_t)((uint64_t)dst >> 32);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t n_units = (uint32_t)__popcll(ready);
+            const uint32_t u = lid >> 2;
+            if (u < (n_units < 16u ? n_units : 16u)) {
+                const uint32_t* slot = s.wsc + 4u * u;
+                // (the ring position was posted as a signed distance from the posting table: both live in this workgroup's LDS)
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(s.wsc) + (ptrdiff_t)(int32_t)slot[0] + 16 * (ptrdiff_t)(lid & 3u));
+                uint8_t* dst = reinterpret_cast<uint8_t*>((uintptr_t)((uint64_t)slot[2] << 32 | slot[1])) + 16u * (lid & 3u);
+                const U128 q{src[0], src[1], src[2], src[3]};
+                if (!(s.dbg & 1u)) *reinterpret_cast<U128*>(dst) = q;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (post) s.fp += kUnitBytes;
+            ready &= ~__ballot(post);
+            ready |= __ballot(post && s.wp - s.fp >= kUnitBytes);       // (a lane may hold more than one complete unit)
+        }
+    } else
+#endif
+    {
+        while (TRRE_WAVE_ANY(s.wp - s.fp >= kUnitBytes)) {
+            if (s.wp - s.fp >= kUnitBytes) stage_store_own_unit(s);
+        }
     }
     if (kAll) {
-        // the rest, byte by byte: what is in the ring and the partial dword of the window
+        // the rest: what is in the ring and the partial dword of the window
         *reinterpret_cast<uint32_t*>(s.buf + (s.wp & (kRingBytes - 1u))) = (uint32_t)s.acc;
         const uint32_t end = s.wp + s.pb;
-        for (uint32_t i = (s.fp == 0 ? s.skip : s.fp); i < end; ++i) s.g0[i] = s.buf[i & (kRingBytes - 1u)];
-        s.skip = end & 31u;                 // (a caller that goes on restarts with stage_begin at stage_out_ptr)
+        stage_store_span(s, s.fp == 0 ? s.skip : s.fp, end);
+        s.skip = end & (kUnitBytes - 1u);     // (a caller that goes on restarts with stage_begin at stage_out_ptr)
     }
 }
 
@@ -813,7 +867,7 @@ TRRE_HD int64_t first_line_start_safe(const ScanArgs& a, int64_t lo, int64_t hi)
 // (a.sym_v0) instead of the byte's class.
 template <int kMode, bool kG16 = false, bool kSym = false>
 TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, int64_t lane, int64_t lane_bytes,
-                                uint8_t* ring, uint64_t out_base, DirectLane& L, uint32_t& status) {
+                                uint8_t* ring, uint64_t out_base, DirectLane& L, uint32_t& status, uint32_t* wave_scratch = nullptr) {
     const uint32_t rs = kG16 ? 16u : 1u;                              // row unit
     const uint32_t done_row = kDoneState * n_cls * rs;
     int64_t lo = lane * lane_bytes, hi = lo + lane_bytes;
@@ -837,6 +891,7 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
     uint32_t of = o;                      // everything below `of` has left the ring
     Stage S{};                            // kMode 2
     S.dbg = a.dbg;
+    S.wsc = wave_scratch;
     if (kMode == 2) {
         if (a.lp_emit) {
             // no count pass: this lane's lines are written where they were read
@@ -999,7 +1054,7 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
                     row = ((elo & kStrEol) && p1 >= rhi) ? done_row : row;
                 }
             }
-            if (kMode == 2 && (d & 1)) stage_flush<false>(S);
+            if (kMode == 2) stage_flush<false>(S);         // (up to 9 bytes per transition: 63 + 4 * 9 fits the ring)
             if (kMode != 0) {
                 // one dword at a time: interleaving the walks of several dwords only costs registers, and left
                 // alone the compiler turns the running sums into trees evaluated at the end of the piece
@@ -1101,7 +1156,7 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
 // byte / packed two per byte (backward DFAs of at most 16 states: half the symbol traffic).
 template <int kMode, int kSym, bool kHasSlow>
 TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, int64_t lane, int64_t lane_bytes, uint8_t* ring,
-                      uint64_t out_base, DirectLane& L, uint32_t& status) {
+                      uint64_t out_base, DirectLane& L, uint32_t& status, uint32_t* wave_scratch = nullptr) {
     static_assert(kMode == 1 || kMode == 2, "count or emit");
     const uint32_t done_row = kDoneState * n_cls * 16u;
     const int64_t lo = lane * lane_bytes;
@@ -1114,6 +1169,7 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
     else row = (lo == a.vbeg || a.in_v0[lo - 1] == (uint8_t)'\n') ? 0u : kSkipState * n_cls * 16u;
     Stage S{};
     S.dbg = a.dbg;
+    S.wsc = wave_scratch;
     if (kMode == 2) {
         if (a.lp_emit) {
             // no count pass: this lane's lines are written where they were read
@@ -1294,17 +1350,22 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
         constexpr bool kEnd = decltype(end_tag)::value;
         const uint32_t y0 = kSym == 2 ? (y.x & 0xffffu) : y.x, y1 = kSym == 2 ? (y.x >> 16) : y.y,
                        y2 = kSym == 2 ? (y.y & 0xffffu) : y.z, y3 = kSym == 2 ? (y.y >> 16) : y.w;
+        // (between two flushes at most 65 bytes may arrive: 8 transitions of up to 5 bytes, or 4 of up to 9 with slow entries)
         if (!kEnd && T.p32) {
             dword_pairs(b.x, y0);
+            if (kMode == 2 && (kHasSlow || T.p32_slow)) stage_flush<false>(S);
             dword_pairs(b.y, y1);
             if (kMode == 2) stage_flush<false>(S);
             dword_pairs(b.z, y2);
+            if (kMode == 2 && (kHasSlow || T.p32_slow)) stage_flush<false>(S);
             dword_pairs(b.w, y3);
         } else {
             dword(end_tag, b.x, y0, rp);
+            if (kMode == 2 && kHasSlow) stage_flush<false>(S);
             dword(end_tag, b.y, y1, rp + 4u);
             if (kMode == 2) stage_flush<false>(S);
             dword(end_tag, b.z, y2, rp + 8u);
+            if (kMode == 2 && kHasSlow) stage_flush<false>(S);
             dword(end_tag, b.w, y3, rp + 12u);
         }
         if (kMode == 2) stage_flush<false>(S);

@@ -337,8 +337,9 @@ constexpr int kDirectEntBytes = 2048;      // table rows in LDS when they all fi
 constexpr int kDirectPoolSmall = 2048;     // ... next to this much of pooled text
 constexpr int kDirectPoolBytes = 4096;     // larger tables stay in global memory (L1/L2); LDS takes their pooled texts when small
 constexpr int kDirectTabSmall = kDirectEntBytes + kDirectPoolSmall;
-constexpr int kDirectLds = 256 + kDirectTabSmall + kDirectThreads * kRingStride + 64;
-constexpr int kDirectLdsHot = 256 + kDirectPoolBytes + kDirectThreads * kRingStride + 64;
+constexpr int kDirectWsc = (kDirectThreads / kWave) * kWaveScratchBytes;       // posting tables of the emit pass's unit stores
+constexpr int kDirectLds = 256 + kDirectTabSmall + kDirectThreads * kRingStride + 64 + kDirectWsc;
+constexpr int kDirectLdsHot = 256 + kDirectPoolBytes + kDirectThreads * kRingStride + 64 + kDirectWsc;
 
 template <bool kLdsEnt>
 __device__ __forceinline__ StreamView direct_stage(const ScanArgs& a, uint8_t* smem) {
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_direct(ScanArgs a, in
     uint64_t base = 0;
     if (kMode == 2 && !a.lp_emit) {
         // lane offsets: workgroup-wide exclusive scan of the counts from the count launch
-        uint32_t* wpart = reinterpret_cast<uint32_t*>(smem + kLds - 64);
+        uint32_t* wpart = reinterpret_cast<uint32_t*>(smem + kLds - kDirectWsc - 64);
         const uint32_t mine = a.lane_counts[lane];
         const uint32_t incl = wave_scan_incl(mine);
         if ((threadIdx.x & (kWave - 1)) == kWave - 1) wpart[threadIdx.x / kWave] = incl;
@@ -393,9 +394,10 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_direct(ScanArgs a, in
             return;
         }
     }
-    stream_direct_lane<kMode, false, kSym>(a, T, n_cls, lane, lane_bytes, ring, base, L, st);
+    uint32_t* wsc = reinterpret_cast<uint32_t*>(smem + kLds - kDirectWsc + (threadIdx.x / kWave) * kWaveScratchBytes);
+    stream_direct_lane<kMode, false, kSym>(a, T, n_cls, lane, lane_bytes, ring, base, L, st, kMode == 2 ? wsc : nullptr);
     if (kMode == 1) {
-        uint64_t* part = reinterpret_cast<uint64_t*>(smem + kLds - 64);
+        uint64_t* part = reinterpret_cast<uint64_t*>(smem + kLds - kDirectWsc - 64);
         if (L.count > 0xffffffffull) { st |= kStCapacity; L.count = 0xffffffffull; }
         a.lane_counts[lane] = (uint32_t)L.count;
         const uint64_t wsum = wave_sum(L.count);
@@ -467,7 +469,8 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_g16(ScanArgs a, int64
             return;
         }
     }
-    g16_lane<kMode, kSym, kHasSlow>(a, T, h.n_cls, lane, lane_bytes, ring, base, L, st);
+    uint32_t* wsc = reinterpret_cast<uint32_t*>(tail + 64) + (threadIdx.x / kWave) * (kWaveScratchBytes / 4);
+    g16_lane<kMode, kSym, kHasSlow>(a, T, h.n_cls, lane, lane_bytes, ring, base, L, st, kMode == 2 ? wsc : nullptr);
     if (kMode == 1) {
         uint64_t* part = reinterpret_cast<uint64_t*>(tail);
         if (L.count > 0xffffffffull) { st |= kStCapacity; L.count = 0xffffffffull; }
@@ -753,7 +756,7 @@ int direct_block_threads() { return kDirectThreads; }
 template <int kSym, bool kHasSlow>
 void launch_g16(int which, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, hipStream_t s, int g16_bytes) {
     const int room = (g16_bytes + 15) / 16 * 16;
-    const int lds = 256 + room + kDirectPoolSmall + kDirectThreads * kRingStride + 64;
+    const int lds = 256 + room + kDirectPoolSmall + kDirectThreads * kRingStride + 64 + kDirectWsc;
     const int lds_count = 256 + room + 64;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_g16<1, kSym, kHasSlow>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_count);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_g16<2, kSym, kHasSlow>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
