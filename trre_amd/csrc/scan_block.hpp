@@ -794,6 +794,16 @@ TRRE_HD void stage_store_own_unit(Stage& s) {        // the unit at stream offse
     }
     s.fp += kUnitBytes;
 }
+// everything the lane holds goes to memory, by the lane itself: for the divergent slow paths (only some lanes of the
+// wave get here, so the wave cannot store their units for them)
+TRRE_HD void stage_flush_solo(Stage& s) {
+    while (s.wp - s.fp >= kUnitBytes) stage_store_own_unit(s);
+    *reinterpret_cast<uint32_t*>(s.buf + (s.wp & (kRingBytes - 1u))) = (uint32_t)s.acc;
+    const uint32_t end = s.wp + s.pb;
+    stage_store_span(s, s.fp == 0 ? s.skip : s.fp, end);
+    s.skip = end & (kUnitBytes - 1u);
+}
+// kAll = false: the complete units (all lanes of the wave must take part); true: what is left as well (end of the lane)
 template <bool kAll>
 TRRE_HD void stage_flush(Stage& s) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -953,8 +963,7 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
                                 } else {
                                     const uint8_t* r = T.pool + str_pool_off(ehi);
                                     if (len == 255u) len = str_pool_len(T, ehi);
-                                    stage_flush<false>(S);
-                                    stage_flush<true>(S);
+                                    stage_flush_solo(S);
                                     uint8_t* gp = stage_out_ptr(S);
                                     for (uint32_t i = 0; i < len; ++i) gp[i] = r[4 + i];
                                     stage_begin(S, S.buf, gp + len);
@@ -995,8 +1004,7 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
                                 // long replacement text: empty the staging buffer, write straight to memory
                                 const uint8_t* r = T.pool + str_pool_off(ehi);
                                 if (len == 255u) len = str_pool_len(T, ehi);
-                                stage_flush<false>(S);
-                                stage_flush<true>(S);
+                                stage_flush_solo(S);
                                 uint8_t* g = stage_out_ptr(S);
                                 for (uint32_t i = 0; i < len; ++i) g[i] = r[4 + i];
                                 stage_begin(S, S.buf, g + len);
@@ -1216,8 +1224,7 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
         // long replacement text: empty the staging buffer, write straight to memory
         const uint8_t* rec = T.pool + str_pool_off(ehi);
         if (len == 255u) len = str_pool_len(T, ehi);
-        stage_flush<false>(S);
-        stage_flush<true>(S);
+        stage_flush_solo(S);
         uint8_t* gp = stage_out_ptr(S);
         for (uint32_t i = 0; i < len; ++i) gp[i] = rec[4 + i];
         stage_begin(S, S.buf, gp + len);
