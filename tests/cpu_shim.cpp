@@ -248,6 +248,39 @@ void run_direct_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uin
     }
 }
 
+// large tables in their fallback form (k_stream_fb): count, scan, emit — lane by lane
+FbView fb_view(const ScanArgs& a) {
+    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
+    FbView T;
+    T.cls = a.blob + h.off_cls;
+    T.rec = reinterpret_cast<const uint64_t*>(a.blob + h.off_fb_rec);
+    T.tab = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_tab);
+    T.lit = reinterpret_cast<const uint64_t*>(a.blob + h.off_fb_lit);
+    T.esc = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_esc);
+    T.pool = a.blob + h.off_fb_pool;
+    return T;
+}
+void run_fb_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64_t& total_out) {
+    const FbView T = fb_view(a);
+    const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
+    alignas(16) uint8_t ring_room[kBRingStride];
+    uint8_t* ring = ring_room + kBRingPad;
+    std::vector<uint64_t> cnt(n_lanes), base(n_lanes);
+    for (int64_t lane = 0; lane < n_lanes; ++lane) {
+        DirectLane L;
+        fb_lane<1>(a, T, lane, lane_bytes, ring, 0, L, status);
+        cnt[lane] = L.count;
+    }
+    uint64_t run = 0;
+    for (int64_t lane = 0; lane < n_lanes; ++lane) { base[lane] = run; run += cnt[lane]; }
+    total_out = run;
+    if (run > a.cap) { status |= kStCapacity; return; }
+    for (int64_t lane = n_lanes - 1; lane >= 0; --lane) {
+        DirectLane L;
+        fb_lane<2>(a, T, lane, lane_bytes, ring, base[lane], L, status);
+    }
+}
+
 // Host emulation of the window kernel (k_stream_lpw): 64 lanes in lockstep over an
 // emulated pair of LDS tiles, the same lane / mover code as the device.
 template <bool kWide>
@@ -387,7 +420,7 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
     a.gscratch = want_scratch ? scratch.data() : nullptr;
     uint32_t status = 0;
     uint64_t total = 0;
-    if (family != 3 && family != 5 && family != 7 && family != 9 && cap < n) return -9;
+    if (family != 3 && family != 5 && family != 7 && family != 9 && family != 22 && cap < n) return -9;
     if (family == 1) { run_bytemap(a, status); total = n; }
     else if (family == 8) {
         if (reinterpret_cast<const StreamBlobHeader*>(blob)->lpw_bytes == 0) return -5;
@@ -401,6 +434,10 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
         const bool g16 = family == 20 && reinterpret_cast<const StreamBlobHeader*>(blob)->g16_bytes != 0;
         run_direct_lp_emit<>(a, geo == 0 ? 2048 : 64, status, g16);
         total = n;
+    }
+    else if (family == 22) {                          // stream general on the fallback form of a large table
+        if (reinterpret_cast<const StreamBlobHeader*>(blob)->fb_states == 0) return -5;
+        run_fb_gen(a, geo == 0 ? 2048 : 48, status, total);
     }
     else if (family == 7 || family == 9) {
         const bool g16 = family == 7 && reinterpret_cast<const StreamBlobHeader*>(blob)->g16_bytes != 0;

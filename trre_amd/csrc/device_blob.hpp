@@ -46,8 +46,16 @@ struct StreamBlobHeader {
     uint32_t off_p32, p32_bytes;              // pair form (0 bytes when not available)
     uint32_t p32_slow;                        // some pair entry is "slow"
     uint32_t pad;
+    // fallback form of a large table (front.hpp, StreamTables::fb_*): 0 states when not available
+    uint32_t fb_states, off_fb_rec;           // u64[fb_states]
+    uint32_t fb_tab_entries, off_fb_tab;      // u32[fb_tab_entries]
+    uint32_t fb_lits, off_fb_lit;             // u64[fb_lits]
+    uint32_t off_fb_esc, off_fb_pool;         // escape records (4 words each) and their texts
 };
-static_assert(sizeof(StreamBlobHeader) == 80, "header layout");
+static_assert(sizeof(StreamBlobHeader) == 112, "header layout");
+
+// entry bits of the fallback form (front.hpp)
+constexpr uint32_t kFbCc = 1u << 16, kFbNl = 1u << 17, kFbEol = 1u << 18, kFbEsc = 1u << 23;
 
 // backward pass of the guided families (guided_build.cpp): a DFA read right to left
 constexpr uint32_t kMagicRev = 0x31525254u;   // "TRR1"

@@ -28,6 +28,10 @@ void launch_direct_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t
 // backward pass of the guided families: fills a.sym_v0 for positions [0 .. round_up(a.vend, 64)) (packed: round_up(.., 128), two per byte)
 void launch_rev_sweep(const ScanArgs& a, int tab_bytes, int64_t lane_bytes, void* stream, bool packed);
 void launch_lpw_kernel(int ent_bytes, bool wide, bool direct_ent_in_lds, const ScanArgs& a, int64_t lane_bytes, void* stream);
+// count / emit passes over the fallback form of a large table (StreamTables::fb_*); hdr: the host's copy of the stream
+// blob's header.  Chunks are those of the direct kernels (direct_block_threads() lanes each).
+void launch_fb_kernel(int which, const ScanArgs& a, const void* hdr, int64_t lane_bytes, int64_t n_chunks, void* stream);
+bool fb_fits(const void* hdr);
 void launch_chunk_scan(const uint64_t* total, uint64_t* base, int64_t n_chunks, void* stream);
 void launch_bytemap(const ScanArgs& a, void* stream);
 

@@ -198,10 +198,25 @@ void serialize_stream(const trre::StreamTables& t, std::vector<uint8_t>& b) {
     h.off_g16 = (uint32_t)off; h.g16_bytes = (uint32_t)(t.g16.size() * 4); off += t.g16.size() * 4;
     off = align_up(off, 16);
     h.off_p32 = (uint32_t)off; h.p32_bytes = (uint32_t)(t.p32.size() * 4); h.p32_slow = t.p32_slow ? 1u : 0u; off += t.p32.size() * 4;
+    off = align_up(off, 16);
+    if (t.fb_ok) {
+        h.fb_states = t.fb_states; h.off_fb_rec = (uint32_t)off; off = align_up(off + t.fb_rec.size() * 8, 16);
+        h.fb_tab_entries = (uint32_t)t.fb_tab.size(); h.off_fb_tab = (uint32_t)off; off = align_up(off + t.fb_tab.size() * 4, 16);
+        h.fb_lits = (uint32_t)t.fb_lit.size(); h.off_fb_lit = (uint32_t)off; off = align_up(off + t.fb_lit.size() * 8, 16);
+        h.off_fb_esc = (uint32_t)off; off = align_up(off + t.fb_esc.size() * 4, 16);
+        h.off_fb_pool = (uint32_t)off; off += t.fb_pool.size();
+    }
     off = align_up(off + 16, 16);
     h.total_bytes = (uint32_t)off;
     b.assign(off, 0);
     put(b, 0, &h, 1);
+    if (t.fb_ok) {
+        put(b, h.off_fb_rec, t.fb_rec.data(), t.fb_rec.size());
+        put(b, h.off_fb_tab, t.fb_tab.data(), t.fb_tab.size());
+        put(b, h.off_fb_lit, t.fb_lit.data(), t.fb_lit.size());
+        put(b, h.off_fb_esc, t.fb_esc.data(), t.fb_esc.size());
+        put(b, h.off_fb_pool, t.fb_pool.data(), t.fb_pool.size());
+    }
     put(b, h.off_cls, t.cls.data(), 256);
     put(b, h.off_ent, t.ent.data(), t.ent.size());
     put(b, h.off_pool, t.pool.data(), t.pool.size());
@@ -450,6 +465,13 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
             args.lp_emit = 1;
             launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, sym_mode, g16_slow);
         }
+    } else if (direct && !is_guided(family) && stt.fb_ok && getenv("TRRE_FB") && fb_fits(p->sblob.data())) {
+        // a large table (a dictionary) in its fallback form: every per-byte lookup in LDS (TRRE_NO_FB=1: the 8-byte rows
+        // through L1/L2, for A/B runs)
+        launch_fb_kernel(1, args, p->sblob.data(), lane_bytes, n_chunks, stream);
+        launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);
+        launch_fb_kernel(2, args, p->sblob.data(), lane_bytes, n_chunks, stream);
+        pd.total_at = cx->d_chunk_base + n_chunks;
     } else if (direct) {
         static const bool no_g16 = getenv("TRRE_NO_G16") != nullptr;          // A/B: the 8-byte entries
         const int g16 = stt.g16_ok && !no_g16 ? (int)(align_up(stt.g16.size() * 4, 16) + stt.p32.size() * 4) : 0;   // LDS room: 16-byte + pair forms

@@ -744,7 +744,50 @@ TRRE_HD void stage_begin(Stage& s, uint8_t* buf, uint8_t* first_out_byte) {
     s.fp = 0;
     s.acc = 0;
 }
-TRRE_HD uint8_t* stage_out_ptr(const Stage& s) { return s.g0 + s.wp + s.pb; }      // where the next byte goes
+// The byte-granular variant (fb_lane): no register window — a transition stores its 8 bytes straight into the ring at the
+// byte position (LDS takes unaligned 8-byte stores on gfx950) and moves on by as many as count; what lies beyond is
+// overwritten by the next one.  A store that runs over the end of the ring is repeated 128 bytes lower, so the ring has
+// 8 spare bytes on either side.  wp is a byte offset here.
+constexpr int kBRingPad = 8;
+constexpr int kBRingStride = 148;              // 8 + 128 + 8, rounded to an odd number of dwords
+struct BStage {
+    uint8_t* buf;        // the lane's ring (kRingBytes, 4-byte aligned; 8 spare bytes below and above)
+    uint8_t* g0;
+    uint32_t wp;         // stream offset of the next byte
+    uint32_t fp, skip, dbg;
+    uint32_t* wsc;
+};
+TRRE_HD void stage_begin(BStage& s, uint8_t* buf, uint8_t* first_out_byte) {
+    const uintptr_t start = reinterpret_cast<uintptr_t>(first_out_byte);
+    s.buf = buf;
+    s.g0 = reinterpret_cast<uint8_t*>(start & ~(uintptr_t)(kUnitBytes - 1u));
+    s.skip = (uint32_t)(start & (kUnitBytes - 1u));
+    s.wp = s.skip;
+    s.fp = 0;
+}
+struct __attribute__((packed)) UnalignedU64 { uint64_t v; };
+// 8 bytes at the fill position, of which the first n (0..8) count
+TRRE_HD void bstage_put8(BStage& s, uint64_t v, uint32_t n) {
+    const uint32_t o = s.wp & (kRingBytes - 1u);
+    if (!(s.dbg & 2u)) {
+        reinterpret_cast<UnalignedU64*>(s.buf + o)->v = v;
+        if (TRRE_WAVE_ANY(o > kRingBytes - 8u)) {
+            if (o > kRingBytes - 8u) reinterpret_cast<UnalignedU64*>(s.buf + o - kRingBytes)->v = v;     // the part beyond the end, at the start
+        }
+    }
+    s.wp += n;
+}
+// one byte at the fill position, counted or not
+TRRE_HD void bstage_put1(BStage& s, uint32_t b, uint32_t n) {
+    if (!(s.dbg & 2u)) s.buf[s.wp & (kRingBytes - 1u)] = (uint8_t)b;
+    s.wp += n;
+}
+TRRE_HD uint32_t stage_fill_end(const Stage& s) { return s.wp + s.pb; }             // stream offset of the next byte
+TRRE_HD uint32_t stage_fill_end(const BStage& s) { return s.wp; }
+TRRE_HD void stage_spill(Stage& s) { *reinterpret_cast<uint32_t*>(s.buf + (s.wp & (kRingBytes - 1u))) = (uint32_t)s.acc; }   // the partial dword of the window
+TRRE_HD void stage_spill(BStage&) {}
+template <class St>
+TRRE_HD uint8_t* stage_out_ptr(const St& s) { return s.g0 + stage_fill_end(s); }      // where the next byte goes
 // append the low n (0..4) bytes of v; the bytes of v above n must be zero
 TRRE_HD void stage_append_n4(Stage& s, uint32_t v, uint32_t n) {
     s.acc |= (uint64_t)v << (8u * s.pb);
@@ -772,14 +815,16 @@ TRRE_HD void stage_append_text_c(Stage& s, uint64_t text, uint32_t len, uint32_t
     stage_append_n4(s, cc ? c : 0u, cc);
 }
 // stream bytes [from, to) from the ring to memory: single bytes up to a dword boundary, dwords, single bytes
-TRRE_HD void stage_store_span(Stage& s, uint32_t from, uint32_t to) {
+template <class St>
+TRRE_HD void stage_store_span(St& s, uint32_t from, uint32_t to) {
     uint32_t i = from;
     for (; i < to && (i & 3u); ++i) s.g0[i] = s.buf[i & (kRingBytes - 1u)];
     for (; i + 4u <= to; i += 4u)
         *reinterpret_cast<uint32_t*>(s.g0 + i) = *reinterpret_cast<const uint32_t*>(s.buf + (i & (kRingBytes - 1u)));
     for (; i < to; ++i) s.g0[i] = s.buf[i & (kRingBytes - 1u)];
 }
-TRRE_HD void stage_store_own_unit(Stage& s) {        // the unit at stream offset fp is complete: the lane stores it itself
+template <class St>
+TRRE_HD void stage_store_own_unit(St& s) {        // the unit at stream offset fp is complete: the lane stores it itself
     if (s.fp == 0 && s.skip) {
         stage_store_span(s, s.skip, kUnitBytes);     // once per lane: the unit it shares with its predecessor
     } else {
@@ -796,16 +841,17 @@ TRRE_HD void stage_store_own_unit(Stage& s) {        // the unit at stream offse
 }
 // everything the lane holds goes to memory, by the lane itself: for the divergent slow paths (only some lanes of the
 // wave get here, so the wave cannot store their units for them)
-TRRE_HD void stage_flush_solo(Stage& s) {
+template <class St>
+TRRE_HD void stage_flush_solo(St& s) {
     while (s.wp - s.fp >= kUnitBytes) stage_store_own_unit(s);
-    *reinterpret_cast<uint32_t*>(s.buf + (s.wp & (kRingBytes - 1u))) = (uint32_t)s.acc;
-    const uint32_t end = s.wp + s.pb;
+    stage_spill(s);
+    const uint32_t end = stage_fill_end(s);
     stage_store_span(s, s.fp == 0 ? s.skip : s.fp, end);
     s.skip = end & (kUnitBytes - 1u);
 }
 // kAll = false: the complete units (all lanes of the wave must take part); true: what is left as well (end of the lane)
-template <bool kAll>
-TRRE_HD void stage_flush(Stage& s) {
+template <bool kAll, class St>
+TRRE_HD void stage_flush(St& s) {
 #if defined(__HIP_DEVICE_COMPILE__)
     if (s.wsc) {
         // a lane's first unit may share its 64 bytes with the lane before it: that one it stores itself
@@ -851,8 +897,8 @@ TRRE_HD void stage_flush(Stage& s) {
     }
     if (kAll) {
         // the rest: what is in the ring and the partial dword of the window
-        *reinterpret_cast<uint32_t*>(s.buf + (s.wp & (kRingBytes - 1u))) = (uint32_t)s.acc;
-        const uint32_t end = s.wp + s.pb;
+        stage_spill(s);
+        const uint32_t end = stage_fill_end(s);
         stage_store_span(s, s.fp == 0 ? s.skip : s.fp, end);
         s.skip = end & (kUnitBytes - 1u);     // (a caller that goes on restarts with stage_begin at stage_out_ptr)
     }
@@ -1442,6 +1488,152 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
     if (kMode == 2 && a.lp_emit && ((seen & 8u) || (seen2 & 256u))) status |= kStNul;
     if (kMode == 1 && ((seen | seen2) & 64u)) status |= kStOverflow;            // bounded fold: the launch is void
     if ((kMode == 1 || a.lp_emit) && ((seen | seen2) & 16u)) status |= kStDiverge;   // guided tables: the reference's search never returns
+    L.count = cnt;
+}
+
+// =============================================================================================
+// Large tables in their fallback form (front.hpp, StreamTables::fb_*): the count and emit passes of a
+// dictionary-like program with every per-byte lookup in LDS.  The 8-byte rows of such a program (~0.9 MB for 1000
+// keys) are a gather through L1/L2 on every byte: the passes ran at the pace of the L1's tag lookups (one address per
+// clock and CU; count 1.65 ms and emit 2.9 ms per GiB, whatever the occupancy).  Here a state is one 8-byte record —
+// a 31-bit mask of its exceptional classes, where its exception entries start, and which dense row (and how many
+// more flushed bytes) stand for every other class — and an entry is 4 bytes: per byte one class lookup, one record,
+// one entry, no loop and no divergence.  What a transition emits is a prefix of the lane's last 7 input bytes (kept in
+// a register pair), or an owed replacement text (8 bytes from a small LDS table), then maybe the input byte or '\n'.
+// The odd cell that is none of that leaves the fast path through an escape record in global memory.
+// =============================================================================================
+struct FbView {
+    const uint8_t* cls;        // [256] (LDS)
+    const uint64_t* rec;       // [fb_states] (LDS)
+    const uint32_t* tab;       // entries (LDS)
+    const uint64_t* lit;       // literal texts (LDS)
+    const uint32_t* esc;       // escape records, 4 words each (global)
+    const uint8_t* pool;       // their texts (global)
+};
+TRRE_HD uint32_t fb_popc(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__popc(x);
+#else
+    return (uint32_t)__builtin_popcount(x);
+#endif
+}
+template <int kMode>
+TRRE_HD void fb_lane(const ScanArgs& a, const FbView& T, int64_t lane, int64_t lane_bytes, uint8_t* ring, uint64_t out_base, DirectLane& L,
+                     uint32_t& status, uint32_t* wave_scratch = nullptr) {
+    static_assert(kMode == 1 || kMode == 2, "count or emit");
+    const int64_t lo = lane * lane_bytes;
+    int64_t hi = lo + lane_bytes;
+    if (hi > a.vend) hi = a.vend;
+    const uint32_t rhi = (uint32_t)(hi > lo ? hi - lo : 0);
+    uint32_t st;                                                      // state id
+    if (lo >= hi) st = kDoneState;
+    else if (lo < a.vbeg) st = kSkipState;                            // filler then '\n' right before the input
+    else st = (lo == a.vbeg || a.in_v0[lo - 1] == (uint8_t)'\n') ? 0u : kSkipState;
+    BStage S{};
+    S.dbg = a.dbg;
+    S.wsc = wave_scratch;
+    if (kMode == 2) stage_begin(S, ring, a.out + out_base);
+    uint64_t cnt = 0;
+    uint64_t hist = 0;                                                // the last 7 input bytes: byte 6 = the one before the current
+    const int64_t vlast = (a.vend - 1) & ~(int64_t)15;               // the last readable aligned block
+    // an escape entry: the output spelled out in global memory (rare)
+    auto esc_count = [&](uint32_t e) -> uint32_t {
+        const uint32_t* r = T.esc + 4u * (((e >> 24) << 4) | ((e >> 19) & 15u));
+        return r[1] + r[2];
+    };
+    auto esc_emit = [&](uint32_t e, uint32_t c) {
+        const uint32_t* r = T.esc + 4u * (((e >> 24) << 4) | ((e >> 19) & 15u));
+        const uint8_t* text = T.pool + r[0];
+        const uint32_t len = r[1];
+        stage_flush_solo(S);
+        uint8_t* gp = stage_out_ptr(S);
+        for (uint32_t i = 0; i < len; ++i) gp[i] = text[i];
+        if (r[2]) gp[len] = (uint8_t)c;
+        stage_begin(S, S.buf, gp + len + r[2]);
+    };
+    // one dword (4 input bytes) whose first byte lies rp bytes into the sub-range; kEnd: a lane may finish in it
+    auto dword = [&](auto end_tag, const uint32_t w, const uint32_t rp) {
+        constexpr bool kEnd = decltype(end_tag)::value;
+        const uint32_t kk[4] = {T.cls[w & 0xffu], T.cls[(w >> 8) & 0xffu], T.cls[(w >> 16) & 0xffu], T.cls[w >> 24]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t k = kk[j], c = (w >> (8 * j)) & 0xffu;
+            const uint64_t r = T.rec[st];
+            const uint32_t mask = (uint32_t)r, rh = (uint32_t)(r >> 32);
+            const bool exc = (mask >> k) & 1u;
+            const uint32_t owed = mask >> 31;
+            const uint32_t field = (rh >> 14) & 0xfffu;               // the fallback row, or (owed) the literal's index
+            const uint32_t idx = exc ? (rh & 0x3fffu) + fb_popc(mask & ((1u << k) - 1u)) : (owed ? 0u : field) + k;
+            const uint32_t e = T.tab[idx];
+            const uint32_t n_rec = exc ? 0u : ((rh >> 26) & 7u) + owed;
+            if (kMode == 1) {
+                uint32_t add = n_rec + ((e >> 19) & 15u);
+                if (TRRE_WAVE_ANY(e & kFbEsc)) {
+                    if (e & kFbEsc) add = n_rec + esc_count(e);
+                }
+                cnt += add;
+            } else {
+                const uint32_t n_tot = n_rec + ((e >> 13) & 7u);      // 0..8 bytes of prefix
+                const uint64_t text = T.lit[owed ? field : 0u];
+                bstage_put8(S, owed ? text : hist >> (8u * (7u - (rh >> 29))), n_tot);
+                bstage_put1(S, (e & kFbCc) ? c : (uint32_t)'\n', ((e >> 16) | (e >> 17)) & 1u);
+                if (TRRE_WAVE_ANY(e & kFbEsc)) {
+                    if (e & kFbEsc) esc_emit(e, c);
+                }
+            }
+            hist = (hist >> 8) | (uint64_t)c << 48;
+            st = (kEnd && (e & kFbEol) && rp + (uint32_t)j + 1u >= rhi) ? kDoneState : (e & 0x1fffu);
+        }
+    };
+    auto block = [&](auto end_tag, const U128& b, const uint32_t rp) {
+        // (between two flushes at most 36 bytes arrive: 4 transitions of up to 9 bytes.  Not unrolled: the rare paths —
+        // escapes, the unit stores — would be there sixteen times, and the loop should stay in the instruction cache)
+#pragma clang loop unroll(disable)
+        for (int d = 0; d < 4; ++d) {
+            dword(end_tag, d == 0 ? b.x : (d == 1 ? b.y : (d == 2 ? b.z : b.w)), rp + 4u * (uint32_t)d);
+            if (kMode == 2) stage_flush<false>(S);
+            if (kMode == 1) TRRE_PIN(cnt);
+            TRRE_SCHED_FENCE();
+        }
+    };
+    U128 c0 = direct_load(a, lo), c1 = direct_load(a, lo + 16), c2 = direct_load(a, lo + 32), c3 = direct_load(a, lo + 48);
+    for (int64_t v = lo;; v += 64) {
+        if (!TRRE_WAVE_ANY(st != kDoneState)) break;
+        const int64_t vn = v + 64;
+        const int64_t x0 = vn < vlast ? vn : vlast, x1 = vn + 16 < vlast ? vn + 16 : vlast,
+                      x2 = vn + 32 < vlast ? vn + 32 : vlast, x3 = vn + 48 < vlast ? vn + 48 : vlast;
+        U128 n0 = *reinterpret_cast<const U128*>(a.in_v0 + x0), n1 = *reinterpret_cast<const U128*>(a.in_v0 + x1),
+             n2 = *reinterpret_cast<const U128*>(a.in_v0 + x2), n3 = *reinterpret_cast<const U128*>(a.in_v0 + x3);
+        if (TRRE_WAVE_ANY(vn < a.vbeg || vn + 64 > a.vend - 1)) {
+            n0 = direct_load(a, vn); n1 = direct_load(a, vn + 16); n2 = direct_load(a, vn + 32); n3 = direct_load(a, vn + 48);
+        }
+        const uint32_t rp = (uint32_t)(v - lo);
+        if (TRRE_WAVE_ALL(rp + 64u < rhi)) {
+            // interior piece: no lane of the wave can finish in it (g16_lane)
+#pragma clang loop unroll(disable)
+            for (int q = 0; q < 4; ++q) {
+                U128 b;
+                b.x = q == 0 ? c0.x : (q == 1 ? c1.x : (q == 2 ? c2.x : c3.x));
+                b.y = q == 0 ? c0.y : (q == 1 ? c1.y : (q == 2 ? c2.y : c3.y));
+                b.z = q == 0 ? c0.z : (q == 1 ? c1.z : (q == 2 ? c2.z : c3.z));
+                b.w = q == 0 ? c0.w : (q == 1 ? c1.w : (q == 2 ? c2.w : c3.w));
+                block(std::false_type{}, b, rp + 16u * (uint32_t)q);
+            }
+        } else {
+#pragma clang loop unroll(disable)
+            for (int q = 0; q < 4; ++q) {
+                U128 b;
+                b.x = q == 0 ? c0.x : (q == 1 ? c1.x : (q == 2 ? c2.x : c3.x));
+                b.y = q == 0 ? c0.y : (q == 1 ? c1.y : (q == 2 ? c2.y : c3.y));
+                b.z = q == 0 ? c0.z : (q == 1 ? c1.z : (q == 2 ? c2.z : c3.z));
+                b.w = q == 0 ? c0.w : (q == 1 ? c1.w : (q == 2 ? c2.w : c3.w));
+                block(std::true_type{}, b, rp + 16u * (uint32_t)q);
+            }
+        }
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    }
+    if (kMode == 2) stage_flush<true>(S);
+    (void)status;
     L.count = cnt;
 }
 

@@ -488,6 +488,82 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_g16(ScanArgs a, int64
     if (st && (threadIdx.x & (kWave - 1)) == 0) atomicOr(a.status, st);
 }
 
+// Count / emit passes over the fallback form of a large table (front.hpp, scan_block.hpp: fb_lane): records, entries and
+// literal texts in LDS (~75 KB for a 1000-key dictionary), so one workgroup per CU; the count pass runs 1024 lanes, the emit
+// pass 512 (its staging rings take the rest of the 160 KB).  Lanes are numbered as everywhere (256 per chunk of the
+// workspace), a workgroup covers kThreads / 256 chunks.
+//   smem: cls[256] | rec | tab | lit | emit: rings[kThreads] | 64 x (kThreads / 256) | posting tables
+template <int kMode, int kThreads>
+__global__ __launch_bounds__(kThreads) void k_stream_fb(ScanArgs a, int64_t lane_bytes, int64_t n_chunks) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
+    const uint32_t rec_bytes = (h.fb_states * 8u + 15u) & ~15u, tab_bytes = (h.fb_tab_entries * 4u + 15u) & ~15u, lit_bytes = (h.fb_lits * 8u + 15u) & ~15u;
+    for (int k = threadIdx.x; k < 256; k += kThreads) smem[k] = a.blob[h.off_cls + k];
+    {
+        const U128* e = reinterpret_cast<const U128*>(a.blob + h.off_fb_rec);
+        U128* d = reinterpret_cast<U128*>(smem + 256);
+        for (int k = threadIdx.x; k < (int)(rec_bytes / 16); k += kThreads) d[k] = e[k];
+        e = reinterpret_cast<const U128*>(a.blob + h.off_fb_tab);
+        d = reinterpret_cast<U128*>(smem + 256 + rec_bytes);
+        for (int k = threadIdx.x; k < (int)(tab_bytes / 16); k += kThreads) d[k] = e[k];
+        e = reinterpret_cast<const U128*>(a.blob + h.off_fb_lit);
+        d = reinterpret_cast<U128*>(smem + 256 + rec_bytes + tab_bytes);
+        for (int k = threadIdx.x; k < (int)(lit_bytes / 16); k += kThreads) d[k] = e[k];
+    }
+    __syncthreads();
+    FbView T;
+    T.cls = smem;
+    T.rec = reinterpret_cast<const uint64_t*>(smem + 256);
+    T.tab = reinterpret_cast<const uint32_t*>(smem + 256 + rec_bytes);
+    T.lit = reinterpret_cast<const uint64_t*>(smem + 256 + rec_bytes + tab_bytes);
+    T.esc = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_esc);
+    T.pool = a.blob + h.off_fb_pool;
+    uint8_t* top = smem + 256 + rec_bytes + tab_bytes + lit_bytes;
+    constexpr int kGroups = kThreads / kDirectThreads;                 // chunks of the workspace per workgroup
+    uint8_t* ring = top + threadIdx.x * kBRingStride + kBRingPad;      // (byte-granular staging: 8 spare bytes on either side)
+    uint8_t* tail = kMode == 1 ? top : top + kThreads * kBRingStride;  // 64 bytes per group
+    uint32_t* wsc = reinterpret_cast<uint32_t*>(tail + 64 * kGroups) + (threadIdx.x / kWave) * (kWaveScratchBytes / 4);
+    const int group = threadIdx.x / kDirectThreads, gtid = threadIdx.x % kDirectThreads;
+    const int64_t chunk = (int64_t)blockIdx.x * kGroups + group;
+    const int64_t lane = chunk * kDirectThreads + gtid;
+    const bool live = chunk < n_chunks;
+    DirectLane L;
+    uint32_t st = 0;
+    uint64_t base = 0;
+    if (kMode == 2) {
+        uint32_t* wpart = reinterpret_cast<uint32_t*>(tail + 64 * group);
+        const uint32_t mine = live ? a.lane_counts[lane] : 0u;
+        const uint32_t incl = wave_scan_incl(mine);
+        if ((threadIdx.x & (kWave - 1)) == kWave - 1) wpart[gtid / kWave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (int w = 0; w < gtid / kWave; ++w) wbase += wpart[w];
+        if (live) base = a.chunk_base[chunk] + wbase + incl - mine;
+        // (bases grow with the chunk index: if the last chunk of this workgroup does not fit, the output is void anyway)
+        const int64_t last = ((int64_t)blockIdx.x + 1) * kGroups - 1 < n_chunks - 1 ? ((int64_t)blockIdx.x + 1) * kGroups - 1 : n_chunks - 1;
+        if (a.chunk_base[last] + a.chunk_total[last] > a.cap) {
+            if (threadIdx.x == 0) atomicOr(a.status, kStCapacity);
+            return;
+        }
+    }
+    // (a lane of a chunk beyond the workspace starts beyond the input: it is done before it begins)
+    fb_lane<kMode>(a, T, live ? lane : (a.vend + lane_bytes - 1) / lane_bytes, lane_bytes, ring, base, L, st, kMode == 2 ? wsc : nullptr);
+    if (kMode == 1) {
+        uint64_t* part = reinterpret_cast<uint64_t*>(tail + 64 * group);
+        if (L.count > 0xffffffffull) { st |= kStCapacity; L.count = 0xffffffffull; }
+        if (live) a.lane_counts[lane] = (uint32_t)L.count;
+        const uint64_t wsum = wave_sum(L.count);
+        if ((threadIdx.x & (kWave - 1)) == 0) part[gtid / kWave] = wsum;
+        __syncthreads();
+        if (gtid == 0 && live) {
+            uint64_t t = 0;
+            for (int w = 0; w < kDirectThreads / kWave; ++w) t += part[w];
+            a.chunk_total[chunk] = t;
+        }
+    }
+    st = wave_or(st);
+    if (st && (threadIdx.x & (kWave - 1)) == 0) atomicOr(a.status, st);
+}
 // ------------------------------------------------------------------------------------------
 // memoryless byte map: out[v] = map[in[v]], 16 bytes per lane per step
 constexpr int kMapThreads = 256;
@@ -819,6 +895,29 @@ void launch_stream_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t
     if (ent_in_lds) launch_stream_t<true>(which, a, n_chunks, s);
     else launch_stream_t<false>(which, a, n_chunks, s);
 }
+
+constexpr int kFbCountThreads = 1024, kFbEmitThreads = 512;
+int fb_lds_bytes(const StreamBlobHeader& h, int which) {
+    const int tables = 256 + (int)((h.fb_states * 8u + 15u) & ~15u) + (int)((h.fb_tab_entries * 4u + 15u) & ~15u) + (int)((h.fb_lits * 8u + 15u) & ~15u);
+    if (which == 1) return tables + 64 * (kFbCountThreads / kDirectThreads);
+    return tables + kFbEmitThreads * kBRingStride + 64 * (kFbEmitThreads / kDirectThreads) + (kFbEmitThreads / kWave) * kWaveScratchBytes;
+}
+// which: 1 count, 2 emit; `hdr`: the host's copy of the blob header (table sizes)
+void launch_fb_kernel(int which, const ScanArgs& a, const void* hdr, int64_t lane_bytes, int64_t n_chunks, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int lds = fb_lds_bytes(*static_cast<const StreamBlobHeader*>(hdr), which);
+    if (which == 1) {
+        constexpr int kG = kFbCountThreads / kDirectThreads;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_fb<1, kFbCountThreads>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((k_stream_fb<1, kFbCountThreads>), dim3((unsigned)((n_chunks + kG - 1) / kG)), dim3(kFbCountThreads), lds, s, a, lane_bytes, n_chunks);
+    } else {
+        constexpr int kG = kFbEmitThreads / kDirectThreads;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_fb<2, kFbEmitThreads>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((k_stream_fb<2, kFbEmitThreads>), dim3((unsigned)((n_chunks + kG - 1) / kG)), dim3(kFbEmitThreads), lds, s, a, lane_bytes, n_chunks);
+    }
+}
+// the fallback form fits next to the emit pass's rings
+bool fb_fits(const void* hdr) { return fb_lds_bytes(*static_cast<const StreamBlobHeader*>(hdr), 2) <= 160 * 1024; }
 
 void launch_chunk_scan(const uint64_t* total, uint64_t* base, int64_t n_chunks, void* stream) {
     hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), total, base, n_chunks);

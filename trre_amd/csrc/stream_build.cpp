@@ -31,9 +31,12 @@
 // up and the launcher uses the general tile kernels instead.
 #include <algorithm>
 #include <array>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <unordered_map>
 
+#include "device_blob.hpp"
 #include "front.hpp"
 #include "stream_pack.hpp"
 
@@ -205,6 +208,7 @@ public:
                 }
             }
         }
+        first_copy_ = (uint32_t)names_.size();
         spread_long_outputs();
         return pack();
     }
@@ -308,6 +312,7 @@ private:
                     hit = made.emplace(rest, id).first;
                 }
                 Cell& x = rows_[s][c];
+                if (s < first_copy_) undo_.push_back(Undo{s, c, x});
                 x.out.resize(4);
                 x.next = hit->second;
             }
@@ -348,8 +353,191 @@ private:
         in.bounded = bounded_;
         StreamTables t = pack_stream_tables(in);
         t.cls = cls;
+        build_fallback(t, in, cls);
         return t;
     }
+
+    // Fallback form of a large table (front.hpp, StreamTables::fb_*), built from the rows as they were before
+    // spread_long_outputs (replacement texts are owed whole here).  Which classes of a state are exceptions to "the
+    // first bytes of the pending string, then the row of the state of its last byte (or of the root)" is found by
+    // comparing the cells, never assumed.
+    struct FbCell {
+        uint32_t next = 0, n = 0;
+        bool cc = false, nl = false, eol = false;
+        int esc = -1;                     // index of an escape record: the cell's output spelled out
+    };
+    void build_fallback(StreamTables& t, const StreamPackInput& in, const std::array<uint8_t, 256>& cls) {
+        const uint32_t n0 = first_copy_, C = t.n_cls;
+        const bool dbg = getenv("TRRE_FB_DEBUG") != nullptr;
+        if (t.g16_ok || bounded_ || C > 31 || n0 > 8000 || n0 < 64) return;   // small tables have the 16-byte form; 5-bit classes, 13-bit ids
+        std::vector<std::vector<Cell>> rows(in.rows.begin(), in.rows.begin() + n0);
+        for (const Undo& u : undo_) rows[u.s][cls[u.c]] = u.cell;
+        auto pending = [&](uint32_t s) { return (s == skip_ || s == done_) ? std::string() : names_[s]; };
+        for (uint32_t s = 0; s < n0; ++s)
+            if (pending(s).size() > 7) return;                                 // the kernels keep 8 bytes of history; a transition appends at most 9
+        std::map<std::string, uint32_t> lits;                                  // owed texts and literal prefixes
+        std::vector<std::string> lit_text;
+        auto lit_id = [&](const std::string& L) {
+            auto hit = lits.find(L);
+            if (hit == lits.end()) {
+                hit = lits.emplace(L, (uint32_t)lit_text.size()).first;
+                lit_text.push_back(L);
+            }
+            return hit->second;
+        };
+        std::map<std::string, uint32_t> owed;                                  // text -> owed-text state (ids from n0 on)
+        std::vector<std::string> owed_text;
+        std::vector<std::string> esc_text;
+        std::vector<bool> esc_cc;
+        size_t hot_escapes = 0;
+        uint32_t class_size[32] = {}, class_byte[32] = {};
+        for (int c = 0; c < 256; ++c) { ++class_size[cls[c]]; class_byte[cls[c]] = (uint32_t)c; }
+        // (the builder writes "ends with the input byte" as a flag: spelled out where the byte is known, so that equal
+        // outputs compare equal)
+        for (uint32_t s = 0; s < n0; ++s)
+            for (uint32_t k = 0; k < C; ++k)
+                if (rows[s][k].copy_c && class_size[k] == 1) { rows[s][k].out.push_back((char)class_byte[k]); rows[s][k].copy_c = false; }
+        // a cell as an entry: leading bytes of the state's pending string, then maybe the input byte or '\n'; a whole
+        // replacement text followed by the root state is owed
+        auto decompose = [&](uint32_t s, uint32_t k, FbCell& y) -> bool {
+            const Cell& x = rows[s][k];
+            if (x.ovf || x.diverge || x.next >= n0) return false;
+            const std::string w = pending(s);
+            size_t n = 0;
+            while (n < x.out.size() && n < w.size() && x.out[n] == w[n]) ++n;
+            std::string lit = x.out.substr(n);
+            bool cc = x.copy_c;
+            if (lit.size() == 1 && class_size[k] == 1 && (uint8_t)lit[0] == class_byte[k]) { lit.clear(); cc = true; }   // the input byte itself
+            y.next = x.next; y.n = (uint32_t)n; y.cc = cc; y.nl = false; y.eol = x.eol;
+            if (lit.empty()) return true;
+            if (lit == "\n" && !cc) { y.nl = true; return true; }
+            if (x.next == 0 && !cc && !x.eol && lit.size() <= 8) {
+                auto hit = owed.find(lit);
+                if (hit == owed.end()) {
+                    hit = owed.emplace(lit, (uint32_t)owed_text.size()).first;
+                    owed_text.push_back(lit);
+                }
+                y.next = n0 + hit->second;
+                return true;
+            }
+            // anything else is spelled out in an escape record (rare at run time: the kernels leave their fast path for it)
+            y.n = 0; y.cc = false; y.nl = false;
+            y.esc = (int)esc_text.size();
+            if (n == 0 && x.next == 0) ++hot_escapes;                          // a completed key with a long replacement: every hit would leave the fast path
+            esc_text.push_back(x.out);
+            esc_cc.push_back(x.copy_c);
+            return true;
+        };
+        auto same = [](const Cell& a, const Cell& b, const std::string& P) {
+            return a.next == b.next && a.copy_c == b.copy_c && a.eol == b.eol && a.ovf == b.ovf && a.diverge == b.diverge &&
+                   a.out.size() == P.size() + b.out.size() && a.out.compare(0, P.size(), P) == 0 &&
+                   a.out.compare(P.size(), std::string::npos, b.out) == 0;
+        };
+        // dense: root, SKIP, DONE, one-byte pending strings; every other state is "a prefix, then the row of a dense state":
+        // the first bytes of its pending string in front of the row of the state of its last byte or of the root, or a
+        // literal text in front of the root row (a completed key that waits for a longer one to fail)
+        struct Plan { bool dense = false, literal = false; uint32_t f = 0; std::string P; std::vector<uint32_t> exc; };
+        std::vector<Plan> plan(n0);
+        uint32_t n_dense = 0;
+        std::vector<uint32_t> row_at(n0, 0);
+        for (uint32_t s = 0; s < n0; ++s)
+            if (s == 0 || s == skip_ || s == done_ || names_[s].size() == 1) { plan[s].dense = true; row_at[s] = C * n_dense++; }
+        std::vector<std::vector<FbCell>> fr(n0, std::vector<FbCell>(C));
+        for (uint32_t s = 0; s < n0; ++s)
+            if (plan[s].dense)
+                for (uint32_t k = 0; k < C; ++k)
+                    if (!decompose(s, k, fr[s][k])) return;
+        size_t n_exc = 0;
+        for (uint32_t s = 0; s < n0; ++s) {
+            if (plan[s].dense) continue;
+            const std::string& w = names_[s];
+            std::vector<Plan> tries;
+            for (size_t keep = 0; keep <= 1; ++keep) {
+                auto hit = index_.find(w.substr(w.size() - keep));
+                if (hit == index_.end() || hit->second >= n0 || !plan[hit->second].dense) continue;
+                Plan p;
+                p.f = hit->second;
+                p.P = w.substr(0, w.size() - keep);
+                tries.push_back(std::move(p));
+            }
+            for (uint32_t k = 0; k < C; ++k) {                                 // a literal in front of the root row: read it off any cell
+                const Cell& x = rows[s][k];
+                const Cell& r = rows[0][k];
+                if (x.out.size() <= r.out.size() || x.out.size() - r.out.size() > 8) continue;
+                Plan p;
+                p.literal = true;
+                p.f = 0;
+                p.P = x.out.substr(0, x.out.size() - r.out.size());
+                tries.push_back(std::move(p));
+                break;
+            }
+            int best = -1;
+            for (size_t i = 0; i < tries.size(); ++i) {
+                Plan& p = tries[i];
+                for (uint32_t k = 0; k < C; ++k)
+                    if (!same(rows[s][k], rows[p.f][k], p.P)) p.exc.push_back(k);
+                if (best < 0 || p.exc.size() < tries[best].exc.size()) best = (int)i;
+            }
+            if (best < 0) return;
+            plan[s] = tries[best];
+            for (uint32_t k : plan[s].exc)
+                if (!decompose(s, k, fr[s][k])) return;
+            n_exc += plan[s].exc.size();
+        }
+        const uint32_t n_all = n0 + (uint32_t)owed_text.size();
+        for (const std::string& L : owed_text) lit_id(L);
+        for (uint32_t s = 0; s < n0; ++s) if (plan[s].literal) lit_id(plan[s].P);
+        const size_t tab_entries = (size_t)n_dense * C + n_exc;
+        const size_t lds = 256 + (size_t)n_all * 8 + tab_entries * 4 + lit_text.size() * 8;
+        if (dbg)
+            fprintf(stderr, "fallback form: %u states + %zu owed texts, %u classes, %u dense, %zu exceptions, %zu literals, %zu escapes, %zu bytes of LDS\n", n0,
+                    owed_text.size(), C, n_dense, n_exc, lit_text.size(), esc_text.size(), lds);
+        if (esc_text.size() > 4095 || hot_escapes > 16) return;               // escapes are for the odd cell, not for every completed key
+        if (n_all > 8191 || tab_entries > 16383 || lit_text.size() > 4095 || (size_t)n_dense * C > 4095 || lds > kFallbackLdsBytes) return;
+        auto entry = [](const FbCell& y) -> uint32_t {
+            if (y.esc >= 0) return y.next | (y.eol ? kFbEol : 0u) | kFbEsc | ((uint32_t)y.esc & 15u) << 19 | ((uint32_t)y.esc >> 4) << 24;
+            return y.next | y.n << 13 | (y.cc ? kFbCc : 0u) | (y.nl ? kFbNl : 0u) | (y.eol ? kFbEol : 0u) | (y.n + (y.cc ? 1u : 0u) + (y.nl ? 1u : 0u)) << 19;
+        };
+        t.fb_rec.assign(n_all, 0);
+        t.fb_tab.assign(tab_entries, 0);
+        t.fb_lit.assign(lit_text.size(), 0);
+        for (size_t i = 0; i < lit_text.size(); ++i)
+            for (size_t b = 0; b < lit_text[i].size(); ++b) t.fb_lit[i] |= (uint64_t)(uint8_t)lit_text[i][b] << (8 * b);
+        size_t at = (size_t)n_dense * C;
+        for (uint32_t s = 0; s < n0; ++s) {
+            const uint64_t wlen = pending(s).size();
+            if (plan[s].dense) {
+                for (uint32_t k = 0; k < C; ++k) t.fb_tab[row_at[s] + k] = entry(fr[s][k]);
+                t.fb_rec[s] = (uint64_t)((1u << C) - 1u) | ((uint64_t)row_at[s] | wlen << 29) << 32;
+                continue;
+            }
+            uint32_t mask = 0;
+            const size_t x = plan[s].exc.empty() ? 0 : at;
+            for (uint32_t k : plan[s].exc) { mask |= 1u << k; t.fb_tab[at++] = entry(fr[s][k]); }
+            if (plan[s].literal)
+                t.fb_rec[s] = (uint64_t)(mask | 1u << 31) | ((uint64_t)x | (uint64_t)lit_id(plan[s].P) << 14 | (uint64_t)(plan[s].P.size() - 1) << 26 | wlen << 29) << 32;
+            else
+                t.fb_rec[s] = (uint64_t)mask | ((uint64_t)x | (uint64_t)row_at[plan[s].f] << 14 | (uint64_t)plan[s].P.size() << 26 | wlen << 29) << 32;
+        }
+        for (size_t i = 0; i < owed_text.size(); ++i)
+            t.fb_rec[n0 + i] = (uint64_t)(1u << 31) | ((uint64_t)lit_id(owed_text[i]) << 14 | (uint64_t)(owed_text[i].size() - 1) << 26) << 32;
+        // escape records: {offset of the text in fb_pool, its length, 1 = then the input byte, 0}
+        for (size_t i = 0; i < esc_text.size(); ++i) {
+            t.fb_esc.push_back((uint32_t)t.fb_pool.size());
+            t.fb_esc.push_back((uint32_t)esc_text[i].size());
+            t.fb_esc.push_back(esc_cc[i] ? 1u : 0u);
+            t.fb_esc.push_back(0u);
+            t.fb_pool.insert(t.fb_pool.end(), esc_text[i].begin(), esc_text[i].end());
+        }
+        t.fb_states = n_all;
+        t.fb_first_owed = n0;
+        t.fb_dense = n_dense;
+        t.fb_ok = true;
+    }
+    static constexpr size_t kFallbackLdsBytes = 90 * 1024;   // the tables' share of the 160 KB (the rest: the emit pass's staging rings)
+    struct Undo { uint32_t s; int c; Cell cell; };
+    std::vector<Undo> undo_;          // the cells spread_long_outputs changed, as they were
+    uint32_t first_copy_ = 0;         // states from here on are the "owed bytes" copies of the root row (spread_long_outputs)
 
     const AttemptModel& m_;
     StreamLimits lim_;
