@@ -253,14 +253,17 @@ FbView fb_view(const ScanArgs& a) {
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
     FbView T;
     T.cls = a.blob + h.off_cls;
-    T.rec = reinterpret_cast<const uint64_t*>(a.blob + h.off_fb_rec);
-    T.tab = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_tab);
+    T.comb = reinterpret_cast<const uint64_t*>(a.blob + h.off_fb_comb);
     T.lit = reinterpret_cast<const uint64_t*>(a.blob + h.off_fb_lit);
+    T.esc_slot = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_esc_slot);
     T.esc = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_esc);
     T.pool = a.blob + h.off_fb_pool;
+    T.n_esc = h.fb_escs;
+    for (int i = 0; i < 3; ++i) { T.start[i][0] = h.fb_start[i][0]; T.start[i][1] = h.fb_start[i][1]; }
     return T;
 }
-void run_fb_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64_t& total_out) {
+// emit8: the emit pass on the 8-byte rows (what the runtime launches: the two forms must agree lane by lane)
+void run_fb_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64_t& total_out, bool emit8) {
     const FbView T = fb_view(a);
     const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
     alignas(16) uint8_t ring_room[kBRingStride];
@@ -275,9 +278,13 @@ void run_fb_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64_
     for (int64_t lane = 0; lane < n_lanes; ++lane) { base[lane] = run; run += cnt[lane]; }
     total_out = run;
     if (run > a.cap) { status |= kStCapacity; return; }
+    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
+    const StreamView T8 = direct_view(a);
+    alignas(16) uint8_t ring8[kRingStride];
     for (int64_t lane = n_lanes - 1; lane >= 0; --lane) {
         DirectLane L;
-        fb_lane<2>(a, T, lane, lane_bytes, ring, base[lane], L, status);
+        if (emit8) stream_direct_lane<2, false, false>(a, T8, h.n_cls, lane, lane_bytes, ring8, base[lane], L, status);
+        else fb_lane<2>(a, T, lane, lane_bytes, ring, base[lane], L, status);
     }
 }
 
@@ -420,7 +427,7 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
     a.gscratch = want_scratch ? scratch.data() : nullptr;
     uint32_t status = 0;
     uint64_t total = 0;
-    if (family != 3 && family != 5 && family != 7 && family != 9 && family != 22 && cap < n) return -9;
+    if (family != 3 && family != 5 && family != 7 && family != 9 && family != 22 && family != 23 && cap < n) return -9;
     if (family == 1) { run_bytemap(a, status); total = n; }
     else if (family == 8) {
         if (reinterpret_cast<const StreamBlobHeader*>(blob)->lpw_bytes == 0) return -5;
@@ -435,9 +442,9 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
         run_direct_lp_emit<>(a, geo == 0 ? 2048 : 64, status, g16);
         total = n;
     }
-    else if (family == 22) {                          // stream general on the fallback form of a large table
-        if (reinterpret_cast<const StreamBlobHeader*>(blob)->fb_states == 0) return -5;
-        run_fb_gen(a, geo == 0 ? 2048 : 48, status, total);
+    else if (family == 22 || family == 23) {          // stream general on the fallback form of a large table (23: count pass only)
+        if (reinterpret_cast<const StreamBlobHeader*>(blob)->fb_slots == 0) return -5;
+        run_fb_gen(a, geo == 0 ? 2048 : 48, status, total, family == 23);
     }
     else if (family == 7 || family == 9) {
         const bool g16 = family == 7 && reinterpret_cast<const StreamBlobHeader*>(blob)->g16_bytes != 0;

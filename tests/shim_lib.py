@@ -49,7 +49,7 @@ def mask_bytes_of(blob, engine):
 def shim_scan(blob, engine, family, data, geo=1, in_mis=0, out_mis=0, scratch=True, cap=None):
     """Run one kernel family of the device code on the host.  Returns (output bytes, status)."""
     if cap is None:
-        cap = len(data) * 8 + 64 if family in (3, 5, 7, 9, 22) else len(data)     # (20, 21: length-preserving)
+        cap = len(data) * 8 + 64 if family in (3, 5, 7, 9, 22, 23) else len(data)     # (20, 21: length-preserving)
     out = ctypes.create_string_buffer(max(cap, 1))
     m = ctypes.c_size_t()
     st = ctypes.c_uint32()
@@ -65,7 +65,7 @@ def shim_scan(blob, engine, family, data, geo=1, in_mis=0, out_mis=0, scratch=Tr
 def has_fallback_form(prog):
     """The stream tables carry the fallback form of a large table (StreamBlobHeader::fb_states)."""
     blob = prog.export_stream_tables()
-    return bool(blob) and len(blob) >= 112 and struct.unpack_from("<28I", blob, 0)[20] != 0
+    return bool(blob) and len(blob) >= 144 and struct.unpack_from("<36I", blob, 0)[20] != 0
 
 
 # shim ids of the guided families (ABI ids 6, 7): LP by the emit pass alone on the 16-byte entries (as the runtime
@@ -73,7 +73,8 @@ def has_fallback_form(prog):
 GUIDED_LP, GUIDED_GEN, GUIDED_GEN8, GUIDED_LP_RING, GUIDED_LP8 = 10, 11, 12, 13, 14
 GUIDED_LP_ALL = (GUIDED_LP, GUIDED_LP_RING, GUIDED_LP8)
 STREAM_LP_EMIT, STREAM_LP_EMIT8 = 20, 21            # stream LP family by the emit pass alone (no window form)
-STREAM_FB = 22                                       # stream general family on the fallback form of a large table
+STREAM_FB, STREAM_FB_COUNT = 22, 23                  # stream general family on the fallback form of a large table: both passes /
+                                                     # the count pass only, emit on the 8-byte rows (what the runtime launches)
 
 
 def shim_scan_guided(prog, family, data, geo=1, in_mis=0, out_mis=0):
@@ -111,7 +112,7 @@ def scan_like_runtime(prog, data, geo=1, family=None, in_mis=0, out_mis=0):
         fam = {6: GUIDED_LP, 7: GUIDED_GEN}.get(info.kernel, info.kernel)
     if fam in (GUIDED_LP, GUIDED_GEN, GUIDED_GEN8, GUIDED_LP_RING, GUIDED_LP8):
         return scan_guided_like_runtime(prog, data, geo, fam, in_mis, out_mis)
-    blob = prog.export_stream_tables() if fam in (4, 5, 6, 7, 8, 9, 20, 21, 22) else prog.export_tables()
+    blob = prog.export_stream_tables() if fam in (4, 5, 6, 7, 8, 9, 20, 21, 22, 23) else prog.export_tables()
     out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
     if out is None:                         # family 8 without a window form: nothing to run
         fam = 6
@@ -125,7 +126,7 @@ def scan_like_runtime(prog, data, geo=1, family=None, in_mis=0, out_mis=0):
     assert not st & ST_MISMATCH, "count and emit passes disagree"
     if st & ST_DIVERGE:
         raise RuntimeError("diverges")
-    if fam not in (3, 5, 7, 9, 22) and st & ST_NUL:
+    if fam not in (3, 5, 7, 9, 22, 23) and st & ST_NUL:
         gen = (7 if fam in (6, 8, 20, 21) else 5) if info.stream_states else 3
         blob = prog.export_stream_tables() if gen in (5, 7) else prog.export_tables()
         out, st = shim_scan(blob, info.engine, gen, data, geo, in_mis, out_mis)

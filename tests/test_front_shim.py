@@ -100,6 +100,8 @@ def shim_families(p):
         fams += [6, 8, shim_lib.STREAM_LP_EMIT, shim_lib.STREAM_LP_EMIT8]      # 7/9 direct walkers of the general one)
     if 5 in fams:
         fams += [7, 9]
+        if shim_lib.has_fallback_form(p):      # a large table: the count pass (and, off by default, the emit pass) in LDS
+            fams += [shim_lib.STREAM_FB, shim_lib.STREAM_FB_COUNT]
     return fams + guided_families(p)
 
 
@@ -240,9 +242,59 @@ def test_dictionary_config_through_the_fold():
         p = trre_amd.Program(pat, eng)
         assert p.info.stream_states > 100 and p.info.kernel == trre_amd.KERNEL_STREAM_GEN
         want = Oracle(pat, eng).scan(data)
+        assert shim_lib.has_fallback_form(p)      # (what the runtime's count pass walks for a table of this size)
         for fam in shim_families(p):
             assert shim_lib.scan_like_runtime(p, data, geo=0, family=fam) == want, (eng, fam)
             assert shim_lib.scan_like_runtime(p, data, geo=1, family=fam) == want, (eng, fam)
+
+
+def test_fallback_form_of_large_tables():
+    """Dictionaries whose tables get the fallback form (front.hpp, StreamTables::fb_*): keys that contain other keys
+    (a completed key inside a longer attempt: literal-prefix states and escape records), keys that are prefixes of
+    longer keys (NFT priority: the longer one listed first), replacement texts of 0..12 bytes (owed texts, escapes),
+    NULs, keys ending lines, key upon key.  Both passes on the form, and the count pass with the emit pass on the
+    8-byte rows (what the runtime launches), against the oracle."""
+    rng = random.Random(2024)
+    letters = "abcdefgh"
+    n_forms = 0
+    for it in range(6):
+        keys = set()
+        while len(keys) < 160:
+            k = "".join(rng.choice(letters) for _ in range(rng.randint(2, 8)))
+            keys.add(k)
+        keys = sorted(keys, key=lambda k: (-len(k), k)) if it % 2 else list(keys)
+        if it % 2 == 0:
+            rng.shuffle(keys)
+        max_val = [8, 8, 12, 5, 8, 3][it]
+        vals = ["".join(rng.choice("XYZxyz01") for _ in range(rng.randint(0, max_val))) for _ in keys]
+        pat = "|".join("%s:%s" % kv for kv in zip(keys, vals))
+        toks = []
+        while sum(map(len, toks)) < 12000:
+            r = rng.random()
+            if r < 0.35:
+                t = rng.choice(keys)
+            elif r < 0.5:
+                t = rng.choice(keys)[:rng.randint(1, 8)] + rng.choice(letters)
+            elif r < 0.6:
+                t = rng.choice(keys) + rng.choice(keys)
+            else:
+                t = "".join(rng.choice(letters + "xyz") for _ in range(rng.randint(1, 9)))
+            toks.append(t + (rng.choice([" ", " ", "\n", ",", "\x00", ""])))
+        data = "".join(toks).encode() + b"\n"
+        for eng in ("dft", "nft"):
+            try:
+                p = trre_amd.Program(pat, eng)
+            except trre_amd.TrreError:
+                continue
+            if not shim_lib.has_fallback_form(p):
+                continue
+            n_forms += 1
+            want = Oracle(pat, eng).scan(data)
+            for fam in (shim_lib.STREAM_FB, shim_lib.STREAM_FB_COUNT, 9):
+                for geo in (0, 1):
+                    got = shim_lib.scan_like_runtime(p, data, geo=geo, family=fam)
+                    assert got == want, (it, eng, fam, geo)
+    assert n_forms >= 6
 
 
 def test_random_replacement_lists():

@@ -46,16 +46,19 @@ struct StreamBlobHeader {
     uint32_t off_p32, p32_bytes;              // pair form (0 bytes when not available)
     uint32_t p32_slow;                        // some pair entry is "slow"
     uint32_t pad;
-    // fallback form of a large table (front.hpp, StreamTables::fb_*): 0 states when not available
-    uint32_t fb_states, off_fb_rec;           // u64[fb_states]
-    uint32_t fb_tab_entries, off_fb_tab;      // u32[fb_tab_entries]
+    // fallback form of a large table (front.hpp, StreamTables::fb_*): 0 slots when not available
+    uint32_t fb_slots, off_fb_comb;           // u64[fb_slots]
     uint32_t fb_lits, off_fb_lit;             // u64[fb_lits]
+    uint32_t fb_escs, off_fb_esc_slot;        // u32[fb_escs] ascending
     uint32_t off_fb_esc, off_fb_pool;         // escape records (4 words each) and their texts
+    uint32_t fb_start[3][2];                  // root, SKIP, DONE: {descriptor, next-state bits of an entry's hi}
+    uint32_t pad2[2];
 };
-static_assert(sizeof(StreamBlobHeader) == 112, "header layout");
+static_assert(sizeof(StreamBlobHeader) == 144, "header layout");
 
 // entry bits of the fallback form (front.hpp)
-constexpr uint32_t kFbCc = 1u << 16, kFbNl = 1u << 17, kFbEol = 1u << 18, kFbEsc = 1u << 23;
+constexpr uint32_t kFbCc = 1u << 17, kFbNl = 1u << 18, kFbEol = 1u << 19;      // (kFbCc and kFbNl both: an escape)
+constexpr uint32_t kFbNoTag = 0x3fffu;
 
 // backward pass of the guided families (guided_build.cpp): a DFA read right to left
 constexpr uint32_t kMagicRev = 0x31525254u;   // "TRR1"

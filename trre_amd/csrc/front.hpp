@@ -199,34 +199,33 @@ struct StreamTables {
     // program are ~0.9 MB: a gather through L1/L2 on every byte, and the passes run at the pace of the L1's tag lookups).
     // The folded scan loop has the Aho-Corasick shape: a failed attempt flushes its first bytes RAW and what is left is a
     // shorter pending string, so the row of a state s is, on most classes, "the first bytes of the pending string, then
-    // the row of the state f of a suffix of it".  Every state has one 64-bit record
-    //   lo  [30:0] mask: bit k set = class k is an exception of this state           [31] owed-text state (below)
-    //   hi  [13:0] x: index of the state's first exception entry   [25:14] row: index of the row of f (the root row is row 0)
-    //       [28:26] plen: bytes of the pending string in front of f's    [31:29] length of the pending string
-    //       with [31] of lo set: [25:14] = index of a literal text in fb_lit, [28:26] = its length - 1, and f is the root
-    // and the transition on class k is entry fb_tab[x + popcount(mask below k)] when k is an exception, otherwise entry
-    // fb_tab[row + k] with plen more bytes flushed.  A dense state (root, SKIP, DONE, the one-byte pending strings) is
-    // the same thing with every class an exception.  Entries are 32 bits:
-    //   [12:0] next state   [15:13] n: leading bytes of the (state's own / f's) pending string to emit   [16] then the
-    //   input byte   [17] then '\n'   [18] record end   [22:19] n + [16] + [17]
-    //   [23] escape: the output is spelled out in escape record ([31:24] << 4 | [22:19]) — a cell that is none of the above
-    //   (raw bytes, then a replacement, then more; a replacement of more than 8 bytes); stays in global memory
-    // No literal bytes anywhere: what a transition emits is a prefix of the pending string, i.e. of the input the lane
-    // has just read (the kernels keep the last 8 input bytes in a register pair) — except replacement texts.  Those are
-    // OWED: a completed key emits nothing and enters a copy of the root state whose record says "emit this text
-    // (1..8 bytes) in front of whatever the root row emits"; a key that is complete but waits for a longer one to fail
-    // is the same with the ways on as exceptions.  Tables with a cell that does not
-    // fit (a literal that is not a whole replacement of 1..8 bytes followed by the root state, more than 7 bytes
-    // pending, more than 31 classes, overflow / diverge marks) have no fallback form.  The relation between rows is
-    // verified cell by cell by the builder, never assumed.
+    // the row of the state f of a suffix of it" — only the ways deeper into a key are the state's own ("exceptions").
+    // The exceptions of all states are interleaved in one array of 8-byte entries (row displacement, the "comb" of
+    // compiler parse tables): state s owns the slots base(s) + k of its exceptional classes k, f(s) is a DENSE state
+    // (root, SKIP, DONE, the one-byte pending strings: every class is its own), and a state travels as a descriptor
+    //   [13:0] base   [27:14] base of f   [30:28] plen: bytes of the pending string in front of f's   [31] owed
+    // so that one step reads fb_comb[base + k] and fb_comb[fbase + k] AT ONCE and takes the first if its tag says
+    // "mine" — one LDS round trip per input byte, no loop, no divergence.  Entries:
+    //   lo       the next state's descriptor
+    //   hi [13:0] tag = base of the owning state    [16:14] n: leading bytes of the owner's pending string to emit
+    //      [17] then the input byte   [18] then '\n'  ([17] and [18] both: escape, below)   [19] record end
+    //      [31:20] about the next state: the length of its pending string, or (owed) the index of its text in fb_lit
+    // No literal bytes in the entries: what a transition emits is a prefix of the pending string, i.e. of the input the
+    // lane has just read (the kernels keep the last 7 input bytes in a register pair) — except replacement texts.  Those
+    // are OWED: a completed key emits nothing and enters a copy of the root state (no slots of its own, f = root) whose
+    // descriptor says "emit the text (plen + 1 = 1..8 bytes) in front of whatever the root row emits"; a key that is
+    // complete but waits for a longer one to fail is the same with the ways on as exceptions.  The odd cell that is none
+    // of this (raw bytes, then a replacement, then more; a replacement of more than 8 bytes) is an ESCAPE: its output is
+    // spelled out in a record in global memory, found by the slot's index (fb_esc_slot, sorted).  Tables with more
+    // than 7 bytes pending, more than 31 classes or overflow / diverge marks have no fallback form.  The relation
+    // between the rows is verified cell by cell by the builder, never assumed.
     bool fb_ok = false;
-    uint32_t fb_states = 0;                 // regular states (ids as in `ent`, before the owed copies of that form) + owed-text states
-    uint32_t fb_first_owed = 0;
-    uint32_t fb_dense = 0;                  // dense states (statistics)
-    std::vector<uint64_t> fb_rec;           // [fb_states]
-    std::vector<uint32_t> fb_tab;           // dense rows, then the exception entries
+    uint32_t fb_states = 0, fb_dense = 0;   // statistics: states (regular + owed-text), dense states
+    uint32_t fb_start[3][2] = {};           // {descriptor, next-state bits [31:20] of an entry's hi} of root, SKIP, DONE
+    std::vector<uint64_t> fb_comb;          // the slots; unused ones carry tag 0x3fff
     std::vector<uint64_t> fb_lit;           // literal texts, little-endian
-    std::vector<uint32_t> fb_esc;           // escape records, 4 words each: {offset in fb_pool, length, 1 = then the input byte, 0}
+    std::vector<uint32_t> fb_esc_slot;      // slots whose entry is an escape, ascending
+    std::vector<uint32_t> fb_esc;           // their records, 4 words each: {offset in fb_pool, length, 1 = then the input byte, 0}
     std::vector<uint8_t> fb_pool;           // texts of the escape records
 };
 StreamTables build_stream_dft(const Dft& dft, const StreamLimits& lim = StreamLimits());

@@ -200,20 +200,21 @@ void serialize_stream(const trre::StreamTables& t, std::vector<uint8_t>& b) {
     h.off_p32 = (uint32_t)off; h.p32_bytes = (uint32_t)(t.p32.size() * 4); h.p32_slow = t.p32_slow ? 1u : 0u; off += t.p32.size() * 4;
     off = align_up(off, 16);
     if (t.fb_ok) {
-        h.fb_states = t.fb_states; h.off_fb_rec = (uint32_t)off; off = align_up(off + t.fb_rec.size() * 8, 16);
-        h.fb_tab_entries = (uint32_t)t.fb_tab.size(); h.off_fb_tab = (uint32_t)off; off = align_up(off + t.fb_tab.size() * 4, 16);
+        h.fb_slots = (uint32_t)t.fb_comb.size(); h.off_fb_comb = (uint32_t)off; off = align_up(off + t.fb_comb.size() * 8, 16);
         h.fb_lits = (uint32_t)t.fb_lit.size(); h.off_fb_lit = (uint32_t)off; off = align_up(off + t.fb_lit.size() * 8, 16);
+        h.fb_escs = (uint32_t)t.fb_esc_slot.size(); h.off_fb_esc_slot = (uint32_t)off; off = align_up(off + t.fb_esc_slot.size() * 4, 16);
         h.off_fb_esc = (uint32_t)off; off = align_up(off + t.fb_esc.size() * 4, 16);
         h.off_fb_pool = (uint32_t)off; off += t.fb_pool.size();
+        std::memcpy(h.fb_start, t.fb_start, sizeof h.fb_start);
     }
     off = align_up(off + 16, 16);
     h.total_bytes = (uint32_t)off;
     b.assign(off, 0);
     put(b, 0, &h, 1);
     if (t.fb_ok) {
-        put(b, h.off_fb_rec, t.fb_rec.data(), t.fb_rec.size());
-        put(b, h.off_fb_tab, t.fb_tab.data(), t.fb_tab.size());
+        put(b, h.off_fb_comb, t.fb_comb.data(), t.fb_comb.size());
         put(b, h.off_fb_lit, t.fb_lit.data(), t.fb_lit.size());
+        put(b, h.off_fb_esc_slot, t.fb_esc_slot.data(), t.fb_esc_slot.size());
         put(b, h.off_fb_esc, t.fb_esc.data(), t.fb_esc.size());
         put(b, h.off_fb_pool, t.fb_pool.data(), t.fb_pool.size());
     }
@@ -465,12 +466,16 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
             args.lp_emit = 1;
             launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, sym_mode, g16_slow);
         }
-    } else if (direct && !is_guided(family) && stt.fb_ok && getenv("TRRE_FB") && fb_fits(p->sblob.data())) {
-        // a large table (a dictionary) in its fallback form: every per-byte lookup in LDS (TRRE_NO_FB=1: the 8-byte rows
-        // through L1/L2, for A/B runs)
+    } else if (direct && !is_guided(family) && stt.fb_ok && !getenv("TRRE_NO_FB") && fb_fits(p->sblob.data())) {
+        // a large table (a dictionary) in its fallback form: the count pass with every per-byte lookup in LDS (0.86 ms per
+        // GiB against 1.62 on the 8-byte rows through L1/L2).  The emit pass over the same form (TRRE_FB_EMIT=1) is
+        // correct but slower than the one over the 8-byte rows (3.8 against 2.9 ms): its tables leave LDS for only 512
+        // staging rings per CU.  TRRE_NO_FB=1: both passes on the 8-byte rows, for A/B runs.
+        static const bool fb_emit = getenv("TRRE_FB_EMIT") != nullptr;
         launch_fb_kernel(1, args, p->sblob.data(), lane_bytes, n_chunks, stream);
         launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);
-        launch_fb_kernel(2, args, p->sblob.data(), lane_bytes, n_chunks, stream);
+        if (fb_emit) launch_fb_kernel(2, args, p->sblob.data(), lane_bytes, n_chunks, stream);
+        else launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, 0, sym_mode, g16_slow);
         pd.total_at = cx->d_chunk_base + n_chunks;
     } else if (direct) {
         static const bool no_g16 = getenv("TRRE_NO_G16") != nullptr;          // A/B: the 8-byte entries

@@ -770,6 +770,8 @@ struct __attribute__((packed)) UnalignedU64 { uint64_t v; };
 TRRE_HD void bstage_put8(BStage& s, uint64_t v, uint32_t n) {
     const uint32_t o = s.wp & (kRingBytes - 1u);
     if (!(s.dbg & 2u)) {
+        // (an LDS store off its natural alignment is replayed at 64 cycles per wave instruction — two 4-byte stores
+        // instead of one 8-byte store were measured slower still: 5.4 ms against 3.8 ms for the pass)
         reinterpret_cast<UnalignedU64*>(s.buf + o)->v = v;
         if (TRRE_WAVE_ANY(o > kRingBytes - 8u)) {
             if (o > kRingBytes - 8u) reinterpret_cast<UnalignedU64*>(s.buf + o - kRingBytes)->v = v;     // the part beyond the end, at the start
@@ -850,8 +852,16 @@ TRRE_HD void stage_flush_solo(St& s) {
     s.skip = end & (kUnitBytes - 1u);
 }
 // kAll = false: the complete units (all lanes of the wave must take part); true: what is left as well (end of the lane)
+// (kAll = false is called after every few input bytes, but stores only once some lane's ring could not take another such
+// interval: kFlushAt bytes held, at most 36..40 more arrive between two calls.  By then about a third of the wave's lanes
+// have a unit ready and one store instruction moves sixteen of them; flushing whenever any lane had one — the first
+// version — ran this path five times as often for three or four units each.)
+constexpr uint32_t kFlushAt = 84;
 template <bool kAll, class St>
 TRRE_HD void stage_flush(St& s) {
+    if (!kAll) {
+        if (!TRRE_WAVE_ANY(s.wp - s.fp >= kFlushAt)) return;
+    }
 #if defined(__HIP_DEVICE_COMPILE__)
     if (s.wsc) {
         // a lane's first unit may share its 64 bytes with the lane before it: that one it stores itself
@@ -1495,27 +1505,33 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
 // Large tables in their fallback form (front.hpp, StreamTables::fb_*): the count and emit passes of a
 // dictionary-like program with every per-byte lookup in LDS.  The 8-byte rows of such a program (~0.9 MB for 1000
 // keys) are a gather through L1/L2 on every byte: the passes ran at the pace of the L1's tag lookups (one address per
-// clock and CU; count 1.65 ms and emit 2.9 ms per GiB, whatever the occupancy).  Here a state is one 8-byte record —
-// a 31-bit mask of its exceptional classes, where its exception entries start, and which dense row (and how many
-// more flushed bytes) stand for every other class — and an entry is 4 bytes: per byte one class lookup, one record,
-// one entry, no loop and no divergence.  What a transition emits is a prefix of the lane's last 7 input bytes (kept in
-// a register pair), or an owed replacement text (8 bytes from a small LDS table), then maybe the input byte or '\n'.
-// The odd cell that is none of that leaves the fast path through an escape record in global memory.
+// clock and CU; count 1.65 ms and emit 2.9 ms per GiB, whatever the occupancy).  Here a state travels as a descriptor
+// {base of its own slots, base of its fallback row} and a step reads both candidate entries at once and keeps the own
+// one if its tag matches: ONE LDS round trip per input byte.  (A first version — a record per state with a mask of its
+// exceptional classes, then the entry — was two dependent reads and ~700 clocks per step: 1.16 ms count, 4.5 ms emit.)
+// What a transition emits is a prefix of the lane's last 7 input bytes (kept in a register pair) or an owed
+// replacement text (8 bytes from a small LDS table), then maybe the input byte or '\n'; it goes into the lane's ring by
+// one unaligned 8-byte store (BStage).  The odd cell that is none of that leaves the fast path through an escape record
+// in global memory.
 // =============================================================================================
 struct FbView {
     const uint8_t* cls;        // [256] (LDS)
-    const uint64_t* rec;       // [fb_states] (LDS)
-    const uint32_t* tab;       // entries (LDS)
-    const uint64_t* lit;       // literal texts (LDS)
-    const uint32_t* esc;       // escape records, 4 words each (global)
+    const uint64_t* comb;      // the slots (LDS)
+    const uint64_t* lit;       // literal texts (LDS; emit pass)
+    const uint32_t* esc_slot;  // slots of the escape entries, ascending (global)
+    const uint32_t* esc;       // their records, 4 words each (global)
     const uint8_t* pool;       // their texts (global)
+    uint32_t n_esc;
+    uint32_t start[3][2];      // root, SKIP, DONE: {descriptor, about bits}
 };
-TRRE_HD uint32_t fb_popc(uint32_t x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (uint32_t)__popc(x);
-#else
-    return (uint32_t)__builtin_popcount(x);
-#endif
+// the record of the escape entry in slot `slot`
+TRRE_HD const uint32_t* fb_esc_record(const FbView& T, uint32_t slot) {
+    uint32_t lo = 0, hi = T.n_esc;
+    while (lo + 1u < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (T.esc_slot[mid] <= slot) lo = mid; else hi = mid;
+    }
+    return T.esc + 4u * lo;
 }
 template <int kMode>
 TRRE_HD void fb_lane(const ScanArgs& a, const FbView& T, int64_t lane, int64_t lane_bytes, uint8_t* ring, uint64_t out_base, DirectLane& L,
@@ -1525,10 +1541,12 @@ TRRE_HD void fb_lane(const ScanArgs& a, const FbView& T, int64_t lane, int64_t l
     int64_t hi = lo + lane_bytes;
     if (hi > a.vend) hi = a.vend;
     const uint32_t rhi = (uint32_t)(hi > lo ? hi - lo : 0);
-    uint32_t st;                                                      // state id
-    if (lo >= hi) st = kDoneState;
-    else if (lo < a.vbeg) st = kSkipState;                            // filler then '\n' right before the input
-    else st = (lo == a.vbeg || a.in_v0[lo - 1] == (uint8_t)'\n') ? 0u : kSkipState;
+    const uint32_t done_st = T.start[2][0], done_ab = T.start[2][1];
+    int first;                                                         // 0 root, 1 SKIP, 2 DONE
+    if (lo >= hi) first = 2;
+    else if (lo < a.vbeg) first = 1;                                   // filler then '\n' right before the input
+    else first = (lo == a.vbeg || a.in_v0[lo - 1] == (uint8_t)'\n') ? 0 : 1;
+    uint32_t st = T.start[first][0], ab = T.start[first][1];          // the state's descriptor, and the entry bits that came with it
     BStage S{};
     S.dbg = a.dbg;
     S.wsc = wave_scratch;
@@ -1537,12 +1555,12 @@ TRRE_HD void fb_lane(const ScanArgs& a, const FbView& T, int64_t lane, int64_t l
     uint64_t hist = 0;                                                // the last 7 input bytes: byte 6 = the one before the current
     const int64_t vlast = (a.vend - 1) & ~(int64_t)15;               // the last readable aligned block
     // an escape entry: the output spelled out in global memory (rare)
-    auto esc_count = [&](uint32_t e) -> uint32_t {
-        const uint32_t* r = T.esc + 4u * (((e >> 24) << 4) | ((e >> 19) & 15u));
+    auto esc_count = [&](uint32_t slot) -> uint32_t {
+        const uint32_t* r = fb_esc_record(T, slot);
         return r[1] + r[2];
     };
-    auto esc_emit = [&](uint32_t e, uint32_t c) {
-        const uint32_t* r = T.esc + 4u * (((e >> 24) << 4) | ((e >> 19) & 15u));
+    auto esc_emit = [&](uint32_t slot, uint32_t c) {
+        const uint32_t* r = fb_esc_record(T, slot);
         const uint8_t* text = T.pool + r[0];
         const uint32_t len = r[1];
         stage_flush_solo(S);
@@ -1558,31 +1576,34 @@ TRRE_HD void fb_lane(const ScanArgs& a, const FbView& T, int64_t lane, int64_t l
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t k = kk[j], c = (w >> (8 * j)) & 0xffu;
-            const uint64_t r = T.rec[st];
-            const uint32_t mask = (uint32_t)r, rh = (uint32_t)(r >> 32);
-            const bool exc = (mask >> k) & 1u;
-            const uint32_t owed = mask >> 31;
-            const uint32_t field = (rh >> 14) & 0xfffu;               // the fallback row, or (owed) the literal's index
-            const uint32_t idx = exc ? (rh & 0x3fffu) + fb_popc(mask & ((1u << k) - 1u)) : (owed ? 0u : field) + k;
-            const uint32_t e = T.tab[idx];
-            const uint32_t n_rec = exc ? 0u : ((rh >> 26) & 7u) + owed;
+            const uint32_t base = st & 0x3fffu, fbase = (st >> 14) & 0x3fffu;
+            const uint64_t e1 = T.comb[base + k], e2 = T.comb[fbase + k];      // the state's own slot and its fallback row's: one round trip
+            const bool mine = ((uint32_t)(e1 >> 32) & 0x3fffu) == base;
+            const uint64_t e = mine ? e1 : e2;
+            const uint32_t eh = (uint32_t)(e >> 32);
+            const uint32_t owed = st >> 31;
+            const uint32_t n_rec = mine ? 0u : ((st >> 28) & 7u) + owed;
+            const bool esc = (eh & (kFbCc | kFbNl)) == (kFbCc | kFbNl);
             if (kMode == 1) {
-                uint32_t add = n_rec + ((e >> 19) & 15u);
-                if (TRRE_WAVE_ANY(e & kFbEsc)) {
-                    if (e & kFbEsc) add = n_rec + esc_count(e);
+                uint32_t add = n_rec + ((eh >> 14) & 7u) + ((eh >> 17) & 1u) + ((eh >> 18) & 1u);
+                if (TRRE_WAVE_ANY(esc)) {
+                    if (esc) add = n_rec + esc_count(mine ? base + k : fbase + k);
                 }
                 cnt += add;
             } else {
-                const uint32_t n_tot = n_rec + ((e >> 13) & 7u);      // 0..8 bytes of prefix
-                const uint64_t text = T.lit[owed ? field : 0u];
-                bstage_put8(S, owed ? text : hist >> (8u * (7u - (rh >> 29))), n_tot);
-                bstage_put1(S, (e & kFbCc) ? c : (uint32_t)'\n', ((e >> 16) | (e >> 17)) & 1u);
-                if (TRRE_WAVE_ANY(e & kFbEsc)) {
-                    if (e & kFbEsc) esc_emit(e, c);
+                const uint32_t about = ab >> 20;                      // of the current state: pending length, or the owed text's index
+                const uint32_t n_tot = n_rec + ((eh >> 14) & 7u);     // 0..8 bytes of prefix (an escape entry has none of its own)
+                const uint64_t text = T.lit[owed ? about : 0u];
+                bstage_put8(S, owed ? text : hist >> (8u * (7u - (about & 7u))), n_tot);
+                bstage_put1(S, (eh & kFbCc) ? c : (uint32_t)'\n', esc ? 0u : ((eh >> 17) | (eh >> 18)) & 1u);
+                if (TRRE_WAVE_ANY(esc)) {
+                    if (esc) esc_emit(mine ? base + k : fbase + k, c);
                 }
             }
             hist = (hist >> 8) | (uint64_t)c << 48;
-            st = (kEnd && (e & kFbEol) && rp + (uint32_t)j + 1u >= rhi) ? kDoneState : (e & 0x1fffu);
+            const bool fin = kEnd && (eh & kFbEol) && rp + (uint32_t)j + 1u >= rhi;
+            st = fin ? done_st : (uint32_t)e;
+            ab = fin ? done_ab : eh;
         }
     };
     auto block = [&](auto end_tag, const U128& b, const uint32_t rp) {
@@ -1598,7 +1619,7 @@ TRRE_HD void fb_lane(const ScanArgs& a, const FbView& T, int64_t lane, int64_t l
     };
     U128 c0 = direct_load(a, lo), c1 = direct_load(a, lo + 16), c2 = direct_load(a, lo + 32), c3 = direct_load(a, lo + 48);
     for (int64_t v = lo;; v += 64) {
-        if (!TRRE_WAVE_ANY(st != kDoneState)) break;
+        if (!TRRE_WAVE_ANY(st != done_st)) break;
         const int64_t vn = v + 64;
         const int64_t x0 = vn < vlast ? vn : vlast, x1 = vn + 16 < vlast ? vn + 16 : vlast,
                       x2 = vn + 32 < vlast ? vn + 32 : vlast, x3 = vn + 48 < vlast ? vn + 48 : vlast;

@@ -488,37 +488,36 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_g16(ScanArgs a, int64
     if (st && (threadIdx.x & (kWave - 1)) == 0) atomicOr(a.status, st);
 }
 
-// Count / emit passes over the fallback form of a large table (front.hpp, scan_block.hpp: fb_lane): records, entries and
-// literal texts in LDS (~75 KB for a 1000-key dictionary), so one workgroup per CU; the count pass runs 1024 lanes, the emit
-// pass 512 (its staging rings take the rest of the 160 KB).  Lanes are numbered as everywhere (256 per chunk of the
-// workspace), a workgroup covers kThreads / 256 chunks.
-//   smem: cls[256] | rec | tab | lit | emit: rings[kThreads] | 64 x (kThreads / 256) | posting tables
+// Count / emit passes over the fallback form of a large table (front.hpp, scan_block.hpp: fb_lane): the comb of entries
+// (and, for the emit pass, the literal texts) in LDS — ~75 KB for a 1000-key dictionary; the emit pass's staging rings take
+// the rest of the 160 KB.  Lanes are numbered as everywhere (256 per chunk of the workspace), a workgroup covers
+// kThreads / 256 chunks.
+//   smem: cls[256] | comb | emit: lit | rings[kThreads] | 64 x (kThreads / 256) | posting tables
 template <int kMode, int kThreads>
-__global__ __launch_bounds__(kThreads) void k_stream_fb(ScanArgs a, int64_t lane_bytes, int64_t n_chunks) {
+__global__ __launch_bounds__(kThreads, (kMode == 1 ? 8 : 2)) void k_stream_fb(ScanArgs a, int64_t lane_bytes, int64_t n_chunks) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
-    const uint32_t rec_bytes = (h.fb_states * 8u + 15u) & ~15u, tab_bytes = (h.fb_tab_entries * 4u + 15u) & ~15u, lit_bytes = (h.fb_lits * 8u + 15u) & ~15u;
+    const uint32_t comb_bytes = (h.fb_slots * 8u + 15u) & ~15u, lit_bytes = kMode == 2 ? (h.fb_lits * 8u + 15u) & ~15u : 0u;
     for (int k = threadIdx.x; k < 256; k += kThreads) smem[k] = a.blob[h.off_cls + k];
     {
-        const U128* e = reinterpret_cast<const U128*>(a.blob + h.off_fb_rec);
+        const U128* e = reinterpret_cast<const U128*>(a.blob + h.off_fb_comb);
         U128* d = reinterpret_cast<U128*>(smem + 256);
-        for (int k = threadIdx.x; k < (int)(rec_bytes / 16); k += kThreads) d[k] = e[k];
-        e = reinterpret_cast<const U128*>(a.blob + h.off_fb_tab);
-        d = reinterpret_cast<U128*>(smem + 256 + rec_bytes);
-        for (int k = threadIdx.x; k < (int)(tab_bytes / 16); k += kThreads) d[k] = e[k];
+        for (int k = threadIdx.x; k < (int)(comb_bytes / 16); k += kThreads) d[k] = e[k];
         e = reinterpret_cast<const U128*>(a.blob + h.off_fb_lit);
-        d = reinterpret_cast<U128*>(smem + 256 + rec_bytes + tab_bytes);
+        d = reinterpret_cast<U128*>(smem + 256 + comb_bytes);
         for (int k = threadIdx.x; k < (int)(lit_bytes / 16); k += kThreads) d[k] = e[k];
     }
     __syncthreads();
     FbView T;
     T.cls = smem;
-    T.rec = reinterpret_cast<const uint64_t*>(smem + 256);
-    T.tab = reinterpret_cast<const uint32_t*>(smem + 256 + rec_bytes);
-    T.lit = reinterpret_cast<const uint64_t*>(smem + 256 + rec_bytes + tab_bytes);
+    T.comb = reinterpret_cast<const uint64_t*>(smem + 256);
+    T.lit = reinterpret_cast<const uint64_t*>(smem + 256 + comb_bytes);
+    T.esc_slot = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_esc_slot);
     T.esc = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_esc);
     T.pool = a.blob + h.off_fb_pool;
-    uint8_t* top = smem + 256 + rec_bytes + tab_bytes + lit_bytes;
+    T.n_esc = h.fb_escs;
+    for (int i = 0; i < 3; ++i) { T.start[i][0] = h.fb_start[i][0]; T.start[i][1] = h.fb_start[i][1]; }
+    uint8_t* top = smem + 256 + comb_bytes + lit_bytes;
     constexpr int kGroups = kThreads / kDirectThreads;                 // chunks of the workspace per workgroup
     uint8_t* ring = top + threadIdx.x * kBRingStride + kBRingPad;      // (byte-granular staging: 8 spare bytes on either side)
     uint8_t* tail = kMode == 1 ? top : top + kThreads * kBRingStride;  // 64 bytes per group
@@ -898,9 +897,9 @@ void launch_stream_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t
 
 constexpr int kFbCountThreads = 1024, kFbEmitThreads = 512;
 int fb_lds_bytes(const StreamBlobHeader& h, int which) {
-    const int tables = 256 + (int)((h.fb_states * 8u + 15u) & ~15u) + (int)((h.fb_tab_entries * 4u + 15u) & ~15u) + (int)((h.fb_lits * 8u + 15u) & ~15u);
+    const int tables = 256 + (int)((h.fb_slots * 8u + 15u) & ~15u);
     if (which == 1) return tables + 64 * (kFbCountThreads / kDirectThreads);
-    return tables + kFbEmitThreads * kBRingStride + 64 * (kFbEmitThreads / kDirectThreads) + (kFbEmitThreads / kWave) * kWaveScratchBytes;
+    return tables + (int)((h.fb_lits * 8u + 15u) & ~15u) + kFbEmitThreads * kBRingStride + 64 * (kFbEmitThreads / kDirectThreads) + (kFbEmitThreads / kWave) * kWaveScratchBytes;
 }
 // which: 1 count, 2 emit; `hdr`: the host's copy of the blob header (table sizes)
 void launch_fb_kernel(int which, const ScanArgs& a, const void* hdr, int64_t lane_bytes, int64_t n_chunks, void* stream) {

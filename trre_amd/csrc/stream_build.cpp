@@ -487,50 +487,82 @@ private:
         const uint32_t n_all = n0 + (uint32_t)owed_text.size();
         for (const std::string& L : owed_text) lit_id(L);
         for (uint32_t s = 0; s < n0; ++s) if (plan[s].literal) lit_id(plan[s].P);
-        const size_t tab_entries = (size_t)n_dense * C + n_exc;
-        const size_t lds = 256 + (size_t)n_all * 8 + tab_entries * 4 + lit_text.size() * 8;
+        if (n_all > 16000 || lit_text.size() > 4095 || esc_text.size() > 4095 || hot_escapes > 16) return;   // escapes are for the odd cell, not for every completed key
+        // row displacement: every state with exceptions gets a base of its own such that its slots base + k are free
+        // (first fit, the states with the most exceptions first); states without exceptions share the tail of the array,
+        // where no slot is ever owned
+        std::vector<std::vector<uint32_t>> exc(n0);
+        for (uint32_t s = 0; s < n0; ++s) {
+            if (plan[s].dense) for (uint32_t k = 0; k < C; ++k) exc[s].push_back(k);
+            else exc[s] = plan[s].exc;
+        }
+        std::vector<uint32_t> order;
+        for (uint32_t s = 0; s < n0; ++s) if (!exc[s].empty()) order.push_back(s);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return exc[x].size() > exc[y].size(); });
+        std::vector<char> used, is_base;
+        std::vector<uint32_t> base(n0, 0);
+        for (uint32_t s : order) {
+            for (size_t b0 = 0;; ++b0) {
+                if (used.size() < b0 + 32) { used.resize(b0 + 32, 0); is_base.resize(b0 + 32, 0); }
+                if (is_base[b0]) continue;
+                bool fits = true;
+                for (uint32_t k : exc[s]) if (used[b0 + k]) { fits = false; break; }
+                if (!fits) continue;
+                base[s] = (uint32_t)b0;
+                is_base[b0] = 1;
+                for (uint32_t k : exc[s]) used[b0 + k] = 1;
+                break;
+            }
+        }
+        size_t top = used.size();
+        while (top > 0 && !used[top - 1]) --top;
+        const uint32_t shared = (uint32_t)top;                                 // base of the states without exceptions
+        const size_t n_slots = top + 32;
+        const size_t lds = 256 + n_slots * 8 + lit_text.size() * 8;
         if (dbg)
-            fprintf(stderr, "fallback form: %u states + %zu owed texts, %u classes, %u dense, %zu exceptions, %zu literals, %zu escapes, %zu bytes of LDS\n", n0,
-                    owed_text.size(), C, n_dense, n_exc, lit_text.size(), esc_text.size(), lds);
-        if (esc_text.size() > 4095 || hot_escapes > 16) return;               // escapes are for the odd cell, not for every completed key
-        if (n_all > 8191 || tab_entries > 16383 || lit_text.size() > 4095 || (size_t)n_dense * C > 4095 || lds > kFallbackLdsBytes) return;
-        auto entry = [](const FbCell& y) -> uint32_t {
-            if (y.esc >= 0) return y.next | (y.eol ? kFbEol : 0u) | kFbEsc | ((uint32_t)y.esc & 15u) << 19 | ((uint32_t)y.esc >> 4) << 24;
-            return y.next | y.n << 13 | (y.cc ? kFbCc : 0u) | (y.nl ? kFbNl : 0u) | (y.eol ? kFbEol : 0u) | (y.n + (y.cc ? 1u : 0u) + (y.nl ? 1u : 0u)) << 19;
+            fprintf(stderr, "fallback form: %u states + %zu owed texts, %u classes, %u dense, %zu exceptions in %zu slots, %zu literals, %zu escapes, %zu bytes of LDS\n",
+                    n0, owed_text.size(), C, n_dense, n_exc, n_slots, lit_text.size(), esc_text.size(), lds);
+        if (n_slots > 16383 || lds > kFallbackLdsBytes) return;
+        for (uint32_t s = 0; s < n0; ++s) if (exc[s].empty()) base[s] = shared;
+        // descriptors and the bits an entry carries about its target state
+        auto desc_of = [&](uint32_t s) -> uint32_t {
+            if (s >= n0) return shared | base[0] << 14 | (uint32_t)(owed_text[s - n0].size() - 1) << 28 | 1u << 31;
+            if (plan[s].dense) return base[s] | base[s] << 14;
+            if (plan[s].literal) return base[s] | base[0] << 14 | (uint32_t)(plan[s].P.size() - 1) << 28 | 1u << 31;
+            return base[s] | base[plan[s].f] << 14 | (uint32_t)plan[s].P.size() << 28;
         };
-        t.fb_rec.assign(n_all, 0);
-        t.fb_tab.assign(tab_entries, 0);
+        auto about_of = [&](uint32_t s) -> uint32_t {
+            if (s >= n0) return lit_id(owed_text[s - n0]);
+            if (!plan[s].dense && plan[s].literal) return lit_id(plan[s].P);
+            return (uint32_t)pending(s).size();
+        };
+        t.fb_comb.assign(n_slots, (uint64_t)kFbNoTag << 32);
         t.fb_lit.assign(lit_text.size(), 0);
         for (size_t i = 0; i < lit_text.size(); ++i)
-            for (size_t b = 0; b < lit_text[i].size(); ++b) t.fb_lit[i] |= (uint64_t)(uint8_t)lit_text[i][b] << (8 * b);
-        size_t at = (size_t)n_dense * C;
+            for (size_t b2 = 0; b2 < lit_text[i].size(); ++b2) t.fb_lit[i] |= (uint64_t)(uint8_t)lit_text[i][b2] << (8 * b2);
+        std::vector<std::pair<uint32_t, int>> esc_at;                          // (slot, escape record)
         for (uint32_t s = 0; s < n0; ++s) {
-            const uint64_t wlen = pending(s).size();
-            if (plan[s].dense) {
-                for (uint32_t k = 0; k < C; ++k) t.fb_tab[row_at[s] + k] = entry(fr[s][k]);
-                t.fb_rec[s] = (uint64_t)((1u << C) - 1u) | ((uint64_t)row_at[s] | wlen << 29) << 32;
-                continue;
+            for (uint32_t k : exc[s]) {
+                const FbCell& y = fr[s][k];
+                uint32_t hi = base[s] | about_of(y.next) << 20 | (y.eol ? kFbEol : 0u);
+                if (y.esc >= 0) { hi |= kFbCc | kFbNl; esc_at.emplace_back(base[s] + k, y.esc); }
+                else hi |= y.n << 14 | (y.cc ? kFbCc : 0u) | (y.nl ? kFbNl : 0u);
+                t.fb_comb[base[s] + k] = (uint64_t)desc_of(y.next) | (uint64_t)hi << 32;
             }
-            uint32_t mask = 0;
-            const size_t x = plan[s].exc.empty() ? 0 : at;
-            for (uint32_t k : plan[s].exc) { mask |= 1u << k; t.fb_tab[at++] = entry(fr[s][k]); }
-            if (plan[s].literal)
-                t.fb_rec[s] = (uint64_t)(mask | 1u << 31) | ((uint64_t)x | (uint64_t)lit_id(plan[s].P) << 14 | (uint64_t)(plan[s].P.size() - 1) << 26 | wlen << 29) << 32;
-            else
-                t.fb_rec[s] = (uint64_t)mask | ((uint64_t)x | (uint64_t)row_at[plan[s].f] << 14 | (uint64_t)plan[s].P.size() << 26 | wlen << 29) << 32;
         }
-        for (size_t i = 0; i < owed_text.size(); ++i)
-            t.fb_rec[n0 + i] = (uint64_t)(1u << 31) | ((uint64_t)lit_id(owed_text[i]) << 14 | (uint64_t)(owed_text[i].size() - 1) << 26) << 32;
-        // escape records: {offset of the text in fb_pool, its length, 1 = then the input byte, 0}
-        for (size_t i = 0; i < esc_text.size(); ++i) {
+        // escape records in slot order: {offset of the text in fb_pool, its length, 1 = then the input byte, 0}
+        std::sort(esc_at.begin(), esc_at.end());
+        for (auto& se : esc_at) {
+            t.fb_esc_slot.push_back(se.first);
             t.fb_esc.push_back((uint32_t)t.fb_pool.size());
-            t.fb_esc.push_back((uint32_t)esc_text[i].size());
-            t.fb_esc.push_back(esc_cc[i] ? 1u : 0u);
+            t.fb_esc.push_back((uint32_t)esc_text[se.second].size());
+            t.fb_esc.push_back(esc_cc[se.second] ? 1u : 0u);
             t.fb_esc.push_back(0u);
-            t.fb_pool.insert(t.fb_pool.end(), esc_text[i].begin(), esc_text[i].end());
+            t.fb_pool.insert(t.fb_pool.end(), esc_text[se.second].begin(), esc_text[se.second].end());
         }
+        const uint32_t starts[3] = {0u, skip_, done_};
+        for (int i = 0; i < 3; ++i) { t.fb_start[i][0] = desc_of(starts[i]); t.fb_start[i][1] = about_of(starts[i]) << 20; }
         t.fb_states = n_all;
-        t.fb_first_owed = n0;
         t.fb_dense = n_dense;
         t.fb_ok = true;
     }
