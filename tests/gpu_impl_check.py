@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run by tests/test_gpu_parity.py in a subprocess with TRRE_STREAM_IMPL /
-TRRE_LANE_BYTES / TRRE_NO_G16 set: checks the alternative implementations of the stream kernel families
+TRRE_LANE_BYTES / TRRE_NO_G16 / TRRE_NO_FB / TRRE_FB_EMIT set: checks the alternative implementations of the stream kernel families
 against the oracle (the environment is read once per process by the library)."""
 import os
 import random
@@ -37,6 +37,20 @@ def main():
                 if got != Oracle(pat, eng).scan(buf):
                     print("MISMATCH", pat, eng, fam, len(buf))
                     bad += 1
+    # a table large enough for the fallback form (TRRE_FB_EMIT / TRRE_NO_FB choose who walks it): keys inside keys, NULs
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import dictgen
+    keys, vals = dictgen.make_dictionary(300)
+    keys += [keys[0][1:] + "q", keys[1] + "zz", keys[2][:2]]
+    vals += ["inner", "", "a-long-replacement-text"]
+    pat = dictgen.pattern(keys, vals)
+    text = dictgen.corpus(keys, 150000) + b"nul\0" + keys[3].encode() + b" rest\n" + (keys[0] + keys[1] + keys[300]).encode()
+    for eng in ("dft", "nft"):
+        p = trre_amd.Program(pat, eng)
+        t = torch.frombuffer(bytearray(text), dtype=torch.uint8).cuda()
+        if p.scan_tensor(t).cpu().numpy().tobytes() != Oracle(pat, eng).scan(text):
+            print("MISMATCH dictionary", eng)
+            bad += 1
     print("impl check: %s" % ("ok" if not bad else "%d mismatches" % bad))
     return 1 if bad else 0
 
