@@ -5,7 +5,8 @@ against the oracle.  Run on the GPU box:   python tools/gpu_fuzz.py --seconds 12
 Random patterns (the generator of tests/fuzz_oracle.py over the alphabet abcxy), random inputs over
 the same alphabet with lines of very different lengths (empty lines, lines longer than a lane's
 sub-range, NULs now and then, with and without a final newline), random buffer sizes and random
-misalignment of the input and output tensors."""
+misalignment of the input and output tensors.  --dict P: that share of the patterns are key:value lists of 80..250 keys
+(large stream tables: the comb-packed fallback form)."""
 import argparse
 import os
 import random
@@ -25,7 +26,10 @@ from oracle_lib import Oracle, OracleError  # noqa: E402
 ALPHA = b"abcxy"
 
 
-def gen_input(rng, n):
+DICT_ALPHA = b"abcdefgh"       # (more byte classes: with 8 the tables of a key list stay small enough for the 16-byte form)
+
+
+def gen_input(rng, n, alpha=ALPHA):
     out = bytearray()
     while len(out) < n:
         r = rng.random()
@@ -37,7 +41,7 @@ def gen_input(rng, n):
             ln = rng.randint(1000, 6000)          # longer than a lane's sub-range
         else:
             ln = rng.randint(20000, 70000)        # longer than an LDS tile
-        line = bytes(rng.choice(ALPHA) for _ in range(min(ln, 64)))
+        line = bytes(rng.choice(alpha) for _ in range(min(ln, 64)))
         line = (line * (ln // max(len(line), 1) + 1))[:ln]
         if rng.random() < 0.01 and ln:
             k = rng.randrange(ln)
@@ -62,6 +66,25 @@ def gen_replacement_list(rng):
     return b"(" + pat + b")" if rng.random() < 0.5 else pat
 
 
+def gen_dictionary(rng):
+    """a key:value list large enough for the fallback form of its stream table (StreamTables::fb_*): 80..250 keys of 2..8
+    bytes over DICT_ALPHA, as the input of these cases (keys inside keys, keys that are prefixes of keys), values of 0..12 bytes"""
+    keys = set()
+    n = rng.randint(80, 250)
+    while len(keys) < n:
+        keys.add(bytes(rng.choice(DICT_ALPHA) for _ in range(rng.randint(2, 8))))
+    keys = list(keys)
+    order = rng.random()
+    if order < 0.4:
+        keys.sort(key=lambda k: (-len(k), k))           # the longer key first: NFT priority waits for it
+    elif order < 0.7:
+        keys.sort()
+    else:
+        rng.shuffle(keys)
+    top = rng.choice([3, 8, 8, 12])
+    return b"|".join(k + b":" + bytes(rng.choice(b"xyzXYZ01") for _ in range(rng.randint(0, top))) for k in keys)
+
+
 def _alarm(signum, frame):
     raise TimeoutError()
 
@@ -72,6 +95,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=60)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--verbose", action="store_true", help="print every case before it runs (to find a crashing one)")
+    ap.add_argument("--dict", type=float, default=0.03, help="share of patterns that are large key:value lists (fallback form)")
     a = ap.parse_args()
     rng = random.Random(a.seed)
     t_end = time.time() + a.seconds
@@ -80,7 +104,9 @@ def main():
     while time.time() < t_end:
         if n_pat % 100 == 99:
             print("... %d patterns, %d scans, %d mismatches" % (n_pat, n_run, bad), flush=True)
-        pat = (gen_replacement_list(rng) if rng.random() < 0.3 else gen_expr(rng)).decode("latin-1")
+        r = rng.random()
+        alpha = DICT_ALPHA if r < a.dict else ALPHA
+        pat = (gen_dictionary(rng) if r < a.dict else gen_replacement_list(rng) if r < a.dict + 0.3 else gen_expr(rng)).decode("latin-1")
         eng = rng.choice(["dft", "nft"])
         try:
             o = Oracle(pat, eng)
@@ -91,7 +117,7 @@ def main():
         n_pat += 1
         for _ in range(2):
             n = rng.choice([1, 7, 100, 5000, 70000, 300000, 1500000])
-            data = gen_input(rng, n)
+            data = gen_input(rng, n, alpha)
             try:
                 want = o.scan(data)
             except OracleError:
