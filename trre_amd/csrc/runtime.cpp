@@ -466,12 +466,13 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
             args.lp_emit = 1;
             launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, sym_mode, g16_slow);
         }
-    } else if (direct && !is_guided(family) && stt.fb_ok && !getenv("TRRE_NO_FB") && fb_fits(p->sblob.data())) {
+    } else if (direct && !is_guided(family) && stt.fb_ok && !getenv("TRRE_NO_FB")) {
         // a large table (a dictionary) in its fallback form: the count pass with every per-byte lookup in LDS (0.86 ms per
         // GiB against 1.62 on the 8-byte rows through L1/L2).  The emit pass over the same form (TRRE_FB_EMIT=1) is
         // correct but slower than the one over the 8-byte rows (3.8 against 2.9 ms): its tables leave LDS for only 512
         // staging rings per CU.  TRRE_NO_FB=1: both passes on the 8-byte rows, for A/B runs.
-        static const bool fb_emit = getenv("TRRE_FB_EMIT") != nullptr;
+        static const bool fb_emit_env = getenv("TRRE_FB_EMIT") != nullptr;
+        const bool fb_emit = fb_emit_env && fb_fits(p->sblob.data());         // (the form next to 512 staging rings)
         launch_fb_kernel(1, args, p->sblob.data(), lane_bytes, n_chunks, stream);
         launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);
         if (fb_emit) launch_fb_kernel(2, args, p->sblob.data(), lane_bytes, n_chunks, stream);
