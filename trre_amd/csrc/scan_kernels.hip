@@ -862,7 +862,7 @@ void launch_direct_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t
 constexpr int kRevThreads = 256;
 
 template <int kDbg, bool kNib>
-__global__ __launch_bounds__(kRevThreads) void k_rev_sweep(ScanArgs a, int64_t lane_bytes) {
+__global__ __launch_bounds__(kRevThreads) void k_rev_sweep(ScanArgs a, int64_t lane_bytes, int tile_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];    // tab[n_rev][256]: at most 64 KiB
     const RevBlobHeader& h = *reinterpret_cast<const RevBlobHeader*>(a.rblob);
     const U128* e = reinterpret_cast<const U128*>(a.rblob + h.off_wide);
@@ -870,7 +870,9 @@ __global__ __launch_bounds__(kRevThreads) void k_rev_sweep(ScanArgs a, int64_t l
     for (int k = threadIdx.x; k < (int)h.n_rev * 16; k += kRevThreads) d[k] = e[k];
     __syncthreads();
     const RevView T{smem};
-    rev_sweep_lane<kDbg, kNib>(a, T, (int64_t)blockIdx.x * kRevThreads + threadIdx.x, lane_bytes);
+    // (packed symbols: a 4 KiB tile per wave behind the table, for the unit stores of interior waves)
+    uint8_t* tile = (kNib && tile_bytes) ? smem + (((int)h.n_rev * 256 + 15) & ~15) + (threadIdx.x / kWave) * 4096 : nullptr;
+    rev_sweep_lane<kDbg, kNib>(a, T, (int64_t)blockIdx.x * kRevThreads + threadIdx.x, lane_bytes, tile);
 }
 void launch_rev_sweep(const ScanArgs& a, int tab_bytes, int64_t lane_bytes, void* stream, bool packed) {
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -879,11 +881,12 @@ void launch_rev_sweep(const ScanArgs& a, int tab_bytes, int64_t lane_bytes, void
     const dim3 grid((unsigned)((n_lanes + kRevThreads - 1) / kRevThreads));
     static const int dbg = getenv("TRRE_REV_DBG") ? atoi(getenv("TRRE_REV_DBG")) : 0;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rev_sweep<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, tab_bytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rev_sweep<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, tab_bytes);
-    if (packed) hipLaunchKernelGGL((k_rev_sweep<0, true>), grid, dim3(kRevThreads), tab_bytes, s, a, lane_bytes);
-    else if (dbg == 1) hipLaunchKernelGGL((k_rev_sweep<1, false>), grid, dim3(kRevThreads), tab_bytes, s, a, lane_bytes);
-    else if (dbg == 2) hipLaunchKernelGGL((k_rev_sweep<2, false>), grid, dim3(kRevThreads), tab_bytes, s, a, lane_bytes);
-    else hipLaunchKernelGGL((k_rev_sweep<0, false>), grid, dim3(kRevThreads), tab_bytes, s, a, lane_bytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rev_sweep<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, tab_bytes + 16 + (kRevThreads / kWave) * 4096);
+    static const int tiles = getenv("TRRE_REV_NO_TILE") ? 0 : (kRevThreads / kWave) * 4096;      // A/B: every lane stores its own 64 bytes
+    if (packed) hipLaunchKernelGGL((k_rev_sweep<0, true>), grid, dim3(kRevThreads), ((tab_bytes + 15) & ~15) + tiles, s, a, lane_bytes, tiles);
+    else if (dbg == 1) hipLaunchKernelGGL((k_rev_sweep<1, false>), grid, dim3(kRevThreads), tab_bytes, s, a, lane_bytes, 0);
+    else if (dbg == 2) hipLaunchKernelGGL((k_rev_sweep<2, false>), grid, dim3(kRevThreads), tab_bytes, s, a, lane_bytes, 0);
+    else hipLaunchKernelGGL((k_rev_sweep<0, false>), grid, dim3(kRevThreads), tab_bytes, s, a, lane_bytes, 0);
 }
 
 int stream_chunk_bytes(int which) { return which == 0 ? GeoStream::CHUNK : GeoStreamGen::CHUNK; }
