@@ -65,6 +65,35 @@ def main():
     inputs["abcd_soup"] = b"".join(bytes(rng.choice(b"abcd ") for _ in range(rng.randint(0, 70))) + b"\n" for _ in range(600))
     cases.append({"pattern": "ab:1|abc:2|abcd:3|b:4|bc:5|cab:6|ca:7|dab:8", "input": "abcd_soup"})
     cases.append({"pattern": "(abcd:3|abc:2|ab:1|dab:8|cab:6|ca:7|bc:5|b:4)", "input": "abcd_soup"})
+    # 2b. key lists large enough for the fallback form of the stream table (StreamTables::fb_*): 160 keys of 2..8 bytes over
+    #     eight letters — keys inside keys, keys that are prefixes of keys (the engines differ), in three orders — with
+    #     replacement texts of 0..3 / 0..8 / 0..12 bytes, on inputs with near-misses, key upon key, NULs and keys at line ends
+    for it, (order, top) in enumerate([("shuffled", 8), ("longest_first", 8), ("sorted", 12), ("shuffled", 3), ("longest_first", 12), ("sorted", 5)]):
+        rng = random.Random(500 + it)
+        letters = "abcdefgh"
+        ks = set()
+        while len(ks) < 160:
+            ks.add("".join(rng.choice(letters) for _ in range(rng.randint(2, 8))))
+        ks = sorted(ks)
+        if order == "shuffled":
+            rng.shuffle(ks)
+        elif order == "longest_first":
+            ks.sort(key=lambda k: (-len(k), k))
+        vs = ["".join(rng.choice("XYZxyz01") for _ in range(rng.randint(0, top))) for _ in ks]
+        toks = []
+        while sum(map(len, toks)) < 6000:
+            r = rng.random()
+            if r < 0.35:
+                t = rng.choice(ks)
+            elif r < 0.5:
+                t = rng.choice(ks)[:rng.randint(1, 8)] + rng.choice(letters)
+            elif r < 0.6:
+                t = rng.choice(ks) + rng.choice(ks)
+            else:
+                t = "".join(rng.choice(letters + "xyz") for _ in range(rng.randint(1, 9)))
+            toks.append(t + rng.choice([" ", " ", "\n", ",", "\x00", ""]))
+        inputs["keys160_%d" % it] = "".join(toks).encode("latin-1") + b"\n"
+        cases.append({"pattern": "|".join("%s:%s" % kv for kv in zip(ks, vs)), "input": "keys160_%d" % it})
     # 3. epsilon cycles: the NFT engine's search runs round them for ever on some inputs ("stack max capacity
     #    reached", exit 1 -> "fail") and never meets them on others
     inputs.update({"eps_no_a": b"b\nxx\nzz\n", "eps_with_a": b"b\nca\n", "eps_ad": b"ad\n", "eps_abc": b"xyz\nabc\n"})
