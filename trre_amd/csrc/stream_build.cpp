@@ -501,8 +501,10 @@ private:
         std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return exc[x].size() > exc[y].size(); });
         std::vector<char> used, is_base;
         std::vector<uint32_t> base(n0, 0);
+        size_t probes = 0;
         for (uint32_t s : order) {
             for (size_t b0 = 0;; ++b0) {
+                if (++probes > 100000000u || b0 > 16383) return;              // (not that kind of table: give the form up rather than search on)
                 if (used.size() < b0 + 32) { used.resize(b0 + 32, 0); is_base.resize(b0 + 32, 0); }
                 if (is_base[b0]) continue;
                 bool fits = true;
