@@ -156,7 +156,7 @@ DftTables flatten_dft(const Dft& dft);
 //   [30]    the undecided attempt outgrew max_pending: the table does not know how it ends.  A launch
 //           that meets such a transition reports it and the runtime runs the tile kernels instead
 struct StreamLimits {
-    size_t max_states = 4096;
+    size_t max_states = 16384;     // (a 4000-key dictionary folds into ~15 000 states: 3.5 MB of 8-byte rows)
     size_t max_pending = 64;
     size_t max_out = 4096;
 };
