@@ -260,6 +260,8 @@ struct NftNodes {
 // (trre_nft.c:635-642), so a list does not stop at its first FINAL (it still holds FINAL at most once: the first
 // occurrence in search order is the one that accepts).
 NftNodes build_nft_nodes(const Nft& nft, bool match_mode = false);
+// the scan loop folded over the follow lists (stream_build.cpp: NodeModel) — same tables as build_stream_nft, built faster
+StreamTables build_stream_nodes(const NftNodes& nodes, const StreamLimits& lim = StreamLimits());
 
 // Tables of the bitmask tile kernels: at most 64 nodes, no Diverge marker (their backward sweep is
 // two-valued; patterns with epsilon cycles need the guided tables below).

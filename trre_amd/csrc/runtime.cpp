@@ -263,7 +263,12 @@ int general_family(const trre_prog& p, bool stream_ok) {
 int auto_family(const trre_prog& p) {
     using namespace trre;
     if (p.engine == TRRE_ENGINE_DFT && (p.dt.flags & kFlagMemoryless)) return TRRE_KERNEL_BYTEMAP;
-    if (p.stt.ok) return lp_inplace(p.stt.flags) ? TRRE_KERNEL_STREAM_LP : TRRE_KERNEL_STREAM_GEN;
+    // a stream table too large for LDS is walked through L1/L2 (<= 0.35 TB/s); guided tables with a small forward table
+    // run at 0.6-0.8 TB/s: prefer them then (patterns with `.` or wide ranges before a literal fold into hundreds of
+    // states x 256 classes)
+    const bool stream_small = p.stt.ok && (p.stt.g16_ok || p.stt.lpw_ok);
+    const bool guided_small = p.gt.ok && p.gt.fwd.g16_ok;
+    if (p.stt.ok && (stream_small || !guided_small)) return lp_inplace(p.stt.flags) ? TRRE_KERNEL_STREAM_LP : TRRE_KERNEL_STREAM_GEN;
     if (p.gt.ok) return lp_inplace(p.gt.fwd.flags) ? TRRE_KERNEL_GUIDED_LP : TRRE_KERNEL_GUIDED_GEN;
     if (p.engine == TRRE_ENGINE_DFT) {
         if ((p.dt.flags & kFlagLengthPreserving) && (p.dt.flags & kFlagNoOverrun)) return TRRE_KERNEL_TILE_LP;
@@ -603,7 +608,22 @@ int compile_impl(const std::string& pattern, int engine, trre_prog** out, int mo
                 if (e.code != kErrUnsupported) throw;
                 deferred.reset(new Error(e));            // too many nodes (or an epsilon cycle) for the bitmask kernels
             }
-            p->stt = build_stream_nft(nft);
+            // the fold walks the follow lists (TRRE_NFT_FOLD=states: the NFT's states as the reference does, =both: both, compared)
+            const char* fold = getenv("TRRE_NFT_FOLD");
+            if (fold && !strcmp(fold, "states")) {
+                p->stt = build_stream_nft(nft);
+            } else {
+                p->stt = build_stream_nodes(nodes);
+                if (fold && !strcmp(fold, "both")) {
+                    const StreamTables ref = build_stream_nft(nft);
+                    // (the walk over the states may run out of budget where this one does not: no table to compare then)
+                    if (ref.ok && !p->stt.ok) throw Error(kErrArg, "error: the fold over the follow lists gave up where the one over the states did not (TRRE_NFT_FOLD=both)");
+                    if (ref.ok)
+                    if (ref.ent != p->stt.ent || ref.pool != p->stt.pool || ref.cls != p->stt.cls || ref.flags != p->stt.flags ||
+                        ref.pending_len != p->stt.pending_len || ref.lpw != p->stt.lpw || ref.g16 != p->stt.g16 || ref.fb_comb != p->stt.fb_comb)
+                        throw Error(kErrArg, "error: the two folds of the NFT scan loop disagree (TRRE_NFT_FOLD=both)");
+                }
+            }
             p->gt = build_guided_nft(nodes);
             // no kernel family can run this pattern (a bounded stream table needs general kernels behind it)
             if (deferred && !p->gt.ok && (!p->stt.ok || p->stt.bounded)) throw *deferred;

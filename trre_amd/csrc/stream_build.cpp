@@ -34,6 +34,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <memory>
 #include <unordered_map>
 
 #include "device_blob.hpp"
@@ -168,6 +169,110 @@ public:
 
 private:
     const Nft& n_;
+    mutable uint64_t work_ = 0;
+    uint64_t budget_ = 30000000ull;
+};
+
+// ---- the same search over the follow lists of nft_tables.cpp ---------------------------------
+// A node's list names, in the reference's depth-first priority order, the consuming nodes / FINAL reachable from it
+// through epsilon states, with the bytes produced on the way; the first occurrence of a target stands for all (a search
+// from the same node at the same position fails again).  Walking the lists instead of the states gives the same
+// outcome, and with the lists indexed by the next input byte an attempt on an alternation of thousands of keys visits
+// only the keys that go on with that byte (the state-by-state walk above visits every SPLIT of the chain: a 1000-key
+// dictionary needed 5e8 steps, larger ones ran out of budget).  TRRE_NFT_FOLD=states selects the walk above, =both
+// builds the tables both ways and compares them.
+class NodeModel : public AttemptModel {
+public:
+    explicit NodeModel(const NftNodes& n) : n_(n), index_(n.follow.size()) {
+        size_t entries = 0;
+        for (const auto& l : n.follow) entries += l.size();
+        budget_ = std::min<uint64_t>(1500000000ull, std::max<uint64_t>(30000000ull, 60000ull * entries));
+    }
+    Outcome attempt(const std::string& w, bool at_eol) const override {
+        struct Frame { uint32_t list; size_t next, i, o; bool muted; };    // next: where to go on in the list (or in its index for this byte)
+        std::vector<Frame> stack;
+        std::string out;
+        Outcome r;
+        size_t steps = 0;
+        auto accept = [&](const Frame& f, const NodeFollow& e) {
+            Outcome a;
+            a.kind = Outcome::Accept;
+            out.resize(f.o);
+            if (!f.muted) out += e.out;                                    // (cut at a NUL already: fputs stops there)
+            a.out = out;
+            a.consumed = f.i;
+            return a;
+        };
+        stack.push_back(Frame{(uint32_t)n_.node.size(), 0, 0, 0, false});
+        while (!stack.empty()) {
+            Frame& f = stack.back();
+            const std::vector<NodeFollow>& list = n_.follow[f.list];
+            const NodeFollow* e = nullptr;
+            if (f.i >= w.size()) {
+                // no input left: a node would need a byte we have not seen (at the end of the line: it fails), FINAL accepts
+                for (; f.next < list.size() && !e; ++f.next) {
+                    if (++steps > 2000000 || ++work_ > budget_) throw GiveUp();
+                    const NodeFollow& x = list[f.next];
+                    if (x.target == kNodeFinal || x.target == kNodeDiverge) e = &x;
+                    else if (!at_eol) { r.kind = Outcome::Undecided; return r; }
+                }
+            } else {
+                const uint8_t c = (uint8_t)w[f.i];
+                if (++steps > 2000000 || ++work_ > budget_) throw GiveUp();
+                if (list.size() <= kShortList) {
+                    for (; f.next < list.size() && !e; ++f.next) {
+                        const NodeFollow& x = list[f.next];
+                        if (x.target == kNodeFinal || x.target == kNodeDiverge || n_.node[x.target].reads(c)) e = &x;
+                    }
+                } else {
+                    const std::vector<uint32_t>& idx = entries_for(f.list, c);
+                    if (f.next < idx.size()) e = &list[idx[f.next++]];
+                }
+            }
+            if (!e) { stack.pop_back(); continue; }
+            if (e->target == kNodeDiverge) throw GiveUp();                 // the reference's search does not come back from here
+            if (e->target == kNodeFinal) return accept(f, *e);
+            // the node consumes w[f.i]
+            Frame g{e->target, 0, f.i + 1, f.o, f.muted};
+            out.resize(f.o);
+            if (!g.muted) {
+                out += e->out;
+                if (e->mute) g.muted = true;
+                else if (n_.node[e->target].echo) out.push_back(w[f.i]);
+            }
+            g.o = out.size();
+            if (g.o > (1u << 16) || stack.size() >= 65536) throw GiveUp();
+            stack.push_back(g);
+        }
+        r.kind = Outcome::Fail;
+        return r;
+    }
+    bool tries_empty_tail() const override { return true; }
+    void alphabet(bool (&used)[256]) const override {
+        for (int c = 0; c < 256; ++c) {
+            used[c] = false;
+            for (const NftNodes::Node& nd : n_.node)
+                if (nd.reads((uint8_t)c)) { used[c] = true; break; }
+        }
+    }
+
+private:
+    static constexpr size_t kShortList = 8;
+    using ByByte = std::array<std::vector<uint32_t>, 256>;
+    // the entries of a long list that can be taken on byte c, in list order
+    const std::vector<uint32_t>& entries_for(uint32_t l, uint8_t c) const {
+        if (!index_[l]) {
+            index_[l].reset(new ByByte());
+            const std::vector<NodeFollow>& list = n_.follow[l];
+            for (uint32_t k = 0; k < list.size(); ++k)
+                for (int b = 0; b < 256; ++b)
+                    if (list[k].target == kNodeFinal || list[k].target == kNodeDiverge || n_.node[list[k].target].reads((uint8_t)b))
+                        (*index_[l])[b].push_back(k);
+        }
+        return (*index_[l])[c];
+    }
+    const NftNodes& n_;
+    mutable std::vector<std::unique_ptr<ByByte>> index_;
     mutable uint64_t work_ = 0;
     uint64_t budget_ = 30000000ull;
 };
@@ -596,5 +701,6 @@ StreamTables build(const AttemptModel& m, const StreamLimits& lim) {
 
 StreamTables build_stream_dft(const Dft& dft, const StreamLimits& lim) { return build(DftModel(dft), lim); }
 StreamTables build_stream_nft(const Nft& nft, const StreamLimits& lim) { return build(NftModel(nft), lim); }
+StreamTables build_stream_nodes(const NftNodes& nodes, const StreamLimits& lim) { return build(NodeModel(nodes), lim); }
 
 }  // namespace trre
