@@ -401,3 +401,33 @@ def test_match_mode_through_the_guided_families():
     with pytest.raises(trre_amd.TrreError) as e:
         trre_amd.Program("cat:dog", "dft", mode="match")
     assert e.value.code == trre_amd.api.E_UNSUPPORTED
+
+
+def test_nft_fold_over_follow_lists_equals_the_walk_over_states():
+    """The NFT scan loop is folded by walking the follow lists indexed by the next byte (stream_build.cpp: NodeModel); the
+    state-by-state walk that mirrors infer_backtrack builds the same tables wherever it finishes.  TRRE_NFT_FOLD=both makes
+    the compiler build both and refuse a pattern on which they differ (the variable is read at compile time of a pattern)."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import os, random, sys
+os.environ["TRRE_NFT_FOLD"] = "both"
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import trre_amd, golden_lib
+from fuzz_oracle import gen_expr
+pats = sorted({c[0] for c in golden_lib.cases()})
+rng = random.Random(77)
+pats += [gen_expr(rng).decode("latin-1") for _ in range(400)]
+n = 0
+for pat in pats:
+    try:
+        trre_amd.Program(pat, "nft")
+        n += 1
+    except trre_amd.TrreError as e:
+        assert "TRRE_NFT_FOLD" not in str(e), (pat, str(e))
+print("compiled", n)
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode("latin-1")[-2000:]
+    assert int(r.stdout.split()[-1]) > 300
