@@ -12,13 +12,22 @@ scan over synthetic ASCII lines — at the size north_star asks for, 8 GiB per G
 no data-path collective (`"scaling": "weak"`); `--scaling strong` splits ONE
 config-4 corpus of `--bytes` over the ranks instead.
 
+`--gpus N` with N > 1 and no launcher around it starts the N ranks itself (the
+driver's own command line: torch.distributed.run on 127.0.0.1) and exits
+non-zero if fewer than N GPUs are visible; under a launcher WORLD_SIZE must
+equal --gpus.  `n_gpus` in the line is the number of ranks that really ran.
+
 On one GPU the same JSON line carries a `configs` array: the other BASELINE
 configurations (Caesar, the NFT cat/dog scan on its own corpus, the 1000-entry
 dictionary) and the general kernel families, each with the kernels' HIP-event
 time, its fraction of the HBM roofline, a `verified` flag and the reference CPU
-binary timed on a bounded sample of the same workload.
+binary timed on a bounded sample of the same workload.  On N > 1 GPUs it carries
+the two configurations that BASELINE.json shards: configs[3] strong-scaled (one
+corpus of --bytes cut into N line shards) and configs[4] weak-scaled (--bytes
+per GPU: 64 GiB at 8 x 8 GiB), each verified on every rank.
 
     python bench.py                       # 1 GPU
+    python bench.py --gpus 8              # starts 8 ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
 
 Prints ONE JSON line on rank 0.
@@ -200,13 +209,83 @@ def run_config(trre_amd, spec, inp, out, tmp, want_cpu):
         ok = bool(m == n and spec["torch_check"](inp, out[:n]))
         rec["verified"], rec["verify"] = ok, "whole output against an independent torch byte map on the device"
     else:
-        oracle = Oracle(spec["pattern"], spec["engine"])
+        veng = spec.get("verify_engine", spec["engine"])
+        oracle = Oracle(spec["pattern"], veng)
         lp = info.kernel in (trre_amd.KERNEL_BYTEMAP, trre_amd.KERNEL_TILE_LP, trre_amd.KERNEL_STREAM_LP, trre_amd.KERNEL_GUIDED_LP)
         rec["verified"], rec["verify"] = verify_scan(prog, oracle, inp, out, m, lp, spec.get("slice", 4 << 20), tmp)
+        if veng != spec["engine"]:
+            rec["verify"] += " (the %s oracle: the two engines agree on this prefix-free dictionary)" % veng.upper()
+        if rec["verified"] and spec.get("own_head"):
+            # and a head against the engine's own oracle (the NFT restatement does ~0.3 MB/s on this pattern)
+            e = line_start_at_or_after(inp, spec["own_head"])
+            want = Oracle(spec["pattern"], spec["engine"]).scan(inp[:e].cpu().numpy().tobytes())
+            rec["verified"] = out[:len(want)].cpu().numpy().tobytes() == want
+            rec["verify"] += "; %d KiB head against the %s oracle" % (spec["own_head"] >> 10, spec["engine"].upper())
     if want_cpu:
         rec["cpu_baseline"] = cpu_baseline(spec["pattern"], spec["engine"], host_sample(inp, spec["cpu_sample"]))
     prog.close()
     return rec
+
+
+class StubProgram:
+    """TRRE_BENCH_STUB=1 (tests/test_bench_spawn.py, no GPU): stands in for trre_amd.Program so that the launch, barrier,
+    timing and reduction plumbing of the N-rank path runs on CPU over gloo.  It scans nothing; the line it yields says
+    "data": "stub" and is not a measurement."""
+
+    class _Info:
+        kernel = 1
+        table_rows = 0
+
+    info = _Info()
+
+    def __init__(self, *a, **k):
+        self._n = 0
+
+    def set_kernel(self, fam):
+        pass
+
+    def set_profiling(self, on=True):
+        pass
+
+    def enqueue(self, inp, out, stream=None):
+        self._n = inp.numel()
+        out[:self._n] = inp
+        time.sleep(0.002)
+
+    def finish(self):
+        return self._n
+
+    def last_kernel_ms(self):
+        return 2.0
+
+    def close(self):
+        pass
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n_gpus, stub):
+    """`python bench.py --gpus N` outside a launcher: start N ranks of this script, one per GPU (the same command line the
+    driver uses: torch.distributed.run, rendezvous on 127.0.0.1).  Fails loudly when fewer than N devices are visible."""
+    if not stub:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n_gpus:
+            raise SystemExit("bench.py: --gpus %d, but %d GPU(s) are visible on this node: nothing measured "
+                             "(every rank needs a device of its own; the scan has no CPU path)" % (n_gpus, have))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -224,28 +303,73 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the configs array and the host-buffer rate")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    stub = os.environ.get("TRRE_BENCH_STUB") == "1"
 
-    import torch
-    import trre_amd
-    import corpora
-
+    # ---- who runs: N ranks, one per GPU -------------------------------------------------------------------------------
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus, stub))               # N workers of this script; rank 0 of them prints the line
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the scan has no CPU path")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but launched with WORLD_SIZE=%d: the line would misreport the GPUs used" % (args.gpus, world))
+
+    import torch
+    import corpora
+    if stub:
+        import types
+        dev = torch.device("cpu")
+        trre_amd = types.SimpleNamespace(Program=StubProgram, KERNEL_NAMES={0: "auto", 1: "bytemap"}, KERNEL_BYTEMAP=1, KERNEL_TILE_LP=2,
+                                         KERNEL_STREAM_LP=4, KERNEL_GUIDED_LP=6)
+        sync = lambda: None                                   # noqa: E731
+    else:
+        import trre_amd
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the scan has no CPU path")
+        if local >= torch.cuda.device_count():
+            raise SystemExit("bench.py: rank %d has no device (%d visible)" % (rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        sync = torch.cuda.synchronize
     dist = None
     if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if stub:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
+
+    def reduce(x, op):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op={"max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN, "sum": dist.ReduceOp.SUM}[op])
+        return float(t.item())
+
+    ranks_running = int(reduce(1.0, "sum"))                   # the ranks that really run (reported as n_gpus)
+
+    def timed(p, inp, out, steps):
+        """the contract's timed region: barrier + synchronize on both sides, EXACTLY `steps` scans, MAX over ranks"""
+        p.set_profiling(True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            p.enqueue(inp, out)
+        m = p.finish()
+        sync()
+        elapsed = time.perf_counter() - t0
+        barrier()
+        kernel_ms = p.last_kernel_ms()                        # HIP events on the launch stream, avg per launch
+        p.set_profiling(False)
+        return reduce(elapsed, "max"), m, kernel_ms
 
     strong = args.scaling == "strong"
     pattern = args.pattern or ("(cat:dog|dog:cat)" if strong else "[a:A-z:Z]")
@@ -253,11 +377,11 @@ def main():
     corpus_name = args.corpus or ("catdog" if strong else "printable")
     n = args.bytes // world if strong else args.bytes         # this rank's line shard
     cfg_index = {"printable": 2, "catdog": 4}.get(corpus_name, 5)
-    fam = {v: k for k, v in trre_amd.KERNEL_NAMES.items()}[args.kernel]
+    fam = {v: k for k, v in trre_amd.KERNEL_NAMES.items()}[args.kernel] if not stub else 0
     prog = trre_amd.Program(pattern, engine)
     prog.set_kernel(fam)
     info = prog.info
-    inp = corpora.by_name(corpus_name, n, corpora.SEED0 + cfg_index + 1000 * rank, dev)
+    inp = corpora.by_name("printable" if stub else corpus_name, n, corpora.SEED0 + cfg_index + 1000 * rank, dev)
     out = torch.empty(n + n // 4 + 4096, dtype=torch.uint8, device=dev)
 
     def run_steps(p, k):
@@ -267,7 +391,9 @@ def main():
 
     # warmup + one verified pass
     m = run_steps(prog, max(args.warmup, 1))
-    if pattern == "[a:A-z:Z]":
+    if stub:
+        verified, verify_how = True, "stub: nothing scanned"
+    elif pattern == "[a:A-z:Z]":
         low = (inp >= 97) & (inp <= 122)
         verified = bool(m == n and torch.equal(out[:n], torch.where(low, inp - 32, inp)))
         verify_how = "whole output against an independent torch byte map on the device"
@@ -278,27 +404,16 @@ def main():
         tmp = None if lp else torch.empty(out.numel() // 2 + (2 << 20), dtype=torch.uint8, device=dev)
         verified, verify_how = verify_scan(prog, Oracle(pattern, engine), inp, out, m, lp, 1 << 20, tmp)
         del tmp
-    if not verified:
-        raise SystemExit("bench: the output is wrong (%s)" % verify_how)
+    if reduce(1.0 if verified else 0.0, "min") < 1.0:
+        raise SystemExit("bench: the output is wrong on some rank (rank %d: %s)" % (rank, verify_how))
 
-    prog.set_profiling(True)
-    barrier()
-    t0 = time.perf_counter()
-    m = run_steps(prog, args.steps)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
-    kernel_ms = prog.last_kernel_ms()                        # HIP events on the launch stream, avg per launch
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, m, kernel_ms = timed(prog, inp, out, args.steps)
 
     ms_per_step = elapsed / args.steps * 1e3
     value = world * n / (elapsed / args.steps) / 1e9          # whole-job input GB/s
     achieved = n / (kernel_ms * 1e-3) / 1e9                   # algorithmic: 1 byte read per input byte
     kname = trre_amd.KERNEL_NAMES[info.kernel]
-    traffic, traffic_source = pmc_traffic("k_bytemap", n) if info.kernel == trre_amd.KERNEL_BYTEMAP else (None, None)
+    traffic, traffic_source = pmc_traffic("k_bytemap", n) if info.kernel == trre_amd.KERNEL_BYTEMAP and not stub else (None, None)
     cfg_note = ""
     if (pattern, engine, corpus_name) == ("[a:A-z:Z]", "dft", "printable"):
         cfg_note = " (BASELINE.json configs[1]" + (")" if n == 1 << 30 else " at north_star's size: >= 8 GiB)" if n >= 8 << 30 else " at another size)")
@@ -306,7 +421,7 @@ def main():
         "metric": "input GB/s (scan mode)",
         "value": round(value, 2),
         "unit": "GB/s",
-        "n_gpus": world,
+        "n_gpus": ranks_running,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
@@ -314,33 +429,86 @@ def main():
         "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "u8",
-        "data": "synthetic",
+        "data": "stub" if stub else "synthetic",
         "config": {
             "workload": "'%s' %s scan over %.3f GiB of synthetic %s lines per GPU%s"
                         % (pattern, engine.upper(), n / 2**30, corpus_name, cfg_note),
             "pattern": pattern, "engine": engine, "corpus": corpus_name, "bytes_per_gpu": n, "output_bytes_per_gpu": m,
             "kernel": kname, "table_rows": info.table_rows,
-            "parallelism": "line-sharded x%d, one rank per GPU, no collective" % world,
+            "parallelism": "line-sharded x%d, one rank per GPU, no data-path collective" % world,
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "traffic": traffic, "traffic_source": traffic_source,
-            "kernel": KERNEL_OF[kname],
+            "kernel": KERNEL_OF.get(kname, kname),
             "kernel_ms": round(kernel_ms, 4),
             "algorithmic_bytes_per_launch": n,
             "achieved_read_plus_write": round((n + m) / (kernel_ms * 1e-3) / 1e9, 1),
+            "note": "per GPU (rank 0)" if world > 1 else None,
         },
         "verified": verified,
         "verify": verify_how,
     }
 
-    extras = rank == 0 and world == 1 and not args.no_extras
-    want_cpu = rank == 0 and world == 1 and not args.no_cpu
+    extras = rank == 0 and world == 1 and not args.no_extras and not stub
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu and not stub
     if want_cpu:
         line["cpu_baseline"] = cpu_baseline(pattern, engine, host_sample(inp, args.cpu_sample_mib << 20), os.cpu_count() or 1)
     elif rank == 0:
         line["cpu_baseline"] = None
+
+    if world > 1 and not args.no_extras:
+        # ---- the BASELINE configurations that shard, in the N-GPU line ---------------------------------------------------
+        #   configs[3]  '(cat:dog|dog:cat)' NFT over ONE corpus of --bytes, line-sharded over the ranks (strong scaling)
+        #   configs[4]  the 1000-entry dictionary, --bytes per GPU (weak scaling: 64 GiB at 8 x 8 GiB)
+        # Same timed region as the headline (barrier, K scans, MAX over ranks); every rank verifies its own shard.
+        import dictgen
+        keys, vals = dictgen.make_dictionary(1000)
+        multi = [
+            {"name": "cfg4_strong", "pattern": "(cat:dog|dog:cat)", "engine": "nft", "corpus": "catdog", "seed": 4, "scaling": "strong",
+             "bytes": args.bytes // world, "steps": 20,
+             "workload": "BASELINE configs[3]: '(cat:dog|dog:cat)' NFT scan, one %.0f GiB word-soup corpus line-sharded over %d GPUs"
+                         % (args.bytes / 2**30, world)},
+            {"name": "cfg5_weak", "pattern": dictgen.pattern(keys, vals), "engine": "dft", "corpus": "dict1000", "seed": 5, "scaling": "weak",
+             "bytes": args.bytes, "steps": 10,
+             "workload": "BASELINE configs[4]: 1000-entry key:value dictionary, DFT engine, %.0f GiB per GPU = %.0f GiB over %d GPUs"
+                         % (args.bytes / 2**30, args.bytes * world / 2**30, world)},
+        ]
+        del inp
+        configs = []
+        for spec in multi:
+            nb = spec["bytes"]
+            inp = corpora.by_name("printable" if stub else spec["corpus"], nb, corpora.SEED0 + spec["seed"] + 1000 * rank, dev)
+            p = trre_amd.Program(spec["pattern"], spec["engine"])
+            pinfo = p.info
+            p.enqueue(inp, out)
+            pm = p.finish()                                  # warm-up: tables uploaded, workspaces sized
+            if stub:
+                ok, how = True, "stub: nothing scanned"
+            else:
+                from oracle_lib import Oracle
+                lp = pinfo.kernel in (trre_amd.KERNEL_BYTEMAP, trre_amd.KERNEL_TILE_LP, trre_amd.KERNEL_STREAM_LP, trre_amd.KERNEL_GUIDED_LP)
+                tmp = None if lp else torch.empty(out.numel() // 2 + (2 << 20), dtype=torch.uint8, device=dev)
+                ok, how = verify_scan(p, Oracle(spec["pattern"], spec["engine"]), inp, out, pm, lp, 2 << 20, tmp)
+                del tmp
+            all_ok = reduce(1.0 if ok else 0.0, "min") >= 1.0
+            el, pm, kms = timed(p, inp, out, spec["steps"])
+            total_in = reduce(float(nb), "sum")
+            rec = {"name": spec["name"], "workload": spec["workload"], "engine": spec["engine"], "scaling": spec["scaling"],
+                   "n_gpus": ranks_running, "bytes_per_gpu": nb, "bytes_total": int(total_in), "steps": spec["steps"],
+                   "ms_per_step": round(el / spec["steps"] * 1e3, 4), "input_GBps": round(total_in / (el / spec["steps"]) / 1e9, 1),
+                   "kernel_family": trre_amd.KERNEL_NAMES.get(pinfo.kernel, "?"), "kernel_ms_rank0": round(kms, 4),
+                   "frac_per_gpu_rank0": round(nb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                   "verified": all_ok, "verify": "every rank, its own shard: " + how}
+            if len(spec["pattern"]) <= 64:
+                rec["pattern"] = spec["pattern"]
+            configs.append(rec)
+            p.close()
+            del inp
+        line["configs"] = configs
+        line["configs_verified"] = all(c["verified"] for c in configs)
+        inp = None
 
     if extras:
         # PCIe-inclusive rate through trre_scan_host on 1 GiB of pageable host memory, timed around the C call (never `value`)
@@ -376,15 +544,15 @@ def main():
         printable = [
             {"name": "cfg3", "workload": "BASELINE configs[2]: Caesar '[a:b-y:zz:a]' DFT scan, %.0f GiB printable lines" % (n / 2**30),
              "pattern": "[a:b-y:zz:a]", "engine": "dft", "steps": 50, "torch_check": caesar_check, "cpu_sample": 128 << 20},
-            {"name": "expand", "workload": "general path, expanding output: 'a:xyz' DFT", "pattern": "a:xyz", "engine": "dft", "steps": 5,
+            {"name": "expand", "workload": "general path, expanding output: 'a:xyz' DFT", "pattern": "a:xyz", "engine": "dft", "steps": 20,
              "cpu_sample": 64 << 20},
             {"name": "nft_loop", "workload": "NFT pattern that does not fold (a loop before the decision): '(a|b)*c:x'",
-             "pattern": "(a|b)*c:x", "engine": "nft", "steps": 5, "cpu_sample": 16 << 20},
-            {"name": "nft_range_loop", "workload": "NFT, a byte range under a loop: '[0-9]+:N'", "pattern": "[0-9]+:N", "engine": "nft", "steps": 5,
+             "pattern": "(a|b)*c:x", "engine": "nft", "steps": 20, "cpu_sample": 16 << 20},
+            {"name": "nft_range_loop", "workload": "NFT, a byte range under a loop: '[0-9]+:N'", "pattern": "[0-9]+:N", "engine": "nft", "steps": 20,
              "cpu_sample": 16 << 20},
             {"name": "nft_dot", "workload": "NFT, '.' rows of the reference's test.sh:114: '(.:x)*.*'", "pattern": "(.:x)*.*", "engine": "nft",
-             "steps": 5, "cpu_sample": 4 << 20},
-            {"name": "nft_greedy", "workload": "NFT, greedy loop ' +: ' (bounded fold, runs <= 64)", "pattern": " +: ", "engine": "nft", "steps": 5,
+             "steps": 20, "cpu_sample": 4 << 20},
+            {"name": "nft_greedy", "workload": "NFT, greedy loop ' +: ' (bounded fold, runs <= 64)", "pattern": " +: ", "engine": "nft", "steps": 20,
              "cpu_sample": 16 << 20},
         ]
         for spec in printable:
@@ -397,14 +565,16 @@ def main():
                                                 "+ near-misses, %d lines" % (n / 2**30, lines)}, inp, out, tmp, want_cpu)
         rec["lines"] = lines
         configs.append(rec)
-        configs.append(run_config(trre_amd, {"name": "cfg4_guided", "pattern": "(cat:dog|dog:cat)", "engine": "nft", "steps": 5,
+        configs.append(run_config(trre_amd, {"name": "cfg4_guided", "pattern": "(cat:dog|dog:cat)", "engine": "nft", "steps": 20,
                                              "workload": "the same scan forced through the guided family (what an NFT pattern that does not "
                                                          "fold runs on)", "force": "guided_lp"}, inp, out, tmp, False))
         del inp
         inp = corpora.dictionary_soup(n, corpora.SEED0 + 5, dev, keys)
-        for eng, steps, sample, sl in (("dft", 5, 16 << 20, 4 << 20), ("nft", 5, 256 << 10, 128 << 10)):
+        # (the dictionary's keys are prefix-free, so the two engines print the same bytes — SURVEY Q9: the NFT run is checked
+        # against the DFT oracle on 4 MiB slices, which the NFT oracle at 0.3 MB/s cannot cover, and against its own on a head)
+        for eng, steps, sample, sl, veng in (("dft", 10, 16 << 20, 4 << 20, "dft"), ("nft", 10, 256 << 10, 4 << 20, "dft")):
             configs.append(run_config(trre_amd, {"name": "cfg5_" + eng, "pattern": dict_pat, "engine": eng, "steps": steps, "cpu_sample": sample,
-                                                 "slice": sl,
+                                                 "slice": sl, "verify_engine": veng, "own_head": 128 << 10 if eng == "nft" else 0,
                                                  "workload": "BASELINE configs[4] shape: 1000-entry key:value dictionary (%d-byte pattern), %s engine, "
                                                              "%.0f GiB per GPU, 30 %% of the tokens are keys" % (len(dict_pat), eng.upper(), n / 2**30)},
                                       inp, out, tmp, want_cpu))
