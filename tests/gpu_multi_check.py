@@ -45,6 +45,18 @@ def main():
     if rc != trre_amd.api.E_CAPACITY or m.value != len(want):
         print("SIZE QUERY", rc, m.value, len(want))
         bad += 1
+    # a length-preserving program whose output NUL bytes shorten: a buffer of exactly the reported size must do
+    # (shards whose place lay beyond `cap` ran as size queries and the call failed for ever)
+    q = trre_amd.Program("[a:A-z:Z]", "dft")
+    nul = (b"abc\0defghijklmnopqrstuvwxyz0123456789\n" * 40000) + big.replace(b"\0", b" ")[: 1 << 20]
+    want_q = Oracle("[a:A-z:Z]", "dft").scan(nul)
+    rc = trre_amd.api.lib().trre_scan_host_multi(q._h, nul, len(nul), None, 0, ctypes.byref(m), 0)
+    exact = ctypes.create_string_buffer(m.value)
+    m2 = ctypes.c_size_t()
+    rc2 = trre_amd.api.lib().trre_scan_host_multi(q._h, nul, len(nul), exact, m.value, ctypes.byref(m2), 0)
+    if rc != trre_amd.api.E_CAPACITY or m.value != len(want_q) or rc2 != 0 or exact.raw[:m2.value] != want_q:
+        print("EXACT CAPACITY", rc, m.value, len(want_q), rc2, m2.value)
+        bad += 1
     rc = trre_amd.api.lib().trre_scan_host_multi(p._h, big, len(big), small, len(small), ctypes.byref(m), 1 << 30)
     if rc != trre_amd.api.E_ARG:
         print("MASK", rc)

@@ -98,3 +98,16 @@ def test_general_families_8gib():
         p = trre_amd.Program(pat, eng)
         got = p.scan_tensor(inp, out=out)
         check_slices(p, Oracle(pat, eng), inp, out, got.numel(), p.info.kernel)
+
+
+@pytest.mark.parametrize("env", [{}, {"TRRE_NO_FB": "1"}, {"TRRE_FB_EMIT": "1"}])
+def test_dictionary_8gib(env):
+    """BASELINE configs[4] at its per-GPU size: the 1000-entry dictionary over 8 GiB of its own corpus (offsets
+    beyond 2^32 through the large-table kernels), both engines, the automatic choice and the two alternative
+    walkers of the large table (the library reads the environment once per process: subprocess)"""
+    import subprocess
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_dict8g_check.py")
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, script], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
+    assert r.returncode == 0, r.stdout.decode("latin-1")[-3000:]

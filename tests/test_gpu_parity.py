@@ -173,6 +173,25 @@ def test_mask_scratch_grows_with_the_input():
             assert gpu_scan(p, data, fam) == o.scan(data), (n_lines, fam)
 
 
+def test_host_path_redownloads_after_a_relaunch():
+    """trre_scan_host queues an early download behind the first launch of a length-preserving chunk; when finish()
+    has to run the chunk again (here: mask scratch for 45 kB lines on the NFT tile kernels) the bytes fetched early
+    are stale and must be fetched again (silently wrong output through trre_scan_host / the CLI)"""
+    p = prog("c", "nft")
+    o = Oracle("c", "nft")
+    data = b"".join(b"abcxy" * 9000 + b"\n" + b"cab\n" for _ in range(12))
+    p.set_kernel(trre_amd.KERNEL_TILE_LP)
+    try:
+        assert p.scan(data) == o.scan(data)
+        assert p.scan(data, device_mask=0) == o.scan(data)
+    finally:
+        p.set_kernel(trre_amd.KERNEL_AUTO)
+    # the same through a bounded fold that overflows (stream_lp -> general family) and through a NUL
+    for pat, eng, d in [("a+:b", "nft", b"x" + b"a" * 200 + b"y\n" + b"caab\n" * 3000), ("(cat:dog|dog:cat)", "nft", b"cat\0dog\n" + b"a cat\n" * 5000)]:
+        pp = prog(pat, eng)
+        assert pp.scan(d) == Oracle(pat, eng).scan(d), (pat, eng)
+
+
 def test_capacity_error_reports_needed_size():
     import ctypes
     import torch

@@ -69,6 +69,7 @@ struct ScanCtx {
     uint8_t* d_sym = nullptr;         // guided families: one symbol per input byte
     size_t sym_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int relaunches = 0;               // finish() ran the scan again (scratch, NUL, overflow): whatever was downloaded early is stale
     Pending pend;
 };
 
@@ -413,7 +414,9 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
     const bool direct_ent_lds = stt.ok && stt.ent.size() * 8 <= (size_t)direct_ent_lds_bytes();
     const bool g16_slow = (stt.flags & kFlagG16Slow) != 0;
     static const bool no_nib = getenv("TRRE_NO_NIBBLES") != nullptr;      // A/B: one symbol per byte
-    const int sym_mode = !is_guided(family) ? 0 : (p->gt.sym_bits == 4 && !no_nib && !getenv("TRRE_NO_G16") ? 2 : 1);
+    static const bool no_g16_env = getenv("TRRE_NO_G16") != nullptr;       // A/B: the 8-byte entries
+    static const bool no_fb_env = getenv("TRRE_NO_FB") != nullptr;         // A/B: large tables walk their 8-byte rows in both passes
+    const int sym_mode = !is_guided(family) ? 0 : (p->gt.sym_bits == 4 && !no_nib && !no_g16_env ? 2 : 1);
     if (direct) n_chunks = (args.vend + lane_bytes * direct_block_threads() - 1) / (lane_bytes * direct_block_threads());
 
     if (!is_gen(family) && cap < n) return TRRE_OK;   // finish() reports the capacity error
@@ -460,8 +463,7 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
         // length-preserving without a window form: the emit pass alone, every lane writing its lines where it read
         // them (TRRE_LP_RING=1: the older in-place walker with an LDS ring, 2.3x slower; kept for A/B runs)
         static const bool lp_ring = getenv("TRRE_LP_RING") != nullptr;
-        static const bool no_g16 = getenv("TRRE_NO_G16") != nullptr;
-        const int g16 = stt.g16_ok && !no_g16 ? (int)(align_up(stt.g16.size() * 4, 16) + stt.p32.size() * 4) : 0;   // LDS room: 16-byte + pair forms
+        const int g16 = stt.g16_ok && !no_g16_env ? (int)(align_up(stt.g16.size() * 4, 16) + stt.p32.size() * 4) : 0;   // LDS room: 16-byte + pair forms
         if (is_guided(family)) launch_rev_sweep(args, (int)p->gt.n_rev * 256, lane_bytes, stream, sym_mode == 2);
         static const bool rev_only = getenv("TRRE_REV_DBG") != nullptr;       // experiments on the backward pass alone (its output may be void)
         if (is_guided(family) && rev_only) {
@@ -471,7 +473,7 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
             args.lp_emit = 1;
             launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, sym_mode, g16_slow);
         }
-    } else if (direct && !is_guided(family) && stt.fb_ok && !getenv("TRRE_NO_FB")) {
+    } else if (direct && !is_guided(family) && stt.fb_ok && !no_fb_env) {
         // a large table (a dictionary) in its fallback form: the count pass with every per-byte lookup in LDS (0.86 ms per
         // GiB against 1.62 on the 8-byte rows through L1/L2).  The emit pass over the same form (TRRE_FB_EMIT=1) is
         // correct but slower than the one over the 8-byte rows (3.8 against 2.9 ms): its tables leave LDS for only 512
@@ -484,8 +486,7 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
         else launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, 0, sym_mode, g16_slow);
         pd.total_at = cx->d_chunk_base + n_chunks;
     } else if (direct) {
-        static const bool no_g16 = getenv("TRRE_NO_G16") != nullptr;          // A/B: the 8-byte entries
-        const int g16 = stt.g16_ok && !no_g16 ? (int)(align_up(stt.g16.size() * 4, 16) + stt.p32.size() * 4) : 0;   // LDS room: 16-byte + pair forms
+        const int g16 = stt.g16_ok && !no_g16_env ? (int)(align_up(stt.g16.size() * 4, 16) + stt.p32.size() * 4) : 0;   // LDS room: 16-byte + pair forms
         if (is_guided(family)) launch_rev_sweep(args, (int)p->gt.n_rev * 256, lane_bytes, stream, sym_mode == 2);
         launch_direct_kernel(1, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, sym_mode, g16_slow);
         launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);
@@ -534,6 +535,7 @@ int finish(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
     }
     const uint32_t status = cx->h_status[0];
     auto again = [&](int family) -> int {
+        cx->relaunches += 1;
         int rc = enqueue(p, st, cx, family, was.d_in, was.n, was.d_out, was.cap, was.stream);
         if (rc) return rc;
         return finish(p, st, cx, out_len);
@@ -888,6 +890,7 @@ int scan_host_on(trre_prog* p, DeviceState* st, const uint8_t* in, size_t n, uin
         CopyPool::get().copy(hs.pin_in, in + at, len, kCopyWays);
         HIP_TRY(hipMemcpyAsync(hs.d_in, hs.pin_in, len, hipMemcpyHostToDevice, hs.stream));
         ch[b].off = at; ch[b].len = len; ch[b].out_at = 0; ch[b].m = 0; ch[b].submitted = true; ch[b].early = false;
+        hs.ctx.relaunches = 0;
         r = enqueue(p, st, &hs.ctx, fam, hs.d_in, len, hs.d_out, hs.out_cap, hs.stream);
         if (r) return r;
         if (fixed_len && !overflow && total_bound + len <= cap) {
@@ -916,7 +919,9 @@ int scan_host_on(trre_prog* p, DeviceState* st, const uint8_t* in, size_t n, uin
         ch[b].out_at = total;
         if (!overflow && total + m > cap) overflow = true;
         if (!overflow && m) {
-            if (!(ch[b].early && m == ch[b].len && !again))
+            // (the early download holds the FIRST launch's bytes: a relaunch inside finish() — mask scratch for a long
+            // line, a NUL, a bounded fold that overflowed — rewrote d_out afterwards)
+            if (!(ch[b].early && m == ch[b].len && !again && hs.ctx.relaunches == 0))
                 HIP_TRY(hipMemcpyAsync(hs.pin_out, hs.d_out, m, hipMemcpyDeviceToHost, hs.stream));
             ch[b].copying = true;
         }
@@ -1037,21 +1042,30 @@ int trre_scan_host_multi(trre_prog* p, const uint8_t* in, size_t n, uint8_t* out
     for (int g = 0; g < G; ++g) {
         th.emplace_back([&, g] {
             Shard& s = sh[g];
-            const size_t lo = bounds[g], len = bounds[g + 1] - lo;
-            if (len == 0) return;
-            const bool direct = fixed_len && lo + len <= cap;
-            uint8_t* dst = nullptr;
-            size_t room = 0;
-            if (direct) { dst = out + lo; room = len; }
-            else if (!fixed_len || cap >= n) { s.buf.resize(len + len / 2 + 4096); s.own = true; dst = s.buf.data(); room = s.buf.size(); }
-            s.rc = trre_scan_host(p, in + lo, len, dst, room, &s.m, devs[g]);
-            if (s.rc == TRRE_E_CAPACITY && s.own) {          // the shard needs s.m bytes
-                s.buf.resize(s.m + 64);
-                s.rc = trre_scan_host(p, in + lo, len, s.buf.data(), s.buf.size(), &s.m, devs[g]);
-            } else if (s.rc == TRRE_E_CAPACITY && direct) {  // a NUL made it a general scan with another size: cannot happen
-                s.rc = TRRE_E_CAPACITY;                      // (a NUL only shortens), kept for symmetry
+            try {
+                const size_t lo = bounds[g], len = bounds[g + 1] - lo;
+                if (len == 0) return;
+                const bool direct = fixed_len && lo + len <= cap;
+                uint8_t* dst = nullptr;
+                size_t room = 0;
+                // cap == 0 is a size query; otherwise a shard that cannot go straight to its place gets a buffer of its
+                // own — also for a length-preserving program whose place lies beyond `cap`: NUL bytes may shorten the
+                // shards before it, and the call must succeed whenever the TOTAL fits
+                if (direct) { dst = out + lo; room = len; }
+                else if (cap > 0) { s.buf.resize(fixed_len ? len + 64 : len + len / 2 + 4096); s.own = true; dst = s.buf.data(); room = s.buf.size(); }
+                s.rc = trre_scan_host(p, in + lo, len, dst, room, &s.m, devs[g]);
+                if (s.rc == TRRE_E_CAPACITY && s.own) {          // the shard needs s.m bytes
+                    s.buf.resize(s.m + 64);
+                    s.rc = trre_scan_host(p, in + lo, len, s.buf.data(), s.buf.size(), &s.m, devs[g]);
+                }
+                if (s.rc && s.rc != TRRE_E_CAPACITY) s.err = trre_last_error();
+            } catch (const std::bad_alloc&) {                    // a multi-GB shard buffer: an error code, not std::terminate
+                s.rc = TRRE_E_TOO_BIG;
+                s.err = "error: out of host memory for a shard's output buffer";
+            } catch (const std::exception& e) {
+                s.rc = TRRE_E_DEVICE;
+                s.err = std::string("error: ") + e.what();
             }
-            if (s.rc && s.rc != TRRE_E_CAPACITY) s.err = trre_last_error();
         });
     }
     for (auto& t : th) t.join();
@@ -1063,7 +1077,7 @@ int trre_scan_host_multi(trre_prog* p, const uint8_t* in, size_t n, uint8_t* out
         total += sh[g].m;
     }
     if (out_len) *out_len = total;
-    if (short_cap || total > cap) return fail(TRRE_E_CAPACITY, "error: output buffer too small");
+    if (short_cap || total > cap) return fail(TRRE_E_CAPACITY, "error: output buffer too small");   // (short_cap: a size query, cap == 0)
     // move the shards into place, in order (a direct shard that came out shorter — NUL bytes — moves down)
     size_t at = 0;
     for (int g = 0; g < G; ++g) {

@@ -16,6 +16,7 @@
 // The per-thread phase bodies live in scan_block.hpp / scan_core.hpp.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
 
 #include "launch.hpp"
@@ -25,6 +26,20 @@ namespace trre {
 namespace {
 
 constexpr int kWave = 64;
+
+// Kernels that take more than 64 KiB of dynamic LDS need the limit raised — once per kernel and device, not per launch
+// (a launch is ~5 us of host time; the call is another 2-3): the limit is set to the CU's whole 160 KiB.
+constexpr int kLdsLimit = 160 * 1024;
+template <auto Kernel>
+void allow_big_lds() {
+    static std::atomic<uint64_t> done{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_relaxed) & bit) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
+    done.fetch_or(bit, std::memory_order_relaxed);
+}
 
 __device__ __forceinline__ int wave_min(int v) {
     for (int d = 32; d; d >>= 1) v = min(v, __shfl_xor(v, d, kWave));
@@ -616,13 +631,9 @@ __global__ __launch_bounds__(kMapThreads) void k_bytemap(ScanArgs a, int64_t nve
 template <class G, class Engine>
 void launch3(int which, const ScanArgs& a, int64_t n_chunks, hipStream_t s) {
     using C = Carve<G, Engine>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan_lp<G, Engine>), hipFuncAttributeMaxDynamicSharedMemorySize, C::kBytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan_count<G, Engine>), hipFuncAttributeMaxDynamicSharedMemorySize, C::kBytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan_emit<G, Engine>), hipFuncAttributeMaxDynamicSharedMemorySize, C::kBytes);
-        attr_done = true;
-    }
+    allow_big_lds<&k_scan_lp<G, Engine>>();
+    allow_big_lds<&k_scan_count<G, Engine>>();
+    allow_big_lds<&k_scan_emit<G, Engine>>();
     const dim3 grid((unsigned)n_chunks), block(G::THREADS);
     if (which == 0) hipLaunchKernelGGL((k_scan_lp<G, Engine>), grid, block, C::kBytes, s, a);
     else if (which == 1) hipLaunchKernelGGL((k_scan_count<G, Engine>), grid, block, C::kBytes, s, a);
@@ -659,7 +670,7 @@ using GeoStreamC = Geometry<512, 512 * 260, 2032>;    // 65 dwords per lane, one
 template <class GL, bool kLdsEnt>
 void launch_stream_lp_geo(const ScanArgs& a, hipStream_t s) {
     const int64_t n_chunks = (a.vend + GL::CHUNK - 1) / GL::CHUNK;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_lp<GL, kLdsEnt>), hipFuncAttributeMaxDynamicSharedMemorySize, StreamCarve<GL>::kBytesOneTile);
+    allow_big_lds<&k_stream_lp<GL, kLdsEnt>>();
     hipLaunchKernelGGL((k_stream_lp<GL, kLdsEnt>), dim3((unsigned)n_chunks), dim3(GL::THREADS), StreamCarve<GL>::kBytesOneTile, s, a);
 }
 
@@ -672,9 +683,9 @@ void launch_stream_t(int which, const ScanArgs& a, int64_t n_chunks, hipStream_t
     }
     using GL = GeoStream;
     using GG = GeoStreamGen;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_lp<GL, kLdsEnt>), hipFuncAttributeMaxDynamicSharedMemorySize, StreamCarve<GL>::kBytesOneTile);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_count<GG, kLdsEnt>), hipFuncAttributeMaxDynamicSharedMemorySize, StreamCarve<GG>::kBytesOneTile);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_emit<GG, kLdsEnt>), hipFuncAttributeMaxDynamicSharedMemorySize, StreamCarve<GG>::kBytesTwoTiles);
+    allow_big_lds<&k_stream_lp<GL, kLdsEnt>>();
+    allow_big_lds<&k_stream_count<GG, kLdsEnt>>();
+    allow_big_lds<&k_stream_emit<GG, kLdsEnt>>();
     const dim3 grid((unsigned)n_chunks);
     if (which == 0) hipLaunchKernelGGL((k_stream_lp<GL, kLdsEnt>), grid, dim3(GL::THREADS), StreamCarve<GL>::kBytesOneTile, s, a);
     else if (which == 1) hipLaunchKernelGGL((k_stream_count<GG, kLdsEnt>), grid, dim3(GG::THREADS), StreamCarve<GG>::kBytesOneTile, s, a);
@@ -807,10 +818,10 @@ void launch_lpw_kernel(int ent_bytes, bool wide, bool direct_ent_in_lds, const S
     const int ent_room = ent_in_lds ? (ent_bytes + 15) / 16 * 16 : 0;
     const int lds = 256 + ent_room + kWtWaves * (kWtTile + kWtOutTile);
     if (ent_in_lds && wide) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_lpw<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        allow_big_lds<&k_stream_lpw<true, true>>();
         hipLaunchKernelGGL((k_stream_lpw<true, true>), grid, dim3(kWtThreads), lds, s, a, lane_bytes, ent_room);
     } else if (ent_in_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_lpw<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        allow_big_lds<&k_stream_lpw<true, false>>();
         hipLaunchKernelGGL((k_stream_lpw<true, false>), grid, dim3(kWtThreads), lds, s, a, lane_bytes, ent_room);
     } else if (wide) {
         hipLaunchKernelGGL((k_stream_lpw<false, true>), grid, dim3(kWtThreads), lds, s, a, lane_bytes, ent_room);
@@ -833,8 +844,8 @@ void launch_g16(int which, const ScanArgs& a, int64_t lane_bytes, int64_t n_bloc
     const int room = (g16_bytes + 15) / 16 * 16;
     const int lds = 256 + room + kDirectPoolSmall + kDirectThreads * kRingStride + 64 + kDirectWsc;
     const int lds_count = 256 + room + 64;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_g16<1, kSym, kHasSlow>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_count);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_g16<2, kSym, kHasSlow>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    allow_big_lds<&k_stream_g16<1, kSym, kHasSlow>>();
+    allow_big_lds<&k_stream_g16<2, kSym, kHasSlow>>();
     if (which == 1) hipLaunchKernelGGL((k_stream_g16<1, kSym, kHasSlow>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds_count, s, a, lane_bytes, room);
     else hipLaunchKernelGGL((k_stream_g16<2, kSym, kHasSlow>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds, s, a, lane_bytes, room);
 }
@@ -880,8 +891,8 @@ void launch_rev_sweep(const ScanArgs& a, int tab_bytes, int64_t lane_bytes, void
     const int64_t n_lanes = (vtop + lane_bytes - 1) / lane_bytes;
     const dim3 grid((unsigned)((n_lanes + kRevThreads - 1) / kRevThreads));
     static const int dbg = getenv("TRRE_REV_DBG") ? atoi(getenv("TRRE_REV_DBG")) : 0;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rev_sweep<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, tab_bytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rev_sweep<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, tab_bytes + 16 + (kRevThreads / kWave) * 4096);
+    allow_big_lds<&k_rev_sweep<0, false>>();
+    allow_big_lds<&k_rev_sweep<0, true>>();
     static const int tiles = getenv("TRRE_REV_NO_TILE") ? 0 : (kRevThreads / kWave) * 4096;      // A/B: every lane stores its own 64 bytes
     if (packed) hipLaunchKernelGGL((k_rev_sweep<0, true>), grid, dim3(kRevThreads), ((tab_bytes + 15) & ~15) + tiles, s, a, lane_bytes, tiles);
     else if (dbg == 1) hipLaunchKernelGGL((k_rev_sweep<1, false>), grid, dim3(kRevThreads), tab_bytes, s, a, lane_bytes, 0);
@@ -910,11 +921,11 @@ void launch_fb_kernel(int which, const ScanArgs& a, const void* hdr, int64_t lan
     const int lds = fb_lds_bytes(*static_cast<const StreamBlobHeader*>(hdr), which);
     if (which == 1) {
         constexpr int kG = kFbCountThreads / kDirectThreads;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_fb<1, kFbCountThreads>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        allow_big_lds<&k_stream_fb<1, kFbCountThreads>>();
         hipLaunchKernelGGL((k_stream_fb<1, kFbCountThreads>), dim3((unsigned)((n_chunks + kG - 1) / kG)), dim3(kFbCountThreads), lds, s, a, lane_bytes, n_chunks);
     } else {
         constexpr int kG = kFbEmitThreads / kDirectThreads;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_fb<2, kFbEmitThreads>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        allow_big_lds<&k_stream_fb<2, kFbEmitThreads>>();
         hipLaunchKernelGGL((k_stream_fb<2, kFbEmitThreads>), dim3((unsigned)((n_chunks + kG - 1) / kG)), dim3(kFbEmitThreads), lds, s, a, lane_bytes, n_chunks);
     }
 }
