@@ -50,10 +50,13 @@ extern "C" {
 #define TRRE_E_DEVICE (-6)      /* HIP runtime failure / no GPU */
 #define TRRE_E_ARG (-7)
 #define TRRE_E_DIVERGES (-8)    /* the reference does not survive this input: an epsilon cycle is entered (NFT: "error: stack max
-                                   capacity reached", exit 1; DFT: unbounded recursion).  The error is for the whole buffer: no
-                                   partial output (the reference has printed the lines before the bad one).  Not modelled: the
-                                   reference's limit of 65 536 live backtrack items in one attempt (a greedy loop over a run of
-                                   65 536 bytes exits 1 there; here it is matched) */
+                                   capacity reached", exit 1; DFT: unbounded recursion, SIGSEGV).  NFT engine: the reference exits
+                                   with everything it had printed so far — the lines before the bad one and the bad line's output up
+                                   to the attempt that does not return (trre_nft.c:551-553, exit() flushes stdout) — and so does the
+                                   scan: those bytes are in the output buffer and *out_len is their count.  DFT engine: the
+                                   reference's buffered output dies with it; *out_len = 0.  Not modelled: the reference's limit of
+                                   65 536 live backtrack items in one attempt (a greedy loop over a run of 65 536 bytes exits 1
+                                   there; here it is matched: tests/test_gpu_parity.py pins the difference) */
 #define TRRE_E_CAPACITY (-9)    /* output buffer too small; *out_len holds the size needed */
 
 /* kernel families (trre_info.kernel, trre_set_kernel) */

@@ -833,8 +833,11 @@ int trre_oracle_scan(trre_oracle_prog *p, const uint8_t *in, size_t n,
     p->scan_out.b = NULL; p->scan_out.n = p->scan_out.cap = 0;
     bv_reserve(&p->scan_out, n + 16);
     if (setjmp(p->jb)) {
-        bv_free(&p->scan_out);
-        *out = NULL; *m = 0;
+        /* the NFT binary exits through exit(), which flushes stdout: what had been printed stays
+         * printed (nft.c:551-553).  The DFT binary dies of a signal with its buffer unflushed. */
+        if (p->engine == TRRE_ORACLE_DFT) bv_free(&p->scan_out);
+        *out = p->scan_out.b; *m = p->scan_out.n;
+        p->scan_out.b = NULL; p->scan_out.n = p->scan_out.cap = 0;
         return p->ecode;
     }
     bvec *dst = &p->scan_out;
@@ -864,8 +867,8 @@ int trre_oracle_match(trre_oracle_prog *p, const uint8_t *in, size_t n, uint8_t 
     p->scan_out.b = NULL; p->scan_out.n = p->scan_out.cap = 0;
     bv_reserve(&p->scan_out, n + 16);
     if (setjmp(p->jb)) {
-        bv_free(&p->scan_out);
-        *out = NULL; *m = 0;
+        *out = p->scan_out.b; *m = p->scan_out.n;      /* (what had been printed: see trre_oracle_scan) */
+        p->scan_out.b = NULL; p->scan_out.n = p->scan_out.cap = 0;
         return p->ecode;
     }
     bvec *dst = &p->scan_out;

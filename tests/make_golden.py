@@ -29,14 +29,20 @@ def enc(b):
     return base64.b64encode(zlib.compress(b, 9)).decode("ascii")
 
 
-def run_ref(engine, pattern, path, flags=()):
+def run_ref_full(engine, pattern, path, flags=()):
+    """(exit status or None on a timeout, stdout, stderr)"""
     binary = os.path.join(REF_DIR, "trre" if engine == "nft" else "trre_dft")
     try:
         p = subprocess.run([binary] + list(flags) + [pattern.encode("latin-1"), path], stdout=subprocess.PIPE,
                            stderr=subprocess.PIPE, timeout=20)
     except subprocess.TimeoutExpired:
-        return None
-    return p.stdout if p.returncode == 0 else None
+        return None, b"", b""
+    return p.returncode, p.stdout, p.stderr
+
+
+def run_ref(engine, pattern, path, flags=()):
+    rc, out, _ = run_ref_full(engine, pattern, path, flags)
+    return out if rc == 0 else None
 
 
 def main():
@@ -96,9 +102,16 @@ def main():
         cases.append({"pattern": "|".join("%s:%s" % kv for kv in zip(ks, vs)), "input": "keys160_%d" % it})
     # 3. epsilon cycles: the NFT engine's search runs round them for ever on some inputs ("stack max capacity
     #    reached", exit 1 -> "fail") and never meets them on others
-    inputs.update({"eps_no_a": b"b\nxx\nzz\n", "eps_with_a": b"b\nca\n", "eps_ad": b"ad\n", "eps_abc": b"xyz\nabc\n"})
+    inputs.update({"eps_no_a": b"b\nxx\nzz\n", "eps_with_a": b"b\nca\n", "eps_ad": b"ad\n", "eps_abc": b"xyz\nabc\n",
+                   # the bad line in the middle, with matches before the attempt that does not return: what the reference
+                   # had printed when it exits is part of the vector ("nft_fail_stdout")
+                   "eps_mid": b"cat one\nxx cat yy\nzzz cat bcd a cat\nnever printed cat\n",
+                   "eps_tail": b"first\ncat cat cat abc"})
     for pat in ("a:*", "a(:y)*", "a(b*)*c|ad"):
         for name in ("eps_no_a", "eps_with_a", "eps_ad", "eps_abc"):
+            cases.append({"pattern": pat, "input": name})
+    for pat in ("cat:dog|a:*", "(cat:dog|b)*|a(:y)*", "a(b*)*c|ad|cat:x"):
+        for name in ("eps_mid", "eps_tail", "eps_no_a"):
             cases.append({"pattern": pat, "input": name})
     out_cases = []
     with tempfile.TemporaryDirectory() as td:
@@ -109,8 +122,10 @@ def main():
                 f.write(data)
         for c in cases:
             for engine in ("nft", "dft"):
-                got = run_ref(engine, c["pattern"], paths[c["input"]])
-                c[engine] = "fail" if got is None else enc(got)
+                rc, got, err = run_ref_full(engine, c["pattern"], paths[c["input"]])
+                c[engine] = enc(got) if rc == 0 else "fail"
+                if engine == "nft" and rc == 1 and err.startswith(b"error: stack max capacity reached"):
+                    c["nft_fail_stdout"] = enc(got)      # exit() flushed stdout: everything printed before the failing attempt
             if "expect_nft_text" in c:
                 want = (c["expect_nft_text"] + "\n").encode("latin-1")
                 assert zlib.decompress(base64.b64decode(c["nft"])) == want, c

@@ -16,10 +16,11 @@ ENGINES = {"nft": 0, "dft": 1}
 
 
 class OracleError(RuntimeError):
-    def __init__(self, code, msg):
+    def __init__(self, code, msg, partial=b""):
         super().__init__("oracle error %d: %s" % (code, msg))
         self.code = code
         self.msg = msg
+        self.partial = partial      # what the reference had printed when it failed (NFT engine; exit() flushes stdout)
 
 
 def build_oracle():
@@ -83,9 +84,9 @@ class Oracle:
         out = ctypes.c_void_p()
         m = ctypes.c_size_t()
         rc = lib().trre_oracle_scan(self._h, data, len(data), ctypes.byref(out), ctypes.byref(m))
-        if rc:
-            raise OracleError(rc, "scan failed")
         try:
+            if rc:
+                raise OracleError(rc, "scan failed", ctypes.string_at(out, m.value) if out else b"")
             return ctypes.string_at(out, m.value)
         finally:
             lib().trre_oracle_release(out)
@@ -96,9 +97,9 @@ class Oracle:
         out = ctypes.c_void_p()
         m = ctypes.c_size_t()
         rc = lib().trre_oracle_match(self._h, data, len(data), ctypes.byref(out), ctypes.byref(m))
-        if rc:
-            raise OracleError(rc, "match failed")
         try:
+            if rc:
+                raise OracleError(rc, "match failed", ctypes.string_at(out, m.value) if out else b"")
             return ctypes.string_at(out, m.value)
         finally:
             lib().trre_oracle_release(out)

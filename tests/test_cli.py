@@ -112,6 +112,14 @@ def test_cli_streams_blocks_and_shards():
 
 @pytest.mark.gpu
 def test_cli_reports_divergence_like_the_reference():
-    """'a:*' on a line with an 'a': the reference prints 'error: stack max capacity reached' and exits 1"""
-    rc, out, err = run(BIN["nft"], ["a:*"], b"b\nca\n")
-    assert rc == 1 and err.startswith(b"error: stack max capacity reached")
+    """an epsilon cycle entered: the reference prints 'error: stack max capacity reached' and exits 1 — with the lines
+    before the bad one and the bad line up to the failing attempt on stdout (exit() flushes).  Same status, same
+    stderr, same stdout, whatever the read block size; compared with the compiled reference when it travelled along."""
+    for pat, name, data, printed in golden_lib.fail_cases():
+        for env in ({}, {"TRRE_CLI_BLOCK": "16"}):
+            rc, out, err = run(BIN["nft"], [pat], data, env)
+            assert rc == 1 and err.startswith(b"error: stack max capacity reached"), (pat, name, err)
+            assert out == printed, (pat, name, env)
+        if ref_available():
+            rrc, rout, rerr = run(REF["nft"], [pat], data)
+            assert (rrc, rout) == (1, printed) and rerr == b"error: stack max capacity reached\n"

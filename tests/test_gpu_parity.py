@@ -75,7 +75,7 @@ def test_golden_vectors_on_gpu():
                 if fam in allowed(p):
                     assert gpu_scan(p, data, fam) == exp, (pat, name, fam)
                     n_guided += 1
-    assert n == 894 and n_fail == 18 and n_guided > 500
+    assert n == 902 and n_fail == 28 and n_guided > 500
 
 
 _allowed = {}
@@ -105,6 +105,66 @@ def test_epsilon_cycle_reports_diverges_on_gpu():
     with pytest.raises(trre_amd.TrreError) as e:
         gpu_scan(p, b"b\nca\n")
     assert e.value.code == trre_amd.api.E_DIVERGES
+
+
+def test_divergence_leaves_what_the_reference_had_printed():
+    """NFT engine: the reference exits 1 with the lines before the bad one and the bad line's output up to the failing
+    attempt on stdout (exit() flushes).  The scan returns TRRE_E_DIVERGES with exactly those bytes: golden vectors, every
+    family that runs the pattern, device and host paths, and a bad line deep inside a large buffer (many lanes and
+    chunks before it, more bad lines after it)."""
+    n = 0
+    for pat, name, data, printed in golden_lib.fail_cases():
+        p = prog(pat, "nft")
+        for fam in [trre_amd.KERNEL_AUTO] + p.allowed_kernels():
+            with pytest.raises(trre_amd.TrreError) as e:
+                gpu_scan(p, data, fam)
+            assert e.value.code == trre_amd.api.E_DIVERGES
+            assert e.value.partial.cpu().numpy().tobytes() == printed, (pat, name, fam)
+        with pytest.raises(trre_amd.TrreError) as e:
+            p.scan(data)
+        assert e.value.code == trre_amd.api.E_DIVERGES and e.value.partial == printed, (pat, name, "host")
+        n += 1
+    assert n >= 13
+    rng = random.Random(77)
+    head = corpus.word_soup(rng, 3 << 20).replace(b"a", b"e")          # no 'a': 'a:*' never enters its cycle here
+    bad = b"cat dog cat xyz cat a cat\n"
+    data = head + bad + corpus.word_soup(rng, 1 << 20) + bad
+    for pat in ("cat:dog|a:*", "cat:doggy|a(:y)*"):
+        want = Oracle(pat, "nft").scan(head) + Oracle(pat, "nft").scan(b"cat dog cat xyz cat \n")[:-1]
+        p = prog(pat, "nft")
+        with pytest.raises(trre_amd.TrreError) as e:
+            gpu_scan(p, data)
+        assert e.value.partial.cpu().numpy().tobytes() == want, pat
+        o_head = Oracle(pat, "nft").scan(head)
+        for kw in ({}, {"device_mask": 0}):
+            with pytest.raises(trre_amd.TrreError) as e:
+                p.scan(data * 12, **kw)                                    # ~50 MiB: the bad line sits in the first chunk of several
+            assert e.value.code == trre_amd.api.E_DIVERGES and e.value.partial == want, (pat, kw)
+            with pytest.raises(trre_amd.TrreError) as e:
+                p.scan(head * 11 + data, **kw)                             # ... and in the second chunk (33 MiB of clean lines first)
+            assert e.value.code == trre_amd.api.E_DIVERGES and e.value.partial == o_head * 11 + want, (pat, kw, "second chunk")
+
+
+def test_stack_limit_is_a_documented_difference():
+    """The reference's backtracking stack holds at most 65 536 live alternatives (trre_nft.c:35-36,548-556): a greedy
+    loop over a run of 65 536 bytes exits 1 ("stack max capacity reached") although the search would succeed.  The GPU
+    path never explores failing alternatives and has no such stack: it prints the match the unbounded search finds.
+    include/trre_mi355x.h documents the difference; this test pins both sides of it."""
+    from oracle_lib import OracleError
+    short, long_ = b"x" + b" " * 65535 + b"y\n", b"x" + b" " * 70000 + b"y\n"
+    o = Oracle(" +: ", "nft")
+    assert o.scan(short) == b"x y\n"
+    with pytest.raises(OracleError):                     # the oracle models the limit (and so does the reference binary)
+        o.scan(long_)
+    p = prog(" +: ", "nft")
+    assert gpu_scan(p, short) == b"x y\n"
+    assert gpu_scan(p, long_) == b"x y\n"               # the documented deviation
+    if ref_available():
+        import subprocess
+        import os
+        from oracle_lib import REF_DIR
+        r = subprocess.run([os.path.join(REF_DIR, "trre"), " +: "], input=long_, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 1 and r.stderr.startswith(b"error: stack max capacity reached")
 
 
 def test_every_kernel_family_agrees_on_gpu():

@@ -29,6 +29,19 @@ def test_oracle_matches_every_golden_vector():
     assert n > 700
 
 
+def test_oracle_keeps_what_the_reference_had_printed_when_it_fails():
+    """an NFT scan that enters an epsilon cycle: the reference exits 1 ("stack max capacity reached") through exit(),
+    which flushes stdout — the lines before the bad one and the bad line up to the attempt that does not return are
+    printed.  The vectors hold that stdout; the oracle's error carries the same bytes."""
+    n = 0
+    for pat, name, data, printed in golden_lib.fail_cases():
+        with pytest.raises(OracleError) as e:
+            Oracle(pat, "nft").scan(data)
+        assert e.value.partial == printed, (pat, name)
+        n += 1
+    assert n >= 13
+
+
 def test_oracle_state_counts():
     # SURVEY.md §8a: NFT sizes of the configuration patterns
     assert Oracle("cat:dog", "nft").nft_states == 7

@@ -36,10 +36,11 @@ class TrreError(RuntimeError):
     """A failed library call; .code is the TRRE_E_* value, .message the
     reference-style 'error: ...' text."""
 
-    def __init__(self, code, message):
+    def __init__(self, code, message, partial=None):
         super().__init__("%s (code %d)" % (message, code))
         self.code = code
         self.message = message
+        self.partial = partial      # E_DIVERGES: what the reference had printed before it failed (bytes / tensor), or None
 
 
 class Info(ctypes.Structure):
@@ -181,6 +182,8 @@ class Program:
             if rc == E_CAPACITY:                       # variable-length output: retry with the size asked for
                 out = torch.empty(m.value + 16, dtype=torch.uint8, device=inp.device)
                 rc = lib().trre_scan_device(self._h, inp.data_ptr(), n, out.data_ptr(), out.numel(), ctypes.byref(m), s)
+        if rc == E_DIVERGES:
+            raise TrreError(rc, lib().trre_last_error().decode("latin-1"), out[:m.value])
         _check(rc)
         return out[:m.value]
 
@@ -211,6 +214,8 @@ class Program:
             if rc == E_CAPACITY:
                 cap = m.value + 64
                 continue
+            if rc == E_DIVERGES:
+                raise TrreError(rc, lib().trre_last_error().decode("latin-1"), out[:m.value].tobytes())
             _check(rc)
             return out[:m.value].tobytes()
         _check(rc)

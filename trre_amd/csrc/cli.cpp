@@ -85,6 +85,12 @@ int main(int argc, char** argv) {
                 out.resize(m + 64);
                 rc = trre_scan_host_multi(prog, in.data(), n, out.data(), out.size(), &m, mask);
             }
+            if (rc == TRRE_E_DIVERGES && m) {
+                // the reference has printed everything up to the attempt it does not come back from (exit() flushes stdout,
+                // trre_nft.c:551-553): so has the library (NFT engine), m bytes
+                (void)std::fwrite(out.data(), 1, m, stdout);
+                std::fflush(stdout);
+            }
             if (rc != TRRE_OK) {
                 std::fprintf(stderr, "%s\n", trre_last_error());
                 return EXIT_FAILURE;

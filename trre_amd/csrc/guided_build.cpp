@@ -172,8 +172,11 @@ private:
                 break;
             }
             const NodeFollow& f = (*cur)[e];
-            if (diverges(f, r)) {    // "error: stack max capacity reached" in the reference
-                c.diverge = true; c.next = 1; c.out.clear();
+            if (diverges(f, r)) {
+                // "error: stack max capacity reached" in the reference, which exits with what it has printed so far: the
+                // outputs of the attempts that ended at this position stay (c.out), nothing of this attempt does (its
+                // bytes would only be printed at FINAL, trre_nft.c:643-645), and the lane is finished (DONE: absorbing)
+                c.diverge = true; c.next = 2;
                 return c;
             }
             if (f.target == kNodeFinal) {
@@ -221,7 +224,7 @@ private:
             return c;
         }
         const NodeFollow& f = list[e];
-        if (diverges(f, r)) { c.diverge = true; c.next = 1; return c; }
+        if (diverges(f, r)) { c.diverge = true; c.next = 2; return c; }      // (nothing of this line is printed; the lane is finished)
         if (!muted) c.out += f.out;
         if (f.target == kNodeFinal) {                                      // (only at the end of the line)
             c.out.push_back('\n');

@@ -525,7 +525,7 @@ int finish(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
         return fail(TRRE_E_CAPACITY, "error: output buffer too small");
     }
     if (was.timed) HIP_TRY(hipEventRecord(cx->ev1, was.stream));
-    HIP_TRY(hipMemcpyAsync(cx->h_status, cx->d_status, 4, hipMemcpyDeviceToHost, was.stream));
+    HIP_TRY(hipMemcpyAsync(cx->h_status, cx->d_status, 8, hipMemcpyDeviceToHost, was.stream));
     if (was.total_at) HIP_TRY(hipMemcpyAsync(cx->h_status + 2, was.total_at, 8, hipMemcpyDeviceToHost, was.stream));
     HIP_TRY(hipStreamSynchronize(was.stream));
     if (was.timed) {
@@ -540,8 +540,36 @@ int finish(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
         if (rc) return rc;
         return finish(p, st, cx, out_len);
     };
-    if (status & kStDiverge)
-        return fail(TRRE_E_DIVERGES, "error: stack max capacity reached (the reference's search does not terminate on this input)");
+    if (status & kStDiverge) {
+        const char* msg = "error: stack max capacity reached (the reference's search does not terminate on this input)";
+        if (out_len) *out_len = 0;
+        // The NFT binary exits with everything it had printed so far (exit() flushes stdout): the lines before the bad one
+        // and the bad line's output up to the attempt that does not return.  The guided tables stop a lane exactly there
+        // (guided_build.cpp), the count pass names the first such lane in stream order and knows every lane's size: the
+        // output up to that point is in the buffer and its length is reported with the error.  (The DFT binary dies of
+        // unbounded recursion, its buffered output is lost: nothing to reproduce, *out_len = 0.)
+        if (p->engine != TRRE_ENGINE_NFT || !p->gt.ok) return fail(TRRE_E_DIVERGES, msg);
+        if (was.family != TRRE_KERNEL_GUIDED_GEN) {
+            const int rc = again(TRRE_KERNEL_GUIDED_GEN);      // (comes back here through the branch below)
+            return rc == TRRE_OK ? fail(TRRE_E_DEVICE, "error: a diverging scan did not diverge when it was run again") : rc;
+        }
+        const uint32_t lane = 0xffffffffu - cx->h_status[1];
+        const int64_t chunk = (int64_t)lane / 256;             // (workspace chunks are 256 lanes: ensure_workspace)
+        std::vector<uint32_t> counts(256);
+        uint64_t base = 0, chunk_total = 0;
+        HIP_TRY(hipMemcpyAsync(counts.data(), cx->d_lane_counts + chunk * 256, 256 * 4, hipMemcpyDeviceToHost, was.stream));
+        HIP_TRY(hipMemcpyAsync(&base, cx->d_chunk_base + chunk, 8, hipMemcpyDeviceToHost, was.stream));
+        HIP_TRY(hipMemcpyAsync(&chunk_total, cx->d_chunk_total + chunk, 8, hipMemcpyDeviceToHost, was.stream));
+        HIP_TRY(hipStreamSynchronize(was.stream));
+        uint64_t upto = base;
+        for (uint32_t k = 0; k <= lane % 256; ++k) upto += counts[k];
+        if (base + chunk_total > was.cap) {                    // the emit pass skipped this chunk: ask for room, the retry reports
+            if (out_len) *out_len = (size_t)(base + chunk_total);
+            return fail(TRRE_E_CAPACITY, "error: output buffer too small");
+        }
+        if (out_len) *out_len = (size_t)upto;
+        return fail(TRRE_E_DIVERGES, msg);
+    }
     if (status & kStNeedScratch) {
         // a line longer than the LDS tile met the non-deterministic engine: give it
         // a mask scratch (one mask per input byte) and run again
@@ -873,6 +901,8 @@ int scan_host_on(trre_prog* p, DeviceState* st, const uint8_t* in, size_t n, uin
     size_t off = 0, total = 0;                        // input consumed, output produced (or needed)
     size_t total_bound = 0;                           // length-preserving: output of everything submitted so far
     bool overflow = false;                            // the caller's buffer is too small: keep counting only
+    bool diverged = false;                            // a chunk reported TRRE_E_DIVERGES: its partial output is the last thing that counts
+    std::string diverge_msg;
     int rc = TRRE_OK;
     auto abandon = [&](int code) -> int {             // leave nothing queued behind an error
         for (auto& hs : st->slot) { (void)hipStreamSynchronize(hs.stream); hs.ctx.pend = Pending(); }
@@ -914,7 +944,13 @@ int scan_host_on(trre_prog* p, DeviceState* st, const uint8_t* in, size_t n, uin
             if (!r) r = finish(p, st, &hs.ctx, &m);
             again = true;
         }
-        if (r) return r;
+        if (r == TRRE_E_DIVERGES) {                   // the reference stops inside this chunk: what it had printed (m bytes) still counts
+            diverged = true;
+            diverge_msg = g_error;
+            again = true;
+        } else if (r) {
+            return r;
+        }
         ch[b].m = m;
         ch[b].out_at = total;
         if (!overflow && total + m > cap) overflow = true;
@@ -965,6 +1001,16 @@ int scan_host_on(trre_prog* p, DeviceState* st, const uint8_t* in, size_t n, uin
             if (ch[b1].submitted) { rc = complete(b1); if (rc) return abandon(rc); }
             rc = drain(b1);
             if (rc) return abandon(rc);
+            if (diverged) {
+                // nothing after the diverging chunk counts: the chunk submitted in this iteration is dropped
+                off = n;
+                for (int b = 0; b < kHostSlots; ++b)
+                    if (ch[b].submitted) {
+                        (void)hipStreamSynchronize(st->slot[b].stream);
+                        st->slot[b].ctx.pend = Pending();
+                        ch[b].submitted = false;
+                    }
+            }
         }
         if (!more) {
             bool busy = false;
@@ -975,6 +1021,7 @@ int scan_host_on(trre_prog* p, DeviceState* st, const uint8_t* in, size_t n, uin
     for (int b = 0; b < kHostSlots; ++b) settle(b);
     if (out_len) *out_len = total;
     if (overflow) return fail(TRRE_E_CAPACITY, "error: output buffer too small");
+    if (diverged) return fail(TRRE_E_DIVERGES, diverge_msg);
     return TRRE_OK;
 }
 
@@ -1071,7 +1118,9 @@ int trre_scan_host_multi(trre_prog* p, const uint8_t* in, size_t n, uint8_t* out
     for (auto& t : th) t.join();
     size_t total = 0;
     bool short_cap = false;
+    int last = G, diverged_at = -1;                   // shards [0, last) count; a shard on which the reference stops is the last one
     for (int g = 0; g < G; ++g) {
+        if (sh[g].rc == TRRE_E_DIVERGES) { diverged_at = g; last = g + 1; total += sh[g].m; break; }
         if (sh[g].rc && sh[g].rc != TRRE_E_CAPACITY) return fail(sh[g].rc, sh[g].err);
         if (sh[g].rc == TRRE_E_CAPACITY) short_cap = true;
         total += sh[g].m;
@@ -1080,11 +1129,12 @@ int trre_scan_host_multi(trre_prog* p, const uint8_t* in, size_t n, uint8_t* out
     if (short_cap || total > cap) return fail(TRRE_E_CAPACITY, "error: output buffer too small");   // (short_cap: a size query, cap == 0)
     // move the shards into place, in order (a direct shard that came out shorter — NUL bytes — moves down)
     size_t at = 0;
-    for (int g = 0; g < G; ++g) {
+    for (int g = 0; g < last; ++g) {
         const uint8_t* src = sh[g].own ? sh[g].buf.data() : out + bounds[g];
         if (sh[g].m && src != out + at) std::memmove(out + at, src, sh[g].m);
         at += sh[g].m;
     }
+    if (diverged_at >= 0) return fail(TRRE_E_DIVERGES, sh[diverged_at].err);
     return TRRE_OK;
 }
 

@@ -411,6 +411,9 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_direct(ScanArgs a, in
     }
     uint32_t* wsc = reinterpret_cast<uint32_t*>(smem + kLds - kDirectWsc + (threadIdx.x / kWave) * kWaveScratchBytes);
     stream_direct_lane<kMode, false, kSym>(a, T, n_cls, lane, lane_bytes, ring, base, L, st, kMode == 2 ? wsc : nullptr);
+    // the first lane (in stream order) on which the reference's search does not return: everything up to the point where
+    // it stopped is what the reference had printed (status[1] = ~lane, the launch zeroes it)
+    if (kMode == 1 && kSym && (st & kStDiverge)) atomicMax(a.status + 1, 0xffffffffu - (uint32_t)lane);
     if (kMode == 1) {
         uint64_t* part = reinterpret_cast<uint64_t*>(smem + kLds - kDirectWsc - 64);
         if (L.count > 0xffffffffull) { st |= kStCapacity; L.count = 0xffffffffull; }
@@ -486,6 +489,7 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_g16(ScanArgs a, int64
     }
     uint32_t* wsc = reinterpret_cast<uint32_t*>(tail + 64) + (threadIdx.x / kWave) * (kWaveScratchBytes / 4);
     g16_lane<kMode, kSym, kHasSlow>(a, T, h.n_cls, lane, lane_bytes, ring, base, L, st, kMode == 2 ? wsc : nullptr);
+    if (kMode == 1 && kSym != 0 && (st & kStDiverge)) atomicMax(a.status + 1, 0xffffffffu - (uint32_t)lane);     // (see k_stream_direct)
     if (kMode == 1) {
         uint64_t* part = reinterpret_cast<uint64_t*>(tail);
         if (L.count > 0xffffffffull) { st |= kStCapacity; L.count = 0xffffffffull; }
