@@ -37,8 +37,17 @@ extern "C" {
 #define TRRE_MODE_SCAN 0  /* default: every line is scanned for matches, the rest is copied (trre_nft.c:775-790) */
 #define TRRE_MODE_MATCH 1 /* `trre -m`: the whole line must match; its output and '\n' are printed, a line that does not
                              match prints nothing (trre_nft.c:791-797, 635-642).  NFT engine only: the reference's
-                             trre_dft -m prints an empty line per record (its emit is commented out, trre_dft.c:1185-1190)
-                             and `-a` (all outputs of all paths) is a CPU feature of the reference, not offered here. */
+                             trre_dft -m prints an empty line per record (its emit is commented out, trre_dft.c:1185-1190) */
+#define TRRE_MODE_SCAN_ALL 2  /* `trre -a` (generator mode, trre_nft.c:736-738 with 647-648): at every position of a line the
+                                 outputs of ALL accepting paths that start there are printed, in the search's depth-first
+                                 priority order, then that position's raw byte (no attempt returns a match: trre_nft.c:780-786) */
+#define TRRE_MODE_MATCH_ALL 3 /* `trre -ma` (what the reference's own test.sh runs, test.sh:4): one output + '\n' per path
+                                 that accepts at the end of the line (trre_nft.c:635-642).
+                                 Both generator modes: NFT engine only (trre_dft -a prints "Not supported yet",
+                                 trre_dft.c:1227-1229).  The amount of output is unbounded in the input; the device computes
+                                 the viability filter (one symbol per input byte: which nodes have an accepting or a
+                                 non-terminating continuation), the accepting paths are enumerated on host threads from the
+                                 device's symbols (trre_amd/csrc/generate.cpp). */
 
 /* return codes */
 #define TRRE_OK 0
@@ -68,6 +77,8 @@ extern "C" {
 #define TRRE_KERNEL_STREAM_GEN 5 /* scan loop folded into the tables, any output length: count + scan + emit */
 #define TRRE_KERNEL_GUIDED_LP 6  /* NFT engine, any pattern: backward DFA sweep (one symbol per byte) + guided forward transducer, in place */
 #define TRRE_KERNEL_GUIDED_GEN 7 /* the same, any output length: backward sweep, count + scan + emit */
+
+#define TRRE_KERNEL_GENERATE 8    /* generator modes: backward viability sweep on the device, enumeration on the host */
 
 typedef struct trre_prog trre_prog;
 
@@ -150,6 +161,11 @@ int trre_scan_host_multi(trre_prog* p, const uint8_t* in, size_t n, uint8_t* out
  * the launch stream around the scan kernels).  Enable first. */
 int trre_set_profiling(trre_prog* p, int on);
 int trre_last_kernel_ms(trre_prog* p, float* ms);
+
+/* Diagnostics / CPU test tier: the enumeration of the generator modes with viability symbols computed elsewhere (sym[i] for
+ * byte i; tests/cpu_shim.cpp runs the backward kernel's per-thread body on the host).  Host-only, no device involved; not a
+ * replacement for trre_scan_host, which computes the symbols on the GPU. */
+int trre_debug_generate(trre_prog* p, const uint8_t* in, size_t n, const uint8_t* sym, uint8_t* out, size_t cap, size_t* out_len);
 
 /* Line sharding (multi-GPU, trre has no exchange step: lines are independent).
  * Fills bounds[0..nshards] with byte offsets such that every shard but the

@@ -111,6 +111,7 @@ struct trre_oracle_prog {
     struct bt_item { int s; size_t i, o; } *bt; size_t nbt, cbt;
     bvec attempt_out;          /* the global `output`, nft.c:44-45              */
     bvec scan_out;             /* whole-buffer output under construction        */
+    int all;                   /* `-a`: every accepting path prints (generator mode, NFT engine) */
     /* lazy DFT */
     dstate **ds; int nds, cds;
     int buckets[ORC_HASH_BUCKETS];
@@ -526,12 +527,16 @@ static void bt_push(P *p, int s, size_t i, size_t o)
 static long nft_attempt_mode(P *p, const unsigned char *in, size_t len, bvec *dst, int match);
 static long nft_attempt(P *p, const unsigned char *in, size_t len, bvec *dst)
 {
-    return nft_attempt_mode(p, in, len, dst, 0);
+    return nft_attempt_mode(p, in, len, dst, p->all ? 2 : 0);
 }
-/* match = 1: `trre -m`, nft.c:635-642 — FINAL accepts only with the whole line consumed (the output is followed by
- * '\n'); anywhere else the search goes on with the next alternative. */
+/* match bit 0: `trre -m`, nft.c:635-642 — FINAL accepts only with the whole line consumed (the output is followed by
+ * '\n'); anywhere else the search goes on with the next alternative.
+ * match bit 1: `-a` (generator mode, nft.c:640-641,647-648: `if (!all) return i;`) — the search does not stop at an
+ * accepting path: every one prints its output, in depth-first priority order, and the attempt returns -1. */
 static long nft_attempt_mode(P *p, const unsigned char *in, size_t len, bvec *dst, int match)
 {
+    const int all = match & 2;
+    match &= 1;
     size_t i = 0, o = 0;
     int s = p->start;
     bvec *out = &p->attempt_out;
@@ -567,7 +572,9 @@ static long nft_attempt_mode(P *p, const unsigned char *in, size_t len, bvec *ds
             while (k < o && out->b[k]) k++;
             bv_append(dst, out->b, k);
             if (match) bv_push(dst, '\n');
-            return (long)i;
+            if (!all) return (long)i;
+            s = -1;                                    /* nft.c:650: on to the next alternative */
+            break;
         }
         }
     }
@@ -879,12 +886,21 @@ int trre_oracle_match(trre_oracle_prog *p, const uint8_t *in, size_t n, uint8_t 
         size_t len = reclen - 1;                       /* line[read-1] = '\0', nft.c:793 */
         const unsigned char *z = memchr(in + pos, 0, len);
         if (z) len = (size_t)(z - (in + pos));
-        nft_attempt_mode(p, in + pos, len, dst, 1);
+        nft_attempt_mode(p, in + pos, len, dst, p->all ? 3 : 1);
         pos += reclen;
     }
     *out = dst->b;
     *m = dst->n;
     dst->b = NULL; dst->n = dst->cap = 0;
+    return ORC_OK;
+}
+
+/* `-a` (nft.c:736-738): the following scans / matches print the output of EVERY accepting path.  NFT engine only
+ * (trre_dft -a prints "Not supported yet", dft.c:1227-1229). */
+int trre_oracle_set_all(trre_oracle_prog *p, int all)
+{
+    if (p->engine != TRRE_ORACLE_NFT) return ORC_E_SYNTAX;
+    p->all = all != 0;
     return ORC_OK;
 }
 

@@ -47,6 +47,11 @@ int trre_oracle_scan(trre_oracle_prog *p, const uint8_t *in, size_t n,
  * NFT engine only. */
 int trre_oracle_match(trre_oracle_prog *p, const uint8_t *in, size_t n, uint8_t **out, size_t *m);
 
+/* `trre -a` / `trre -ma` (generator mode, trre_nft.c:736-738 with 640-641, 647-648): after this call
+ * trre_oracle_scan / trre_oracle_match print the output of EVERY accepting path, in the search's depth-first
+ * priority order (scan mode: all outputs of the attempt at a position, then that position's raw byte).  NFT engine only. */
+int trre_oracle_set_all(trre_oracle_prog *p, int all);
+
 /* Line-sharded scan over `threads` host threads (input split at '\n'
  * boundaries, outputs concatenated in order).  Each thread compiles its own
  * program because the lazily grown DFT cache is not thread-safe. */

@@ -43,6 +43,13 @@ REF_M_CASES = [
 MATCH_PATTERNS = ["(cat:dog|dog:cat| |[a-z]|[A-Z]|.)*", ".*(cat:dog).*", "(.:x)*?.*", "[a-z ]*", "(a:x|b|c:|d:yy| )*", ".*", "a:*",
                   "([a-z]:W| :_)*", "\xe9*.*:!"]
 
+# generator mode (`-a`): patterns with several parses.  Whole-line (`-ma`) and scan (`-a`) sets; inputs are short (see
+# make_golden.py) because the number of outputs multiplies with every ambiguity.
+GEN_MATCH_PATTERNS = ["(a|a:x)*", "(a:x|a:y|b)*", "a*a*", "(:x|:y)(a|b)*", "(a|ab)(b|:z)*", ".*", "(.:x)*?.*", "(cat:dog|cat:cow|.)*",
+                      "(:a){,2}(:b)?[a-z ]*", "a{,2}a{,2}", "a:*", "(ab|a)(b|:q)|a.?"]
+GEN_SCAN_PATTERNS = ["a*", "(a:x|a:y)", "(cat:dog|cat:cow|ca:C)", ":=", "(a|ab)(b|:z)", "[ab]+:N", "(:x|:y)a", "a:*", "a??b?:(1|2)",
+                     "b*c?"]
+
 # --- README examples with a stated result (README.md:39-44,57-62,123-128,180-203) ---------
 README_CASES = [
     ("cat", "cat:dog", "dog"),

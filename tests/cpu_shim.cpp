@@ -522,4 +522,24 @@ int shim_scan_guided(const uint8_t* rblob, const uint8_t* gblob, int family, int
     return 0;
 }
 
+// The backward pass alone (k_rev_sweep's per-thread body): one symbol per input byte into sym_out[0, n).  Used for the
+// guided families' symbols and for the viability symbols of the generator modes (generate.cpp).
+int shim_rev_sweep(const uint8_t* rblob, int geo, const uint8_t* in, size_t n, int in_mis, uint8_t* sym_out) {
+    if (n == 0) return 0;
+    std::vector<uint8_t> ibuf(n + 64, 0xAA);
+    uint8_t* ia = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(ibuf.data()) + 15) & ~(uintptr_t)15) + in_mis;
+    std::memcpy(ia, in, n);
+    ScanArgs a{};
+    const int64_t al = (int64_t)(reinterpret_cast<uintptr_t>(ia) & 15u);
+    a.in_v0 = ia - al;
+    a.vbeg = al;
+    a.vend = al + (int64_t)n;
+    a.rblob = rblob;
+    std::vector<uint8_t> sym(n + 512, 0xDD);
+    a.sym_v0 = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(sym.data()) + 63) & ~(uintptr_t)63);
+    run_rev_sweep(a, geo == 0 ? 2048 : 128, false);
+    std::memcpy(sym_out, a.sym_v0 + al, n);
+    return 0;
+}
+
 }  // extern "C"

@@ -29,6 +29,10 @@ def enc(b):
     return base64.b64encode(zlib.compress(b, 9)).decode("ascii")
 
 
+def dec_(s):
+    return zlib.decompress(base64.b64decode(s)) if s != "fail" else b""
+
+
 def run_ref_full(engine, pattern, path, flags=()):
     """(exit status or None on a timeout, stdout, stderr)"""
     binary = os.path.join(REF_DIR, "trre" if engine == "nft" else "trre_dft")
@@ -147,15 +151,47 @@ def main():
             for name in ("words", "many_short", "embedded_nul", "no_trailing_newline", "only_newlines", "empty", "abcd_soup", "eps_with_a"):
                 got = run_ref("nft", pat, paths[name], ["-m"])
                 match_cases.append({"pattern": pat, "input": name, "nft_m": "fail" if got is None else enc(got)})
+        # 5. generator mode (`-a`: every accepting path prints, trre_nft.c:640-641,647-648): the reference's own match
+        #    table with the command line its test.sh uses (`./trre -ma`, test.sh:4) — ALL outputs of all 51 rows —, whole-line
+        #    patterns with several parses on multi-line inputs, and scan mode with -a (all outputs of the attempt at every
+        #    position, then that position's raw byte) on short inputs.  Outputs grow fast (every start position, every
+        #    parse): inputs are kept small; runs the reference does not finish in 20 s or that exit non-zero are "fail"
+        #    with what they had printed (exit() flushes).
+        inputs.update({"gen_lines": b"a\nab\naab\n\nabab\ncat\nb\n", "gen_text": b"cat dog\nthe cat sat\n\naaa\nabcabc",
+                       "gen_nul": b"ab\0ab\nba\n"})
+        for name in ("gen_lines", "gen_text", "gen_nul"):
+            paths[name] = os.path.join(td, name)
+            with open(paths[name], "wb") as f:
+                f.write(inputs[name])
+        all_cases = []
+
+        def add_all(pat, name, flags):
+            rc, got, err = run_ref_full("nft", pat, paths[name], flags)
+            rec = {"pattern": pat, "input": name, "flags": "".join(flags), "out": enc(got) if rc == 0 else "fail"}
+            if rc == 1 and err.startswith(b"error: stack max capacity reached"):
+                rec["fail_stdout"] = enc(got)
+            all_cases.append(rec)
+
+        for k, (inp, pat, first) in enumerate(corpus.REF_M_CASES):
+            add_all(pat, "refm_%02d" % k, ["-ma"])
+            got = dec_(all_cases[-1]["out"])
+            assert (got.split(b"\n")[0] if got else None) == (first.encode("latin-1") if first is not None else None), (inp, pat, got)
+        for pat in corpus.GEN_MATCH_PATTERNS:
+            for name in ("gen_lines", "gen_text", "gen_nul", "many_short", "only_newlines", "empty", "eps_with_a"):
+                add_all(pat, name, ["-ma"])
+        for pat in corpus.GEN_SCAN_PATTERNS:
+            for name in ("gen_lines", "gen_text", "gen_nul", "no_trailing_newline", "only_newlines", "empty", "eps_with_a"):
+                add_all(pat, name, ["-a"])
     doc = {"about": "scan-mode (and `-m`) outputs of the compiled reference (c0stya/trre @ 2025-05-23), see make_golden.py",
-           "inputs": {k: enc(v) for k, v in inputs.items()}, "cases": out_cases, "match_cases": match_cases}
+           "inputs": {k: enc(v) for k, v in inputs.items()}, "cases": out_cases, "match_cases": match_cases, "all_cases": all_cases}
     os.makedirs(os.path.join(HERE, "golden"), exist_ok=True)
     path = os.path.join(HERE, "golden", "golden.json")
     with open(path, "w") as f:
         json.dump(doc, f, indent=0, sort_keys=True)
     nfail = sum(1 for c in out_cases for e in ("nft", "dft") if c[e] == "fail")
-    print("wrote %s: %d inputs, %d cases (%d reference failures), %d bytes"
-          % (path, len(inputs), len(out_cases), nfail, os.path.getsize(path)))
+    print("wrote %s: %d inputs, %d cases (%d reference failures), %d match cases, %d generator-mode cases (%d failures), %d bytes"
+          % (path, len(inputs), len(out_cases), nfail, len(match_cases), len(all_cases), sum(1 for c in all_cases if c["out"] == "fail"),
+             os.path.getsize(path)))
 
 
 if __name__ == "__main__":

@@ -52,6 +52,7 @@ def lib():
         L.trre_oracle_scan_mt.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p,
                                           ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p),
                                           ctypes.POINTER(ctypes.c_size_t)]
+        L.trre_oracle_set_all.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.trre_oracle_release.argtypes = [ctypes.c_void_p]
         L.trre_oracle_release.restype = None
         L.trre_oracle_free.argtypes = [ctypes.c_void_p]
@@ -69,7 +70,8 @@ def _as_bytes(x):
 class Oracle:
     """One compiled pattern.  engine: 'nft' (./trre) or 'dft' (./trre_dft)."""
 
-    def __init__(self, pattern, engine="nft"):
+    def __init__(self, pattern, engine="nft", all_outputs=False):
+        """all_outputs: `-a`, generator mode — scan() / match() print the output of every accepting path"""
         self.pattern = _as_bytes(pattern)
         self.engine = ENGINES[engine]
         self._h = ctypes.c_void_p()
@@ -78,6 +80,8 @@ class Oracle:
         if rc:
             self._h = None
             raise OracleError(rc, err.value.decode("latin-1"))
+        if all_outputs and lib().trre_oracle_set_all(self._h, 1):
+            raise OracleError(-1, "generator mode is an NFT feature")
 
     def scan(self, data):
         data = _as_bytes(data)

@@ -35,6 +35,7 @@ def lib():
         L.shim_scan_guided.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p,
                                        ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
                                        ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_uint32)]
+        L.shim_rev_sweep.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_char_p]
         _lib = L
     return _lib
 
@@ -132,3 +133,20 @@ def scan_like_runtime(prog, data, geo=1, family=None, in_mis=0, out_mis=0):
         out, st = shim_scan(blob, info.engine, gen, data, geo, in_mis, out_mis)
         assert not st & ST_MISMATCH
     return out
+
+
+def rev_symbols(rblob, data, geo=1, in_mis=0):
+    """the backward pass on the host: one symbol per byte of `data`"""
+    out = ctypes.create_string_buffer(max(len(data), 1))
+    rc = lib().shim_rev_sweep(rblob, geo, data, len(data), in_mis, out)
+    if rc:
+        raise RuntimeError("shim rc %d" % rc)
+    return out.raw[:len(data)]
+
+
+def generate_like_runtime(prog, data, geo=1, in_mis=0):
+    """generator modes as the runtime runs them: viability symbols from the backward kernel's body (here on the host), then
+    the library's own enumeration (generate.cpp)"""
+    rblob, _ = prog.export_guided_tables()
+    assert rblob
+    return prog.generate_with_symbols(data, rev_symbols(rblob, data, geo, in_mis))

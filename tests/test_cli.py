@@ -46,11 +46,15 @@ def test_cli_errors_match_the_reference(eng):
 
 @pytest.mark.parametrize("eng", ["nft", "dft"])
 def test_cli_refuses_the_cpu_only_modes(eng):
-    """-d / -a (and trre_dft's -m, which only prints empty lines in the reference) are CPU features of the reference,
-    not GPU paths: refused, status 1, nothing on stdout"""
-    for flag in ("-d", "-a") + (("-m",) if eng == "dft" else ()):
+    """-d (Graphviz dumps) and trre_dft's -m (which only prints empty lines in the reference) are CPU features of the
+    reference, not GPU paths: refused, status 1, nothing on stdout.  trre_dft -a answers like the reference."""
+    for flag in ("-d",) + (("-m",) if eng == "dft" else ()):
         rc, out, err = run(BIN[eng], [flag, "a"])
         assert rc == 1 and out == b"" and err.startswith(b"error: " + flag.encode()), (eng, flag, err)
+    if eng == "dft":
+        assert run(BIN[eng], ["-a", "a"]) == (1, b"", b"Not supported yet\n")        # trre_dft.c:1227-1229
+        if ref_available():
+            assert run(REF[eng], ["-a", "a"]) == (1, b"", b"Not supported yet\n")
 
 
 @pytest.mark.gpu

@@ -18,13 +18,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TRRE_LIB_PATH") or os.path.join(_HERE, "lib", "libtrre_mi355x.so")   # override: A/B builds only
 
 ENGINE_NFT, ENGINE_DFT = 0, 1
-MODE_SCAN, MODE_MATCH = 0, 1
+MODE_SCAN, MODE_MATCH, MODE_SCAN_ALL, MODE_MATCH_ALL = 0, 1, 2, 3
 _ENGINES = {"nft": ENGINE_NFT, "dft": ENGINE_DFT, ENGINE_NFT: ENGINE_NFT, ENGINE_DFT: ENGINE_DFT}
 
 KERNEL_AUTO, KERNEL_BYTEMAP, KERNEL_TILE_LP, KERNEL_TILE_GEN, KERNEL_STREAM_LP, KERNEL_STREAM_GEN = 0, 1, 2, 3, 4, 5
 KERNEL_GUIDED_LP, KERNEL_GUIDED_GEN = 6, 7
+KERNEL_GENERATE = 8
 KERNEL_NAMES = {0: "auto", 1: "bytemap", 2: "tile_lp", 3: "tile_gen", 4: "stream_lp", 5: "stream_gen", 6: "guided_lp",
-                7: "guided_gen"}
+                7: "guided_gen", 8: "generate"}
 
 FLAG_LENGTH_PRESERVING, FLAG_MEMORYLESS, FLAG_NO_OVERRUN = 1, 2, 4
 
@@ -95,6 +96,7 @@ def lib():
         L.trre_scan_host_multi.argtypes = [vp, ctypes.c_char_p, sz, vp, sz, ctypes.POINTER(sz), ctypes.c_uint32]
         L.trre_set_profiling.argtypes = [vp, ctypes.c_int]
         L.trre_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+        L.trre_debug_generate.argtypes = [vp, ctypes.c_char_p, sz, ctypes.c_char_p, vp, sz, ctypes.POINTER(sz)]
         L.trre_shard_bounds.argtypes = [ctypes.c_char_p, sz, ctypes.c_int, ctypes.POINTER(sz)]
         _lib = L
     return _lib
@@ -113,10 +115,11 @@ class Program:
     """A compiled pattern bound to one engine."""
 
     def __init__(self, pattern, engine="nft", mode="scan"):
-        """mode "scan" (default) or "match" (`trre -m`: whole-line matches only, NFT engine)"""
+        """mode "scan" (default), "match" (`trre -m`: whole-line matches only, NFT engine), "scan_all" (`trre -a`) or
+        "match_all" (`trre -ma`): generator modes, every accepting path prints (NFT engine)"""
         self.pattern = _bytes(pattern)
         self.engine = _ENGINES[engine]
-        self.mode = {"scan": MODE_SCAN, "match": MODE_MATCH, MODE_SCAN: MODE_SCAN, MODE_MATCH: MODE_MATCH}[mode]
+        self.mode = {"scan": MODE_SCAN, "match": MODE_MATCH, "scan_all": MODE_SCAN_ALL, "match_all": MODE_MATCH_ALL}.get(mode, mode)
         self._h = ctypes.c_void_p()
         _check(lib().trre_compile_mode(self.pattern, len(self.pattern), self.engine, self.mode, ctypes.byref(self._h)))
 
@@ -211,6 +214,24 @@ class Program:
             else:
                 rc = lib().trre_scan_host_multi(self._h, data, len(data), out.ctypes.data_as(ctypes.c_char_p), cap, ctypes.byref(m),
                                                 device_mask)
+            if rc == E_CAPACITY:
+                cap = m.value + 64
+                continue
+            if rc == E_DIVERGES:
+                raise TrreError(rc, lib().trre_last_error().decode("latin-1"), out[:m.value].tobytes())
+            _check(rc)
+            return out[:m.value].tobytes()
+        _check(rc)
+
+    def generate_with_symbols(self, data, sym):
+        """generator modes, host only (CPU test tier): the enumeration with viability symbols computed elsewhere"""
+        import numpy as np
+        data, sym = _bytes(data), _bytes(sym)
+        cap = 1 << 16
+        for _ in range(2):
+            out = np.empty(cap, dtype=np.uint8)
+            m = ctypes.c_size_t()
+            rc = lib().trre_debug_generate(self._h, data, len(data), sym, out.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(m))
             if rc == E_CAPACITY:
                 cap = m.value + 64
                 continue

@@ -3,10 +3,11 @@
 // Same command line as the reference (trre_nft.c:728-773, trre_dft.c:1217-1270,
 // trre.1:8-28): `trre [-d] [-m] [-a] PATTERN [FILE]`, FILE defaults to stdin,
 // errors go to stderr as "error: ..." with exit status 1.  Scan mode (the GPU
-// hot path) and, for the NFT engine, `-m` (whole-line match, first output: trre_nft.c:791-797) run
-// here; -a (all outputs), -d (debug dumps) and trre_dft's -m (which only prints empty lines,
-// trre_dft.c:1185-1190) belong to the reference's CPU binaries and are refused rather than emulated
-// on the host.
+// hot path) and, for the NFT engine, `-m` (whole-line match, first output: trre_nft.c:791-797) and the
+// generator modes `-a` / `-ma` (every accepting path prints: trre_nft.c:640-641,647-648) run here; -d
+// (Graphviz dumps) and trre_dft's -m (which only prints empty lines, trre_dft.c:1185-1190) belong to the
+// reference's CPU binaries and are refused rather than emulated; trre_dft -a answers "Not supported
+// yet" like the reference (trre_dft.c:1227-1229).
 //
 // Like the reference's getline loop the input is streamed: it is read in blocks
 // of up to 256 MiB, every block is cut after its last '\n' (the rest is carried
@@ -28,14 +29,19 @@
 
 int main(int argc, char** argv) {
     int opt;
-    int mode = TRRE_MODE_SCAN;
+    bool match = false, all = false;
     while ((opt = getopt(argc, argv, "dma")) != -1) {
         switch (opt) {
         case 'm':
-            if (TRRE_CLI_ENGINE == TRRE_ENGINE_NFT) { mode = TRRE_MODE_MATCH; break; }
-            /* fall through */
-        case 'd': case 'a':
-            std::fprintf(stderr, "error: -%c is not part of the GPU scan path; use the reference binary for it\n", opt);
+            if (TRRE_CLI_ENGINE == TRRE_ENGINE_NFT) { match = true; break; }
+            std::fprintf(stderr, "error: -m is not part of the GPU scan path; use the reference binary for it\n");
+            return EXIT_FAILURE;
+        case 'a':
+            if (TRRE_CLI_ENGINE == TRRE_ENGINE_NFT) { all = true; break; }
+            std::fprintf(stderr, "Not supported yet\n");               // trre_dft.c:1227-1229
+            return EXIT_FAILURE;
+        case 'd':
+            std::fprintf(stderr, "error: -d is not part of the GPU scan path; use the reference binary for it\n");
             return EXIT_FAILURE;
         default:
             std::fprintf(stderr, TRRE_CLI_ENGINE == TRRE_ENGINE_NFT ? "Usage: %s [-d] [-m] expr [file]\n"
@@ -43,6 +49,7 @@ int main(int argc, char** argv) {
             return EXIT_FAILURE;
         }
     }
+    const int mode = all ? (match ? TRRE_MODE_MATCH_ALL : TRRE_MODE_SCAN_ALL) : (match ? TRRE_MODE_MATCH : TRRE_MODE_SCAN);
     if (optind >= argc) {
         std::fprintf(stderr, "error: missing trre expression\n");
         return EXIT_FAILURE;

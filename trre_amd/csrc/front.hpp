@@ -259,7 +259,9 @@ struct NftNodes {
 // match_mode (trre -m): FINAL accepts only at the end of the line and the search goes on past it otherwise
 // (trre_nft.c:635-642), so a list does not stop at its first FINAL (it still holds FINAL at most once: the first
 // occurrence in search order is the one that accepts).
-NftNodes build_nft_nodes(const Nft& nft, bool match_mode = false);
+// all_paths (generator mode, `-a`): EVERY epsilon path is listed, in search order, nothing is deduplicated and the list goes
+// on past FINAL — each occurrence is a path of its own that prints its own output (trre_nft.c:640-641,647-648).
+NftNodes build_nft_nodes(const Nft& nft, bool match_mode = false, bool all_paths = false);
 // the scan loop folded over the follow lists (stream_build.cpp: NodeModel) — same tables as build_stream_nft, built faster
 StreamTables build_stream_nodes(const NftNodes& nodes, const StreamLimits& lim = StreamLimits());
 
@@ -312,5 +314,24 @@ struct GuidedTables {
 // byte, accepted only if it ends exactly at the end of the line; an accepted line prints its output and '\n', a
 // rejected one prints nothing.
 GuidedTables build_guided_nft(const NftNodes& nodes, const GuidedLimits& lim = GuidedLimits());
+
+// Generator mode (`trre -a` / `trre -ma`): generate.cpp.  The backward DFA (one symbol per input byte, computed on the
+// device by the guided families' backward kernel) says which nodes are worth entering — SOME path accepts, or SOME path
+// runs into an epsilon cycle —, the enumeration of the accepting paths over the un-deduplicated follow lists runs on the host.
+struct GenTables {
+    bool ok = false;
+    bool match_mode = false;
+    NftNodes nodes;                           // follow lists with every epsilon path
+    uint32_t n_rev = 0, n_cls = 0;            // backward DFA: states (= symbols; 0 dead, 1 at '\n', 2 at a NUL) x byte classes
+    std::array<uint8_t, 256> cls{};
+    std::vector<uint8_t> rev;                 // [n_rev][n_cls]
+    uint32_t viable_words = 0;
+    std::vector<uint64_t> viable;             // [n_rev][viable_words]: bit t = node t is worth entering at a position with this symbol
+};
+GenTables build_gen_tables(const Nft& nft, bool match_mode);
+// in[0, n): the whole buffer (records end at '\n'; the last byte of the buffer ends its record whatever it is, trre_nft.c:777);
+// sym[i]: the backward pass's symbol of byte i.  Appends what the reference prints; false: a path ran into an epsilon cycle
+// (the reference exits 1 there, `out` holds what it had printed).
+bool generate_buffer(const GenTables& g, const uint8_t* in, size_t n, const uint8_t* sym, std::vector<uint8_t>& out, int threads);
 
 }  // namespace trre

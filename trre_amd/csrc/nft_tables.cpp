@@ -21,7 +21,7 @@
 
 namespace trre {
 
-NftNodes build_nft_nodes(const Nft& nft, bool match_mode) {
+NftNodes build_nft_nodes(const Nft& nft, bool match_mode, bool all_paths) {
     NftNodes t;
     t.match_mode = match_mode;
     t.n_states = (uint32_t)nft.st.size();
@@ -59,6 +59,7 @@ NftNodes build_nft_nodes(const Nft& nft, bool match_mode) {
     const uint32_t n_nodes = (uint32_t)t.node.size();
 
     std::vector<uint8_t> on_path(nft.st.size(), 0);
+    size_t n_entries = 0;
     auto list_for = [&](int32_t from_state, std::vector<NodeFollow>& list) {
         // depth-first, priority order, first occurrence of each target wins,
         // stop at FINAL or when an epsilon cycle closes
@@ -70,14 +71,15 @@ NftNodes build_nft_nodes(const Nft& nft, bool match_mode) {
                 const NState& st = nft.st[s];
                 if (node_of[s] >= 0 || st.kind == NKind::Final) {
                     const bool fin = st.kind == NKind::Final;
-                    if (fin ? !seen_final : !seen[node_of[s]]) {
+                    if (all_paths || (fin ? !seen_final : !seen[node_of[s]])) {
                         NodeFollow f;
                         f.target = fin ? kNodeFinal : (uint32_t)node_of[s];
                         const size_t nul = out.find('\0');
                         f.out = nul == std::string::npos ? out : out.substr(0, nul);
                         f.mute = nul != std::string::npos;
                         list.push_back(std::move(f));
-                        if (fin) { seen_final = true; if (!match_mode) done = true; }   // scan mode: FINAL always accepts
+                        if (all_paths && ++n_entries > (4u << 20)) throw Error(kErrTooBig, "error: too many epsilon paths for generator mode");
+                        if (fin) { seen_final = true; if (!match_mode && !all_paths) done = true; }   // scan mode: FINAL always accepts
                         else seen[node_of[s]] = 1;
                     }
                     break;

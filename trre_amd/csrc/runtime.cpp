@@ -108,6 +108,8 @@ struct trre_prog {
     trre::NftTables nt;
     trre::StreamTables stt;
     trre::GuidedTables gt;
+    trre::GenTables gen;              // generator modes (`-a`): viability DFA for the device, follow lists for the host enumeration
+    int mode = TRRE_MODE_SCAN;
     uint32_t nft_nodes = 0;
     bool has_engine_tables = false;   // tile kernels available (always for DFT; NFT: <= 64 nodes, no epsilon cycle)
     std::vector<uint8_t> blob;
@@ -227,29 +229,32 @@ void serialize_stream(const trre::StreamTables& t, std::vector<uint8_t>& b) {
     put(b, h.off_p32, t.p32.data(), t.p32.size());
 }
 
-void serialize_rev(const trre::GuidedTables& g, std::vector<uint8_t>& b) {
+void serialize_rev_table(uint32_t n_rev, uint32_t n_cls, uint32_t sym_bits, const std::array<uint8_t, 256>& cls, const std::vector<uint8_t>& rev,
+                         std::vector<uint8_t>& b) {
     using namespace trre;
     RevBlobHeader h{};
     h.magic = kMagicRev;
-    h.n_rev = g.n_rev;
-    h.n_cls = g.n_cls;
-    h.sym_bits = g.sym_bits;
+    h.n_rev = n_rev;
+    h.n_cls = n_cls;
+    h.sym_bits = sym_bits;
     size_t off = sizeof h;
     h.off_cls = (uint32_t)off; off += 256;
-    h.off_tab = (uint32_t)off; off += align_up(g.rev.size(), 16);
-    h.off_wide = (uint32_t)off; off += (size_t)g.n_rev * 256;
+    h.off_tab = (uint32_t)off; off += align_up(rev.size(), 16);
+    h.off_wide = (uint32_t)off; off += (size_t)n_rev * 256;
     off = align_up(off + 16, 16);
     h.total_bytes = (uint32_t)off;
     b.assign(off, 0);
-    std::vector<uint8_t> wide((size_t)g.n_rev * 256);
-    for (uint32_t r = 0; r < g.n_rev; ++r)
-        for (int c = 0; c < 256; ++c) wide[(size_t)r * 256 + c] = g.rev[(size_t)r * g.n_cls + g.cls[c]];
+    std::vector<uint8_t> wide((size_t)n_rev * 256);
+    for (uint32_t r = 0; r < n_rev; ++r)
+        for (int c = 0; c < 256; ++c) wide[(size_t)r * 256 + c] = rev[(size_t)r * n_cls + cls[c]];
     put(b, 0, &h, 1);
-    put(b, h.off_cls, g.cls.data(), 256);
-    put(b, h.off_tab, g.rev.data(), g.rev.size());
+    put(b, h.off_cls, cls.data(), 256);
+    put(b, h.off_tab, rev.data(), rev.size());
     put(b, h.off_wide, wide.data(), wide.size());
 }
+void serialize_rev(const trre::GuidedTables& g, std::vector<uint8_t>& b) { serialize_rev_table(g.n_rev, g.n_cls, g.sym_bits, g.cls, g.rev, b); }
 
+bool is_generate(int mode) { return mode == TRRE_MODE_SCAN_ALL || mode == TRRE_MODE_MATCH_ALL; }
 bool is_stream(int fam) { return fam == TRRE_KERNEL_STREAM_LP || fam == TRRE_KERNEL_STREAM_GEN; }
 bool is_guided(int fam) { return fam == TRRE_KERNEL_GUIDED_LP || fam == TRRE_KERNEL_GUIDED_GEN; }
 bool is_gen(int fam) { return fam == TRRE_KERNEL_TILE_GEN || fam == TRRE_KERNEL_STREAM_GEN || fam == TRRE_KERNEL_GUIDED_GEN; }
@@ -602,12 +607,14 @@ int compile_impl(const std::string& pattern, int engine, trre_prog** out, int mo
     if (!out) return fail(TRRE_E_ARG, "error: null output handle");
     *out = nullptr;
     if (engine != TRRE_ENGINE_NFT && engine != TRRE_ENGINE_DFT) return fail(TRRE_E_ARG, "error: unknown engine");
-    if (mode != TRRE_MODE_SCAN && mode != TRRE_MODE_MATCH) return fail(TRRE_E_ARG, "error: unknown mode");
+    if (mode != TRRE_MODE_SCAN && mode != TRRE_MODE_MATCH && !is_generate(mode)) return fail(TRRE_E_ARG, "error: unknown mode");
     if (mode == TRRE_MODE_MATCH && engine != TRRE_ENGINE_NFT)
         return fail(TRRE_E_UNSUPPORTED, "error: match mode is offered for the non-deterministic engine only (trre_dft -m prints empty lines)");
+    if (is_generate(mode) && engine != TRRE_ENGINE_NFT) return fail(TRRE_E_UNSUPPORTED, "Not supported yet");   // trre_dft.c:1227-1229
     try {
         std::unique_ptr<trre_prog> p(new trre_prog);
         p->engine = engine;
+        p->mode = mode;
         Ast ast = parse_pattern(pattern);
         Nft nft = build_nft(ast, engine == TRRE_ENGINE_DFT);
         p->nft_states = (uint32_t)nft.st.size();
@@ -618,6 +625,13 @@ int compile_impl(const std::string& pattern, int engine, trre_prog** out, int mo
             serialize_dft(*p);
             p->has_engine_tables = true;
             p->stt = build_stream_dft(dft);
+        } else if (is_generate(mode)) {
+            // trre -a / -ma: every accepting path prints (generate.cpp): a viability DFA for the device, the lists for the host
+            p->gen = build_gen_tables(nft, mode == TRRE_MODE_MATCH_ALL);
+            if (!p->gen.ok)
+                throw Error(kErrUnsupported, "error: the viability automaton of this pattern has more than 256 states (generator mode)");
+            p->nft_nodes = (uint32_t)p->gen.nodes.node.size();
+            serialize_rev_table(p->gen.n_rev, p->gen.n_cls, 8, p->gen.cls, p->gen.rev, p->rblob);
         } else if (mode == TRRE_MODE_MATCH) {
             // trre -m: one attempt per line, accepted at its end only — the guided tables in match form
             const NftNodes nodes = build_nft_nodes(nft, true);
@@ -719,7 +733,7 @@ int trre_get_info(const trre_prog* p, trre_info* info) {
     if (!p || !info) return fail(TRRE_E_ARG, "error: null argument");
     std::memset(info, 0, sizeof *info);
     info->engine = p->engine;
-    info->kernel = p->forced_family ? p->forced_family : auto_family(*p);
+    info->kernel = is_generate(p->mode) ? TRRE_KERNEL_GENERATE : (p->forced_family ? p->forced_family : auto_family(*p));
     info->nft_states = p->nft_states;
     info->nft_cons_states = p->nft_cons;
     if (p->engine == TRRE_ENGINE_DFT) {
@@ -736,11 +750,13 @@ int trre_get_info(const trre_prog* p, trre_info* info) {
     if (p->stt.ok) { info->stream_states = p->stt.n_states; info->stream_classes = p->stt.n_cls; }
     info->nft_nodes = p->nft_nodes;
     if (p->gt.ok) { info->guided_rev_states = p->gt.n_rev; info->guided_fwd_states = p->gt.fwd.n_states; }
+    if (p->gen.ok) info->guided_rev_states = p->gen.n_rev;
     return TRRE_OK;
 }
 
 int trre_set_kernel(trre_prog* p, int family) {
     if (!p) return fail(TRRE_E_ARG, "error: null argument");
+    if (is_generate(p->mode)) return family == TRRE_KERNEL_AUTO ? TRRE_OK : fail(TRRE_E_UNSUPPORTED, "error: generator mode has one implementation");
     if (family != TRRE_KERNEL_AUTO && !family_allowed(*p, family))
         return fail(TRRE_E_UNSUPPORTED, "error: this kernel family cannot run these tables");
     p->forced_family = family;
@@ -778,6 +794,7 @@ int trre_scan_enqueue(trre_prog* p, const uint8_t* d_in, size_t n, uint8_t* d_ou
     DeviceState* st;
     int rc = current_state(p, &st);
     if (rc) return rc;
+    if (is_generate(p->mode)) return fail(TRRE_E_ARG, "error: generator mode has no split form: use trre_scan_device / trre_scan_host");
     const int fam = p->forced_family ? p->forced_family : auto_family(*p);
     return enqueue(p, st, &st->ctx, fam, d_in, n, d_out, cap, static_cast<hipStream_t>(stream));
 }
@@ -790,6 +807,69 @@ int trre_scan_finish(trre_prog* p, size_t* out_len) {
     return finish(p, st, &st->ctx, out_len);
 }
 
+namespace {
+int slot_reserve(DeviceState::HostSlot& hs, bool input, size_t bytes);
+constexpr size_t kGenChunk = (size_t)16 << 20;
+
+// Generator modes on one device, host buffers: chunks cut at record ends go up, the backward kernel leaves one viability
+// symbol per byte (k_rev_sweep, the guided families' backward pass with the tables of generate.cpp), the symbols come
+// down and the accepting paths are enumerated on a few host threads.  `result` takes what the reference prints; false
+// through `diverged`: a path ran into an epsilon cycle (what was printed before it stays).
+int generate_on(trre_prog* p, DeviceState* st, const uint8_t* in, size_t n, std::vector<uint8_t>& result, bool& diverged) {
+    using namespace trre;
+    diverged = false;
+    DeviceState::HostSlot& hs = st->slot[0];
+    if (!hs.stream) HIP_TRY(hipStreamCreateWithFlags(&hs.stream, hipStreamNonBlocking));
+    int rc = ctx_init(hs.ctx);
+    if (rc) return rc;
+    static const int threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency() / 2));
+    size_t off = 0;
+    while (off < n && !diverged) {
+        size_t len = n - off;
+        if (len > kGenChunk) {
+            const void* nl = std::memchr(in + off + kGenChunk - 1, '\n', n - off - (kGenChunk - 1));
+            len = nl ? (size_t)(static_cast<const uint8_t*>(nl) - (in + off)) + 1 : n - off;
+        }
+        rc = slot_reserve(hs, true, len);
+        if (!rc) rc = slot_reserve(hs, false, len + 512);                  // (pin_out / d_out of the slot carry the symbols)
+        if (rc) return rc;
+        std::memcpy(hs.pin_in, in + off, len);
+        HIP_TRY(hipMemcpyAsync(hs.d_in, hs.pin_in, len, hipMemcpyHostToDevice, hs.stream));
+        ScanArgs args{};
+        args.in_v0 = hs.d_in;                                              // (hipMalloc'ed: 16-byte aligned, v == g)
+        args.vbeg = 0;
+        args.vend = (int64_t)len;
+        args.rblob = st->d_rblob;
+        args.sym_v0 = hs.d_out;
+        args.status = hs.ctx.d_status;
+        launch_rev_sweep(args, (int)p->gen.n_rev * 256, 2048, hs.stream, false);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(hs.pin_out, hs.d_out, len, hipMemcpyDeviceToHost, hs.stream));
+        HIP_TRY(hipStreamSynchronize(hs.stream));
+        try {
+            if (!generate_buffer(p->gen, in + off, len, hs.pin_out, result, threads)) diverged = true;
+        } catch (const std::bad_alloc&) {
+            return fail(TRRE_E_TOO_BIG, "error: out of host memory for the outputs of generator mode");
+        }
+        off += len;
+    }
+    return TRRE_OK;
+}
+constexpr const char* kDivergeMsg = "error: stack max capacity reached (the reference's search does not terminate on this input)";
+}  // namespace
+
+// host-only entry for the CPU test tier: the enumeration of generator mode with symbols computed elsewhere (tests/cpu_shim.cpp
+// runs the backward kernel's per-thread body on the host).  Not part of the drop-in boundary.
+int trre_debug_generate(trre_prog* p, const uint8_t* in, size_t n, const uint8_t* sym, uint8_t* out, size_t cap, size_t* out_len) {
+    if (!p || !is_generate(p->mode) || (n && (!in || !sym))) return fail(TRRE_E_ARG, "error: bad argument");
+    std::vector<uint8_t> result;
+    const bool ok = trre::generate_buffer(p->gen, in, n, sym, result, 2);
+    if (out_len) *out_len = result.size();
+    if (result.size() > cap) return fail(TRRE_E_CAPACITY, "error: output buffer too small");
+    if (!result.empty()) std::memcpy(out, result.data(), result.size());
+    return ok ? TRRE_OK : fail(TRRE_E_DIVERGES, kDivergeMsg);
+}
+
 int trre_scan_device(trre_prog* p, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, size_t* out_len,
                      void* stream) {
     if (!p || (n && (!d_in || !d_out))) return fail(TRRE_E_ARG, "error: null argument");
@@ -797,6 +877,23 @@ int trre_scan_device(trre_prog* p, const uint8_t* d_in, size_t n, uint8_t* d_out
     int rc = current_state(p, &st);
     if (rc) return rc;
     std::lock_guard<std::mutex> lock(st->mu);        // one scan call at a time per (prog, device); other devices run in parallel
+    if (is_generate(p->mode)) {
+        // the enumeration runs on the host (generate.cpp): input down, output up; the device computes the viability symbols
+        if (out_len) *out_len = 0;
+        if (n == 0) return TRRE_OK;
+        std::vector<uint8_t> host(n), result;
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        HIP_TRY(hipMemcpyAsync(host.data(), d_in, n, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        bool diverged = false;
+        rc = generate_on(p, st, host.data(), n, result, diverged);
+        if (rc) return rc;
+        if (out_len) *out_len = result.size();
+        if (result.size() > cap) return fail(TRRE_E_CAPACITY, "error: output buffer too small");
+        if (!result.empty()) HIP_TRY(hipMemcpyAsync(d_out, result.data(), result.size(), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return diverged ? fail(TRRE_E_DIVERGES, kDivergeMsg) : TRRE_OK;
+    }
     const int fam = p->forced_family ? p->forced_family : auto_family(*p);
     rc = enqueue(p, st, &st->ctx, fam, d_in, n, d_out, cap, static_cast<hipStream_t>(stream));
     if (rc) { st->ctx.pend = Pending(); return rc; }
@@ -1047,6 +1144,16 @@ int trre_scan_host(trre_prog* p, const uint8_t* in, size_t n, uint8_t* out, size
     int rc = device_state(p, device, &st);
     if (rc) return rc;
     std::lock_guard<std::mutex> lock(st->mu);
+    if (is_generate(p->mode)) {
+        std::vector<uint8_t> result;
+        bool diverged = false;
+        rc = generate_on(p, st, in, n, result, diverged);
+        if (rc) return rc;
+        if (out_len) *out_len = result.size();
+        if (result.size() > cap) return fail(TRRE_E_CAPACITY, "error: output buffer too small");
+        if (!result.empty()) std::memcpy(out, result.data(), result.size());
+        return diverged ? fail(TRRE_E_DIVERGES, kDivergeMsg) : TRRE_OK;
+    }
     return scan_host_on(p, st, in, n, out, cap, out_len);
 }
 
@@ -1079,7 +1186,7 @@ int trre_scan_host_multi(trre_prog* p, const uint8_t* in, size_t n, uint8_t* out
     int rc = trre_shard_bounds(in, n, G, bounds.data());
     if (rc) return rc;
     const int fam = p->forced_family ? p->forced_family : auto_family(*p);
-    const bool fixed_len = !is_gen(fam);
+    const bool fixed_len = !is_gen(fam) && !is_generate(p->mode);
     // A length-preserving program writes every shard straight to its place (output offset == input offset);
     // otherwise a shard's offset is known only when the shards before it are done: each goes to a buffer of its
     // own and is moved into place afterwards.
