@@ -51,6 +51,27 @@ def main():
         if p.scan_tensor(t).cpu().numpy().tobytes() != Oracle(pat, eng).scan(text):
             print("MISMATCH dictionary", eng)
             bad += 1
+    # the general families whatever implements them (TRRE_PATCH=1: record + patch): small tables, guided tables, edits in
+    # every byte of a piece (more than 7 per 64 bytes: overflow records), texts longer than a piece, a diverging line
+    for pat, eng in [("a:xyz", "dft"), ("a:", "nft"), (" +: ", "nft"), ("(a|b)*c:x", "nft"), ("[0-9]+:N", "nft"), ("[a-z]:xy", "dft"),
+                     ("e:a-replacement-text-of-more-than-sixty-four-bytes-0123456789-0123456789-0123456789-0123456789", "dft"), (":=", "nft")]:
+        p = trre_amd.Program(pat, eng)
+        for buf in (clean, data, b"aaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaa 123 b\n" * 3000, b"a"):
+            t = torch.frombuffer(bytearray(buf), dtype=torch.uint8).cuda()
+            got = p.scan_tensor(t).cpu().numpy().tobytes()
+            if got != Oracle(pat, eng).scan(buf):
+                print("MISMATCH general", pat, eng, len(buf))
+                bad += 1
+    try:
+        p = trre_amd.Program("cat:dog|a:*", "nft")
+        t = torch.frombuffer(bytearray(b"cat b\ncat xa cat\n"), dtype=torch.uint8).cuda()
+        p.scan_tensor(t)
+        print("MISMATCH: no divergence")
+        bad += 1
+    except trre_amd.TrreError as e:
+        if e.code != trre_amd.api.E_DIVERGES or e.partial.cpu().numpy().tobytes() != b"dog b\ndog x":
+            print("MISMATCH diverge partial", e.code)
+            bad += 1
     print("impl check: %s" % ("ok" if not bad else "%d mismatches" % bad))
     return 1 if bad else 0
 

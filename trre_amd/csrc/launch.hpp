@@ -5,6 +5,7 @@
 namespace trre {
 
 struct ScanArgs;
+struct PatchArgs;
 
 constexpr int kEngineNft = 0, kEngineDft = 1;
 
@@ -23,8 +24,11 @@ int direct_ent_lds_bytes();
 int direct_block_threads();
 // sym: guided families — columns are the symbols of the backward pass (a.sym_v0): 1 one per byte, 2 packed two per byte
 // (16-byte entries only)
+// which 3 (16-byte entries only): the record pass of the record + patch form (patch_block.hpp), `pa` its slots
 void launch_direct_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, void* stream, int g16_bytes = 0,
-                          int sym = 0, bool g16_slow = true);
+                          int sym = 0, bool g16_slow = true, const PatchArgs* pa = nullptr);
+void launch_group_sum(const uint64_t* block_total, uint64_t* group_total, int64_t n_blocks, void* stream);
+void launch_patch(const ScanArgs& a, const PatchArgs& pa, int64_t n_blocks, int g16_bytes, void* stream);
 // backward pass of the guided families: fills a.sym_v0 for positions [0 .. round_up(a.vend, 64)) (packed: round_up(.., 128), two per byte)
 void launch_rev_sweep(const ScanArgs& a, int tab_bytes, int64_t lane_bytes, void* stream, bool packed);
 void launch_lpw_kernel(int ent_bytes, bool wide, bool direct_ent_in_lds, const ScanArgs& a, int64_t lane_bytes, void* stream);

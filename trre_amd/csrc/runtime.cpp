@@ -21,6 +21,7 @@
 #include "device_blob.hpp"
 #include "front.hpp"
 #include "launch.hpp"
+#include "patch_block.hpp"
 #include "scan_block.hpp"
 
 namespace {
@@ -50,6 +51,7 @@ struct Pending {
     bool timed = false;
     int count = 0;          // launches in the current batch
     const uint64_t* total_at = nullptr;   // general families: where the launch leaves its output size
+    bool patched = false;                 // the launch was a record + patch pair (patch_block.hpp), not a count / emit pair
 };
 
 // Everything ONE in-flight scan needs on a device besides the tables: status words, the workspaces of the
@@ -69,6 +71,15 @@ struct ScanCtx {
     uint8_t* d_sym = nullptr;         // guided families: one symbol per input byte
     size_t sym_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // record + patch form of the general families (patch_block.hpp): a 32-byte slot per 64 input bytes, overflow records,
+    // block totals and their exclusive sum
+    uint32_t* d_slots = nullptr;
+    uint32_t* d_ovf = nullptr;
+    uint32_t* d_ovf_count = nullptr;
+    uint64_t* d_block_total = nullptr;   // [n_blocks], then the group totals [n_groups] (zeroed together)
+    uint64_t* d_group_base = nullptr;    // [n_groups + 1]
+    int64_t patch_pieces = 0;         // capacity, in pieces
+    bool patch_off = false;           // finish() runs the scan again as a count / emit pair (diverged, or out of overflow records)
     int relaunches = 0;               // finish() ran the scan again (scratch, NUL, overflow): whatever was downloaded early is stale
     Pending pend;
 };
@@ -317,6 +328,11 @@ void ctx_free(ScanCtx& c) {
     (void)hipFree(c.d_scratch);
     (void)hipFree(c.d_redo);
     (void)hipFree(c.d_sym);
+    (void)hipFree(c.d_slots);
+    (void)hipFree(c.d_ovf);
+    (void)hipFree(c.d_ovf_count);
+    (void)hipFree(c.d_block_total);
+    (void)hipFree(c.d_group_base);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
     if (c.ev1) (void)hipEventDestroy(c.ev1);
     c = ScanCtx();
@@ -357,6 +373,23 @@ int ensure_workspace(ScanCtx* c, int64_t n_chunks, int threads) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_chunk_total), (size_t)n_chunks * 8));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_chunk_base), (size_t)(n_chunks + 1) * 8));
     c->ws_chunks = n_chunks;
+    return TRRE_OK;
+}
+
+int64_t patch_ovf_records(int64_t n_pieces) { return n_pieces / 128 + 1024; }
+int ensure_patch_workspace(ScanCtx* c, int64_t n_pieces) {
+    if (n_pieces <= c->patch_pieces) return TRRE_OK;
+    (void)hipFree(c->d_slots); (void)hipFree(c->d_ovf); (void)hipFree(c->d_ovf_count); (void)hipFree(c->d_block_total); (void)hipFree(c->d_group_base);
+    c->d_slots = nullptr; c->d_ovf = nullptr; c->d_ovf_count = nullptr; c->d_block_total = nullptr; c->d_group_base = nullptr;
+    c->patch_pieces = 0;
+    const int64_t n_blocks = (n_pieces + trre::kBlockPieces - 1) / trre::kBlockPieces;
+    const int64_t n_groups = (n_blocks + trre::kGroupBlocks - 1) / trre::kGroupBlocks;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_slots), (size_t)n_pieces * trre::kSlotWords * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_ovf), (size_t)patch_ovf_records(n_pieces) * trre::kOvfWords * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_ovf_count), 16));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_block_total), (size_t)(n_blocks + n_groups) * 8));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_group_base), (size_t)(n_groups + 1) * 8));
+    c->patch_pieces = n_pieces;
     return TRRE_OK;
 }
 
@@ -493,10 +526,41 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
     } else if (direct) {
         const int g16 = stt.g16_ok && !no_g16_env ? (int)(align_up(stt.g16.size() * 4, 16) + stt.p32.size() * 4) : 0;   // LDS room: 16-byte + pair forms
         if (is_guided(family)) launch_rev_sweep(args, (int)p->gt.n_rev * 256, lane_bytes, stream, sym_mode == 2);
+        // TRRE_PATCH=1 (experimental, off by default): ONE walk that lists the edits per 64-byte piece, then a patch pass that
+        // copies the input around them (patch_block.hpp) — instead of a count walk and an emit walk that appends byte by byte.
+        // Correct (parity-tested on the host shim and on the GPU) but slower as it stands: 'a:xyz' at 1 GiB record 0.78 ms +
+        // patch 1.61 ms against count 0.42 + emit 0.97.  (Its first lane starts at v = 0: 16-byte aligned
+        // inputs only; a scan that diverges or runs out of overflow records is run again as a count / emit pair.)
+        static const bool no_patch_env = getenv("TRRE_PATCH") == nullptr;
+        if (g16 > 0 && a == 0 && !no_patch_env && !cx->patch_off && lane_bytes % kPieceBytes == 0) {
+            const int64_t n_pieces = (args.vend + kPieceBytes - 1) / kPieceBytes;
+            const int64_t n_blocks = (n_pieces + kBlockPieces - 1) / kBlockPieces;
+            rc = ensure_patch_workspace(cx, n_pieces);
+            if (rc) return rc;
+            PatchArgs pa{};
+            pa.slots = cx->d_slots;
+            pa.ovf = cx->d_ovf;
+            pa.ovf_count = cx->d_ovf_count;
+            pa.ovf_cap = (uint32_t)patch_ovf_records(cx->patch_pieces);
+            const int64_t n_groups = (n_blocks + kGroupBlocks - 1) / kGroupBlocks;
+            pa.block_total = cx->d_block_total;
+            pa.group_total = cx->d_block_total + n_blocks;
+            pa.group_base = cx->d_group_base;
+            pa.n_pieces = n_pieces;
+            HIP_TRY(hipMemsetAsync(cx->d_block_total, 0, (size_t)(n_blocks + n_groups) * 8, stream));
+            HIP_TRY(hipMemsetAsync(cx->d_ovf_count, 0, 4, stream));
+            launch_direct_kernel(3, direct_ent_lds, args, lane_bytes, n_chunks, stream, (int)align_up(stt.g16.size() * 4, 16), sym_mode, g16_slow, &pa);
+            launch_group_sum(pa.block_total, pa.group_total, n_blocks, stream);
+            launch_chunk_scan(pa.group_total, pa.group_base, n_groups, stream);
+            launch_patch(args, pa, n_blocks, (int)(stt.g16.size() * 4), stream);
+            pd.total_at = cx->d_group_base + n_groups;
+            pd.patched = true;
+        } else {
         launch_direct_kernel(1, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, sym_mode, g16_slow);
         launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);
         launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, sym_mode, g16_slow);
         pd.total_at = cx->d_chunk_base + n_chunks;
+        }
     } else if (family == TRRE_KERNEL_STREAM_LP) {
         launch_stream_kernel(0, ent_lds, args, n_chunks, stream);
     } else if (family == TRRE_KERNEL_STREAM_GEN) {
@@ -554,8 +618,10 @@ int finish(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
         // output up to that point is in the buffer and its length is reported with the error.  (The DFT binary dies of
         // unbounded recursion, its buffered output is lost: nothing to reproduce, *out_len = 0.)
         if (p->engine != TRRE_ENGINE_NFT || !p->gt.ok) return fail(TRRE_E_DIVERGES, msg);
-        if (was.family != TRRE_KERNEL_GUIDED_GEN) {
+        if (was.family != TRRE_KERNEL_GUIDED_GEN || was.patched) {
+            cx->patch_off = true;                              // (the count / emit pair knows every lane's size)
             const int rc = again(TRRE_KERNEL_GUIDED_GEN);      // (comes back here through the branch below)
+            cx->patch_off = false;
             return rc == TRRE_OK ? fail(TRRE_E_DEVICE, "error: a diverging scan did not diverge when it was run again") : rc;
         }
         const uint32_t lane = 0xffffffffu - cx->h_status[1];
@@ -586,6 +652,13 @@ int finish(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
             cx->scratch_bytes = need;
         }
         return again(was.family);
+    }
+    if (was.patched && (status & kStEditOverflow)) {
+        // more pieces with more than 7 edits than there are overflow records (or an edit text of kilobytes): the count / emit pair
+        cx->patch_off = true;
+        const int rc = again(was.family);
+        cx->patch_off = false;
+        return rc;
     }
     // an undecided attempt outgrew the stream table (bounded fold): the guided (or the tile) kernels take the buffer
     if (is_stream(was.family) && (status & kStOverflow)) return again(general_family(*p, false));

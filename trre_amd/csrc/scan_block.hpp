@@ -1203,6 +1203,110 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
 }
 
 // =============================================================================================
+// Record pass of the "record + patch" form of the general families (patch_block.hpp has the whole story): the count walk
+// plus, per 64-byte piece of the input, a slot that lists the transitions which do not simply emit the byte they read.
+// =============================================================================================
+constexpr int kPieceBytes = 64;
+constexpr int kSlotWords = 8;                   // 32 bytes per piece
+constexpr int kSlotEdits = 7;
+constexpr int kBlockPieces = 256;               // pieces per patch workgroup / block total
+constexpr int kGroupBlocks = 1024;              // blocks per group total (16 MiB of input: the exclusive sum runs over groups, a patch
+                                                // workgroup adds the totals of the blocks before it in its group)
+constexpr int kOvfWords = 64;                   // an overflow record: all edits of one piece (at most one per input byte)
+constexpr uint32_t kSlotWritten = 1u << 24;
+constexpr uint32_t kSlotOverflow = 255u;
+constexpr uint32_t kStEditOverflow = 1u << 6;   // the overflow records ran out: the launch is void, the count / emit pair runs instead
+
+// what the record pass and the patch pass share besides ScanArgs
+struct PatchArgs {
+    uint32_t* slots;           // [n_pieces][kSlotWords]
+    uint32_t* ovf;             // [ovf_cap][kOvfWords]
+    uint32_t* ovf_count;       // records handed out so far
+    uint32_t ovf_cap;
+    uint64_t* block_total;     // [n_blocks] output bytes of the block's pieces (record: atomics; zeroed by the runtime)
+    uint64_t* group_total;     // [n_groups] the same per GROUP of kGroupBlocks blocks (k_group_sum; a lane adding to its group's
+                               // total as well would serialise thousands of atomics on one address: measured 5x the whole pass)
+    uint64_t* group_base;      // [n_groups + 1] exclusive sum of the group totals; [n_groups] = size of the whole output
+    int64_t n_pieces;
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TRRE_ATOMIC_ADD_U64(p, v) atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)(v))
+#define TRRE_ATOMIC_INC_U32(p) atomicAdd((p), 1u)
+#else
+#define TRRE_ATOMIC_ADD_U64(p, v) (*(p) += (v))
+#define TRRE_ATOMIC_INC_U32(p) ((*(p))++)
+#endif
+
+// ---- record pass: per-lane state ------------------------------------------------------------------------------
+// stage: the lane's edits of the current piece (LDS, kRecStage words: a dword of input adds at most 4, the spill test
+// runs after every dword)
+constexpr int kRecStage = kSlotEdits + 5;
+constexpr int kRecStageStride = kRecStage + 1;   // words between two lanes' stages (13: odd, lanes in step hit distinct banks)
+struct RecState {
+    uint32_t* stage;
+    uint32_t cnt = 0;          // edits staged
+    int32_t dl = 0;            // bytes the piece's edits add
+    bool rec = false;          // the piece being walked is this lane's to record
+    bool fin = false;          // the lane's last line has ended: the lane is done at the end of this piece
+    int32_t ovf = -1;          // overflow record of the current piece
+    uint32_t ovf_n = 0;
+    int64_t acc = 0, acc_block = -1;   // output bytes of recorded pieces not yet added to their block's total
+};
+TRRE_HD void rec_spill(const PatchArgs& pa, RecState& r, uint32_t& status) {
+    if (r.ovf < 0) {
+        const uint32_t idx = TRRE_ATOMIC_INC_U32(pa.ovf_count);
+        if (idx >= pa.ovf_cap) { status |= kStEditOverflow; r.cnt = 0; return; }
+        r.ovf = (int32_t)idx;
+        r.ovf_n = 0;
+    }
+    uint32_t* dst = pa.ovf + (size_t)r.ovf * kOvfWords;
+    for (uint32_t k = 0; k < r.cnt && r.ovf_n < (uint32_t)kOvfWords; ++k) dst[r.ovf_n++] = r.stage[k];
+    r.cnt = 0;
+}
+// end of the piece at v-space offset `v`; walked: the lane was not done when the piece began; saw_eol: a record end has
+// been seen by now (the lane is past its first line start)
+TRRE_HD void rec_commit(const ScanArgs& a, const PatchArgs& pa, RecState& r, int64_t v, bool walked, bool saw_eol, uint32_t& status) {
+    if (walked && r.rec) {
+        const int64_t q = v / kPieceBytes;
+        uint32_t* slot = pa.slots + (size_t)q * kSlotWords;
+        if (r.ovf >= 0 || r.cnt > (uint32_t)kSlotEdits) {
+            rec_spill(pa, r, status);
+            slot[0] = ((uint32_t)r.dl & 0xffffu) | kSlotOverflow << 16 | kSlotWritten;
+            slot[1] = (uint32_t)r.ovf;
+            slot[2] = r.ovf_n;
+        } else {
+            U128 s0, s1;
+            s0.x = ((uint32_t)r.dl & 0xffffu) | r.cnt << 16 | kSlotWritten;
+            s0.y = r.stage[0]; s0.z = r.stage[1]; s0.w = r.stage[2];
+            s1.x = r.stage[3]; s1.y = r.stage[4]; s1.z = r.stage[5]; s1.w = r.stage[6];
+            U128* d = reinterpret_cast<U128*>(slot);
+            d[0] = s0;
+            d[1] = s1;
+        }
+        if (r.dl > 32767 || r.dl < -32768) status |= kStEditOverflow;     // (texts of kilobytes in one piece: not this path)
+        int64_t valid = a.vend - v;
+        valid = valid < 0 ? 0 : (valid > kPieceBytes ? kPieceBytes : valid);
+        const int64_t blk = q / kBlockPieces;
+        if (blk != r.acc_block) {
+            if (r.acc_block >= 0 && r.acc) TRRE_ATOMIC_ADD_U64(pa.block_total + r.acc_block, (uint64_t)r.acc);
+            r.acc_block = blk;
+            r.acc = 0;
+        }
+        r.acc += valid + r.dl;
+    }
+    r.rec = r.rec || saw_eol;
+    r.cnt = 0;
+    r.dl = 0;
+    r.ovf = -1;
+}
+TRRE_HD void rec_finish(const PatchArgs& pa, RecState& r) {
+    if (r.acc_block >= 0 && r.acc) TRRE_ATOMIC_ADD_U64(pa.block_total + r.acc_block, (uint64_t)r.acc);
+    r.acc = 0;
+}
+
+
+// =============================================================================================
 // Small tables (16-byte entries, whole table in LDS): the count and emit passes written for instruction
 // count — these passes are bound by VALU issue (a wave64 integer instruction occupies its SIMD for 4
 // cycles), not by memory.  Differences from stream_direct_lane<.., kG16>:
@@ -1218,10 +1322,11 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
 // =============================================================================================
 // kSym: 0 columns are byte classes; 1 / 2 (guided families) columns are the symbols the backward pass left, one per
 // byte / packed two per byte (backward DFAs of at most 16 states: half the symbol traffic).
+// kMode 3: the record pass (above): `ring` is the lane's stage of kRecStage words, `pa` the slots.
 template <int kMode, int kSym, bool kHasSlow>
 TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, int64_t lane, int64_t lane_bytes, uint8_t* ring,
-                      uint64_t out_base, DirectLane& L, uint32_t& status, uint32_t* wave_scratch = nullptr) {
-    static_assert(kMode == 1 || kMode == 2, "count or emit");
+                      uint64_t out_base, DirectLane& L, uint32_t& status, uint32_t* wave_scratch = nullptr, const PatchArgs* pa = nullptr) {
+    static_assert(kMode == 1 || kMode == 2 || kMode == 3, "count, emit or record");
     const uint32_t done_row = kDoneState * n_cls * 16u;
     const int64_t lo = lane * lane_bytes;
     int64_t hi = lo + lane_bytes;
@@ -1246,6 +1351,11 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
     }
     uint64_t cnt = 0;
     uint32_t seen = 0;
+    RecState R;                                                      // kMode 3
+    R.stage = reinterpret_cast<uint32_t*>(ring);
+    R.rec = row == 0u;                                               // a lane that starts at a line start records from its first piece on
+    bool walked = row != done_row;                                   // the lane was not done when the current piece began
+    const uint32_t vlim = a.vend - lo > 0xffffffffll ? 0xffffffffu : (uint32_t)(a.vend - lo > 0 ? a.vend - lo : 0);   // input ends here
     const int64_t vlast = (a.vend - 1) & ~(int64_t)15;               // the last readable aligned block
     // symbols: per byte — 16 bytes per 16-byte block; packed — 16 bytes per 32 input bytes (fetched for offsets 0 and 32 of a piece)
     const int64_t slast = kSym == 2 ? (((a.vend + 127) & ~(int64_t)127) >> 1) - 16 : ((a.vend + 63) & ~(int64_t)63) - 16;
@@ -1320,6 +1430,51 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
             }
             seen |= fl;
             cnt += c;
+        } else if (kMode == 3) {
+            // the count walk, and every transition that does not simply emit the byte it reads is listed as an edit of its
+            // piece: the event word is stored at the stage's fill position whatever the transition, the position moves on
+            // only for an edit (no branch)
+            const uint32_t row0 = row;
+            uint32_t fl = 0;
+            const uint32_t pbase = (rp & (uint32_t)(kPieceBytes - 1)) + 1u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t eoff = row + (kk[j] << 4);
+                const uint64_t g = *reinterpret_cast<const uint64_t*>(T.g16 + eoff);
+                const uint32_t meta = (uint32_t)(g >> 32);
+                uint32_t edit = (meta >> 9) & 1u;
+                int32_t add = (int32_t)(meta << 8) >> 24;                // [23:16]: bytes emitted - 1
+                if (kEnd) {                                              // (the bytes after the end of the input are nobody's)
+                    const bool inside = rp + (uint32_t)j < vlim;
+                    edit = inside ? edit : 0u;
+                    add = inside ? add : 0;
+                    R.fin = R.fin || ((meta & 32u) && rp + (uint32_t)j + 1u >= rhi);
+                }
+                R.stage[R.cnt] = (pbase + (uint32_t)j) | (eoff << 5);    // [6:0] p, [31:9] the entry's index
+                R.cnt += edit;
+                R.dl += add;
+                fl |= meta;
+                row = (uint32_t)g;
+            }
+            if (kHasSlow) {
+                if (TRRE_WAVE_ANY(fl & 128u)) {
+                    if (fl & 128u) {              // slow entries count 0 above: add their texts' lengths
+                        uint32_t r = row0;
+                        for (int j = 0; j < 4; ++j) {
+                            const uint64_t g = *reinterpret_cast<const uint64_t*>(T.g16 + r + (kk[j] << 4));
+                            if (((uint32_t)(g >> 32) & 128u) && (!kEnd || rp + (uint32_t)j < vlim)) R.dl += (int32_t)slow_count(r, kk[j]);
+                            r = (uint32_t)g;
+                        }
+                    }
+                }
+            }
+            seen |= fl;
+            if (TRRE_WAVE_ANY(R.cnt > (uint32_t)kSlotEdits)) {
+                if (R.cnt > (uint32_t)kSlotEdits) {
+                    if (walked && R.rec) rec_spill(*pa, R, status);
+                    else R.cnt = 0;                                      // (a lane before its first line start, or done: nothing of this is kept)
+                }
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1414,7 +1569,7 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
         const uint32_t y0 = kSym == 2 ? (y.x & 0xffffu) : y.x, y1 = kSym == 2 ? (y.x >> 16) : y.y,
                        y2 = kSym == 2 ? (y.y & 0xffffu) : y.z, y3 = kSym == 2 ? (y.y >> 16) : y.w;
         // (between two flushes at most 65 bytes may arrive: 8 transitions of up to 5 bytes, or 4 of up to 9 with slow entries)
-        if (!kEnd && T.p32) {
+        if (!kEnd && T.p32 && kMode != 3) {
             dword_pairs(b.x, y0);
             if (kMode == 2 && (kHasSlow || T.p32_slow)) stage_flush<false>(S);
             dword_pairs(b.y, y1);
@@ -1457,6 +1612,7 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
     };
     for (int64_t v = lo;; v += 64) {
         if (!TRRE_WAVE_ANY(row != done_row)) break;
+        if (kMode == 3) walked = row != done_row;
         const int64_t vn = v + 64;
         const int64_t x0 = vn < vlast ? vn : vlast, x1 = vn + 16 < vlast ? vn + 16 : vlast,
                       x2 = vn + 32 < vlast ? vn + 32 : vlast, x3 = vn + 48 < vlast ? vn + 48 : vlast;
@@ -1491,13 +1647,19 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
                 block(std::true_type{}, b, sym_of(q), rp + 16u * (uint32_t)q);
             }
         }
+        if (kMode == 3) {
+            // the piece is complete: its slot (if it is this lane's to record), and the lane ends here if its last line has ended
+            rec_commit(a, *pa, R, v, walked, (seen & 32u) != 0u, status);
+            if (R.fin) row = done_row;
+        }
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         if (kSym) { s0 = t0; s1 = t1; s2 = t2; s3 = t3; }
     }
+    if (kMode == 3) rec_finish(*pa, R);
     if (kMode == 2) stage_flush<true>(S);
     if (kMode == 2 && a.lp_emit && ((seen & 8u) || (seen2 & 256u))) status |= kStNul;
-    if (kMode == 1 && ((seen | seen2) & 64u)) status |= kStOverflow;            // bounded fold: the launch is void
-    if ((kMode == 1 || a.lp_emit) && ((seen | seen2) & 16u)) status |= kStDiverge;   // guided tables: the reference's search never returns
+    if ((kMode == 1 || kMode == 3) && ((seen | seen2) & 64u)) status |= kStOverflow;            // bounded fold: the launch is void
+    if ((kMode == 1 || kMode == 3 || a.lp_emit) && ((seen | seen2) & 16u)) status |= kStDiverge;   // guided tables: the reference's search never returns
     L.count = cnt;
 }
 

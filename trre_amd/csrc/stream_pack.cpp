@@ -60,8 +60,13 @@ void build_gen16(StreamTables& t, const StreamPackInput& in) {
             uint32_t* e = &v[((size_t)s * t.n_cls + k) * 4];
             e[0] = x.next * t.n_cls * 16u;
             const bool silent = s == in.skip || s == in.done;
+            // [8] identity: the transition emits exactly the byte it reads (the record pass of the patch path lists every
+            // other transition as an edit: scan_block.hpp g16_lane<3>); a record's '\n' emitted on the '\n' column is the byte read
+            const bool ident = (x.out.empty() && x.copy_c) || (in.col_kind[k] == kColNewline && !x.copy_c && x.out == "\n");
             e[1] = (slow ? 128u : (uint32_t)n) | (x.eol ? 32u : 0u) | (x.ovf ? 64u : 0u) | (x.diverge ? 16u : 0u) |
-                   ((in.col_kind[k] == kColNul && !silent) ? 8u : 0u);
+                   ((in.col_kind[k] == kColNul && !silent) ? 8u : 0u) | (ident && !x.ovf && !x.diverge ? 256u : 512u) |
+                   // [9] an edit (not the identity), [23:16] what it adds: bytes emitted - 1 (signed; a slow entry counts as 0 here)
+                   (((uint32_t)(int32_t)((slow ? 0 : (int)n) - 1) & 0xffu) << 16);
             uint32_t bytes = 0, sel = 0x0c0c0c0cu;                       // constant 0x00 everywhere
             if (!slow) {
                 sel = 0;
