@@ -217,8 +217,10 @@ void run_rev_sweep(const ScanArgs& a, int64_t lane_bytes, bool packed) {
     const int64_t vtop = packed ? (a.vend + 127) & ~(int64_t)127 : (a.vend + 63) & ~(int64_t)63;
     const int64_t n_lanes = (vtop + lane_bytes - 1) / lane_bytes;
     for (int64_t lane = 0; lane < n_lanes; ++lane) {
-        if (packed) rev_sweep_lane<0, true>(a, T, lane, lane_bytes);
-        else rev_sweep_lane<0, false>(a, T, lane, lane_bytes);
+        // (the tiny geometry bounds the look-ahead at 256 bytes: every line of a few hundred bytes has a walker)
+        const int64_t max_look = lane_bytes <= 128 ? 256 : kRevMaxLook;
+        if (packed) rev_sweep_lane<0, true>(a, T, lane, lane_bytes, nullptr, max_look);
+        else rev_sweep_lane<0, false>(a, T, lane, lane_bytes, nullptr, max_look);
     }
 }
 // g16: walk the 16-byte entries (when the tables have them), like k_stream_g16

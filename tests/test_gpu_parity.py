@@ -206,6 +206,26 @@ def test_long_lines_on_gpu():
     assert gpu_scan(prog("(cat:dog|dog:cat)", "dft"), one) == Oracle("(cat:dog|dog:cat)", "dft").scan(one)
 
 
+def test_very_long_lines_through_the_guided_families():
+    """The backward pass bounds its look-ahead (64 KiB): inside a longer line one lane becomes the line's walker and carries
+    the state through the lanes that stand back (every lane used to rescan the rest of the line — quadratic, an
+    8 MiB line took minutes).  Lines of 100 kB .. 6 MB between ordinary ones, every guided family, against the oracle."""
+    import time
+    rng = random.Random(31)
+    long1 = (b"abcab xyz " * 10000)[:100000]
+    long2 = bytes(rng.choice(b"abcxyz 0123") for _ in range(700000))
+    long3 = (b"abx cat 7" * 700000)                           # 6 MB (loops stay short: the reference's stack holds 65 536 items)
+    data = corpus.word_soup(rng, 50000) + long1 + b"\n" + b"short abc\n" + long2 + b"c\n" + corpus.word_soup(rng, 30000) + long3 + b"\nabc\n" + long1
+    for pat in ("(a|b)*c:x", "[0-9]+:N", "(cat:dog|dog:cat)"):
+        p = prog(pat, "nft")
+        want = Oracle(pat, "nft").scan(data)
+        for fam in (trre_amd.KERNEL_GUIDED_LP, trre_amd.KERNEL_GUIDED_GEN):
+            if fam in p.allowed_kernels():
+                t0 = time.time()
+                assert gpu_scan(p, data, fam) == want, (pat, fam)
+                assert time.time() - t0 < 20, (pat, fam, "the backward pass must not be quadratic in the line length")
+
+
 @pytest.mark.parametrize("env", [{"TRRE_STREAM_IMPL": "0"}, {"TRRE_STREAM_IMPL": "1"}, {"TRRE_STREAM_IMPL": "1", "TRRE_LANE_BYTES": "256"},
                                  {"TRRE_STREAM_IMPL": "2", "TRRE_LANE_BYTES": "4096"}, {"TRRE_STREAM_IMPL": "2", "TRRE_LANE_BYTES": "1024"},
                                  {"TRRE_NO_G16": "1"}, {"TRRE_NO_FB": "1"}, {"TRRE_FB_EMIT": "1"}, {"TRRE_PATCH": "1"}])
@@ -358,7 +378,7 @@ def test_random_patterns_against_the_oracle():
     import subprocess
     import sys
     script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gpu_fuzz.py")
-    r = subprocess.run([sys.executable, script, "--seconds", "12", "--seed", "20250926"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    r = subprocess.run([sys.executable, script, "--seconds", "40", "--seed", "20250926"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     out = r.stdout.decode("latin-1")
     assert r.returncode == 0 and "0 mismatches" in out, out[-2000:]
 

@@ -2152,18 +2152,74 @@ TRRE_HD void rev_block_n(const RevView& T, uint32_t& r, const U128& b, uint32_t&
     x = h0 | h1 << 16;
     y = h2 | h3 << 16;
 }
+// one lane's sub-range [lo, hi) by a thread on its own (no wave-level stores, every load patched at the ends of the input):
+// the long-line walker below continues with this through the sub-ranges of the lanes it stands in for
+template <bool kNib>
+TRRE_HD void rev_pieces_solo(const ScanArgs& a, const RevView& T, int64_t lo, int64_t hi, uint32_t& r) {
+    if (kNib) {
+        for (int64_t v = hi - 128; v >= lo; v -= 128) {
+            U128 b[8], y[4];
+            for (int k = 0; k < 8; ++k) b[k] = direct_load(a, v + 16 * k);
+            rev_block_n(T, r, b[7], y[3].z, y[3].w); rev_block_n(T, r, b[6], y[3].x, y[3].y);
+            rev_block_n(T, r, b[5], y[2].z, y[2].w); rev_block_n(T, r, b[4], y[2].x, y[2].y);
+            rev_block_n(T, r, b[3], y[1].z, y[1].w); rev_block_n(T, r, b[2], y[1].x, y[1].y);
+            rev_block_n(T, r, b[1], y[0].z, y[0].w); rev_block_n(T, r, b[0], y[0].x, y[0].y);
+            U128* dst = reinterpret_cast<U128*>(a.sym_v0 + (v >> 1));
+            dst[0] = y[0]; dst[1] = y[1]; dst[2] = y[2]; dst[3] = y[3];
+        }
+        return;
+    }
+    for (int64_t v = hi - 64; v >= lo; v -= 64) {
+        const U128 b0 = direct_load(a, v), b1 = direct_load(a, v + 16), b2 = direct_load(a, v + 32), b3 = direct_load(a, v + 48);
+        U128 y0, y1, y2, y3;
+        y3.w = rev_step4(T, r, b3.w); y3.z = rev_step4(T, r, b3.z); y3.y = rev_step4(T, r, b3.y); y3.x = rev_step4(T, r, b3.x);
+        y2.w = rev_step4(T, r, b2.w); y2.z = rev_step4(T, r, b2.z); y2.y = rev_step4(T, r, b2.y); y2.x = rev_step4(T, r, b2.x);
+        y1.w = rev_step4(T, r, b1.w); y1.z = rev_step4(T, r, b1.z); y1.y = rev_step4(T, r, b1.y); y1.x = rev_step4(T, r, b1.x);
+        y0.w = rev_step4(T, r, b0.w); y0.z = rev_step4(T, r, b0.z); y0.y = rev_step4(T, r, b0.y); y0.x = rev_step4(T, r, b0.x);
+        U128* dst = reinterpret_cast<U128*>(a.sym_v0 + v);
+        dst[0] = y0; dst[1] = y1; dst[2] = y2; dst[3] = y3;
+    }
+}
+// the input byte at v as the walkers see it
+TRRE_HD uint32_t rev_byte_at(const ScanArgs& a, int64_t v) {
+    const U128 q = direct_load(a, v & ~(int64_t)15);
+    const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+    return (wd[(v & 15) >> 2] >> (8 * (int)(v & 3))) & 0xffu;
+}
+// is there a '\n' in [lo, hi) (16-byte aligned bounds)
+TRRE_HD bool rev_has_newline(const ScanArgs& a, int64_t lo, int64_t hi) {
+    for (int64_t v = lo; v < hi; v += 16) {
+        const U128 q = direct_load(a, v);
+        const uint32_t wd[4] = {q.x ^ 0x0a0a0a0au, q.y ^ 0x0a0a0a0au, q.z ^ 0x0a0a0a0au, q.w ^ 0x0a0a0a0au};
+        for (int d = 0; d < 4; ++d)
+            if ((wd[d] - 0x01010101u) & ~wd[d] & 0x80808080u) return true;
+    }
+    return false;
+}
+// A lane needs the DFA's state at the end of its sub-range, i.e. it first runs from the end of the line that crosses that
+// end — for a line of megabytes every lane inside it would rescan the rest of the line: quadratic.  So the
+// look-ahead is bounded by max_look: of the lanes inside a longer line exactly one lies between max_look and max_look +
+// lane_bytes from the line's end; it becomes the line's WALKER — after its own sub-range it carries the state on through
+// the sub-ranges of the lanes to its left, one after the other, down to the lane in which the line starts —, the others
+// stand back and write nothing.  A line of n bytes costs its walker n sequential steps (one thread, ~0.5 GB/s: the reference
+// itself is a single thread), everything else stays parallel.
+constexpr int64_t kRevMaxLook = 64 * 1024;
 template <int kDbg = 0, bool kNib = false>
-TRRE_HD void rev_sweep_lane(const ScanArgs& a, const RevView& T, int64_t lane, int64_t lane_bytes, uint8_t* wave_tile = nullptr) {
+TRRE_HD void rev_sweep_lane(const ScanArgs& a, const RevView& T, int64_t lane, int64_t lane_bytes, uint8_t* wave_tile = nullptr,
+                            int64_t max_look = kRevMaxLook) {
     const int64_t lo = lane * lane_bytes;
     const int64_t vtop = kNib ? (a.vend + 127) & ~(int64_t)127 : (a.vend + 63) & ~(int64_t)63;
     int64_t hi = lo + lane_bytes;
     if (hi > vtop) hi = vtop;
-    if (lo >= hi) return;
+    const bool empty = lo >= hi;
     uint32_t r = 1;            // kSymEol, the state right of a '\n': nothing alive (every byte from vend - 1 on reads as '\n')
-    if (hi < a.vend - 1) {
+    int role = 0;              // 0 an ordinary lane, 1 the walker of a long line, 2 inside a long line: the walker does its bytes
+    if (!empty && hi < a.vend - 1 && rev_byte_at(a, hi - 1) != (uint32_t)'\n') {      // (right of a '\n' the state is known)
         // the line that crosses hi: find its end e (first '\n' at or after hi), then run e - 1 .. hi
         int64_t e = hi;        // hi is a multiple of 16
-        for (;; e += 16) {
+        const int64_t limit = hi + max_look + lane_bytes;
+        bool found_end = false;
+        for (; e <= limit; e += 16) {
             const U128 q = direct_load(a, e);
             const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
             int found = -1;
@@ -2178,9 +2234,12 @@ TRRE_HD void rev_sweep_lane(const ScanArgs& a, const RevView& T, int64_t lane, i
 #endif
                 }
             }
-            if (found >= 0) { e += found; break; }
+            if (found >= 0) { e += found; found_end = true; break; }
         }
+        if (!found_end || e - hi > max_look + lane_bytes) role = 2;
+        else if (e - hi > max_look) role = 1;
         // blocks from the one holding e - 1 down to hi; bytes at or beyond e are skipped
+        if (role != 2)
         for (int64_t v = (e - 1) & ~(int64_t)15; v >= hi && e > hi; v -= 16) {
             const U128 q = direct_load(a, v);
             const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
@@ -2191,6 +2250,10 @@ TRRE_HD void rev_sweep_lane(const ScanArgs& a, const RevView& T, int64_t lane, i
             }
         }
     }
+    // (a wave with a lane that is not ordinary does without the stores through the wave's tile: they need all 64 lanes)
+    const bool odd_wave = TRRE_WAVE_ANY(role != 0);
+    if (empty || role == 2) return;
+    do {
     // The lane's own pieces, highest first.  A wave whose 64 sub-ranges lie wholly inside the input takes the loop
     // whose loads and stores are unconditional — the piece below is requested before this one is walked, and with
     // a fixed number of memory operations per iteration the wait for it can leave the previous piece's stores in
@@ -2209,7 +2272,7 @@ TRRE_HD void rev_sweep_lane(const ScanArgs& a, const RevView& T, int64_t lane, i
                 for (int k = 0; k < 8; ++k) b[k] = direct_load(a, vv + 16 * k);
             }
         };
-        const bool interior = TRRE_WAVE_ALL(lo >= a.vbeg && lo + lane_bytes + 128 <= a.vend - 1 && hi == lo + lane_bytes);
+        const bool interior = !odd_wave && TRRE_WAVE_ALL(lo >= a.vbeg && lo + lane_bytes + 128 <= a.vend - 1 && hi == lo + lane_bytes);
         U128 b[8];
         fetch8(hi - 128, b, interior);
         for (int64_t v = hi - 128; v >= lo; v -= 128) {
@@ -2248,7 +2311,7 @@ TRRE_HD void rev_sweep_lane(const ScanArgs& a, const RevView& T, int64_t lane, i
 #pragma unroll
             for (int k = 0; k < 8; ++k) b[k] = nx[k];
         }
-        return;
+        break;
     }
     auto walk_piece = [&](const U128& b0, const U128& b1, const U128& b2, const U128& b3, int64_t v) {
         U128 y0, y1, y2, y3;
@@ -2272,7 +2335,7 @@ TRRE_HD void rev_sweep_lane(const ScanArgs& a, const RevView& T, int64_t lane, i
             walk_piece(b0, b1, b2, b3, v);
             b0 = n0; b1 = n1; b2 = n2; b3 = n3;
         }
-        return;
+        break;
     }
     auto fetch = [&](int64_t v, U128& b0, U128& b1, U128& b2, U128& b3) {
         const int64_t vv = v >= lo ? v : lo;              // (the fetch below the lane's first piece is not used)
@@ -2285,6 +2348,18 @@ TRRE_HD void rev_sweep_lane(const ScanArgs& a, const RevView& T, int64_t lane, i
         fetch(v - 64, n0, n1, n2, n3);
         walk_piece(b0, b1, b2, b3, v);
         b0 = n0; b1 = n1; b2 = n2; b3 = n3;
+    }
+    } while (false);
+    if (role == 1) {
+        // the walker: on through the lanes to the left that stood back, down to the one in which the long line starts
+        for (int64_t k = lane; k > 0;) {
+            const int64_t lok = k * lane_bytes;
+            // the long line starts inside lane k if the lane holds a '\n' at all (every '\n' in it lies before that start),
+            // or right at its first byte
+            if (lok <= a.vbeg || rev_byte_at(a, lok - 1) == (uint32_t)'\n' || rev_has_newline(a, lok, lok + lane_bytes)) break;
+            --k;
+            rev_pieces_solo<kNib>(a, T, k * lane_bytes, (k + 1) * lane_bytes, r);
+        }
     }
 }
 
