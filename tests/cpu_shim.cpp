@@ -593,7 +593,7 @@ int shim_scan_guided(const uint8_t* rblob, const uint8_t* gblob, int family, int
     a.blob = gblob;
     a.rblob = rblob;
     a.cap = cap;
-    std::vector<uint8_t> sym(n + 512, 0xDD);        // poison: every symbol the forward pass walks must have been written
+    std::vector<uint8_t> sym(2 * n + 1024, 0xDD);   // poison: every symbol the forward pass walks must have been written
     a.sym_v0 = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(sym.data()) + 63) & ~(uintptr_t)63);
     uint32_t status = 0;
     uint64_t total = 0;
@@ -602,6 +602,29 @@ int shim_scan_guided(const uint8_t* rblob, const uint8_t* gblob, int family, int
     // like the runtime: symbols are packed two per byte when the backward DFA allows it and the walk uses the 16-byte entries
     const bool has_g16 = reinterpret_cast<const StreamBlobHeader*>(gblob)->g16_bytes != 0;
     const bool packed = reinterpret_cast<const RevBlobHeader*>(rblob)->sym_bits == 4 && has_g16 && (family == 10 || family == 11 || family == 15);
+    if (reinterpret_cast<const RevBlobHeader*>(rblob)->sym_bits == 16) {
+        // wide guided tables (more than 256 backward states): k_rev_wide, k_wide_fwd<count>, scan, k_wide_fwd<emit>
+        if (family == 10 || family == 13 || family == 14) return -5;
+        const RevBlobHeader& rh = *reinterpret_cast<const RevBlobHeader*>(rblob);
+        const RevWideView RT{reinterpret_cast<const uint16_t*>(rblob + rh.off_wide)};
+        const int64_t max_look = lane_bytes <= 128 ? 256 : kRevMaxLook;
+        const int64_t vtop = (a.vend + 63) & ~(int64_t)63;
+        for (int64_t lane = 0; lane < (vtop + lane_bytes - 1) / lane_bytes; ++lane) rev_wide_lane(a, RT, lane, lane_bytes, max_look);
+        const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(gblob);
+        const StreamView T = direct_view(a);
+        const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
+        std::vector<uint64_t> cnt(n_lanes), base(n_lanes);
+        for (int64_t lane = 0; lane < n_lanes; ++lane) { DirectLane L; wide_fwd_lane<1>(a, T, h.n_cls, lane, lane_bytes, 0, L, status); cnt[lane] = L.count; }
+        uint64_t run = 0;
+        for (int64_t lane = 0; lane < n_lanes; ++lane) { base[lane] = run; run += cnt[lane]; }
+        total = run;
+        if (run > cap) { status |= kStCapacity; *status_out = status; *m = (size_t)total; return 0; }
+        for (int64_t lane = n_lanes - 1; lane >= 0; --lane) { DirectLane L; wide_fwd_lane<2>(a, T, h.n_cls, lane, lane_bytes, base[lane], L, status); }
+        *status_out = status;
+        *m = (size_t)total;
+        std::memcpy(out, oa, (size_t)total);
+        return 0;
+    }
     run_rev_sweep(a, lane_bytes, packed);
     if (family == 10 || family == 13 || family == 14) {
         if (family == 13) run_direct_lp<1>(a, lane_bytes, status);                  // the LDS-ring walker (A/B variant)

@@ -43,13 +43,16 @@ def test_engine_limits_are_errors_not_fallbacks():
     # unbounded look-ahead and > 64 CONS states: round 1 refused it, the guided families run it
     p = trre_amd.Program("(" + big.replace(":x", "") + ")*z:y", "nft")
     assert p.info.kernel == trre_amd.KERNEL_GUIDED_GEN and p.info.nft_nodes == 161
-    # what is still refused: the backward DFA of the guided families explodes (which of the next ten bytes is a
-    # 'c': > 256 states), the fold explodes (8^9 pending strings) and there are more nodes than mask bits
+    # a backward DFA of more than 256 states (which of the next ten bytes is a 'c': 4 604) and more nodes than mask bits:
+    # round 2 refused it, the wide guided tables (16-bit symbols) run it
+    p = trre_amd.Program("a(a|b|c|d|e|f|g|h){9}c:x", "nft")
+    assert p.info.kernel == trre_amd.KERNEL_GUIDED_GEN and p.info.guided_rev_states == 4604 and trre_amd.KERNEL_GUIDED_LP not in p.allowed_kernels()
+    # what is still refused: more than 16 384 backward states with more than 64 nodes
     with pytest.raises(trre_amd.TrreError) as e:
-        trre_amd.Program("a(a|b|c|d|e|f|g|h){9}c:x", "nft")
+        trre_amd.Program("a(a|b|c|d|e|f|g|h){12}c:x", "nft")
     assert e.value.code == api.E_UNSUPPORTED
-    p = trre_amd.Program("a(a|b|c){9}c:x", "nft")            # the same with 29 nodes: the bitmask tile kernels
-    assert p.info.kernel == trre_amd.KERNEL_TILE_GEN and p.info.guided_rev_states == 0
+    p = trre_amd.Program("a(a|b|c){9}c:x", "nft")            # 29 nodes: the bitmask tile kernels are preferred to wide tables
+    assert p.info.kernel == trre_amd.KERNEL_TILE_GEN and p.info.guided_rev_states > 256
     # an epsilon cycle is not a compile error: like the reference's lazy tables, the scan fails (TRRE_E_DIVERGES) only
     # on an input that makes it explore the cycle (tests/test_front_shim.py, golden 'eps_*' inputs)
     assert trre_amd.Program("(a*)*", "dft").info.dft_states >= 1

@@ -477,3 +477,21 @@ def test_record_and_patch_form_of_the_general_families():
             data = corpus.word_soup(rng, 3000 + 997 * k, max_len=200) + b"nul\0rest of the record\n" + b"cat aaa" * k
             out, st = shim_lib.shim_scan(p.export_stream_tables(), p.info.engine, 24, data, 0)
             assert out is not None and not st & (shim_lib.ST_MISMATCH | 64) and out == o.scan(data), (pat, eng, k)
+
+
+def test_wide_guided_tables():
+    """backward DFAs of more than 256 states (16-bit symbols, k_rev_wide / k_wide_fwd): scan and match mode against the
+    oracle, both geometries (the tiny one bounds the look-ahead at 256 bytes: long-line walkers run too)"""
+    rng = random.Random(5)
+    data = b"".join(bytes(rng.choice(b"abcdefghxyz ") for _ in range(rng.randint(0, 400))) + b"\n" for _ in range(200)) + b"xabcdefghy tail"
+    for pat in ("a(a|b|c|d|e|f|g|h){9}c:x", "x.{8}y:z", "a(a|b|c|d){7}c:x"):
+        p = prog(pat, "nft")
+        assert p.info.guided_rev_states > 256
+        want = Oracle(pat, "nft").scan(data)
+        for geo in (1, 0):
+            out, st = shim_lib.shim_scan_guided(p, shim_lib.GUIDED_GEN, data, geo)
+            assert st == 0 and out == want, (pat, geo)
+    pm = trre_amd.Program("[a-h]{8}(a|b)[a-z ]*", "nft", mode="match")
+    assert pm.info.guided_rev_states > 256
+    out, st = shim_lib.shim_scan_guided(pm, shim_lib.GUIDED_GEN, data, 0)
+    assert st == 0 and out == Oracle("[a-h]{8}(a|b)[a-z ]*", "nft").match(data)

@@ -383,6 +383,25 @@ def test_random_patterns_against_the_oracle():
     assert r.returncode == 0 and "0 mismatches" in out, out[-2000:]
 
 
+def test_wide_guided_tables_on_gpu():
+    """patterns whose backward DFA has more than 256 states (round 2: TRRE_E_UNSUPPORTED beyond 64 nodes): 16-bit symbols,
+    both tables through L1 / L2.  Scan mode (automatic choice and forced), match mode, a divergence's partial output."""
+    rng = random.Random(6)
+    data = b"".join(bytes(rng.choice(b"abcdefghxyz ") for _ in range(rng.randint(0, 300))) + b"\n" for _ in range(20000)) + b"xabcdefghy tail"
+    for pat in ("a(a|b|c|d|e|f|g|h){9}c:x", "x.{8}y:z", "a(a|b|c){9}c:x"):
+        p = prog(pat, "nft")
+        assert p.info.guided_rev_states > 256
+        want = Oracle(pat, "nft").scan(data)
+        assert gpu_scan(p, data) == want, pat
+        assert gpu_scan(p, data, trre_amd.KERNEL_GUIDED_GEN) == want, (pat, "wide")
+    pat = "[a-h]{8}(a|b)[a-z ]*"
+    assert gpu_scan(trre_amd.Program(pat, "nft", mode="match"), data) == Oracle(pat, "nft").match(data)
+    p = prog("x.{8}y:z|q:*", "nft")
+    with pytest.raises(trre_amd.TrreError) as e:
+        gpu_scan(p, b"x12345678y a\nx12345678y q b\nnever\n")
+    assert e.value.code == trre_amd.api.E_DIVERGES and e.value.partial.cpu().numpy().tobytes() == b"z a\nz "
+
+
 def test_match_mode_on_gpu():
     """`trre -m` through the C ABI (trre_compile_mode, TRRE_MODE_MATCH): golden vectors of the compiled reference,
     and a larger buffer against the oracle's match mode"""

@@ -299,16 +299,21 @@ NftTables build_nft_tables(const NftNodes& nodes);
 // '\n' and NUL reset the backward DFA (symbols kSymEol / kSymNul); symbol 0 is "nothing alive".
 constexpr uint32_t kSymDead = 0, kSymEol = 1, kSymNul = 2;
 struct GuidedLimits {
-    size_t max_rev_states = 256;      // symbols are bytes
+    size_t max_rev_states = 16384;    // up to 256: symbols are bytes and the backward table lives in LDS; beyond: 16-bit symbols,
+                                      // both tables through L1 / L2 (the "wide" kernels: correct, an order of magnitude slower)
     size_t max_fwd_states = 4096;
     size_t max_out = 4096;
+    size_t max_fwd_cells = 2u << 20;  // forward states x symbols (8 bytes each: 16 MB)
 };
 struct GuidedTables {
     bool ok = false;
     uint32_t n_rev = 0, n_cls = 0;          // backward DFA: states (= symbols) x byte classes
-    uint32_t sym_bits = 8;                  // 4: at most 16 states and a small forward table — symbols are stored two per byte
+    uint32_t sym_bits = 8;                  // 4: at most 16 states and a small forward table — symbols are stored two per byte;
+                                            // 16: more than 256 states (wide)
+    bool wide = false;
     std::array<uint8_t, 256> cls{};         // byte -> class; class 0 = '\n', class 1 = NUL
-    std::vector<uint8_t> rev;               // [n_rev][n_cls] next state
+    std::vector<uint8_t> rev;               // [n_rev][n_cls] next state (n_rev <= 256)
+    std::vector<uint16_t> rev16;            // the same when wide
     StreamTables fwd;                       // columns = symbols (fwd.cls is unused)
 };
 // With nodes built for match mode the tables compute `trre -m` (trre_nft.c:791-797): one attempt per line from its first

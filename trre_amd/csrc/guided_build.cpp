@@ -61,7 +61,8 @@ public:
         byte_classes(g);
         backward(g);
         forward(g);
-        g.sym_bits = (g.n_rev <= 16 && g.fwd.g16_ok) ? 4 : 8;
+        g.wide = g.n_rev > 256;
+        g.sym_bits = g.wide ? 16 : ((g.n_rev <= 16 && g.fwd.g16_ok) ? 4 : 8);
         g.ok = true;
         return g;
     }
@@ -111,11 +112,11 @@ private:
         // right of a line's last byte — states 1 and 2 — and nowhere else)
         rev_.assign(3, RevSets());
         rev_index_.emplace(std::vector<uint32_t>{0xffffffffu}, kSymDead);
-        std::vector<std::vector<uint8_t>> rows;
+        std::vector<std::vector<uint16_t>> rows;
         for (uint32_t r = 0; r < rev_.size(); ++r) {        // (rev_ grows while we go)
-            std::vector<uint8_t> row(g.n_cls, 0);
-            row[0] = (uint8_t)kSymEol;
-            row[1] = (uint8_t)kSymNul;
+            std::vector<uint16_t> row(g.n_cls, 0);
+            row[0] = (uint16_t)kSymEol;
+            row[1] = (uint16_t)kSymNul;
             for (uint32_t k = 2; k < g.n_cls; ++k) {
                 RevSets nx;
                 for (uint32_t t : readers_[k]) {
@@ -124,13 +125,19 @@ private:
                     nx.alive.push_back(t);
                     if (diverges(nd_.follow[t][e], rev_[r])) nx.div.push_back(t);
                 }
-                row[k] = (uint8_t)intern_rev(std::move(nx));
+                row[k] = (uint16_t)intern_rev(std::move(nx));
             }
             rows.push_back(std::move(row));
         }
         g.n_rev = (uint32_t)rev_.size();
-        g.rev.resize((size_t)g.n_rev * g.n_cls);
-        for (uint32_t r = 0; r < g.n_rev; ++r) std::copy(rows[r].begin(), rows[r].end(), g.rev.begin() + (size_t)r * g.n_cls);
+        if (g.n_rev <= 256) {
+            g.rev.resize((size_t)g.n_rev * g.n_cls);
+            for (uint32_t r = 0; r < g.n_rev; ++r)
+                for (uint32_t k = 0; k < g.n_cls; ++k) g.rev[(size_t)r * g.n_cls + k] = (uint8_t)rows[r][k];
+        } else {
+            g.rev16.resize((size_t)g.n_rev * g.n_cls);
+            for (uint32_t r = 0; r < g.n_rev; ++r) std::copy(rows[r].begin(), rows[r].end(), g.rev16.begin() + (size_t)r * g.n_cls);
+        }
     }
 
     bool final_ok(uint32_t sym) const { return !match_ || sym == kSymEol || sym == kSymNul; }
@@ -242,7 +249,9 @@ private:
     void forward(GuidedTables& g) {
         StreamPackInput in;
         fwd_.assign(3, 0);
+        in.wide_cols = g.n_rev > 256;
         for (uint32_t s = 0; s < fwd_.size(); ++s) {        // (fwd_ grows while we go)
+            if ((uint64_t)(s + 1) * g.n_rev > lim_.max_fwd_cells) throw StreamGiveUp();
             std::vector<StreamCell> row;
             row.reserve(g.n_rev);
             for (uint32_t y = 0; y < g.n_rev; ++y) row.push_back(cell(s, y));

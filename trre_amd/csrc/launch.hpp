@@ -31,6 +31,9 @@ void launch_group_sum(const uint64_t* block_total, uint64_t* group_total, int64_
 void launch_patch(const ScanArgs& a, const PatchArgs& pa, int64_t n_blocks, int g16_bytes, void* stream);
 // backward pass of the guided families: fills a.sym_v0 for positions [0 .. round_up(a.vend, 64)) (packed: round_up(.., 128), two per byte)
 void launch_rev_sweep(const ScanArgs& a, int tab_bytes, int64_t lane_bytes, void* stream, bool packed);
+// wide guided tables (more than 256 backward states: 16-bit symbols at a.sym_v0, both tables through L1 / L2); which: 1 count, 2 emit
+void launch_rev_wide(const ScanArgs& a, int64_t lane_bytes, void* stream);
+void launch_wide_fwd(int which, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, void* stream);
 void launch_lpw_kernel(int ent_bytes, bool wide, bool direct_ent_in_lds, const ScanArgs& a, int64_t lane_bytes, void* stream);
 // count / emit passes over the fallback form of a large table (StreamTables::fb_*); hdr: the host's copy of the stream
 // blob's header.  Chunks are those of the direct kernels (direct_block_threads() lanes each).

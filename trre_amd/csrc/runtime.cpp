@@ -263,7 +263,30 @@ void serialize_rev_table(uint32_t n_rev, uint32_t n_cls, uint32_t sym_bits, cons
     put(b, h.off_tab, rev.data(), rev.size());
     put(b, h.off_wide, wide.data(), wide.size());
 }
-void serialize_rev(const trre::GuidedTables& g, std::vector<uint8_t>& b) { serialize_rev_table(g.n_rev, g.n_cls, g.sym_bits, g.cls, g.rev, b); }
+void serialize_rev(const trre::GuidedTables& g, std::vector<uint8_t>& b) {
+    if (!g.wide) { serialize_rev_table(g.n_rev, g.n_cls, g.sym_bits, g.cls, g.rev, b); return; }
+    // more than 256 states: 16-bit entries, [state][raw byte], read through L1 / L2 by k_rev_wide
+    using namespace trre;
+    RevBlobHeader h{};
+    h.magic = kMagicRev;
+    h.n_rev = g.n_rev;
+    h.n_cls = g.n_cls;
+    h.sym_bits = 16;
+    size_t off = sizeof h;
+    h.off_cls = (uint32_t)off; off += 256;
+    h.off_tab = (uint32_t)off; off += align_up(g.rev16.size() * 2, 16);
+    h.off_wide = (uint32_t)off; off += (size_t)g.n_rev * 256 * 2;
+    off = align_up(off + 16, 16);
+    h.total_bytes = (uint32_t)off;
+    b.assign(off, 0);
+    std::vector<uint16_t> wide((size_t)g.n_rev * 256);
+    for (uint32_t r = 0; r < g.n_rev; ++r)
+        for (int c = 0; c < 256; ++c) wide[(size_t)r * 256 + c] = g.rev16[(size_t)r * g.n_cls + g.cls[c]];
+    put(b, 0, &h, 1);
+    put(b, h.off_cls, g.cls.data(), 256);
+    put(b, h.off_tab, g.rev16.data(), g.rev16.size());
+    put(b, h.off_wide, wide.data(), wide.size());
+}
 
 bool is_generate(int mode) { return mode == TRRE_MODE_SCAN_ALL || mode == TRRE_MODE_MATCH_ALL; }
 bool is_stream(int fam) { return fam == TRRE_KERNEL_STREAM_LP || fam == TRRE_KERNEL_STREAM_GEN; }
@@ -284,9 +307,12 @@ int auto_family(const trre_prog& p) {
     // run at 0.6-0.8 TB/s: prefer them then (patterns with `.` or wide ranges before a literal fold into hundreds of
     // states x 256 classes)
     const bool stream_small = p.stt.ok && (p.stt.g16_ok || p.stt.lpw_ok);
-    const bool guided_small = p.gt.ok && p.gt.fwd.g16_ok;
+    const bool guided_small = p.gt.ok && p.gt.fwd.g16_ok && !p.gt.wide;
     if (p.stt.ok && (stream_small || !guided_small)) return lp_inplace(p.stt.flags) ? TRRE_KERNEL_STREAM_LP : TRRE_KERNEL_STREAM_GEN;
-    if (p.gt.ok) return lp_inplace(p.gt.fwd.flags) ? TRRE_KERNEL_GUIDED_LP : TRRE_KERNEL_GUIDED_GEN;
+    // (wide guided tables — 16-bit symbols, both tables through L1 / L2 — are the last resort before refusing a pattern: the
+    // bitmask tile kernels, where the pattern has few enough nodes for them, are preferred)
+    if (p.gt.ok && !(p.gt.wide && p.has_engine_tables))
+        return lp_inplace(p.gt.fwd.flags) && !p.gt.wide ? TRRE_KERNEL_GUIDED_LP : TRRE_KERNEL_GUIDED_GEN;
     if (p.engine == TRRE_ENGINE_DFT) {
         if ((p.dt.flags & kFlagLengthPreserving) && (p.dt.flags & kFlagNoOverrun)) return TRRE_KERNEL_TILE_LP;
         return TRRE_KERNEL_TILE_GEN;
@@ -299,7 +325,7 @@ bool family_allowed(const trre_prog& p, int fam) {
     if (fam == TRRE_KERNEL_STREAM_GEN) return p.stt.ok;
     if (fam == TRRE_KERNEL_STREAM_LP) return p.stt.ok && lp_inplace(p.stt.flags);
     if (fam == TRRE_KERNEL_GUIDED_GEN) return p.gt.ok;
-    if (fam == TRRE_KERNEL_GUIDED_LP) return p.gt.ok && lp_inplace(p.gt.fwd.flags);
+    if (fam == TRRE_KERNEL_GUIDED_LP) return p.gt.ok && lp_inplace(p.gt.fwd.flags) && !p.gt.wide;
     if (!p.has_engine_tables) return false;
     if (fam == TRRE_KERNEL_TILE_GEN) return true;
     if (p.engine == TRRE_ENGINE_DFT) {
@@ -467,7 +493,7 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
     }
     if (is_guided(family)) {
         // one symbol per input byte, written by the backward pass (whole 64-byte pieces) and read by the forward pass
-        const size_t need = (size_t)((args.vend + 63) & ~(int64_t)63) + 256;
+        const size_t need = ((size_t)((args.vend + 63) & ~(int64_t)63) + 256) * (p->gt.wide ? 2 : 1);
         if (cx->sym_bytes < need) {
             if (cx->d_sym) (void)hipFree(cx->d_sym);
             cx->d_sym = nullptr; cx->sym_bytes = 0;
@@ -497,6 +523,13 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
         HIP_TRY(hipMemsetAsync(cx->d_redo, 0, 4, stream));
         args.redo = cx->d_redo;
         launch_lpw_kernel((int)(p->stt.lpw.size() * 4), p->stt.lpw_delay > 3, direct_ent_lds, args, lane_bytes, stream);
+    } else if (is_guided(family) && p->gt.wide) {
+        // a backward DFA of more than 256 states: 16-bit symbols, both tables through L1 / L2 (scan_block.hpp: wide guided tables)
+        launch_rev_wide(args, lane_bytes, stream);
+        launch_wide_fwd(1, args, lane_bytes, n_chunks, stream);
+        launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);
+        launch_wide_fwd(2, args, lane_bytes, n_chunks, stream);
+        pd.total_at = cx->d_chunk_base + n_chunks;
     } else if (direct && !is_gen(family)) {
         // length-preserving without a window form: the emit pass alone, every lane writing its lines where it read
         // them (TRRE_LP_RING=1: the older in-place walker with an LDS ring, 2.3x slower; kept for A/B runs)
@@ -711,7 +744,7 @@ int compile_impl(const std::string& pattern, int engine, trre_prog** out, int mo
             p->nft_nodes = (uint32_t)nodes.node.size();
             p->gt = build_guided_nft(nodes);
             if (!p->gt.ok)
-                throw Error(kErrUnsupported, "error: the backward automaton of this pattern has more than 256 states (match mode runs on the guided tables only)");
+                throw Error(kErrUnsupported, "error: the backward automaton of this pattern has too many states (match mode runs on the guided tables only)");
         } else {
             const NftNodes nodes = build_nft_nodes(nft);
             p->nft_nodes = (uint32_t)nodes.node.size();

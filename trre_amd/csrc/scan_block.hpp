@@ -2364,6 +2364,118 @@ TRRE_HD void rev_sweep_lane(const ScanArgs& a, const RevView& T, int64_t lane, i
 }
 
 // =============================================================================================
+// Wide guided tables: a backward DFA of more than 256 states (e.g. 'a(a|b|c|d|e|f|g|h){9}c:x': which of the next ten bytes
+// is a 'c' — 4 604 states).  Symbols are 16 bits, neither table fits LDS: both passes go through L1 / L2, one lookup per
+// byte and lane, no staging — the simplest correct walkers (an order of magnitude slower than the byte-symbol kernels, far
+// faster than refusing the pattern).  Same lane ownership, same count / scan / emit plumbing as k_stream_direct.
+// =============================================================================================
+struct RevWideView { const uint16_t* tab; };     // [n_rev][256] next state by raw byte
+// symbols of the positions [lo, hi) (multiples of 16), highest first; r: the state right of hi - 1 on entry, of lo on return
+TRRE_HD void rev_wide_span(const ScanArgs& a, const RevWideView& T, int64_t lo, int64_t hi, uint32_t& r) {
+    uint16_t* sym = reinterpret_cast<uint16_t*>(a.sym_v0);
+    for (int64_t v = hi - 16; v >= lo; v -= 16) {
+        const U128 q = direct_load(a, v);
+        const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+        uint32_t y[8];
+#pragma clang loop unroll(disable)
+        for (int k = 15; k >= 0; --k) {
+            r = T.tab[(r << 8) | ((wd[k >> 2] >> (8 * (k & 3))) & 0xffu)];
+            if (k & 1) y[k >> 1] = r << 16; else y[k >> 1] |= r;
+        }
+        U128* dst = reinterpret_cast<U128*>(sym + v);
+        dst[0] = U128{y[0], y[1], y[2], y[3]};
+        dst[1] = U128{y[4], y[5], y[6], y[7]};
+    }
+}
+// first '\n' at or after `from` (a multiple of 16), looking no further than `limit`; false: none up to there
+TRRE_HD bool rev_line_end(const ScanArgs& a, int64_t from, int64_t limit, int64_t& e) {
+    for (e = from; e <= limit; e += 16) {
+        const U128 q = direct_load(a, e);
+        const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+        for (int d = 0; d < 4; ++d) {
+            const uint32_t x = wd[d] ^ 0x0a0a0a0au;
+            const uint32_t m = (x - 0x01010101u) & ~x & 0x80808080u;   // the lowest flag is exact
+            if (m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                e += 4 * d + ((__ffs((int)m) - 1) >> 3);
+#else
+                e += 4 * d + (__builtin_ctz(m) >> 3);
+#endif
+                return true;
+            }
+        }
+    }
+    return false;
+}
+// the backward pass of one lane, with the long-line walker of rev_sweep_lane
+TRRE_HD void rev_wide_lane(const ScanArgs& a, const RevWideView& T, int64_t lane, int64_t lane_bytes, int64_t max_look = kRevMaxLook) {
+    const int64_t lo = lane * lane_bytes;
+    const int64_t vtop = (a.vend + 63) & ~(int64_t)63;
+    int64_t hi = lo + lane_bytes;
+    if (hi > vtop) hi = vtop;
+    if (lo >= hi) return;
+    uint32_t r = 1;            // kSymEol
+    int role = 0;
+    if (hi < a.vend - 1 && rev_byte_at(a, hi - 1) != (uint32_t)'\n') {
+        int64_t e;
+        const bool found = rev_line_end(a, hi, hi + max_look + lane_bytes, e);
+        if (!found || e - hi > max_look + lane_bytes) role = 2;
+        else if (e - hi > max_look) role = 1;
+        if (role != 2)
+            for (int64_t v = (e - 1) & ~(int64_t)15; v >= hi && e > hi; v -= 16) {
+                const U128 q = direct_load(a, v);
+                const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+#pragma clang loop unroll(disable)
+                for (int k = 15; k >= 0; --k)
+                    if (v + k < e) r = T.tab[(r << 8) | ((wd[k >> 2] >> (8 * (k & 3))) & 0xffu)];
+            }
+    }
+    if (role == 2) return;
+    rev_wide_span(a, T, lo, hi, r);
+    if (role == 1)
+        for (int64_t k = lane; k > 0;) {
+            const int64_t lok = k * lane_bytes;
+            if (lok <= a.vbeg || rev_byte_at(a, lok - 1) == (uint32_t)'\n' || rev_has_newline(a, lok, lok + lane_bytes)) break;
+            --k;
+            rev_wide_span(a, T, k * lane_bytes, (k + 1) * lane_bytes, r);
+        }
+}
+// the forward pass of one lane: kMode 1 count, 2 emit (straight to memory at its offset)
+template <int kMode>
+TRRE_HD void wide_fwd_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, int64_t lane, int64_t lane_bytes, uint64_t out_base, DirectLane& L,
+                           uint32_t& status) {
+    const uint32_t done_row = kDoneState * n_cls;
+    const int64_t lo = lane * lane_bytes;
+    int64_t hi = lo + lane_bytes;
+    if (hi > a.vend) hi = a.vend;
+    uint32_t row;
+    if (lo >= hi) row = done_row;
+    else if (lo < a.vbeg) row = kSkipState * n_cls;
+    else row = (lo == a.vbeg || a.in_v0[lo - 1] == (uint8_t)'\n') ? 0u : kSkipState * n_cls;
+    const uint16_t* sym = reinterpret_cast<const uint16_t*>(a.sym_v0);
+    uint64_t cnt = 0;
+    int64_t o = (int64_t)out_base;
+    uint32_t seen = 0;
+    for (int64_t v = lo; row != done_row; v += 16) {
+        const U128 q = direct_load(a, v);
+        const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+#pragma clang loop unroll(disable)
+        for (int k = 0; k < 16 && row != done_row; ++k) {
+            const uint8_t c = (uint8_t)(wd[k >> 2] >> (8 * (k & 3)));
+            const uint64_t e = T.ent[row + sym[v + k]];
+            const uint32_t elo = (uint32_t)e, ehi = (uint32_t)(e >> 32);
+            if (kMode == 1) cnt += str_count(T, elo, ehi);
+            else o = str_emit(T, a.out, o, elo, ehi, c);
+            seen |= elo;
+            row = str_next(elo);
+            if ((elo & kStrEol) && v + k + 1 >= hi) row = done_row;
+        }
+    }
+    if (kMode == 1 && (seen & kStrDiv)) status |= kStDiverge;
+    L.count = cnt;
+}
+
+// =============================================================================================
 // Memoryless tables: out[v] = map[in[v]] for one 16-byte vector at v.
 // =============================================================================================
 TRRE_HD uint32_t map4(const uint8_t* m, uint32_t w) {

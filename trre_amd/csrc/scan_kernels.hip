@@ -1037,6 +1037,67 @@ void launch_rev_sweep(const ScanArgs& a, int tab_bytes, int64_t lane_bytes, void
     else hipLaunchKernelGGL((k_rev_sweep<0, false>), grid, dim3(kRevThreads), tab_bytes, s, a, lane_bytes, 0);
 }
 
+// ---- wide guided tables (16-bit symbols, tables through L1 / L2): scan_block.hpp ------------------------------
+__global__ __launch_bounds__(kRevThreads) void k_rev_wide(ScanArgs a, int64_t lane_bytes) {
+    const RevBlobHeader& h = *reinterpret_cast<const RevBlobHeader*>(a.rblob);
+    const RevWideView T{reinterpret_cast<const uint16_t*>(a.rblob + h.off_wide)};
+    rev_wide_lane(a, T, (int64_t)blockIdx.x * kRevThreads + threadIdx.x, lane_bytes);
+}
+template <int kMode>
+__global__ __launch_bounds__(kDirectThreads) void k_wide_fwd(ScanArgs a, int64_t lane_bytes) {
+    __shared__ uint64_t part[kDirectThreads / kWave];
+    __shared__ uint32_t wpart[kDirectThreads / kWave];
+    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
+    StreamView T;
+    T.cls = a.blob + h.off_cls;
+    T.ent = reinterpret_cast<const uint64_t*>(a.blob + h.off_ent);
+    T.pool = a.blob + h.off_pool;
+    T.long_pool = h.max_out >= 255u;
+    const int64_t lane = (int64_t)blockIdx.x * kDirectThreads + threadIdx.x;
+    DirectLane L;
+    uint32_t st = 0;
+    uint64_t base = 0;
+    if (kMode == 2) {
+        const uint32_t mine = a.lane_counts[lane];
+        const uint32_t incl = wave_scan_incl(mine);
+        if ((threadIdx.x & (kWave - 1)) == kWave - 1) wpart[threadIdx.x / kWave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (int w = 0; w < (int)threadIdx.x / kWave; ++w) wbase += wpart[w];
+        base = a.chunk_base[blockIdx.x] + wbase + incl - mine;
+        if (a.chunk_base[blockIdx.x] + a.chunk_total[blockIdx.x] > a.cap) {
+            if (threadIdx.x == 0) atomicOr(a.status, kStCapacity);
+            return;
+        }
+    }
+    wide_fwd_lane<kMode>(a, T, h.n_cls, lane, lane_bytes, base, L, st);
+    if (kMode == 1 && (st & kStDiverge)) atomicMax(a.status + 1, 0xffffffffu - (uint32_t)lane);     // (see k_stream_direct)
+    if (kMode == 1) {
+        if (L.count > 0xffffffffull) { st |= kStCapacity; L.count = 0xffffffffull; }
+        a.lane_counts[lane] = (uint32_t)L.count;
+        const uint64_t wsum = wave_sum(L.count);
+        if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = wsum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t t = 0;
+            for (int w = 0; w < kDirectThreads / kWave; ++w) t += part[w];
+            a.chunk_total[blockIdx.x] = t;
+        }
+    }
+    st = wave_or(st);
+    if (st && (threadIdx.x & (kWave - 1)) == 0) atomicOr(a.status, st);
+}
+void launch_rev_wide(const ScanArgs& a, int64_t lane_bytes, void* stream) {
+    const int64_t vtop = (a.vend + 63) & ~(int64_t)63;
+    const int64_t n_lanes = (vtop + lane_bytes - 1) / lane_bytes;
+    hipLaunchKernelGGL(k_rev_wide, dim3((unsigned)((n_lanes + kRevThreads - 1) / kRevThreads)), dim3(kRevThreads), 0, static_cast<hipStream_t>(stream), a, lane_bytes);
+}
+void launch_wide_fwd(int which, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (which == 1) hipLaunchKernelGGL((k_wide_fwd<1>), dim3((unsigned)n_blocks), dim3(kDirectThreads), 0, s, a, lane_bytes);
+    else hipLaunchKernelGGL((k_wide_fwd<2>), dim3((unsigned)n_blocks), dim3(kDirectThreads), 0, s, a, lane_bytes);
+}
+
 int stream_chunk_bytes(int which) { return which == 0 ? GeoStream::CHUNK : GeoStreamGen::CHUNK; }
 int stream_block_threads(int which) { return which == 0 ? GeoStream::THREADS : GeoStreamGen::THREADS; }
 

@@ -138,7 +138,7 @@ StreamTables pack_stream_tables(const StreamPackInput& in) {
     t.n_states = n;
     t.pending_len = in.pending_len;
     t.n_cls = (uint32_t)in.col_kind.size();
-    if (t.n_cls > 256 || (uint64_t)n * t.n_cls >= (1u << 24)) throw StreamGiveUp();
+    if ((t.n_cls > 256 && !in.wide_cols) || t.n_cls > 65535 || (uint64_t)n * t.n_cls >= (1u << 24)) throw StreamGiveUp();
     t.ent.resize((size_t)n * t.n_cls);
     std::unordered_map<std::string, uint32_t> pooled;
     bool lp = !in.never_lp, inplace_ok = true;
@@ -190,9 +190,9 @@ StreamTables pack_stream_tables(const StreamPackInput& in) {
     t.ok = true;
     t.bounded = in.bounded;
     if (in.bounded) lp = false;         // (a void launch must be noticed: only the count pass reports it)
-    if (lp) build_window_form(t, in);
-    build_gen16(t, in);
-    build_pairs(t, in);
+    if (lp && !in.wide_cols) build_window_form(t, in);
+    if (!in.wide_cols) build_gen16(t, in);
+    if (!in.wide_cols) build_pairs(t, in);
     if (lp) t.flags |= kFlagLengthPreserving;
     if (lp && inplace_ok) t.flags |= kFlagNoOverrun;    // the in-place kernel may run
     return t;

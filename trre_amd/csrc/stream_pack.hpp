@@ -30,6 +30,7 @@ struct StreamPackInput {
     uint32_t skip = 1, done = 2;
     bool bounded = false;
     bool never_lp = false;                       // the caller knows the program is not length-preserving
+    bool wide_cols = false;                      // more than 256 columns (16-bit symbols of a wide backward DFA): 8-byte entries only
 };
 
 // fills everything but StreamTables::cls
