@@ -47,7 +47,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))   # oracle bindings: verificatio
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 
-KERNEL_OF = {"bytemap": "k_bytemap", "tile_lp": "k_scan_lp", "tile_gen": "k_scan_count + k_scan_emit",
+KERNEL_OF = {"generate": "k_rev_sweep (viability symbols) + host enumeration", "bytemap": "k_bytemap", "tile_lp": "k_scan_lp", "tile_gen": "k_scan_count + k_scan_emit",
              "stream_lp": "k_stream_lpw (window form) / k_stream_g16<emit> alone",
              "stream_gen": "k_stream_g16<count> + <emit> (small tables) / k_stream_direct<count> + <emit>",
              "guided_lp": "k_rev_sweep + k_stream_g16<emit, sym>", "guided_gen": "k_rev_sweep + k_stream_g16<count, sym> + <emit, sym>"}
@@ -186,7 +186,7 @@ def run_config(trre_amd, spec, inp, out, tmp, want_cpu):
         prog.set_kernel({v: k for k, v in trre_amd.KERNEL_NAMES.items()}[spec["force"]])
     info = prog.info
     rec = {"name": spec["name"], "workload": spec["workload"], "engine": spec["engine"], "bytes": n,
-           "kernel_family": trre_amd.KERNEL_NAMES[info.kernel], "kernels": KERNEL_OF[trre_amd.KERNEL_NAMES[info.kernel]]}
+           "kernel_family": trre_amd.KERNEL_NAMES[info.kernel], "kernels": KERNEL_OF.get(trre_amd.KERNEL_NAMES[info.kernel], "?")}
     if len(spec["pattern"]) <= 64:
         rec["pattern"] = spec["pattern"]
     prog.enqueue(inp, out)
@@ -211,7 +211,7 @@ def run_config(trre_amd, spec, inp, out, tmp, want_cpu):
     else:
         veng = spec.get("verify_engine", spec["engine"])
         oracle = Oracle(spec["pattern"], veng)
-        lp = info.kernel in (trre_amd.KERNEL_BYTEMAP, trre_amd.KERNEL_TILE_LP, trre_amd.KERNEL_STREAM_LP, trre_amd.KERNEL_GUIDED_LP)
+        lp = info.kernel in (trre_amd.KERNEL_BYTEMAP, trre_amd.KERNEL_TILE_LP, trre_amd.KERNEL_STREAM_LP, trre_amd.KERNEL_GUIDED_LP) and m == n
         rec["verified"], rec["verify"] = verify_scan(prog, oracle, inp, out, m, lp, spec.get("slice", 4 << 20), tmp)
         if veng != spec["engine"]:
             rec["verify"] += " (the %s oracle: the two engines agree on this prefix-free dictionary)" % veng.upper()
@@ -557,6 +557,20 @@ def main():
         ]
         for spec in printable:
             configs.append(run_config(trre_amd, spec, inp, out, tmp, want_cpu))
+        # the fallbacks, measured rather than assumed: the headline scan on the same corpus with ONE NUL
+        # byte per GiB — a NUL cuts its line short (C-string semantics, trre_dft.c:1277), so the positional launch is void and
+        # the whole buffer runs again on the general family —, and the tile kernels (what a DFT pattern that does not fold runs on)
+        nul_at = [int((k + 0.5) * (1 << 30)) for k in range(n >> 30)] or [n // 2]
+        saved = inp[nul_at].clone()
+        inp[nul_at] = 0
+        configs.append(run_config(trre_amd, {"name": "cfg2_with_nuls", "pattern": "[a:A-z:Z]", "engine": "dft", "steps": 5, "cpu_sample": 0,
+                                             "workload": "headline scan, %d NUL byte(s) in the %.0f GiB: bytemap launch void, the buffer runs again on the "
+                                                         "general family (kernel_ms = both)" % (len(nul_at), n / 2**30)}, inp, out, tmp, False))
+        inp[nul_at] = saved
+        nt = min(n, 1 << 30)
+        configs.append(run_config(trre_amd, {"name": "tile_fallback", "pattern": "a:xyz", "engine": "dft", "steps": 3, "force": "tile_gen",
+                                             "workload": "the LDS-tile kernels (fallback of last resort for DFT patterns that do not fold): 'a:xyz' forced "
+                                                         "through tile_gen, %.0f GiB" % (nt / 2**30)}, inp[:nt], out, tmp, False))
         del inp
         inp = corpora.cat_dog_soup(n, corpora.SEED0 + 4, dev)
         lines = int((inp == 10).sum())

@@ -51,8 +51,8 @@ def test_engine_limits_are_errors_not_fallbacks():
     with pytest.raises(trre_amd.TrreError) as e:
         trre_amd.Program("a(a|b|c|d|e|f|g|h){12}c:x", "nft")
     assert e.value.code == api.E_UNSUPPORTED
-    p = trre_amd.Program("a(a|b|c){9}c:x", "nft")            # 29 nodes: the bitmask tile kernels are preferred to wide tables
-    assert p.info.kernel == trre_amd.KERNEL_TILE_GEN and p.info.guided_rev_states > 256
+    p = trre_amd.Program("a(a|b|c){9}c:x", "nft")            # 29 nodes: the bitmask tile kernels could run it, the wide tables are
+    assert p.info.kernel == trre_amd.KERNEL_GUIDED_GEN and p.info.guided_rev_states > 256 and trre_amd.KERNEL_TILE_GEN in p.allowed_kernels()   # 2x faster
     # an epsilon cycle is not a compile error: like the reference's lazy tables, the scan fails (TRRE_E_DIVERGES) only
     # on an input that makes it explore the cycle (tests/test_front_shim.py, golden 'eps_*' inputs)
     assert trre_amd.Program("(a*)*", "dft").info.dft_states >= 1

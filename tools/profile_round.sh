@@ -38,6 +38,11 @@ cfg4_nft_guided|--case (cat:dog|dog:cat);;nft;;catdog;;guided_lp
 dict1000_dft|--dict 1000 --engine dft
 expand_dft|--case a:xyz;;dft;;printable;;auto
 nft_loop_guided|--case (a|b)*c:x;;nft;;printable;;auto
+tile_dft|--case a:xyz;;dft;;printable;;tile_gen --bytes 268435456
+wide_guided|--case a(a|b|c|d|e|f|g|h){9}c:x;;nft;;printable;;auto --bytes 268435456
 CASES
+# 4. the experimental record + patch form of the general families (TRRE_PATCH=1), kernel-trace stats only
+TRRE_PATCH=1 timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/raw/st_patch -o s -- python tools/kbench.py --case 'a:xyz;;dft;;printable;;auto' --steps 5 > gpurun_out/raw/st_patch.log 2>&1
+{ echo "# TRRE_PATCH=1 kbench --case a:xyz;;dft;;printable;;auto --steps 5"; python tools/rocpd_summary.py gpurun_out/raw/st_patch/s_results.db trre; grep '^pattern' gpurun_out/raw/st_patch.log; } > $out/${tag}_patch_expand_kernel_stats.txt
 rm -rf gpurun_out/raw
 ls -la $out
