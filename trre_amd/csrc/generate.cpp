@@ -201,11 +201,19 @@ bool generate_buffer(const GenTables& g, const uint8_t* in, size_t n, const uint
         cut[t] = nl ? (size_t)(static_cast<const uint8_t*>(nl) - in) + 1 : n;
     }
     std::vector<std::vector<uint8_t>> part(threads);
-    std::vector<char> ok(threads, 1);
+    std::vector<char> ok(threads, 1), oom(threads, 0);
     std::vector<std::thread> th;
     for (int t = 0; t < threads; ++t)
-        th.emplace_back([&, t] { ok[t] = generate_range(g, in, sym, cut[t], cut[t + 1], part[t]) ? 1 : 0; });
+        th.emplace_back([&, t] {
+            try {
+                ok[t] = generate_range(g, in, sym, cut[t], cut[t + 1], part[t]) ? 1 : 0;
+            } catch (const std::bad_alloc&) {      // (the outputs of generator mode are unbounded: an error, not std::terminate)
+                oom[t] = 1;
+            }
+        });
     for (auto& x : th) x.join();
+    for (int t = 0; t < threads; ++t)
+        if (oom[t]) throw std::bad_alloc();
     for (int t = 0; t < threads; ++t) {
         out.insert(out.end(), part[t].begin(), part[t].end());
         if (!ok[t]) return false;                                            // what was printed before the cycle stays printed

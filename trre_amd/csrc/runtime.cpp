@@ -968,7 +968,12 @@ constexpr const char* kDivergeMsg = "error: stack max capacity reached (the refe
 int trre_debug_generate(trre_prog* p, const uint8_t* in, size_t n, const uint8_t* sym, uint8_t* out, size_t cap, size_t* out_len) {
     if (!p || !is_generate(p->mode) || (n && (!in || !sym))) return fail(TRRE_E_ARG, "error: bad argument");
     std::vector<uint8_t> result;
-    const bool ok = trre::generate_buffer(p->gen, in, n, sym, result, 2);
+    bool ok;
+    try {
+        ok = trre::generate_buffer(p->gen, in, n, sym, result, 2);
+    } catch (const std::bad_alloc&) {
+        return fail(TRRE_E_TOO_BIG, "error: out of host memory for the outputs of generator mode");
+    }
     if (out_len) *out_len = result.size();
     if (result.size() > cap) return fail(TRRE_E_CAPACITY, "error: output buffer too small");
     if (!result.empty()) std::memcpy(out, result.data(), result.size());
@@ -986,7 +991,12 @@ int trre_scan_device(trre_prog* p, const uint8_t* d_in, size_t n, uint8_t* d_out
         // the enumeration runs on the host (generate.cpp): input down, output up; the device computes the viability symbols
         if (out_len) *out_len = 0;
         if (n == 0) return TRRE_OK;
-        std::vector<uint8_t> host(n), result;
+        std::vector<uint8_t> host, result;
+        try {
+            host.resize(n);
+        } catch (const std::bad_alloc&) {
+            return fail(TRRE_E_TOO_BIG, "error: out of host memory for generator mode");
+        }
         hipStream_t s = static_cast<hipStream_t>(stream);
         HIP_TRY(hipMemcpyAsync(host.data(), d_in, n, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
