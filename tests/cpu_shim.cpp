@@ -378,6 +378,43 @@ void run_fb_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64_
     }
 }
 
+// The copy form of a large table (k_fb_mark / k_chunk_scan / k_fb_copy): the comb walk marks where the replacement texts go,
+// the copy pass walks no automaton.  ev_cap: ids per lane (small in the tests: the overflow route runs too).
+void run_fb_copy(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64_t& total_out, uint32_t ev_cap) {
+    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
+    const FbView T = fb_view(a);
+    const uint16_t* lit_meta = reinterpret_cast<const uint16_t*>(a.blob + h.off_fb_lit_meta);
+    const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
+    std::vector<uint32_t> hdr((size_t)n_lanes * 4, 0xEEEEEEEEu);
+    std::vector<uint32_t> events((size_t)((n_lanes + 63) / 64) * ev_cap * 64, 0xEEEEEEEEu);
+    FbCopyArgs ca{};
+    ca.events = events.data();
+    ca.lane_hdr = hdr.data();
+    ca.ev_cap = ev_cap;
+    std::vector<uint64_t> cnt(n_lanes), base(n_lanes);
+    uint32_t stage[kMarkStage];
+    for (int64_t lane = n_lanes - 1; lane >= 0; --lane) {      // any order
+        DirectLane L;
+        fb_lane<3>(a, T, lane, lane_bytes, reinterpret_cast<uint8_t*>(stage), 0, L, status, nullptr, &ca);
+        cnt[lane] = L.count;
+    }
+    if (status & (kStEditOverflow | kStNul)) return;
+    uint64_t run = 0;
+    for (int64_t lane = 0; lane < n_lanes; ++lane) { base[lane] = run; run += cnt[lane]; }
+    total_out = run;
+    if (run > a.cap) { status |= kStCapacity; return; }
+    std::vector<U128> lit(h.fb_lits + 1);
+    const uint64_t* tx = reinterpret_cast<const uint64_t*>(a.blob + h.off_fb_lit);
+    for (uint32_t k = 0; k < h.fb_lits; ++k) lit[k] = U128{(uint32_t)tx[k], (uint32_t)(tx[k] >> 32), (uint32_t)lit_meta[k], 0u};
+    FbCopyTables CT;
+    CT.lit = lit.data();
+    CT.esc = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_esc);
+    CT.pool = a.blob + h.off_fb_pool;
+    alignas(16) uint8_t ring[kRingStride];
+    std::memset(a.out, 0xEE, (size_t)run);
+    for (int64_t lane = n_lanes - 1; lane >= 0; --lane) fb_copy_lane(a, CT, ca, lane, lane_bytes, ring, base[lane], status);
+}
+
 // Host emulation of the window kernel (k_stream_lpw): 64 lanes in lockstep over an
 // emulated pair of LDS tiles, the same lane / mover code as the device.
 template <bool kWide>
@@ -517,7 +554,7 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
     a.gscratch = want_scratch ? scratch.data() : nullptr;
     uint32_t status = 0;
     uint64_t total = 0;
-    if (family != 3 && family != 5 && family != 7 && family != 9 && family != 22 && family != 23 && family != 24 && cap < n) return -9;
+    if (family != 3 && family != 5 && family != 7 && family != 9 && family != 22 && family != 23 && family != 24 && family != 25 && cap < n) return -9;
     if (family == 1) { run_bytemap(a, status); total = n; }
     else if (family == 8) {
         if (reinterpret_cast<const StreamBlobHeader*>(blob)->lpw_bytes == 0) return -5;
@@ -545,6 +582,12 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
         total = n;
     } else if (family == 5) {
         if (geo == 0) run_stream_gen<GeoStreamGen>(a, status, total); else run_stream_gen<GeoTinyStream>(a, status, total);
+    }
+    else if (family == 25) {
+        // large table by its copy form
+        const StreamBlobHeader& sh = *reinterpret_cast<const StreamBlobHeader*>(blob);
+        if (!sh.fb_slots || !sh.off_fb_lit_meta) return -5;
+        run_fb_copy(a, geo == 0 ? 2048 : 128, status, total, geo == 0 ? 256u : 64u);
     }
     else if (family == 24) {
         // stream general family by record + patch (16-byte entries; 16-byte aligned inputs only, like the runtime)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Run by tests/test_gpu_fullsize.py::test_dictionary_8gib in a subprocess (TRRE_NO_FB / TRRE_FB_EMIT select the
+"""Run by tests/test_gpu_fullsize.py::test_dictionary_8gib in a subprocess (TRRE_NO_FB_COPY / TRRE_NO_FB / TRRE_FB_EMIT select the
 walkers of the large table; the library reads them once per process).
 
 8 GiB of config 5's corpus through the 1000-entry dictionary, both engines.  No CPU can check 8 GiB (the

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run by tests/test_gpu_parity.py in a subprocess with TRRE_STREAM_IMPL /
-TRRE_LANE_BYTES / TRRE_NO_G16 / TRRE_NO_FB / TRRE_FB_EMIT set: checks the alternative implementations of the stream kernel families
+TRRE_LANE_BYTES / TRRE_NO_G16 / TRRE_NO_FB / TRRE_FB_EMIT / TRRE_NO_FB_COPY set: checks the alternative implementations of the stream kernel families
 against the oracle (the environment is read once per process by the library)."""
 import os
 import random
@@ -51,6 +51,23 @@ def main():
         if p.scan_tensor(t).cpu().numpy().tobytes() != Oracle(pat, eng).scan(text):
             print("MISMATCH dictionary", eng)
             bad += 1
+    # the same table without the empty text has a copy form (TRRE_NO_FB_COPY=1: the count / emit pair): clean input (the copy
+    # form runs), misaligned, a NUL (void launch, rerun), texts every three bytes (more events than a lane's list holds: void
+    # launch, rerun, and the program stops trying)
+    vals[301] = "zz-inner"
+    pat = dictgen.pattern(keys, vals)
+    clean_text = dictgen.corpus(keys, 400000) + (keys[0] + keys[1] + keys[300]).encode()
+    dense = (" ".join(keys[302] for _ in range(4000)) + "\n").encode() * 3
+    for eng in ("dft", "nft"):
+        p = trre_amd.Program(pat, eng)
+        o = Oracle(pat, eng)
+        for buf, skip in ((clean_text, 0), (clean_text, 5), (text, 0), (clean_text[:70000] + dense + clean_text[:5000], 0), (clean_text, 3)):
+            if eng == "nft":
+                buf = buf[: 1 << 17]
+            t = torch.frombuffer(bytearray(b"x" * skip + buf), dtype=torch.uint8).cuda()[skip:]
+            if p.scan_tensor(t).cpu().numpy().tobytes() != o.scan(buf):
+                print("MISMATCH dictionary (copy form)", eng, len(buf), skip)
+                bad += 1
     # the general families whatever implements them (TRRE_PATCH=1: record + patch): small tables, guided tables, edits in
     # every byte of a piece (more than 7 per 64 bytes: overflow records), texts longer than a piece, a diverging line
     for pat, eng in [("a:xyz", "dft"), ("a:", "nft"), (" +: ", "nft"), ("(a|b)*c:x", "nft"), ("[0-9]+:N", "nft"), ("[a-z]:xy", "dft"),

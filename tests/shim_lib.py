@@ -50,7 +50,7 @@ def mask_bytes_of(blob, engine):
 def shim_scan(blob, engine, family, data, geo=1, in_mis=0, out_mis=0, scratch=True, cap=None):
     """Run one kernel family of the device code on the host.  Returns (output bytes, status)."""
     if cap is None:
-        cap = len(data) * 8 + 64 if family in (3, 5, 7, 9, 22, 23, 24) else len(data)     # (20, 21: length-preserving)
+        cap = len(data) * 8 + 64 if family in (3, 5, 7, 9, 22, 23, 24, 25) else len(data)     # (20, 21: length-preserving)
     out = ctypes.create_string_buffer(max(cap, 1))
     m = ctypes.c_size_t()
     st = ctypes.c_uint32()
@@ -69,11 +69,22 @@ def has_fallback_form(prog):
     return bool(blob) and len(blob) >= 144 and struct.unpack_from("<36I", blob, 0)[20] != 0
 
 
+def has_copy_form(prog):
+    """... and the copy form on top of it (StreamBlobHeader::off_fb_lit_meta): every replacement text is non-empty and
+    every cell of the fallback form is a copy, an owed text or an escape that says which input bytes it stands for."""
+    blob = prog.export_stream_tables()
+    return has_fallback_form(prog) and struct.unpack_from("<36I", blob, 0)[34] != 0
+
+
+ST_EDIT_OVERFLOW = 64
+
+
 # shim ids of the guided families (ABI ids 6, 7): LP by the emit pass alone on the 16-byte entries (as the runtime
 # launches it), general on the 16-byte / 8-byte entries, LP by the older LDS-ring walker, LP emit on the 8-byte entries
 GUIDED_LP, GUIDED_GEN, GUIDED_GEN8, GUIDED_LP_RING, GUIDED_LP8 = 10, 11, 12, 13, 14
 GUIDED_LP_ALL = (GUIDED_LP, GUIDED_LP_RING, GUIDED_LP8)
 STREAM_LP_EMIT, STREAM_LP_EMIT8 = 20, 21            # stream LP family by the emit pass alone (no window form)
+STREAM_FB_COPY = 25                                  # ... by its copy form: mark pass + copy pass (what the runtime launches by default)
 STREAM_FB, STREAM_FB_COUNT = 22, 23                  # stream general family on the fallback form of a large table: both passes /
                                                      # the count pass only, emit on the 8-byte rows (what the runtime launches)
 

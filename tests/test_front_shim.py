@@ -297,6 +297,84 @@ def test_fallback_form_of_large_tables():
     assert n_forms >= 6
 
 
+def test_copy_form_of_large_tables():
+    """The copy form (scan_block.hpp: fb_lane<3> marks where the replacement texts go, fb_copy_lane copies the input around
+    them): the golden dictionary slice, then seeded dictionaries — prefix-free or keys inside keys (escape records), texts
+    of 1..8 bytes, partial keys, key upon key, lines of kilobytes, inputs with and without a final newline — at every
+    buffer alignment, both geometries, against the oracle.  A launch may declare itself void (more texts in 64 bytes or in
+    a sub-range than the event lists hold: the runtime then runs the count / emit pair); most must not."""
+    n = void = 0
+    for pat, name, data, eng, exp in golden_lib.cases():
+        if exp is None or len(pat) < 300:
+            continue
+        p = trre_amd.Program(pat, eng)
+        if not shim_lib.has_copy_form(p):
+            continue
+        for geo in (0, 1):
+            out, st = shim_lib.shim_scan(p.export_stream_tables(), p.info.engine, shim_lib.STREAM_FB_COPY, data, geo)
+            assert not st & (shim_lib.ST_EDIT_OVERFLOW | shim_lib.ST_NUL), (name, eng, geo)
+            assert out == exp, (name, eng, geo)
+            n += 1
+    assert n >= 4
+    rng = random.Random(77)
+    forms = 0
+    for it in range(10):
+        letters = "abcdefgh"[:rng.randint(3, 8)]
+        keys = set()
+        while len(keys) < rng.choice([120, 200, 400]):
+            keys.add("".join(rng.choice(letters) for _ in range(rng.randint(2, 7))))
+        keys = sorted(keys)
+        if it % 2:
+            keys = [k for k in keys if not any(o != k and k.startswith(o) for o in keys)]
+        rng.shuffle(keys)
+        vals = ["".join(rng.choice("XYZxyz01") for _ in range(rng.randint(1, 8))) for _ in keys]
+        pat = "|".join("%s:%s" % kv for kv in zip(keys, vals))
+        density = rng.choice([0.1, 0.25, 0.4])
+        toks = []
+        while sum(map(len, toks)) < rng.choice([300, 3000, 9000]):
+            r = rng.random()
+            if r < density:
+                t = rng.choice(keys)
+            elif r < density + 0.1:
+                t = rng.choice(keys)[:rng.randint(1, 6)] + rng.choice(letters)
+            elif r < density + 0.15:
+                t = rng.choice(keys) + rng.choice(keys) + rng.choice(keys)
+            else:
+                t = "".join(rng.choice(letters + "xyz") for _ in range(rng.randint(1, 9)))
+            toks.append(t + rng.choice([" ", " ", "\n", ",", "", ""]))
+        data = "".join(toks).encode() + rng.choice([b"\n", b"", b"\n\n"])
+        if rng.random() < 0.3:
+            data = data.replace(b"\n", b" ", data.count(b"\n") // 2 + 1)      # long lines
+        for eng in ("dft", "nft"):
+            try:
+                p = trre_amd.Program(pat, eng)
+            except trre_amd.TrreError:
+                continue
+            if not shim_lib.has_copy_form(p):
+                continue
+            forms += 1
+            want = Oracle(pat, eng).scan(data)
+            for geo in (0, 1):
+                out, st = shim_lib.shim_scan(p.export_stream_tables(), p.info.engine, shim_lib.STREAM_FB_COPY, data, geo,
+                                             in_mis=rng.choice([0, 0, 1, 5, 15]), out_mis=rng.choice([0, 3, 9]))
+                n += 1
+                if st & shim_lib.ST_EDIT_OVERFLOW:
+                    void += 1
+                    continue
+                assert out == want, (it, eng, geo)
+    assert forms >= 10 and void * 2 < n, (forms, void, n)
+    # a NUL voids the launch; empty replacement texts: no copy form, or one that deletes the key
+    p = trre_amd.Program(pat, "dft")
+    out, st = shim_lib.shim_scan(p.export_stream_tables(), p.info.engine, shim_lib.STREAM_FB_COPY, b"ab\0cd " + keys[0].encode() + b"\n", 0)
+    assert st & shim_lib.ST_NUL
+    for pat2 in (pat + "|zzzzzz:", "|".join("%s:%s" % (k, "" if i % 3 == 0 else v) for i, (k, v) in enumerate(zip(keys, vals)))):
+        p = trre_amd.Program(pat2, "dft")
+        if shim_lib.has_copy_form(p):
+            text = b"a zzzzzz b zzzzz zzzzzzz " + " ".join(keys[:40]).encode() + b"\nzzzzzz\n"
+            out, st = shim_lib.shim_scan(p.export_stream_tables(), p.info.engine, shim_lib.STREAM_FB_COPY, text, 0)
+            assert not st and out == Oracle(pat2, "dft").scan(text)
+
+
 def test_random_replacement_lists():
     """alternations of literal key:value pairs with values of 0..12 bytes and keys that overlap, share
     prefixes and end lines: long outputs (inline, split over two transitions, pooled), all stream families"""

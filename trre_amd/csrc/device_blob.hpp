@@ -52,7 +52,8 @@ struct StreamBlobHeader {
     uint32_t fb_escs, off_fb_esc_slot;        // u32[fb_escs] ascending
     uint32_t off_fb_esc, off_fb_pool;         // escape records (4 words each) and their texts
     uint32_t fb_start[3][2];                  // root, SKIP, DONE: {descriptor, next-state bits of an entry's hi}
-    uint32_t pad2[2];
+    uint32_t off_fb_lit_meta;                 // u16[fb_lits]: the copy form (front.hpp); 0: the tables do not have it
+    uint32_t pad2;
 };
 static_assert(sizeof(StreamBlobHeader) == 144, "header layout");
 

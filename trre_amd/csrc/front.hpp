@@ -228,6 +228,14 @@ struct StreamTables {
     std::vector<uint32_t> fb_esc_slot;      // slots whose entry is an escape, ascending
     std::vector<uint32_t> fb_esc;           // their records, 4 words each: {offset in fb_pool, length, 1 = then the input byte, 0}
     std::vector<uint8_t> fb_pool;           // texts of the escape records
+    // The same automaton read as NET EDITS (the "copy form": scan_block.hpp fb_lane<3> / fb_copy_lane): the output is the
+    // input with a replacement text put where a key stood.  A text is emitted exactly when an owed state is left through
+    // its fallback row, and it then stands for the fb_lit_meta[id] >> 8 input bytes right before the current one (the key,
+    // or the whole pending string of a state that waited for a longer key); an escape record's text stands for the bytes
+    // esc[4 i + 3] says ([7:0] how many, [15:8] how far back the first one lies).  Every other transition only passes
+    // input bytes through, late.  The builder checks this reading cell by cell (fb_copy_ok).
+    bool fb_copy_ok = false;
+    std::vector<uint16_t> fb_lit_meta;      // per literal: [7:0] length of the text, [15:8] input bytes it stands for
 };
 StreamTables build_stream_dft(const Dft& dft, const StreamLimits& lim = StreamLimits());
 StreamTables build_stream_nft(const Nft& nft, const StreamLimits& lim = StreamLimits());

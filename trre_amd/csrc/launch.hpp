@@ -6,6 +6,7 @@ namespace trre {
 
 struct ScanArgs;
 struct PatchArgs;
+struct FbCopyArgs;
 
 constexpr int kEngineNft = 0, kEngineDft = 1;
 
@@ -39,6 +40,10 @@ void launch_lpw_kernel(int ent_bytes, bool wide, bool direct_ent_in_lds, const S
 // blob's header.  Chunks are those of the direct kernels (direct_block_threads() lanes each).
 void launch_fb_kernel(int which, const ScanArgs& a, const void* hdr, int64_t lane_bytes, int64_t n_chunks, void* stream);
 bool fb_fits(const void* hdr);
+// the copy form of a large table (scan_block.hpp): mark pass (count + flags + ids), copy pass (no automaton)
+void launch_fb_mark(const ScanArgs& a, const FbCopyArgs& ca, const void* hdr, int64_t lane_bytes, int64_t n_chunks, void* stream);
+void launch_fb_copy(const ScanArgs& a, const FbCopyArgs& ca, const void* hdr, int64_t lane_bytes, int64_t n_chunks, void* stream);
+bool fb_copy_fits(const void* hdr);
 void launch_chunk_scan(const uint64_t* total, uint64_t* base, int64_t n_chunks, void* stream);
 void launch_bytemap(const ScanArgs& a, void* stream);
 

@@ -79,6 +79,10 @@ struct ScanCtx {
     uint64_t* d_block_total = nullptr;   // [n_blocks], then the group totals [n_groups] (zeroed together)
     uint64_t* d_group_base = nullptr;    // [n_groups + 1]
     int64_t patch_pieces = 0;         // capacity, in pieces
+    // the copy form of a large table (scan_block.hpp fb_lane<3> / fb_copy_lane): events, lane headers
+    uint32_t* d_cevents = nullptr;
+    uint32_t* d_chdr = nullptr;
+    int64_t copy_lanes = 0;
     bool patch_off = false;           // finish() runs the scan again as a count / emit pair (diverged, or out of overflow records)
     int relaunches = 0;               // finish() ran the scan again (scratch, NUL, overflow): whatever was downloaded early is stale
     Pending pend;
@@ -129,6 +133,7 @@ struct trre_prog {
     int mask_bytes = 0;
     bool profiling = false;
     std::atomic<float> last_ms{-1.f};
+    std::atomic<bool> copy_form_off{false};   // a launch of the copy form met more texts than its event lists hold: the count / emit pair from now on
     std::mutex dev_mu;                                  // guards the map (not the states)
     std::map<int, std::unique_ptr<DeviceState>> dev;
 };
@@ -218,7 +223,8 @@ void serialize_stream(const trre::StreamTables& t, std::vector<uint8_t>& b) {
         h.fb_lits = (uint32_t)t.fb_lit.size(); h.off_fb_lit = (uint32_t)off; off = align_up(off + t.fb_lit.size() * 8, 16);
         h.fb_escs = (uint32_t)t.fb_esc_slot.size(); h.off_fb_esc_slot = (uint32_t)off; off = align_up(off + t.fb_esc_slot.size() * 4, 16);
         h.off_fb_esc = (uint32_t)off; off = align_up(off + t.fb_esc.size() * 4, 16);
-        h.off_fb_pool = (uint32_t)off; off += t.fb_pool.size();
+        h.off_fb_pool = (uint32_t)off; off = align_up(off + t.fb_pool.size(), 16);
+        if (t.fb_copy_ok) { h.off_fb_lit_meta = (uint32_t)off; off += t.fb_lit_meta.size() * 2; }
         std::memcpy(h.fb_start, t.fb_start, sizeof h.fb_start);
     }
     off = align_up(off + 16, 16);
@@ -231,6 +237,7 @@ void serialize_stream(const trre::StreamTables& t, std::vector<uint8_t>& b) {
         put(b, h.off_fb_esc_slot, t.fb_esc_slot.data(), t.fb_esc_slot.size());
         put(b, h.off_fb_esc, t.fb_esc.data(), t.fb_esc.size());
         put(b, h.off_fb_pool, t.fb_pool.data(), t.fb_pool.size());
+        if (t.fb_copy_ok) put(b, h.off_fb_lit_meta, t.fb_lit_meta.data(), t.fb_lit_meta.size());
     }
     put(b, h.off_cls, t.cls.data(), 256);
     put(b, h.off_ent, t.ent.data(), t.ent.size());
@@ -358,6 +365,8 @@ void ctx_free(ScanCtx& c) {
     (void)hipFree(c.d_ovf_count);
     (void)hipFree(c.d_block_total);
     (void)hipFree(c.d_group_base);
+    (void)hipFree(c.d_cevents);
+    (void)hipFree(c.d_chdr);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
     if (c.ev1) (void)hipEventDestroy(c.ev1);
     c = ScanCtx();
@@ -415,6 +424,19 @@ int ensure_patch_workspace(ScanCtx* c, int64_t n_pieces) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_block_total), (size_t)(n_blocks + n_groups) * 8));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_group_base), (size_t)(n_groups + 1) * 8));
     c->patch_pieces = n_pieces;
+    return TRRE_OK;
+}
+
+constexpr uint32_t kCopyEvCap = 256;       // events per lane of the copy form (a 2 KiB sub-range of the dictionary corpus holds ~120)
+int ensure_copy_workspace(ScanCtx* c, int64_t n_lanes) {
+    if (n_lanes <= c->copy_lanes) return TRRE_OK;
+    (void)hipFree(c->d_cevents); (void)hipFree(c->d_chdr);
+    c->d_cevents = nullptr; c->d_chdr = nullptr;
+    c->copy_lanes = 0;
+    // (events: [wave][slot][lane of the wave], 4 bytes each)
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_cevents), (size_t)((n_lanes + 63) / 64) * kCopyEvCap * 256));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_chdr), (size_t)n_lanes * 16));
+    c->copy_lanes = n_lanes;
     return TRRE_OK;
 }
 
@@ -550,11 +572,31 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
         // staging rings per CU.  TRRE_NO_FB=1: both passes on the 8-byte rows, for A/B runs.
         static const bool fb_emit_env = getenv("TRRE_FB_EMIT") != nullptr;
         const bool fb_emit = fb_emit_env && fb_fits(p->sblob.data());         // (the form next to 512 staging rings)
+        // The copy form (default where the tables have it): the comb walk also lists where the replacement texts go, the
+        // second pass copies the input around them without walking any table (scan_block.hpp).  TRRE_NO_FB_COPY=1: the
+        // count pass + the emit pass on the 8-byte rows, for A/B runs and what finish() falls back to (a NUL in the input,
+        // more texts in a sub-range than its event list holds).
+        static const bool no_copy_env = getenv("TRRE_NO_FB_COPY") != nullptr;
+        if (!no_copy_env && !fb_emit_env && !cx->patch_off && !p->copy_form_off.load() && lane_bytes % 64 == 0 && fb_copy_fits(p->sblob.data())) {
+            const int64_t n_lanes = n_chunks * direct_block_threads();
+            rc = ensure_copy_workspace(cx, n_lanes);
+            if (rc) return rc;
+            FbCopyArgs ca{};
+            ca.events = cx->d_cevents;
+            ca.lane_hdr = cx->d_chdr;
+            ca.ev_cap = kCopyEvCap;
+            launch_fb_mark(args, ca, p->sblob.data(), lane_bytes, n_chunks, stream);
+            launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);
+            launch_fb_copy(args, ca, p->sblob.data(), lane_bytes, n_chunks, stream);
+            pd.total_at = cx->d_chunk_base + n_chunks;
+            pd.patched = true;
+        } else {
         launch_fb_kernel(1, args, p->sblob.data(), lane_bytes, n_chunks, stream);
         launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);
         if (fb_emit) launch_fb_kernel(2, args, p->sblob.data(), lane_bytes, n_chunks, stream);
         else launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, 0, sym_mode, g16_slow);
         pd.total_at = cx->d_chunk_base + n_chunks;
+        }
     } else if (direct) {
         const int g16 = stt.g16_ok && !no_g16_env ? (int)(align_up(stt.g16.size() * 4, 16) + stt.p32.size() * 4) : 0;   // LDS room: 16-byte + pair forms
         if (is_guided(family)) launch_rev_sweep(args, (int)p->gt.n_rev * 256, lane_bytes, stream, sym_mode == 2);
@@ -685,8 +727,11 @@ int finish(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
         }
         return again(was.family);
     }
-    if (was.patched && (status & kStEditOverflow)) {
-        // more pieces with more than 7 edits than there are overflow records (or an edit text of kilobytes): the count / emit pair
+    if (was.patched && (status & (kStEditOverflow | kStNul))) {
+        // record + patch: more pieces with more than 7 edits than there are overflow records (or an edit text of kilobytes); copy
+        // form of a large table: more texts in a sub-range (or in 64 bytes of it) than its event list holds, or a NUL byte —
+        // the count / emit pair
+        if (status & kStEditOverflow) p->copy_form_off.store(true);      // (a property of the dictionary and its corpus: do not try again)
         cx->patch_off = true;
         const int rc = again(was.family);
         cx->patch_off = false;

@@ -1686,6 +1686,17 @@ struct FbView {
     uint32_t n_esc;
     uint32_t start[3][2];      // root, SKIP, DONE: {descriptor, about bits}
 };
+// the mark pass's product (the copy form, below): events and lane headers
+constexpr int kMarkStage = 16;                 // events a lane can collect per 64 input bytes (LDS, 17 dwords apart)
+constexpr int kMarkStageStride = 17;
+struct FbCopyArgs {
+    uint32_t* events;          // [n_waves][ev_cap][64]
+    uint32_t* lane_hdr;        // [n_lanes][4]: {events, first line start, end of the last line (offsets from the sub-range's start), -}
+    uint32_t ev_cap;
+};
+TRRE_HD uint32_t* copy_event_slot(const FbCopyArgs& ca, int64_t lane, uint32_t slot) {
+    return ca.events + ((size_t)(lane >> 6) * ca.ev_cap + slot) * 64u + (size_t)(lane & 63);
+}
 // the record of the escape entry in slot `slot`
 TRRE_HD const uint32_t* fb_esc_record(const FbView& T, uint32_t slot) {
     uint32_t lo = 0, hi = T.n_esc;
@@ -1697,8 +1708,8 @@ TRRE_HD const uint32_t* fb_esc_record(const FbView& T, uint32_t slot) {
 }
 template <int kMode>
 TRRE_HD void fb_lane(const ScanArgs& a, const FbView& T, int64_t lane, int64_t lane_bytes, uint8_t* ring, uint64_t out_base, DirectLane& L,
-                     uint32_t& status, uint32_t* wave_scratch = nullptr) {
-    static_assert(kMode == 1 || kMode == 2, "count or emit");
+                     uint32_t& status, uint32_t* wave_scratch = nullptr, const FbCopyArgs* ca = nullptr) {
+    static_assert(kMode == 1 || kMode == 2 || kMode == 3, "count, emit, or mark (count + the copy form's events)");
     const int64_t lo = lane * lane_bytes;
     int64_t hi = lo + lane_bytes;
     if (hi > a.vend) hi = a.vend;
@@ -1716,9 +1727,22 @@ TRRE_HD void fb_lane(const ScanArgs& a, const FbView& T, int64_t lane, int64_t l
     uint64_t cnt = 0;
     uint64_t hist = 0;                                                // the last 7 input bytes: byte 6 = the one before the current
     const int64_t vlast = (a.vend - 1) & ~(int64_t)15;               // the last readable aligned block
+    // mark: the lane's events, where its first line starts and where its last line ends
+    // (events are collected in the lane's stage — LDS, kMarkStage dwords — and leave for memory after every 64 input bytes:
+    // a store to memory per event, some lane of the wave has one at almost every byte, held the walk up for the store's
+    // round trip: 2.25 ms per GiB against 0.86 for the count walk alone)
+    uint32_t* evp = nullptr;
+    uint32_t* const stage0 = reinterpret_cast<uint32_t*>(ring);
+    uint32_t* sp = stage0;
+    uint32_t n_ev = 0, b_rel = 0, e_rel = 0, nul = 0, far = 0, esc_index = 0;
+    if (kMode == 3) {
+        evp = copy_event_slot(*ca, lane, 0);
+        if (first == 1) b_rel = (uint32_t)(first_line_start_safe(a, lo, hi) - lo);
+    }
     // an escape entry: the output spelled out in global memory (rare)
     auto esc_count = [&](uint32_t slot) -> uint32_t {
         const uint32_t* r = fb_esc_record(T, slot);
+        if (kMode == 3) esc_index = (uint32_t)((r - T.esc) >> 2);
         return r[1] + r[2];
     };
     auto esc_emit = [&](uint32_t slot, uint32_t c) {
@@ -1735,6 +1759,7 @@ TRRE_HD void fb_lane(const ScanArgs& a, const FbView& T, int64_t lane, int64_t l
     auto dword = [&](auto end_tag, const uint32_t w, const uint32_t rp) {
         constexpr bool kEnd = decltype(end_tag)::value;
         const uint32_t kk[4] = {T.cls[w & 0xffu], T.cls[(w >> 8) & 0xffu], T.cls[(w >> 16) & 0xffu], T.cls[w >> 24]};
+        if (kMode == 3) nul |= (w - 0x01010101u) & ~w & 0x80808080u;          // a zero byte in these four
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t k = kk[j], c = (w >> (8 * j)) & 0xffu;
@@ -1746,12 +1771,24 @@ TRRE_HD void fb_lane(const ScanArgs& a, const FbView& T, int64_t lane, int64_t l
             const uint32_t owed = st >> 31;
             const uint32_t n_rec = mine ? 0u : ((st >> 28) & 7u) + owed;
             const bool esc = (eh & (kFbCc | kFbNl)) == (kFbCc | kFbNl);
-            if (kMode == 1) {
+            if (kMode == 1 || kMode == 3) {
                 uint32_t add = n_rec + ((eh >> 14) & 7u) + ((eh >> 17) & 1u) + ((eh >> 18) & 1u);
+                // mark: an owed state left through its fallback row emits its text now (it stands for the bytes right before this one)
+                bool ev = kMode == 3 && owed && !mine;
+                uint32_t id = ab >> 20;
                 if (TRRE_WAVE_ANY(esc)) {
-                    if (esc) add = n_rec + esc_count(mine ? base + k : fbase + k);
+                    if (esc) {
+                        add = n_rec + esc_count(mine ? base + k : fbase + k);
+                        if (kMode == 3) { ev = true; id = 0x8000u | esc_index; }
+                    }
                 }
                 cnt += add;
+                if (kMode == 3) {
+                    if (ev) *sp = (rp + (uint32_t)j) | id << 16;
+                    uint32_t* const nsp = sp + 1 < stage0 + (kMarkStage - 1) ? sp + 1 : stage0 + (kMarkStage - 1);   // (a full stage: the launch is void)
+                    sp = ev ? nsp : sp;
+                    if (kEnd && ev && rp + (uint32_t)j > 0xffffu) far = 1;
+                }
             } else {
                 const uint32_t about = ab >> 20;                      // of the current state: pending length, or the owed text's index
                 const uint32_t n_tot = n_rec + ((eh >> 14) & 7u);     // 0..8 bytes of prefix (an escape entry has none of its own)
@@ -1764,6 +1801,7 @@ TRRE_HD void fb_lane(const ScanArgs& a, const FbView& T, int64_t lane, int64_t l
             }
             hist = (hist >> 8) | (uint64_t)c << 48;
             const bool fin = kEnd && (eh & kFbEol) && rp + (uint32_t)j + 1u >= rhi;
+            if (kMode == 3 && kEnd && fin && st != done_st) e_rel = rp + (uint32_t)j + 1u;
             st = fin ? done_st : (uint32_t)e;
             ab = fin ? done_ab : eh;
         }
@@ -1775,7 +1813,7 @@ TRRE_HD void fb_lane(const ScanArgs& a, const FbView& T, int64_t lane, int64_t l
         for (int d = 0; d < 4; ++d) {
             dword(end_tag, d == 0 ? b.x : (d == 1 ? b.y : (d == 2 ? b.z : b.w)), rp + 4u * (uint32_t)d);
             if (kMode == 2) stage_flush<false>(S);
-            if (kMode == 1) TRRE_PIN(cnt);
+            if (kMode == 1 || kMode == 3) TRRE_PIN(cnt);
             TRRE_SCHED_FENCE();
         }
     };
@@ -1813,11 +1851,190 @@ TRRE_HD void fb_lane(const ScanArgs& a, const FbView& T, int64_t lane, int64_t l
                 block(std::true_type{}, b, rp + 16u * (uint32_t)q);
             }
         }
+        if (kMode == 3) {
+            // the piece's events: slot by slot, the lanes of the wave side by side (copy_event_slot)
+            const uint32_t n_loc = (uint32_t)(sp - stage0);
+            if (n_loc >= (uint32_t)kMarkStage - 1u) far = 1;
+            for (uint32_t k = 0; TRRE_WAVE_ANY(k < n_loc); ++k) {
+                if (k < n_loc && n_ev + k < ca->ev_cap) evp[(size_t)k * 64u] = stage0[k];
+            }
+            evp += (size_t)n_loc * 64u;
+            n_ev += n_loc;
+            sp = stage0;
+        }
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     }
     if (kMode == 2) stage_flush<true>(S);
+    if (kMode == 3) {
+        if (n_ev > ca->ev_cap || far) status |= kStEditOverflow;
+        if (nul) status |= kStNul;
+        uint32_t* hdr = ca->lane_hdr + (size_t)lane * 4;
+        hdr[0] = n_ev < ca->ev_cap ? n_ev : ca->ev_cap;
+        hdr[1] = b_rel;
+        hdr[2] = b_rel < rhi ? e_rel : b_rel;          // (no line starts in the sub-range: the lane has nothing to copy)
+        hdr[3] = 0;
+    }
     (void)status;
     L.count = cnt;
+}
+
+// =============================================================================================
+// The copy form of a large table (front.hpp, StreamTables::fb_copy_ok): the dictionary's second pass without a table
+// walk.  The emit pass over the 8-byte rows of such a table costs 70 instructions per byte: most of it the
+// walk itself.  But the automaton's output is the input with EDITS — a replacement text where a key stood — and the count
+// walk over the comb in LDS (fb_lane<1>: 29 instructions per byte) sees every edit go by:
+//
+//   fb_lane<3>     (mark) the count walk, plus one 4-byte EVENT per edit, in input order: [15:0] the position (from the
+//                  start of the lane's sub-range) of the byte on which the text came out — a text is known only when its
+//                  key is complete: it stands for the kb bytes right before that byte — and [31:16] the text's id
+//                  (0x8000 | index: an escape record).  Plus the lane's first line start and the end of its last line.
+//   fb_copy_lane   no automaton: input and events in, copy the bytes, insert the texts, skip what they stand for.
+//                  Per input dword and event: the bytes before the text, the text, and on the next turn the bytes after
+//                  it, each one append of a contiguous byte range with no branch on the data.
+//
+// A lane's events are 256 bytes apart: slot i of the 64 lanes of a wave is one 256-byte row (copy_event_slot).  The lanes
+// of a wave reach slot i at about the same time, so a row is written, and later read, as whole cache lines; a lane's
+// own run of slots (the first layout) was one line per lane and load, refetched for every slot: the pass ran at the
+// pace of those fetches, 2.0 ms per GiB instead of 0.7.
+// A NUL ends a line early (the rest of the record is swallowed, not passed through): the launch is void and the count /
+// emit pair runs (kStNul), as for the length-preserving kernels.  So does a lane with more than ev_cap events, or with an
+// event more than 64 KiB behind its start (a very long last line): kStEditOverflow.
+// =============================================================================================
+
+// what the copy pass needs about a literal: its text (8 bytes, zero beyond its length), its length and the input bytes it stands for
+struct FbCopyTables {
+    const U128* lit;           // [fb_lits] {text lo, text hi, n | kb << 8, -}  (LDS)
+    const uint32_t* esc;       // escape records (global) ...
+    const uint8_t* pool;       // ... and their texts
+};
+TRRE_HD uint32_t copy_mask(uint32_t cnt) { return cnt >= 4u ? 0xffffffffu : (1u << (8u * cnt)) - 1u; }
+template <class Dummy = void>
+TRRE_HD void fb_copy_lane(const ScanArgs& a, const FbCopyTables& T, const FbCopyArgs& ca, int64_t lane, int64_t lane_bytes, uint8_t* ring,
+                          uint64_t out_base, uint32_t& status, uint32_t* wave_scratch = nullptr) {
+    const int64_t lo = lane * lane_bytes;
+    const bool exists = lo < a.vend;
+    const uint32_t* hdr = ca.lane_hdr + (size_t)lane * 4;
+    uint32_t n_ev = exists ? hdr[0] : 0u;
+    const uint32_t b_rel = exists ? hdr[1] : 0u, e_rel = exists ? hdr[2] : 0u;
+    int64_t end = lo + (int64_t)e_rel;
+    if (end > a.vend) end = a.vend;
+    int64_t v = (lo + (int64_t)b_rel) & ~(int64_t)63;
+    uint32_t skip = (uint32_t)(lo + (int64_t)b_rel - v);                   // bytes still to drop: up to the first line start, then what the texts stand for
+    if (e_rel <= b_rel) { v = lo; end = lo; n_ev = 0; skip = 0; }
+    uint32_t prel = (uint32_t)(v - lo);                                    // position of the piece, as the events count it
+    Stage S{};
+    S.dbg = a.dbg;
+    S.wsc = wave_scratch;
+    stage_begin(S, ring, a.out + out_base);
+    // the event in front of the lane, decoded: where its text goes, the text, and what it stands for; the raw event after
+    // it is already here, the one after that on its way (a lane meets a text every ~20 bytes)
+    const uint32_t* evp = copy_event_slot(ca, lane, 0);
+    uint32_t nfp = 0xffffffffu, nn = 0, nkb = 0, nesc = 0;                // nesc: 1 + offset of an escape's text in the pool
+    uint64_t ntext = 0;
+    uint32_t raw1 = n_ev > 1u ? evp[64] : 0u;
+    uint32_t taken = 0;                                                    // events decoded so far
+    auto decode = [&](uint32_t raw) {
+        const uint32_t id = raw >> 16, pos = raw & 0xffffu;
+        nesc = 0;
+        if (!(id & 0x8000u)) {
+            const U128 r = T.lit[id];
+            ntext = (uint64_t)r.x | (uint64_t)r.y << 32;
+            nn = r.z & 255u;
+            nkb = r.z >> 8;
+            nfp = pos - nkb;
+        }
+        if (TRRE_WAVE_ANY((id & 0x8000u) != 0u)) {
+            if (id & 0x8000u) {
+                const uint32_t* r = T.esc + 4u * (id & 0x7fffu);
+                nesc = 1u + r[0];
+                nn = r[1];
+                nkb = r[3] & 255u;
+                nfp = pos - (r[3] >> 8);
+            }
+        }
+    };
+    if (n_ev) { decode(evp[0]); taken = 1; }
+    auto advance = [&]() {               // (only lanes that met their event call this)
+        if (taken < n_ev) {
+            decode(raw1);
+            ++taken;
+            if (taken < n_ev) raw1 = evp[(size_t)taken * 64u];
+        } else {
+            nfp = 0xffffffffu;
+        }
+    };
+    const int64_t vlast = (a.vend - 1) & ~(int64_t)15;
+    // a piece's input is requested while the piece before it is copied
+    auto fetch = [&](int64_t at, U128* c) {
+        const int64_t vv = at < end ? at : lo;                             // (a finished lane reads something harmless)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t x = vv + 16 * q < vlast ? vv + 16 * q : vlast;
+            c[q] = *reinterpret_cast<const U128*>(a.in_v0 + x);
+        }
+        if (TRRE_WAVE_ANY(vv < a.vbeg || vv + 64 > a.vend - 1)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c[q] = direct_load(a, vv + 16 * q);
+        }
+    };
+    U128 c[4], nx[4];
+    fetch(v, c);
+    for (;; v += 64, prel += 64u) {
+        const bool act = v < end;
+        if (!TRRE_WAVE_ANY(act)) break;
+        fetch(v + 64, nx);
+        const int32_t rem = !act ? 0 : (end - v >= 64 ? 64 : (int32_t)(end - v));
+#pragma clang loop unroll(disable)
+        for (int q = 0; q < 4; ++q) {
+            // (selects, not an indexed array: that would live in scratch memory)
+            U128 b;
+            b.x = q == 0 ? c[0].x : (q == 1 ? c[1].x : (q == 2 ? c[2].x : c[3].x));
+            b.y = q == 0 ? c[0].y : (q == 1 ? c[1].y : (q == 2 ? c[2].y : c[3].y));
+            b.z = q == 0 ? c[0].z : (q == 1 ? c[1].z : (q == 2 ? c[2].z : c[3].z));
+            b.w = q == 0 ? c[0].w : (q == 1 ? c[1].w : (q == 2 ? c[2].w : c[3].w));
+#pragma clang loop unroll(disable)
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t w = r == 0 ? b.x : (r == 1 ? b.y : (r == 2 ? b.z : b.w));
+                const uint32_t p = prel + 16u * (uint32_t)q + 4u * (uint32_t)r;
+                const int32_t left = rem - (16 * q + 4 * r);               // input bytes of the lane from this dword on
+                const uint32_t nval = left <= 0 ? 0u : (left >= 4 ? 4u : (uint32_t)left);
+                uint32_t cur = 0;                                          // bytes of the dword dealt with
+                for (;;) {
+                    const bool has = nfp - p < nval;                       // a text goes in front of one of these bytes
+                    const uint32_t fpos = has ? nfp - p : nval;
+                    // the bytes up to there (those that an earlier text does not stand for)
+                    const uint32_t gap = fpos - cur;
+                    const uint32_t a0 = skip < gap ? skip : gap;
+                    const uint32_t from = cur + a0, cnt = fpos - from;
+                    stage_append_n4(S, (w >> (8u * (from & 3u))) & copy_mask(cnt), cnt);
+                    skip -= a0;
+                    cur = fpos;
+                    if (!TRRE_WAVE_ANY(has)) break;
+                    if (has) {
+                        if (!nesc) stage_append(S, ntext, nn);
+                    }
+                    if (TRRE_WAVE_ANY(has && nesc)) {
+                        if (has && nesc) {                                 // a text spelled out in memory: straight to memory (rare)
+                            const uint8_t* text = T.pool + (nesc - 1u);
+                            stage_flush_solo(S);
+                            uint8_t* gp = stage_out_ptr(S);
+                            for (uint32_t i = 0; i < nn; ++i) gp[i] = text[i];
+                            stage_begin(S, S.buf, gp + nn);
+                        }
+                    }
+                    if (has) {
+                        skip = nkb;
+                        advance();
+                    }
+                }
+                stage_flush<false>(S);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c[q] = nx[q];
+    }
+    stage_flush<true>(S);
+    (void)status;
 }
 
 // =============================================================================================

@@ -687,6 +687,97 @@ __global__ __launch_bounds__(kThreads, (kMode == 1 ? 8 : 2)) void k_stream_fb(Sc
     st = wave_or(st);
     if (st && (threadIdx.x & (kWave - 1)) == 0) atomicOr(a.status, st);
 }
+// The copy form of a large table (scan_block.hpp: fb_lane<3> / fb_copy_lane).
+// Mark pass: the comb walk of k_stream_fb<1> plus the events; one 1024-lane workgroup per CU (the event stages take the
+// LDS the count pass's second workgroup has).   smem: cls[256] | comb | event stages[1024 x 68] | 64 x groups
+constexpr int kFbMarkThreads = 1024;
+__global__ __launch_bounds__(kFbMarkThreads, 4) void k_fb_mark(ScanArgs a, FbCopyArgs ca, int64_t lane_bytes, int64_t n_chunks) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
+    const uint32_t comb_bytes = (h.fb_slots * 8u + 15u) & ~15u;
+    for (int k = threadIdx.x; k < 256; k += kFbMarkThreads) smem[k] = a.blob[h.off_cls + k];
+    {
+        const U128* e = reinterpret_cast<const U128*>(a.blob + h.off_fb_comb);
+        U128* d = reinterpret_cast<U128*>(smem + 256);
+        for (int k = threadIdx.x; k < (int)(comb_bytes / 16); k += kFbMarkThreads) d[k] = e[k];
+    }
+    __syncthreads();
+    FbView T;
+    T.cls = smem;
+    T.comb = reinterpret_cast<const uint64_t*>(smem + 256);
+    T.lit = nullptr;
+    T.esc_slot = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_esc_slot);
+    T.esc = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_esc);
+    T.pool = a.blob + h.off_fb_pool;
+    T.n_esc = h.fb_escs;
+    for (int i = 0; i < 3; ++i) { T.start[i][0] = h.fb_start[i][0]; T.start[i][1] = h.fb_start[i][1]; }
+    uint8_t* stage = smem + 256 + comb_bytes + threadIdx.x * (kMarkStageStride * 4);
+    uint8_t* tail = smem + 256 + comb_bytes + kFbMarkThreads * (kMarkStageStride * 4);
+    constexpr int kGroups = kFbMarkThreads / kDirectThreads;
+    const int group = threadIdx.x / kDirectThreads, gtid = threadIdx.x % kDirectThreads;
+    const int64_t chunk = (int64_t)blockIdx.x * kGroups + group;
+    const int64_t lane = chunk * kDirectThreads + gtid;
+    const bool live = chunk < n_chunks;
+    DirectLane L;
+    uint32_t st = 0;
+    // (a lane of a chunk beyond the workspace is not walked: it has no header and no events)
+    if (live) fb_lane<3>(a, T, lane, lane_bytes, stage, 0, L, st, nullptr, &ca);
+    uint64_t* part = reinterpret_cast<uint64_t*>(tail + 64 * group);
+    if (L.count > 0xffffffffull) { st |= kStCapacity; L.count = 0xffffffffull; }
+    if (live) a.lane_counts[lane] = (uint32_t)L.count;
+    const uint64_t wsum = wave_sum(live ? L.count : 0ull);
+    if ((threadIdx.x & (kWave - 1)) == 0) part[gtid / kWave] = wsum;
+    __syncthreads();
+    if (gtid == 0 && live) {
+        uint64_t t = 0;
+        for (int w = 0; w < kDirectThreads / kWave; ++w) t += part[w];
+        a.chunk_total[chunk] = t;
+    }
+    st = wave_or(st);
+    if (st && (threadIdx.x & (kWave - 1)) == 0) atomicOr(a.status, st);
+}
+// Copy pass: no automaton.  kThreads / 256 chunks per workgroup: as many lanes per CU as the rings leave room for (they
+// share the literals).   smem: literals[fb_lits x 16] | rings[kThreads] | 64 x groups | posting tables
+template <int kThreads>
+__global__ __launch_bounds__(kThreads) void k_fb_copy(ScanArgs a, FbCopyArgs ca, int64_t lane_bytes, int64_t n_chunks) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
+    U128* lit = reinterpret_cast<U128*>(smem);
+    {
+        const uint64_t* tx = reinterpret_cast<const uint64_t*>(a.blob + h.off_fb_lit);
+        const uint16_t* m = reinterpret_cast<const uint16_t*>(a.blob + h.off_fb_lit_meta);
+        for (int k = threadIdx.x; k < (int)h.fb_lits; k += kThreads) lit[k] = U128{(uint32_t)tx[k], (uint32_t)(tx[k] >> 32), (uint32_t)m[k], 0u};
+    }
+    constexpr int kGroups = kThreads / kDirectThreads;
+    uint8_t* top = smem + h.fb_lits * 16u;
+    uint8_t* ring = top + threadIdx.x * kRingStride;
+    uint8_t* tail = top + kThreads * kRingStride;
+    const int group = threadIdx.x / kDirectThreads, gtid = threadIdx.x % kDirectThreads;
+    const int64_t chunk = (int64_t)blockIdx.x * kGroups + group;
+    const int64_t lane = chunk * kDirectThreads + gtid;
+    const bool live = chunk < n_chunks;
+    uint32_t* wpart = reinterpret_cast<uint32_t*>(tail + 64 * group);
+    const uint32_t mine = live ? a.lane_counts[lane] : 0u;
+    const uint32_t incl = wave_scan_incl(mine);
+    if ((threadIdx.x & (kWave - 1)) == kWave - 1) wpart[gtid / kWave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < gtid / kWave; ++w) wbase += wpart[w];
+    const uint64_t base = live ? a.chunk_base[chunk] + wbase + incl - mine : 0ull;
+    // (bases grow with the chunk index: if the last chunk of this workgroup does not fit, the output is void anyway)
+    const int64_t last = ((int64_t)blockIdx.x + 1) * kGroups - 1 < n_chunks - 1 ? ((int64_t)blockIdx.x + 1) * kGroups - 1 : n_chunks - 1;
+    if (a.chunk_base[last] + a.chunk_total[last] > a.cap) {
+        if (threadIdx.x == 0) atomicOr(a.status, kStCapacity);
+        return;
+    }
+    FbCopyTables T;
+    T.lit = lit;
+    T.esc = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_esc);
+    T.pool = a.blob + h.off_fb_pool;
+    uint32_t* wsc = reinterpret_cast<uint32_t*>(tail + 64 * kGroups) + (threadIdx.x / kWave) * (kWaveScratchBytes / 4);
+    uint32_t st = 0;
+    if (live) fb_copy_lane(a, T, ca, lane, lane_bytes, ring, base, st, wsc);
+}
 // ------------------------------------------------------------------------------------------
 // memoryless byte map: out[v] = map[in[v]], 16 bytes per lane per step
 constexpr int kMapThreads = 256;
@@ -1096,6 +1187,40 @@ void launch_wide_fwd(int which, const ScanArgs& a, int64_t lane_bytes, int64_t n
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (which == 1) hipLaunchKernelGGL((k_wide_fwd<1>), dim3((unsigned)n_blocks), dim3(kDirectThreads), 0, s, a, lane_bytes);
     else hipLaunchKernelGGL((k_wide_fwd<2>), dim3((unsigned)n_blocks), dim3(kDirectThreads), 0, s, a, lane_bytes);
+}
+
+void launch_fb_mark(const ScanArgs& a, const FbCopyArgs& ca, const void* hdr, int64_t lane_bytes, int64_t n_chunks, void* stream) {
+    const StreamBlobHeader& h = *static_cast<const StreamBlobHeader*>(hdr);
+    constexpr int kG = kFbMarkThreads / kDirectThreads;
+    const int lds = 256 + (int)((h.fb_slots * 8u + 15u) & ~15u) + kFbMarkThreads * kMarkStageStride * 4 + 64 * kG;
+    allow_big_lds<&k_fb_mark>();
+    hipLaunchKernelGGL(k_fb_mark, dim3((unsigned)((n_chunks + kG - 1) / kG)), dim3(kFbMarkThreads), lds, static_cast<hipStream_t>(stream), a, ca, lane_bytes, n_chunks);
+}
+// workgroup size of the copy pass: the largest whose rings fit next to the literals
+int fb_copy_lds(const StreamBlobHeader& h, int threads) {
+    return (int)h.fb_lits * 16 + threads * kRingStride + 64 * (threads / kDirectThreads) + (threads / kWave) * kWaveScratchBytes;
+}
+void launch_fb_copy(const ScanArgs& a, const FbCopyArgs& ca, const void* hdr, int64_t lane_bytes, int64_t n_chunks, void* stream) {
+    const StreamBlobHeader& h = *static_cast<const StreamBlobHeader*>(hdr);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    static const int want = getenv("TRRE_COPY_THREADS") ? atoi(getenv("TRRE_COPY_THREADS")) : 1024;      // (A/B runs)
+    if (want >= 1024 && fb_copy_lds(h, 1024) <= kLdsLimit) {
+        allow_big_lds<&k_fb_copy<1024>>();
+        hipLaunchKernelGGL(k_fb_copy<1024>, dim3((unsigned)((n_chunks + 3) / 4)), dim3(1024), fb_copy_lds(h, 1024), s, a, ca, lane_bytes, n_chunks);
+    } else if (want >= 512 && fb_copy_lds(h, 512) <= kLdsLimit) {
+        allow_big_lds<&k_fb_copy<512>>();
+        hipLaunchKernelGGL(k_fb_copy<512>, dim3((unsigned)((n_chunks + 1) / 2)), dim3(512), fb_copy_lds(h, 512), s, a, ca, lane_bytes, n_chunks);
+    } else {
+        allow_big_lds<&k_fb_copy<256>>();
+        hipLaunchKernelGGL(k_fb_copy<256>, dim3((unsigned)n_chunks), dim3(256), fb_copy_lds(h, 256), s, a, ca, lane_bytes, n_chunks);
+    }
+}
+// the copy form's LDS fits
+bool fb_copy_fits(const void* hdr) {
+    const StreamBlobHeader& h = *static_cast<const StreamBlobHeader*>(hdr);
+    if (!h.off_fb_lit_meta) return false;
+    const int mark = 256 + (int)((h.fb_slots * 8u + 15u) & ~15u) + kFbMarkThreads * kMarkStageStride * 4 + 256;
+    return mark <= kLdsLimit && fb_copy_lds(h, 256) <= kLdsLimit;
 }
 
 int stream_chunk_bytes(int which) { return which == 0 ? GeoStream::CHUNK : GeoStreamGen::CHUNK; }

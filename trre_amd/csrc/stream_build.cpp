@@ -480,20 +480,27 @@ private:
         auto pending = [&](uint32_t s) { return (s == skip_ || s == done_) ? std::string() : names_[s]; };
         for (uint32_t s = 0; s < n0; ++s)
             if (pending(s).size() > 7) return;                                 // the kernels keep 8 bytes of history; a transition appends at most 9
-        std::map<std::string, uint32_t> lits;                                  // owed texts and literal prefixes
+        // owed texts and literal prefixes, each with the number of input bytes it stands for (the copy form reads the
+        // automaton as net edits: front.hpp) — the same text for another number of bytes is another literal
+        std::map<std::pair<std::string, uint32_t>, uint32_t> lits;
         std::vector<std::string> lit_text;
-        auto lit_id = [&](const std::string& L) {
-            auto hit = lits.find(L);
+        std::vector<uint32_t> lit_kb;
+        auto lit_id = [&](const std::string& L, uint32_t kb) {
+            auto hit = lits.find(std::make_pair(L, kb));
             if (hit == lits.end()) {
-                hit = lits.emplace(L, (uint32_t)lit_text.size()).first;
+                hit = lits.emplace(std::make_pair(L, kb), (uint32_t)lit_text.size()).first;
                 lit_text.push_back(L);
+                lit_kb.push_back(kb);
             }
             return hit->second;
         };
-        std::map<std::string, uint32_t> owed;                                  // text -> owed-text state (ids from n0 on)
+        std::map<std::pair<std::string, uint32_t>, uint32_t> owed;            // (text, bytes it stands for) -> owed-text state (ids from n0 on)
         std::vector<std::string> owed_text;
+        std::vector<uint32_t> owed_kb;
         std::vector<std::string> esc_text;
         std::vector<bool> esc_cc;
+        std::vector<uint32_t> esc_net;                                         // [7:0] input bytes the text stands for, [15:8] how far back the first lies
+        bool copy_ok = true;
         size_t hot_escapes = 0;
         uint32_t class_size[32] = {}, class_byte[32] = {};
         for (int c = 0; c < 256; ++c) { ++class_size[cls[c]]; class_byte[cls[c]] = (uint32_t)c; }
@@ -517,10 +524,12 @@ private:
             if (lit.empty()) return true;
             if (lit == "\n" && !cc) { y.nl = true; return true; }
             if (x.next == 0 && !cc && !x.eol && lit.size() <= 8) {
-                auto hit = owed.find(lit);
+                const uint32_t kb = (uint32_t)(w.size() - n + 1);              // the key: what is left of the pending string, and this byte
+                auto hit = owed.find(std::make_pair(lit, kb));
                 if (hit == owed.end()) {
-                    hit = owed.emplace(lit, (uint32_t)owed_text.size()).first;
+                    hit = owed.emplace(std::make_pair(lit, kb), (uint32_t)owed_text.size()).first;
                     owed_text.push_back(lit);
+                    owed_kb.push_back(kb);
                 }
                 y.next = n0 + hit->second;
                 return true;
@@ -531,6 +540,32 @@ private:
             if (n == 0 && x.next == 0) ++hot_escapes;                          // a completed key with a long replacement: every hit would leave the fast path
             esc_text.push_back(x.out);
             esc_cc.push_back(x.copy_c);
+            {
+                // as a net edit: the text stands for the first bytes of (pending + this byte) that are not pending afterwards;
+                // with the copy flag the byte itself passes through behind the text
+                const size_t left = pending(x.next).size();
+                const size_t kb = x.copy_c ? w.size() : w.size() + 1 - left;
+                if ((x.copy_c && left != 0) || w.size() + 1 < left || kb == 0 || kb > 15 || w.size() > 8) {
+                    if (dbg && copy_ok) fprintf(stderr, "copy form: escape of state '%s' class %u: copy %d left %zu kb %zu\n", w.c_str(), k, (int)x.copy_c, left, kb);
+                    copy_ok = false;
+                }
+                esc_net.push_back((uint32_t)kb | (uint32_t)w.size() << 8);
+            }
+            return true;
+        };
+        // the same classification without creating anything (the copy form's check below)
+        auto decompose_again = [&](uint32_t s, uint32_t k, FbCell& y) -> bool {
+            const Cell& x = rows[s][k];
+            const std::string w = pending(s);
+            size_t n = 0;
+            while (n < x.out.size() && n < w.size() && x.out[n] == w[n]) ++n;
+            std::string lit = x.out.substr(n);
+            bool cc = x.copy_c;
+            if (lit.size() == 1 && class_size[k] == 1 && (uint8_t)lit[0] == class_byte[k]) { lit.clear(); cc = true; }
+            y.next = x.next; y.esc = -1;
+            if (lit.empty() || (lit == "\n" && !cc)) return true;
+            if (x.next == 0 && !cc && !x.eol && lit.size() <= 8) { y.next = n0; return true; }
+            y.esc = 0;
             return true;
         };
         auto same = [](const Cell& a, const Cell& b, const std::string& P) {
@@ -590,8 +625,8 @@ private:
             n_exc += plan[s].exc.size();
         }
         const uint32_t n_all = n0 + (uint32_t)owed_text.size();
-        for (const std::string& L : owed_text) lit_id(L);
-        for (uint32_t s = 0; s < n0; ++s) if (plan[s].literal) lit_id(plan[s].P);
+        for (size_t i = 0; i < owed_text.size(); ++i) lit_id(owed_text[i], owed_kb[i]);
+        for (uint32_t s = 0; s < n0; ++s) if (plan[s].literal) lit_id(plan[s].P, (uint32_t)names_[s].size());
         if (n_all > 16000 || lit_text.size() > 4095 || esc_text.size() > 4095 || hot_escapes > 16) return;   // escapes are for the odd cell, not for every completed key
         // row displacement: every state with exceptions gets a base of its own such that its slots base + k are free
         // (first fit, the states with the most exceptions first); states without exceptions share the tail of the array,
@@ -639,8 +674,8 @@ private:
             return base[s] | base[plan[s].f] << 14 | (uint32_t)plan[s].P.size() << 28;
         };
         auto about_of = [&](uint32_t s) -> uint32_t {
-            if (s >= n0) return lit_id(owed_text[s - n0]);
-            if (!plan[s].dense && plan[s].literal) return lit_id(plan[s].P);
+            if (s >= n0) return lit_id(owed_text[s - n0], owed_kb[s - n0]);
+            if (!plan[s].dense && plan[s].literal) return lit_id(plan[s].P, (uint32_t)names_[s].size());
             return (uint32_t)pending(s).size();
         };
         t.fb_comb.assign(n_slots, (uint64_t)kFbNoTag << 32);
@@ -664,7 +699,7 @@ private:
             t.fb_esc.push_back((uint32_t)t.fb_pool.size());
             t.fb_esc.push_back((uint32_t)esc_text[se.second].size());
             t.fb_esc.push_back(esc_cc[se.second] ? 1u : 0u);
-            t.fb_esc.push_back(0u);
+            t.fb_esc.push_back(esc_net[se.second]);
             t.fb_pool.insert(t.fb_pool.end(), esc_text[se.second].begin(), esc_text[se.second].end());
         }
         const uint32_t starts[3] = {0u, skip_, done_};
@@ -672,6 +707,40 @@ private:
         t.fb_states = n_all;
         t.fb_dense = n_dense;
         t.fb_ok = true;
+        // The copy form: is every transition that is neither an owed text nor an escape a pure pass-through of input bytes?
+        // Checked on the cells themselves: what a cell emits must be exactly the bytes of (pending + this byte) that are no
+        // longer pending afterwards.  (SKIP swallows what it reads and a NUL ends a line early: the kernels leave the copy
+        // form on a NUL; DONE is silent.)
+        for (uint32_t s = 0; s < n0 && copy_ok; ++s) {
+            if (s == skip_ || s == done_) continue;
+            const std::string w = pending(s);
+            for (uint32_t k = 0; k < C && copy_ok; ++k) {
+                if (in.col_kind[k] == kColNul) continue;
+                const Cell& x = rows[s][k];
+                if (x.ovf || x.diverge || x.next >= n0) { copy_ok = false; break; }
+                const std::string rest = pending(x.next);
+                FbCell y;
+                if (!decompose_again(s, k, y)) { copy_ok = false; break; }
+                if (y.esc >= 0 || y.next >= n0) continue;                      // an edit: spelled out, or owed
+                // (a class of several bytes: any of them; the copy flag stands for the byte)
+                const std::string wc = w + (char)class_byte[k];
+                const std::string full = x.out + (x.copy_c ? std::string(1, (char)class_byte[k]) : std::string());
+                if (wc.size() < rest.size() || full != wc.substr(0, wc.size() - rest.size()) || wc.substr(wc.size() - rest.size()) != rest) {
+                    if (dbg) fprintf(stderr, "copy form: state '%s' class %u emits '%s' and leaves '%s'\n", w.c_str(), k, full.c_str(), rest.c_str());
+                    copy_ok = false;
+                }
+            }
+        }
+        for (size_t i = 0; i < lit_text.size(); ++i)
+            if (lit_kb[i] > 15 || lit_text[i].size() > 8) {
+                if (dbg && copy_ok) fprintf(stderr, "copy form: literal '%s' stands for %u bytes\n", lit_text[i].c_str(), lit_kb[i]);
+                copy_ok = false;
+            }
+        if (copy_ok) {
+            t.fb_lit_meta.resize(lit_text.size());
+            for (size_t i = 0; i < lit_text.size(); ++i) t.fb_lit_meta[i] = (uint16_t)(lit_text[i].size() | lit_kb[i] << 8);
+            t.fb_copy_ok = true;
+        }
     }
     static constexpr size_t kFallbackLdsBytes = 90 * 1024;   // the tables' share of the 160 KB (the rest: the emit pass's staging rings)
     struct Undo { uint32_t s; int c; Cell cell; };
