@@ -345,6 +345,7 @@ FbView fb_view(const ScanArgs& a) {
     T.cls = a.blob + h.off_cls;
     T.comb = reinterpret_cast<const uint64_t*>(a.blob + h.off_fb_comb);
     T.lit = reinterpret_cast<const uint64_t*>(a.blob + h.off_fb_lit);
+    T.lit_meta = h.off_fb_lit_meta ? reinterpret_cast<const uint16_t*>(a.blob + h.off_fb_lit_meta) : nullptr;
     T.esc_slot = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_esc_slot);
     T.esc = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_esc);
     T.pool = a.blob + h.off_fb_pool;

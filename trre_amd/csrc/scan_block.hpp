@@ -1680,6 +1680,7 @@ struct FbView {
     const uint8_t* cls;        // [256] (LDS)
     const uint64_t* comb;      // the slots (LDS)
     const uint64_t* lit;       // literal texts (LDS; emit pass)
+    const uint16_t* lit_meta;  // per literal: length | input bytes it stands for << 8 (LDS; mark pass)
     const uint32_t* esc_slot;  // slots of the escape entries, ascending (global)
     const uint32_t* esc;       // their records, 4 words each (global)
     const uint8_t* pool;       // their texts (global)
@@ -1734,7 +1735,8 @@ TRRE_HD void fb_lane(const ScanArgs& a, const FbView& T, int64_t lane, int64_t l
     uint32_t* evp = nullptr;
     uint32_t* const stage0 = reinterpret_cast<uint32_t*>(ring);
     uint32_t* sp = stage0;
-    uint32_t n_ev = 0, b_rel = 0, e_rel = 0, nul = 0, far = 0, esc_index = 0;
+    uint32_t n_ev = 0, b_rel = 0, e_rel = 0, nul = 0, far = 0;
+    int64_t delta = 0;
     if (kMode == 3) {
         evp = copy_event_slot(*ca, lane, 0);
         if (first == 1) b_rel = (uint32_t)(first_line_start_safe(a, lo, hi) - lo);
@@ -1742,7 +1744,6 @@ TRRE_HD void fb_lane(const ScanArgs& a, const FbView& T, int64_t lane, int64_t l
     // an escape entry: the output spelled out in global memory (rare)
     auto esc_count = [&](uint32_t slot) -> uint32_t {
         const uint32_t* r = fb_esc_record(T, slot);
-        if (kMode == 3) esc_index = (uint32_t)((r - T.esc) >> 2);
         return r[1] + r[2];
     };
     auto esc_emit = [&](uint32_t slot, uint32_t c) {
@@ -1771,24 +1772,29 @@ TRRE_HD void fb_lane(const ScanArgs& a, const FbView& T, int64_t lane, int64_t l
             const uint32_t owed = st >> 31;
             const uint32_t n_rec = mine ? 0u : ((st >> 28) & 7u) + owed;
             const bool esc = (eh & (kFbCc | kFbNl)) == (kFbCc | kFbNl);
-            if (kMode == 1 || kMode == 3) {
+            if (kMode == 1) {
                 uint32_t add = n_rec + ((eh >> 14) & 7u) + ((eh >> 17) & 1u) + ((eh >> 18) & 1u);
-                // mark: an owed state left through its fallback row emits its text now (it stands for the bytes right before this one)
-                bool ev = kMode == 3 && owed && !mine;
+                if (TRRE_WAVE_ANY(esc)) {
+                    if (esc) add = n_rec + esc_count(mine ? base + k : fbase + k);
+                }
+                cnt += add;
+            } else if (kMode == 3) {
+                // an owed state left through its fallback row emits its text now (it stands for the bytes right before this
+                // one).  No byte count here: every other transition copies what it reads, the events' texts are accounted
+                // for when they leave the stage.
+                bool ev = owed && !mine;
                 uint32_t id = ab >> 20;
                 if (TRRE_WAVE_ANY(esc)) {
                     if (esc) {
-                        add = n_rec + esc_count(mine ? base + k : fbase + k);
-                        if (kMode == 3) { ev = true; id = 0x8000u | esc_index; }
+                        ev = true;
+                        id = 0x8000u | (uint32_t)((fb_esc_record(T, mine ? base + k : fbase + k) - T.esc) >> 2);
                     }
                 }
-                cnt += add;
-                if (kMode == 3) {
-                    if (ev) *sp = (rp + (uint32_t)j) | id << 16;
-                    uint32_t* const nsp = sp + 1 < stage0 + (kMarkStage - 1) ? sp + 1 : stage0 + (kMarkStage - 1);   // (a full stage: the launch is void)
-                    sp = ev ? nsp : sp;
-                    if (kEnd && ev && rp + (uint32_t)j > 0xffffu) far = 1;
+                if (ev) {
+                    *sp = (rp + (uint32_t)j) | id << 16;
+                    sp = sp + 1 < stage0 + (kMarkStage - 1) ? sp + 1 : stage0 + (kMarkStage - 1);      // (a full stage: the launch is void)
                 }
+                if (kEnd && ev && rp + (uint32_t)j > 0xffffu) far = 1;
             } else {
                 const uint32_t about = ab >> 20;                      // of the current state: pending length, or the owed text's index
                 const uint32_t n_tot = n_rec + ((eh >> 14) & 7u);     // 0..8 bytes of prefix (an escape entry has none of its own)
@@ -1813,7 +1819,7 @@ TRRE_HD void fb_lane(const ScanArgs& a, const FbView& T, int64_t lane, int64_t l
         for (int d = 0; d < 4; ++d) {
             dword(end_tag, d == 0 ? b.x : (d == 1 ? b.y : (d == 2 ? b.z : b.w)), rp + 4u * (uint32_t)d);
             if (kMode == 2) stage_flush<false>(S);
-            if (kMode == 1 || kMode == 3) TRRE_PIN(cnt);
+            if (kMode == 1) TRRE_PIN(cnt);
             TRRE_SCHED_FENCE();
         }
     };
@@ -1856,7 +1862,18 @@ TRRE_HD void fb_lane(const ScanArgs& a, const FbView& T, int64_t lane, int64_t l
             const uint32_t n_loc = (uint32_t)(sp - stage0);
             if (n_loc >= (uint32_t)kMarkStage - 1u) far = 1;
             for (uint32_t k = 0; TRRE_WAVE_ANY(k < n_loc); ++k) {
-                if (k < n_loc && n_ev + k < ca->ev_cap) evp[(size_t)k * 64u] = stage0[k];
+                if (k < n_loc) {
+                    const uint32_t ev = stage0[k], id = ev >> 16;
+                    if (n_ev + k < ca->ev_cap) evp[(size_t)k * 64u] = ev;
+                    // what the text adds: its length - the input bytes it stands for
+                    if (!(id & 0x8000u)) {
+                        const uint32_t m = T.lit_meta[id];
+                        delta += (int32_t)(m & 255u) - (int32_t)(m >> 8);
+                    } else {
+                        const uint32_t* r = T.esc + 4u * (id & 0x7fffu);
+                        delta += (int32_t)r[1] - (int32_t)(r[3] & 255u);
+                    }
+                }
             }
             evp += (size_t)n_loc * 64u;
             n_ev += n_loc;
@@ -1873,6 +1890,12 @@ TRRE_HD void fb_lane(const ScanArgs& a, const FbView& T, int64_t lane, int64_t l
         hdr[1] = b_rel;
         hdr[2] = b_rel < rhi ? e_rel : b_rel;          // (no line starts in the sub-range: the lane has nothing to copy)
         hdr[3] = 0;
+        cnt = 0;
+        if (b_rel < rhi && e_rel > b_rel) {
+            const int64_t end = lo + (int64_t)e_rel < a.vend ? lo + (int64_t)e_rel : a.vend;
+            const int64_t bytes = end - (lo + (int64_t)b_rel) + delta;
+            cnt = bytes > 0 ? (uint64_t)bytes : 0;
+        }
     }
     (void)status;
     L.count = cnt;

@@ -636,6 +636,7 @@ __global__ __launch_bounds__(kThreads, (kMode == 1 ? 8 : 2)) void k_stream_fb(Sc
     T.cls = smem;
     T.comb = reinterpret_cast<const uint64_t*>(smem + 256);
     T.lit = reinterpret_cast<const uint64_t*>(smem + 256 + comb_bytes);
+    T.lit_meta = nullptr;
     T.esc_slot = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_esc_slot);
     T.esc = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_esc);
     T.pool = a.blob + h.off_fb_pool;
@@ -689,30 +690,34 @@ __global__ __launch_bounds__(kThreads, (kMode == 1 ? 8 : 2)) void k_stream_fb(Sc
 }
 // The copy form of a large table (scan_block.hpp: fb_lane<3> / fb_copy_lane).
 // Mark pass: the comb walk of k_stream_fb<1> plus the events; one 1024-lane workgroup per CU (the event stages take the
-// LDS the count pass's second workgroup has).   smem: cls[256] | comb | event stages[1024 x 68] | 64 x groups
+// LDS the count pass's second workgroup has).   smem: cls[256] | comb | literals' meta (u16) | event stages[1024 x 68] | 64 x groups
 constexpr int kFbMarkThreads = 1024;
 __global__ __launch_bounds__(kFbMarkThreads, 4) void k_fb_mark(ScanArgs a, FbCopyArgs ca, int64_t lane_bytes, int64_t n_chunks) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
-    const uint32_t comb_bytes = (h.fb_slots * 8u + 15u) & ~15u;
+    const uint32_t comb_bytes = (h.fb_slots * 8u + 15u) & ~15u, meta_bytes = (h.fb_lits * 2u + 15u) & ~15u;
     for (int k = threadIdx.x; k < 256; k += kFbMarkThreads) smem[k] = a.blob[h.off_cls + k];
     {
         const U128* e = reinterpret_cast<const U128*>(a.blob + h.off_fb_comb);
         U128* d = reinterpret_cast<U128*>(smem + 256);
         for (int k = threadIdx.x; k < (int)(comb_bytes / 16); k += kFbMarkThreads) d[k] = e[k];
+        const uint16_t* m = reinterpret_cast<const uint16_t*>(a.blob + h.off_fb_lit_meta);
+        uint16_t* dm = reinterpret_cast<uint16_t*>(smem + 256 + comb_bytes);
+        for (int k = threadIdx.x; k < (int)h.fb_lits; k += kFbMarkThreads) dm[k] = m[k];
     }
     __syncthreads();
     FbView T;
     T.cls = smem;
     T.comb = reinterpret_cast<const uint64_t*>(smem + 256);
     T.lit = nullptr;
+    T.lit_meta = reinterpret_cast<const uint16_t*>(smem + 256 + comb_bytes);
     T.esc_slot = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_esc_slot);
     T.esc = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_esc);
     T.pool = a.blob + h.off_fb_pool;
     T.n_esc = h.fb_escs;
     for (int i = 0; i < 3; ++i) { T.start[i][0] = h.fb_start[i][0]; T.start[i][1] = h.fb_start[i][1]; }
-    uint8_t* stage = smem + 256 + comb_bytes + threadIdx.x * (kMarkStageStride * 4);
-    uint8_t* tail = smem + 256 + comb_bytes + kFbMarkThreads * (kMarkStageStride * 4);
+    uint8_t* stage = smem + 256 + comb_bytes + meta_bytes + threadIdx.x * (kMarkStageStride * 4);
+    uint8_t* tail = smem + 256 + comb_bytes + meta_bytes + kFbMarkThreads * (kMarkStageStride * 4);
     constexpr int kGroups = kFbMarkThreads / kDirectThreads;
     const int group = threadIdx.x / kDirectThreads, gtid = threadIdx.x % kDirectThreads;
     const int64_t chunk = (int64_t)blockIdx.x * kGroups + group;
@@ -1192,7 +1197,7 @@ void launch_wide_fwd(int which, const ScanArgs& a, int64_t lane_bytes, int64_t n
 void launch_fb_mark(const ScanArgs& a, const FbCopyArgs& ca, const void* hdr, int64_t lane_bytes, int64_t n_chunks, void* stream) {
     const StreamBlobHeader& h = *static_cast<const StreamBlobHeader*>(hdr);
     constexpr int kG = kFbMarkThreads / kDirectThreads;
-    const int lds = 256 + (int)((h.fb_slots * 8u + 15u) & ~15u) + kFbMarkThreads * kMarkStageStride * 4 + 64 * kG;
+    const int lds = 256 + (int)((h.fb_slots * 8u + 15u) & ~15u) + (int)((h.fb_lits * 2u + 15u) & ~15u) + kFbMarkThreads * kMarkStageStride * 4 + 64 * kG;
     allow_big_lds<&k_fb_mark>();
     hipLaunchKernelGGL(k_fb_mark, dim3((unsigned)((n_chunks + kG - 1) / kG)), dim3(kFbMarkThreads), lds, static_cast<hipStream_t>(stream), a, ca, lane_bytes, n_chunks);
 }
@@ -1219,7 +1224,7 @@ void launch_fb_copy(const ScanArgs& a, const FbCopyArgs& ca, const void* hdr, in
 bool fb_copy_fits(const void* hdr) {
     const StreamBlobHeader& h = *static_cast<const StreamBlobHeader*>(hdr);
     if (!h.off_fb_lit_meta) return false;
-    const int mark = 256 + (int)((h.fb_slots * 8u + 15u) & ~15u) + kFbMarkThreads * kMarkStageStride * 4 + 256;
+    const int mark = 256 + (int)((h.fb_slots * 8u + 15u) & ~15u) + (int)((h.fb_lits * 2u + 15u) & ~15u) + kFbMarkThreads * kMarkStageStride * 4 + 256;
     return mark <= kLdsLimit && fb_copy_lds(h, 256) <= kLdsLimit;
 }
 
