@@ -49,7 +49,7 @@ HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~630
 
 KERNEL_OF = {"generate": "k_rev_sweep (viability symbols) + host enumeration", "bytemap": "k_bytemap", "tile_lp": "k_scan_lp", "tile_gen": "k_scan_count + k_scan_emit",
              "stream_lp": "k_stream_lpw (window form) / k_stream_g16<emit> alone",
-             "stream_gen": "k_stream_g16<count> + <emit> (small tables) / k_stream_direct<count> + <emit>",
+             "stream_gen": "k_stream_g16<count> + <emit> (small tables) / k_fb_mark + k_fb_copy (large tables: the copy form)",
              "guided_lp": "k_rev_sweep + k_stream_g16<emit, sym>", "guided_gen": "k_rev_sweep + k_stream_g16<count, sym> + <emit, sym>"}
 
 
@@ -280,7 +280,7 @@ def self_launch(n_gpus, stub):
     if not stub:
         import torch
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-        if have < n_gpus:
+        if have < n_gpus and not (have and os.environ.get("TRRE_BENCH_SHARE_GPU") == "1"):
             raise SystemExit("bench.py: --gpus %d, but %d GPU(s) are visible on this node: nothing measured "
                              "(every rank needs a device of its own; the scan has no CPU path)" % (n_gpus, have))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
@@ -321,6 +321,7 @@ def main():
 
     import torch
     import corpora
+    share = False
     if stub:
         import types
         dev = torch.device("cpu")
@@ -331,8 +332,12 @@ def main():
         import trre_amd
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: the scan has no CPU path")
-        if local >= torch.cuda.device_count():
+        # TRRE_BENCH_SHARE_GPU=1 (a debugging aid for 1-GPU boxes, marked in the line): ranks beyond the devices share
+        # them and synchronise over gloo — the N-rank code path on real kernels, never a measurement of N GPUs
+        share = os.environ.get("TRRE_BENCH_SHARE_GPU") == "1" and world > torch.cuda.device_count()
+        if local >= torch.cuda.device_count() and not share:
             raise SystemExit("bench.py: rank %d has no device (%d visible)" % (rank, torch.cuda.device_count()))
+        local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
         sync = torch.cuda.synchronize
@@ -340,7 +345,7 @@ def main():
     if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if stub:
+        if stub or share:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
@@ -353,7 +358,7 @@ def main():
     def reduce(x, op):
         if dist is None:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(t, op={"max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN, "sum": dist.ReduceOp.SUM}[op])
         return float(t.item())
 
@@ -432,7 +437,8 @@ def main():
         "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "u8",
-        "data": "stub" if stub else "synthetic",
+        "data": "stub" if stub else ("synthetic; DEBUG: %d ranks share %d GPU(s), not a measurement of %d GPUs" % (world, torch.cuda.device_count(), world)
+                                     if share else "synthetic"),
         "config": {
             "workload": "'%s' %s scan over %.3f GiB of synthetic %s lines per GPU%s"
                         % (pattern, engine.upper(), n / 2**30, corpus_name, cfg_note),
