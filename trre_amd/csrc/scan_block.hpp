@@ -1915,10 +1915,11 @@ TRRE_HD void fb_lane(const ScanArgs& a, const FbView& T, int64_t lane, int64_t l
 //                  Per input dword and event: the bytes before the text, the text, and on the next turn the bytes after
 //                  it, each one append of a contiguous byte range with no branch on the data.
 //
-// A lane's events are 256 bytes apart: slot i of the 64 lanes of a wave is one 256-byte row (copy_event_slot).  The lanes
-// of a wave reach slot i at about the same time, so a row is written, and later read, as whole cache lines; a lane's
-// own run of slots (the first layout) was one line per lane and load, refetched for every slot: the pass ran at the
-// pace of those fetches, 2.0 ms per GiB instead of 0.7.
+// A lane's events are 256 bytes apart: slot i of the 64 lanes of a wave is one 256-byte row (copy_event_slot), so lanes
+// that reach slot i at about the same time share its cache lines.  (They drift apart — after 2 KiB by some tens of
+// slots — and the rows end up written and read as scattered 4-byte accesses all the same: DESIGN.md §4.2a has the
+// traffic.  What holds the copy pass up is not the layout but the wait: a lane asks for its next event on demand, the
+// wave waits for memory whenever any lane has just asked.)
 // A NUL ends a line early (the rest of the record is swallowed, not passed through): the launch is void and the count /
 // emit pair runs (kStNul), as for the length-preserving kernels.  So does a lane with more than ev_cap events, or with an
 // event more than 64 KiB behind its start (a very long last line): kStEditOverflow.
