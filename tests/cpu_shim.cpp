@@ -387,7 +387,7 @@ void run_fb_copy(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64
     const uint16_t* lit_meta = reinterpret_cast<const uint16_t*>(a.blob + h.off_fb_lit_meta);
     const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
     std::vector<uint32_t> hdr((size_t)n_lanes * 4, 0xEEEEEEEEu);
-    std::vector<uint32_t> events((size_t)((n_lanes + 63) / 64) * ev_cap * 64, 0xEEEEEEEEu);
+    std::vector<uint32_t> events((size_t)n_lanes * ev_cap + 4, 0xEEEEEEEEu);
     FbCopyArgs ca{};
     ca.events = events.data();
     ca.lane_hdr = hdr.data();

@@ -433,8 +433,8 @@ int ensure_copy_workspace(ScanCtx* c, int64_t n_lanes) {
     (void)hipFree(c->d_cevents); (void)hipFree(c->d_chdr);
     c->d_cevents = nullptr; c->d_chdr = nullptr;
     c->copy_lanes = 0;
-    // (events: [wave][slot][lane of the wave], 4 bytes each)
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_cevents), (size_t)((n_lanes + 63) / 64) * kCopyEvCap * 256));
+    // (events: a row of kCopyEvCap per lane, 4 bytes each)
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_cevents), (size_t)n_lanes * kCopyEvCap * 4));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_chdr), (size_t)n_lanes * 16));
     c->copy_lanes = n_lanes;
     return TRRE_OK;

@@ -1691,13 +1691,11 @@ struct FbView {
 constexpr int kMarkStage = 16;                 // events a lane can collect per 64 input bytes (LDS, 17 dwords apart)
 constexpr int kMarkStageStride = 17;
 struct FbCopyArgs {
-    uint32_t* events;          // [n_waves][ev_cap][64]
+    uint32_t* events;          // [n_lanes][ev_cap]: a lane's events side by side (ev_cap: a multiple of 4 — the copy pass reads them 16 bytes at a time)
     uint32_t* lane_hdr;        // [n_lanes][4]: {events, first line start, end of the last line (offsets from the sub-range's start), -}
     uint32_t ev_cap;
 };
-TRRE_HD uint32_t* copy_event_slot(const FbCopyArgs& ca, int64_t lane, uint32_t slot) {
-    return ca.events + ((size_t)(lane >> 6) * ca.ev_cap + slot) * 64u + (size_t)(lane & 63);
-}
+TRRE_HD uint32_t* copy_event_row(const FbCopyArgs& ca, int64_t lane) { return ca.events + (size_t)lane * ca.ev_cap; }
 // the record of the escape entry in slot `slot`
 TRRE_HD const uint32_t* fb_esc_record(const FbView& T, uint32_t slot) {
     uint32_t lo = 0, hi = T.n_esc;
@@ -1738,7 +1736,7 @@ TRRE_HD void fb_lane(const ScanArgs& a, const FbView& T, int64_t lane, int64_t l
     uint32_t n_ev = 0, b_rel = 0, e_rel = 0, nul = 0, far = 0;
     int64_t delta = 0;
     if (kMode == 3) {
-        evp = copy_event_slot(*ca, lane, 0);
+        evp = copy_event_row(*ca, lane);
         if (first == 1) b_rel = (uint32_t)(first_line_start_safe(a, lo, hi) - lo);
     }
     // an escape entry: the output spelled out in global memory (rare)
@@ -1858,13 +1856,13 @@ TRRE_HD void fb_lane(const ScanArgs& a, const FbView& T, int64_t lane, int64_t l
             }
         }
         if (kMode == 3) {
-            // the piece's events: slot by slot, the lanes of the wave side by side (copy_event_slot)
+            // the piece's events, to the end of the lane's row
             const uint32_t n_loc = (uint32_t)(sp - stage0);
             if (n_loc >= (uint32_t)kMarkStage - 1u) far = 1;
             for (uint32_t k = 0; TRRE_WAVE_ANY(k < n_loc); ++k) {
                 if (k < n_loc) {
                     const uint32_t ev = stage0[k], id = ev >> 16;
-                    if (n_ev + k < ca->ev_cap) evp[(size_t)k * 64u] = ev;
+                    if (n_ev + k < ca->ev_cap) evp[k] = ev;
                     // what the text adds: its length - the input bytes it stands for
                     if (!(id & 0x8000u)) {
                         const uint32_t m = T.lit_meta[id];
@@ -1875,7 +1873,7 @@ TRRE_HD void fb_lane(const ScanArgs& a, const FbView& T, int64_t lane, int64_t l
                     }
                 }
             }
-            evp += (size_t)n_loc * 64u;
+            evp += n_loc;
             n_ev += n_loc;
             sp = stage0;
         }
@@ -1915,11 +1913,13 @@ TRRE_HD void fb_lane(const ScanArgs& a, const FbView& T, int64_t lane, int64_t l
 //                  Per input dword and event: the bytes before the text, the text, and on the next turn the bytes after
 //                  it, each one append of a contiguous byte range with no branch on the data.
 //
-// A lane's events are 256 bytes apart: slot i of the 64 lanes of a wave is one 256-byte row (copy_event_slot), so lanes
-// that reach slot i at about the same time share its cache lines.  (They drift apart — after 2 KiB by some tens of
-// slots — and the rows end up written and read as scattered 4-byte accesses all the same: DESIGN.md §4.2a has the
-// traffic.  What holds the copy pass up is not the layout but the wait: a lane asks for its next event on demand, the
-// wave waits for memory whenever any lane has just asked.)
+// A lane's events lie side by side (a row of ev_cap per lane).  The copy pass takes them one at a time, the next one
+// requested when one has been used.  Measured alternatives: slot i of a wave's 64 lanes as one
+// 256-byte row — the lanes drift apart by tens of slots, the rows end up as scattered 4-byte accesses (2.4 GiB read per
+// GiB of input against 1.9) at the same speed; events 16 bytes at a time with eight more requested at the top of every
+// piece — no waiting for memory inside a piece, but the register shuffling costs what the waiting did (1.52 against
+// 1.43 ms).  With the events switched off (TRRE_EMIT_DBG=4: a plain copy through the same loop) the pass takes 0.75 ms,
+// without its stores and ring writes 0.55: it is bound by its own instructions, 35 per byte.
 // A NUL ends a line early (the rest of the record is swallowed, not passed through): the launch is void and the count /
 // emit pair runs (kStNul), as for the length-preserving kernels.  So does a lane with more than ev_cap events, or with an
 // event more than 64 KiB behind its start (a very long last line): kStEditOverflow.
@@ -1945,17 +1945,22 @@ TRRE_HD void fb_copy_lane(const ScanArgs& a, const FbCopyTables& T, const FbCopy
     int64_t v = (lo + (int64_t)b_rel) & ~(int64_t)63;
     uint32_t skip = (uint32_t)(lo + (int64_t)b_rel - v);                   // bytes still to drop: up to the first line start, then what the texts stand for
     if (e_rel <= b_rel) { v = lo; end = lo; n_ev = 0; skip = 0; }
+    if (a.dbg & 4u) n_ev = 0;                                              // (timing experiments: a plain copy)
     uint32_t prel = (uint32_t)(v - lo);                                    // position of the piece, as the events count it
     Stage S{};
     S.dbg = a.dbg;
     S.wsc = wave_scratch;
     stage_begin(S, ring, a.out + out_base);
-    // the event in front of the lane, decoded: where its text goes, the text, and what it stands for; the raw event after
-    // it is already here, the one after that on its way (a lane meets a text every ~20 bytes)
-    const uint32_t* evp = copy_event_slot(ca, lane, 0);
+    // The event in front of the lane, decoded: where its text goes, the text, and what it stands for.  The raw events come
+    // 16 bytes (four events) at a time: E holds the four the lane is taking, E1 and E2 the eight after them — asked for at
+    // the top of a piece, for all lanes at once, a piece or more before they are needed.  (A lane that asked for its next
+    // event when it had used one — the first version — made the whole wave wait for memory: `s_waitcnt vmcnt` is per wave,
+    // and in almost every dword some lane had just asked.)  A lane that runs through all twelve between two piece tops
+    // asks on the spot.
+    const uint32_t* evp = copy_event_row(ca, lane);
     uint32_t nfp = 0xffffffffu, nn = 0, nkb = 0, nesc = 0;                // nesc: 1 + offset of an escape's text in the pool
     uint64_t ntext = 0;
-    uint32_t raw1 = n_ev > 1u ? evp[64] : 0u;
+    uint32_t raw1 = n_ev > 1u ? evp[1] : 0u;
     uint32_t taken = 0;                                                    // events decoded so far
     auto decode = [&](uint32_t raw) {
         const uint32_t id = raw >> 16, pos = raw & 0xffffu;
@@ -1982,7 +1987,7 @@ TRRE_HD void fb_copy_lane(const ScanArgs& a, const FbCopyTables& T, const FbCopy
         if (taken < n_ev) {
             decode(raw1);
             ++taken;
-            if (taken < n_ev) raw1 = evp[(size_t)taken * 64u];
+            if (taken < n_ev) raw1 = evp[taken];
         } else {
             nfp = 0xffffffffu;
         }
