@@ -1915,8 +1915,8 @@ TRRE_HD void fb_lane(const ScanArgs& a, const FbView& T, int64_t lane, int64_t l
 //
 // A lane's events lie side by side (a row of ev_cap per lane).  The copy pass takes them one at a time, the next one
 // requested when one has been used.  Measured alternatives: slot i of a wave's 64 lanes as one
-// 256-byte row — the lanes drift apart by tens of slots, the rows end up as scattered 4-byte accesses (2.4 GiB read per
-// GiB of input against 1.9) at the same speed; events 16 bytes at a time with eight more requested at the top of every
+// 256-byte row — the lanes drift apart by tens of slots, the rows end up as scattered 4-byte accesses, same speed and
+// same traffic in sum; events 16 bytes at a time with eight more requested at the top of every
 // piece — no waiting for memory inside a piece, but the register shuffling costs what the waiting did (1.52 against
 // 1.43 ms).  With the events switched off (TRRE_EMIT_DBG=4: a plain copy through the same loop) the pass takes 0.75 ms,
 // without its stores and ring writes 0.55: it is bound by its own instructions, 35 per byte.
