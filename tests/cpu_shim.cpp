@@ -418,13 +418,14 @@ void run_fb_copy(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64
 
 // Host emulation of the window kernel (k_stream_lpw): 64 lanes in lockstep over an
 // emulated pair of LDS tiles, the same lane / mover code as the device.
-template <bool kWide>
+template <bool kWide, bool kPair = false>
 void run_lpw_t(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
     LpwView T;
     T.cls = a.blob + h.off_cls;
-    T.ent = reinterpret_cast<const U128*>(a.blob + h.off_lpw);
+    T.ent = reinterpret_cast<const U128*>(a.blob + (kPair ? h.off_lpw2 : h.off_lpw));
     T.delay = h.lpw_delay;
+    T.n_cls = h.n_cls;
     const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
     const int64_t n_waves = (n_lanes + 63) / 64;
     std::vector<uint32_t> redo(n_waves * 64 + 1, 0);
@@ -433,7 +434,7 @@ void run_lpw_t(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
     alignas(16) static uint8_t tin[kWtTile], tout[kWtOutTile];
     const int64_t vhi = (a.vend - 16) & ~(int64_t)15;
     for (int64_t wv = n_waves - 1; wv >= 0; --wv) {
-        WtLane<kWide> L[64];
+        WtLane<kWide, kPair> L[64];
         WtMover M[64];
         const int64_t lane0 = wv * 64;
         for (int lid = 0; lid < 64; ++lid) L[lid].init(b, T, h.n_cls, lane0 + lid, lane_bytes);
@@ -498,8 +499,10 @@ void run_lpw_t(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
     }
 }
 
-void run_lpw(const ScanArgs& a, int64_t lane_bytes, uint32_t& status) {
-    if (reinterpret_cast<const StreamBlobHeader*>(a.blob)->lpw_delay > 3) run_lpw_t<true>(a, lane_bytes, status);
+// pair: the pair form of the window entries (what the runtime launches when the tables have it)
+void run_lpw(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, bool pair = false) {
+    if (pair) run_lpw_t<false, true>(a, lane_bytes, status);
+    else if (reinterpret_cast<const StreamBlobHeader*>(a.blob)->lpw_delay > 3) run_lpw_t<true>(a, lane_bytes, status);
     else run_lpw_t<false>(a, lane_bytes, status);
 }
 
@@ -562,6 +565,12 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
         // like the runtime: buffers that are not congruent mod 16 go to the direct walker
         if (reinterpret_cast<uintptr_t>(a.out_v0) & 15u) run_direct_lp<>(a, geo == 0 ? 2048 : 48, status);
         else run_lpw(a, geo == 0 ? 2048 : 64, status);
+        total = n;
+    }
+    else if (family == 26) {                          // the window kernel on the pair form of its entries
+        if (reinterpret_cast<const StreamBlobHeader*>(blob)->lpw2_bytes == 0) return -5;
+        if (reinterpret_cast<uintptr_t>(a.out_v0) & 15u) run_direct_lp<>(a, geo == 0 ? 2048 : 48, status);
+        else run_lpw(a, geo == 0 ? 2048 : 64, status, true);
         total = n;
     }
     else if (family == 6) { run_direct_lp<>(a, geo == 0 ? 2048 : 48, status); total = n; }

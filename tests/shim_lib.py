@@ -84,6 +84,7 @@ ST_EDIT_OVERFLOW = 64
 GUIDED_LP, GUIDED_GEN, GUIDED_GEN8, GUIDED_LP_RING, GUIDED_LP8 = 10, 11, 12, 13, 14
 GUIDED_LP_ALL = (GUIDED_LP, GUIDED_LP_RING, GUIDED_LP8)
 STREAM_LP_EMIT, STREAM_LP_EMIT8 = 20, 21            # stream LP family by the emit pass alone (no window form)
+STREAM_LPW_PAIR = 26                                 # the window kernel on the pair form of its entries (what the runtime launches when the tables have one)
 STREAM_FB_COPY = 25                                  # ... by its copy form: mark pass + copy pass (what the runtime launches by default)
 STREAM_FB, STREAM_FB_COUNT = 22, 23                  # stream general family on the fallback form of a large table: both passes /
                                                      # the count pass only, emit on the 8-byte rows (what the runtime launches)
@@ -124,9 +125,9 @@ def scan_like_runtime(prog, data, geo=1, family=None, in_mis=0, out_mis=0):
         fam = {6: GUIDED_LP, 7: GUIDED_GEN}.get(info.kernel, info.kernel)
     if fam in (GUIDED_LP, GUIDED_GEN, GUIDED_GEN8, GUIDED_LP_RING, GUIDED_LP8):
         return scan_guided_like_runtime(prog, data, geo, fam, in_mis, out_mis)
-    blob = prog.export_stream_tables() if fam in (4, 5, 6, 7, 8, 9, 20, 21, 22, 23) else prog.export_tables()
+    blob = prog.export_stream_tables() if fam in (4, 5, 6, 7, 8, 9, 20, 21, 22, 23, STREAM_LPW_PAIR) else prog.export_tables()
     out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
-    if out is None:                         # family 8 without a window form: nothing to run
+    if out is None:                         # family 8 / 26 without a window (pair) form: nothing to run
         fam = 6
         out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
     if fam in (5, 7, 9) and st & ST_OVERFLOW:           # bounded stream table: the guided (or the tile) kernels take over
@@ -139,7 +140,7 @@ def scan_like_runtime(prog, data, geo=1, family=None, in_mis=0, out_mis=0):
     if st & ST_DIVERGE:
         raise RuntimeError("diverges")
     if fam not in (3, 5, 7, 9, 22, 23) and st & ST_NUL:
-        gen = (7 if fam in (6, 8, 20, 21) else 5) if info.stream_states else 3
+        gen = (7 if fam in (6, 8, 20, 21, STREAM_LPW_PAIR) else 5) if info.stream_states else 3
         blob = prog.export_stream_tables() if gen in (5, 7) else prog.export_tables()
         out, st = shim_scan(blob, info.engine, gen, data, geo, in_mis, out_mis)
         assert not st & ST_MISMATCH

@@ -97,7 +97,7 @@ def shim_families(p):
     allowed = list(p.allowed_kernels())
     fams = [f for f in allowed if f <= 5]
     if 4 in fams:             # (shim ids: 6/8 LDS-ring and window walkers of the stream LP family, 20/21 its emit-only form,
-        fams += [6, 8, shim_lib.STREAM_LP_EMIT, shim_lib.STREAM_LP_EMIT8]      # 7/9 direct walkers of the general one)
+        fams += [6, 8, shim_lib.STREAM_LPW_PAIR, shim_lib.STREAM_LP_EMIT, shim_lib.STREAM_LP_EMIT8]      # 7/9 direct walkers of the general one; 26: window walk, two bytes per step)
     if 5 in fams:
         fams += [7, 9]
         if shim_lib.has_fallback_form(p):      # a large table: the count pass (and, off by default, the emit pass) in LDS

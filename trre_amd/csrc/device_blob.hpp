@@ -45,7 +45,7 @@ struct StreamBlobHeader {
     uint32_t off_g16, g16_bytes;              // 16-byte count / emit entries (0 bytes when not available)
     uint32_t off_p32, p32_bytes;              // pair form (0 bytes when not available)
     uint32_t p32_slow;                        // some pair entry is "slow"
-    uint32_t pad;
+    uint32_t off_lpw2;                        // pair form of the window entries (lpw2_bytes: 0 when not available)
     // fallback form of a large table (front.hpp, StreamTables::fb_*): 0 slots when not available
     uint32_t fb_slots, off_fb_comb;           // u64[fb_slots]
     uint32_t fb_lits, off_fb_lit;             // u64[fb_lits]
@@ -53,7 +53,7 @@ struct StreamBlobHeader {
     uint32_t off_fb_esc, off_fb_pool;         // escape records (4 words each) and their texts
     uint32_t fb_start[3][2];                  // root, SKIP, DONE: {descriptor, next-state bits of an entry's hi}
     uint32_t off_fb_lit_meta;                 // u16[fb_lits]: the copy form (front.hpp); 0: the tables do not have it
-    uint32_t pad2;
+    uint32_t lpw2_bytes;
 };
 static_assert(sizeof(StreamBlobHeader) == 144, "header layout");
 

@@ -179,6 +179,12 @@ struct StreamTables {
     bool lpw_ok = false;
     uint32_t lpw_delay = 0;                 // max pending length
     std::vector<uint32_t> lpw;              // [n_states][n_cls][4 or 8]
+    // pair form of the window entries (delay <= 3, at most 32 KiB): [n_states][n_cls][n_cls][8] = {next row (byte offset),
+    // flags (64 / 512: the first / second byte ends a record, 128 NUL, 256 diverges), bytes 0..3, selector 0..3, bytes 4..7,
+    // selector 4..7, -, -}: what two steps put into the window, already in place (the second step's bytes one byte up);
+    // selectors as for the single entries, 5 = the second input byte.  Two input bytes per table read.
+    bool lpw2_ok = false;
+    std::vector<uint32_t> lpw2;
     // 16-byte entries for the count / emit passes of small tables (any output length): like the window
     // form without the shift, {next row offset, meta, inline bytes, v_perm selector}; meta [2:0] = bytes
     // the transition appends (inline bytes, then maybe the input byte), [3] a NUL cut a line short, [4] the

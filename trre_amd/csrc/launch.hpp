@@ -35,7 +35,7 @@ void launch_rev_sweep(const ScanArgs& a, int tab_bytes, int64_t lane_bytes, void
 // wide guided tables (more than 256 backward states: 16-bit symbols at a.sym_v0, both tables through L1 / L2); which: 1 count, 2 emit
 void launch_rev_wide(const ScanArgs& a, int64_t lane_bytes, void* stream);
 void launch_wide_fwd(int which, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, void* stream);
-void launch_lpw_kernel(int ent_bytes, bool wide, bool direct_ent_in_lds, const ScanArgs& a, int64_t lane_bytes, void* stream);
+void launch_lpw_kernel(int ent_bytes, bool wide, bool direct_ent_in_lds, const ScanArgs& a, int64_t lane_bytes, void* stream, int pair_bytes = 0);
 // count / emit passes over the fallback form of a large table (StreamTables::fb_*); hdr: the host's copy of the stream
 // blob's header.  Chunks are those of the direct kernels (direct_block_threads() lanes each).
 void launch_fb_kernel(int which, const ScanArgs& a, const void* hdr, int64_t lane_bytes, int64_t n_chunks, void* stream);

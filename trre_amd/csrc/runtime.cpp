@@ -218,6 +218,8 @@ void serialize_stream(const trre::StreamTables& t, std::vector<uint8_t>& b) {
     off = align_up(off, 16);
     h.off_p32 = (uint32_t)off; h.p32_bytes = (uint32_t)(t.p32.size() * 4); h.p32_slow = t.p32_slow ? 1u : 0u; off += t.p32.size() * 4;
     off = align_up(off, 16);
+    h.off_lpw2 = (uint32_t)off; h.lpw2_bytes = (uint32_t)(t.lpw2.size() * 4); off += t.lpw2.size() * 4;
+    off = align_up(off, 16);
     if (t.fb_ok) {
         h.fb_slots = (uint32_t)t.fb_comb.size(); h.off_fb_comb = (uint32_t)off; off = align_up(off + t.fb_comb.size() * 8, 16);
         h.fb_lits = (uint32_t)t.fb_lit.size(); h.off_fb_lit = (uint32_t)off; off = align_up(off + t.fb_lit.size() * 8, 16);
@@ -245,6 +247,7 @@ void serialize_stream(const trre::StreamTables& t, std::vector<uint8_t>& b) {
     put(b, h.off_lpw, t.lpw.data(), t.lpw.size());
     put(b, h.off_g16, t.g16.data(), t.g16.size());
     put(b, h.off_p32, t.p32.data(), t.p32.size());
+    put(b, h.off_lpw2, t.lpw2.data(), t.lpw2.size());
 }
 
 void serialize_rev_table(uint32_t n_rev, uint32_t n_cls, uint32_t sym_bits, const std::array<uint8_t, 256>& cls, const std::vector<uint8_t>& rev,
@@ -543,7 +546,10 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
         }
         HIP_TRY(hipMemsetAsync(cx->d_redo, 0, 4, stream));
         args.redo = cx->d_redo;
-        launch_lpw_kernel((int)(p->stt.lpw.size() * 4), p->stt.lpw_delay > 3, direct_ent_lds, args, lane_bytes, stream);
+        // (the pair form of the window entries where the tables have it: two input bytes per table read.  TRRE_NO_LPW_PAIR=1: A/B runs)
+        static const bool no_pair_env = getenv("TRRE_NO_LPW_PAIR") != nullptr;
+        launch_lpw_kernel((int)(p->stt.lpw.size() * 4), p->stt.lpw_delay > 3, direct_ent_lds, args, lane_bytes, stream,
+                          p->stt.lpw2_ok && !no_pair_env ? (int)(p->stt.lpw2.size() * 4) : 0);
     } else if (is_guided(family) && p->gt.wide) {
         // a backward DFA of more than 256 states: 16-bit symbols, both tables through L1 / L2 (scan_block.hpp: wide guided tables)
         launch_rev_wide(args, lane_bytes, stream);

@@ -2088,10 +2088,11 @@ TRRE_HD void fb_copy_lane(const ScanArgs& a, const FbCopyTables& T, const FbCopy
 // =============================================================================================
 struct LpwView {
     const uint8_t* cls;      // [256]
-    const U128* ent;         // [n_states][n_cls] entries of 16 bytes (delay <= 3) or 32 bytes
+    const U128* ent;         // [n_states][n_cls] entries of 16 bytes (delay <= 3) or 32 bytes; pair form: [n_states][n_cls][n_cls] of 32 bytes
     uint32_t delay;
+    uint32_t n_cls;          // (pair form: the first byte's class times this, plus the second byte's, is the column)
 };
-constexpr uint32_t kLpwEol = 64u, kLpwNul = 128u, kLpwDiv = 256u;
+constexpr uint32_t kLpwEol = 64u, kLpwNul = 128u, kLpwDiv = 256u, kLpwEol2 = 512u;
 
 // position after the first '\n' at or after lo - 1 (the lane's first line start); >= hi: none
 TRRE_HD int64_t first_line_start_global(const ScanArgs& a, int64_t lo, int64_t hi) {
@@ -2224,7 +2225,56 @@ TRRE_HD void wt_block(const LpwView& T, const U128& cur, uint32_t next_w, uint32
     }
 }
 
-template <bool kWide>
+// The same with the pair form of the entries (front.hpp, lpw2): one table read per TWO input bytes.  The walk is a chain
+// of dependent LDS reads — with three waves per SIMD (the tiles fill the LDS) each step took ~260 clocks, twice what its
+// ten instructions and its 16 bytes of LDS traffic need — so the way to go faster is fewer, fatter steps: an entry holds
+// what two steps put into the window, already in place, and the window releases two bytes at a time.
+template <bool kCheckEnd>
+TRRE_HD void wt_block_pair(const LpwView& T, const U128& cur, uint32_t next_w, uint32_t (&kk)[4], int32_t rv, int32_t rhi, uint32_t& row,
+                           uint32_t& win, uint32_t& win_hi, uint32_t& seen, uint32_t (&Rm)[4], uint32_t& done, int32_t& rend) {
+    const uint32_t wd[5] = {cur.x, cur.y, cur.z, cur.w, next_w};
+    uint32_t R = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const uint32_t w = wd[d];
+        const uint32_t kc[4] = {kk[0], kk[1], kk[2], kk[3]};
+        lpw_classes(T, wd[d + 1], kk);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            const uint32_t col = __umul24(kc[2 * j], T.n_cls) + kc[2 * j + 1];     // (a full 32-bit multiply is quarter rate)
+#else
+            const uint32_t col = kc[2 * j] * T.n_cls + kc[2 * j + 1];
+#endif
+            const uint8_t* ep = reinterpret_cast<const uint8_t*>(T.ent) + row + (col << 5);
+            const U128 e = *reinterpret_cast<const U128*>(ep);
+            const uint64_t e2 = *reinterpret_cast<const uint64_t*>(ep + 16);
+            const uint32_t w2 = w >> (16 * j);                                   // the pair's bytes in bytes 0 and 1
+            win |= perm_b32(w2, e.z, e.w);
+            win_hi |= perm_b32(w2, (uint32_t)e2, (uint32_t)(e2 >> 32));
+            R = alignbit_b32(win, R, 16);
+            win = alignbit_b32(win_hi, win, 16);
+            win_hi >>= 16;
+            row = e.x;
+            seen |= e.y;
+            if (kCheckEnd) {
+                const int32_t p1 = rv + 4 * d + 2 * j + 1;
+                const uint32_t hit1 = ((e.y >> 6) & 1u) & (uint32_t)(p1 >= rhi) & (done ^ 1u);
+                rend = hit1 ? p1 : rend;
+                done |= hit1;
+                const uint32_t hit2 = ((e.y >> 9) & 1u) & (uint32_t)(p1 + 1 >= rhi) & (done ^ 1u);
+                rend = hit2 ? p1 + 1 : rend;
+                done |= hit2;
+            }
+        }
+        Rm[d] = R;
+        TRRE_PIN(seen);
+        if (kCheckEnd) { TRRE_PIN(done); TRRE_PIN(rend); }
+        TRRE_SCHED_FENCE();
+    }
+}
+
+template <bool kWide, bool kPair = false>
 struct WtLane {
     int64_t lo;
     int32_t rhi, rfs, rlimit, rv, rend;
@@ -2250,7 +2300,7 @@ struct WtLane {
         const int64_t room = a.vend - lo - 3 * kWtPiece;          // pieces are fetched one ahead: never run into
         rlimit = room < 0x40000000 ? (int32_t)room : 0x40000000;  // the end of the input; keep 32-bit offsets exact
         rv = rfs & ~(kWtOutRow - 1);                              // (output rows of all lanes complete in step)
-        row = rv == rfs ? 0u : kSkipState * n_cls * (kWide ? 32u : 16u);   // the byte before fs is '\n': SKIP reaches root exactly at fs
+        row = rv == rfs ? 0u : (kPair ? kSkipState * n_cls * n_cls * 32u : kSkipState * n_cls * (kWide ? 32u : 16u));   // the byte before fs is '\n': SKIP reaches root exactly at fs
         win = 0; win_hi = 0; Rprev = 0; done = 0;
         rend = 0x7fffffff;
         carry = U128{};
@@ -2282,7 +2332,8 @@ struct WtLane {
     template <bool kCheckEnd, bool kHead>
     TRRE_HD void step(const LpwView& T, const U128& blk, uint32_t next_w, int q, const WtOutRow& orow, uint8_t* out_v0) {
         uint32_t Rm[4];
-        wt_block<kCheckEnd, kWide>(T, blk, next_w, kk, rv + 16 * q, rhi, row, win, win_hi, seen, Rm, done, rend);
+        if (kPair) wt_block_pair<kCheckEnd>(T, blk, next_w, kk, rv + 16 * q, rhi, row, win, win_hi, seen, Rm, done, rend);
+        else wt_block<kCheckEnd, kWide>(T, blk, next_w, kk, rv + 16 * q, rhi, row, win, win_hi, seen, Rm, done, rend);
         if (!kWide) {
             carry.w = alignbyte_b32(Rm[0], Rprev, D);
         } else {

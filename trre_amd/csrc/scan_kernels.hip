@@ -902,28 +902,31 @@ constexpr int kWtThreads = 256;
 constexpr int kWtWaves = kWtThreads / kWave;
 constexpr int kWtEntMax = 32768;          // larger window tables stay in global memory (L1/L2)
 
-template <bool kLdsEnt, bool kWide>
+// kPair: the pair form of the entries (always in LDS)
+template <bool kLdsEnt, bool kWide, bool kPair = false>
 __global__ __launch_bounds__(kWtThreads) void k_stream_lpw(ScanArgs a, int64_t lane_bytes, int ent_room) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];    // cls[256] | entries[ent_room] | tiles[waves][in 4 KiB, out 8 KiB]
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
     for (int k = threadIdx.x; k < 256; k += kWtThreads) smem[k] = a.blob[h.off_cls + k];
+    const uint32_t off_ent = kPair ? h.off_lpw2 : h.off_lpw, ent_bytes = kPair ? h.lpw2_bytes : h.lpw_bytes;
     if (kLdsEnt) {
-        const U128* e = reinterpret_cast<const U128*>(a.blob + h.off_lpw);
+        const U128* e = reinterpret_cast<const U128*>(a.blob + off_ent);
         U128* d = reinterpret_cast<U128*>(smem + 256);
-        for (int k = threadIdx.x; k < (int)(h.lpw_bytes / 16); k += kWtThreads) d[k] = e[k];
+        for (int k = threadIdx.x; k < (int)(ent_bytes / 16); k += kWtThreads) d[k] = e[k];
     }
     __syncthreads();
     LpwView T;
     T.cls = smem;
-    T.ent = kLdsEnt ? reinterpret_cast<const U128*>(smem + 256) : reinterpret_cast<const U128*>(a.blob + h.off_lpw);
+    T.ent = kLdsEnt ? reinterpret_cast<const U128*>(smem + 256) : reinterpret_cast<const U128*>(a.blob + off_ent);
     T.delay = h.lpw_delay;
+    T.n_cls = h.n_cls;
     const int lid = threadIdx.x & (kWave - 1);
     uint8_t* tin = smem + 256 + ent_room + (threadIdx.x / kWave) * (kWtTile + kWtOutTile);
     uint8_t* tout = tin + kWtTile;
     const int64_t lane = (int64_t)blockIdx.x * kWtThreads + threadIdx.x;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-    WtLane<kWide> L;
+    WtLane<kWide, kPair> L;
     L.init(a, T, h.n_cls, lane, lane_bytes);
     WtMover M;
 #pragma unroll
@@ -1015,14 +1018,18 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_redo(ScanArgs a, int6
     }
     if (st) atomicOr(a.status, st);
 }
-void launch_lpw_kernel(int ent_bytes, bool wide, bool direct_ent_in_lds, const ScanArgs& a, int64_t lane_bytes, void* stream) {
+void launch_lpw_kernel(int ent_bytes, bool wide, bool direct_ent_in_lds, const ScanArgs& a, int64_t lane_bytes, void* stream, int pair_bytes) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
     const dim3 grid((unsigned)((n_lanes + kWtThreads - 1) / kWtThreads));
-    const bool ent_in_lds = ent_bytes <= kWtEntMax;
-    const int ent_room = ent_in_lds ? (ent_bytes + 15) / 16 * 16 : 0;
+    const bool pair = pair_bytes > 0 && pair_bytes <= kWtEntMax && !wide;
+    const bool ent_in_lds = pair || ent_bytes <= kWtEntMax;
+    const int ent_room = pair ? (pair_bytes + 15) / 16 * 16 : (ent_in_lds ? (ent_bytes + 15) / 16 * 16 : 0);
     const int lds = 256 + ent_room + kWtWaves * (kWtTile + kWtOutTile);
-    if (ent_in_lds && wide) {
+    if (pair) {
+        allow_big_lds<&k_stream_lpw<true, false, true>>();
+        hipLaunchKernelGGL((k_stream_lpw<true, false, true>), grid, dim3(kWtThreads), lds, s, a, lane_bytes, ent_room);
+    } else if (ent_in_lds && wide) {
         allow_big_lds<&k_stream_lpw<true, true>>();
         hipLaunchKernelGGL((k_stream_lpw<true, true>), grid, dim3(kWtThreads), lds, s, a, lane_bytes, ent_room);
     } else if (ent_in_lds) {

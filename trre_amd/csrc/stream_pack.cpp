@@ -47,6 +47,57 @@ void build_window_form(StreamTables& t, const StreamPackInput& in) {
     t.lpw_ok = true;
 }
 
+// pair form of the window entries (front.hpp): the composite of two steps, for tables whose pair form fits LDS
+void build_window_pair_form(StreamTables& t, const StreamPackInput& in) {
+    if (!t.lpw_ok || t.lpw_delay > 3) return;
+    const size_t C = t.n_cls, n = t.n_states;
+    if (n * C * C * 32 > 32768) return;
+    const uint32_t delay = t.lpw_delay;
+    std::vector<uint32_t> v(n * C * C * 8, 0);
+    for (uint32_t s = 0; s < n; ++s) {
+        for (uint32_t k0 = 0; k0 < C; ++k0) {
+            const StreamCell& a = in.rows[s][k0];
+            for (uint32_t k1 = 0; k1 < C; ++k1) {
+                const StreamCell& b = in.rows[a.next][k1];
+                const bool silent_a = s == in.skip || s == in.done, silent_b = a.next == in.skip || a.next == in.done;
+                // window positions (bytes past the release point before the first step): a step's bytes land at
+                // delay - pending of its state; the second step happens one release later
+                const uint32_t off_a = silent_a ? 0u : delay - t.pending_len[s];
+                const uint32_t off_b = (silent_b ? 0u : delay - t.pending_len[a.next]) + 1u;
+                int what[8];                                  // -1 nothing, 0..255 a literal, 256 / 257 the first / second input byte
+                for (int& w : what) w = -1;
+                bool ok = true;
+                auto place = [&](const StreamCell& x, uint32_t off, int input) {
+                    uint32_t pos = off;
+                    for (unsigned char ch : x.out) { if (pos >= 8 || what[pos] != -1) { ok = false; return; } what[pos++] = ch; }
+                    if (x.copy_c) { if (pos >= 8 || what[pos] != -1) { ok = false; return; } what[pos++] = 256 + input; }
+                };
+                place(a, off_a, 0);
+                place(b, off_b, 1);
+                if (!ok) return;                              // (not a table the window walk can take two steps at a time)
+                uint32_t* e = &v[((size_t)s * C * C + (size_t)k0 * C + k1) * 8];
+                e[0] = (uint32_t)(b.next * C * C * 32u);
+                e[1] = (a.eol ? 64u : 0u) | (b.eol ? 512u : 0u) | ((a.diverge || b.diverge) ? 256u : 0u) |
+                       (((in.col_kind[k0] == kColNul && !silent_a) || (in.col_kind[k1] == kColNul && !silent_b)) ? 128u : 0u);
+                for (int half = 0; half < 2; ++half) {
+                    uint32_t bytes = 0, sel = 0;
+                    for (int i = 0; i < 4; ++i) {
+                        const int w = what[4 * half + i];
+                        uint32_t pick = 0x0cu;                                   // constant 0x00
+                        if (w >= 256) pick = 4u + (uint32_t)(w - 256);           // byte 0 / 1 of the input register
+                        else if (w >= 0) { bytes |= (uint32_t)w << (8 * i); pick = (uint32_t)i; }
+                        sel |= pick << (8 * i);
+                    }
+                    e[2 + 2 * half] = bytes;
+                    e[3 + 2 * half] = sel;
+                }
+            }
+        }
+    }
+    t.lpw2 = std::move(v);
+    t.lpw2_ok = true;
+}
+
 // 16-byte entries for the count and emit passes (see front.hpp); small tables only (they live in LDS)
 void build_gen16(StreamTables& t, const StreamPackInput& in) {
     if ((size_t)t.n_states * t.n_cls > 2048) return;
@@ -191,6 +242,7 @@ StreamTables pack_stream_tables(const StreamPackInput& in) {
     t.bounded = in.bounded;
     if (in.bounded) lp = false;         // (a void launch must be noticed: only the count pass reports it)
     if (lp && !in.wide_cols) build_window_form(t, in);
+    if (lp && !in.wide_cols) build_window_pair_form(t, in);
     if (!in.wide_cols) build_gen16(t, in);
     if (!in.wide_cols) build_pairs(t, in);
     if (lp) t.flags |= kFlagLengthPreserving;
