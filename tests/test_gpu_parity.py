@@ -336,6 +336,53 @@ def test_dictionary_config_on_gpu():
         assert got == want, eng
 
 
+def test_random_dictionaries_on_gpu():
+    """Seeded dictionaries large enough for the fallback form of their tables — prefix-free or keys inside keys, texts of
+    0..8 bytes, partial keys, key upon key, lines of kilobytes, sparse and dense — both engines against the oracle: the copy
+    form where the tables have it (most of these), the count / emit pair where they do not or where a launch declares itself
+    void (texts every three bytes)."""
+    rng = random.Random(4242)
+    checked = 0
+    for it in range(8):
+        letters = "abcdefgh"[:rng.randint(6, 8)]
+        keys = set()
+        while len(keys) < rng.choice([300, 450, 600]):
+            keys.add("".join(rng.choice(letters) for _ in range(rng.randint(2, 7))))
+        keys = sorted(keys)
+        if it % 2:
+            keys = [k for k in keys if not any(o != k and k.startswith(o) for o in keys)]
+        rng.shuffle(keys)
+        lo = 0 if it == 5 else 1
+        vals = ["".join(rng.choice("XYZxyz01") for _ in range(rng.randint(lo, 8))) for _ in keys]
+        pat = "|".join("%s:%s" % kv for kv in zip(keys, vals))
+        density = [0.05, 0.15, 0.3, 0.6][it % 4]
+        toks = []
+        size = 0
+        while size < 400000:
+            r = rng.random()
+            if r < density:
+                t = rng.choice(keys)
+            elif r < density + 0.1:
+                t = rng.choice(keys)[:rng.randint(1, 6)] + rng.choice(letters)
+            elif r < density + 0.15:
+                t = rng.choice(keys) + rng.choice(keys) + rng.choice(keys)
+            else:
+                t = "".join(rng.choice(letters + "xyz") for _ in range(rng.randint(1, 9)))
+            t += rng.choice([" ", " ", "\n", ",", "", ""]) if it != 3 else rng.choice([" ", ",", ""])
+            toks.append(t)
+            size += len(t)
+        data = "".join(toks).encode() + rng.choice([b"\n", b""])
+        for eng in ("dft", "nft"):
+            try:
+                p = prog(pat, eng)
+            except trre_amd.TrreError:
+                continue
+            buf = data if eng == "dft" else data[: 1 << 16]           # (the NFT oracle is slow on these)
+            assert gpu_scan(p, buf) == Oracle(pat, eng).scan(buf), (it, eng)
+            checked += 1
+    assert checked >= 12
+
+
 def test_bounded_fold_falls_back_to_the_tile_kernels():
     """greedy loops fold into stream tables for runs of up to 64 bytes; a longer run voids the launch
     (overflow mark) and the tile kernels produce the result"""
