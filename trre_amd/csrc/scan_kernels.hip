@@ -775,6 +775,9 @@ __global__ __launch_bounds__(kThreads) void k_fb_copy(ScanArgs a, FbCopyArgs ca,
         if (threadIdx.x == 0) atomicOr(a.status, kStCapacity);
         return;
     }
+    // a void launch (the mark pass met a NUL, or more events than a lane's row holds: its sizes and the rows disagree):
+    // nothing is written, finish() runs the count / emit pair
+    if (*a.status & (kStEditOverflow | kStNul)) return;
     FbCopyTables T;
     T.lit = lit;
     T.esc = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_esc);
