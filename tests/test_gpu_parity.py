@@ -336,6 +336,35 @@ def test_dictionary_config_on_gpu():
         assert got == want, eng
 
 
+def test_byte_map_repairs_its_output_after_nul_bytes():
+    """A NUL cuts its line short (Q2): the byte map's positional launch is void, the library maps the stretches between
+    the cut lines again to where they belong (runtime.cpp, repair_bytemap_nuls) — NULs at every place of a line, several in
+    one line, in the last line with and without a newline, as the first and the last byte, misaligned buffers; more NULs
+    or cut lines than the repair takes (the general family runs instead); against the oracle."""
+    import torch
+    rng = random.Random(5)
+    p = prog("[a:A-z:Z]", "dft")
+    assert p.info.kernel == trre_amd.KERNEL_BYTEMAP
+    o = Oracle("[a:A-z:Z]", "dft")
+    base = corpus.word_soup(rng, 300000)
+    cases = [b"ab\0cd\nef\n", b"ab\0cd", b"\0", b"\0\n", b"a\0", b"\0a\n\0\nb\n", b"x\0y\0z\nq\n", b"abc\n\0", b"abc\n\0\n"]
+    for k in (1, 3, 40, 200, 300, 1500):
+        buf = bytearray(base)
+        for _ in range(k):
+            buf[rng.randrange(len(buf))] = 0
+        cases.append(bytes(buf))
+    one = bytearray(base)
+    one[len(one) // 2] = 0
+    cases += [bytes(one) + b"tail without newline", b"\0" + bytes(one), bytes(one) + b"\0"]
+    for data in cases:
+        want = o.scan(data)
+        for skip_in, skip_out in ((0, 0), (3, 3), (5, 0)):
+            t = torch.frombuffer(bytearray(b"x" * skip_in + data), dtype=torch.uint8).cuda()[skip_in:]
+            out = torch.empty(len(data) + 64 + skip_out, dtype=torch.uint8, device="cuda")[skip_out:]
+            got = p.scan_tensor(t, out=out).cpu().numpy().tobytes()
+            assert got == want, (len(data), data[:20], skip_in, skip_out)
+
+
 def test_random_dictionaries_on_gpu():
     """Seeded dictionaries large enough for the fallback form of their tables — prefix-free or keys inside keys, texts of
     0..8 bytes, partial keys, key upon key, lines of kilobytes, sparse and dense — both engines against the oracle: the copy

@@ -46,5 +46,7 @@ void launch_fb_copy(const ScanArgs& a, const FbCopyArgs& ca, const void* hdr, in
 bool fb_copy_fits(const void* hdr);
 void launch_chunk_scan(const uint64_t* total, uint64_t* base, int64_t n_chunks, void* stream);
 void launch_bytemap(const ScanArgs& a, void* stream);
+void launch_nul_eol(const uint8_t* in, int64_t n, const uint64_t* pos, uint64_t* eol, uint32_t count, void* stream);
+void launch_bytemap_shift(const uint8_t* blob, const uint8_t* src, uint8_t* dst, int64_t len, bool nl, void* stream);
 
 }  // namespace trre

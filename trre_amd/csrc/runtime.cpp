@@ -347,8 +347,9 @@ bool family_allowed(const trre_prog& p, int fam) {
 
 int ctx_init(ScanCtx& c) {
     if (c.d_status) return TRRE_OK;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c.d_status), 16));
-    HIP_TRY(hipMemset(c.d_status, 0, 16));
+    // status words [4], then the byte map's NUL list: a count, kNulCap offsets, kNulCap line ends (repair_bytemap_nuls)
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c.d_status), 24 + (size_t)trre::kNulCap * 16));
+    HIP_TRY(hipMemset(c.d_status, 0, 24));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c.h_status), 16, hipHostMallocDefault));
     HIP_TRY(hipEventCreate(&c.ev0));
     HIP_TRY(hipEventCreate(&c.ev1));
@@ -528,11 +529,12 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
         args.sym_v0 = cx->d_sym;
     }
     if (!batch) {
-        HIP_TRY(hipMemsetAsync(cx->d_status, 0, 16, stream));
+        HIP_TRY(hipMemsetAsync(cx->d_status, 0, 24, stream));          // (status words and the NUL count)
         if (p->profiling) HIP_TRY(hipEventRecord(cx->ev0, stream));
     }
     pd.timed = p->profiling;
     if (family == TRRE_KERNEL_BYTEMAP) {
+        args.nul_list = cx->d_status + 4;
         launch_bytemap(args, stream);
     } else if (family == TRRE_KERNEL_TILE_LP) {
         launch_tile_kernel(0, p->engine, p->mask_bytes, args, n_chunks, stream);
@@ -662,6 +664,60 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
     return TRRE_OK;
 }
 
+// A byte map's launch met NUL bytes: a NUL cuts its line short (Q2) — the bytes before it are mapped, a '\n' stands at its
+// position, the rest of the record is gone — so everything behind it moves up.  The kernel listed the NULs; the lines'
+// ends are looked up, and the stretches between the cuts are mapped again from the input to where they belong (the
+// first one is in place already).  Returns TRRE_OK with *out_len, an error, or -1: not a case for this (more NULs than the
+// list holds, more than 256 cut lines, an in-place scan) — the caller runs the buffer through the general family.
+int repair_bytemap_nuls(DeviceState* st, ScanCtx* cx, const Pending& was, size_t* out_len) {
+    using namespace trre;
+    static const bool off = getenv("TRRE_NO_NUL_REPAIR") != nullptr;
+    if (off || was.d_in == was.d_out) return -1;
+    uint32_t count = 0;
+    HIP_TRY(hipMemcpyAsync(&count, cx->d_status + 4, 4, hipMemcpyDeviceToHost, was.stream));
+    HIP_TRY(hipStreamSynchronize(was.stream));
+    if (count == 0 || count > kNulCap) return -1;
+    uint64_t* d_pos = reinterpret_cast<uint64_t*>(cx->d_status + 6);
+    uint64_t* d_eol = d_pos + kNulCap;
+    launch_nul_eol(was.d_in, (int64_t)was.n, d_pos, d_eol, count, was.stream);
+    std::vector<uint64_t> pos(count), eol(count);
+    HIP_TRY(hipMemcpyAsync(pos.data(), d_pos, (size_t)count * 8, hipMemcpyDeviceToHost, was.stream));
+    HIP_TRY(hipMemcpyAsync(eol.data(), d_eol, (size_t)count * 8, hipMemcpyDeviceToHost, was.stream));
+    HIP_TRY(hipStreamSynchronize(was.stream));
+    std::vector<std::pair<uint64_t, uint64_t>> cuts;          // (the NUL, the end of its line): the first NUL of every line
+    {
+        std::vector<std::pair<uint64_t, uint64_t>> all(count);
+        for (uint32_t i = 0; i < count; ++i) all[i] = {pos[i], eol[i]};
+        std::sort(all.begin(), all.end());
+        bool any = false;
+        uint64_t done_to = 0;
+        for (const auto& c : all) {
+            if (any && c.first <= done_to) continue;
+            cuts.push_back(c);
+            done_to = c.second;
+            any = true;
+        }
+    }
+    if (cuts.size() > 256) return -1;
+    const uint8_t* blob = st->d_blob;
+    // stretch by stretch: input [s, the next NUL) mapped to s - shift, then a '\n'; the last one ends at the last byte of
+    // the input, which is a terminator whatever it holds (Q1)
+    uint64_t s = 0, shift = 0;
+    const uint64_t last_byte = (uint64_t)was.n - 1;
+    for (size_t j = 0; j < cuts.size(); ++j) {
+        const uint64_t nul = cuts[j].first;
+        if (j == 0) launch_bytemap_shift(blob, was.d_in + nul, was.d_out + nul, 0, true, was.stream);       // (in place already: only its '\n')
+        else launch_bytemap_shift(blob, was.d_in + s, was.d_out + (s - shift), (int64_t)(nul - s), true, was.stream);
+        shift += cuts[j].second - nul;
+        s = cuts[j].second + 1;
+    }
+    if (s <= last_byte) launch_bytemap_shift(blob, was.d_in + s, was.d_out + (s - shift), (int64_t)(last_byte - s), true, was.stream);
+    HIP_TRY(hipStreamSynchronize(was.stream));
+    cx->relaunches += 1;
+    if (out_len) *out_len = (size_t)((uint64_t)was.n - shift);
+    return TRRE_OK;
+}
+
 int finish(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
     using namespace trre;
     Pending& pd = cx->pend;
@@ -747,6 +803,10 @@ int finish(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
     if (is_stream(was.family) && (status & kStOverflow)) return again(general_family(*p, false));
     if (!is_gen(was.family)) {
         // a NUL cuts its line short, so output positions no longer equal input positions: redo with a general family
+        if ((status & kStNul) && was.family == TRRE_KERNEL_BYTEMAP) {
+            const int rc = repair_bytemap_nuls(st, cx, was, out_len);
+            if (rc >= 0) return rc;
+        }
         if (status & kStNul) return again(general_family(*p, !is_guided(was.family)));
         if (out_len) *out_len = was.n;
         return TRRE_OK;

@@ -62,7 +62,10 @@ struct ScanArgs {
                              // the position of its first line start (output position == input position at line starts)
     uint8_t* sym_v0;         // guided families: one symbol per input byte, indexed like in_v0 (v-space); the
                              // backward pass fills [0, round_up(vend, 64)), the forward pass reads it
+    uint32_t* nul_list;      // byte map: [0] = NUL bytes met, from [2] on their offsets in the input (64 bits each, the first
+                             // kNulCap of them), or null: what finish() repairs the output from (runtime.cpp)
 };
+constexpr uint32_t kNulCap = 1024;
 
 // ---- phase: stage the tile -------------------------------------------------------------
 template <class G>
@@ -2783,12 +2786,31 @@ TRRE_HD uint32_t map4(const uint8_t* m, uint32_t w) {
 }
 TRRE_HD uint32_t has_zero_byte(uint32_t w) { return (w - 0x01010101u) & ~w & 0x80808080u; }
 
+// the NUL bytes of a vector, for the repair of the output (rare: a list in memory, appended to with an atomic)
+TRRE_HD void nul_record(const ScanArgs& a, const U128& w, int64_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (!a.nul_list) return;
+    const uint32_t wd[4] = {w.x, w.y, w.z, w.w};
+    for (int b = 0; b < 16; ++b) {
+        const int64_t vv = v + b;
+        if (vv < a.vbeg || vv >= a.vend - 1 || ((wd[b >> 2] >> (8 * (b & 3))) & 0xffu) != 0u) continue;
+        const uint32_t k = atomicAdd(a.nul_list, 1u);
+        if (k < kNulCap) reinterpret_cast<uint64_t*>(a.nul_list + 2)[k] = (uint64_t)(vv - a.vbeg);
+    }
+#else
+    (void)a; (void)w; (void)v;
+#endif
+}
 TRRE_HD void bytemap_vec(const ScanArgs& a, const uint8_t* map, const U128& w, int64_t v, bool aligned, uint32_t& zero) {
     U128 r;
     r.x = map4(map, w.x); r.y = map4(map, w.y); r.z = map4(map, w.z); r.w = map4(map, w.w);
     if (v >= a.vbeg && v + 16 <= a.vend - 1) {            // interior vector
-        zero |= has_zero_byte(w.x) | has_zero_byte(w.y) | has_zero_byte(w.z) | has_zero_byte(w.w);
+        const uint32_t z = has_zero_byte(w.x) | has_zero_byte(w.y) | has_zero_byte(w.z) | has_zero_byte(w.w);
+        if (z) nul_record(a, w, v);
+        zero |= z;
         if (aligned) { *reinterpret_cast<U128*>(a.out_v0 + v) = r; return; }
+    } else {
+        nul_record(a, w, v);
     }
     const uint8_t* src = reinterpret_cast<const uint8_t*>(&w);
     const uint8_t* dst = reinterpret_cast<const uint8_t*>(&r);

@@ -823,7 +823,9 @@ __global__ __launch_bounds__(kMapThreads) void k_bytemap(ScanArgs a, int64_t nve
             if (kNonTemporal && aligned && v >= a.vbeg && v + 16 <= a.vend - 1) {
                 U128 r;
                 r.x = map4(map, w[u].x); r.y = map4(map, w[u].y); r.z = map4(map, w[u].z); r.w = map4(map, w[u].w);
-                zero |= has_zero_byte(w[u].x) | has_zero_byte(w[u].y) | has_zero_byte(w[u].z) | has_zero_byte(w[u].w);
+                const uint32_t z = has_zero_byte(w[u].x) | has_zero_byte(w[u].y) | has_zero_byte(w[u].z) | has_zero_byte(w[u].w);
+                if (z) nul_record(a, w[u], v);
+                zero |= z;
                 U128* dst = reinterpret_cast<U128*>(a.out_v0 + v);
                 __builtin_nontemporal_store(r.x, &dst->x); __builtin_nontemporal_store(r.y, &dst->y);
                 __builtin_nontemporal_store(r.z, &dst->z); __builtin_nontemporal_store(r.w, &dst->w);
@@ -1272,6 +1274,48 @@ bool fb_fits(const void* hdr) { return fb_lds_bytes(*static_cast<const StreamBlo
 
 void launch_chunk_scan(const uint64_t* total, uint64_t* base, int64_t n_chunks, void* stream) {
     hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), total, base, n_chunks);
+}
+
+// ---- repair of a byte map's output after NUL bytes (runtime.cpp, repair_bytemap_nuls) ----------------------------------
+// where the line of each listed NUL ends: the first '\n' at or behind it, or the last byte of the input (a terminator, Q1)
+__global__ void k_nul_eol(const uint8_t* in, int64_t n, const uint64_t* pos, uint64_t* eol, uint32_t count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    int64_t j = (int64_t)pos[i];
+    while (j < n - 1 && in[j] != (uint8_t)'\n') ++j;
+    eol[i] = (uint64_t)j;
+}
+// dst[0, len) = map[src[0, len)], then (nl) a '\n' at dst[len]: any alignment of either side (aligned 16-byte stores, the
+// loads as they fall)
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+__global__ __launch_bounds__(kMapThreads) void k_bytemap_shift(const uint8_t* blob, const uint8_t* src, uint8_t* dst, int64_t len, int nl) {
+    __shared__ uint8_t map[256];
+    const DftBlobHeader& h = *reinterpret_cast<const DftBlobHeader*>(blob);
+    map[threadIdx.x] = blob[h.off_bytemap + threadIdx.x];
+    __syncthreads();
+    int64_t head = (int64_t)((16u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u);
+    if (head > len) head = len;
+    const int64_t nvec = (len - head) >> 4;
+    const int64_t gid = (int64_t)blockIdx.x * kMapThreads + threadIdx.x, stride = (int64_t)gridDim.x * kMapThreads;
+    for (int64_t k = gid; k < nvec; k += stride) {
+        const u32_unaligned* s4 = reinterpret_cast<const u32_unaligned*>(src + head + 16 * k);
+        U128 r;
+        r.x = map4(map, s4[0]); r.y = map4(map, s4[1]); r.z = map4(map, s4[2]); r.w = map4(map, s4[3]);
+        *reinterpret_cast<U128*>(dst + head + 16 * k) = r;
+    }
+    if (gid < head) dst[gid] = map[src[gid]];
+    const int64_t tail0 = head + 16 * nvec;
+    if (gid < len - tail0) dst[tail0 + gid] = map[src[tail0 + gid]];
+    if (nl && gid == 0) dst[len] = (uint8_t)'\n';
+}
+void launch_nul_eol(const uint8_t* in, int64_t n, const uint64_t* pos, uint64_t* eol, uint32_t count, void* stream) {
+    hipLaunchKernelGGL(k_nul_eol, dim3((count + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), in, n, pos, eol, count);
+}
+void launch_bytemap_shift(const uint8_t* blob, const uint8_t* src, uint8_t* dst, int64_t len, bool nl, void* stream) {
+    int64_t blocks = (len / 16 + kMapThreads - 1) / kMapThreads;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_bytemap_shift, dim3((unsigned)blocks), dim3(kMapThreads), 0, static_cast<hipStream_t>(stream), blob, src, dst, len, nl ? 1 : 0);
 }
 
 void launch_bytemap(const ScanArgs& a, void* stream) {
