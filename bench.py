@@ -203,6 +203,8 @@ def run_config(trre_amd, spec, inp, out, tmp, want_cpu):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / spec["steps"]
     kernel_ms = prog.last_kernel_ms()
+    if spec.get("finish_each"):
+        kernel_ms = dt * 1e3             # (the events bracket the first launch only: a step that finish() completes with more launches is timed whole)
     rec.update({"output_bytes": m, "steps": spec["steps"], "ms_per_step": round(dt * 1e3, 4), "input_GBps": round(n / dt / 1e9, 1),
                 "kernel_ms": round(kernel_ms, 4), "achieved_GBps": round(n / (kernel_ms * 1e-3) / 1e9, 1),
                 "frac": round(n / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
