@@ -355,7 +355,8 @@ def test_byte_map_repairs_its_output_after_nul_bytes():
         cases.append(bytes(buf))
     one = bytearray(base)
     one[len(one) // 2] = 0
-    cases += [bytes(one) + b"tail without newline", b"\0" + bytes(one), bytes(one) + b"\0"]
+    cases += [bytes(one) + b"tail without newline", b"\0" + bytes(one), bytes(one) + b"\0",
+              b"ab\0" + b"x" * (5 << 20) + b"\nend\n"]               # (a line of megabytes behind a NUL: not repaired, run again)
     for data in cases:
         want = o.scan(data)
         for skip_in, skip_out in ((0, 0), (3, 3), (5, 0)):

@@ -687,7 +687,10 @@ int repair_bytemap_nuls(DeviceState* st, ScanCtx* cx, const Pending& was, size_t
     std::vector<std::pair<uint64_t, uint64_t>> cuts;          // (the NUL, the end of its line): the first NUL of every line
     {
         std::vector<std::pair<uint64_t, uint64_t>> all(count);
-        for (uint32_t i = 0; i < count; ++i) all[i] = {pos[i], eol[i]};
+        for (uint32_t i = 0; i < count; ++i) {
+            if (eol[i] == ~0ull) return -1;                   // (a line of many megabytes behind a NUL)
+            all[i] = {pos[i], eol[i]};
+        }
         std::sort(all.begin(), all.end());
         bool any = false;
         uint64_t done_to = 0;

@@ -1282,8 +1282,9 @@ __global__ void k_nul_eol(const uint8_t* in, int64_t n, const uint64_t* pos, uin
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     int64_t j = (int64_t)pos[i];
-    while (j < n - 1 && in[j] != (uint8_t)'\n') ++j;
-    eol[i] = (uint64_t)j;
+    const int64_t limit = j + (4 << 20);                   // (one thread per NUL: a line of many megabytes is not for this path)
+    while (j < n - 1 && j < limit && in[j] != (uint8_t)'\n') ++j;
+    eol[i] = (j < n - 1 && in[j] != (uint8_t)'\n') ? ~0ull : (uint64_t)j;
 }
 // dst[0, len) = map[src[0, len)], then (nl) a '\n' at dst[len]: any alignment of either side (aligned 16-byte stores, the
 // loads as they fall)
