@@ -297,6 +297,27 @@ def test_fallback_form_of_large_tables():
     assert n_forms >= 6
 
 
+def test_compile_time_of_nested_optional_groups():
+    """The follow lists are one walk over the epsilon states, not one per path: nested optional groups compiled in
+    exponential time (tools/gpu_fuzz.py seed 33 found a pattern whose compile did not end).  In a subprocess: a C call
+    cannot be interrupted."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pats = [r"(((:(:cy)y|.+:.|ca\c)a)[b-y]x:)\]??:c[a:b-b:b]|[axa]\a:((y.{,2}?b)?.{,2}|[b-c]a(b\[??a:))(a:(x))|ax{2}",
+            "(a?b?c?d?e?){,2}" * 4 + "x:y", "((a?:x)?(b?:y)?(c?:z)?)??" * 6 + "q"]
+    code = ("import sys; sys.path.insert(0, %r); import trre_amd\n"
+            "for pat in %r:\n"
+            "    for eng in ('nft', 'dft'):\n"
+            "        try: trre_amd.Program(pat, eng)\n"
+            "        except trre_amd.TrreError: pass\n"
+            "        try: trre_amd.Program(pat, 'nft', mode='match')\n"
+            "        except trre_amd.TrreError: pass\n" % (root, pats))
+    r = subprocess.run([sys.executable, "-c", code], timeout=240)
+    assert r.returncode == 0
+
+
 def test_copy_form_of_large_tables():
     """The copy form (scan_block.hpp: fb_lane<3> marks where the replacement texts go, fb_copy_lane copies the input around
     them): the golden dictionary slice, then seeded dictionaries — prefix-free or keys inside keys (escape records), texts

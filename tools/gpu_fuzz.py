@@ -146,6 +146,8 @@ def main():
         alpha = DICT_ALPHA if r < a.dict else ALPHA
         pat = (gen_dictionary(rng) if r < a.dict else gen_replacement_list(rng) if r < a.dict + 0.3 else gen_expr(rng)).decode("latin-1")
         eng = rng.choice(["dft", "nft"])
+        if a.verbose:
+            print("pattern %r eng=%s" % (pat, eng), flush=True)      # (before it is compiled: a compile that does not end shows here)
         try:
             o = Oracle(pat, eng)
             p = trre_amd.Program(pat, eng)

@@ -59,10 +59,18 @@ NftNodes build_nft_nodes(const Nft& nft, bool match_mode, bool all_paths) {
     const uint32_t n_nodes = (uint32_t)t.node.size();
 
     std::vector<uint8_t> on_path(nft.st.size(), 0);
+    // Epsilon states already walked for the list in hand.  The first occurrence of every target wins, so a state reached
+    // again (off the current path) has nothing to add: every target behind it is listed, every cycle behind it was met
+    // the first time (a cycle through a state that is only now on the path would have run into the path of the first
+    // walk).  Without this the walk follows every PATH: nested optional groups — (a?b?c?)??{,2} — made it exponential
+    // (found by tools/gpu_fuzz.py, seed 33: a compile that did not end).
+    std::vector<uint32_t> walked(nft.st.size(), 0);
+    uint32_t epoch = 0;
     size_t n_entries = 0;
     auto list_for = [&](int32_t from_state, std::vector<NodeFollow>& list) {
         // depth-first, priority order, first occurrence of each target wins,
         // stop at FINAL or when an epsilon cycle closes
+        ++epoch;
         std::vector<uint8_t> seen(n_nodes, 0);
         bool done = false, seen_final = false;
         std::function<void(int32_t, std::string&)> visit = [&](int32_t s, std::string& out) {
@@ -93,6 +101,8 @@ NftNodes build_nft_nodes(const Nft& nft, bool match_mode, bool all_paths) {
                     done = true;
                     break;
                 }
+                if (!all_paths && walked[s] == epoch) break;
+                walked[s] = epoch;
                 on_path[s] = 1;
                 entered.push_back(s);
                 if (st.kind == NKind::Prod) {

@@ -859,9 +859,14 @@ int compile_impl(const std::string& pattern, int engine, trre_prog** out, int mo
             if (!p->gt.ok)
                 throw Error(kErrUnsupported, "error: the backward automaton of this pattern has too many states (match mode runs on the guided tables only)");
         } else {
+            // TRRE_COMPILE_TRACE=1: the stages of the NFT compile on stderr as they start (to find the one a pattern is slow in)
+            static const bool trace_on = getenv("TRRE_COMPILE_TRACE") != nullptr;
+            auto trace = [&](const char* what) { if (trace_on) fprintf(stderr, "compile: %s\n", what); };
+            trace("nodes");
             const NftNodes nodes = build_nft_nodes(nft);
             p->nft_nodes = (uint32_t)nodes.node.size();
             std::unique_ptr<Error> deferred;
+            trace("bitmask tables");
             try {
                 p->nt = build_nft_tables(nodes);
                 p->mask_bytes = p->nt.n_cons <= 8 ? 1 : p->nt.n_cons <= 16 ? 2 : p->nt.n_cons <= 32 ? 4 : 8;
@@ -873,6 +878,7 @@ int compile_impl(const std::string& pattern, int engine, trre_prog** out, int mo
             }
             // the fold walks the follow lists (TRRE_NFT_FOLD=states: the NFT's states as the reference does, =both: both, compared)
             const char* fold = getenv("TRRE_NFT_FOLD");
+            trace("fold");
             if (fold && !strcmp(fold, "states")) {
                 p->stt = build_stream_nft(nft);
             } else {
@@ -887,7 +893,9 @@ int compile_impl(const std::string& pattern, int engine, trre_prog** out, int mo
                         throw Error(kErrArg, "error: the two folds of the NFT scan loop disagree (TRRE_NFT_FOLD=both)");
                 }
             }
+            trace("guided tables");
             p->gt = build_guided_nft(nodes);
+            trace("done");
             // no kernel family can run this pattern (a bounded stream table needs general kernels behind it)
             if (deferred && !p->gt.ok && (!p->stt.ok || p->stt.bounded)) throw *deferred;
         }
