@@ -120,6 +120,9 @@ private:
             for (uint32_t k = 2; k < g.n_cls; ++k) {
                 RevSets nx;
                 for (uint32_t t : readers_[k]) {
+                    // (a budget on the construction's work: up to 16 384 states x classes x nodes x follow entries would be hours)
+                    work_ += nd_.follow[t].size() + 1;
+                    if (work_ > kGuidedWork) throw StreamGiveUp();
                     const int e = decisive(nd_.follow[t], rev_[r], final_ok(r));
                     if (e < 0) continue;
                     nx.alive.push_back(t);
@@ -141,6 +144,8 @@ private:
     }
 
     bool final_ok(uint32_t sym) const { return !match_ || sym == kSymEol || sym == kSymNul; }
+    static constexpr uint64_t kGuidedWork = 400u * 1000u * 1000u;      // follow entries looked at (a few seconds)
+    uint64_t work_ = 0;
 
     // forward states: 0 root, 1 SKIP, 2 DONE (the stream kernels' conventions), then (node, muted)
     uint32_t intern_fwd(uint32_t node, bool muted) {
