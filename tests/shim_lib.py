@@ -107,7 +107,7 @@ def shim_scan_guided(prog, family, data, geo=1, in_mis=0, out_mis=0):
 def scan_guided_like_runtime(prog, data, geo=1, family=GUIDED_LP, in_mis=0, out_mis=0):
     out, st = shim_scan_guided(prog, family, data, geo, in_mis, out_mis)
     assert not st & ST_MISMATCH, "count and emit passes disagree"
-    if st & ST_DIVERGE:
+    if st & ST_DIVERGE and not (family in GUIDED_LP_ALL and st & ST_NUL):      # (void by a NUL: the general family decides)
         raise RuntimeError("diverges")
     if family in GUIDED_LP_ALL and st & ST_NUL:
         out, st = shim_scan_guided(prog, GUIDED_GEN, data, geo, in_mis, out_mis)
@@ -137,13 +137,16 @@ def scan_like_runtime(prog, data, geo=1, family=None, in_mis=0, out_mis=0):
         blob = prog.export_tables()
         out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
     assert not st & ST_MISMATCH, "count and emit passes disagree"
-    if st & ST_DIVERGE:
+    lp = fam not in (3, 5, 7, 9, 22, 23)
+    if st & ST_DIVERGE and not (lp and st & ST_NUL):      # (a positional launch that met a NUL is void, whatever else it says)
         raise RuntimeError("diverges")
-    if fam not in (3, 5, 7, 9, 22, 23) and st & ST_NUL:
+    if lp and st & ST_NUL:
         gen = (7 if fam in (6, 8, 20, 21, STREAM_LPW_PAIR) else 5) if info.stream_states else 3
         blob = prog.export_stream_tables() if gen in (5, 7) else prog.export_tables()
         out, st = shim_scan(blob, info.engine, gen, data, geo, in_mis, out_mis)
         assert not st & ST_MISMATCH
+        if st & ST_DIVERGE:
+            raise RuntimeError("diverges")
     return out
 
 

@@ -297,6 +297,18 @@ def test_fallback_form_of_large_tables():
     assert n_forms >= 6
 
 
+def test_a_positional_launch_void_by_a_nul_reports_nothing_else():
+    """A length-preserving launch walks on behind a NUL, where the reference never looks; what it meets there (here: a
+    diverging attempt) is not the scan's result — the general family decides.  (Found by a shim fuzz run, round 3.)"""
+    for pat, data in [(b"c|(\\\\c)?((a:.*[c:a-y:a]):x.)|(a).[b:y-y:y]", b"x\x00axa\nx\n"),
+                      (b"y|[ba](\\([c-y]|c[aa]*?:([b-y]a{2})+?)", b"xzx<>xcyz\nbxcabay\nc\x00cbyacbycacy\nxxxcxbbxcy\n\ny\n")]:
+        p = prog(pat, "dft")
+        want = Oracle(pat, "dft").scan(data)
+        for fam in shim_families(p):
+            for geo in (0, 1):
+                assert shim_lib.scan_like_runtime(p, data, geo=geo, family=fam) == want, (pat, fam, geo)
+
+
 def test_compile_time_of_nested_optional_groups():
     """The follow lists are one walk over the epsilon states, not one per path: nested optional groups compiled in
     exponential time (tools/gpu_fuzz.py seed 33 found a pattern whose compile did not end).  In a subprocess: a C call

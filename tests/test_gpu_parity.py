@@ -336,6 +336,16 @@ def test_dictionary_config_on_gpu():
         assert got == want, eng
 
 
+def test_a_positional_launch_void_by_a_nul_reports_nothing_else():
+    """(tests/test_front_shim.py, the same name) through the library: every family, no TRRE_E_DIVERGES"""
+    for pat, data in [(b"c|(\\\\c)?((a:.*[c:a-y:a]):x.)|(a).[b:y-y:y]", b"x\x00axa\nx\n"),
+                      (b"y|[ba](\\([c-y]|c[aa]*?:([b-y]a{2})+?)", b"xzx<>xcyz\nbxcabay\nc\x00cbyacbycacy\nxxxcxbbxcy\n\ny\n")]:
+        p = prog(pat, "dft")
+        want = Oracle(pat, "dft").scan(data)
+        for fam in p.allowed_kernels():
+            assert gpu_scan(p, data, fam) == want, (pat, fam)
+
+
 def test_byte_map_repairs_its_output_after_nul_bytes():
     """A NUL cuts its line short (Q2): the byte map's positional launch is void, the library maps the stretches between
     the cut lines again to where they belong (runtime.cpp, repair_bytemap_nuls) — NULs at every place of a line, several in

@@ -748,7 +748,10 @@ int finish(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
         if (rc) return rc;
         return finish(p, st, cx, out_len);
     };
-    if (status & kStDiverge) {
+    // (a length-preserving launch that met a NUL is void — it went on walking behind the NUL, where the reference never
+    // looks — and so is whatever else it reports: the general family decides, below)
+    const bool void_by_nul = !is_gen(was.family) && (status & kStNul);
+    if ((status & kStDiverge) && !void_by_nul) {
         const char* msg = "error: stack max capacity reached (the reference's search does not terminate on this input)";
         if (out_len) *out_len = 0;
         // The NFT binary exits with everything it had printed so far (exit() flushes stdout): the lines before the bad one
