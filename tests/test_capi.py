@@ -62,7 +62,8 @@ def test_info_and_table_export():
     p = trre_amd.Program("(cat:dog|dog:cat)", "dft")
     blob = p.export_tables()
     sblob = p.export_stream_tables()
-    assert blob[:4] == b"TRD1" and sblob[:4] == b"TRS1" and len(blob) + len(sblob) == p.info.table_bytes
+    rblob, gblob = p.export_guided_tables()      # (round 4: the deterministic engine has guided tables too)
+    assert blob[:4] == b"TRD1" and sblob[:4] == b"TRS1" and len(blob) + len(sblob) + len(rblob) + len(gblob) == p.info.table_bytes
     p = trre_amd.Program("(cat:dog|dog:cat)", "nft")
     assert p.export_tables()[:4] == b"TRN1"
     with pytest.raises(trre_amd.TrreError):

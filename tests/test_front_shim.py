@@ -34,7 +34,8 @@ REFUSED_GOLDEN = set()
 def test_golden_vectors_tiny_geometry():
     """every golden case through the auto-selected kernel family, 64-byte chunks; NFT cases also through
     every guided family the pattern admits"""
-    n = n_guided = n_fail = 0
+    n = n_fail = 0
+    n_guided = {"nft": 0, "dft": 0}
     for pat, name, data, engine, exp in golden_lib.cases():
         p = prog(pat, engine)
         if isinstance(p, trre_amd.TrreError):
@@ -45,20 +46,21 @@ def test_golden_vectors_tiny_geometry():
             continue                      # the 100 kB line runs in the production-geometry test
         if exp is None:
             # the reference exits 1 on this input (an epsilon cycle entered): the product must report it, not print
-            for fam in [None] + (guided_families(p) if engine == "nft" else []):
+            for fam in [None] + guided_families(p):
                 with pytest.raises(RuntimeError, match="diverges"):
                     shim_lib.scan_like_runtime(p, data, geo=1, family=fam)
             n_fail += 1
             continue
         assert shim_lib.scan_like_runtime(p, data, geo=1) == exp, (pat, name, engine)
         n += 1
-        if engine == "nft":
-            # (the backward DFA of the 1000-key dictionary has more than 256 states: it runs on its folded stream table)
-            assert p.info.guided_rev_states or len(pat) > 1000, (pat, "no guided tables")
-            for fam in guided_families(p):
-                assert shim_lib.scan_like_runtime(p, data, geo=1, family=fam) == exp, (pat, name, fam)
-                n_guided += 1
-    assert n >= 870 and n_guided > 1000 and n_fail == 28
+        # (the backward DFA of the 1000-key dictionary has more than 256 states: it runs on its folded stream table; a DFT
+        # pattern whose tables are a byte map has no use for guided tables)
+        memoryless = engine == "dft" and p.info.flags & trre_amd.api.FLAG_MEMORYLESS
+        assert p.info.guided_rev_states or len(pat) > 1000 or memoryless, (pat, engine, "no guided tables")
+        for fam in guided_families(p):
+            assert shim_lib.scan_like_runtime(p, data, geo=1, family=fam) == exp, (pat, name, engine, fam)
+            n_guided[engine] += 1
+    assert n >= 870 and n_guided["nft"] > 1000 and n_guided["dft"] > 700 and n_fail == 28, (n, n_guided, n_fail)
 
 
 def guided_families(p):

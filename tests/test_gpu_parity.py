@@ -55,27 +55,30 @@ REFUSED_GOLDEN = set()
 
 
 def test_golden_vectors_on_gpu():
-    n = n_guided = n_fail = 0
+    n = n_fail = 0
+    n_guided = {"nft": 0, "dft": 0}
+    guided = (trre_amd.KERNEL_GUIDED_LP, trre_amd.KERNEL_GUIDED_GEN)
     for pat, name, data, engine, exp in golden_lib.cases():
         p = prog(pat, engine)
         if isinstance(p, trre_amd.TrreError):
             assert (pat, engine) in REFUSED_GOLDEN, (pat, engine, p)
             continue
         if exp is None:                     # the reference exits 1 here (epsilon cycle entered): so must the scan
-            with pytest.raises(trre_amd.TrreError) as e:
-                gpu_scan(p, data)
-            assert e.value.code == trre_amd.api.E_DIVERGES, (pat, name, engine)
+            for fam in [None] + [f for f in guided if f in allowed(p)]:
+                with pytest.raises(trre_amd.TrreError) as e:
+                    gpu_scan(p, data, fam)
+                assert e.value.code == trre_amd.api.E_DIVERGES, (pat, name, engine, fam)
             n_fail += 1
             continue
         assert gpu_scan(p, data) == exp, (pat, name, engine)
         n += 1
-        if engine == "nft":
-            # the guided families run every NFT pattern: check them too, not only where AUTO picks them
-            for fam in (trre_amd.KERNEL_GUIDED_LP, trre_amd.KERNEL_GUIDED_GEN):
-                if fam in allowed(p):
-                    assert gpu_scan(p, data, fam) == exp, (pat, name, fam)
-                    n_guided += 1
-    assert n == 902 and n_fail == 28 and n_guided > 500
+        # the guided families run every NFT pattern and (round 4) every DFT pattern that is not a byte map: check them
+        # too, not only where AUTO picks them
+        for fam in guided:
+            if fam in allowed(p):
+                assert gpu_scan(p, data, fam) == exp, (pat, name, engine, fam)
+                n_guided[engine] += 1
+    assert n == 902 and n_fail == 28 and n_guided["nft"] > 500 and n_guided["dft"] > 350, (n, n_fail, n_guided)
 
 
 _allowed = {}

@@ -334,6 +334,11 @@ struct GuidedTables {
 // byte, accepted only if it ends exactly at the end of the line; an accepted line prints its output and '\n', a
 // rejected one prints nothing.
 GuidedTables build_guided_nft(const NftNodes& nodes, const GuidedLimits& lim = GuidedLimits());
+// The deterministic engine in the same form (trre_dft.c:1110-1196): the backward DFA says at every position what becomes of an
+// attempt from START there (and which class the byte has), the forward transducer walks the determinised tables only through
+// attempts that succeed.  For patterns whose scan loop does not fold into a stream table (a loop before the decision:
+// 'a*b:x', '[a-z]+ing:X') and as what takes over when a bounded fold overflows.
+GuidedTables build_guided_dft(const Dft& dft, const GuidedLimits& lim = GuidedLimits());
 
 // Generator mode (`trre -a` / `trre -ma`): generate.cpp.  The backward DFA (one symbol per input byte, computed on the
 // device by the guided families' backward kernel) says which nodes are worth entering — SOME path accepts, or SOME path

@@ -38,6 +38,36 @@ struct RevSets {
 
 bool has(const std::vector<uint32_t>& v, uint32_t x) { return std::binary_search(v.begin(), v.end(), x); }
 
+// columns, pending bytes per state (consumed, not yet emitted) if that is a function of the state, and the packer:
+// shared by the two builders of forward tables (rows of cells over symbols; states 0 root, 1 SKIP, 2 DONE)
+StreamTables pack_forward(StreamPackInput& in, uint32_t n_rev, bool never_lp) {
+    for (uint32_t y = 0; y < n_rev; ++y) in.col_kind.push_back(y == kSymEol ? kColNewline : (y == kSymNul ? kColNul : kColPlain));
+    in.skip = 1;
+    in.done = 2;
+    const uint32_t n = (uint32_t)in.rows.size();
+    std::vector<int64_t> pend(n, INT64_MIN);
+    std::vector<uint32_t> work{0};
+    pend[0] = 0;
+    bool lp = true;
+    while (!work.empty() && lp) {
+        const uint32_t s = work.back();
+        work.pop_back();
+        for (uint32_t y = 0; y < n_rev && lp; ++y) {
+            const StreamCell& x = in.rows[s][y];
+            if (y == kSymNul || x.diverge) continue;
+            const int64_t p = pend[s] + 1 - (int64_t)x.out.size() - (x.copy_c ? 1 : 0);
+            if (p < 0) { lp = false; break; }
+            if (pend[x.next] == INT64_MIN) { pend[x.next] = p; work.push_back(x.next); }
+            else if (pend[x.next] != p) lp = false;
+        }
+    }
+    in.never_lp = !lp || never_lp;
+    in.pending_len.assign(n, 0);
+    if (lp)
+        for (uint32_t s = 0; s < n; ++s) in.pending_len[s] = pend[s] == INT64_MIN || s == 1 || s == 2 ? 0u : (uint32_t)pend[s];
+    return pack_stream_tables(in);
+}
+
 // index of the first entry of `list` the search does not get past, or -1 (the search fails).  final_ok: FINAL accepts
 // here (always in scan mode; in match mode only when nothing of the line is left)
 int decisive(const std::vector<NodeFollow>& list, const RevSets& r, bool final_ok) {
@@ -262,32 +292,7 @@ private:
             for (uint32_t y = 0; y < g.n_rev; ++y) row.push_back(cell(s, y));
             in.rows.push_back(std::move(row));
         }
-        for (uint32_t y = 0; y < g.n_rev; ++y) in.col_kind.push_back(y == kSymEol ? kColNewline : (y == kSymNul ? kColNul : kColPlain));
-        in.skip = 1;
-        in.done = 2;
-        // pending bytes per state (consumed, not yet emitted) if that is a function of the state
-        const uint32_t n = (uint32_t)fwd_.size();
-        std::vector<int64_t> pend(n, INT64_MIN);
-        std::vector<uint32_t> work{0};
-        pend[0] = 0;
-        bool lp = true;
-        while (!work.empty() && lp) {
-            const uint32_t s = work.back();
-            work.pop_back();
-            for (uint32_t y = 0; y < g.n_rev && lp; ++y) {
-                const StreamCell& x = in.rows[s][y];
-                if (y == kSymNul || x.diverge) continue;
-                const int64_t p = pend[s] + 1 - (int64_t)x.out.size() - (x.copy_c ? 1 : 0);
-                if (p < 0) { lp = false; break; }
-                if (pend[x.next] == INT64_MIN) { pend[x.next] = p; work.push_back(x.next); }
-                else if (pend[x.next] != p) lp = false;
-            }
-        }
-        in.never_lp = !lp || match_;
-        in.pending_len.assign(n, 0);
-        if (lp)
-            for (uint32_t s = 0; s < n; ++s) in.pending_len[s] = pend[s] == INT64_MIN || s == 1 || s == 2 ? 0u : (uint32_t)pend[s];
-        g.fwd = pack_stream_tables(in);
+        g.fwd = pack_forward(in, g.n_rev, match_);
     }
 
     const NftNodes& nd_;
@@ -302,6 +307,269 @@ private:
     std::map<uint64_t, uint32_t> fwd_index_;
 };
 
+// ---- the deterministic engine's attempts as the same two passes ----------------------------------------------
+// infer_dft (trre_dft.c:1110-1196) walks the determinised tables from START and succeeds at the FIRST final state it
+// enters (:1120-1125); a dead edge or the end of the line discards the attempt (:1132-1134, :1193-1195) and the line loop
+// (:1277-1283) copies one raw byte.  Whether the walk from a table state d at position i ends in success, failure or on an
+// edge the reference's closure never returns from (kEdgeDiverge) depends only on the rest of the line, and as a vector over
+// the states it is a function of the same vector at i + 1 and of line[i]: the backward DFA's raw state is (class of line[i],
+// {d that do not fail}, {d that diverge}).  The forward pass needs two things of it: the byte's class (an attempt under way
+// takes edge[d][class]: the walk is deterministic, and it is under way only if it succeeds) and what becomes of an attempt
+// from START — so the raw automaton is reduced to the coarsest one that still tells these (Moore's partition refinement,
+// output = (class, START's value)), and its states are the symbols.
+class GuidedDftBuilder {
+public:
+    GuidedDftBuilder(const Dft& d, const GuidedLimits& lim) : d_(d), lim_(lim) {}
+
+    GuidedTables run() {
+        GuidedTables g;
+        rows();
+        byte_classes(g);
+        raw_backward();
+        reduce(g);
+        forward(g);
+        g.wide = g.n_rev > 256;
+        g.sym_bits = g.wide ? 16 : ((g.n_rev <= 16 && g.fwd.g16_ok) ? 4 : 8);
+        g.ok = true;
+        return g;
+    }
+
+private:
+    struct Raw { uint32_t k = 0; std::vector<uint32_t> alive, div; };      // (sorted row indices)
+    enum : uint32_t { kFail = 0, kOk = 1, kDiv = 2 };
+
+    // what reading byte c in state s does, with the target named by `name_of` (final targets by their output)
+    std::string edge_sig(uint32_t s, int c, const std::vector<int32_t>& name_of) const {
+        const DftEdge& e = d_.st[s].edge[c];
+        if (e.to == kEdgeDiverge) return "D";
+        if (e.to < 0) return "-";
+        std::string sig = d_.st[e.to].final ? "F" : "G" + std::to_string(name_of[e.to]);
+        sig.push_back(':');
+        sig += std::to_string(e.out.size() + (d_.st[e.to].final ? d_.st[e.to].final_out.size() : 0));
+        sig.push_back(':');
+        sig += e.out;
+        if (d_.st[e.to].final) sig += d_.st[e.to].final_out;
+        return sig;
+    }
+
+    // table rows: the states an attempt can be in (a final state is left at once, a diverging one never entered), reduced:
+    // the reference's determinisation keeps one state per item list ('[a-z]+' has a state per letter); states that emit the
+    // same bytes and go to equivalent states on every byte are one row here (partition refinement; START stays alone at 0)
+    void rows() {
+        std::vector<uint32_t> live;
+        for (size_t s = 0; s < d_.st.size(); ++s)
+            if (!d_.st[s].final && !d_.st[s].diverges) live.push_back((uint32_t)s);
+        if (live.empty() || live[0] != 0) throw StreamGiveUp();
+        std::vector<int32_t> block(d_.st.size(), -1);
+        for (uint32_t s : live) block[s] = s == 0 ? 0 : 1;
+        size_t n_blocks = live.size() > 1 ? 2 : 1;
+        for (;;) {
+            std::map<std::string, int32_t> ids;
+            std::vector<int32_t> nb(d_.st.size(), -1);
+            nb[0] = 0;
+            for (uint32_t s : live) {
+                if (s == 0) continue;
+                work_ += 256;
+                if (work_ > kWork) throw StreamGiveUp();
+                std::string sig = std::to_string(block[s]);
+                for (int c = 1; c < 256; ++c) {
+                    if (c == '\n') continue;
+                    sig.push_back('|');
+                    sig += edge_sig(s, c, block);
+                }
+                nb[s] = ids.emplace(std::move(sig), (int32_t)ids.size() + 1).first->second;
+            }
+            block.swap(nb);
+            if (ids.size() + 1 == n_blocks) break;             // (a refinement only splits: the same count is the same partition)
+            n_blocks = ids.size() + 1;
+        }
+        row_of_ = block;
+        state_of_.assign(n_blocks, 0xffffffffu);
+        for (uint32_t s : live)
+            if (state_of_[row_of_[s]] == 0xffffffffu) state_of_[row_of_[s]] = s;
+    }
+
+    // bytes with the same edges out of every row behave alike; '\n' and NUL never occur inside a line
+    void byte_classes(GuidedTables& g) {
+        std::map<std::string, uint8_t> index;
+        g.cls['\n'] = 0;
+        g.cls[0] = 1;
+        rep_ = {'\n', 0};
+        for (int c = 1; c < 256; ++c) {
+            if (c == '\n') continue;
+            std::string sig;
+            for (uint32_t s : state_of_) { sig += edge_sig(s, c, row_of_); sig.push_back('|'); }
+            auto hit = index.find(sig);
+            if (hit == index.end()) {
+                if (rep_.size() >= 256) throw StreamGiveUp();
+                hit = index.emplace(std::move(sig), (uint8_t)rep_.size()).first;
+                rep_.push_back(c);
+            }
+            g.cls[c] = hit->second;
+        }
+        g.n_cls = (uint32_t)rep_.size();
+    }
+
+    uint32_t intern_raw(Raw&& r) {
+        if (r.alive.empty()) return kSymDead;
+        std::vector<uint32_t> key{r.k};
+        key.insert(key.end(), r.alive.begin(), r.alive.end());
+        key.push_back(0xffffffffu);
+        key.insert(key.end(), r.div.begin(), r.div.end());
+        auto hit = raw_index_.find(key);
+        if (hit != raw_index_.end()) return hit->second;
+        if (raw_.size() >= kMaxRaw) throw StreamGiveUp();
+        const uint32_t id = (uint32_t)raw_.size();
+        raw_.push_back(std::move(r));
+        raw_index_.emplace(std::move(key), id);
+        return id;
+    }
+
+    void raw_backward() {
+        raw_.assign(3, Raw());                               // 0 nothing alive, 1 at a '\n', 2 at a NUL
+        const uint32_t C = (uint32_t)rep_.size();
+        for (uint32_t r = 0; r < raw_.size(); ++r) {         // (raw_ grows while we go)
+            std::vector<uint32_t> row(C, 0);
+            row[0] = kSymEol;
+            row[1] = kSymNul;
+            for (uint32_t k = 2; k < C; ++k) {
+                work_ += state_of_.size();
+                if (work_ > kWork) throw StreamGiveUp();
+                Raw nx;
+                nx.k = k;
+                for (uint32_t q = 0; q < state_of_.size(); ++q) {
+                    const DftEdge& e = d_.st[state_of_[q]].edge[rep_[k]];
+                    if (e.to == kEdgeDiverge) { nx.alive.push_back(q); nx.div.push_back(q); continue; }
+                    if (e.to < 0) continue;
+                    if (d_.st[e.to].final) { nx.alive.push_back(q); continue; }
+                    const uint32_t t = (uint32_t)row_of_[e.to];
+                    if (!has(raw_[r].alive, t)) continue;
+                    nx.alive.push_back(q);
+                    if (has(raw_[r].div, t)) nx.div.push_back(q);
+                }
+                row[k] = intern_raw(std::move(nx));
+            }
+            raw_next_.push_back(std::move(row));
+        }
+    }
+
+    uint32_t start_value(const Raw& r) const { return !has(r.alive, 0) ? kFail : (has(r.div, 0) ? kDiv : kOk); }
+
+    // Moore reduction of the raw automaton; blocks 0..2 stay the three special symbols
+    void reduce(GuidedTables& g) {
+        const uint32_t n = (uint32_t)raw_.size(), C = (uint32_t)rep_.size();
+        std::vector<uint32_t> block(n);
+        {
+            std::map<std::pair<uint32_t, uint32_t>, uint32_t> first;
+            uint32_t next_id = 3;
+            for (uint32_t r = 0; r < n; ++r) {
+                if (r < 3) { block[r] = r; continue; }
+                auto hit = first.emplace(std::make_pair(raw_[r].k, start_value(raw_[r])), next_id);
+                if (hit.second) ++next_id;
+                block[r] = hit.first->second;
+            }
+        }
+        for (;;) {
+            std::map<std::vector<uint32_t>, uint32_t> ids;
+            std::vector<uint32_t> nb(n);
+            uint32_t next_id = 3;
+            std::vector<uint32_t> sig(C + 1);
+            for (uint32_t r = 0; r < n; ++r) {
+                if (r < 3) { nb[r] = r; continue; }
+                work_ += C;
+                if (work_ > kWork) throw StreamGiveUp();
+                sig[0] = block[r];
+                for (uint32_t k = 0; k < C; ++k) sig[k + 1] = block[raw_next_[r][k]];
+                auto hit = ids.emplace(sig, next_id);
+                if (hit.second) ++next_id;
+                nb[r] = hit.first->second;
+            }
+            uint32_t before = 0, after = 0;
+            for (uint32_t r = 0; r < n; ++r) { before = std::max(before, block[r]); after = std::max(after, nb[r]); }
+            block.swap(nb);
+            if (after == before) break;                       // (a refinement never merges: same count, same partition)
+        }
+        uint32_t n_blocks = 0;
+        for (uint32_t r = 0; r < n; ++r) n_blocks = std::max(n_blocks, block[r] + 1);
+        if (n_blocks > lim_.max_rev_states) throw StreamGiveUp();
+        sym_k_.assign(n_blocks, 0);
+        sym_start_.assign(n_blocks, kFail);
+        std::vector<std::vector<uint16_t>> tab(n_blocks);
+        for (uint32_t r = 0; r < n; ++r) {
+            const uint32_t b = block[r];
+            if (!tab[b].empty()) continue;
+            tab[b].resize(C);
+            for (uint32_t k = 0; k < C; ++k) tab[b][k] = (uint16_t)block[raw_next_[r][k]];
+            sym_k_[b] = raw_[r].k;
+            sym_start_[b] = r < 3 ? (uint32_t)kFail : start_value(raw_[r]);
+        }
+        g.n_rev = n_blocks;
+        if (n_blocks <= 256) {
+            g.rev.resize((size_t)n_blocks * C);
+            for (uint32_t b = 0; b < n_blocks; ++b)
+                for (uint32_t k = 0; k < C; ++k) g.rev[(size_t)b * C + k] = (uint8_t)tab[b][k];
+        } else {
+            g.rev16.resize((size_t)n_blocks * C);
+            for (uint32_t b = 0; b < n_blocks; ++b) std::copy(tab[b].begin(), tab[b].end(), g.rev16.begin() + (size_t)b * C);
+        }
+    }
+
+    // forward states: 0 root, 1 SKIP, 2 DONE (the stream kernels' conventions), then the table rows but START's (3 + row - 1)
+    StreamCell cell(uint32_t s, uint32_t y) const {
+        StreamCell c;
+        if (s == 1) { c.next = y == kSymEol ? 0u : 1u; c.eol = y == kSymEol; return c; }
+        if (s == 2) { c.next = 2; return c; }
+        const bool at_end = y == kSymEol || y == kSymNul;
+        if (s == 0) {
+            if (at_end) {                                     // (no attempt on the empty tail: START is never final, trre_dft.c:938)
+                c.out.push_back('\n');
+                c.next = y == kSymNul ? 1u : 0u;
+                c.eol = y == kSymEol;
+                return c;
+            }
+            if (sym_start_[y] == kDiv) { c.diverge = true; c.next = 2; return c; }     // the reference does not come back from this attempt
+            if (sym_start_[y] == kFail) { c.copy_c = true; c.next = 0; return c; }     // one raw byte (trre_dft.c:1281-1282)
+        }
+        // an attempt under way (or begun here) reads this byte: it is one that succeeds, so the edge exists
+        const uint32_t q = s == 0 ? 0u : s - 2;
+        const DftEdge* e = (at_end || y == kSymDead) ? nullptr : &d_.st[state_of_[q]].edge[rep_[sym_k_[y]]];
+        if (!e || e->to < 0) { c.diverge = true; c.next = 1; return c; }               // cannot happen (a pair the passes never meet)
+        c.out = e->out;
+        if (d_.st[e->to].final) { c.out += d_.st[e->to].final_out; c.next = 0; }       // first final state: the attempt ends (trre_dft.c:1120-1125)
+        else if (row_of_[e->to] <= 0) throw StreamGiveUp();                             // (START is never re-entered: its item list is the initial JOIN alone)
+        else c.next = (uint32_t)row_of_[e->to] + 2;
+        if (c.out.size() > lim_.max_out) throw StreamGiveUp();
+        return c;
+    }
+
+    void forward(GuidedTables& g) {
+        StreamPackInput in;
+        in.wide_cols = g.n_rev > 256;
+        const uint32_t n_fwd = (uint32_t)state_of_.size() + 2;      // (START is the root's attempt: rows 1.. are states 3..)
+        if (n_fwd > lim_.max_fwd_states || (uint64_t)n_fwd * g.n_rev > lim_.max_fwd_cells) throw StreamGiveUp();
+        for (uint32_t s = 0; s < n_fwd; ++s) {
+            std::vector<StreamCell> row;
+            row.reserve(g.n_rev);
+            for (uint32_t y = 0; y < g.n_rev; ++y) row.push_back(cell(s, y));
+            in.rows.push_back(std::move(row));
+        }
+        g.fwd = pack_forward(in, g.n_rev, false);
+    }
+
+    static constexpr size_t kMaxRaw = 65536;                  // raw backward states before the reduction
+    static constexpr uint64_t kWork = 100u * 1000u * 1000u;      // row visits (a second or so: the 1000-key dictionary gives up here)
+    const Dft& d_;
+    GuidedLimits lim_;
+    uint64_t work_ = 0;
+    std::vector<int32_t> row_of_;                             // determinised state -> row, or -1
+    std::vector<uint32_t> state_of_;
+    std::vector<int> rep_;                                    // class -> a representative byte
+    std::vector<Raw> raw_;
+    std::map<std::vector<uint32_t>, uint32_t> raw_index_;
+    std::vector<std::vector<uint32_t>> raw_next_;             // [raw state][class]
+    std::vector<uint32_t> sym_k_, sym_start_;                 // per symbol: the byte class it stands on, START's value there
+};
+
 }  // namespace
 
 GuidedTables build_guided_nft(const NftNodes& nodes, const GuidedLimits& lim) {
@@ -312,4 +580,14 @@ GuidedTables build_guided_nft(const NftNodes& nodes, const GuidedLimits& lim) {
     }
 }
 
+}  // namespace trre
+
+namespace trre {
+GuidedTables build_guided_dft(const Dft& dft, const GuidedLimits& lim) {
+    try {
+        return GuidedDftBuilder(dft, lim).run();
+    } catch (const StreamGiveUp&) {
+        return GuidedTables();        // ok == false
+    }
+}
 }  // namespace trre

@@ -847,6 +847,10 @@ int compile_impl(const std::string& pattern, int engine, trre_prog** out, int mo
             serialize_dft(*p);
             p->has_engine_tables = true;
             p->stt = build_stream_dft(dft);
+            // the guided route (guided_build.cpp: GuidedDftBuilder): what a pattern whose scan loop does not fold runs on ('[a-z]+ing:X':
+            // a loop before the decision), and what takes over when a bounded fold overflows ('a*b:x' behind a run of 65 a's) — the
+            // tile kernels remain for tables beyond its limits.  (A byte map needs neither.)
+            if (!(p->dt.flags & kFlagMemoryless)) p->gt = build_guided_dft(dft);
         } else if (is_generate(mode)) {
             // trre -a / -ma: every accepting path prints (generate.cpp): a viability DFA for the device, the lists for the host
             p->gen = build_gen_tables(nft, mode == TRRE_MODE_MATCH_ALL);
