@@ -15,6 +15,7 @@
 
 #include "../trre_amd/csrc/patch_block.hpp"
 #include "../trre_amd/csrc/scan_block.hpp"
+#include "../trre_amd/csrc/splice_block.hpp"
 
 using namespace trre;
 
@@ -381,7 +382,7 @@ void run_fb_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64_
 
 // The copy form of a large table (k_fb_mark / k_chunk_scan / k_fb_copy): the comb walk marks where the replacement texts go,
 // the copy pass walks no automaton.  ev_cap: ids per lane (small in the tests: the overflow route runs too).
-void run_fb_copy(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64_t& total_out, uint32_t ev_cap) {
+void run_fb_copy(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64_t& total_out, uint32_t ev_cap, bool splice = false) {
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
     const FbView T = fb_view(a);
     const uint16_t* lit_meta = reinterpret_cast<const uint16_t*>(a.blob + h.off_fb_lit_meta);
@@ -413,6 +414,15 @@ void run_fb_copy(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64
     CT.pool = a.blob + h.off_fb_pool;
     alignas(16) uint8_t ring[kRingStride];
     std::memset(a.out, 0xEE, (size_t)run);
+    if (splice) {
+        // the wave-cooperative second pass (k_fb_splice): one emulated wave per sub-range, its LDS carve poisoned every time
+        alignas(16) static uint8_t lds[kSpLdsPerWave];
+        for (int64_t lane = n_lanes - 1; lane >= 0; --lane) {
+            std::memset(lds, 0xEE, sizeof lds);
+            fb_splice_range(a, CT, ca, lane, lane_bytes, base[lane], SpliceLds{lds});
+        }
+        return;
+    }
     for (int64_t lane = n_lanes - 1; lane >= 0; --lane) fb_copy_lane(a, CT, ca, lane, lane_bytes, ring, base[lane], status);
 }
 
@@ -598,6 +608,12 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
         const StreamBlobHeader& sh = *reinterpret_cast<const StreamBlobHeader*>(blob);
         if (!sh.fb_slots || !sh.off_fb_lit_meta) return -5;
         run_fb_copy(a, geo == 0 ? 2048 : 128, status, total, geo == 0 ? 256u : 64u);
+    }
+    else if (family == 27) {
+        // ... its second pass by the wave-cooperative splice (what the runtime launches by default)
+        const StreamBlobHeader& sh = *reinterpret_cast<const StreamBlobHeader*>(blob);
+        if (!sh.fb_slots || !sh.off_fb_lit_meta) return -5;
+        run_fb_copy(a, geo == 0 ? 2048 : 128, status, total, geo == 0 ? 256u : 64u, true);
     }
     else if (family == 24) {
         // stream general family by record + patch (16-byte entries; 16-byte aligned inputs only, like the runtime)

@@ -13,7 +13,7 @@ ST_NUL, ST_DIVERGE, ST_CAPACITY, ST_LONGLINE, ST_NEEDSCRATCH, ST_OVERFLOW, ST_MI
 
 
 def build():
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("scan_block.hpp", "scan_core.hpp", "device_blob.hpp")]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("scan_block.hpp", "scan_core.hpp", "device_blob.hpp", "splice_block.hpp", "patch_block.hpp")]
     if os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(d) for d in deps):
         return SO
     os.makedirs(os.path.dirname(SO), exist_ok=True)
@@ -50,7 +50,7 @@ def mask_bytes_of(blob, engine):
 def shim_scan(blob, engine, family, data, geo=1, in_mis=0, out_mis=0, scratch=True, cap=None):
     """Run one kernel family of the device code on the host.  Returns (output bytes, status)."""
     if cap is None:
-        cap = len(data) * 8 + 64 if family in (3, 5, 7, 9, 22, 23, 24, 25) else len(data)     # (20, 21: length-preserving)
+        cap = len(data) * 8 + 64 if family in (3, 5, 7, 9, 22, 23, 24, 25, 27) else len(data)     # (20, 21: length-preserving)
     out = ctypes.create_string_buffer(max(cap, 1))
     m = ctypes.c_size_t()
     st = ctypes.c_uint32()
@@ -85,6 +85,8 @@ GUIDED_LP, GUIDED_GEN, GUIDED_GEN8, GUIDED_LP_RING, GUIDED_LP8 = 10, 11, 12, 13,
 GUIDED_LP_ALL = (GUIDED_LP, GUIDED_LP_RING, GUIDED_LP8)
 STREAM_LP_EMIT, STREAM_LP_EMIT8 = 20, 21            # stream LP family by the emit pass alone (no window form)
 STREAM_LPW_PAIR = 26                                 # the window kernel on the pair form of its entries (what the runtime launches when the tables have one)
+STREAM_FB_SPLICE = 27                                # ... the second pass as the wave-cooperative splice (what the runtime launches by default)
+STREAM_FB_SPLICE = 27                                # ... the second pass as the wave-cooperative splice (what the runtime launches by default)
 STREAM_FB_COPY = 25                                  # ... by its copy form: mark pass + copy pass (what the runtime launches by default)
 STREAM_FB, STREAM_FB_COUNT = 22, 23                  # stream general family on the fallback form of a large table: both passes /
                                                      # the count pass only, emit on the 8-byte rows (what the runtime launches)
@@ -125,7 +127,7 @@ def scan_like_runtime(prog, data, geo=1, family=None, in_mis=0, out_mis=0):
         fam = {6: GUIDED_LP, 7: GUIDED_GEN}.get(info.kernel, info.kernel)
     if fam in (GUIDED_LP, GUIDED_GEN, GUIDED_GEN8, GUIDED_LP_RING, GUIDED_LP8):
         return scan_guided_like_runtime(prog, data, geo, fam, in_mis, out_mis)
-    blob = prog.export_stream_tables() if fam in (4, 5, 6, 7, 8, 9, 20, 21, 22, 23, STREAM_LPW_PAIR) else prog.export_tables()
+    blob = prog.export_stream_tables() if fam in (4, 5, 6, 7, 8, 9, 20, 21, 22, 23, 25, 27, STREAM_LPW_PAIR) else prog.export_tables()
     out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
     if out is None:                         # family 8 / 26 without a window (pair) form: nothing to run
         fam = 6

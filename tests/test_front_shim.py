@@ -332,9 +332,12 @@ def test_compile_time_of_nested_optional_groups():
     assert r.returncode == 0
 
 
+COPY_FORMS = (shim_lib.STREAM_FB_SPLICE, shim_lib.STREAM_FB_COPY)
+
+
 def test_copy_form_of_large_tables():
-    """The copy form (scan_block.hpp: fb_lane<3> marks where the replacement texts go, fb_copy_lane copies the input around
-    them): the golden dictionary slice, then seeded dictionaries — prefix-free or keys inside keys (escape records), texts
+    """The copy form (scan_block.hpp: fb_lane<3> marks where the replacement texts go; the second pass copies the input around
+    them — the wave-cooperative splice of splice_block.hpp, what the runtime launches, and the older lane-sequential fb_copy_lane): the golden dictionary slice, then seeded dictionaries — prefix-free or keys inside keys (escape records), texts
     of 1..8 bytes, partial keys, key upon key, lines of kilobytes, inputs with and without a final newline — at every
     buffer alignment, both geometries, against the oracle.  A launch may declare itself void (more texts in 64 bytes or in
     a sub-range than the event lists hold: the runtime then runs the count / emit pair); most must not."""
@@ -346,10 +349,11 @@ def test_copy_form_of_large_tables():
         if not shim_lib.has_copy_form(p):
             continue
         for geo in (0, 1):
-            out, st = shim_lib.shim_scan(p.export_stream_tables(), p.info.engine, shim_lib.STREAM_FB_COPY, data, geo)
-            assert not st & (shim_lib.ST_EDIT_OVERFLOW | shim_lib.ST_NUL), (name, eng, geo)
-            assert out == exp, (name, eng, geo)
-            n += 1
+            for fam in COPY_FORMS:
+                out, st = shim_lib.shim_scan(p.export_stream_tables(), p.info.engine, fam, data, geo)
+                assert not st & (shim_lib.ST_EDIT_OVERFLOW | shim_lib.ST_NUL), (name, eng, geo, fam)
+                assert out == exp, (name, eng, geo, fam)
+                n += 1
     assert n >= 4
     rng = random.Random(77)
     forms = 0
@@ -390,13 +394,14 @@ def test_copy_form_of_large_tables():
             forms += 1
             want = Oracle(pat, eng).scan(data)
             for geo in (0, 1):
-                out, st = shim_lib.shim_scan(p.export_stream_tables(), p.info.engine, shim_lib.STREAM_FB_COPY, data, geo,
-                                             in_mis=rng.choice([0, 0, 1, 5, 15]), out_mis=rng.choice([0, 3, 9]))
-                n += 1
-                if st & shim_lib.ST_EDIT_OVERFLOW:
-                    void += 1
-                    continue
-                assert out == want, (it, eng, geo)
+                in_mis, out_mis = rng.choice([0, 0, 1, 5, 15]), rng.choice([0, 3, 9])
+                for fam in COPY_FORMS:
+                    out, st = shim_lib.shim_scan(p.export_stream_tables(), p.info.engine, fam, data, geo, in_mis=in_mis, out_mis=out_mis)
+                    n += 1
+                    if st & shim_lib.ST_EDIT_OVERFLOW:
+                        void += 1
+                        continue
+                    assert out == want, (it, eng, geo, fam, in_mis, out_mis)
     assert forms >= 10 and void * 2 < n, (forms, void, n)
     # a NUL voids the launch; empty replacement texts: no copy form, or one that deletes the key
     p = trre_amd.Program(pat, "dft")
@@ -406,8 +411,9 @@ def test_copy_form_of_large_tables():
         p = trre_amd.Program(pat2, "dft")
         if shim_lib.has_copy_form(p):
             text = b"a zzzzzz b zzzzz zzzzzzz " + " ".join(keys[:40]).encode() + b"\nzzzzzz\n"
-            out, st = shim_lib.shim_scan(p.export_stream_tables(), p.info.engine, shim_lib.STREAM_FB_COPY, text, 0)
-            assert not st and out == Oracle(pat2, "dft").scan(text)
+            for fam in COPY_FORMS:
+                out, st = shim_lib.shim_scan(p.export_stream_tables(), p.info.engine, fam, text, 0)
+                assert not st and out == Oracle(pat2, "dft").scan(text), fam
 
 
 def test_random_replacement_lists():

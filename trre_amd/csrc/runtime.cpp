@@ -23,6 +23,7 @@
 #include "launch.hpp"
 #include "patch_block.hpp"
 #include "scan_block.hpp"
+#include "splice_block.hpp"
 
 namespace {
 
@@ -595,7 +596,13 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
             ca.ev_cap = kCopyEvCap;
             launch_fb_mark(args, ca, p->sblob.data(), lane_bytes, n_chunks, stream);
             launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);
-            launch_fb_copy(args, ca, p->sblob.data(), lane_bytes, n_chunks, stream);
+            // second pass: the wave-cooperative splice (splice_block.hpp; round 4), or — TRRE_NO_FB_SPLICE=1 for A/B runs, and for tables
+            // with an escape text longer than its tiles take — the lane-sequential copy pass
+            static const bool no_splice_env = getenv("TRRE_NO_FB_SPLICE") != nullptr;
+            uint32_t esc_max = 0;
+            for (size_t k = 0; k + 3 < p->stt.fb_esc.size(); k += 4) esc_max = std::max(esc_max, p->stt.fb_esc[k + 1]);
+            if (!no_splice_env && esc_max <= kSpMaxText && fb_splice_fits(p->sblob.data())) launch_fb_splice(args, ca, p->sblob.data(), lane_bytes, n_chunks, stream);
+            else launch_fb_copy(args, ca, p->sblob.data(), lane_bytes, n_chunks, stream);
             pd.total_at = cx->d_chunk_base + n_chunks;
             pd.patched = true;
         } else {

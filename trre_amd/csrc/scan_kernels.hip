@@ -22,6 +22,7 @@
 #include "launch.hpp"
 #include "patch_block.hpp"
 #include "scan_block.hpp"
+#include "splice_block.hpp"
 
 namespace trre {
 namespace {
@@ -786,6 +787,59 @@ __global__ __launch_bounds__(kThreads) void k_fb_copy(ScanArgs a, FbCopyArgs ca,
     uint32_t st = 0;
     if (live) fb_copy_lane(a, T, ca, lane, lane_bytes, ring, base, st, wsc);
 }
+// The same pass as a wave-cooperative splice (splice_block.hpp): a workgroup takes kThreads / 256 chunks of the workspace (256
+// sub-ranges of the mark pass each), the four waves of a chunk take its sub-ranges in turn, a whole wave on each.  The pass
+// is a chain of dependent steps per window (edits -> offsets -> markers -> phase A -> phase B -> store), so it wants waves to
+// switch between: 1024 threads share one copy of the literals, two such workgroups fill a CU's 32 wave slots.
+//   smem: literals[fb_lits x 16] | output bases of the sub-ranges (u64) | 64 per chunk | the per-wave carves
+template <int kThreads>
+__global__ __launch_bounds__(kThreads) void k_fb_splice(ScanArgs a, FbCopyArgs ca, int64_t lane_bytes, int64_t n_chunks) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
+    U128* lit = reinterpret_cast<U128*>(smem);
+    {
+        const uint64_t* tx = reinterpret_cast<const uint64_t*>(a.blob + h.off_fb_lit);
+        const uint16_t* m = reinterpret_cast<const uint16_t*>(a.blob + h.off_fb_lit_meta);
+        for (int k = threadIdx.x; k < (int)h.fb_lits; k += kThreads) lit[k] = U128{(uint32_t)tx[k], (uint32_t)(tx[k] >> 32), (uint32_t)m[k], 0u};
+    }
+    constexpr int kGroups = kThreads / kDirectThreads;
+    uint64_t* sbase = reinterpret_cast<uint64_t*>(smem + h.fb_lits * 16u);
+    uint32_t* wparts = reinterpret_cast<uint32_t*>(sbase + kThreads);
+    uint8_t* carve = reinterpret_cast<uint8_t*>(wparts + 16 * kGroups);
+    const int group = threadIdx.x / kDirectThreads, gtid = threadIdx.x % kDirectThreads;
+    const int64_t chunk = (int64_t)blockIdx.x * kGroups + group;
+    const bool live = chunk < n_chunks;
+    const int64_t lane0 = chunk * kDirectThreads;
+    uint32_t* wpart = wparts + 16 * group;
+    const uint32_t mine = live ? a.lane_counts[lane0 + gtid] : 0u;
+    const uint32_t incl = wave_scan_incl(mine);
+    if ((threadIdx.x & (kWave - 1)) == kWave - 1) wpart[gtid / kWave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < gtid / kWave; ++w) wbase += wpart[w];
+    sbase[threadIdx.x] = live ? a.chunk_base[chunk] + wbase + incl - mine : 0ull;
+    // (bases grow with the chunk index: if the last chunk of this workgroup does not fit, the output is void anyway)
+    const int64_t last = ((int64_t)blockIdx.x + 1) * kGroups - 1 < n_chunks - 1 ? ((int64_t)blockIdx.x + 1) * kGroups - 1 : n_chunks - 1;
+    if (a.chunk_base[last] + a.chunk_total[last] > a.cap) {               // (uniform for the workgroup)
+        if (threadIdx.x == 0) atomicOr(a.status, kStCapacity);
+        return;
+    }
+    // a void launch (the mark pass met a NUL, or more events than a row holds): nothing is written, finish() runs the count / emit pair
+    if (*a.status & (kStEditOverflow | kStNul)) return;
+    __syncthreads();
+    if (!live) return;
+    FbCopyTables T;
+    T.lit = lit;
+    T.esc = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_esc);
+    T.pool = a.blob + h.off_fb_pool;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x / kWave);             // in the workgroup
+    const int gwave = wave % (kDirectThreads / kWave);                                     // in its chunk
+    const SpliceLds L{carve + wave * kSpLdsPerWave};
+    for (int i = 0; i < kWave; ++i) {
+        const int sub = i * (kDirectThreads / kWave) + gwave;             // (neighbouring sub-ranges at the same time: neighbouring lines of the output)
+        fb_splice_range(a, T, ca, lane0 + sub, lane_bytes, sbase[group * kDirectThreads + sub], L);
+    }
+}
 // ------------------------------------------------------------------------------------------
 // memoryless byte map: out[v] = map[in[v]], 16 bytes per lane per step
 constexpr int kMapThreads = 256;
@@ -1232,6 +1286,25 @@ void launch_fb_copy(const ScanArgs& a, const FbCopyArgs& ca, const void* hdr, in
         hipLaunchKernelGGL(k_fb_copy<256>, dim3((unsigned)n_chunks), dim3(256), fb_copy_lds(h, 256), s, a, ca, lane_bytes, n_chunks);
     }
 }
+int fb_splice_lds(const StreamBlobHeader& h, int threads) {
+    return (int)h.fb_lits * 16 + threads * 8 + 64 * (threads / kDirectThreads) + (threads / kWave) * (int)kSpLdsPerWave;
+}
+void launch_fb_splice(const ScanArgs& a, const FbCopyArgs& ca, const void* hdr, int64_t lane_bytes, int64_t n_chunks, void* stream) {
+    const StreamBlobHeader& h = *static_cast<const StreamBlobHeader*>(hdr);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    static const int want = getenv("TRRE_SPLICE_THREADS") ? atoi(getenv("TRRE_SPLICE_THREADS")) : 1024;      // (A/B runs)
+    if (want >= 1024 && 2 * fb_splice_lds(h, 1024) <= kLdsLimit) {
+        allow_big_lds<&k_fb_splice<1024>>();
+        hipLaunchKernelGGL(k_fb_splice<1024>, dim3((unsigned)((n_chunks + 3) / 4)), dim3(1024), fb_splice_lds(h, 1024), s, a, ca, lane_bytes, n_chunks);
+    } else if (want >= 512) {
+        allow_big_lds<&k_fb_splice<512>>();
+        hipLaunchKernelGGL(k_fb_splice<512>, dim3((unsigned)((n_chunks + 1) / 2)), dim3(512), fb_splice_lds(h, 512), s, a, ca, lane_bytes, n_chunks);
+    } else {
+        allow_big_lds<&k_fb_splice<256>>();
+        hipLaunchKernelGGL(k_fb_splice<256>, dim3((unsigned)n_chunks), dim3(256), fb_splice_lds(h, 256), s, a, ca, lane_bytes, n_chunks);
+    }
+}
+bool fb_splice_fits(const void* hdr) { return fb_splice_lds(*static_cast<const StreamBlobHeader*>(hdr), 512) <= kLdsLimit; }
 // the copy form's LDS fits
 bool fb_copy_fits(const void* hdr) {
     const StreamBlobHeader& h = *static_cast<const StreamBlobHeader*>(hdr);
