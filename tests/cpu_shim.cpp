@@ -8,6 +8,7 @@
 //
 // Besides the production geometry it instantiates a tiny one (4 lanes, 64-byte
 // chunks, 32-byte halo) so that small inputs cross chunk and tile boundaries.
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -416,10 +417,16 @@ void run_fb_copy(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64
     std::memset(a.out, 0xEE, (size_t)run);
     if (splice) {
         // the wave-cooperative second pass (k_fb_splice): one emulated wave per sub-range, its LDS carve poisoned every time
+        // (as the kernel deals them out: a wave takes every fourth sub-range of a chunk of 256)
         alignas(16) static uint8_t lds[kSpLdsPerWave];
-        for (int64_t lane = n_lanes - 1; lane >= 0; --lane) {
-            std::memset(lds, 0xEE, sizeof lds);
-            fb_splice_range(a, CT, ca, lane, lane_bytes, base[lane], SpliceLds{lds});
+        for (int64_t first = 0; first < n_lanes; first += 256) {
+            for (int w = 3; w >= 0; --w) {
+                std::memset(lds, 0xEE, sizeof lds);
+                const int64_t left = n_lanes - (first + w);
+                if (left <= 0) continue;
+                const SpliceWork W{first + w, 4, (int)std::min<int64_t>(64, (left + 3) / 4), base.data() + first + w, 4};
+                fb_splice_ranges(a, CT, ca, W, lane_bytes, SpliceLds{lds});
+            }
         }
         return;
     }

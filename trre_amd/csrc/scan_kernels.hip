@@ -835,10 +835,9 @@ __global__ __launch_bounds__(kThreads) void k_fb_splice(ScanArgs a, FbCopyArgs c
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x / kWave);             // in the workgroup
     const int gwave = wave % (kDirectThreads / kWave);                                     // in its chunk
     const SpliceLds L{carve + wave * kSpLdsPerWave};
-    for (int i = 0; i < kWave; ++i) {
-        const int sub = i * (kDirectThreads / kWave) + gwave;             // (neighbouring sub-ranges at the same time: neighbouring lines of the output)
-        fb_splice_range(a, T, ca, lane0 + sub, lane_bytes, sbase[group * kDirectThreads + sub], L);
-    }
+    // (the chunk's waves take neighbouring sub-ranges at the same time: neighbouring lines of the output)
+    const SpliceWork W{lane0 + gwave, kDirectThreads / kWave, kWave, sbase + group * kDirectThreads + gwave, kDirectThreads / kWave};
+    fb_splice_ranges(a, T, ca, W, lane_bytes, L);
 }
 // ------------------------------------------------------------------------------------------
 // memoryless byte map: out[v] = map[in[v]], 16 bytes per lane per step
