@@ -49,7 +49,7 @@ HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~630
 
 KERNEL_OF = {"generate": "k_rev_sweep (viability symbols) + host enumeration", "bytemap": "k_bytemap", "tile_lp": "k_scan_lp", "tile_gen": "k_scan_count + k_scan_emit",
              "stream_lp": "k_stream_lpw (window form) / k_stream_g16<emit> alone",
-             "stream_gen": "k_stream_g16<count> + <emit> (small tables) / k_fb_mark + k_fb_copy (large tables: the copy form)",
+             "stream_gen": "k_stream_g16<count> + <emit> (small tables) / k_fb_mark + k_fb_splice (large tables: the copy form)",
              "guided_lp": "k_rev_sweep + k_stream_g16<emit, sym>", "guided_gen": "k_rev_sweep + k_stream_g16<count, sym> + <emit, sym>"}
 
 
@@ -87,6 +87,34 @@ def pmc_traffic(kernel_name, nbytes):
     return total, "rocprofv3 --pmc passes of this command, committed: " + ", ".join(src)
 
 
+# HBM traffic per GiB of input of the other configurations, from the committed PMC passes of tools/profile_round.sh /
+# tools/pmc_dict4.sh (1 GiB runs; FETCH_SIZE doubled as for the headline): summed over the kernels of one scan.  Measured
+# under rocprofv3 in separate passes, NOT in this run — labelled as such in the record.
+CONFIG_PMC = {"cfg4": "cfg4_nft", "cfg4_guided": "cfg4_nft_guided", "cfg5_dft": "dict1000_dft", "cfg5_nft": "dict1000_dft", "expand": "expand_dft",
+              "nft_loop": "nft_loop_guided", "dft_loop": "dft_loop_guided", "tile_fallback": "tile_dft"}
+
+
+def config_traffic(name):
+    import glob
+    import re
+    tag = CONFIG_PMC.get(name)
+    if not tag:
+        return None
+    total = 0.0
+    src = []
+    for c, mul in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_%s.txt" % (tag, c))))
+        if not files:
+            return None
+        vals = re.findall(r"^\s+%s\s+([0-9.]+)" % c, open(files[-1]).read(), re.M)
+        if not vals:
+            return None
+        total += mul * sum(float(v) for v in vals) * 1024
+        src.append(os.path.relpath(files[-1], ROOT))
+    return {"hbm_bytes_per_GiB_of_input": int(total),
+            "source": "rocprofv3 --pmc passes at 1 GiB (256 MiB for the tile kernels), committed (not this run): " + ", ".join(src)}
+
+
 def cpu_baseline(pattern, engine, sample, cores_mt=0):
     """Time the reference's CPU path on the host cores over a bounded sample.  Prefers the compiled reference
     binary (kind "reference"); falls back to the oracle's C restatement (kind "port")."""
@@ -116,6 +144,10 @@ def cpu_baseline(pattern, engine, sample, cores_mt=0):
         dt = time.perf_counter() - t0
         res["port_all_cores"] = {"value": round(nbytes / dt / 1e9, 4), "unit": "GB/s", "cores": cores_mt, "kind": "port",
                                  "sample": "same sample, line-sharded threads, %.1f s" % dt}
+        # (the same figure as flat keys of cpu_baseline: a parser that keeps scalars only keeps it)
+        res["value_all_cores"] = res["port_all_cores"]["value"]
+        res["cores_all"] = cores_mt
+        res["kind_all_cores"] = "port"
     return res
 
 
@@ -210,6 +242,13 @@ def run_config(trre_amd, spec, inp, out, tmp, want_cpu):
                 "frac": round(n / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                 "read_plus_write_GBps": round((n + m) / (kernel_ms * 1e-3) / 1e9, 1)})
     prog.set_profiling(False)
+    if prog.info.kernel != info.kernel:          # (a bounded fold that overflowed: the scans after it run on the guided kernels)
+        rec["kernel_family_after_first_scan"] = trre_amd.KERNEL_NAMES[prog.info.kernel]
+    tr = config_traffic(spec["name"])
+    if tr:
+        # algorithmic bytes per GiB of input: the GiB itself and the output it becomes
+        tr["x_algorithmic"] = round(tr["hbm_bytes_per_GiB_of_input"] / ((1 << 30) * (1.0 + m / float(n))), 2)
+        rec["traffic"] = tr
     if spec.get("torch_check") is not None:
         ok = bool(m == n and spec["torch_check"](inp, out[:n]))
         rec["verified"], rec["verify"] = ok, "whole output against an independent torch byte map on the device"
@@ -559,6 +598,10 @@ def main():
              "cpu_sample": 64 << 20},
             {"name": "nft_loop", "workload": "NFT pattern that does not fold (a loop before the decision): '(a|b)*c:x'",
              "pattern": "(a|b)*c:x", "engine": "nft", "steps": 20, "cpu_sample": 16 << 20},
+            {"name": "dft_loop", "workload": "DFT pattern that does not fold (a loop before the decision; round 3: the tile kernels at 48 GB/s): '(a|b)*c:x'",
+             "pattern": "(a|b)*c:x", "engine": "dft", "steps": 20, "cpu_sample": 16 << 20},
+            {"name": "dft_suffix", "workload": "DFT, a range under a loop before a literal: '[a-z]+ing:X'", "pattern": "[a-z]+ing:X", "engine": "dft", "steps": 20,
+             "cpu_sample": 16 << 20},
             {"name": "nft_range_loop", "workload": "NFT, a byte range under a loop: '[0-9]+:N'", "pattern": "[0-9]+:N", "engine": "nft", "steps": 20,
              "cpu_sample": 16 << 20},
             {"name": "nft_dot", "workload": "NFT, '.' rows of the reference's test.sh:114: '(.:x)*.*'", "pattern": "(.:x)*.*", "engine": "nft",
@@ -579,6 +622,19 @@ def main():
                                                          "general family (ms_per_step = both launches, host-timed; kernel_ms = the second alone)"
                                                          % (len(nul_at), n / 2**30)}, inp, out, tmp, False))
         inp[nul_at] = saved
+        # a bounded fold that meets a run it was not built for (' +: ' folds runs of up to 64 spaces; one run of 300 per GiB): the count
+        # pass finds out, the emit pass leaves at once, the guided kernels take the buffer — and the scans after it go there directly
+        run_at = [int((k + 0.5) * (1 << 30)) for k in range(n >> 30)] or [n // 2]
+        idx = torch.cat([torch.arange(p0, p0 + 300, device=dev) for p0 in run_at])
+        saved = inp[idx].clone()
+        inp[idx] = 32
+        configs.append(run_config(trre_amd, {"name": "greedy_overflow", "pattern": " +: ", "engine": "nft", "steps": 5, "cpu_sample": 0, "finish_each": True,
+                                             "workload": "' +: ' NFT with %d run(s) of 300 spaces in the %.0f GiB: the bounded stream table overflows on the first scan "
+                                                         "(count pass void, emit pass skipped, guided kernels take over), later scans go to the guided "
+                                                         "kernels directly (ms_per_step host-timed over all steps but the warm-up, which is the one that overflows)"
+                                                         % (len(run_at), n / 2**30)}, inp, out, tmp, False))
+        inp[idx] = saved
+        del idx, saved
         nt = min(n, 1 << 30)
         configs.append(run_config(trre_amd, {"name": "tile_fallback", "pattern": "a:xyz", "engine": "dft", "steps": 3, "force": "tile_gen",
                                              "workload": "the LDS-tile kernels (fallback of last resort for DFT patterns that do not fold): 'a:xyz' forced "

@@ -152,7 +152,11 @@ def test_static_properties_of_config_tables():
     assert i.kernel == trre_amd.KERNEL_STREAM_GEN and not i.flags & 1
     # attempts with unbounded look-ahead fold up to 64 pending bytes (longer runs void the launch and the
     # tile kernels take over); where the pending strings branch the fold gives up: tile kernels only
+    # (round 4: a bounded table whose flushes do not fit the 16-byte entries — here up to 64 a's go out raw when no b comes —
+    # leaves the choice to the guided tables; ' +: ' flushes at most two bytes and keeps its stream table)
     i = prog("a*b:x", "nft").info
+    assert i.stream_states == 67 and i.kernel == trre_amd.KERNEL_GUIDED_GEN and trre_amd.KERNEL_STREAM_GEN in prog("a*b:x", "nft").allowed_kernels()
+    i = prog(" +: ", "nft").info
     assert i.stream_states == 67 and i.kernel == trre_amd.KERNEL_STREAM_GEN
     i = prog("(a|b)*c:x", "nft").info
     assert i.stream_states == 0 and i.kernel == trre_amd.KERNEL_GUIDED_GEN

@@ -20,6 +20,7 @@ ap.add_argument("--corpus", default="printable", help="printable | catdog | dict
 ap.add_argument("--bytes", type=int, default=1 << 30)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--dict", type=int, default=0, help="use the seeded N-entry key:value dictionary pattern and corpus (config 5)")
+ap.add_argument("--out-mis", type=int, default=0, help="misalign the output buffer by this many bytes")
 ap.add_argument("--case", action="append", default=[], help="pattern;;engine;;corpus;;kernel (repeatable)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -30,7 +31,7 @@ if not cases:
     else:
         cases = [[a.pattern, a.engine, a.corpus, a.kernel]]
 bufs = {}
-out = torch.empty(a.bytes * 2 + 64, dtype=torch.uint8, device=dev)
+out = torch.empty(a.bytes * 2 + 64, dtype=torch.uint8, device=dev)[a.out_mis:]
 for pat, eng, corp, kern in cases:
     if pat.startswith("@dict"):
         import dictgen

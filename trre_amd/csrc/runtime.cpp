@@ -134,6 +134,7 @@ struct trre_prog {
     int mask_bytes = 0;
     bool profiling = false;
     std::atomic<float> last_ms{-1.f};
+    std::atomic<bool> bounded_off{false};     // a launch on a bounded stream table met a run it was not built for: the guided / tile kernels from now on
     std::atomic<bool> copy_form_off{false};   // a launch of the copy form met more texts than its event lists hold: the count / emit pair from now on
     std::mutex dev_mu;                                  // guards the map (not the states)
     std::map<int, std::unique_ptr<DeviceState>> dev;
@@ -319,7 +320,10 @@ int auto_family(const trre_prog& p) {
     // states x 256 classes)
     const bool stream_small = p.stt.ok && (p.stt.g16_ok || p.stt.lpw_ok);
     const bool guided_small = p.gt.ok && p.gt.fwd.g16_ok && !p.gt.wide;
-    if (p.stt.ok && (stream_small || !guided_small)) return lp_inplace(p.stt.flags) ? TRRE_KERNEL_STREAM_LP : TRRE_KERNEL_STREAM_GEN;
+    // (a bounded fold whose flushes do not fit the 16-byte entries — 'a*b:x': up to 64 pending bytes go out raw when the b does not
+    // come — walks them on its slow path: 0.30 TB/s against 0.60 for the guided tables of the same pattern; ' +: ' has none: 0.72 / 0.59)
+    const bool bounded_slow = p.stt.ok && p.stt.bounded && (p.stt.flags & kFlagG16Slow) && guided_small;
+    if (p.stt.ok && !bounded_slow && (stream_small || !guided_small)) return lp_inplace(p.stt.flags) ? TRRE_KERNEL_STREAM_LP : TRRE_KERNEL_STREAM_GEN;
     // (wide guided tables — 16-bit symbols, both tables through L1 / L2 — still beat the bitmask tile kernels: 37 against 17 GB/s
     // on 'a(a|b|c){9}c:x', 256 MiB of printable lines)
     if (p.gt.ok) return lp_inplace(p.gt.fwd.flags) && !p.gt.wide ? TRRE_KERNEL_GUIDED_LP : TRRE_KERNEL_GUIDED_GEN;
@@ -328,6 +332,15 @@ int auto_family(const trre_prog& p) {
         return TRRE_KERNEL_TILE_GEN;
     }
     return (p.nt.flags & kFlagLengthPreserving) ? TRRE_KERNEL_TILE_LP : TRRE_KERNEL_TILE_GEN;
+}
+
+// the family a scan call launches: the forced one, else the automatic choice — which leaves a bounded stream table alone once
+// a launch on it has overflowed
+int scan_family(const trre_prog& p) {
+    if (p.forced_family) return p.forced_family;
+    const int fam = auto_family(p);
+    if (is_stream(fam) && p.stt.bounded && p.bounded_off.load()) return general_family(p, false);
+    return fam;
 }
 
 bool family_allowed(const trre_prog& p, int fam) {
@@ -492,7 +505,8 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
     static const int stream_impl = getenv("TRRE_STREAM_IMPL") ? atoi(getenv("TRRE_STREAM_IMPL")) : 2;
     static const int64_t lane_bytes_env = getenv("TRRE_LANE_BYTES") ? atoll(getenv("TRRE_LANE_BYTES")) : 0;
     const bool window = is_stream(family) && stream_impl == 2 && family == TRRE_KERNEL_STREAM_LP && p->stt.lpw_ok &&
-                        (reinterpret_cast<uintptr_t>(args.out_v0) & 15u) == 0;   // its 16-byte stores need in and out congruent mod 16
+                        (reinterpret_cast<uintptr_t>(args.out_v0) & 15u) == 0;   // its 16-byte stores: in and out congruent mod 16 (unaligned they work, at the pace
+                                                                                 // of the emit pass alone: 0.94 against 0.98 ms per GiB, round 4)
     // sub-range per lane: 2 KiB, growing with the input so that about half a million lanes (8192 waves)
     // walk it — per-lane costs (the skipped head, the tail beyond the sub-range, the wave waiting for its
     // slowest lane) shrink with longer lanes: cfg 4 at 8 GiB 1.72 TB/s with 2 KiB lanes, 2.06 with 16 KiB
@@ -812,14 +826,21 @@ int finish(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
         cx->patch_off = false;
         return rc;
     }
-    // an undecided attempt outgrew the stream table (bounded fold): the guided (or the tile) kernels take the buffer
-    if (is_stream(was.family) && (status & kStOverflow)) return again(general_family(*p, false));
+    // an undecided attempt outgrew the stream table (bounded fold): the guided (or the tile) kernels take the buffer — this one
+    // and, the corpus being what it is, the ones after it (the count pass found out; the emit pass saw the mark and left at once)
+    if (is_stream(was.family) && (status & kStOverflow)) {
+        p->bounded_off.store(true);
+        return again(general_family(*p, false));
+    }
     if (!is_gen(was.family)) {
         // a NUL cuts its line short, so output positions no longer equal input positions: redo with a general family
         if ((status & kStNul) && was.family == TRRE_KERNEL_BYTEMAP) {
             const int rc = repair_bytemap_nuls(st, cx, was, out_len);
             if (rc >= 0) return rc;
         }
+        // (the same repair for the other length-preserving families — the NULs looked up by a pass over the input, the stretches
+        // scanned again by the window kernel with unaligned stores — was built and measured in round 4: 13.5 ms for 8 GiB with a
+        // NUL per GiB against 12.9 ms for the general family over the whole buffer; not kept.  DESIGN.md §5)
         if (status & kStNul) return again(general_family(*p, !is_guided(was.family)));
         if (out_len) *out_len = was.n;
         return TRRE_OK;
@@ -830,6 +851,7 @@ int finish(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
     if ((status & kStCapacity) || total > was.cap) return fail(TRRE_E_CAPACITY, "error: output buffer too small");
     return TRRE_OK;
 }
+
 
 int compile_impl(const std::string& pattern, int engine, trre_prog** out, int mode = TRRE_MODE_SCAN) {
     using namespace trre;
@@ -974,7 +996,7 @@ int trre_get_info(const trre_prog* p, trre_info* info) {
     if (!p || !info) return fail(TRRE_E_ARG, "error: null argument");
     std::memset(info, 0, sizeof *info);
     info->engine = p->engine;
-    info->kernel = is_generate(p->mode) ? TRRE_KERNEL_GENERATE : (p->forced_family ? p->forced_family : auto_family(*p));
+    info->kernel = is_generate(p->mode) ? TRRE_KERNEL_GENERATE : scan_family(*p);
     info->nft_states = p->nft_states;
     info->nft_cons_states = p->nft_cons;
     if (p->engine == TRRE_ENGINE_DFT) {
@@ -1036,7 +1058,7 @@ int trre_scan_enqueue(trre_prog* p, const uint8_t* d_in, size_t n, uint8_t* d_ou
     int rc = current_state(p, &st);
     if (rc) return rc;
     if (is_generate(p->mode)) return fail(TRRE_E_ARG, "error: generator mode has no split form: use trre_scan_device / trre_scan_host");
-    const int fam = p->forced_family ? p->forced_family : auto_family(*p);
+    const int fam = scan_family(*p);
     return enqueue(p, st, &st->ctx, fam, d_in, n, d_out, cap, static_cast<hipStream_t>(stream));
 }
 
@@ -1145,7 +1167,7 @@ int trre_scan_device(trre_prog* p, const uint8_t* d_in, size_t n, uint8_t* d_out
         HIP_TRY(hipStreamSynchronize(s));
         return diverged ? fail(TRRE_E_DIVERGES, kDivergeMsg) : TRRE_OK;
     }
-    const int fam = p->forced_family ? p->forced_family : auto_family(*p);
+    const int fam = scan_family(*p);
     rc = enqueue(p, st, &st->ctx, fam, d_in, n, d_out, cap, static_cast<hipStream_t>(stream));
     if (rc) { st->ctx.pend = Pending(); return rc; }
     return finish(p, st, &st->ctx, out_len);
@@ -1241,7 +1263,7 @@ int scan_host_on(trre_prog* p, DeviceState* st, const uint8_t* in, size_t n, uin
         int rc = ctx_init(hs.ctx);
         if (rc) return rc;
     }
-    const int fam = p->forced_family ? p->forced_family : auto_family(*p);
+    const int fam = scan_family(*p);
     const bool fixed_len = !is_gen(fam);              // output size == input size (unless a NUL forces a general family)
 
     struct Chunk { size_t off = 0, len = 0, out_at = 0, m = 0; bool submitted = false, copying = false, leaving = false, early = false; CopyPool::Job job; };
@@ -1436,7 +1458,7 @@ int trre_scan_host_multi(trre_prog* p, const uint8_t* in, size_t n, uint8_t* out
     std::vector<size_t> bounds(G + 1);
     int rc = trre_shard_bounds(in, n, G, bounds.data());
     if (rc) return rc;
-    const int fam = p->forced_family ? p->forced_family : auto_family(*p);
+    const int fam = scan_family(*p);
     const bool fixed_len = !is_gen(fam) && !is_generate(p->mode);
     // A length-preserving program writes every shard straight to its place (output offset == input offset);
     // otherwise a shard's offset is known only when the shards before it are done: each goes to a buffer of its

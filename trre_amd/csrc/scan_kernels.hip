@@ -396,6 +396,8 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_direct(ScanArgs a, in
     DirectLane L;
     uint32_t st = 0;
     uint64_t base = 0;
+    // (a bounded fold that overflowed in the count pass: the launch is void, finish() runs the buffer on another family)
+    if (kMode == 2 && !a.lp_emit && (*a.status & kStOverflow)) return;
     if (kMode == 2 && !a.lp_emit) {
         // lane offsets: workgroup-wide exclusive scan of the counts from the count launch
         uint32_t* wpart = reinterpret_cast<uint32_t*>(smem + kLds - kDirectWsc - 64);
@@ -476,6 +478,8 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_g16(ScanArgs a, int64
     DirectLane L;
     uint32_t st = 0;
     uint64_t base = 0;
+    // (a bounded fold that overflowed in the count pass: the launch is void, finish() runs the buffer on another family)
+    if (kMode == 2 && !a.lp_emit && (*a.status & kStOverflow)) return;
     if (kMode == 2 && !a.lp_emit) {
         uint32_t* wpart = reinterpret_cast<uint32_t*>(tail);
         const uint32_t mine = a.lane_counts[lane];
