@@ -253,6 +253,50 @@ void run_direct_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uin
     }
 }
 
+// The splice form of a small table (k_stream_g16<4> / k_chunk_scan / k_g16_splice): the count walk lists the edits, the
+// wave-cooperative second pass copies the input around them.  ev_cap: events per lane.
+template <int kSym = 0>
+void run_g16_splice(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64_t& total_out, uint32_t ev_cap) {
+    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
+    StreamView T = direct_view(a);
+    T.p32 = nullptr;
+    const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
+    std::vector<uint32_t> hdr((size_t)n_lanes * 4, 0xEEEEEEEEu);
+    std::vector<uint32_t> events((size_t)n_lanes * ev_cap + 4, 0xEEEEEEEEu);
+    FbCopyArgs ca{};
+    ca.events = events.data();
+    ca.lane_hdr = hdr.data();
+    ca.ev_cap = ev_cap;
+    std::vector<uint64_t> cnt(n_lanes), base(n_lanes);
+    uint32_t stage[kMarkStageStride];
+    for (int64_t lane = n_lanes - 1; lane >= 0; --lane) {      // any order
+        DirectLane L;
+        if (h.flags & kFlagG16SlowBit) g16_lane<4, kSym, true>(a, T, h.n_cls, lane, lane_bytes, reinterpret_cast<uint8_t*>(stage), 0, L, status, nullptr, nullptr, &ca);
+        else g16_lane<4, kSym, false>(a, T, h.n_cls, lane, lane_bytes, reinterpret_cast<uint8_t*>(stage), 0, L, status, nullptr, nullptr, &ca);
+        cnt[lane] = L.count;
+    }
+    if (status & (kStEditOverflow | kStNul | kStOverflow | kStDiverge)) return;
+    uint64_t run = 0;
+    for (int64_t lane = 0; lane < n_lanes; ++lane) { base[lane] = run; run += cnt[lane]; }
+    total_out = run;
+    if (run > a.cap) { status |= kStCapacity; return; }
+    std::memset(a.out, 0xEE, (size_t)run);
+    SpliceTables ST;
+    ST.g16 = T.g16;
+    ST.ent8 = T.ent;
+    ST.pool = T.pool;
+    alignas(16) static uint8_t lds[kSpLdsPerWave];
+    for (int64_t first = 0; first < n_lanes; first += 256) {
+        for (int w = 3; w >= 0; --w) {
+            std::memset(lds, 0xEE, sizeof lds);
+            const int64_t left = n_lanes - (first + w);
+            if (left <= 0) continue;
+            const SpliceWork W{first + w, 4, (int)std::min<int64_t>(64, (left + 3) / 4), base.data() + first + w, 4};
+            fb_splice_ranges<true>(a, ST, ca, W, lane_bytes, SpliceLds{lds});
+        }
+    }
+}
+
 // The record + patch form of the general families (patch_block.hpp) as k_stream_g16<3> / k_chunk_scan / k_patch run it:
 // the record pass lane by lane, the exclusive sum of the block totals, then every block's pieces into an emulated LDS tile
 // (same skewed layout) and the tile out.  tile_cap: logical capacity of the tile (smaller than the production one in the
@@ -425,7 +469,9 @@ void run_fb_copy(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64
                 const int64_t left = n_lanes - (first + w);
                 if (left <= 0) continue;
                 const SpliceWork W{first + w, 4, (int)std::min<int64_t>(64, (left + 3) / 4), base.data() + first + w, 4};
-                fb_splice_ranges(a, CT, ca, W, lane_bytes, SpliceLds{lds});
+                SpliceTables ST;
+                ST.lit = CT.lit; ST.esc = CT.esc; ST.pool = CT.pool;
+                fb_splice_ranges<false>(a, ST, ca, W, lane_bytes, SpliceLds{lds});
             }
         }
         return;
@@ -622,6 +668,11 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
         if (!sh.fb_slots || !sh.off_fb_lit_meta) return -5;
         run_fb_copy(a, geo == 0 ? 2048 : 128, status, total, geo == 0 ? 256u : 64u, true);
     }
+    else if (family == 28) {
+        // stream general family by the splice form of its 16-byte entries (what the runtime launches by default)
+        if (!reinterpret_cast<const StreamBlobHeader*>(blob)->g16_bytes) return -5;
+        run_g16_splice<0>(a, geo == 0 ? 2048 : 128, status, total, geo == 0 ? 256u : 64u);
+    }
     else if (family == 24) {
         // stream general family by record + patch (16-byte entries; 16-byte aligned inputs only, like the runtime)
         if (!reinterpret_cast<const StreamBlobHeader*>(blob)->g16_bytes || al != 0) return -5;
@@ -707,6 +758,12 @@ int shim_scan_guided(const uint8_t* rblob, const uint8_t* gblob, int family, int
         else if (packed) run_direct_lp_emit<2>(a, lane_bytes, status, true);
         else run_direct_lp_emit<1>(a, lane_bytes, status, family == 10 && has_g16);  // 14: on the 8-byte entries
         total = n;
+    }
+    else if (family == 16) {
+        // general guided family by the splice form (what the runtime launches by default when the forward table has 16-byte entries)
+        if (!has_g16) return -5;
+        if (packed) run_g16_splice<2>(a, lane_bytes, status, total, geo == 0 ? 256u : 64u);
+        else run_g16_splice<1>(a, lane_bytes, status, total, geo == 0 ? 256u : 64u);
     }
     else if (family == 15) {
         if (!has_g16 || al != 0) return -5;

@@ -50,7 +50,7 @@ def mask_bytes_of(blob, engine):
 def shim_scan(blob, engine, family, data, geo=1, in_mis=0, out_mis=0, scratch=True, cap=None):
     """Run one kernel family of the device code on the host.  Returns (output bytes, status)."""
     if cap is None:
-        cap = len(data) * 8 + 64 if family in (3, 5, 7, 9, 22, 23, 24, 25, 27) else len(data)     # (20, 21: length-preserving)
+        cap = len(data) * 8 + 64 if family in (3, 5, 7, 9, 22, 23, 24, 25, 27, 28) else len(data)     # (20, 21: length-preserving)
     out = ctypes.create_string_buffer(max(cap, 1))
     m = ctypes.c_size_t()
     st = ctypes.c_uint32()
@@ -82,6 +82,8 @@ ST_EDIT_OVERFLOW = 64
 # shim ids of the guided families (ABI ids 6, 7): LP by the emit pass alone on the 16-byte entries (as the runtime
 # launches it), general on the 16-byte / 8-byte entries, LP by the older LDS-ring walker, LP emit on the 8-byte entries
 GUIDED_LP, GUIDED_GEN, GUIDED_GEN8, GUIDED_LP_RING, GUIDED_LP8 = 10, 11, 12, 13, 14
+GUIDED_GEN_SPLICE = 16                               # general guided family by the splice form of its 16-byte entries (mark + splice: the runtime's default)
+STREAM_G16_SPLICE = 28                               # stream general family, the same
 GUIDED_LP_ALL = (GUIDED_LP, GUIDED_LP_RING, GUIDED_LP8)
 STREAM_LP_EMIT, STREAM_LP_EMIT8 = 20, 21            # stream LP family by the emit pass alone (no window form)
 STREAM_LPW_PAIR = 26                                 # the window kernel on the pair form of its entries (what the runtime launches when the tables have one)
@@ -107,6 +109,22 @@ def shim_scan_guided(prog, family, data, geo=1, in_mis=0, out_mis=0):
 
 
 def scan_guided_like_runtime(prog, data, geo=1, family=GUIDED_LP, in_mis=0, out_mis=0):
+    if family == GUIDED_GEN_SPLICE:
+        lib().shim_scan_guided          # (argtypes set)
+        rblob, gblob = prog.export_guided_tables()
+        cap = len(data) * 8 + 64
+        o = ctypes.create_string_buffer(max(cap, 1))
+        m = ctypes.c_size_t()
+        stt = ctypes.c_uint32()
+        rc = lib().shim_scan_guided(rblob, gblob, family, geo, data, len(data), in_mis, o, cap, out_mis, ctypes.byref(m), ctypes.byref(stt))
+        if rc == -5:                         # no 16-byte entries: nothing to splice
+            family = GUIDED_GEN
+        elif rc:
+            raise RuntimeError("shim rc %d" % rc)
+        elif stt.value & (ST_EDIT_OVERFLOW | ST_NUL | ST_DIVERGE | ST_OVERFLOW):
+            family = GUIDED_GEN              # a void launch: the count / emit pair decides (runtime.cpp: finish)
+        else:
+            return o.raw[:m.value]
     out, st = shim_scan_guided(prog, family, data, geo, in_mis, out_mis)
     assert not st & ST_MISMATCH, "count and emit passes disagree"
     if st & ST_DIVERGE and not (family in GUIDED_LP_ALL and st & ST_NUL):      # (void by a NUL: the general family decides)
@@ -125,9 +143,14 @@ def scan_like_runtime(prog, data, geo=1, family=None, in_mis=0, out_mis=0):
     fam = family
     if not fam:                       # ABI ids -> shim ids (the shim's 6..9 are the direct walkers of the stream families)
         fam = {6: GUIDED_LP, 7: GUIDED_GEN}.get(info.kernel, info.kernel)
-    if fam in (GUIDED_LP, GUIDED_GEN, GUIDED_GEN8, GUIDED_LP_RING, GUIDED_LP8):
+    if fam in (GUIDED_LP, GUIDED_GEN, GUIDED_GEN8, GUIDED_LP_RING, GUIDED_LP8, GUIDED_GEN_SPLICE):
         return scan_guided_like_runtime(prog, data, geo, fam, in_mis, out_mis)
-    blob = prog.export_stream_tables() if fam in (4, 5, 6, 7, 8, 9, 20, 21, 22, 23, 25, 27, STREAM_LPW_PAIR) else prog.export_tables()
+    blob = prog.export_stream_tables() if fam in (4, 5, 6, 7, 8, 9, 20, 21, 22, 23, 25, 27, 28, STREAM_LPW_PAIR) else prog.export_tables()
+    if fam == STREAM_G16_SPLICE:
+        out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
+        if out is not None and not st & (ST_EDIT_OVERFLOW | ST_NUL | ST_DIVERGE | ST_OVERFLOW):
+            return out
+        fam = 7                             # no 16-byte entries, or a void launch: the count / emit pair
     out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
     if out is None:                         # family 8 / 26 without a window (pair) form: nothing to run
         fam = 6

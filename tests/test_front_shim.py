@@ -69,7 +69,7 @@ def guided_families(p):
     if trre_amd.KERNEL_GUIDED_LP in allowed:
         fams += list(shim_lib.GUIDED_LP_ALL)
     if trre_amd.KERNEL_GUIDED_GEN in allowed:
-        fams += [shim_lib.GUIDED_GEN, shim_lib.GUIDED_GEN8]
+        fams += [shim_lib.GUIDED_GEN, shim_lib.GUIDED_GEN8, shim_lib.GUIDED_GEN_SPLICE]
     return fams
 
 
@@ -101,7 +101,7 @@ def shim_families(p):
     if 4 in fams:             # (shim ids: 6/8 LDS-ring and window walkers of the stream LP family, 20/21 its emit-only form,
         fams += [6, 8, shim_lib.STREAM_LPW_PAIR, shim_lib.STREAM_LP_EMIT, shim_lib.STREAM_LP_EMIT8]      # 7/9 direct walkers of the general one; 26: window walk, two bytes per step)
     if 5 in fams:
-        fams += [7, 9]
+        fams += [7, 9, shim_lib.STREAM_G16_SPLICE]
         if shim_lib.has_fallback_form(p):      # a large table: the count pass (and, off by default, the emit pass) in LDS
             fams += [shim_lib.STREAM_FB, shim_lib.STREAM_FB_COUNT]
     return fams + guided_families(p)

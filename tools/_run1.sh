@@ -1,7 +1,10 @@
-python tools/nul_bench.py 2>&1 | tail -3
-python tools/nul_bench.py --bytes $((8<<30)) --steps 3 2>&1 | tail -3
-TRRE_NO_NUL_REPAIR=1 python tools/nul_bench.py --bytes $((8<<30)) --steps 3 2>&1 | tail -3
-python tools/kbench.py --case "(cat:dog|dog:cat);;nft;;catdog;;auto" --steps 5 2>&1 | tail -1
-python tools/kbench.py --case "(cat:dog|dog:cat);;nft;;catdog;;auto" --steps 5 --out-mis 5 2>&1 | tail -1
-TRRE_LPW_ALIGNED_ONLY=1 python tools/kbench.py --case "(cat:dog|dog:cat);;nft;;catdog;;auto" --steps 5 --out-mis 5 2>&1 | tail -1
-python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "nul or relaunch or unaligned or golden or every_kernel" 2>&1 | tail -3
+cd /tmp && export TMPDIR=/tmp
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p gpurun_out/raw
+for v in A TRRE_NO_G16_SPLICE; do
+for c in "a:xyz;;dft;;printable;;auto" "(a|b)*c:x;;nft;;printable;;auto"; do
+env $v=1 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/raw/x -o s -- python tools/kbench.py --case "$c" --steps 5 > gpurun_out/raw/x.log 2>&1
+echo "== $v $c"; python tools/rocpd_summary.py gpurun_out/raw/x/s_results.db trre | cut -c1-150 | grep -v "^kernel\|^$"
+rm -rf gpurun_out/raw/x
+done; done
+rm -rf gpurun_out/raw

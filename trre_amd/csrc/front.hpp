@@ -190,7 +190,8 @@ struct StreamTables {
     // the transition appends (inline bytes, then maybe the input byte), [3] a NUL cut a line short, [4] the
     // reference's search diverges (guided tables), [5] record end, [6] bounded-fold overflow, [7] "slow":
     // more than 4 bytes or pooled text — handled from the 8-byte entry, [8] identity: the transition emits exactly the byte
-    // it reads; [9] every other transition: an edit for the patch path, [23:16] bytes emitted - 1 (signed, 0 bytes for a slow entry)
+    // it reads; [9] every other transition: an edit for the patch path, [10] a transition of SKIP / DONE, [11] an edit for the
+    // mark pass of the splice form ([9] and not [10]), [23:16] bytes emitted - 1 (signed, 0 bytes for a slow entry)
     bool g16_ok = false;
     std::vector<uint32_t> g16;              // [n_states][n_cls][4]
     // Pair form of a small table: one entry per (state, class of byte 0, class of byte 1) = the two transitions composed,

@@ -47,6 +47,9 @@ bool fb_copy_fits(const void* hdr);
 // ... its second pass as a wave-cooperative splice (splice_block.hpp); the workspace's chunks must be full (the mark pass fills every lane's header)
 void launch_fb_splice(const ScanArgs& a, const FbCopyArgs& ca, const void* hdr, int64_t lane_bytes, int64_t n_chunks, void* stream);
 bool fb_splice_fits(const void* hdr);
+// the splice form of a SMALL table: launch_direct_kernel(4, ...) marks (its PatchArgs carry the event rows: slots, the lane headers: ovf,
+// and the events per row: ovf_cap), this splices
+void launch_g16_splice(const ScanArgs& a, const FbCopyArgs& ca, int g16_bytes, int64_t lane_bytes, int64_t n_chunks, void* stream);
 void launch_chunk_scan(const uint64_t* total, uint64_t* base, int64_t n_chunks, void* stream);
 void launch_bytemap(const ScanArgs& a, void* stream);
 void launch_nul_eol(const uint8_t* in, int64_t n, const uint64_t* pos, uint64_t* eol, uint32_t count, void* stream);

@@ -304,6 +304,7 @@ bool is_generate(int mode) { return mode == TRRE_MODE_SCAN_ALL || mode == TRRE_M
 bool is_stream(int fam) { return fam == TRRE_KERNEL_STREAM_LP || fam == TRRE_KERNEL_STREAM_GEN; }
 bool is_guided(int fam) { return fam == TRRE_KERNEL_GUIDED_LP || fam == TRRE_KERNEL_GUIDED_GEN; }
 bool is_gen(int fam) { return fam == TRRE_KERNEL_TILE_GEN || fam == TRRE_KERNEL_STREAM_GEN || fam == TRRE_KERNEL_GUIDED_GEN; }
+bool is_guided_wide(const trre_prog& p, int fam) { return (fam == TRRE_KERNEL_GUIDED_LP || fam == TRRE_KERNEL_GUIDED_GEN) && p.gt.wide; }
 bool lp_inplace(uint32_t flags) { return (flags & trre::kFlagLengthPreserving) && (flags & trre::kFlagNoOverrun); }
 // the family that takes over when a length-preserving launch met a NUL, or a bounded stream table a long run
 int general_family(const trre_prog& p, bool stream_ok) {
@@ -635,6 +636,34 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
         // patch 1.61 ms against count 0.42 + emit 0.97.  (Its first lane starts at v = 0: 16-byte aligned
         // inputs only; a scan that diverges or runs out of overflow records is run again as a count / emit pair.)
         static const bool no_patch_env = getenv("TRRE_PATCH") == nullptr;
+        // The splice form (round 4; tables with the 16-byte entries): the count walk also lists the lane's edits (the
+        // transitions that do not simply pass on the byte they read), the second pass copies the input around them, a wave per
+        // sub-range, without walking the table again (splice_block.hpp) — instead of the emit walk, the slowest kernel of every
+        // general family.  A NUL, a sub-range with more edits than its list holds (256, or 15 in 64 bytes: a corpus full of
+        // edits), a pooled text of more than 255 bytes send the buffer to the count / emit pair.
+        // (as it stands the form loses on small tables — 'a:xyz', 1 GiB: mark 0.84 + splice 0.76 ms against count 0.45 + emit 1.00 —
+        // so it is OFF by default: TRRE_G16_SPLICE=1 selects it, for A/B runs and the parity tests)
+        static const bool no_g16_splice_env = getenv("TRRE_G16_SPLICE") == nullptr;
+        const bool splice_form = g16 > 0 && no_patch_env && !no_g16_splice_env && !cx->patch_off && !p->copy_form_off.load() && lane_bytes % 64 == 0 &&
+                                 stt.max_out <= kSpMaxText && !is_guided_wide(*p, family);
+        if (splice_form) {
+            const int64_t n_lanes = n_chunks * direct_block_threads();
+            rc = ensure_copy_workspace(cx, n_lanes);
+            if (rc) return rc;
+            FbCopyArgs ca{};
+            ca.events = cx->d_cevents;
+            ca.lane_hdr = cx->d_chdr;
+            ca.ev_cap = kCopyEvCap;
+            PatchArgs pa{};                                   // (how the mark pass receives them: launch.hpp)
+            pa.slots = ca.events;
+            pa.ovf = ca.lane_hdr;
+            pa.ovf_cap = ca.ev_cap;
+            launch_direct_kernel(4, direct_ent_lds, args, lane_bytes, n_chunks, stream, (int)align_up(stt.g16.size() * 4, 16), sym_mode, g16_slow, &pa);
+            launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);
+            launch_g16_splice(args, ca, (int)(stt.g16.size() * 4), lane_bytes, n_chunks, stream);
+            pd.total_at = cx->d_chunk_base + n_chunks;
+            pd.patched = true;
+        } else
         if (g16 > 0 && a == 0 && !no_patch_env && !cx->patch_off && lane_bytes % kPieceBytes == 0) {
             const int64_t n_pieces = (args.vend + kPieceBytes - 1) / kPieceBytes;
             const int64_t n_blocks = (n_pieces + kBlockPieces - 1) / kBlockPieces;

@@ -1328,10 +1328,23 @@ TRRE_HD void rec_finish(const PatchArgs& pa, RecState& r) {
 // kSym: 0 columns are byte classes; 1 / 2 (guided families) columns are the symbols the backward pass left, one per
 // byte / packed two per byte (backward DFAs of at most 16 states: half the symbol traffic).
 // kMode 3: the record pass (above): `ring` is the lane's stage of kRecStage words, `pa` the slots.
+// kMode 4: the mark pass of the splice form (round 4; splice_block.hpp): the count walk, which also lists the lane's EDITS —
+// the transitions that do not simply pass on the byte they read (meta bit 11) — as 4-byte events {[15:0] the byte's position
+// in the sub-range, [31:16] the entry's index}, collected in the lane's stage (`ring`: kMarkStage dwords) and moved to its row
+// of `ca` after every 64 input bytes, plus where its first line starts and its last one ends.  The second pass copies the
+// input around the edits without walking the table again.  A NUL (the rest of its record is swallowed), more edits than the
+// lists hold or a line of more than 64 KiB void the launch (kStNul / kStEditOverflow): the count / emit pair runs.
+struct FbCopyArgs;
+TRRE_HD uint32_t* copy_event_row(const FbCopyArgs& ca, int64_t lane);
+TRRE_HD uint32_t copy_event_cap(const FbCopyArgs& ca);
+TRRE_HD uint32_t* copy_lane_hdr(const FbCopyArgs& ca, int64_t lane);
+constexpr int kMarkStage = 16;                 // events a lane can collect per 64 input bytes (LDS, 17 dwords apart)
+constexpr int kMarkStageStride = 17;
 template <int kMode, int kSym, bool kHasSlow>
 TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, int64_t lane, int64_t lane_bytes, uint8_t* ring,
-                      uint64_t out_base, DirectLane& L, uint32_t& status, uint32_t* wave_scratch = nullptr, const PatchArgs* pa = nullptr) {
-    static_assert(kMode == 1 || kMode == 2 || kMode == 3, "count, emit or record");
+                      uint64_t out_base, DirectLane& L, uint32_t& status, uint32_t* wave_scratch = nullptr, const PatchArgs* pa = nullptr,
+                      const FbCopyArgs* ca = nullptr) {
+    static_assert(kMode == 1 || kMode == 2 || kMode == 3 || kMode == 4, "count, emit, record or mark");
     const uint32_t done_row = kDoneState * n_cls * 16u;
     const int64_t lo = lane * lane_bytes;
     int64_t hi = lo + lane_bytes;
@@ -1356,6 +1369,15 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
     }
     uint64_t cnt = 0;
     uint32_t seen = 0;
+    // kMode 4: the stage, the lane's row of events, its first line start and the end of its last line
+    uint32_t* const stage0 = reinterpret_cast<uint32_t*>(ring);
+    uint32_t si = 0, n_ev = 0, b_rel = 0, e_rel = 0, far = 0;
+    uint32_t* evp = nullptr;
+    if (kMode == 4) {
+        evp = copy_event_row(*ca, lane);
+        if (row != 0u && row != done_row) b_rel = (uint32_t)(first_line_start_safe(a, lo, hi) - lo);
+        if (row == done_row) b_rel = rhi;
+    }
     RecState R;                                                      // kMode 3
     R.stage = reinterpret_cast<uint32_t*>(ring);
     R.rec = row == 0u;                                               // a lane that starts at a line start records from its first piece on
@@ -1429,6 +1451,45 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
                             const uint32_t meta = (uint32_t)(g >> 32);
                             c += (meta & 128u) ? slow_count(row, kk[j]) : (meta & 7u);
                             row = (kEnd && (meta & 32u) && rp + (uint32_t)j + 1u >= rhi) ? done_row : (uint32_t)g;
+                        }
+                    }
+                }
+            }
+            seen |= fl;
+            cnt += c;
+        } else if (kMode == 4) {
+            const uint32_t row0 = row;
+            uint32_t c = 0, fl = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t eoff = row + (kk[j] << 4);
+                const uint64_t g = *reinterpret_cast<const uint64_t*>(T.g16 + eoff);
+                const uint32_t meta = (uint32_t)(g >> 32);
+                c += meta & 7u;
+                fl |= meta;
+                uint32_t edit = (meta >> 11) & 1u;
+                if (kEnd) {
+                    // the last byte of the input ends its record whatever it holds (Q1): what the transition emits there is not
+                    // "the byte it read" unless that byte is the '\n' the walk saw
+                    edit |= (uint32_t)(rp + (uint32_t)j + 1u == vlim) & (((meta >> 10) & 1u) ^ 1u);
+                    if (rp + (uint32_t)j > 0xffffu) far |= edit;
+                }
+                stage0[si] = (rp + (uint32_t)j) | (eoff << 12);              // [15:0] position, [31:16] the entry's index
+                si = si + edit < (uint32_t)kMarkStage - 1u ? si + edit : (uint32_t)kMarkStage - 1u;   // (a full stage: the launch is void)
+                const bool fin = kEnd && (meta & 32u) && rp + (uint32_t)j + 1u >= rhi;
+                if (kEnd && fin && row != done_row) e_rel = rp + (uint32_t)j + 1u;
+                row = fin ? done_row : (uint32_t)g;
+            }
+            if (kHasSlow) {
+                if (TRRE_WAVE_ANY(fl & 128u)) {
+                    if (fl & 128u) {              // count this dword again, slow entries from their 8-byte form
+                        uint32_t r = row0;
+                        c = 0;
+                        for (int j = 0; j < 4; ++j) {
+                            const uint64_t g = *reinterpret_cast<const uint64_t*>(T.g16 + r + (kk[j] << 4));
+                            const uint32_t meta = (uint32_t)(g >> 32);
+                            c += (meta & 128u) ? slow_count(r, kk[j]) : (meta & 7u);
+                            r = (kEnd && (meta & 32u) && rp + (uint32_t)j + 1u >= rhi) ? done_row : (uint32_t)g;
                         }
                     }
                 }
@@ -1574,7 +1635,7 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
         const uint32_t y0 = kSym == 2 ? (y.x & 0xffffu) : y.x, y1 = kSym == 2 ? (y.x >> 16) : y.y,
                        y2 = kSym == 2 ? (y.y & 0xffffu) : y.z, y3 = kSym == 2 ? (y.y >> 16) : y.w;
         // (between two flushes at most 65 bytes may arrive: 8 transitions of up to 5 bytes, or 4 of up to 9 with slow entries)
-        if (!kEnd && T.p32 && kMode != 3) {
+        if (!kEnd && T.p32 && kMode != 3 && kMode != 4) {
             dword_pairs(b.x, y0);
             if (kMode == 2 && (kHasSlow || T.p32_slow)) stage_flush<false>(S);
             dword_pairs(b.y, y1);
@@ -1657,14 +1718,33 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
             rec_commit(a, *pa, R, v, walked, (seen & 32u) != 0u, status);
             if (R.fin) row = done_row;
         }
+        if (kMode == 4) {
+            // the piece's events, to the end of the lane's row
+            const uint32_t n_loc = si;
+            if (n_loc >= (uint32_t)kMarkStage - 1u) far = 1;
+            for (uint32_t k = 0; TRRE_WAVE_ANY(k < n_loc); ++k)
+                if (k < n_loc && n_ev + k < copy_event_cap(*ca)) evp[k] = stage0[k];
+            evp += n_loc;
+            n_ev += n_loc;
+            si = 0;
+        }
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         if (kSym) { s0 = t0; s1 = t1; s2 = t2; s3 = t3; }
     }
     if (kMode == 3) rec_finish(*pa, R);
+    if (kMode == 4) {
+        if (n_ev > copy_event_cap(*ca) || far) status |= kStEditOverflow;
+        if (seen & 8u) status |= kStNul;
+        uint32_t* hdr = copy_lane_hdr(*ca, lane);
+        hdr[0] = n_ev < copy_event_cap(*ca) ? n_ev : copy_event_cap(*ca);
+        hdr[1] = b_rel;
+        hdr[2] = b_rel < rhi ? e_rel : b_rel;          // (no line starts in the sub-range: the lane has nothing to copy)
+        hdr[3] = 0;
+    }
     if (kMode == 2) stage_flush<true>(S);
     if (kMode == 2 && a.lp_emit && ((seen & 8u) || (seen2 & 256u))) status |= kStNul;
-    if ((kMode == 1 || kMode == 3) && ((seen | seen2) & 64u)) status |= kStOverflow;            // bounded fold: the launch is void
-    if ((kMode == 1 || kMode == 3 || a.lp_emit) && ((seen | seen2) & 16u)) status |= kStDiverge;   // guided tables: the reference's search never returns
+    if ((kMode == 1 || kMode == 3 || kMode == 4) && ((seen | seen2) & 64u)) status |= kStOverflow;            // bounded fold: the launch is void
+    if ((kMode == 1 || kMode == 3 || kMode == 4 || a.lp_emit) && ((seen | seen2) & 16u)) status |= kStDiverge;   // guided tables: the reference's search never returns
     L.count = cnt;
 }
 
@@ -1693,14 +1773,14 @@ struct FbView {
     uint32_t start[3][2];      // root, SKIP, DONE: {descriptor, about bits}
 };
 // the mark pass's product (the copy form, below): events and lane headers
-constexpr int kMarkStage = 16;                 // events a lane can collect per 64 input bytes (LDS, 17 dwords apart)
-constexpr int kMarkStageStride = 17;
 struct FbCopyArgs {
     uint32_t* events;          // [n_lanes][ev_cap]: a lane's events side by side (ev_cap: a multiple of 4 — the copy pass reads them 16 bytes at a time)
     uint32_t* lane_hdr;        // [n_lanes][4]: {events, first line start, end of the last line (offsets from the sub-range's start), -}
     uint32_t ev_cap;
 };
 TRRE_HD uint32_t* copy_event_row(const FbCopyArgs& ca, int64_t lane) { return ca.events + (size_t)lane * ca.ev_cap; }
+TRRE_HD uint32_t copy_event_cap(const FbCopyArgs& ca) { return ca.ev_cap; }
+TRRE_HD uint32_t* copy_lane_hdr(const FbCopyArgs& ca, int64_t lane) { return ca.lane_hdr + (size_t)lane * 4; }
 // the record of the escape entry in slot `slot`
 TRRE_HD const uint32_t* fb_esc_record(const FbView& T, uint32_t slot) {
     uint32_t lo = 0, hi = T.n_esc;

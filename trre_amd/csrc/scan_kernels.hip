@@ -472,8 +472,11 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_g16(ScanArgs a, int64
     // large table in global memory that does not pay: k_stream_direct's count pass is fastest at the
     // 16 waves per CU its emit-sized LDS allows — 1.63 ms against 1.9 ms at 8 or 28 waves: cache capacity)
     // (the record pass: a stage of kRecStage words per lane instead of the rings)
-    uint8_t* ring = kMode == 1 ? pool_lds : (kMode == 3 ? pool_lds + threadIdx.x * (kRecStageStride * 4) : pool_lds + kDirectPoolSmall + threadIdx.x * kRingStride);
-    uint8_t* tail = kMode == 1 ? pool_lds : (kMode == 3 ? pool_lds + kDirectThreads * (kRecStageStride * 4) : pool_lds + kDirectPoolSmall + kDirectThreads * kRingStride);       // 64 bytes
+    // (the mark pass: a stage of kMarkStage events per lane)
+    uint8_t* ring = kMode == 1 ? pool_lds : (kMode == 3 ? pool_lds + threadIdx.x * (kRecStageStride * 4) : (kMode == 4 ? pool_lds + threadIdx.x * (kMarkStageStride * 4)
+                               : pool_lds + kDirectPoolSmall + threadIdx.x * kRingStride));
+    uint8_t* tail = kMode == 1 ? pool_lds : (kMode == 3 ? pool_lds + kDirectThreads * (kRecStageStride * 4) : (kMode == 4 ? pool_lds + kDirectThreads * (kMarkStageStride * 4)
+                               : pool_lds + kDirectPoolSmall + kDirectThreads * kRingStride));       // 64 bytes
     const int64_t lane = (int64_t)blockIdx.x * kDirectThreads + threadIdx.x;
     DirectLane L;
     uint32_t st = 0;
@@ -495,9 +498,11 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_g16(ScanArgs a, int64
         }
     }
     uint32_t* wsc = reinterpret_cast<uint32_t*>(tail + 64) + (threadIdx.x / kWave) * (kWaveScratchBytes / 4);
-    g16_lane<kMode, kSym, kHasSlow>(a, T, h.n_cls, lane, lane_bytes, ring, base, L, st, kMode == 2 ? wsc : nullptr, &pa);
+    // (the mark pass's events and lane headers travel in `pa`: slots = the event rows, ovf = the headers, ovf_cap = events per row)
+    const FbCopyArgs ca{pa.slots, pa.ovf, pa.ovf_cap};
+    g16_lane<kMode, kSym, kHasSlow>(a, T, h.n_cls, lane, lane_bytes, ring, base, L, st, kMode == 2 ? wsc : nullptr, &pa, &ca);
     if (kMode == 1 && kSym != 0 && (st & kStDiverge)) atomicMax(a.status + 1, 0xffffffffu - (uint32_t)lane);     // (see k_stream_direct)
-    if (kMode == 1) {
+    if (kMode == 1 || kMode == 4) {
         uint64_t* part = reinterpret_cast<uint64_t*>(tail);
         if (L.count > 0xffffffffull) { st |= kStCapacity; L.count = 0xffffffffull; }
         a.lane_counts[lane] = (uint32_t)L.count;
@@ -832,7 +837,7 @@ __global__ __launch_bounds__(kThreads) void k_fb_splice(ScanArgs a, FbCopyArgs c
     if (*a.status & (kStEditOverflow | kStNul)) return;
     __syncthreads();
     if (!live) return;
-    FbCopyTables T;
+    SpliceTables T;
     T.lit = lit;
     T.esc = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_esc);
     T.pool = a.blob + h.off_fb_pool;
@@ -841,7 +846,56 @@ __global__ __launch_bounds__(kThreads) void k_fb_splice(ScanArgs a, FbCopyArgs c
     const SpliceLds L{carve + wave * kSpLdsPerWave};
     // (the chunk's waves take neighbouring sub-ranges at the same time: neighbouring lines of the output)
     const SpliceWork W{lane0 + gwave, kDirectThreads / kWave, kWave, sbase + group * kDirectThreads + gwave, kDirectThreads / kWave};
-    fb_splice_ranges(a, T, ca, W, lane_bytes, L);
+    fb_splice_ranges<false>(a, T, ca, W, lane_bytes, L);
+}
+// The same second pass for SMALL tables (the 16-byte entries; mark pass: k_stream_g16<4>): an edit names the entry of its
+// transition.  The entries are looked up in LDS when the table is at most 8 KiB, in memory otherwise (edits are sparse where
+// this pays).   smem: entries (or nothing) | output bases of the sub-ranges (u64) | 64 per chunk | the per-wave carves
+constexpr int kSpliceTabMax = 8192;
+template <int kThreads>
+__global__ __launch_bounds__(kThreads) void k_g16_splice(ScanArgs a, FbCopyArgs ca, int64_t lane_bytes, int64_t n_chunks, int tab_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
+    {
+        const U128* e = reinterpret_cast<const U128*>(a.blob + h.off_g16);
+        U128* d = reinterpret_cast<U128*>(smem);
+        for (int k = threadIdx.x; k < tab_bytes / 16; k += kThreads) d[k] = e[k];
+    }
+    constexpr int kGroups = kThreads / kDirectThreads;
+    uint64_t* sbase = reinterpret_cast<uint64_t*>(smem + tab_bytes);
+    uint32_t* wparts = reinterpret_cast<uint32_t*>(sbase + kThreads);
+    uint8_t* carve = reinterpret_cast<uint8_t*>(wparts + 16 * kGroups);
+    const int group = threadIdx.x / kDirectThreads, gtid = threadIdx.x % kDirectThreads;
+    const int64_t chunk = (int64_t)blockIdx.x * kGroups + group;
+    const bool live = chunk < n_chunks;
+    const int64_t lane0 = chunk * kDirectThreads;
+    uint32_t* wpart = wparts + 16 * group;
+    const uint32_t mine = live ? a.lane_counts[lane0 + gtid] : 0u;
+    const uint32_t incl = wave_scan_incl(mine);
+    if ((threadIdx.x & (kWave - 1)) == kWave - 1) wpart[gtid / kWave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < gtid / kWave; ++w) wbase += wpart[w];
+    sbase[threadIdx.x] = live ? a.chunk_base[chunk] + wbase + incl - mine : 0ull;
+    const int64_t last = ((int64_t)blockIdx.x + 1) * kGroups - 1 < n_chunks - 1 ? ((int64_t)blockIdx.x + 1) * kGroups - 1 : n_chunks - 1;
+    if (a.chunk_base[last] + a.chunk_total[last] > a.cap) {               // (uniform for the workgroup)
+        if (threadIdx.x == 0) atomicOr(a.status, kStCapacity);
+        return;
+    }
+    // a void launch (a NUL, more edits than a row holds, a bounded fold that overflowed, an attempt that does not return):
+    // nothing is written, finish() runs the count / emit pair
+    if (*a.status & (kStEditOverflow | kStNul | kStOverflow | kStDiverge)) return;
+    __syncthreads();
+    if (!live) return;
+    SpliceTables T;
+    T.g16 = tab_bytes ? smem : a.blob + h.off_g16;
+    T.ent8 = reinterpret_cast<const uint64_t*>(a.blob + h.off_ent);
+    T.pool = a.blob + h.off_pool;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x / kWave);
+    const int gwave = wave % (kDirectThreads / kWave);
+    const SpliceLds L{carve + wave * kSpLdsPerWave};
+    const SpliceWork W{lane0 + gwave, kDirectThreads / kWave, kWave, sbase + group * kDirectThreads + gwave, kDirectThreads / kWave};
+    fb_splice_ranges<true>(a, T, ca, W, lane_bytes, L);
 }
 // ------------------------------------------------------------------------------------------
 // memoryless byte map: out[v] = map[in[v]], 16 bytes per lane per step
@@ -1119,12 +1173,17 @@ void launch_g16(int which, const ScanArgs& a, int64_t lane_bytes, int64_t n_bloc
     const int lds = 256 + room + kDirectPoolSmall + kDirectThreads * kRingStride + 64 + kDirectWsc;
     const int lds_count = 256 + room + 64;
     const int lds_rec = 256 + room + kDirectThreads * kRecStageStride * 4 + 64 + kDirectWsc;
+    const int lds_mark = 256 + room + kDirectThreads * kMarkStageStride * 4 + 64 + kDirectWsc;
     allow_big_lds<&k_stream_g16<1, kSym, kHasSlow>>();
     allow_big_lds<&k_stream_g16<2, kSym, kHasSlow>>();
     allow_big_lds<&k_stream_g16<3, kSym, kHasSlow>>();
     const PatchArgs none{};
     if (which == 1) hipLaunchKernelGGL((k_stream_g16<1, kSym, kHasSlow>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds_count, s, a, lane_bytes, room, none);
     else if (which == 3) hipLaunchKernelGGL((k_stream_g16<3, kSym, kHasSlow>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds_rec, s, a, lane_bytes, room, *pa);
+    else if (which == 4) {
+        allow_big_lds<&k_stream_g16<4, kSym, kHasSlow>>();
+        hipLaunchKernelGGL((k_stream_g16<4, kSym, kHasSlow>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds_mark, s, a, lane_bytes, room, *pa);
+    }
     else hipLaunchKernelGGL((k_stream_g16<2, kSym, kHasSlow>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds, s, a, lane_bytes, room, none);
 }
 template <int kSym>
@@ -1308,6 +1367,13 @@ void launch_fb_splice(const ScanArgs& a, const FbCopyArgs& ca, const void* hdr, 
     }
 }
 bool fb_splice_fits(const void* hdr) { return fb_splice_lds(*static_cast<const StreamBlobHeader*>(hdr), 512) <= kLdsLimit; }
+void launch_g16_splice(const ScanArgs& a, const FbCopyArgs& ca, int g16_bytes, int64_t lane_bytes, int64_t n_chunks, void* stream) {
+    const int tab = g16_bytes <= kSpliceTabMax ? (g16_bytes + 15) / 16 * 16 : 0;
+    constexpr int kT = 512;
+    const int lds = tab + kT * 8 + 64 * (kT / kDirectThreads) + (kT / kWave) * (int)kSpLdsPerWave;
+    allow_big_lds<&k_g16_splice<kT>>();
+    hipLaunchKernelGGL(k_g16_splice<kT>, dim3((unsigned)((n_chunks + 1) / 2)), dim3(kT), lds, static_cast<hipStream_t>(stream), a, ca, lane_bytes, n_chunks, tab);
+}
 // the copy form's LDS fits
 bool fb_copy_fits(const void* hdr) {
     const StreamBlobHeader& h = *static_cast<const StreamBlobHeader*>(hdr);

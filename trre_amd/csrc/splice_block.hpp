@@ -95,6 +95,18 @@ TRRE_HD uint32_t sp_ctz64(uint64_t x) {
 #endif
 }
 
+// what the edits' texts are looked up in.  Large tables (the copy form, scan_block.hpp: fb_lane<3>): an edit names a literal
+// {text, length, input bytes it stands for} or an escape record.  Small tables (the mark pass of g16_lane): an edit names the
+// 16-byte entry of the transition, which stands for the one byte it read and emits the entry's bytes around that byte (or,
+// "slow" entries, a pooled text).
+struct SpliceTables {
+    const U128* lit = nullptr;          // [fb_lits] {text lo, text hi, n | kb << 8, -}  (LDS)
+    const uint32_t* esc = nullptr;      // escape records (global) ...
+    const uint8_t* pool = nullptr;      // ... and their texts; small tables: the pool of the 8-byte entries
+    const uint8_t* g16 = nullptr;       // small tables: the 16-byte entries (LDS or global)
+    const uint64_t* ent8 = nullptr;     // ... and the 8-byte ones (global; slow entries only)
+};
+
 struct SpliceLds {            // one wave's share of the workgroup's LDS (kSpLdsPerWave bytes, 16-byte aligned)
     uint8_t* base;
     TRRE_HD uint8_t* tin() const { return base; }
@@ -134,8 +146,8 @@ TRRE_HD SpliceSub splice_open(const ScanArgs& a, const FbCopyArgs& ca, const Spl
 }
 
 // a.dbg & 1: no global stores (timing experiments).
-template <class Dummy = void>
-TRRE_HD void fb_splice_ranges(const ScanArgs& a, const FbCopyTables& T, const FbCopyArgs& ca, const SpliceWork& W, int64_t lane_bytes,
+template <bool kG16>
+TRRE_HD void fb_splice_ranges(const ScanArgs& a, const SpliceTables& T, const FbCopyArgs& ca, const SpliceWork& W, int64_t lane_bytes,
                               const SpliceLds& L) {
     uint8_t* const tin = L.tin();
     uint8_t* const tout = L.tout();
@@ -199,11 +211,33 @@ TRRE_HD void fb_splice_ranges(const ScanArgs& a, const FbCopyTables& T, const Fb
         SPV(uint32_t, fp0); SPV(uint32_t, n0); SPV(uint32_t, kb0); SPV(uint32_t, tlo0); SPV(uint32_t, thi0); SPV(uint32_t, esc0);
         SPV(uint32_t, fp1); SPV(uint32_t, n1); SPV(uint32_t, kb1); SPV(uint32_t, tlo1); SPV(uint32_t, thi1); SPV(uint32_t, esc1);
         SPV(int32_t, cum0); SPV(int32_t, cum1);
-#define SP_DECODE(raw, fp, n, kb, tlo, thi, ex, cum)                                                              \
+#define SP_DECODE(raw, fp, n, kb, tlo, thi, ex, cum)                                                               \
         SP(fp) = 0xffffffffu; SP(n) = 0; SP(kb) = 0; SP(tlo) = 0; SP(thi) = 0; SP(ex) = 0;                      \
         if (SP(raw) != 0xffffffffu) {                                                                             \
             const uint32_t id = SP(raw) >> 16, p = SP(raw) & 0xffffu;                                             \
-            if (!(id & 0x8000u)) {                                                                                \
+            if (kG16) {                                   /* the transition's entry; it stands for the byte it read */ \
+                const U128 e = *reinterpret_cast<const U128*>(T.g16 + 16u * id);                                  \
+                int32_t ci = 16 + (int32_t)(lo + (int64_t)p - tin0);                                              \
+                ci = ci < 0 ? 0 : (ci > (int32_t)kSpIn + 15 ? (int32_t)kSpIn + 15 : ci);   /* (an edit beyond the window: looked at again there) */ \
+                const uint32_t c = tin[ci];                                                                       \
+                SP(kb) = 1u; SP(fp) = p;                                                                          \
+                if (!(e.y & 128u)) {                                                                              \
+                    SP(tlo) = perm_b32(c, e.z, e.w); SP(n) = e.y & 7u;                                            \
+                } else {                                  /* more than 4 bytes, or a pooled text (rare) */        \
+                    const uint64_t e8 = T.ent8[id];                                                               \
+                    const uint32_t l8 = (uint32_t)e8, h8 = (uint32_t)(e8 >> 32), ol = (l8 >> 24) & 7u, cc = (l8 >> 27) & 1u; \
+                    if (ol != 7u) {                                                                               \
+                        SP(tlo) = ol < 4u ? (h8 | (cc ? c << (8u * ol) : 0u)) : h8;                               \
+                        SP(thi) = ol == 4u && cc ? c : 0u;                                                        \
+                        SP(n) = ol + cc;                                                                          \
+                    } else {                                                                                      \
+                        const uint32_t off = (h8 & 0xffffffu) << 2;                                               \
+                        uint32_t len = h8 >> 24;                                                                  \
+                        if (len == 255u) len = *reinterpret_cast<const uint32_t*>(T.pool + off);                  \
+                        SP(ex) = 1u + off + 4u; SP(n) = len + cc; SP(tlo) = c; SP(thi) = cc;                      \
+                    }                                                                                             \
+                }                                                                                                 \
+            } else if (!(id & 0x8000u)) {                                                                         \
                 const U128 r = T.lit[id];                                                                         \
                 SP(tlo) = r.x; SP(thi) = r.y; SP(n) = r.z & 255u; SP(kb) = r.z >> 8; SP(fp) = p - SP(kb);          \
             } else {                                      /* a text spelled out in memory (rare) */               \
@@ -212,6 +246,7 @@ TRRE_HD void fb_splice_ranges(const ScanArgs& a, const FbCopyTables& T, const Fb
             }                                                                                                     \
         }                                                                                                         \
         SP(cum) = (SP(fp) < w1 && SP(n) > SP(kb)) ? (int32_t)(SP(n) - SP(kb)) : 0;
+        SP_WAVE_SYNC();                                                                  // (the staged input is looked at: kG16)
         SP_FOR {
             SP_DECODE(praw0, fp0, n0, kb0, tlo0, thi0, esc0, cum0)
             SP_DECODE(praw1, fp1, n1, kb1, tlo1, thi1, esc1, cum1)
@@ -364,15 +399,20 @@ TRRE_HD void fb_splice_ranges(const ScanArgs& a, const FbCopyTables& T, const Fb
         if (escmask0 | escmask1) {                                                       // texts from memory (rare; they may be longer than 8 bytes)
             SP_WAVE_SYNC();
             SP_FOR {
+                // (kG16: thi = 1: the text is followed by the input byte, kept in tlo)
                 if (SP_LANE < m0 && SP(esc0)) {
                     const uint8_t* text = T.pool + (SP(esc0) - 1u);
                     uint8_t* t = tout + oa + (uint32_t)SP(P0);
-                    for (uint32_t i = 0; i < SP(n0); ++i) t[i] = text[i];
+                    const uint32_t nt = kG16 ? SP(n0) - SP(thi0) : SP(n0);
+                    for (uint32_t i = 0; i < nt; ++i) t[i] = text[i];
+                    if (kG16 && SP(thi0)) t[nt] = (uint8_t)SP(tlo0);
                 }
                 if (SP_LANE < m1 && SP(esc1)) {
                     const uint8_t* text = T.pool + (SP(esc1) - 1u);
                     uint8_t* t = tout + oa + (uint32_t)SP(P1);
-                    for (uint32_t i = 0; i < SP(n1); ++i) t[i] = text[i];
+                    const uint32_t nt = kG16 ? SP(n1) - SP(thi1) : SP(n1);
+                    for (uint32_t i = 0; i < nt; ++i) t[i] = text[i];
+                    if (kG16 && SP(thi1)) t[nt] = (uint8_t)SP(tlo1);
                 }
             }
         }

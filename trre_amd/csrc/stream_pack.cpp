@@ -116,6 +116,8 @@ void build_gen16(StreamTables& t, const StreamPackInput& in) {
             const bool ident = (x.out.empty() && x.copy_c) || (in.col_kind[k] == kColNewline && !x.copy_c && x.out == "\n");
             e[1] = (slow ? 128u : (uint32_t)n) | (x.eol ? 32u : 0u) | (x.ovf ? 64u : 0u) | (x.diverge ? 16u : 0u) |
                    ((in.col_kind[k] == kColNul && !silent) ? 8u : 0u) | (ident && !x.ovf && !x.diverge ? 256u : 512u) |
+                   // [10] a transition of SKIP / DONE (nobody's bytes), [11] an edit for the mark pass of the splice form: [9] and not [10]
+                   (silent ? 1024u : 0u) | (!silent && !(ident && !x.ovf && !x.diverge) ? 2048u : 0u) |
                    // [9] an edit (not the identity), [23:16] what it adds: bytes emitted - 1 (signed; a slow entry counts as 0 here)
                    (((uint32_t)(int32_t)((slow ? 0 : (int)n) - 1) & 0xffu) << 16);
             uint32_t bytes = 0, sel = 0x0c0c0c0cu;                       // constant 0x00 everywhere
