@@ -47,7 +47,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))   # oracle bindings: verificatio
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 
-KERNEL_OF = {"generate": "k_rev_sweep (viability symbols) + host enumeration", "bytemap": "k_bytemap", "tile_lp": "k_scan_lp", "tile_gen": "k_scan_count + k_scan_emit",
+KERNEL_OF = {"generate": "k_rev_sweep (viability symbols) + k_gen<count> + k_gen<emit>", "bytemap": "k_bytemap", "tile_lp": "k_scan_lp", "tile_gen": "k_scan_count + k_scan_emit",
              "stream_lp": "k_stream_lpw (window form) / k_stream_g16<emit> alone",
              "stream_gen": "k_stream_g16<count> + <emit> (small tables) / k_fb_mark + k_fb_splice (large tables: the copy form)",
              "guided_lp": "k_rev_sweep + k_stream_g16<emit, sym>", "guided_gen": "k_rev_sweep + k_stream_g16<count, sym> + <emit, sym>"}
@@ -660,6 +660,30 @@ def main():
                                                  "workload": "BASELINE configs[4] shape: 1000-entry key:value dictionary (%d-byte pattern), %s engine, "
                                                              "%.0f GiB per GPU, 30 %% of the tokens are keys" % (len(dict_pat), eng.upper(), n / 2**30)},
                                       inp, out, tmp, want_cpu))
+        # generator modes (row f4): the enumeration kernel behind the viability sweep, host buffer in -> host buffer out
+        # (trre_scan_host: the output is unbounded in the input, the C ABI hands it over on the host)
+        try:
+            import random
+            import corpus as tcorpus
+            from oracle_lib import Oracle
+            gdata = tcorpus.word_soup(random.Random(23), 32 << 20, max_len=60)
+            for gname, gpat, gmode in (("gen_a", "(cat:dog|cat:cow|ca:C)", "scan_all"), ("gen_ma", "(cat:dog|cat:cow|.)*", "match_all")):
+                gp = trre_amd.Program(gpat, "nft", mode=gmode)
+                head = gdata[:1 << 20]
+                head = head[:head.rfind(b"\n") + 1]
+                o = Oracle(gpat, "nft", all_outputs=True)
+                ok = gp.scan(head) == (o.match(head) if gmode == "match_all" else o.scan(head))
+                t0 = time.perf_counter()
+                gout = gp.scan(gdata)
+                dt = time.perf_counter() - t0
+                configs.append({"name": gname, "workload": "generator mode (trre %s): every accepting path prints; %d MiB of word soup, host buffer in, host buffer out"
+                                                         % ("-ma" if gmode == "match_all" else "-a", len(gdata) >> 20),
+                                "pattern": gpat, "engine": "nft", "kernel_family": "generate", "kernels": "k_rev_sweep (viability symbols) + k_gen<count> + k_chunk_scan + k_gen<emit>",
+                                "bytes": len(gdata), "output_bytes": len(gout), "ms_per_step": round(dt * 1e3, 2), "input_GBps": round(len(gdata) / dt / 1e9, 4),
+                                "verified": bool(ok), "verify": "a 1 MiB head against the oracle"})
+                gp.close()
+        except Exception as e:      # (the headline must not depend on it)
+            configs.append({"name": "gen_ma", "verified": False, "verify": "failed: %r" % (e,)})
         line["configs"] = configs
         line["configs_verified"] = all(c.get("verified") for c in configs)
 

@@ -17,6 +17,7 @@
 #include "../trre_amd/csrc/patch_block.hpp"
 #include "../trre_amd/csrc/scan_block.hpp"
 #include "../trre_amd/csrc/splice_block.hpp"
+#include "../trre_amd/csrc/gen_block.hpp"
 
 using namespace trre;
 
@@ -780,6 +781,52 @@ int shim_scan_guided(const uint8_t* rblob, const uint8_t* gblob, int family, int
 
 // The backward pass alone (k_rev_sweep's per-thread body): one symbol per input byte into sym_out[0, n).  Used for the
 // guided families' symbols and for the viability symbols of the generator modes (generate.cpp).
+// Generator modes as the runtime runs them on the device: the backward sweep (viability symbols), then the enumeration
+// kernel's lane body — count, exclusive sum, emit (gen_block.hpp).  status: kStDiverge / kStEditOverflow mean "this input goes
+// to the host enumeration".  frames / path_cap: a lane's stack and path buffer (small in the tests: the overflow route runs too).
+int shim_generate(const uint8_t* rblob, const uint8_t* nblob, int geo, const uint8_t* in, size_t n, int in_mis, uint8_t* out, size_t cap,
+                  uint32_t frames, uint32_t path_cap, size_t* m, uint32_t* status_out) {
+    *m = 0; *status_out = 0;
+    if (n == 0) return 0;
+    std::vector<uint8_t> ibuf(n + 64, 0xAA), sym(n + 1024, 0xEE);
+    uint8_t* ia = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(ibuf.data()) + 15) & ~(uintptr_t)15) + in_mis;
+    std::memcpy(ia, in, n);
+    ScanArgs a{};
+    const int64_t al = (int64_t)(reinterpret_cast<uintptr_t>(ia) & 15u);
+    a.in_v0 = ia - al;
+    a.vbeg = al;
+    a.vend = al + (int64_t)n;
+    a.rblob = rblob;
+    a.sym_v0 = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(sym.data()) + 15) & ~(uintptr_t)15);
+    uint32_t status = 0;
+    a.status = &status;
+    run_rev_sweep(a, geo == 0 ? 2048 : 128, false);
+    a.blob = nblob;
+    a.out = out;
+    a.cap = cap;
+    const GenView G = gen_view(nblob);
+    const int64_t lane_bytes = geo == 0 ? 512 : 64;
+    const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
+    std::vector<uint32_t> stack((size_t)n_lanes * frames * 4 + 4, 0xEEEEEEEEu);
+    std::vector<uint8_t> path((size_t)n_lanes * path_cap + 4, 0xEE);
+    GenArgs ga{stack.data(), path.data(), frames, path_cap};
+    std::vector<uint64_t> cnt(n_lanes), base(n_lanes);
+    for (int64_t lane = n_lanes - 1; lane >= 0; --lane) { DirectLane L; gen_lane<1>(a, G, ga, lane, lane_bytes, 0, L, status); cnt[lane] = L.count; }
+    *status_out = status;
+    if (status & (kStDiverge | kStEditOverflow)) return 0;
+    uint64_t run = 0;
+    for (int64_t lane = 0; lane < n_lanes; ++lane) { base[lane] = run; run += cnt[lane]; }
+    *m = (size_t)run;
+    if (run > cap) { *status_out = status | kStCapacity; return 0; }
+    for (int64_t lane = 0; lane < n_lanes; ++lane) {
+        DirectLane L;
+        gen_lane<2>(a, G, ga, lane, lane_bytes, base[lane], L, status);
+        if (L.count != cnt[lane]) status |= 1u << 30;                     // count and emit passes disagree
+    }
+    *status_out = status;
+    return 0;
+}
+
 int shim_rev_sweep(const uint8_t* rblob, int geo, const uint8_t* in, size_t n, int in_mis, uint8_t* sym_out) {
     if (n == 0) return 0;
     std::vector<uint8_t> ibuf(n + 64, 0xAA);

@@ -13,7 +13,7 @@ ST_NUL, ST_DIVERGE, ST_CAPACITY, ST_LONGLINE, ST_NEEDSCRATCH, ST_OVERFLOW, ST_MI
 
 
 def build():
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("scan_block.hpp", "scan_core.hpp", "device_blob.hpp", "splice_block.hpp", "patch_block.hpp")]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("scan_block.hpp", "scan_core.hpp", "device_blob.hpp", "splice_block.hpp", "patch_block.hpp", "gen_block.hpp")]
     if os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(d) for d in deps):
         return SO
     os.makedirs(os.path.dirname(SO), exist_ok=True)
@@ -36,6 +36,8 @@ def lib():
                                        ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
                                        ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_uint32)]
         L.shim_rev_sweep.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_char_p]
+        L.shim_generate.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p,
+                                    ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_uint32)]
         _lib = L
     return _lib
 
@@ -190,3 +192,28 @@ def generate_like_runtime(prog, data, geo=1, in_mis=0):
     rblob, _ = prog.export_guided_tables()
     assert rblob
     return prog.generate_with_symbols(data, rev_symbols(rblob, data, geo, in_mis))
+
+
+def generate_on_device_like_runtime(prog, data, geo=1, in_mis=0, frames=512, path_cap=2048):
+    """generator modes as the runtime runs them since round 4: backward sweep, then the enumeration kernel's lane body (count,
+    exclusive sum, emit) on the host; an input the kernel hands back (a path that never returns, a search deeper than a lane's
+    stack) goes to the library's host enumeration, as in runtime.cpp.  Returns (output, went_to_the_host)."""
+    rblob, _ = prog.export_guided_tables()
+    nblob = prog.export_gen_tables()
+    assert rblob and nblob
+    cap = 1 << 16
+    for _ in range(2):
+        out = ctypes.create_string_buffer(cap)
+        m = ctypes.c_size_t()
+        st = ctypes.c_uint32()
+        rc = lib().shim_generate(rblob, nblob, geo, data, len(data), in_mis, out, cap, frames, path_cap, ctypes.byref(m), ctypes.byref(st))
+        if rc:
+            raise RuntimeError("shim rc %d" % rc)
+        assert not st.value & ST_MISMATCH, "count and emit passes disagree"
+        if st.value & (ST_DIVERGE | ST_EDIT_OVERFLOW):
+            return generate_like_runtime(prog, data, geo, in_mis), True
+        if st.value & ST_CAPACITY:
+            cap = m.value + 64
+            continue
+        return out.raw[:m.value], False
+    raise RuntimeError("capacity")

@@ -73,6 +73,35 @@ def test_generator_mode_enumeration_with_the_backward_sweep_on_the_host():
     assert n >= 200 and n_fail >= 10
 
 
+def test_generator_mode_enumeration_kernel_body_on_the_host():
+    """round 4: the enumeration is a kernel (gen_block.hpp): its lane body — count, exclusive sum, emit — on the host behind
+    the backward sweep, against every vector of the compiled reference; with a stack of a few frames too, so that the route
+    back to the host enumeration (a search deeper than a lane's stack, a path that never returns) runs as well"""
+    n = n_host = n_dev = 0
+    for pat, flags, name, data, exp, printed in golden_lib.all_cases():
+        p = trre_amd.Program(pat, "nft", mode=mode_of(flags))
+        for geo, mis, frames, cap in ((1, 0, 512, 2048), (0, 5, 512, 2048), (1, 3, 6, 24)):
+            if exp is None:
+                if printed is None:
+                    continue
+                with pytest.raises(trre_amd.TrreError) as e:
+                    shim_lib.generate_on_device_like_runtime(p, data, geo, mis, frames, cap)
+                assert e.value.code == trre_amd.api.E_DIVERGES and e.value.partial == printed, (pat, flags, name)
+            else:
+                out, host = shim_lib.generate_on_device_like_runtime(p, data, geo, mis, frames, cap)
+                assert out == exp, (pat, flags, name, geo, frames)
+                n_host += host
+                n_dev += not host
+        n += 1
+    assert n >= 200 and n_dev > 350 and n_host >= 3, (n, n_dev, n_host)
+    rng = random.Random(19)
+    data = corpus.word_soup(rng, 40000, max_len=40) + b"nul\0cat\n" + b"cat cat"
+    for pat, flags in [("(cat:dog|cat:cow|ca:C)", "-a"), ("a*", "-a"), (":=", "-a"), ("(cat:dog|cat:cow|.)*", "-ma"), ("[a-z ]*|.*", "-ma")]:
+        p = trre_amd.Program(pat, "nft", mode=mode_of(flags))
+        out, host = shim_lib.generate_on_device_like_runtime(p, data, 0)
+        assert out == oracle_run(pat, flags, data) and not host, (pat, flags)
+
+
 def test_generator_mode_on_larger_inputs_against_the_oracle():
     rng = random.Random(19)
     data = corpus.word_soup(rng, 40000, max_len=40) + b"nul\0cat\n" + b"cat cat"

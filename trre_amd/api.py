@@ -161,6 +161,13 @@ class Program:
             blobs.append(buf.raw[:n])
         return tuple(blobs)
 
+    def export_gen_tables(self):
+        """generator modes: the tables of the device enumeration (gen_block.hpp), or b"" """
+        n = lib().trre_export_guided_tables(self._h, 2, None, 0)
+        buf = ctypes.create_string_buffer(max(n, 1))
+        lib().trre_export_guided_tables(self._h, 2, buf, n)
+        return buf.raw[:n]
+
     def allowed_kernels(self):
         ok = []
         for fam in (KERNEL_BYTEMAP, KERNEL_TILE_LP, KERNEL_TILE_GEN, KERNEL_STREAM_LP, KERNEL_STREAM_GEN, KERNEL_GUIDED_LP,

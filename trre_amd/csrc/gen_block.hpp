@@ -1,0 +1,160 @@
+// gen_block.hpp — generator mode (`trre -a`, `trre -ma`) on the device: the enumeration of ALL accepting paths
+// (infer_backtrack with all = 1, trre_nft.c:593-657: FINAL prints and the search goes on, :640-641, :647-648; the line
+// loops trre_nft.c:775-797).
+//
+// Round 3 ran the viability filter on the device (k_rev_sweep over the tables of generate.cpp) and the enumeration on
+// host threads.  Here the enumeration is a kernel too: a lane owns the records that start in its sub-range and walks, for
+// every attempt, the follow lists depth first with an explicit stack in its own stretch of scratch memory, entering a node
+// only if the symbol of the byte says some path from it prints (or never returns): the work is proportional to what is
+// printed.  Two passes like every general family — count, exclusive sum, emit — because the amount of output is unbounded
+// in the input.  What the kernel does not do itself: a path that runs into an epsilon cycle (the reference exits 1 with what
+// it had printed), a line whose search goes deeper than the lane's stack or builds a longer output than its path buffer —
+// it says so (kStDiverge / kStEditOverflow) and the runtime hands that chunk of the input to the host enumeration of
+// generate.cpp, which is also what the tests check the kernel against.
+//
+// The lane body is TRRE_HD: tests/cpu_shim.cpp runs it lane by lane on the host.
+#pragma once
+#include "scan_block.hpp"
+
+namespace trre {
+
+constexpr uint32_t kMagicGen = 0x31475254u;   // "TRG1"
+struct GenBlobHeader {
+    uint32_t magic, n_nodes, n_rev, words, match_mode, n_follow;
+    uint32_t off_bytes;      // u32[n_nodes][8]: the bytes a node reads
+    uint32_t off_echo;       // u8[n_nodes]: copy mode — reading a byte also produces it
+    uint32_t off_foff;       // u32[n_nodes + 2]: follow lists; [n_nodes] = the start's
+    uint32_t off_follow;     // u32[n_follow][3]: {target, offset of the bytes produced on the way, their number | mute << 16}
+    uint32_t off_pool, pool_bytes;
+    uint32_t off_viable;     // u64[n_rev][words]: nodes worth entering at a byte with that symbol
+    uint32_t total_bytes;
+};
+static_assert(sizeof(GenBlobHeader) == 56, "header layout");
+
+struct GenView {
+    const uint32_t* bytes;
+    const uint8_t* echo;
+    const uint32_t* foff;
+    const uint32_t* follow;
+    const uint8_t* pool;
+    const uint64_t* viable;
+    uint32_t n_nodes, words, match;
+};
+TRRE_HD GenView gen_view(const uint8_t* blob) {
+    const GenBlobHeader& h = *reinterpret_cast<const GenBlobHeader*>(blob);
+    GenView G;
+    G.bytes = reinterpret_cast<const uint32_t*>(blob + h.off_bytes);
+    G.echo = blob + h.off_echo;
+    G.foff = reinterpret_cast<const uint32_t*>(blob + h.off_foff);
+    G.follow = reinterpret_cast<const uint32_t*>(blob + h.off_follow);
+    G.pool = blob + h.off_pool;
+    G.viable = reinterpret_cast<const uint64_t*>(blob + h.off_viable);
+    G.n_nodes = h.n_nodes; G.words = h.words; G.match = h.match_mode;
+    return G;
+}
+
+// a lane's scratch: its stack of frames {list, next entry, input position, output length | muted << 31} and the output of
+// the path it is on
+struct GenArgs {
+    uint32_t* stack;         // [n_lanes][frames][4]
+    uint8_t* path;           // [n_lanes][path_cap]
+    uint32_t frames, path_cap;
+};
+constexpr uint32_t kGenTgtFinal = 0xFFFFFFFFu, kGenTgtDiverge = 0xFFFFFFFEu;    // (front.hpp: kNodeFinal, kNodeDiverge)
+
+// kMode 1: count; 2: emit at a.out + out_base
+template <int kMode>
+TRRE_HD void gen_lane(const ScanArgs& a, const GenView& G, const GenArgs& ga, int64_t lane, int64_t lane_bytes, uint64_t out_base, DirectLane& L,
+                      uint32_t& status) {
+    const int64_t lo = lane * lane_bytes;
+    int64_t hi = lo + lane_bytes;
+    if (hi > a.vend) hi = a.vend;
+    uint64_t cnt = 0;
+    L.count = 0;
+    if (lo >= hi) return;
+    uint32_t* const stack = ga.stack + (size_t)lane * ga.frames * 4;
+    uint8_t* const path = ga.path + (size_t)lane * ga.path_cap;
+    uint8_t* op = kMode == 2 ? a.out + out_base : nullptr;
+    auto byte_at = [&](int64_t v) -> uint8_t { return v >= a.vend - 1 ? (uint8_t)'\n' : a.in_v0[v]; };   // the last byte ends its record (Q1)
+    auto put = [&](const uint8_t* src, uint32_t n) {
+        if (kMode == 2) { for (uint32_t i = 0; i < n; ++i) op[cnt + i] = src[i]; }
+        cnt += n;
+    };
+    auto put1 = [&](uint8_t c) {
+        if (kMode == 2) op[cnt] = c;
+        cnt += 1;
+    };
+    // all accepting paths of ONE attempt at position p of the record [rec, rec + len)
+    auto attempt = [&](int64_t rec, uint32_t len, uint32_t p) -> bool {
+        uint32_t sp = 1;
+        stack[0] = G.n_nodes; stack[1] = 0; stack[2] = p; stack[3] = 0;
+        while (sp) {
+            uint32_t* f = stack + 4 * (sp - 1);
+            const uint32_t list = f[0], idx = f[1], fi = f[2], fo = f[3];
+            const uint32_t beg = G.foff[list], end = G.foff[list + 1];
+            if (beg + idx >= end) { --sp; continue; }
+            f[1] = idx + 1;
+            const uint32_t* e = G.follow + 3 * (size_t)(beg + idx);
+            const uint32_t target = e[0], out_off = e[1], out_len = e[2] & 0xffffu, mute = e[2] >> 16;
+            const uint32_t olen = fo & 0x7fffffffu, muted = fo >> 31;
+            if (target == kGenTgtDiverge) { status |= kStDiverge; return false; }
+            if (target == kGenTgtFinal) {
+                if (G.match && fi != len) continue;                                 // trre_nft.c:636: only with the whole line consumed
+                put(path, olen);
+                if (!muted) put(G.pool + out_off, out_len);
+                if (G.match) put1((uint8_t)'\n');
+                continue;
+            }
+            if (fi >= len) continue;
+            const uint8_t c = a.in_v0[rec + fi];
+            if (!((G.bytes[8 * (size_t)target + (c >> 5)] >> (c & 31u)) & 1u)) continue;
+            const uint64_t v = G.viable[(size_t)a.sym_v0[rec + fi] * G.words + (target >> 6)];
+            if (!((v >> (target & 63u)) & 1u)) continue;                            // nothing printed, nothing entered below: skip
+            uint32_t nlen = olen, nmuted = muted;
+            if (!muted) {
+                if (olen + out_len + 1u > ga.path_cap) { status |= kStEditOverflow; return false; }
+                for (uint32_t i = 0; i < out_len; ++i) path[olen + i] = G.pool[out_off + i];
+                nlen = olen + out_len;
+                if (mute) nmuted = 1;
+                else if (G.echo[target]) path[nlen++] = c;
+            }
+            if (sp >= ga.frames) { status |= kStEditOverflow; return false; }
+            uint32_t* nf = stack + 4 * sp;
+            nf[0] = target; nf[1] = 0; nf[2] = fi + 1; nf[3] = nlen | nmuted << 31;
+            ++sp;
+        }
+        return true;
+    };
+    // the records that start in [lo, hi)
+    int64_t pos = lo;
+    if (!(lo == a.vbeg || (lo > a.vbeg && a.in_v0[lo - 1] == (uint8_t)'\n'))) pos = lo < a.vbeg ? a.vbeg : first_line_start_safe(a, lo, hi);
+    while (pos < hi) {
+        int64_t e = pos;
+        uint32_t len = 0xffffffffu;
+        for (;; ++e) {
+            const uint8_t c = byte_at(e);
+            if (c == (uint8_t)'\n') break;
+            if (c == 0 && len == 0xffffffffu) len = (uint32_t)(e - pos);            // cut at the first NUL (Q2)
+        }
+        if (len == 0xffffffffu) {
+            if (e - pos > 0x7ffffff0ll) { status |= kStEditOverflow; break; }
+            len = (uint32_t)(e - pos);
+        }
+        bool ok = true;
+        if (G.match) {
+            ok = attempt(pos, len, 0);                                              // trre_nft.c:791-797
+        } else {
+            for (uint32_t p = 0; p < len && ok; ++p) {                              // trre_nft.c:780-786 with all = 1: no attempt returns > 0
+                ok = attempt(pos, len, p);
+                if (ok) put1(a.in_v0[pos + p]);
+            }
+            if (ok) ok = attempt(pos, len, len);                                    // the empty tail (trre_nft.c:788)
+            if (ok) put1((uint8_t)'\n');
+        }
+        if (!ok) break;                                                             // (the chunk goes to the host enumeration)
+        pos = e + 1;
+    }
+    L.count = cnt;
+}
+
+}  // namespace trre

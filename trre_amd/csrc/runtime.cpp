@@ -24,6 +24,7 @@
 #include "patch_block.hpp"
 #include "scan_block.hpp"
 #include "splice_block.hpp"
+#include "gen_block.hpp"
 
 namespace {
 
@@ -70,6 +71,8 @@ struct ScanCtx {
     uint32_t* d_redo = nullptr;       // window kernel redo list
     int64_t redo_lanes = 0;
     uint8_t* d_sym = nullptr;         // guided families: one symbol per input byte
+    uint8_t* d_gen_out = nullptr;     // generator modes: the enumeration's output before it goes down
+    size_t gen_out_cap = 0;
     size_t sym_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // record + patch form of the general families (patch_block.hpp): a 32-byte slot per 64 input bytes, overflow records,
@@ -98,6 +101,7 @@ struct DeviceState {
     uint8_t* d_sblob = nullptr;       // stream tables
     uint8_t* d_gblob = nullptr;       // guided families: forward tables (stream form) ...
     uint8_t* d_rblob = nullptr;       // ... and the backward DFA
+    uint8_t* d_nblob = nullptr;       // generator modes: the enumeration's tables
     ScanCtx ctx;
     struct HostSlot {
         uint8_t *pin_in = nullptr, *pin_out = nullptr, *d_in = nullptr, *d_out = nullptr;
@@ -131,6 +135,7 @@ struct trre_prog {
     std::vector<uint8_t> blob;
     std::vector<uint8_t> sblob;
     std::vector<uint8_t> gblob, rblob;
+    std::vector<uint8_t> nblob;       // generator modes: the enumeration's tables (gen_block.hpp)
     int mask_bytes = 0;
     bool profiling = false;
     std::atomic<float> last_ms{-1.f};
@@ -300,6 +305,54 @@ void serialize_rev(const trre::GuidedTables& g, std::vector<uint8_t>& b) {
     put(b, h.off_wide, wide.data(), wide.size());
 }
 
+// generator modes: follow lists (every epsilon path), the nodes' byte sets, the viability sets per symbol (gen_block.hpp)
+void serialize_gen(const trre::GenTables& g, std::vector<uint8_t>& b) {
+    using namespace trre;
+    const NftNodes& nd = g.nodes;
+    const uint32_t n_nodes = (uint32_t)nd.node.size();
+    std::vector<uint32_t> bytes((size_t)n_nodes * 8, 0), foff, follow;
+    std::vector<uint8_t> echo(n_nodes, 0), pool;
+    for (uint32_t t = 0; t < n_nodes; ++t) {
+        for (int c = 0; c < 256; ++c)
+            if (nd.node[t].reads((uint8_t)c)) bytes[(size_t)t * 8 + (c >> 5)] |= 1u << (c & 31);
+        echo[t] = nd.node[t].echo ? 1 : 0;
+    }
+    for (size_t l = 0; l < nd.follow.size(); ++l) {
+        foff.push_back((uint32_t)(follow.size() / 3));
+        for (const NodeFollow& e : nd.follow[l]) {
+            if (e.out.size() > 0xffff) throw Error(kErrTooBig, "error: an output of more than 64 KiB on one epsilon path (generator mode)");
+            follow.push_back(e.target);
+            follow.push_back((uint32_t)pool.size());
+            follow.push_back((uint32_t)e.out.size() | (e.mute ? 1u << 16 : 0u));
+            pool.insert(pool.end(), e.out.begin(), e.out.end());
+        }
+    }
+    foff.push_back((uint32_t)(follow.size() / 3));
+    GenBlobHeader h{};
+    h.magic = kMagicGen;
+    h.n_nodes = n_nodes;
+    h.n_rev = g.n_rev;
+    h.words = g.viable_words;
+    h.match_mode = g.match_mode ? 1u : 0u;
+    h.n_follow = (uint32_t)(follow.size() / 3);
+    size_t off = align_up(sizeof h, 16);
+    h.off_bytes = (uint32_t)off; off = align_up(off + bytes.size() * 4, 16);
+    h.off_echo = (uint32_t)off; off = align_up(off + echo.size(), 16);
+    h.off_foff = (uint32_t)off; off = align_up(off + foff.size() * 4, 16);
+    h.off_follow = (uint32_t)off; off = align_up(off + follow.size() * 4, 16);
+    h.off_pool = (uint32_t)off; h.pool_bytes = (uint32_t)pool.size(); off = align_up(off + pool.size() + 8, 16);
+    h.off_viable = (uint32_t)off; off = align_up(off + g.viable.size() * 8, 16);
+    h.total_bytes = (uint32_t)off;
+    b.assign(off, 0);
+    put(b, 0, &h, 1);
+    put(b, h.off_bytes, bytes.data(), bytes.size());
+    put(b, h.off_echo, echo.data(), echo.size());
+    put(b, h.off_foff, foff.data(), foff.size());
+    put(b, h.off_follow, follow.data(), follow.size());
+    put(b, h.off_pool, pool.data(), pool.size());
+    put(b, h.off_viable, g.viable.data(), g.viable.size());
+}
+
 bool is_generate(int mode) { return mode == TRRE_MODE_SCAN_ALL || mode == TRRE_MODE_MATCH_ALL; }
 bool is_stream(int fam) { return fam == TRRE_KERNEL_STREAM_LP || fam == TRRE_KERNEL_STREAM_GEN; }
 bool is_guided(int fam) { return fam == TRRE_KERNEL_GUIDED_LP || fam == TRRE_KERNEL_GUIDED_GEN; }
@@ -379,6 +432,7 @@ void ctx_free(ScanCtx& c) {
     (void)hipFree(c.d_scratch);
     (void)hipFree(c.d_redo);
     (void)hipFree(c.d_sym);
+    (void)hipFree(c.d_gen_out);
     (void)hipFree(c.d_slots);
     (void)hipFree(c.d_ovf);
     (void)hipFree(c.d_ovf_count);
@@ -408,6 +462,7 @@ int device_state(trre_prog* p, int dev, DeviceState** out) {
         if (!rc) rc = upload(p->sblob, &st->d_sblob);
         if (!rc) rc = upload(p->gblob, &st->d_gblob);
         if (!rc) rc = upload(p->rblob, &st->d_rblob);
+        if (!rc) rc = upload(p->nblob, &st->d_nblob);
         if (!rc) rc = ctx_init(st->ctx);
         if (rc) return rc;
         it = p->dev.emplace(dev, std::move(st)).first;
@@ -916,6 +971,7 @@ int compile_impl(const std::string& pattern, int engine, trre_prog** out, int mo
                 throw Error(kErrUnsupported, "error: the viability automaton of this pattern has more than 256 states (generator mode)");
             p->nft_nodes = (uint32_t)p->gen.nodes.node.size();
             serialize_rev_table(p->gen.n_rev, p->gen.n_cls, 8, p->gen.cls, p->gen.rev, p->rblob);
+            serialize_gen(p->gen, p->nblob);
         } else if (mode == TRRE_MODE_MATCH) {
             // trre -m: one attempt per line, accepted at its end only — the guided tables in match form
             const NftNodes nodes = build_nft_nodes(nft, true);
@@ -1005,6 +1061,7 @@ void trre_free(trre_prog* p) {
         (void)hipFree(st.d_sblob);
         (void)hipFree(st.d_gblob);
         (void)hipFree(st.d_rblob);
+        (void)hipFree(st.d_nblob);
         ctx_free(st.ctx);
         for (auto& hs : st.slot) {
             if (hs.pin_in) (void)hipHostFree(hs.pin_in);
@@ -1069,7 +1126,7 @@ size_t trre_export_stream_tables(const trre_prog* p, void* buf, size_t cap) {
 
 size_t trre_export_guided_tables(const trre_prog* p, int which, void* buf, size_t cap) {
     if (!p) return 0;
-    const std::vector<uint8_t>& b = which == 0 ? p->rblob : p->gblob;
+    const std::vector<uint8_t>& b = which == 0 ? p->rblob : (which == 2 ? p->nblob : p->gblob);   // (2: generator modes, the enumeration's tables)
     if (buf && cap) std::memcpy(buf, b.data(), cap < b.size() ? cap : b.size());
     return b.size();
 }
@@ -1102,6 +1159,8 @@ int trre_scan_finish(trre_prog* p, size_t* out_len) {
 namespace {
 int slot_reserve(DeviceState::HostSlot& hs, bool input, size_t bytes);
 constexpr size_t kGenChunk = (size_t)16 << 20;
+constexpr int64_t kGenLaneBytes = 512;          // generator modes on the device: a lane per 512 bytes of input (the records that start there),
+constexpr uint32_t kGenFrames = 512, kGenPathCap = 2048;   // a stack of 512 frames and 2 KiB of path output each (deeper / longer: the host enumeration)
 
 // Generator modes on one device, host buffers: chunks cut at record ends go up, the backward kernel leaves one viability
 // symbol per byte (k_rev_sweep, the guided families' backward pass with the tables of generate.cpp), the symbols come
@@ -1136,12 +1195,72 @@ int generate_on(trre_prog* p, DeviceState* st, const uint8_t* in, size_t n, std:
         args.status = hs.ctx.d_status;
         launch_rev_sweep(args, (int)p->gen.n_rev * 256, 2048, hs.stream, false);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(hs.pin_out, hs.d_out, len, hipMemcpyDeviceToHost, hs.stream));
-        HIP_TRY(hipStreamSynchronize(hs.stream));
-        try {
-            if (!generate_buffer(p->gen, in + off, len, hs.pin_out, result, threads)) diverged = true;
-        } catch (const std::bad_alloc&) {
-            return fail(TRRE_E_TOO_BIG, "error: out of host memory for the outputs of generator mode");
+        // The enumeration on the device (gen_block.hpp; TRRE_GEN_HOST=1: on host threads, as in round 3): count, exclusive
+        // sum, emit.  A chunk on which a path never returns, a search goes deeper than a lane's stack or the sizes leave 32 bits
+        // goes to the host enumeration below, which also knows what the reference had printed when it gave up.
+        static const bool gen_host = getenv("TRRE_GEN_HOST") != nullptr;
+        bool done = false;
+        if (!gen_host) {
+            const int64_t n_lanes_raw = ((int64_t)len + kGenLaneBytes - 1) / kGenLaneBytes;
+            const int64_t n_chunks = (n_lanes_raw + 255) / 256, n_lanes = n_chunks * 256;
+            rc = ensure_workspace(&hs.ctx, n_chunks, 256);
+            const size_t need = (size_t)n_lanes * (kGenFrames * 16 + kGenPathCap);
+            if (!rc && hs.ctx.scratch_bytes < need) {
+                if (hs.ctx.d_scratch) (void)hipFree(hs.ctx.d_scratch);
+                hs.ctx.d_scratch = nullptr; hs.ctx.scratch_bytes = 0;
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&hs.ctx.d_scratch), need));
+                hs.ctx.scratch_bytes = need;
+            }
+            if (rc) return rc;
+            GenArgs ga{};
+            ga.stack = reinterpret_cast<uint32_t*>(hs.ctx.d_scratch);
+            ga.path = hs.ctx.d_scratch + (size_t)n_lanes * kGenFrames * 16;
+            ga.frames = kGenFrames;
+            ga.path_cap = kGenPathCap;
+            args.blob = st->d_nblob;
+            args.lane_counts = hs.ctx.d_lane_counts;
+            args.chunk_total = hs.ctx.d_chunk_total;
+            args.chunk_base = hs.ctx.d_chunk_base;
+            HIP_TRY(hipMemsetAsync(hs.ctx.d_status, 0, 24, hs.stream));
+            launch_gen(1, args, ga, kGenLaneBytes, n_chunks, hs.stream);
+            launch_chunk_scan(hs.ctx.d_chunk_total, hs.ctx.d_chunk_base, n_chunks, hs.stream);
+            uint64_t total = 0;
+            HIP_TRY(hipMemcpyAsync(hs.ctx.h_status, hs.ctx.d_status, 8, hipMemcpyDeviceToHost, hs.stream));
+            HIP_TRY(hipMemcpyAsync(&total, hs.ctx.d_chunk_base + n_chunks, 8, hipMemcpyDeviceToHost, hs.stream));
+            HIP_TRY(hipStreamSynchronize(hs.stream));
+            if (!(hs.ctx.h_status[0] & (kStDiverge | kStEditOverflow | kStCapacity))) {
+                // (the symbols sit in the slot's output buffer: the output gets a buffer of its own, kept by the context)
+                if (hs.ctx.gen_out_cap < total + 64) {
+                    if (hs.ctx.d_gen_out) (void)hipFree(hs.ctx.d_gen_out);
+                    hs.ctx.d_gen_out = nullptr; hs.ctx.gen_out_cap = 0;
+                    const size_t want = (size_t)total + (size_t)total / 4 + 4096;
+                    if (hipMalloc(reinterpret_cast<void**>(&hs.ctx.d_gen_out), want) != hipSuccess)
+                        return fail(TRRE_E_TOO_BIG, "error: out of device memory for the outputs of generator mode");
+                    hs.ctx.gen_out_cap = want;
+                }
+                args.out = hs.ctx.d_gen_out;
+                args.cap = hs.ctx.gen_out_cap;
+                launch_gen(2, args, ga, kGenLaneBytes, n_chunks, hs.stream);
+                HIP_TRY(hipGetLastError());
+                try {
+                    const size_t at = result.size();
+                    result.resize(at + (size_t)total);
+                    if (total) HIP_TRY(hipMemcpyAsync(result.data() + at, hs.ctx.d_gen_out, (size_t)total, hipMemcpyDeviceToHost, hs.stream));
+                } catch (const std::bad_alloc&) {
+                    return fail(TRRE_E_TOO_BIG, "error: out of host memory for the outputs of generator mode");
+                }
+                HIP_TRY(hipStreamSynchronize(hs.stream));
+                done = true;
+            }
+        }
+        if (!done) {
+            HIP_TRY(hipMemcpyAsync(hs.pin_out, hs.d_out, len, hipMemcpyDeviceToHost, hs.stream));
+            HIP_TRY(hipStreamSynchronize(hs.stream));
+            try {
+                if (!generate_buffer(p->gen, in + off, len, hs.pin_out, result, threads)) diverged = true;
+            } catch (const std::bad_alloc&) {
+                return fail(TRRE_E_TOO_BIG, "error: out of host memory for the outputs of generator mode");
+            }
         }
         off += len;
     }

@@ -23,6 +23,7 @@
 #include "patch_block.hpp"
 #include "scan_block.hpp"
 #include "splice_block.hpp"
+#include "gen_block.hpp"
 
 namespace trre {
 namespace {
@@ -897,6 +898,48 @@ __global__ __launch_bounds__(kThreads) void k_g16_splice(ScanArgs a, FbCopyArgs 
     const SpliceWork W{lane0 + gwave, kDirectThreads / kWave, kWave, sbase + group * kDirectThreads + gwave, kDirectThreads / kWave};
     fb_splice_ranges<true>(a, T, ca, W, lane_bytes, L);
 }
+// Generator modes (gen_block.hpp): count / emit passes of the enumeration, a lane per sub-range of lane_bytes.  Lanes are
+// numbered as everywhere (256 per chunk of the workspace).
+constexpr int kGenThreads = kDirectThreads;
+template <int kMode>
+__global__ __launch_bounds__(kGenThreads) void k_gen(ScanArgs a, GenArgs ga, int64_t lane_bytes) {
+    __shared__ uint64_t part[kGenThreads / kWave];
+    __shared__ uint32_t wpart[kGenThreads / kWave];
+    const int64_t lane = (int64_t)blockIdx.x * kGenThreads + threadIdx.x;
+    const GenView G = gen_view(a.blob);
+    uint64_t base = 0;
+    if (kMode == 2) {
+        const uint32_t mine = a.lane_counts[lane];
+        const uint32_t incl = wave_scan_incl(mine);
+        if ((threadIdx.x & (kWave - 1)) == kWave - 1) wpart[threadIdx.x / kWave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (int w = 0; w < (int)threadIdx.x / kWave; ++w) wbase += wpart[w];
+        base = a.chunk_base[blockIdx.x] + wbase + incl - mine;
+        if (a.chunk_base[blockIdx.x] + a.chunk_total[blockIdx.x] > a.cap) {
+            if (threadIdx.x == 0) atomicOr(a.status, kStCapacity);
+            return;
+        }
+    }
+    DirectLane L;
+    uint32_t st = 0;
+    gen_lane<kMode>(a, G, ga, lane, lane_bytes, base, L, st);
+    if (kMode == 1) {
+        if (L.count > 0xffffffffull) { st |= kStCapacity; L.count = 0xffffffffull; }
+        a.lane_counts[lane] = (uint32_t)L.count;
+        const uint64_t wsum = wave_sum(L.count);
+        if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = wsum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t t = 0;
+            for (int w = 0; w < kGenThreads / kWave; ++w) t += part[w];
+            a.chunk_total[blockIdx.x] = t;
+        }
+    }
+    st = wave_or(st);
+    if (st && (threadIdx.x & (kWave - 1)) == 0) atomicOr(a.status, st);
+}
+
 // ------------------------------------------------------------------------------------------
 // memoryless byte map: out[v] = map[in[v]], 16 bytes per lane per step
 constexpr int kMapThreads = 256;
@@ -1373,6 +1416,11 @@ void launch_g16_splice(const ScanArgs& a, const FbCopyArgs& ca, int g16_bytes, i
     const int lds = tab + kT * 8 + 64 * (kT / kDirectThreads) + (kT / kWave) * (int)kSpLdsPerWave;
     allow_big_lds<&k_g16_splice<kT>>();
     hipLaunchKernelGGL(k_g16_splice<kT>, dim3((unsigned)((n_chunks + 1) / 2)), dim3(kT), lds, static_cast<hipStream_t>(stream), a, ca, lane_bytes, n_chunks, tab);
+}
+void launch_gen(int which, const ScanArgs& a, const GenArgs& ga, int64_t lane_bytes, int64_t n_chunks, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (which == 1) hipLaunchKernelGGL(k_gen<1>, dim3((unsigned)n_chunks), dim3(kGenThreads), 0, s, a, ga, lane_bytes);
+    else hipLaunchKernelGGL(k_gen<2>, dim3((unsigned)n_chunks), dim3(kGenThreads), 0, s, a, ga, lane_bytes);
 }
 // the copy form's LDS fits
 bool fb_copy_fits(const void* hdr) {
