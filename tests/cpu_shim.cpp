@@ -259,8 +259,7 @@ void run_direct_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uin
 template <int kSym = 0>
 void run_g16_splice(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64_t& total_out, uint32_t ev_cap) {
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
-    StreamView T = direct_view(a);
-    T.p32 = nullptr;
+    StreamView T = direct_view(a);              // (with the pair form where the tables have one: the mark pass walks pairs)
     const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
     std::vector<uint32_t> hdr((size_t)n_lanes * 4, 0xEEEEEEEEu);
     std::vector<uint32_t> events((size_t)n_lanes * ev_cap + 4, 0xEEEEEEEEu);
@@ -284,6 +283,7 @@ void run_g16_splice(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uin
     std::memset(a.out, 0xEE, (size_t)run);
     SpliceTables ST;
     ST.g16 = T.g16;
+    ST.p32 = T.p32;
     ST.ent8 = T.ent;
     ST.pool = T.pool;
     alignas(16) static uint8_t lds[kSpLdsPerWave];
@@ -293,7 +293,7 @@ void run_g16_splice(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uin
             const int64_t left = n_lanes - (first + w);
             if (left <= 0) continue;
             const SpliceWork W{first + w, 4, (int)std::min<int64_t>(64, (left + 3) / 4), base.data() + first + w, 4};
-            fb_splice_ranges<true>(a, ST, ca, W, lane_bytes, SpliceLds{lds});
+            fb_splice_ranges<true, 1>(a, ST, ca, W, lane_bytes, SpliceLds{lds});
         }
     }
 }
@@ -472,7 +472,7 @@ void run_fb_copy(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64
                 const SpliceWork W{first + w, 4, (int)std::min<int64_t>(64, (left + 3) / 4), base.data() + first + w, 4};
                 SpliceTables ST;
                 ST.lit = CT.lit; ST.esc = CT.esc; ST.pool = CT.pool;
-                fb_splice_ranges<false>(a, ST, ca, W, lane_bytes, SpliceLds{lds});
+                fb_splice_ranges<false, 2>(a, ST, ca, W, lane_bytes, SpliceLds{lds});
             }
         }
         return;

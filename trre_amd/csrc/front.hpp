@@ -198,7 +198,8 @@ struct StreamTables {
     // 32 bytes: {next row offset (in the 16-byte form), meta, bytes 0..3, selector, bytes 4..7, selector, 0, 0}; meta [3:0] =
     // bytes the pair appends (0..8: literal bytes and the two input bytes, v_perm picks 4 / 5), [4] diverge, [5] a record
     // ends inside the pair, [6] overflow, [7] "slow" (more than 8 bytes or pooled text: walked as two single steps),
-    // [8] a NUL cut a line short.  The count and emit passes walk two input bytes per table step wherever no lane of the
+    // [8] a NUL cut a line short, [9] one of the two transitions is an edit for the mark pass of the splice form, [10] the pair begins in
+    // SKIP / DONE.  The count and emit passes walk two input bytes per table step wherever no lane of the
     // wave can finish (the passes are bound by instruction issue, §4.2 of DESIGN.md).
     bool p32_ok = false, p32_slow = false;
     std::vector<uint32_t> p32;              // [n_states][n_cls][n_cls][8]

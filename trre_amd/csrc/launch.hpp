@@ -50,7 +50,7 @@ void launch_fb_splice(const ScanArgs& a, const FbCopyArgs& ca, const void* hdr, 
 bool fb_splice_fits(const void* hdr);
 // the splice form of a SMALL table: launch_direct_kernel(4, ...) marks (its PatchArgs carry the event rows: slots, the lane headers: ovf,
 // and the events per row: ovf_cap), this splices
-void launch_g16_splice(const ScanArgs& a, const FbCopyArgs& ca, int g16_bytes, int64_t lane_bytes, int64_t n_chunks, void* stream);
+void launch_g16_splice(const ScanArgs& a, const FbCopyArgs& ca, int g16_bytes, int p32_bytes, int64_t lane_bytes, int64_t n_chunks, void* stream);
 // generator modes (gen_block.hpp): which 1 count, 2 emit; a.blob = the tables of serialize_gen (runtime.cpp), chunks of 256 lanes
 void launch_gen(int which, const ScanArgs& a, const GenArgs& ga, int64_t lane_bytes, int64_t n_chunks, void* stream);
 void launch_chunk_scan(const uint64_t* total, uint64_t* base, int64_t n_chunks, void* stream);

@@ -4,6 +4,7 @@
 // bytes on the host.
 #include <hip/hip_runtime_api.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
@@ -713,9 +714,9 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
             pa.slots = ca.events;
             pa.ovf = ca.lane_hdr;
             pa.ovf_cap = ca.ev_cap;
-            launch_direct_kernel(4, direct_ent_lds, args, lane_bytes, n_chunks, stream, (int)align_up(stt.g16.size() * 4, 16), sym_mode, g16_slow, &pa);
+            launch_direct_kernel(4, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, sym_mode, g16_slow, &pa);
             launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);
-            launch_g16_splice(args, ca, (int)(stt.g16.size() * 4), lane_bytes, n_chunks, stream);
+            launch_g16_splice(args, ca, (int)(stt.g16.size() * 4), (int)(stt.p32.size() * 4), lane_bytes, n_chunks, stream);
             pd.total_at = cx->d_chunk_base + n_chunks;
             pd.patched = true;
         } else
@@ -900,6 +901,9 @@ int finish(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
         }
         return again(was.family);
     }
+    static const bool trace_void = getenv("TRRE_TRACE_VOID") != nullptr;      // (why a launch was void, on stderr)
+    if (trace_void && was.patched && (status & (kStEditOverflow | kStNul | kStOverflow | kStDiverge)))
+        fprintf(stderr, "trre: a mark + splice launch of family %d was void: status 0x%x\n", was.family, status);
     if (was.patched && (status & (kStEditOverflow | kStNul))) {
         // record + patch: more pieces with more than 7 edits than there are overflow records (or an edit text of kilobytes); copy
         // form of a large table: more texts in a sub-range (or in 64 bytes of it) than its event list holds, or a NUL byte —

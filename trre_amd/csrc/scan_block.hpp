@@ -1571,7 +1571,7 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
         }
         row = g.x;
     };
-    auto dword_pairs = [&](const uint32_t w, const uint32_t sw) {
+    auto dword_pairs = [&](const uint32_t w, const uint32_t sw, const uint32_t rp) {
         uint32_t kk[4];
         if (kSym == 2) { kk[0] = sw & 15u; kk[1] = (sw >> 4) & 15u; kk[2] = (sw >> 8) & 15u; kk[3] = (sw >> 12) & 15u; }
         else if (kSym == 1) { kk[0] = sw & 0xffu; kk[1] = (sw >> 8) & 0xffu; kk[2] = (sw >> 16) & 0xffu; kk[3] = sw >> 24; }
@@ -1598,6 +1598,36 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
             }
             row = r;
             seen2 |= fl;
+            cnt += c;
+        } else if (kMode == 4) {
+            // the mark pass on pairs: an event per PAIR that holds an edit — [15:0] the position of its first byte, [31:16] 0x8000 | the
+            // pair entry's index (the splice pass reads what the two transitions emit from that entry).  A pair that begins in SKIP /
+            // DONE and holds an edit (a lane's first line start in the middle of it), or whose bytes do not fit its entry: two steps
+            const uint32_t row0 = row;
+            const uint32_t si0 = si;
+            uint32_t c = 0, fl = 0, r = row;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t poff = r * pair_mul + ((kk[2 * h] * n_cls + kk[2 * h + 1]) << 5);
+                const uint64_t g = *reinterpret_cast<const uint64_t*>(T.p32 + poff);
+                const uint32_t meta = (uint32_t)(g >> 32);
+                c += meta & 15u;
+                fl |= meta | ((meta & (meta >> 1) & 512u) << 2);                 // (bit 11: [9] and [10] in the same pair)
+                stage0[si] = (rp + 2u * (uint32_t)h) | (0x8000u | (poff >> 5)) << 16;
+                const uint32_t edit = (meta >> 9) & 1u;
+                si = si + edit < (uint32_t)kMarkStage - 1u ? si + edit : (uint32_t)kMarkStage - 1u;
+                r = (uint32_t)g;
+            }
+            if (TRRE_WAVE_ANY(fl & (128u | 2048u))) {
+                if (fl & (128u | 2048u)) {                                        // this dword again, byte by byte
+                    row = row0;
+                    si = si0;
+                    dword(std::false_type{}, w, sw, rp);
+                    return;
+                }
+            }
+            row = r;
+            seen2 |= fl & ~2048u;
             cnt += c;
         } else {
 #pragma unroll
@@ -1635,14 +1665,25 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
         const uint32_t y0 = kSym == 2 ? (y.x & 0xffffu) : y.x, y1 = kSym == 2 ? (y.x >> 16) : y.y,
                        y2 = kSym == 2 ? (y.y & 0xffffu) : y.z, y3 = kSym == 2 ? (y.y >> 16) : y.w;
         // (between two flushes at most 65 bytes may arrive: 8 transitions of up to 5 bytes, or 4 of up to 9 with slow entries)
-        if (!kEnd && T.p32 && kMode != 3 && kMode != 4) {
-            dword_pairs(b.x, y0);
+        if (kMode == 4) {
+            // (the mark pass: one copy of the step code, not four — the pair step carries the single step as its way out, and the
+            // unrolled form spilled registers)
+#pragma clang loop unroll(disable)
+            for (int d = 0; d < 4; ++d) {
+                const uint32_t w = d == 0 ? b.x : (d == 1 ? b.y : (d == 2 ? b.z : b.w));
+                const uint32_t yy = d == 0 ? y0 : (d == 1 ? y1 : (d == 2 ? y2 : y3));
+                if (!kEnd && T.p32) dword_pairs(w, yy, rp + 4u * (uint32_t)d);
+                else dword(end_tag, w, yy, rp + 4u * (uint32_t)d);
+            }
+        } else
+        if (!kEnd && T.p32 && kMode != 3) {
+            dword_pairs(b.x, y0, rp);
             if (kMode == 2 && (kHasSlow || T.p32_slow)) stage_flush<false>(S);
-            dword_pairs(b.y, y1);
+            dword_pairs(b.y, y1, rp + 4u);
             if (kMode == 2) stage_flush<false>(S);
-            dword_pairs(b.z, y2);
+            dword_pairs(b.z, y2, rp + 8u);
             if (kMode == 2 && (kHasSlow || T.p32_slow)) stage_flush<false>(S);
-            dword_pairs(b.w, y3);
+            dword_pairs(b.w, y3, rp + 12u);
         } else {
             dword(end_tag, b.x, y0, rp);
             if (kMode == 2 && kHasSlow) stage_flush<false>(S);
@@ -1734,7 +1775,7 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
     if (kMode == 3) rec_finish(*pa, R);
     if (kMode == 4) {
         if (n_ev > copy_event_cap(*ca) || far) status |= kStEditOverflow;
-        if (seen & 8u) status |= kStNul;
+        if ((seen & 8u) || (seen2 & 256u)) status |= kStNul;
         uint32_t* hdr = copy_lane_hdr(*ca, lane);
         hdr[0] = n_ev < copy_event_cap(*ca) ? n_ev : copy_event_cap(*ca);
         hdr[1] = b_rel;

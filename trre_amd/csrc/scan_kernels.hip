@@ -847,7 +847,7 @@ __global__ __launch_bounds__(kThreads) void k_fb_splice(ScanArgs a, FbCopyArgs c
     const SpliceLds L{carve + wave * kSpLdsPerWave};
     // (the chunk's waves take neighbouring sub-ranges at the same time: neighbouring lines of the output)
     const SpliceWork W{lane0 + gwave, kDirectThreads / kWave, kWave, sbase + group * kDirectThreads + gwave, kDirectThreads / kWave};
-    fb_splice_ranges<false>(a, T, ca, W, lane_bytes, L);
+    fb_splice_ranges<false, 2>(a, T, ca, W, lane_bytes, L);
 }
 // The same second pass for SMALL tables (the 16-byte entries; mark pass: k_stream_g16<4>): an edit names the entry of its
 // transition.  The entries are looked up in LDS when the table is at most 8 KiB, in memory otherwise (edits are sparse where
@@ -857,10 +857,14 @@ template <int kThreads>
 __global__ __launch_bounds__(kThreads) void k_g16_splice(ScanArgs a, FbCopyArgs ca, int64_t lane_bytes, int64_t n_chunks, int tab_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
+    const int g16_room = tab_bytes ? (int)((h.g16_bytes + 15u) & ~15u) : 0;     // (tab_bytes: the 16-byte entries and, behind them, the pair form)
     {
         const U128* e = reinterpret_cast<const U128*>(a.blob + h.off_g16);
         U128* d = reinterpret_cast<U128*>(smem);
-        for (int k = threadIdx.x; k < tab_bytes / 16; k += kThreads) d[k] = e[k];
+        for (int k = threadIdx.x; k < g16_room / 16; k += kThreads) d[k] = e[k];
+        e = reinterpret_cast<const U128*>(a.blob + h.off_p32);
+        d = reinterpret_cast<U128*>(smem + g16_room);
+        for (int k = threadIdx.x; k < (tab_bytes - g16_room) / 16; k += kThreads) d[k] = e[k];
     }
     constexpr int kGroups = kThreads / kDirectThreads;
     uint64_t* sbase = reinterpret_cast<uint64_t*>(smem + tab_bytes);
@@ -890,13 +894,14 @@ __global__ __launch_bounds__(kThreads) void k_g16_splice(ScanArgs a, FbCopyArgs 
     if (!live) return;
     SpliceTables T;
     T.g16 = tab_bytes ? smem : a.blob + h.off_g16;
+    T.p32 = tab_bytes ? smem + g16_room : a.blob + h.off_p32;
     T.ent8 = reinterpret_cast<const uint64_t*>(a.blob + h.off_ent);
     T.pool = a.blob + h.off_pool;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x / kWave);
     const int gwave = wave % (kDirectThreads / kWave);
     const SpliceLds L{carve + wave * kSpLdsPerWave};
     const SpliceWork W{lane0 + gwave, kDirectThreads / kWave, kWave, sbase + group * kDirectThreads + gwave, kDirectThreads / kWave};
-    fb_splice_ranges<true>(a, T, ca, W, lane_bytes, L);
+    fb_splice_ranges<true, 1>(a, T, ca, W, lane_bytes, L);
 }
 // Generator modes (gen_block.hpp): count / emit passes of the enumeration, a lane per sub-range of lane_bytes.  Lanes are
 // numbered as everywhere (256 per chunk of the workspace).
@@ -1410,8 +1415,9 @@ void launch_fb_splice(const ScanArgs& a, const FbCopyArgs& ca, const void* hdr, 
     }
 }
 bool fb_splice_fits(const void* hdr) { return fb_splice_lds(*static_cast<const StreamBlobHeader*>(hdr), 512) <= kLdsLimit; }
-void launch_g16_splice(const ScanArgs& a, const FbCopyArgs& ca, int g16_bytes, int64_t lane_bytes, int64_t n_chunks, void* stream) {
-    const int tab = g16_bytes <= kSpliceTabMax ? (g16_bytes + 15) / 16 * 16 : 0;
+void launch_g16_splice(const ScanArgs& a, const FbCopyArgs& ca, int g16_bytes, int p32_bytes, int64_t lane_bytes, int64_t n_chunks, void* stream) {
+    const int both = (g16_bytes + 15) / 16 * 16 + (p32_bytes + 15) / 16 * 16;
+    const int tab = both <= kSpliceTabMax ? both : 0;
     constexpr int kT = 512;
     const int lds = tab + kT * 8 + 64 * (kT / kDirectThreads) + (kT / kWave) * (int)kSpLdsPerWave;
     allow_big_lds<&k_g16_splice<kT>>();

@@ -105,6 +105,7 @@ struct SpliceTables {
     const uint8_t* pool = nullptr;      // ... and their texts; small tables: the pool of the 8-byte entries
     const uint8_t* g16 = nullptr;       // small tables: the 16-byte entries (LDS or global)
     const uint64_t* ent8 = nullptr;     // ... and the 8-byte ones (global; slow entries only)
+    const uint8_t* p32 = nullptr;       // ... and the pair form (an edit of the mark pass's pair steps names a pair entry: id bit 15)
 };
 
 struct SpliceLds {            // one wave's share of the workgroup's LDS (kSpLdsPerWave bytes, 16-byte aligned)
@@ -146,7 +147,9 @@ TRRE_HD SpliceSub splice_open(const ScanArgs& a, const FbCopyArgs& ca, const Spl
 }
 
 // a.dbg & 1: no global stores (timing experiments).
-template <bool kG16>
+// kBatches: edits per lane and window (2: 128 edits per window, the dictionary's density; 1: sparse edits — the window's
+// fixed costs, two prefix sums and a phase B per batch, are paid once)
+template <bool kG16, int kBatches = 2>
 TRRE_HD void fb_splice_ranges(const ScanArgs& a, const SpliceTables& T, const FbCopyArgs& ca, const SpliceWork& W, int64_t lane_bytes,
                               const SpliceLds& L) {
     uint8_t* const tin = L.tin();
@@ -156,6 +159,8 @@ TRRE_HD void fb_splice_ranges(const ScanArgs& a, const SpliceTables& T, const Fb
     uint8_t* const carry = L.carry();
     const uint32_t* tin32 = reinterpret_cast<const uint32_t*>(tin);
     const int64_t vlast = (a.vend - 1) & ~(int64_t)15;                    // the last readable aligned block
+    constexpr bool kB2 = kBatches == 2;
+    constexpr uint32_t kLimit = 64u * (uint32_t)kBatches;
 
     // ---- a window's input bytes and raw edits, requested one window ahead -------------------------------------------------
     SPV(uint32_t, praw0); SPV(uint32_t, praw1);                          // raw edits of the two batches (all ones: none)
@@ -166,7 +171,7 @@ TRRE_HD void fb_splice_ranges(const ScanArgs& a, const SpliceTables& T, const Fb
         SP_FOR {                                                                                                     \
             const uint32_t j0 = (from_ev) + SP_LANE, j1 = j0 + 64u;                                                  \
             SP(praw0) = j0 < (s).n_ev ? (s).evp[j0] : 0xffffffffu;                                                   \
-            SP(praw1) = j1 < (s).n_ev ? (s).evp[j1] : 0xffffffffu;                                                   \
+            SP(praw1) = kB2 && j1 < (s).n_ev ? (s).evp[j1] : 0xffffffffu;                                            \
             const int64_t v0 = rq0_ + 16 * (int64_t)SP_LANE, v1 = v0 + 1024, v2 = v0 + 2048;                         \
             SP(pin0) = *reinterpret_cast<const U128*>(a.in_v0 + (v0 < vlast ? v0 : vlast));                          \
             SP(pin1) = *reinterpret_cast<const U128*>(a.in_v0 + (v1 < vlast ? v1 : vlast));                          \
@@ -216,12 +221,18 @@ TRRE_HD void fb_splice_ranges(const ScanArgs& a, const SpliceTables& T, const Fb
         if (SP(raw) != 0xffffffffu) {                                                                             \
             const uint32_t id = SP(raw) >> 16, p = SP(raw) & 0xffffu;                                             \
             if (kG16) {                                   /* the transition's entry; it stands for the byte it read */ \
-                const U128 e = *reinterpret_cast<const U128*>(T.g16 + 16u * id);                                  \
                 int32_t ci = 16 + (int32_t)(lo + (int64_t)p - tin0);                                              \
-                ci = ci < 0 ? 0 : (ci > (int32_t)kSpIn + 15 ? (int32_t)kSpIn + 15 : ci);   /* (an edit beyond the window: looked at again there) */ \
+                ci = ci < 0 ? 0 : (ci > (int32_t)kSpIn + 14 ? (int32_t)kSpIn + 14 : ci);   /* (an edit beyond the window: looked at again there) */ \
                 const uint32_t c = tin[ci];                                                                       \
+                const U128 e = (id & 0x8000u) ? *reinterpret_cast<const U128*>(T.p32 + 32u * (id & 0x7fffu))      \
+                                              : *reinterpret_cast<const U128*>(T.g16 + 16u * id);                 \
                 SP(kb) = 1u; SP(fp) = p;                                                                          \
-                if (!(e.y & 128u)) {                                                                              \
+                if (id & 0x8000u) {                       /* a pair step: both transitions, two input bytes */    \
+                    const uint64_t e2 = *reinterpret_cast<const uint64_t*>(T.p32 + 32u * (id & 0x7fffu) + 16u);   \
+                    const uint32_t ws = c | (uint32_t)tin[ci + 1] << 8;                                           \
+                    SP(tlo) = perm_b32(ws, e.z, e.w); SP(thi) = perm_b32(ws, (uint32_t)e2, (uint32_t)(e2 >> 32)); \
+                    SP(n) = e.y & 15u; SP(kb) = 2u;                                                               \
+                } else if (!(e.y & 128u)) {                                                                       \
                     SP(tlo) = perm_b32(c, e.z, e.w); SP(n) = e.y & 7u;                                            \
                 } else {                                  /* more than 4 bytes, or a pooled text (rare) */        \
                     const uint64_t e8 = T.ent8[id];                                                               \
@@ -249,26 +260,29 @@ TRRE_HD void fb_splice_ranges(const ScanArgs& a, const SpliceTables& T, const Fb
         SP_WAVE_SYNC();                                                                  // (the staged input is looked at: kG16)
         SP_FOR {
             SP_DECODE(praw0, fp0, n0, kb0, tlo0, thi0, esc0, cum0)
-            SP_DECODE(praw1, fp1, n1, kb1, tlo1, thi1, esc1, cum1)
+            if (kB2) { SP_DECODE(praw1, fp1, n1, kb1, tlo1, thi1, esc1, cum1) }
+            else { SP(fp1) = 0xffffffffu; SP(n1) = 0; SP(kb1) = 0; SP(tlo1) = 0; SP(thi1) = 0; SP(esc1) = 0; SP(cum1) = 0; }
         }
 #undef SP_DECODE
         SP_SCAN_ADD(cum0);
-        SP_SCAN_ADD(cum1);
-        const int32_t grow0 = (int32_t)SP_BCAST(cum0, 63);
-        uint64_t ok0, ok1, in0, in1;
+        uint64_t ok0, ok1 = 0, in0, in1 = 0;
         SP_BALLOT(in0, SP(fp0) < w1);
-        SP_BALLOT(in1, SP(fp1) < w1);
         SP_BALLOT(ok0, SP(fp0) < w1 && SP(cum0) <= (int32_t)kSpGrow);
-        SP_BALLOT(ok1, SP(fp1) < w1 && grow0 + SP(cum1) <= (int32_t)kSpGrow);
-        uint32_t m = sp_ctz64(~ok0);                                       // the edits this window takes: the first m of the 128
-        if (m == 64u) m += sp_ctz64(~ok1);
+        if (kB2) {
+            SP_SCAN_ADD(cum1);
+            const int32_t grow0 = (int32_t)SP_BCAST(cum0, 63);
+            SP_BALLOT(in1, SP(fp1) < w1);
+            SP_BALLOT(ok1, SP(fp1) < w1 && grow0 + SP(cum1) <= (int32_t)kSpGrow);
+        }
+        uint32_t m = sp_ctz64(~ok0);                                       // the edits this window takes: the first m of the kLimit
+        if (kB2 && m == 64u) m += sp_ctz64(~ok1);
         const uint32_t m0 = m < 64u ? m : 64u, m1 = m - m0;               // ... of the first / second batch
-        if (m < kSpEdits) {
+        if (m < kLimit) {
             const bool next_in = m < 64u ? (in0 >> m) & 1u : (in1 >> (m - 64u)) & 1u;
             if (next_in) w1 = m < 64u ? (uint32_t)SP_BCAST(fp0, m) : (uint32_t)SP_BCAST(fp1, m - 64u);   // in the window but does not fit: end before it
         } else {
             // (there may be more edits in the window than a window takes: end where the last one taken ends — the next begins no earlier)
-            const uint32_t r_end = (uint32_t)SP_BCAST(fp1, 63) + (uint32_t)SP_BCAST(kb1, 63);
+            const uint32_t r_end = kB2 ? (uint32_t)SP_BCAST(fp1, 63) + (uint32_t)SP_BCAST(kb1, 63) : (uint32_t)SP_BCAST(fp0, 63) + (uint32_t)SP_BCAST(kb0, 63);
             if (r_end < w1) w1 = r_end;
         }
         const bool last = w1 >= end_rel;
@@ -286,12 +300,12 @@ TRRE_HD void fb_splice_ranges(const ScanArgs& a, const SpliceTables& T, const Fb
             SP(d1) = SP_LANE < m1 ? (int32_t)SP(n1) - (int32_t)SP(kb1) : 0; SP(S1) = SP(d1);
         }
         SP_SCAN_ADD(S0);
-        SP_SCAN_ADD(S1);
-        const int32_t sum0 = (int32_t)SP_BCAST(S0, 63), sum1 = (int32_t)SP_BCAST(S1, 63);
+        if (kB2) SP_SCAN_ADD(S1);
+        const int32_t sum0 = (int32_t)SP_BCAST(S0, 63), sum1 = kB2 ? (int32_t)SP_BCAST(S1, 63) : 0;
         const int32_t D0 = -(int32_t)(w0 + skip);
         const int32_t Dm = D0 + sum0 + sum1;
         uint32_t rm = w0 + skip;
-        if (m1) rm = (uint32_t)SP_BCAST(fp1, m1 - 1) + (uint32_t)SP_BCAST(kb1, m1 - 1);
+        if (kB2 && m1) rm = (uint32_t)SP_BCAST(fp1, m1 - 1) + (uint32_t)SP_BCAST(kb1, m1 - 1);
         else if (m0) rm = (uint32_t)SP_BCAST(fp0, m0 - 1) + (uint32_t)SP_BCAST(kb0, m0 - 1);
         const uint32_t top = w1 > rm ? w1 : rm;
         const uint32_t out_len = (uint32_t)((int32_t)top + Dm);
@@ -306,7 +320,7 @@ TRRE_HD void fb_splice_ranges(const ScanArgs& a, const SpliceTables& T, const Fb
             SP(C0) = cbase - Dj0;
             SP(C1) = cbase - Dj1;
             if (SP_LANE < m0) tab[SP_LANE] = SP(C0);
-            if (SP_LANE < m1) tab[64u + SP_LANE] = SP(C1);
+            if (kB2 && SP_LANE < m1) tab[64u + SP_LANE] = SP(C1);
             if (SP_LANE == (m & 63u)) tab[m] = cbase - Dm;
         }
         // the dword whose FIRST byte is at or behind the start of text j belongs to run j + 1 (or a later one) from there on
@@ -315,13 +329,15 @@ TRRE_HD void fb_splice_ranges(const ScanArgs& a, const SpliceTables& T, const Fb
             SP(q0) = SP_LANE < m0 ? (oa + (uint32_t)SP(P0) + 3u) >> 2 : 0xffffffffu;
             SP(q1) = SP_LANE < m1 ? (oa + (uint32_t)SP(P1) + 3u) >> 2 : 0xffffffffu;
         }
-        const uint32_t q1_first = (uint32_t)SP_BCAST(q1, 0);
+        const uint32_t q1_first = kB2 ? (uint32_t)SP_BCAST(q1, 0) : 0xffffffffu;
         SP_FROM_NEXT(qn0, q0, q1_first);
-        SP_FROM_NEXT(qn1, q1, 0xffffffffu);
         SP_FOR { if (SP_LANE < m0 && SP(qn0) != SP(q0)) mk[SP(q0)] = (uint8_t)(SP_LANE + 1u); }
         SP_WAVE_SYNC();
-        SP_FOR { if (SP_LANE < m1 && SP(qn1) != SP(q1)) mk[SP(q1)] = (uint8_t)(SP_LANE + 65u); }
-        SP_WAVE_SYNC();
+        if (kB2) {
+            SP_FROM_NEXT(qn1, q1, 0xffffffffu);
+            SP_FOR { if (SP_LANE < m1 && SP(qn1) != SP(q1)) mk[SP(q1)] = (uint8_t)(SP_LANE + 65u); }
+            SP_WAVE_SYNC();
+        }
         // ---- phase A: 16 output bytes per lane and round ---------------------------------------------------------------
         const uint32_t total = oa + out_len;
         const uint32_t rounds = (total + 1023u) >> 10;
@@ -361,12 +377,14 @@ TRRE_HD void fb_splice_ranges(const ScanArgs& a, const SpliceTables& T, const Fb
         SP_WAVE_SYNC();
         // ---- the line carried over from the window before, then phase B: the texts -------------------------------------
         SPV(int32_t, Pn0); SPV(int32_t, Pn1);
-        const int32_t P1_first = (int32_t)SP_BCAST(P1, 0);
+        const int32_t P1_first = kB2 ? (int32_t)SP_BCAST(P1, 0) : 0;
         SP_FROM_NEXT(Pn0, P0, P1_first);
-        SP_FROM_NEXT(Pn1, P1, 0);
-        uint64_t escmask0, escmask1;
+        uint64_t escmask0, escmask1 = 0;
         SP_BALLOT(escmask0, SP_LANE < m0 && SP(esc0) != 0u);
-        SP_BALLOT(escmask1, SP_LANE < m1 && SP(esc1) != 0u);
+        if (kB2) {
+            SP_FROM_NEXT(Pn1, P1, 0);
+            SP_BALLOT(escmask1, SP_LANE < m1 && SP(esc1) != 0u);
+        }
 #define SP_TEXT(mb, idx0, P, Pn, n, tlo, thi, esc, Cj, d)                                                              \
         if (SP_LANE < (mb)) {                                                                                         \
             uint8_t* t = tout + oa + (uint32_t)SP(P);                                                                 \
@@ -391,7 +409,7 @@ TRRE_HD void fb_splice_ranges(const ScanArgs& a, const SpliceTables& T, const Fb
             if (carried && SP_LANE < oa) tout[SP_LANE] = carry[SP_LANE];
             SP_TEXT(m0, 0u, P0, Pn0, n0, tlo0, thi0, esc0, C0, d0)
         }
-        if (m1) {
+        if (kB2 && m1) {
             SP_WAVE_SYNC();
             SP_FOR { SP_TEXT(m1, 64u, P1, Pn1, n1, tlo1, thi1, esc1, C1, d1) }
         }
@@ -407,7 +425,7 @@ TRRE_HD void fb_splice_ranges(const ScanArgs& a, const SpliceTables& T, const Fb
                     for (uint32_t i = 0; i < nt; ++i) t[i] = text[i];
                     if (kG16 && SP(thi0)) t[nt] = (uint8_t)SP(tlo0);
                 }
-                if (SP_LANE < m1 && SP(esc1)) {
+                if (kB2 && SP_LANE < m1 && SP(esc1)) {
                     const uint8_t* text = T.pool + (SP(esc1) - 1u);
                     uint8_t* t = tout + oa + (uint32_t)SP(P1);
                     const uint32_t nt = kG16 ? SP(n1) - SP(thi1) : SP(n1);

@@ -158,8 +158,14 @@ void build_pairs(StreamTables& t, const StreamPackInput& in) {
                 const bool slow = seq.size() > 8;
                 uint32_t* e = &v[((size_t)s * C * C + (size_t)k0 * C + k1) * 8];
                 e[0] = b.next * t.n_cls * 16u;
+                // [9] one of the two is an edit for the mark pass of the splice form (as bit 11 of the 16-byte entries: not the identity,
+                // not a transition of SKIP / DONE), [10] the pair begins in SKIP / DONE (with [9]: the mark pass walks it as two steps)
+                auto ident = [&](const StreamCell& x, uint32_t k) {
+                    return ((x.out.empty() && x.copy_c) || (in.col_kind[k] == kColNewline && !x.copy_c && x.out == "\n")) && !x.ovf && !x.diverge;
+                };
+                const bool edit = (!silent_a && !ident(a, k0)) || (!silent_b && !ident(b, k1));
                 e[1] = (slow ? 128u : (uint32_t)seq.size()) | ((a.diverge || b.diverge) ? 16u : 0u) | ((a.eol || b.eol) ? 32u : 0u) |
-                       ((a.ovf || b.ovf) ? 64u : 0u) |
+                       ((a.ovf || b.ovf) ? 64u : 0u) | (edit ? 512u : 0u) | (silent_a ? 1024u : 0u) |
                        (((in.col_kind[k0] == kColNul && !silent_a) || (in.col_kind[k1] == kColNul && !silent_b)) ? 256u : 0u);
                 if (slow) t.p32_slow = true;
                 for (int half = 0; half < 2; ++half) {
