@@ -428,7 +428,7 @@ void run_fb_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64_
 
 // The copy form of a large table (k_fb_mark / k_chunk_scan / k_fb_copy): the comb walk marks where the replacement texts go,
 // the copy pass walks no automaton.  ev_cap: ids per lane (small in the tests: the overflow route runs too).
-void run_fb_copy(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64_t& total_out, uint32_t ev_cap, bool splice = false) {
+void run_fb_copy(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64_t& total_out, uint32_t ev_cap, bool splice = false, bool mark8 = false) {
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
     const FbView T = fb_view(a);
     const uint16_t* lit_meta = reinterpret_cast<const uint16_t*>(a.blob + h.off_fb_lit_meta);
@@ -440,10 +440,25 @@ void run_fb_copy(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64
     ca.lane_hdr = hdr.data();
     ca.ev_cap = ev_cap;
     std::vector<uint64_t> cnt(n_lanes), base(n_lanes);
-    uint32_t stage[kMarkStage];
+    uint32_t stage[kMarkStageStride];
+    // (the mark form of the comb where the tables have it — what the runtime launches —, or mark8: the 8-byte comb)
+    Fb4View T4{};
+    std::vector<uint8_t> cls4(256);
+    if (h.fb4_slots && !mark8) {
+        for (int c = 0; c < 256; ++c) cls4[c] = (uint8_t)(a.blob[h.off_cls + c] << 2);
+        T4.cls4 = cls4.data();
+        T4.comb4 = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_comb4);
+        T4.dense4 = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_dense4);
+        T4.lit_meta = lit_meta;
+        T4.dense_base = reinterpret_cast<const uint16_t*>(a.blob + h.off_fb_dense_base);
+        T4.esc_slot = T.esc_slot; T4.esc = T.esc; T4.n_esc = T.n_esc;
+        T4.pad = h.fb_pad;
+        for (int i = 0; i < 3; ++i) T4.start[i] = h.fb_start4[i];
+    }
     for (int64_t lane = n_lanes - 1; lane >= 0; --lane) {      // any order
         DirectLane L;
-        fb_lane<3>(a, T, lane, lane_bytes, reinterpret_cast<uint8_t*>(stage), 0, L, status, nullptr, &ca);
+        if (T4.comb4) fb_mark4_lane(a, T4, lane, lane_bytes, reinterpret_cast<uint8_t*>(stage), L, status, ca);
+        else fb_lane<3>(a, T, lane, lane_bytes, reinterpret_cast<uint8_t*>(stage), 0, L, status, nullptr, &ca);
         cnt[lane] = L.count;
     }
     if (status & (kStEditOverflow | kStNul)) return;
@@ -668,6 +683,12 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
         const StreamBlobHeader& sh = *reinterpret_cast<const StreamBlobHeader*>(blob);
         if (!sh.fb_slots || !sh.off_fb_lit_meta) return -5;
         run_fb_copy(a, geo == 0 ? 2048 : 128, status, total, geo == 0 ? 256u : 64u, true);
+    }
+    else if (family == 29) {
+        // ... with the first pass on the 8-byte comb (round 3's mark pass; what tables without the mark form run)
+        const StreamBlobHeader& sh = *reinterpret_cast<const StreamBlobHeader*>(blob);
+        if (!sh.fb_slots || !sh.off_fb_lit_meta) return -5;
+        run_fb_copy(a, geo == 0 ? 2048 : 128, status, total, geo == 0 ? 256u : 64u, true, true);
     }
     else if (family == 28) {
         // stream general family by the splice form of its 16-byte entries (what the runtime launches by default)

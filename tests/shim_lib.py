@@ -52,7 +52,7 @@ def mask_bytes_of(blob, engine):
 def shim_scan(blob, engine, family, data, geo=1, in_mis=0, out_mis=0, scratch=True, cap=None):
     """Run one kernel family of the device code on the host.  Returns (output bytes, status)."""
     if cap is None:
-        cap = len(data) * 8 + 64 if family in (3, 5, 7, 9, 22, 23, 24, 25, 27, 28) else len(data)     # (20, 21: length-preserving)
+        cap = len(data) * 8 + 64 if family in (3, 5, 7, 9, 22, 23, 24, 25, 27, 28, 29) else len(data)     # (20, 21: length-preserving)
     out = ctypes.create_string_buffer(max(cap, 1))
     m = ctypes.c_size_t()
     st = ctypes.c_uint32()
@@ -69,6 +69,12 @@ def has_fallback_form(prog):
     """The stream tables carry the fallback form of a large table (StreamBlobHeader::fb_states)."""
     blob = prog.export_stream_tables()
     return bool(blob) and len(blob) >= 144 and struct.unpack_from("<36I", blob, 0)[20] != 0
+
+
+def has_mark_form(prog):
+    """... and the 32-bit mark form of the comb (StreamBlobHeader::fb4_slots)"""
+    blob = prog.export_stream_tables()
+    return has_copy_form(prog) and len(blob) >= 192 and struct.unpack_from("<48I", blob, 0)[36] != 0
 
 
 def has_copy_form(prog):
@@ -89,7 +95,9 @@ STREAM_G16_SPLICE = 28                               # stream general family, th
 GUIDED_LP_ALL = (GUIDED_LP, GUIDED_LP_RING, GUIDED_LP8)
 STREAM_LP_EMIT, STREAM_LP_EMIT8 = 20, 21            # stream LP family by the emit pass alone (no window form)
 STREAM_LPW_PAIR = 26                                 # the window kernel on the pair form of its entries (what the runtime launches when the tables have one)
+STREAM_FB_SPLICE8 = 29                               # ... with the mark pass on the 8-byte comb (tables without the mark form; round 3's first pass)
 STREAM_FB_SPLICE = 27                                # ... the second pass as the wave-cooperative splice (what the runtime launches by default)
+STREAM_FB_SPLICE8 = 29                               # ... with the mark pass on the 8-byte comb (tables without the mark form; round 3's first pass)
 STREAM_FB_SPLICE = 27                                # ... the second pass as the wave-cooperative splice (what the runtime launches by default)
 STREAM_FB_COPY = 25                                  # ... by its copy form: mark pass + copy pass (what the runtime launches by default)
 STREAM_FB, STREAM_FB_COUNT = 22, 23                  # stream general family on the fallback form of a large table: both passes /

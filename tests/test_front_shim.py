@@ -336,7 +336,7 @@ def test_compile_time_of_nested_optional_groups():
     assert r.returncode == 0
 
 
-COPY_FORMS = (shim_lib.STREAM_FB_SPLICE, shim_lib.STREAM_FB_COPY)
+COPY_FORMS = (shim_lib.STREAM_FB_SPLICE, shim_lib.STREAM_FB_SPLICE8, shim_lib.STREAM_FB_COPY)
 
 
 def test_copy_form_of_large_tables():

@@ -1,3 +1,6 @@
-run() { python tools/kbench.py --case "a:xyz;;dft;;printable;;auto" --case "(a|b)*c:x;;nft;;printable;;auto" --case "[a-z]+ing:X;;dft;;printable;;auto" --case " +: ;;nft;;printable;;auto" --steps 5 2>&1 | grep "pattern\|void"; }
-TRRE_TRACE_VOID=1 TRRE_G16_SPLICE=1 run
-run
+bash tools/prof_dict4.sh r04d 2>&1 | grep "k_fb\|GB/s" | cut -c1-160 | head -2
+cd /tmp && export TMPDIR=/tmp
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+TRRE_EMIT_DBG=8 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/raw/x -o s -- python tools/kbench.py --dict 1000 --engine dft --steps 5 > gpurun_out/raw/x.log 2>&1
+python tools/rocpd_summary.py gpurun_out/raw/x/s_results.db trre | cut -c1-150 | grep "k_fb"
+rm -rf gpurun_out/raw

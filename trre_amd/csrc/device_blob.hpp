@@ -54,8 +54,15 @@ struct StreamBlobHeader {
     uint32_t fb_start[3][2];                  // root, SKIP, DONE: {descriptor, next-state bits of an entry's hi}
     uint32_t off_fb_lit_meta;                 // u16[fb_lits]: the copy form (front.hpp); 0: the tables do not have it
     uint32_t lpw2_bytes;
+    // the mark form of the comb (front.hpp, StreamTables::fb_comb4): 0 slots when not available
+    uint32_t fb4_slots, off_fb_comb4;         // u32[fb4_slots]
+    uint32_t fb4_dense, off_fb_dense4;        // u32[fb4_dense][32]
+    uint32_t off_fb_dense_base;               // u16[fb4_dense]
+    uint32_t fb_pad;
+    uint32_t fb_start4[3];
+    uint32_t pad4[3];
 };
-static_assert(sizeof(StreamBlobHeader) == 144, "header layout");
+static_assert(sizeof(StreamBlobHeader) == 192, "header layout");
 
 // entry bits of the fallback form (front.hpp)
 constexpr uint32_t kFbCc = 1u << 17, kFbNl = 1u << 18, kFbEol = 1u << 19;      // (kFbCc and kFbNl both: an escape)

@@ -244,6 +244,21 @@ struct StreamTables {
     // input bytes through, late.  The builder checks this reading cell by cell (fb_copy_ok).
     bool fb_copy_ok = false;
     std::vector<uint16_t> fb_lit_meta;      // per literal: [7:0] length of the text, [15:8] input bytes it stands for
+    // The MARK FORM of the comb (round 4): what the copy form's first pass needs of an entry fits 32 bits, so its walk reads half
+    // the LDS bytes and spends half the instructions.  Same slots as fb_comb; an entry:
+    //   [13:0]  the next state's own base — for an owed-text state (no slots of its own) fb_pad + the index of its text: a stretch
+    //           of never-owned slots behind the comb, so that the walk needs no special case and the event can name the text
+    //   [20:14] the next state's fallback state, as an index into fb_dense4 (rows of 32 entries: the dense states)
+    //   [21]    the next state is owed      [22] escape (the slot's record is looked up)      [23] record end
+    //   [31:24] 4 x the class that owns the slot (124: nobody) — "mine" is one byte compare with the class the walk looks up
+    // A state travels as bits [21:0].  Only for tables whose owed states have no slots of their own (a prefix-free dictionary:
+    // no key waits for a longer one) and at most 128 dense states.
+    bool fb_mark4_ok = false;
+    uint32_t fb_pad = 0;                    // first slot of the stretch behind the comb
+    uint32_t fb_start4[3] = {};             // descriptors of root, SKIP, DONE
+    std::vector<uint32_t> fb_comb4;         // [fb_pad + literals + 32]
+    std::vector<uint32_t> fb_dense4;        // [dense states][32]
+    std::vector<uint16_t> fb_dense_base;    // per dense state: its base in the comb (escape records are keyed by slot)
 };
 StreamTables build_stream_dft(const Dft& dft, const StreamLimits& lim = StreamLimits());
 StreamTables build_stream_nft(const Nft& nft, const StreamLimits& lim = StreamLimits());

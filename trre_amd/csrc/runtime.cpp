@@ -234,7 +234,14 @@ void serialize_stream(const trre::StreamTables& t, std::vector<uint8_t>& b) {
         h.fb_escs = (uint32_t)t.fb_esc_slot.size(); h.off_fb_esc_slot = (uint32_t)off; off = align_up(off + t.fb_esc_slot.size() * 4, 16);
         h.off_fb_esc = (uint32_t)off; off = align_up(off + t.fb_esc.size() * 4, 16);
         h.off_fb_pool = (uint32_t)off; off = align_up(off + t.fb_pool.size(), 16);
-        if (t.fb_copy_ok) { h.off_fb_lit_meta = (uint32_t)off; off += t.fb_lit_meta.size() * 2; }
+        if (t.fb_copy_ok) { h.off_fb_lit_meta = (uint32_t)off; off = align_up(off + t.fb_lit_meta.size() * 2, 16); }
+        if (t.fb_mark4_ok) {
+            h.fb4_slots = (uint32_t)t.fb_comb4.size(); h.off_fb_comb4 = (uint32_t)off; off = align_up(off + t.fb_comb4.size() * 4, 16);
+            h.fb4_dense = (uint32_t)t.fb_dense_base.size(); h.off_fb_dense4 = (uint32_t)off; off = align_up(off + t.fb_dense4.size() * 4, 16);
+            h.off_fb_dense_base = (uint32_t)off; off = align_up(off + t.fb_dense_base.size() * 2, 16);
+            h.fb_pad = t.fb_pad;
+            std::memcpy(h.fb_start4, t.fb_start4, sizeof h.fb_start4);
+        }
         std::memcpy(h.fb_start, t.fb_start, sizeof h.fb_start);
     }
     off = align_up(off + 16, 16);
@@ -248,6 +255,11 @@ void serialize_stream(const trre::StreamTables& t, std::vector<uint8_t>& b) {
         put(b, h.off_fb_esc, t.fb_esc.data(), t.fb_esc.size());
         put(b, h.off_fb_pool, t.fb_pool.data(), t.fb_pool.size());
         if (t.fb_copy_ok) put(b, h.off_fb_lit_meta, t.fb_lit_meta.data(), t.fb_lit_meta.size());
+        if (t.fb_mark4_ok) {
+            put(b, h.off_fb_comb4, t.fb_comb4.data(), t.fb_comb4.size());
+            put(b, h.off_fb_dense4, t.fb_dense4.data(), t.fb_dense4.size());
+            put(b, h.off_fb_dense_base, t.fb_dense_base.data(), t.fb_dense_base.size());
+        }
     }
     put(b, h.off_cls, t.cls.data(), 256);
     put(b, h.off_ent, t.ent.data(), t.ent.size());

@@ -2026,6 +2026,191 @@ TRRE_HD void fb_lane(const ScanArgs& a, const FbView& T, int64_t lane, int64_t l
 }
 
 // =============================================================================================
+// The copy form's first pass on the MARK FORM of the comb (round 4; front.hpp: StreamTables::fb_comb4): the same walk and
+// the same product as fb_lane<3> — events, lane header, the lane's output size — from 32-bit entries.  A step reads the
+// state's own slot and its fallback row's (two 4-byte LDS reads, half the bytes of the 8-byte comb), "mine" is one byte
+// compare (the slot's class against the byte's), the event word is the state itself next to the position (an owed state's
+// base field names its text) and is stored at the stage's fill position whatever happens — the position moves on only
+// for an owed state: no branch in the step.  Escape entries are looked for once per dword (on the cfg 5 corpus one dword in
+// 10 000 holds one); a dword that met one is walked again the careful way.
+// =============================================================================================
+struct Fb4View {
+    const uint8_t* cls4;         // [256] 4 x class (LDS)
+    const uint32_t* comb4;       // the slots and the never-owned stretch behind them (LDS)
+    const uint32_t* dense4;      // [dense states][32] (LDS)
+    const uint16_t* lit_meta;    // per literal: length | input bytes it stands for << 8 (LDS)
+    const uint16_t* dense_base;  // per dense state: its base in the comb (global; escapes only)
+    const uint32_t* esc_slot;    // slots of the escape entries, ascending (global)
+    const uint32_t* esc;         // their records, 4 words each (global)
+    uint32_t n_esc, pad;
+    uint32_t start[3];           // root, SKIP, DONE
+};
+constexpr uint32_t kFb4Owed = 1u << 21, kFb4Esc = 1u << 22, kFb4Eol = 1u << 23, kFb4State = 0x3fffffu;
+template <class Dummy = void>
+TRRE_HD void fb_mark4_lane(const ScanArgs& a, const Fb4View& T, int64_t lane, int64_t lane_bytes, uint8_t* stage_mem, DirectLane& L, uint32_t& status,
+                           const FbCopyArgs& ca) {
+    const int64_t lo = lane * lane_bytes;
+    int64_t hi = lo + lane_bytes;
+    if (hi > a.vend) hi = a.vend;
+    const uint32_t rhi = (uint32_t)(hi > lo ? hi - lo : 0);
+    const uint32_t done_st = T.start[2];
+    int first;                                                         // 0 root, 1 SKIP, 2 DONE
+    if (lo >= hi) first = 2;
+    else if (lo < a.vbeg) first = 1;
+    else first = (lo == a.vbeg || a.in_v0[lo - 1] == (uint8_t)'\n') ? 0 : 1;
+    uint32_t st = T.start[first];
+    const int64_t vlast = (a.vend - 1) & ~(int64_t)15;
+    uint32_t* const stage0 = reinterpret_cast<uint32_t*>(stage_mem);
+    uint32_t* evp = copy_event_row(ca, lane);
+    uint32_t si = 0, escmask = 0, n_ev = 0, b_rel = 0, e_rel = 0, nul = 0, far = 0;
+    int64_t delta = 0;
+    if (first == 1) b_rel = (uint32_t)(first_line_start_safe(a, lo, hi) - lo);
+    const uint8_t* const comb_b = reinterpret_cast<const uint8_t*>(T.comb4);
+    const uint8_t* const dense_b = reinterpret_cast<const uint8_t*>(T.dense4);
+    // an escape entry's record, by the slot it sits in (the 8-byte comb's numbering)
+    auto esc_index = [&](uint32_t slot) -> uint32_t {
+        uint32_t l = 0, h = T.n_esc;
+        while (l + 1u < h) {
+            const uint32_t mid = (l + h) >> 1;
+            if (T.esc_slot[mid] <= slot) l = mid; else h = mid;
+        }
+        return l;
+    };
+    // one dword (4 input bytes) whose first byte lies rp bytes into the sub-range; kEnd: a lane may finish in it
+    auto dword = [&](auto end_tag, const uint32_t w, const uint32_t rp) {
+        constexpr bool kEnd = decltype(end_tag)::value;
+        const uint32_t kk[4] = {T.cls4[w & 0xffu], T.cls4[(w >> 8) & 0xffu], T.cls4[(w >> 16) & 0xffu], T.cls4[w >> 24]};
+        nul |= (w - 0x01010101u) & ~w & 0x80808080u;                              // a zero byte in these four
+        const uint32_t st0 = st, si0 = si, e_rel0 = e_rel, far0 = far;
+        uint32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t k4 = kk[j];
+            const uint32_t e1 = *reinterpret_cast<const uint32_t*>(comb_b + ((st & 0x3fffu) << 2) + k4);
+            const uint32_t e2 = *reinterpret_cast<const uint32_t*>(dense_b + (((st >> 14) & 0x7fu) << 7) + k4);
+            const uint32_t e = (e1 >> 24) == k4 ? e1 : e2;
+            const uint32_t ev = (st >> 21) & 1u;                                  // an owed state is left: its text goes here
+            stage0[si] = (rp + (uint32_t)j) | st << 16;
+            si = si + ev < (uint32_t)kMarkStage - 2u ? si + ev : (uint32_t)kMarkStage - 2u;   // (a full stage: the launch is void)
+            acc |= e;
+            if (kEnd) {
+                if (ev && rp + (uint32_t)j > 0xffffu) far = 1;
+                const bool fin = (e & kFb4Eol) && rp + (uint32_t)j + 1u >= rhi;
+                if (fin && (st & kFb4State) != done_st) e_rel = rp + (uint32_t)j + 1u;
+                st = fin ? done_st : e;
+            } else {
+                st = e;
+            }
+        }
+        if (TRRE_WAVE_ANY(acc & kFb4Esc)) {
+            if (acc & kFb4Esc) {                                                  // an escape entry in these four: again, looking
+                st = st0; si = si0; e_rel = e_rel0; far = far0;
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t k4 = kk[j];
+                    const uint32_t base = st & 0x3fffu, dn = (st >> 14) & 0x7fu;
+                    const uint32_t e1 = *reinterpret_cast<const uint32_t*>(comb_b + (base << 2) + k4);
+                    const uint32_t e2 = *reinterpret_cast<const uint32_t*>(dense_b + (dn << 7) + k4);
+                    const bool mine = (e1 >> 24) == k4;
+                    const uint32_t e = mine ? e1 : e2;
+                    uint32_t ev = (st >> 21) & 1u;
+                    uint32_t word = (rp + (uint32_t)j) | st << 16;
+                    if (e & kFb4Esc) {
+                        const uint32_t slot = (mine ? base : (uint32_t)T.dense_base[dn]) + (k4 >> 2);
+                        word = (rp + (uint32_t)j) | (0x8000u | esc_index(slot)) << 16;
+                        escmask |= 1u << si;
+                        ev = 1u;
+                    }
+                    if (ev) stage0[si] = word;
+                    si = si + ev < (uint32_t)kMarkStage - 2u ? si + ev : (uint32_t)kMarkStage - 2u;
+                    if (kEnd && ev && rp + (uint32_t)j > 0xffffu) far = 1;
+                    const bool fin = kEnd && (e & kFb4Eol) && rp + (uint32_t)j + 1u >= rhi;
+                    if (fin && (st & kFb4State) != done_st) e_rel = rp + (uint32_t)j + 1u;
+                    st = fin ? done_st : e;
+                }
+            }
+        }
+    };
+    auto block = [&](auto end_tag, const U128& b, const uint32_t rp) {
+#pragma clang loop unroll(disable)
+        for (int d = 0; d < 4; ++d) {
+            dword(end_tag, d == 0 ? b.x : (d == 1 ? b.y : (d == 2 ? b.z : b.w)), rp + 4u * (uint32_t)d);
+            TRRE_SCHED_FENCE();
+        }
+    };
+    U128 c0 = direct_load(a, lo), c1 = direct_load(a, lo + 16), c2 = direct_load(a, lo + 32), c3 = direct_load(a, lo + 48);
+    for (int64_t v = lo;; v += 64) {
+        if (!TRRE_WAVE_ANY((st & kFb4State) != done_st)) break;
+        const int64_t vn = v + 64;
+        const int64_t x0 = vn < vlast ? vn : vlast, x1 = vn + 16 < vlast ? vn + 16 : vlast,
+                      x2 = vn + 32 < vlast ? vn + 32 : vlast, x3 = vn + 48 < vlast ? vn + 48 : vlast;
+        U128 n0 = *reinterpret_cast<const U128*>(a.in_v0 + x0), n1 = *reinterpret_cast<const U128*>(a.in_v0 + x1),
+             n2 = *reinterpret_cast<const U128*>(a.in_v0 + x2), n3 = *reinterpret_cast<const U128*>(a.in_v0 + x3);
+        if (TRRE_WAVE_ANY(vn < a.vbeg || vn + 64 > a.vend - 1)) {
+            n0 = direct_load(a, vn); n1 = direct_load(a, vn + 16); n2 = direct_load(a, vn + 32); n3 = direct_load(a, vn + 48);
+        }
+        const uint32_t rp = (uint32_t)(v - lo);
+        if (TRRE_WAVE_ALL(rp + 64u < rhi)) {
+#pragma clang loop unroll(disable)
+            for (int q = 0; q < 4; ++q) {
+                U128 b;
+                b.x = q == 0 ? c0.x : (q == 1 ? c1.x : (q == 2 ? c2.x : c3.x));
+                b.y = q == 0 ? c0.y : (q == 1 ? c1.y : (q == 2 ? c2.y : c3.y));
+                b.z = q == 0 ? c0.z : (q == 1 ? c1.z : (q == 2 ? c2.z : c3.z));
+                b.w = q == 0 ? c0.w : (q == 1 ? c1.w : (q == 2 ? c2.w : c3.w));
+                block(std::false_type{}, b, rp + 16u * (uint32_t)q);
+            }
+        } else {
+#pragma clang loop unroll(disable)
+            for (int q = 0; q < 4; ++q) {
+                U128 b;
+                b.x = q == 0 ? c0.x : (q == 1 ? c1.x : (q == 2 ? c2.x : c3.x));
+                b.y = q == 0 ? c0.y : (q == 1 ? c1.y : (q == 2 ? c2.y : c3.y));
+                b.z = q == 0 ? c0.z : (q == 1 ? c1.z : (q == 2 ? c2.z : c3.z));
+                b.w = q == 0 ? c0.w : (q == 1 ? c1.w : (q == 2 ? c2.w : c3.w));
+                block(std::true_type{}, b, rp + 16u * (uint32_t)q);
+            }
+        }
+        // the piece's events, to the end of the lane's row: an owed state's base field becomes the index of its text
+        const uint32_t n_loc = si;
+        if (n_loc >= (uint32_t)kMarkStage - 2u) far = 1;
+        for (uint32_t k = 0; TRRE_WAVE_ANY(k < n_loc); ++k) {
+            if (k < n_loc) {
+                uint32_t ev = stage0[k];
+                if ((escmask >> k) & 1u) {
+                    const uint32_t* r = T.esc + 4u * ((ev >> 16) & 0x7fffu);
+                    delta += (int32_t)r[1] - (int32_t)(r[3] & 255u);
+                } else {
+                    const uint32_t id = ((ev >> 16) & 0x3fffu) - T.pad;
+                    const uint32_t m = T.lit_meta[id];
+                    delta += (int32_t)(m & 255u) - (int32_t)(m >> 8);
+                    ev = (ev & 0xffffu) | id << 16;
+                }
+                if (n_ev + k < ca.ev_cap) evp[k] = ev;
+            }
+        }
+        evp += n_loc;
+        n_ev += n_loc;
+        si = 0;
+        escmask = 0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    }
+    if (n_ev > ca.ev_cap || far) status |= kStEditOverflow;
+    if (nul) status |= kStNul;
+    uint32_t* hdr = ca.lane_hdr + (size_t)lane * 4;
+    hdr[0] = n_ev < ca.ev_cap ? n_ev : ca.ev_cap;
+    hdr[1] = b_rel;
+    hdr[2] = b_rel < rhi ? e_rel : b_rel;          // (no line starts in the sub-range: the lane has nothing to copy)
+    hdr[3] = 0;
+    uint64_t cnt = 0;
+    if (b_rel < rhi && e_rel > b_rel) {
+        const int64_t end = lo + (int64_t)e_rel < a.vend ? lo + (int64_t)e_rel : a.vend;
+        const int64_t bytes = end - (lo + (int64_t)b_rel) + delta;
+        cnt = bytes > 0 ? (uint64_t)bytes : 0;
+    }
+    L.count = cnt;
+}
+
+// =============================================================================================
 // The copy form of a large table (front.hpp, StreamTables::fb_copy_ok): the dictionary's second pass without a table
 // walk.  The emit pass over the 8-byte rows of such a table costs 70 instructions per byte: most of it the
 // walk itself.  But the automaton's output is the input with EDITS — a replacement text where a key stood — and the count

@@ -752,6 +752,61 @@ __global__ __launch_bounds__(kFbMarkThreads, 4) void k_fb_mark(ScanArgs a, FbCop
     st = wave_or(st);
     if (st && (threadIdx.x & (kWave - 1)) == 0) atomicOr(a.status, st);
 }
+// The same pass on the mark form of the comb (scan_block.hpp: fb_mark4_lane; front.hpp: fb_comb4): 32-bit entries.
+//   smem: 4 x cls[256] | comb4 | dense4 | literals' meta (u16) | event stages[1024 x 68] | 64 x groups
+__global__ __launch_bounds__(kFbMarkThreads, 4) void k_fb_mark4(ScanArgs a, FbCopyArgs ca, int64_t lane_bytes, int64_t n_chunks) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
+    const uint32_t comb_bytes = (h.fb4_slots * 4u + 15u) & ~15u, dense_bytes = h.fb4_dense * 128u, meta_bytes = (h.fb_lits * 2u + 15u) & ~15u;
+    for (int k = threadIdx.x; k < 256; k += kFbMarkThreads) smem[k] = (uint8_t)(a.blob[h.off_cls + k] << 2);
+    {
+        const U128* e = reinterpret_cast<const U128*>(a.blob + h.off_fb_comb4);
+        U128* d = reinterpret_cast<U128*>(smem + 256);
+        for (int k = threadIdx.x; k < (int)(comb_bytes / 16); k += kFbMarkThreads) d[k] = e[k];
+        e = reinterpret_cast<const U128*>(a.blob + h.off_fb_dense4);
+        d = reinterpret_cast<U128*>(smem + 256 + comb_bytes);
+        for (int k = threadIdx.x; k < (int)(dense_bytes / 16); k += kFbMarkThreads) d[k] = e[k];
+        const uint16_t* m = reinterpret_cast<const uint16_t*>(a.blob + h.off_fb_lit_meta);
+        uint16_t* dm = reinterpret_cast<uint16_t*>(smem + 256 + comb_bytes + dense_bytes);
+        for (int k = threadIdx.x; k < (int)h.fb_lits; k += kFbMarkThreads) dm[k] = m[k];
+    }
+    __syncthreads();
+    Fb4View T;
+    T.cls4 = smem;
+    T.comb4 = reinterpret_cast<const uint32_t*>(smem + 256);
+    T.dense4 = reinterpret_cast<const uint32_t*>(smem + 256 + comb_bytes);
+    T.lit_meta = reinterpret_cast<const uint16_t*>(smem + 256 + comb_bytes + dense_bytes);
+    T.dense_base = reinterpret_cast<const uint16_t*>(a.blob + h.off_fb_dense_base);
+    T.esc_slot = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_esc_slot);
+    T.esc = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_esc);
+    T.n_esc = h.fb_escs;
+    T.pad = h.fb_pad;
+    for (int i = 0; i < 3; ++i) T.start[i] = h.fb_start4[i];
+    uint8_t* top = smem + 256 + comb_bytes + dense_bytes + meta_bytes;
+    uint8_t* stage = top + threadIdx.x * (kMarkStageStride * 4);
+    uint8_t* tail = top + kFbMarkThreads * (kMarkStageStride * 4);
+    constexpr int kGroups = kFbMarkThreads / kDirectThreads;
+    const int group = threadIdx.x / kDirectThreads, gtid = threadIdx.x % kDirectThreads;
+    const int64_t chunk = (int64_t)blockIdx.x * kGroups + group;
+    const int64_t lane = chunk * kDirectThreads + gtid;
+    const bool live = chunk < n_chunks;
+    DirectLane L;
+    uint32_t st = 0;
+    if (live) fb_mark4_lane(a, T, lane, lane_bytes, stage, L, st, ca);
+    uint64_t* part = reinterpret_cast<uint64_t*>(tail + 64 * group);
+    if (L.count > 0xffffffffull) { st |= kStCapacity; L.count = 0xffffffffull; }
+    if (live) a.lane_counts[lane] = (uint32_t)L.count;
+    const uint64_t wsum = wave_sum(live ? L.count : 0ull);
+    if ((threadIdx.x & (kWave - 1)) == 0) part[gtid / kWave] = wsum;
+    __syncthreads();
+    if (gtid == 0 && live) {
+        uint64_t t = 0;
+        for (int w = 0; w < kDirectThreads / kWave; ++w) t += part[w];
+        a.chunk_total[chunk] = t;
+    }
+    st = wave_or(st);
+    if (st && (threadIdx.x & (kWave - 1)) == 0) atomicOr(a.status, st);
+}
 // Copy pass: no automaton.  kThreads / 256 chunks per workgroup: as many lanes per CU as the rings leave room for (they
 // share the literals).   smem: literals[fb_lits x 16] | rings[kThreads] | 64 x groups | posting tables
 template <int kThreads>
@@ -1373,6 +1428,15 @@ void launch_wide_fwd(int which, const ScanArgs& a, int64_t lane_bytes, int64_t n
 void launch_fb_mark(const ScanArgs& a, const FbCopyArgs& ca, const void* hdr, int64_t lane_bytes, int64_t n_chunks, void* stream) {
     const StreamBlobHeader& h = *static_cast<const StreamBlobHeader*>(hdr);
     constexpr int kG = kFbMarkThreads / kDirectThreads;
+    // the mark form of the comb where the tables have it (TRRE_NO_FB_MARK4=1: the 8-byte comb, for A/B runs)
+    static const bool no_mark4 = getenv("TRRE_NO_FB_MARK4") != nullptr;
+    if (h.fb4_slots && !no_mark4) {
+        const int lds4 = 256 + (int)((h.fb4_slots * 4u + 15u) & ~15u) + (int)h.fb4_dense * 128 + (int)((h.fb_lits * 2u + 15u) & ~15u) +
+                         kFbMarkThreads * kMarkStageStride * 4 + 64 * kG;
+        allow_big_lds<&k_fb_mark4>();
+        hipLaunchKernelGGL(k_fb_mark4, dim3((unsigned)((n_chunks + kG - 1) / kG)), dim3(kFbMarkThreads), lds4, static_cast<hipStream_t>(stream), a, ca, lane_bytes, n_chunks);
+        return;
+    }
     const int lds = 256 + (int)((h.fb_slots * 8u + 15u) & ~15u) + (int)((h.fb_lits * 2u + 15u) & ~15u) + kFbMarkThreads * kMarkStageStride * 4 + 64 * kG;
     allow_big_lds<&k_fb_mark>();
     hipLaunchKernelGGL(k_fb_mark, dim3((unsigned)((n_chunks + kG - 1) / kG)), dim3(kFbMarkThreads), lds, static_cast<hipStream_t>(stream), a, ca, lane_bytes, n_chunks);

@@ -458,8 +458,12 @@ private:
         in.bounded = bounded_;
         StreamTables t = pack_stream_tables(in);
         t.cls = cls;
-        build_fallback(t, in, cls);
-        return t;
+        // (first without "a literal in front of the root row" as a way to describe a state: such a state is owed AND has slots of
+        // its own, which the 32-bit mark form cannot express; if the comb does not come out with that form, as before)
+        StreamTables t2 = t;
+        build_fallback(t2, in, cls, false);
+        if (!t2.fb_mark4_ok) { t2 = t; build_fallback(t2, in, cls, true); }
+        return t2;
     }
 
     // Fallback form of a large table (front.hpp, StreamTables::fb_*), built from the rows as they were before
@@ -471,7 +475,7 @@ private:
         bool cc = false, nl = false, eol = false;
         int esc = -1;                     // index of an escape record: the cell's output spelled out
     };
-    void build_fallback(StreamTables& t, const StreamPackInput& in, const std::array<uint8_t, 256>& cls) {
+    void build_fallback(StreamTables& t, const StreamPackInput& in, const std::array<uint8_t, 256>& cls, bool allow_literal_plans) {
         const uint32_t n0 = first_copy_, C = t.n_cls;
         const bool dbg = getenv("TRRE_FB_DEBUG") != nullptr;
         if (t.g16_ok || bounded_ || C > 31 || n0 > 8000 || n0 < 64) return;   // small tables have the 16-byte form; 5-bit classes, 13-bit ids
@@ -600,7 +604,7 @@ private:
                 p.P = w.substr(0, w.size() - keep);
                 tries.push_back(std::move(p));
             }
-            for (uint32_t k = 0; k < C; ++k) {                                 // a literal in front of the root row: read it off any cell
+            for (uint32_t k = 0; k < C && allow_literal_plans; ++k) {          // a literal in front of the root row: read it off any cell
                 const Cell& x = rows[s][k];
                 const Cell& r = rows[0][k];
                 if (x.out.size() <= r.out.size() || x.out.size() - r.out.size() > 8) continue;
@@ -740,6 +744,36 @@ private:
             t.fb_lit_meta.resize(lit_text.size());
             for (size_t i = 0; i < lit_text.size(); ++i) t.fb_lit_meta[i] = (uint16_t)(lit_text[i].size() | lit_kb[i] << 8);
             t.fb_copy_ok = true;
+        }
+        // The mark form (front.hpp): 32-bit entries for the copy form's first pass
+        bool any_literal_state = false;
+        for (uint32_t s = 0; s < n0; ++s) any_literal_state = any_literal_state || (!plan[s].dense && plan[s].literal);
+        if (dbg) fprintf(stderr, "mark form: copy %d literal states %d dense %u slots %zu lits %zu\n", (int)t.fb_copy_ok, (int)any_literal_state, n_dense, n_slots, lit_text.size());
+        if (t.fb_copy_ok && !any_literal_state && n_dense <= 128 && n_slots + lit_text.size() + 32 <= 16383) {
+            std::vector<uint32_t> dense_idx(n0, 0);
+            t.fb_dense_base.clear();
+            for (uint32_t s = 0; s < n0; ++s)
+                if (plan[s].dense) { dense_idx[s] = (uint32_t)t.fb_dense_base.size(); t.fb_dense_base.push_back((uint16_t)base[s]); }
+            const uint32_t pad = (uint32_t)n_slots;
+            auto desc4 = [&](uint32_t s) -> uint32_t {
+                if (s >= n0) return (pad + lit_id(owed_text[s - n0], owed_kb[s - n0])) | dense_idx[0] << 14 | 1u << 21;
+                if (plan[s].dense) return base[s] | dense_idx[s] << 14;
+                return base[s] | dense_idx[plan[s].f] << 14;
+            };
+            t.fb_comb4.assign(n_slots + lit_text.size() + 32, 124u << 24);
+            t.fb_dense4.assign((size_t)t.fb_dense_base.size() * 32, 124u << 24);
+            for (uint32_t s = 0; s < n0; ++s) {
+                for (uint32_t k : exc[s]) {
+                    const FbCell& y = fr[s][k];
+                    const uint32_t e = desc4(y.next) | (y.esc >= 0 ? 1u << 22 : 0u) | (y.eol ? 1u << 23 : 0u) | (4u * k) << 24;
+                    t.fb_comb4[base[s] + k] = e;
+                    if (plan[s].dense) t.fb_dense4[(size_t)dense_idx[s] * 32 + k] = e;
+                }
+            }
+            const uint32_t starts4[3] = {0u, skip_, done_};
+            for (int i = 0; i < 3; ++i) t.fb_start4[i] = desc4(starts4[i]);
+            t.fb_pad = pad;
+            t.fb_mark4_ok = true;
         }
     }
     static constexpr size_t kFallbackLdsBytes = 90 * 1024;   // the tables' share of the 160 KB (the rest: the emit pass's staging rings)
