@@ -857,18 +857,17 @@ __global__ __launch_bounds__(kThreads) void k_fb_copy(ScanArgs a, FbCopyArgs ca,
 // is a chain of dependent steps per window (edits -> offsets -> markers -> phase A -> phase B -> store), so it wants waves to
 // switch between: 1024 threads share one copy of the literals, two such workgroups fill a CU's 32 wave slots.
 //   smem: literals[fb_lits x 16] | output bases of the sub-ranges (u64) | 64 per chunk | the per-wave carves
-template <int kThreads>
+template <int kThreads, bool kLitLds>
 __global__ __launch_bounds__(kThreads) void k_fb_splice(ScanArgs a, FbCopyArgs ca, int64_t lane_bytes, int64_t n_chunks) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
     U128* lit = reinterpret_cast<U128*>(smem);
-    {
-        const uint64_t* tx = reinterpret_cast<const uint64_t*>(a.blob + h.off_fb_lit);
-        const uint16_t* m = reinterpret_cast<const uint16_t*>(a.blob + h.off_fb_lit_meta);
-        for (int k = threadIdx.x; k < (int)h.fb_lits; k += kThreads) lit[k] = U128{(uint32_t)tx[k], (uint32_t)(tx[k] >> 32), (uint32_t)m[k], 0u};
-    }
+    const uint64_t* tx = reinterpret_cast<const uint64_t*>(a.blob + h.off_fb_lit);
+    const uint16_t* tm = reinterpret_cast<const uint16_t*>(a.blob + h.off_fb_lit_meta);
+    if (kLitLds)
+        for (int k = threadIdx.x; k < (int)h.fb_lits; k += kThreads) lit[k] = U128{(uint32_t)tx[k], (uint32_t)(tx[k] >> 32), (uint32_t)tm[k], 0u};
     constexpr int kGroups = kThreads / kDirectThreads;
-    uint64_t* sbase = reinterpret_cast<uint64_t*>(smem + h.fb_lits * 16u);
+    uint64_t* sbase = reinterpret_cast<uint64_t*>(smem + (kLitLds ? h.fb_lits * 16u : 0u));
     uint32_t* wparts = reinterpret_cast<uint32_t*>(sbase + kThreads);
     uint8_t* carve = reinterpret_cast<uint8_t*>(wparts + 16 * kGroups);
     const int group = threadIdx.x / kDirectThreads, gtid = threadIdx.x % kDirectThreads;
@@ -894,7 +893,8 @@ __global__ __launch_bounds__(kThreads) void k_fb_splice(ScanArgs a, FbCopyArgs c
     __syncthreads();
     if (!live) return;
     SpliceTables T;
-    T.lit = lit;
+    if (kLitLds) T.lit = lit;
+    else { T.lit_text = tx; T.lit_meta = tm; }
     T.esc = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_esc);
     T.pool = a.blob + h.off_fb_pool;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x / kWave);             // in the workgroup
@@ -1460,25 +1460,25 @@ void launch_fb_copy(const ScanArgs& a, const FbCopyArgs& ca, const void* hdr, in
         hipLaunchKernelGGL(k_fb_copy<256>, dim3((unsigned)n_chunks), dim3(256), fb_copy_lds(h, 256), s, a, ca, lane_bytes, n_chunks);
     }
 }
-int fb_splice_lds(const StreamBlobHeader& h, int threads) {
-    return (int)h.fb_lits * 16 + threads * 8 + 64 * (threads / kDirectThreads) + (threads / kWave) * (int)kSpLdsPerWave;
+int fb_splice_lds(const StreamBlobHeader& h, int threads, bool lit_lds) {
+    return (lit_lds ? (int)h.fb_lits * 16 : 0) + threads * 8 + 64 * (threads / kDirectThreads) + (threads / kWave) * (int)kSpLdsPerWave;
 }
 void launch_fb_splice(const ScanArgs& a, const FbCopyArgs& ca, const void* hdr, int64_t lane_bytes, int64_t n_chunks, void* stream) {
     const StreamBlobHeader& h = *static_cast<const StreamBlobHeader*>(hdr);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static const int want = getenv("TRRE_SPLICE_THREADS") ? atoi(getenv("TRRE_SPLICE_THREADS")) : 1024;      // (A/B runs)
-    if (want >= 1024 && 2 * fb_splice_lds(h, 1024) <= kLdsLimit) {
-        allow_big_lds<&k_fb_splice<1024>>();
-        hipLaunchKernelGGL(k_fb_splice<1024>, dim3((unsigned)((n_chunks + 3) / 4)), dim3(1024), fb_splice_lds(h, 1024), s, a, ca, lane_bytes, n_chunks);
-    } else if (want >= 512) {
-        allow_big_lds<&k_fb_splice<512>>();
-        hipLaunchKernelGGL(k_fb_splice<512>, dim3((unsigned)((n_chunks + 1) / 2)), dim3(512), fb_splice_lds(h, 512), s, a, ca, lane_bytes, n_chunks);
+    // workgroups of 512: eight waves share the literals and the sub-range bases of two chunks; two of them per CU.  The literals
+    // in LDS — or (TRRE_SPLICE_LIT_MEM=1, and for tables whose literals do not fit) read from memory, which makes room for a third
+    // workgroup per CU with windows of 2 176 bytes and buys nothing: 2.04 against 1.94 ms per GiB for the whole scan (round 4)
+    static const bool lit_lds = getenv("TRRE_SPLICE_LIT_MEM") == nullptr;
+    if (lit_lds && fb_splice_lds(h, 512, true) <= kLdsLimit) {
+        allow_big_lds<&k_fb_splice<512, true>>();
+        hipLaunchKernelGGL((k_fb_splice<512, true>), dim3((unsigned)((n_chunks + 1) / 2)), dim3(512), fb_splice_lds(h, 512, true), s, a, ca, lane_bytes, n_chunks);
     } else {
-        allow_big_lds<&k_fb_splice<256>>();
-        hipLaunchKernelGGL(k_fb_splice<256>, dim3((unsigned)n_chunks), dim3(256), fb_splice_lds(h, 256), s, a, ca, lane_bytes, n_chunks);
+        allow_big_lds<&k_fb_splice<512, false>>();
+        hipLaunchKernelGGL((k_fb_splice<512, false>), dim3((unsigned)((n_chunks + 1) / 2)), dim3(512), fb_splice_lds(h, 512, false), s, a, ca, lane_bytes, n_chunks);
     }
 }
-bool fb_splice_fits(const void* hdr) { return fb_splice_lds(*static_cast<const StreamBlobHeader*>(hdr), 512) <= kLdsLimit; }
+bool fb_splice_fits(const void* hdr) { return fb_splice_lds(*static_cast<const StreamBlobHeader*>(hdr), 512, false) <= kLdsLimit; }
 void launch_g16_splice(const ScanArgs& a, const FbCopyArgs& ca, int g16_bytes, int p32_bytes, int64_t lane_bytes, int64_t n_chunks, void* stream) {
     const int both = (g16_bytes + 15) / 16 * 16 + (p32_bytes + 15) / 16 * 16;
     const int tab = both <= kSpliceTabMax ? both : 0;

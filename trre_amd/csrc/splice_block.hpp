@@ -31,17 +31,22 @@
 
 namespace trre {
 
-constexpr uint32_t kSpWin = 2304;          // input bytes per window
+#ifndef TRRE_SP_WIN
+#define TRRE_SP_WIN 2304
+#define TRRE_SP_GROW 640
+#endif
+constexpr uint32_t kSpWin = TRRE_SP_WIN;   // input bytes per window
 constexpr uint32_t kSpEdits = 128;         // edits per window: two per lane
-constexpr uint32_t kSpIn = 2352;           // staged input (at tin + 16): at most 15 + 2304 bytes and the second dword of a funnel read are looked at
-constexpr uint32_t kSpGrow = 640;          // what the texts of one window may add
-constexpr uint32_t kSpOut = 2960;          // tile of output bytes: 15 + 2304 + 640, rounded up to 16
+constexpr uint32_t kSpIn = (15 + kSpWin + 8 + 15) / 16 * 16 + 16;   // staged input (at tin + 16): at most 15 + the window and the second dword of a funnel read are looked at
+constexpr uint32_t kSpGrow = TRRE_SP_GROW; // what the texts of one window may add
+constexpr uint32_t kSpOut = (15 + kSpWin + kSpGrow + 15) / 16 * 16;   // tile of output bytes
+constexpr uint32_t kSpMk = (kSpOut / 4 + 15) / 16 * 16;               // markers: a byte per output dword
 constexpr uint32_t kSpMaxText = 255;       // longest escape text a table may have for this pass (runtime.cpp checks)
 // per wave: staged input | output tile | markers | displacement table [129] | the carried line
-constexpr uint32_t kSpOffOut = 16 + kSpIn, kSpOffMk = kSpOffOut + kSpOut, kSpOffTab = kSpOffMk + 752,
+constexpr uint32_t kSpOffOut = 16 + kSpIn, kSpOffMk = kSpOffOut + kSpOut, kSpOffTab = kSpOffMk + kSpMk,
                    kSpOffCarry = kSpOffTab + 528, kSpLdsPerWave = kSpOffCarry + 16;
-static_assert(kSpLdsPerWave % 16 == 0 && kSpOut / 4 <= 752 && (kSpEdits + 1) * 4 <= 528, "per-wave LDS carve");
-static_assert(15 + kSpWin + kSpGrow <= kSpOut && 15 + kSpWin + 8 <= kSpIn && kSpOut <= 3 * 1024, "tile sizes");
+static_assert(kSpLdsPerWave % 16 == 0 && (kSpEdits + 1) * 4 <= 528, "per-wave LDS carve");
+static_assert(15 + kSpWin + kSpGrow <= kSpOut && 15 + kSpWin + 8 <= kSpIn && kSpOut <= 3 * 1024 && kSpIn <= 3 * 1024, "tile sizes");
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define SPV(T, x) T x
@@ -100,7 +105,9 @@ TRRE_HD uint32_t sp_ctz64(uint64_t x) {
 // 16-byte entry of the transition, which stands for the one byte it read and emits the entry's bytes around that byte (or,
 // "slow" entries, a pooled text).
 struct SpliceTables {
-    const U128* lit = nullptr;          // [fb_lits] {text lo, text hi, n | kb << 8, -}  (LDS)
+    const U128* lit = nullptr;          // [fb_lits] {text lo, text hi, n | kb << 8, -}  (LDS), or null: ...
+    const uint64_t* lit_text = nullptr; // ... the texts and their {n | kb << 8} from memory (the table stays in L1 / L2: more LDS for tiles)
+    const uint16_t* lit_meta = nullptr;
     const uint32_t* esc = nullptr;      // escape records (global) ...
     const uint8_t* pool = nullptr;      // ... and their texts; small tables: the pool of the 8-byte entries
     const uint8_t* g16 = nullptr;       // small tables: the 16-byte entries (LDS or global)
@@ -209,7 +216,7 @@ TRRE_HD void fb_splice_ranges(const ScanArgs& a, const SpliceTables& T, const Fb
                 *reinterpret_cast<U128*>(tin + 16u + 16u * SP_LANE) = SP(pin0);
                 if (need > 1024u) *reinterpret_cast<U128*>(tin + 16u + 1024u + 16u * SP_LANE) = SP(pin1);
                 if (need > 2048u && 2048u + 16u * SP_LANE < kSpIn) *reinterpret_cast<U128*>(tin + 16u + 2048u + 16u * SP_LANE) = SP(pin2);
-                if (SP_LANE < 47u) reinterpret_cast<U128*>(mk)[SP_LANE] = U128{0, 0, 0, 0};
+                if (SP_LANE < kSpMk / 16u) reinterpret_cast<U128*>(mk)[SP_LANE] = U128{0, 0, 0, 0};
             }
         }
         // ---- the window's edits, two per lane -----------------------------------------------------------------------
@@ -249,7 +256,9 @@ TRRE_HD void fb_splice_ranges(const ScanArgs& a, const SpliceTables& T, const Fb
                     }                                                                                             \
                 }                                                                                                 \
             } else if (!(id & 0x8000u)) {                                                                         \
-                const U128 r = T.lit[id];                                                                         \
+                U128 r;                                                                                           \
+                if (T.lit) r = T.lit[id];                                                                         \
+                else { const uint64_t tx = T.lit_text[id]; r.x = (uint32_t)tx; r.y = (uint32_t)(tx >> 32); r.z = T.lit_meta[id]; r.w = 0; } \
                 SP(tlo) = r.x; SP(thi) = r.y; SP(n) = r.z & 255u; SP(kb) = r.z >> 8; SP(fp) = p - SP(kb);          \
             } else {                                      /* a text spelled out in memory (rare) */               \
                 const uint32_t* r = T.esc + 4u * (id & 0x7fffu);                                                  \
