@@ -46,8 +46,10 @@ extern "C" {
                                  Both generator modes: NFT engine only (trre_dft -a prints "Not supported yet",
                                  trre_dft.c:1227-1229).  The amount of output is unbounded in the input; the device computes
                                  the viability filter (one symbol per input byte: which nodes have an accepting or a
-                                 non-terminating continuation), the accepting paths are enumerated on host threads from the
-                                 device's symbols (trre_amd/csrc/generate.cpp). */
+                                 non-terminating continuation) and, since round 4, enumerates the accepting paths itself —
+                                 count, exclusive sum, emit: trre_amd/csrc/gen_block.hpp —; the host enumeration of round 3
+                                 (trre_amd/csrc/generate.cpp) takes a chunk on which a path never returns or a search
+                                 outgrows a lane's stack. */
 
 /* return codes */
 #define TRRE_OK 0
@@ -75,10 +77,11 @@ extern "C" {
 #define TRRE_KERNEL_TILE_GEN 3  /* any tables: count + scan + emit */
 #define TRRE_KERNEL_STREAM_LP 4 /* scan loop folded into the tables, length-preserving: in-place, single launch */
 #define TRRE_KERNEL_STREAM_GEN 5 /* scan loop folded into the tables, any output length: count + scan + emit */
-#define TRRE_KERNEL_GUIDED_LP 6  /* NFT engine, any pattern: backward DFA sweep (one symbol per byte) + guided forward transducer, in place */
+#define TRRE_KERNEL_GUIDED_LP 6  /* NFT engine, any pattern (round 4: DFT engine too, any pattern that is not a byte map): backward DFA sweep (one symbol per byte) + guided forward transducer, in place */
 #define TRRE_KERNEL_GUIDED_GEN 7 /* the same, any output length: backward sweep, count + scan + emit */
 
-#define TRRE_KERNEL_GENERATE 8    /* generator modes: backward viability sweep on the device, enumeration on the host */
+#define TRRE_KERNEL_GENERATE 8    /* generator modes: backward viability sweep and enumeration (count, exclusive sum, emit) on the device;
+                                     a chunk on which a path never returns or a search outgrows a lane's stack: the host enumeration */
 
 typedef struct trre_prog trre_prog;
 

@@ -100,11 +100,11 @@ def test_general_families_8gib():
         check_slices(p, Oracle(pat, eng), inp, out, got.numel(), p.info.kernel)
 
 
-@pytest.mark.parametrize("env", [{}, {"TRRE_NO_FB_COPY": "1"}, {"TRRE_NO_FB": "1"}, {"TRRE_FB_EMIT": "1"}])
+@pytest.mark.parametrize("env", [{}, {"TRRE_NO_FB_SPLICE": "1"}, {"TRRE_NO_FB_MARK4": "1"}, {"TRRE_NO_FB_COPY": "1"}, {"TRRE_NO_FB": "1"}, {"TRRE_FB_EMIT": "1"}])
 def test_dictionary_8gib(env):
     """BASELINE configs[4] at its per-GPU size: the 1000-entry dictionary over 8 GiB of its own corpus (offsets
-    beyond 2^32 through the large-table kernels), both engines, the automatic choice (the copy form) and the three alternative
-    walkers of the large table (the library reads the environment once per process: subprocess)"""
+    beyond 2^32 through the large-table kernels), both engines, the automatic choice (the copy form: mark pass on the 32-bit comb, wave-cooperative
+    splice), round 3's second pass (TRRE_NO_FB_SPLICE) and first pass (TRRE_NO_FB_MARK4) and the three alternative walkers of the large table (the library reads the environment once per process: subprocess)"""
     import subprocess
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_dict8g_check.py")
     e = dict(os.environ)

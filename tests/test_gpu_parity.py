@@ -426,6 +426,21 @@ def test_random_dictionaries_on_gpu():
     assert checked >= 12
 
 
+def test_a_program_stops_trying_its_bounded_table_after_an_overflow():
+    """round 4: the count pass of a bounded fold that meets a run it was not built for voids the launch (the emit pass leaves at
+    once), finish() runs the buffer on the guided kernels — and the scans after it go there directly"""
+    p = trre_amd.Program(" +: ", "nft")
+    o = Oracle(" +: ", "nft")
+    assert p.info.kernel == trre_amd.KERNEL_STREAM_GEN
+    short = b"a  b   c\n" * 20000
+    assert gpu_scan(p, short) == o.scan(short) and p.info.kernel == trre_amd.KERNEL_STREAM_GEN
+    long_run = short + b"x" + b" " * 300 + b"y\n" + short
+    assert gpu_scan(p, long_run) == o.scan(long_run)
+    assert p.info.kernel == trre_amd.KERNEL_GUIDED_GEN                     # (what a scan launches from now on)
+    assert gpu_scan(p, short) == o.scan(short) and gpu_scan(p, long_run) == o.scan(long_run)
+    assert gpu_scan(p, short, trre_amd.KERNEL_STREAM_GEN) == o.scan(short)  # (forcing the family still works)
+
+
 def test_bounded_fold_falls_back_to_the_tile_kernels():
     """greedy loops fold into stream tables for runs of up to 64 bytes; a longer run voids the launch
     (overflow mark) and the tile kernels produce the result"""
