@@ -57,7 +57,8 @@ extern "C" {
 #define TRRE_E_UNDEFINED (-2)   /* the reference reads outside its buffers on this pattern */
 #define TRRE_E_EPS_CYCLE (-3)   /* epsilon cycle: the reference recurses without bound (DFT) */
 #define TRRE_E_TOO_BIG (-4)     /* determinisation exceeds the state/residual caps */
-#define TRRE_E_UNSUPPORTED (-5) /* legal pattern, outside this engine's GPU limits (NFT: backward DFA > 256 states and > 64 nodes) */
+#define TRRE_E_UNSUPPORTED (-5) /* legal pattern, outside this engine's GPU limits (modes other than scan: a backward DFA beyond the guided
+                                   families' limits; scan mode, NFT engine, at run time: an attempt beyond the backtracking fallback's limits) */
 #define TRRE_E_DEVICE (-6)      /* HIP runtime failure / no GPU */
 #define TRRE_E_ARG (-7)
 #define TRRE_E_DIVERGES (-8)    /* the reference does not survive this input: an epsilon cycle is entered (NFT: "error: stack max
@@ -82,6 +83,11 @@ extern "C" {
 
 #define TRRE_KERNEL_GENERATE 8    /* generator modes: backward viability sweep and enumeration (count, exclusive sum, emit) on the device;
                                      a chunk on which a path never returns or a search outgrows a lane's stack: the host enumeration */
+
+#define TRRE_KERNEL_BACKTRACK 9   /* NFT engine, scan mode, any pattern: the reference's depth-first search itself, a lane per sub-range with an
+                                     explicit stack (round 4).  What a pattern beyond the limits of every other family runs on (round 3:
+                                     TRRE_E_UNSUPPORTED); exponential where the reference is.  A 1 KiB sub-range whose search takes more than 16 M steps, an
+                                     attempt that consumes more than 1 024 bytes or builds more than 2 KiB of output: TRRE_E_UNSUPPORTED at run time */
 
 typedef struct trre_prog trre_prog;
 

@@ -848,6 +848,60 @@ int shim_generate(const uint8_t* rblob, const uint8_t* nblob, int geo, const uin
     return 0;
 }
 
+// The backtracking fallback as the runtime runs it: count per sub-range, exclusive sum, emit (gen_block.hpp: bt_lane), with a pool
+// of `pool` stacks the sub-ranges take in turn.  status: kStDiverge (with *m = the output up to the attempt that does not return),
+// kStEditOverflow (the limits).
+int shim_backtrack(const uint8_t* nblob, int geo, const uint8_t* in, size_t n, int in_mis, uint8_t* out, size_t cap, uint32_t frames,
+                   uint32_t path_cap, uint32_t budget, size_t* m, uint32_t* status_out) {
+    *m = 0; *status_out = 0;
+    if (n == 0) return 0;
+    std::vector<uint8_t> ibuf(n + 64, 0xAA);
+    uint8_t* ia = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(ibuf.data()) + 15) & ~(uintptr_t)15) + in_mis;
+    std::memcpy(ia, in, n);
+    ScanArgs a{};
+    const int64_t al = (int64_t)(reinterpret_cast<uintptr_t>(ia) & 15u);
+    a.in_v0 = ia - al;
+    a.vbeg = al;
+    a.vend = al + (int64_t)n;
+    uint32_t status = 0;
+    a.status = &status;
+    a.blob = nblob;
+    a.out = out;
+    a.cap = cap;
+    const GenView G = gen_view(nblob);
+    const int64_t lane_bytes = geo == 0 ? 1024 : 64;
+    const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
+    const int64_t pool = 3;
+    std::vector<uint32_t> stack((size_t)pool * frames * 4 + 4, 0xEEEEEEEEu);
+    std::vector<uint8_t> path((size_t)pool * path_cap + 4, 0xEE);
+    GenArgs ga{stack.data(), path.data(), frames, path_cap};
+    std::vector<uint64_t> cnt(n_lanes), base(n_lanes);
+    int64_t first_div = -1;
+    for (int64_t lane = n_lanes - 1; lane >= 0; --lane) {
+        DirectLane L;
+        uint32_t lst = 0;
+        bt_lane<1>(a, G, ga, lane % pool, lane, lane_bytes, 0, budget, L, lst);
+        cnt[lane] = L.count;
+        if (lst & kStDiverge) first_div = lane;
+        status |= lst;
+    }
+    *status_out = status;
+    if (status & kStEditOverflow) return 0;
+    uint64_t run = 0;
+    for (int64_t lane = 0; lane < n_lanes; ++lane) { base[lane] = run; run += cnt[lane]; }
+    if (first_div >= 0) run = base[first_div] + cnt[first_div];
+    *m = (size_t)run;
+    if (run > cap) { *status_out = status | kStCapacity; return 0; }
+    for (int64_t lane = 0; lane < n_lanes && (first_div < 0 || lane <= first_div); ++lane) {
+        DirectLane L;
+        uint32_t lst = 0;
+        bt_lane<2>(a, G, ga, lane % pool, lane, lane_bytes, base[lane], budget, L, lst);
+        if (L.count != cnt[lane]) status |= 1u << 30;                     // count and emit passes disagree
+    }
+    *status_out = status;
+    return 0;
+}
+
 int shim_rev_sweep(const uint8_t* rblob, int geo, const uint8_t* in, size_t n, int in_mis, uint8_t* sym_out) {
     if (n == 0) return 0;
     std::vector<uint8_t> ibuf(n + 64, 0xAA);

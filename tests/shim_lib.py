@@ -38,6 +38,8 @@ def lib():
         L.shim_rev_sweep.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_char_p]
         L.shim_generate.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p,
                                     ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_uint32)]
+        L.shim_backtrack.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
+                                     ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_uint32)]
         _lib = L
     return _lib
 
@@ -155,6 +157,13 @@ def scan_like_runtime(prog, data, geo=1, family=None, in_mis=0, out_mis=0):
         fam = {6: GUIDED_LP, 7: GUIDED_GEN}.get(info.kernel, info.kernel)
     if fam in (GUIDED_LP, GUIDED_GEN, GUIDED_GEN8, GUIDED_LP_RING, GUIDED_LP8, GUIDED_GEN_SPLICE):
         return scan_guided_like_runtime(prog, data, geo, fam, in_mis, out_mis)
+    if family == BACKTRACK or (not family and info.kernel == 9):       # (ABI family 9; the shim's own 9 is a direct walker of the stream family)
+        out, st = scan_backtrack(prog, data, geo, in_mis)
+        if st & ST_EDIT_OVERFLOW:
+            raise RuntimeError("limits")
+        if st & ST_DIVERGE:
+            raise RuntimeError("diverges")
+        return out
     blob = prog.export_stream_tables() if fam in (4, 5, 6, 7, 8, 9, 20, 21, 22, 23, 25, 27, 28, STREAM_LPW_PAIR) else prog.export_tables()
     if fam == STREAM_G16_SPLICE:
         out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
@@ -183,6 +192,30 @@ def scan_like_runtime(prog, data, geo=1, family=None, in_mis=0, out_mis=0):
         if st & ST_DIVERGE:
             raise RuntimeError("diverges")
     return out
+
+
+BACKTRACK = 30                                       # the backtracking fallback (ABI family 9)
+
+
+def scan_backtrack(prog, data, geo=1, in_mis=0, frames=1024, path_cap=2048, budget=16 << 20):
+    """the backtracking fallback's lane body on the host, as the runtime drives it: (output, status) — with ST_DIVERGE the output is
+    what the reference had printed when it gave up"""
+    nblob = prog.export_gen_tables()
+    assert nblob
+    cap = max(1 << 16, 4 * len(data))
+    for _ in range(2):
+        out = ctypes.create_string_buffer(cap)
+        m = ctypes.c_size_t()
+        st = ctypes.c_uint32()
+        rc = lib().shim_backtrack(nblob, geo, data, len(data), in_mis, out, cap, frames, path_cap, budget, ctypes.byref(m), ctypes.byref(st))
+        if rc:
+            raise RuntimeError("shim rc %d" % rc)
+        assert not st.value & ST_MISMATCH, "count and emit passes disagree"
+        if st.value & ST_CAPACITY:
+            cap = m.value + 64
+            continue
+        return out.raw[:m.value], st.value
+    raise RuntimeError("capacity")
 
 
 def rev_symbols(rblob, data, geo=1, in_mis=0):

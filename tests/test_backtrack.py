@@ -1,0 +1,119 @@
+"""The backtracking fallback (family 9: gen_block.hpp bt_lane): the reference's depth-first search itself, a lane per
+sub-range.  What a pattern beyond every table form runs on; here its lane body runs on the host (tests/cpu_shim.cpp) on
+every golden vector of the NFT engine and against the oracle."""
+import random
+
+import pytest
+
+import corpus
+import golden_lib
+import shim_lib
+import trre_amd
+from oracle_lib import Oracle, OracleError
+
+_progs = {}
+
+
+def prog(pat):
+    if pat not in _progs:
+        _progs[pat] = trre_amd.Program(pat, "nft")
+    return _progs[pat]
+
+
+def test_golden_vectors_through_the_backtracking_fallback():
+    n = n_fail = 0
+    for pat, name, data, engine, exp in golden_lib.cases():
+        if engine != "nft" or len(data) > 20000:
+            continue
+        p = prog(pat)
+        assert trre_amd.KERNEL_BACKTRACK in p.allowed_kernels()
+        for geo in (1, 0):
+            if exp is None:
+                with pytest.raises(RuntimeError, match="diverges"):
+                    shim_lib.scan_like_runtime(p, data, geo=geo, family=shim_lib.BACKTRACK)
+                n_fail += 1
+                continue
+            assert shim_lib.scan_like_runtime(p, data, geo=geo, family=shim_lib.BACKTRACK) == exp, (pat, name, geo)
+            n += 1
+    assert n >= 880 and n_fail == 26, (n, n_fail)
+
+
+def test_a_diverging_scan_keeps_what_the_reference_had_printed():
+    """the NFT binary exits 1 with its stdout flushed: the lines before the bad one and the bad line's output up to the attempt
+    that does not return"""
+    for pat, data in [("a:*", b"xx\nbab\nzz\n"), ("a(:y)*", b"q\n" * 40 + b"cca\nzz\n"), ("(x:y)|a(b*)*c|ad", b"xxx\nxxad\nq\n")]:
+        with pytest.raises(OracleError) as e:
+            Oracle(pat, "nft").scan(data)
+        for geo in (1, 0):
+            out, st = shim_lib.scan_backtrack(prog(pat), data, geo=geo)
+            assert st & shim_lib.ST_DIVERGE and out == e.value.partial, (pat, geo, out, e.value.partial)
+
+
+def test_patterns_beyond_every_table_form():
+    """more than 64 nodes, a backward automaton beyond the guided limits, no fold: TRRE_E_UNSUPPORTED until round 4"""
+    rng = random.Random(11)
+    for pat, k_mid in [("a(a|b|c|d|e|f|g|h){12}c:x", 12), ("(:<)a(a|b|c|d|e|f|g|h){14}c:>", 14)]:
+        p = prog(pat)
+        assert p.info.kernel == trre_amd.KERNEL_BACKTRACK and p.allowed_kernels() == [trre_amd.KERNEL_BACKTRACK]
+        o = Oracle(pat, "nft")
+        lines = []
+        for _ in range(60):
+            k = rng.randrange(0, 40)
+            s = bytes(rng.choice(b"abcdefgh") for _ in range(k))
+            if rng.random() < 0.5:
+                s += b"a" + bytes(rng.choice(b"abcdefgh") for _ in range(k_mid)) + b"c" + bytes(rng.choice(b"abch") for _ in range(rng.randrange(3)))
+            lines.append(s)
+        data = b"\n".join(lines) + b"\n"
+        want = o.scan(data)
+        assert want != data
+        for geo in (1, 0):
+            assert shim_lib.scan_like_runtime(p, data, geo=geo) == want, (pat, geo)
+
+
+def test_the_limits_are_an_error_not_a_hang():
+    p = prog("(a|aa)*b:x")
+    data = b"a" * 40 + b"\n"                                   # exponential for the reference too
+    out, st = shim_lib.scan_backtrack(p, data, budget=100000)
+    assert st & shim_lib.ST_EDIT_OVERFLOW
+    out, st = shim_lib.scan_backtrack(p, b"a" * 12 + b"\n" + b"aab\n", budget=100000)
+    assert not st & shim_lib.ST_EDIT_OVERFLOW and out == Oracle("(a|aa)*b:x", "nft").scan(b"a" * 12 + b"\n" + b"aab\n")
+    # an attempt deeper than the stack, an output longer than the path buffer
+    out, st = shim_lib.scan_backtrack(prog("a*b:x"), b"a" * 100 + b"b\n", frames=64)
+    assert st & shim_lib.ST_EDIT_OVERFLOW
+    out, st = shim_lib.scan_backtrack(prog("(a:xyzw)*b"), b"a" * 100 + b"b\n", path_cap=128)
+    assert st & shim_lib.ST_EDIT_OVERFLOW
+
+
+def test_random_patterns_on_the_backtracking_fallback():
+    import fuzz_oracle as F
+    import time
+    rng = random.Random(77)
+    n = n_div = 0
+    t_end = time.time() + 40
+    for _ in range(300):
+        if time.time() > t_end:
+            break
+        pat = F.gen_soup(rng) if rng.random() < 0.2 else F.gen_expr(rng)
+        if b"\0" in pat or not pat:
+            continue
+        try:
+            p = trre_amd.Program(pat, "nft")
+        except trre_amd.TrreError:
+            continue
+        assert trre_amd.KERNEL_BACKTRACK in p.allowed_kernels()
+        data = F.gen_input(rng) + F.gen_input(rng)
+        try:
+            want = Oracle(pat, "nft").scan(data)
+        except OracleError as e:
+            if e.code != 1:
+                continue
+            out, st = shim_lib.scan_backtrack(p, data)
+            assert st & shim_lib.ST_DIVERGE and out == e.partial, (pat, data)
+            n_div += 1
+            continue
+        out, st = shim_lib.scan_backtrack(p, data, geo=rng.choice((0, 1)))
+        if st & shim_lib.ST_EDIT_OVERFLOW:
+            continue
+        assert not st & shim_lib.ST_DIVERGE and out == want, (pat, data)
+        n += 1
+    assert n > 80, (n, n_div)

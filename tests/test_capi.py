@@ -47,10 +47,9 @@ def test_engine_limits_are_errors_not_fallbacks():
     # round 2 refused it, the wide guided tables (16-bit symbols) run it
     p = trre_amd.Program("a(a|b|c|d|e|f|g|h){9}c:x", "nft")
     assert p.info.kernel == trre_amd.KERNEL_GUIDED_GEN and p.info.guided_rev_states == 4604 and trre_amd.KERNEL_GUIDED_LP not in p.allowed_kernels()
-    # what is still refused: more than 16 384 backward states with more than 64 nodes
-    with pytest.raises(trre_amd.TrreError) as e:
-        trre_amd.Program("a(a|b|c|d|e|f|g|h){12}c:x", "nft")
-    assert e.value.code == api.E_UNSUPPORTED
+    # more than 16 384 backward states with more than 64 nodes: round 3 refused it, the backtracking fallback runs it
+    p = trre_amd.Program("a(a|b|c|d|e|f|g|h){12}c:x", "nft")
+    assert p.info.kernel == trre_amd.KERNEL_BACKTRACK and p.allowed_kernels() == [trre_amd.KERNEL_BACKTRACK]
     p = trre_amd.Program("a(a|b|c){9}c:x", "nft")            # 29 nodes: the bitmask tile kernels could run it, the wide tables are
     assert p.info.kernel == trre_amd.KERNEL_GUIDED_GEN and p.info.guided_rev_states > 256 and trre_amd.KERNEL_TILE_GEN in p.allowed_kernels()   # 2x faster
     # an epsilon cycle is not a compile error: like the reference's lazy tables, the scan fails (TRRE_E_DIVERGES) only

@@ -527,3 +527,36 @@ def test_match_mode_on_gpu():
     data = corpus.word_soup(rng, 2 << 20, max_len=30) + b"cat\ndog\n\nlast cat"
     for pat in ("(cat:dog|dog:cat| |[a-z]|[A-Z])*", "[a-z ]*", ".*(cat:dog).*"):
         assert gpu_scan(trre_amd.Program(pat, "nft", mode="match"), data) == Oracle(pat, "nft").match(data), pat
+
+
+def test_backtracking_fallback_on_gpu():
+    """family 9 (round 4): the reference's depth-first search, a lane per KiB with its own stack — every NFT golden vector, and a
+    pattern beyond every table form (round 3: TRRE_E_UNSUPPORTED) on 32 MiB against the oracle"""
+    n = 0
+    for pat, name, data, engine, exp in golden_lib.cases():
+        if engine != "nft" or exp is None or len(data) > 20000:
+            continue
+        p = prog(pat, engine)
+        assert gpu_scan(p, data, trre_amd.KERNEL_BACKTRACK) == exp, (pat, name)
+        n += 1
+    assert n > 430, n
+    pat = "a(a|b|c|d|e|f|g|h){12}c:x"
+    p = prog(pat, "nft")
+    assert p.info.kernel == trre_amd.KERNEL_BACKTRACK
+    rng = random.Random(3)
+    block = bytearray(corpus.printable_lines(rng, 1 << 20))
+    for _ in range(3000):
+        at = rng.randrange(len(block) - 20)
+        if b"\n" not in block[at:at + 14]:
+            block[at:at + 14] = b"a" + bytes(rng.choice(b"abcdefgh") for _ in range(12)) + b"c"
+    data = bytes(block) * 32
+    want = Oracle(pat, "nft").scan(bytes(block))
+    assert want != bytes(block)
+    assert gpu_scan(p, data) == want * 32
+    assert p.scan(bytes(block)) == want                                # host buffers
+    # beyond its limits: an error, not a hang and not a wrong answer
+    q = prog("(a|aa)*b:x", "nft")
+    with pytest.raises(trre_amd.TrreError) as e:
+        gpu_scan(q, b"a" * 60 + b"\n" + b"aab\n" * 100, trre_amd.KERNEL_BACKTRACK)
+    assert e.value.code == trre_amd.api.E_UNSUPPORTED
+    assert gpu_scan(q, b"a" * 12 + b"\n" + b"aab\n" * 100, trre_amd.KERNEL_BACKTRACK) == b"a" * 12 + b"\n" + b"x\n" * 100

@@ -24,8 +24,9 @@ _ENGINES = {"nft": ENGINE_NFT, "dft": ENGINE_DFT, ENGINE_NFT: ENGINE_NFT, ENGINE
 KERNEL_AUTO, KERNEL_BYTEMAP, KERNEL_TILE_LP, KERNEL_TILE_GEN, KERNEL_STREAM_LP, KERNEL_STREAM_GEN = 0, 1, 2, 3, 4, 5
 KERNEL_GUIDED_LP, KERNEL_GUIDED_GEN = 6, 7
 KERNEL_GENERATE = 8
+KERNEL_BACKTRACK = 9
 KERNEL_NAMES = {0: "auto", 1: "bytemap", 2: "tile_lp", 3: "tile_gen", 4: "stream_lp", 5: "stream_gen", 6: "guided_lp",
-                7: "guided_gen", 8: "generate"}
+                7: "guided_gen", 8: "generate", 9: "backtrack"}
 
 FLAG_LENGTH_PRESERVING, FLAG_MEMORYLESS, FLAG_NO_OVERRUN = 1, 2, 4
 
@@ -171,7 +172,7 @@ class Program:
     def allowed_kernels(self):
         ok = []
         for fam in (KERNEL_BYTEMAP, KERNEL_TILE_LP, KERNEL_TILE_GEN, KERNEL_STREAM_LP, KERNEL_STREAM_GEN, KERNEL_GUIDED_LP,
-                    KERNEL_GUIDED_GEN):
+                    KERNEL_GUIDED_GEN, KERNEL_BACKTRACK):
             if lib().trre_set_kernel(self._h, fam) == 0:
                 ok.append(fam)
         lib().trre_set_kernel(self._h, KERNEL_AUTO)

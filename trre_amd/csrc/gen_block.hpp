@@ -77,7 +77,12 @@ TRRE_HD void gen_lane(const ScanArgs& a, const GenView& G, const GenArgs& ga, in
     uint8_t* op = kMode == 2 ? a.out + out_base : nullptr;
     auto byte_at = [&](int64_t v) -> uint8_t { return v >= a.vend - 1 ? (uint8_t)'\n' : a.in_v0[v]; };   // the last byte ends its record (Q1)
     auto put = [&](const uint8_t* src, uint32_t n) {
-        if (kMode == 2) { for (uint32_t i = 0; i < n; ++i) op[cnt + i] = src[i]; }
+        if (kMode == 2) {
+            // (eight bytes at a time: neither side is aligned, global memory does not mind)
+            uint32_t i = 0;
+            for (; i + 8u <= n; i += 8u) reinterpret_cast<UnalignedU64*>(op + cnt + i)->v = reinterpret_cast<const UnalignedU64*>(src + i)->v;
+            for (; i < n; ++i) op[cnt + i] = src[i];
+        }
         cnt += n;
     };
     auto put1 = [&](uint8_t c) {
@@ -152,6 +157,119 @@ TRRE_HD void gen_lane(const ScanArgs& a, const GenView& G, const GenArgs& ga, in
             if (ok) put1((uint8_t)'\n');
         }
         if (!ok) break;                                                             // (the chunk goes to the host enumeration)
+        pos = e + 1;
+    }
+    L.count = cnt;
+}
+
+// =============================================================================================
+// The search itself, for the patterns nothing else runs (round 4): infer_backtrack with all = 0 (trre_nft.c:593-657: depth
+// first, the first path that reaches FINAL wins) and the scan line loop around it (trre_nft.c:775-790), a lane per sub-range
+// and an explicit stack in scratch memory — what the reference does, on every line at once.  The guided families answer
+// every attempt in time linear in the line; this walker is exponential where the reference is.  It is what an NFT pattern
+// runs on when its backward automaton has more than 16 384 states, it does not fold and it has more than 64 nodes (round 3:
+// TRRE_E_UNSUPPORTED): the engine then runs every pattern the reference runs.  Tables: the follow lists of nft_tables.cpp
+// (first occurrence of a target per list, a list ends at its first FINAL) in the generator modes' blob form; no symbols.
+// An attempt that takes more than `budget` steps, goes deeper than the lane's stack or builds more output than its path
+// buffer gives up (kStCapacity is not it: kStEditOverflow) — an error, not a hang; an epsilon cycle is kStDiverge.
+// =============================================================================================
+template <int kMode>
+TRRE_HD void bt_lane(const ScanArgs& a, const GenView& G, const GenArgs& ga, int64_t slot, int64_t lane, int64_t lane_bytes, uint64_t out_base,
+                     uint32_t budget, DirectLane& L, uint32_t& status) {
+    const int64_t lo = lane * lane_bytes;
+    int64_t hi = lo + lane_bytes;
+    if (hi > a.vend) hi = a.vend;
+    uint64_t cnt = 0;
+    L.count = 0;
+    if (lo >= hi) return;
+    uint32_t* const stack = ga.stack + (size_t)slot * ga.frames * 4;
+    uint8_t* const path = ga.path + (size_t)slot * ga.path_cap;
+    uint8_t* op = kMode == 2 ? a.out + out_base : nullptr;
+    auto byte_at = [&](int64_t v) -> uint8_t { return v >= a.vend - 1 ? (uint8_t)'\n' : a.in_v0[v]; };
+    auto put = [&](const uint8_t* src, uint32_t n) {
+        if (kMode == 2) { for (uint32_t i = 0; i < n; ++i) op[cnt + i] = src[i]; }
+        cnt += n;
+    };
+    auto put1 = [&](uint8_t c) {
+        if (kMode == 2) op[cnt] = c;
+        cnt += 1;
+    };
+    // the first accepting path of ONE attempt at position p: prints its output; returns the bytes it consumed, -1: no path, -2: gave up
+    uint32_t steps = 0;                                                             // (of the whole sub-range: the launch ends in bounded time)
+    auto attempt = [&](int64_t rec, uint32_t len, uint32_t p) -> int64_t {
+        uint32_t sp = 1;
+        stack[0] = G.n_nodes; stack[1] = 0; stack[2] = p; stack[3] = 0;
+        while (sp) {
+            if (++steps > budget) { status |= kStEditOverflow; return -2; }
+            uint32_t* f = stack + 4 * (sp - 1);
+            const uint32_t list = f[0], idx = f[1], fi = f[2], fo = f[3];
+            const uint32_t beg = G.foff[list], end = G.foff[list + 1];
+            if (beg + idx >= end) { --sp; continue; }
+            f[1] = idx + 1;
+            const uint32_t* e = G.follow + 3 * (size_t)(beg + idx);
+            const uint32_t target = e[0], out_off = e[1], out_len = e[2] & 0xffffu, mute = e[2] >> 16;
+            const uint32_t olen = fo & 0x7fffffffu, muted = fo >> 31;
+            if (target == kGenTgtDiverge) { status |= kStDiverge; return -2; }
+            if (target == kGenTgtFinal) {                                           // trre_nft.c:643-648: print, return the offset
+                put(path, olen);
+                if (!muted) put(G.pool + out_off, out_len);
+                return (int64_t)fi - (int64_t)p;
+            }
+            if (fi >= len) continue;
+            const uint8_t c = a.in_v0[rec + fi];
+            if (!((G.bytes[8 * (size_t)target + (c >> 5)] >> (c & 31u)) & 1u)) continue;
+            uint32_t nlen = olen, nmuted = muted;
+            if (!muted) {
+                if (olen + out_len + 1u > ga.path_cap) { status |= kStEditOverflow; return -2; }
+                for (uint32_t i = 0; i < out_len; ++i) path[olen + i] = G.pool[out_off + i];
+                nlen = olen + out_len;
+                if (mute) nmuted = 1;
+                else if (G.echo[target]) path[nlen++] = c;
+            }
+            if (sp >= ga.frames) { status |= kStEditOverflow; return -2; }
+            uint32_t* nf = stack + 4 * sp;
+            nf[0] = target; nf[1] = 0; nf[2] = fi + 1; nf[3] = nlen | nmuted << 31;
+            ++sp;
+        }
+        return -1;
+    };
+    // the bytes an attempt can begin with (all of them when the start's list reaches FINAL or a cycle without reading): elsewhere the
+    // attempt is known to fail and the byte is copied without a search
+    uint32_t first[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t k = G.foff[G.n_nodes]; k < G.foff[G.n_nodes + 1]; ++k) {
+        const uint32_t target = G.follow[3 * (size_t)k];
+        for (int w = 0; w < 8; ++w) first[w] |= target >= kGenTgtDiverge ? 0xffffffffu : G.bytes[8 * (size_t)target + w];
+    }
+    int64_t pos = lo;
+    if (!(lo == a.vbeg || (lo > a.vbeg && a.in_v0[lo - 1] == (uint8_t)'\n'))) pos = lo < a.vbeg ? a.vbeg : first_line_start_safe(a, lo, hi);
+    while (pos < hi) {
+        int64_t e = pos;
+        uint32_t len = 0xffffffffu;
+        for (;; ++e) {
+            const uint8_t c = byte_at(e);
+            if (c == (uint8_t)'\n') break;
+            if (c == 0 && len == 0xffffffffu) len = (uint32_t)(e - pos);            // cut at the first NUL (Q2)
+        }
+        if (len == 0xffffffffu) {
+            if (e - pos > 0x7ffffff0ll) { status |= kStEditOverflow; break; }
+            len = (uint32_t)(e - pos);
+        }
+        bool ok = true;
+        uint32_t p = 0;
+        while (p < len) {                                                           // trre_nft.c:780-786
+            const uint8_t c0 = a.in_v0[pos + p];
+            uint32_t fw = first[0];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) fw = (c0 >> 5) == w ? first[w] : fw;
+            if (!((fw >> (c0 & 31u)) & 1u)) { put1(c0); ++p; continue; }
+            const int64_t r = attempt(pos, len, p);
+            if (r == -2) { ok = false; break; }
+            if (r > 0) p += (uint32_t)r;
+            else { put1(a.in_v0[pos + p]); ++p; }                                   // no match, or an empty one (its output is printed: Q3)
+        }
+        if (ok && attempt(pos, len, len) == -2) ok = false;                         // the empty tail (trre_nft.c:788)
+        if (!ok) break;
+        put1((uint8_t)'\n');
         pos = e + 1;
     }
     L.count = cnt;

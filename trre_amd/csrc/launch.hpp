@@ -53,6 +53,9 @@ bool fb_splice_fits(const void* hdr);
 void launch_g16_splice(const ScanArgs& a, const FbCopyArgs& ca, int g16_bytes, int p32_bytes, int64_t lane_bytes, int64_t n_chunks, void* stream);
 // generator modes (gen_block.hpp): which 1 count, 2 emit; a.blob = the tables of serialize_gen (runtime.cpp), chunks of 256 lanes
 void launch_gen(int which, const ScanArgs& a, const GenArgs& ga, int64_t lane_bytes, int64_t n_chunks, void* stream);
+// the backtracking fallback (gen_block.hpp: bt_lane): which 1 count, 2 emit; pool_blocks workgroups of 256 threads take the chunks in turn (ga holds
+// pool_blocks * 256 stacks and path buffers)
+void launch_bt(int which, const ScanArgs& a, const GenArgs& ga, int64_t lane_bytes, int64_t n_chunks, int64_t pool_blocks, uint32_t budget, void* stream);
 void launch_chunk_scan(const uint64_t* total, uint64_t* base, int64_t n_chunks, void* stream);
 void launch_bytemap(const ScanArgs& a, void* stream);
 void launch_nul_eol(const uint8_t* in, int64_t n, const uint64_t* pos, uint64_t* eol, uint32_t count, void* stream);

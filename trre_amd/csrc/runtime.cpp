@@ -136,7 +136,8 @@ struct trre_prog {
     std::vector<uint8_t> blob;
     std::vector<uint8_t> sblob;
     std::vector<uint8_t> gblob, rblob;
-    std::vector<uint8_t> nblob;       // generator modes: the enumeration's tables (gen_block.hpp)
+    std::vector<uint8_t> nblob;       // generator modes: the enumeration's tables (gen_block.hpp); scan mode, NFT engine: the same lists for the backtracking fallback
+    bool bt_ok = false;               // scan mode, NFT engine: nblob holds the backtracking fallback's tables
     int mask_bytes = 0;
     bool profiling = false;
     std::atomic<float> last_ms{-1.f};
@@ -369,14 +370,14 @@ void serialize_gen(const trre::GenTables& g, std::vector<uint8_t>& b) {
 bool is_generate(int mode) { return mode == TRRE_MODE_SCAN_ALL || mode == TRRE_MODE_MATCH_ALL; }
 bool is_stream(int fam) { return fam == TRRE_KERNEL_STREAM_LP || fam == TRRE_KERNEL_STREAM_GEN; }
 bool is_guided(int fam) { return fam == TRRE_KERNEL_GUIDED_LP || fam == TRRE_KERNEL_GUIDED_GEN; }
-bool is_gen(int fam) { return fam == TRRE_KERNEL_TILE_GEN || fam == TRRE_KERNEL_STREAM_GEN || fam == TRRE_KERNEL_GUIDED_GEN; }
+bool is_gen(int fam) { return fam == TRRE_KERNEL_TILE_GEN || fam == TRRE_KERNEL_STREAM_GEN || fam == TRRE_KERNEL_GUIDED_GEN || fam == TRRE_KERNEL_BACKTRACK; }
 bool is_guided_wide(const trre_prog& p, int fam) { return (fam == TRRE_KERNEL_GUIDED_LP || fam == TRRE_KERNEL_GUIDED_GEN) && p.gt.wide; }
 bool lp_inplace(uint32_t flags) { return (flags & trre::kFlagLengthPreserving) && (flags & trre::kFlagNoOverrun); }
 // the family that takes over when a length-preserving launch met a NUL, or a bounded stream table a long run
 int general_family(const trre_prog& p, bool stream_ok) {
     if (stream_ok && p.stt.ok) return TRRE_KERNEL_STREAM_GEN;
     if (p.gt.ok) return TRRE_KERNEL_GUIDED_GEN;
-    return TRRE_KERNEL_TILE_GEN;
+    return p.has_engine_tables ? TRRE_KERNEL_TILE_GEN : TRRE_KERNEL_BACKTRACK;
 }
 
 int auto_family(const trre_prog& p) {
@@ -398,6 +399,8 @@ int auto_family(const trre_prog& p) {
         if ((p.dt.flags & kFlagLengthPreserving) && (p.dt.flags & kFlagNoOverrun)) return TRRE_KERNEL_TILE_LP;
         return TRRE_KERNEL_TILE_GEN;
     }
+    // beyond every table form (more than 64 nodes, a backward automaton beyond the guided limits, no fold): the search itself
+    if (!p.has_engine_tables) return TRRE_KERNEL_BACKTRACK;
     return (p.nt.flags & kFlagLengthPreserving) ? TRRE_KERNEL_TILE_LP : TRRE_KERNEL_TILE_GEN;
 }
 
@@ -416,6 +419,7 @@ bool family_allowed(const trre_prog& p, int fam) {
     if (fam == TRRE_KERNEL_STREAM_LP) return p.stt.ok && lp_inplace(p.stt.flags);
     if (fam == TRRE_KERNEL_GUIDED_GEN) return p.gt.ok;
     if (fam == TRRE_KERNEL_GUIDED_LP) return p.gt.ok && lp_inplace(p.gt.fwd.flags) && !p.gt.wide;
+    if (fam == TRRE_KERNEL_BACKTRACK) return p.bt_ok;
     if (!p.has_engine_tables) return false;
     if (fam == TRRE_KERNEL_TILE_GEN) return true;
     if (p.engine == TRRE_ENGINE_DFT) {
@@ -527,6 +531,9 @@ int ensure_copy_workspace(ScanCtx* c, int64_t n_lanes) {
     return TRRE_OK;
 }
 
+// the backtracking fallback: sub-range per thread, frames (= bytes an attempt may consume) and path bytes per thread, workgroups in the pool, steps per sub-range
+constexpr int64_t kBtLaneBytes = 1024, kBtPoolBlocks = 256;
+constexpr uint32_t kBtFrames = 1024, kBtPathCap = 2048, kBtBudget = 16u << 20;
 int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap,
             hipStream_t stream) {
     using namespace trre;
@@ -561,10 +568,13 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
     args.dbg = emit_dbg;
     // a mask scratch left by an earlier, smaller scan must not be used: the kernel asks for one again
     args.gscratch = cx->scratch_bytes >= (n + 32) * (size_t)p->mask_bytes ? cx->d_scratch : nullptr;
-    const int chunk = is_stream(family) ? stream_chunk_bytes(family == TRRE_KERNEL_STREAM_LP ? 0 : 1)
-                                        : chunk_bytes(p->engine, p->mask_bytes);
-    const int threads = is_stream(family) ? stream_block_threads(family == TRRE_KERNEL_STREAM_LP ? 0 : 1)
-                                          : block_threads(p->engine, p->mask_bytes);
+    const bool backtrack = family == TRRE_KERNEL_BACKTRACK;
+    const int chunk = backtrack ? (int)kBtLaneBytes * 256
+                      : is_stream(family) ? stream_chunk_bytes(family == TRRE_KERNEL_STREAM_LP ? 0 : 1)
+                                          : chunk_bytes(p->engine, p->mask_bytes);
+    const int threads = backtrack ? 256
+                        : is_stream(family) ? stream_block_threads(family == TRRE_KERNEL_STREAM_LP ? 0 : 1)
+                                            : block_threads(p->engine, p->mask_bytes);
     int64_t n_chunks = (args.vend + chunk - 1) / chunk;
     const bool ent_lds = stt.ok && stt.ent.size() * 8 <= (size_t)StreamEngine::kLdsEntBytes;
     // stream families have three implementations (TRRE_STREAM_IMPL, for A/B measurements):
@@ -582,6 +592,12 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
     int64_t lane_auto = 2048;
     if (window)
         while (lane_auto < 16384 && (int64_t)n / (lane_auto * 2) >= 524288) lane_auto *= 2;
+    // (the count / emit pair on the 16-byte entries gains too — 'a:xyz' at 8 GiB: 920 GB/s with 2 KiB lanes, 967 with 8 KiB, 946 with
+    // 32 KiB; ' +: ' 896 / 947 / 805 — the guided families do not: 647 / 641; the large-table forms keep 2 KiB, what their event lists
+    // are sized for)
+    static const bool no_fb_env0 = getenv("TRRE_NO_FB") != nullptr;
+    if (family == TRRE_KERNEL_STREAM_GEN && stream_impl >= 1 && p->stt.g16_ok && !(p->stt.fb_ok && !no_fb_env0))
+        while (lane_auto < 8192 && (int64_t)n / (lane_auto * 2) >= 262144) lane_auto *= 2;
     const int64_t lane_bytes = lane_bytes_env > 0 ? (lane_bytes_env + 127) / 128 * 128 : lane_auto;
     const bool direct = (is_stream(family) && stream_impl >= 1) || is_guided(family);
     const bool direct_ent_lds = stt.ok && stt.ent.size() * 8 <= (size_t)direct_ent_lds_bytes();
@@ -617,7 +633,29 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
         if (p->profiling) HIP_TRY(hipEventRecord(cx->ev0, stream));
     }
     pd.timed = p->profiling;
-    if (family == TRRE_KERNEL_BYTEMAP) {
+    if (backtrack) {
+        // the search itself (gen_block.hpp: bt_lane): a pool of workgroups takes the chunks of 256 sub-ranges in turn, each thread
+        // with a stack and a path buffer of its own for the whole launch
+        const int64_t pool_blocks = n_chunks < kBtPoolBlocks ? n_chunks : kBtPoolBlocks;
+        const size_t need = (size_t)pool_blocks * 256 * ((size_t)kBtFrames * 16 + kBtPathCap);
+        if (cx->scratch_bytes < need) {
+            if (cx->d_scratch) (void)hipFree(cx->d_scratch);
+            cx->d_scratch = nullptr; cx->scratch_bytes = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&cx->d_scratch), need));
+            cx->scratch_bytes = need;
+        }
+        GenArgs ga{};
+        ga.stack = reinterpret_cast<uint32_t*>(cx->d_scratch);
+        ga.path = cx->d_scratch + (size_t)pool_blocks * 256 * kBtFrames * 16;
+        ga.frames = kBtFrames;
+        ga.path_cap = kBtPathCap;
+        args.blob = st->d_nblob;
+        static const uint32_t budget = getenv("TRRE_BT_BUDGET") ? (uint32_t)atoll(getenv("TRRE_BT_BUDGET")) : kBtBudget;
+        launch_bt(1, args, ga, kBtLaneBytes, n_chunks, pool_blocks, budget, stream);
+        launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);
+        launch_bt(2, args, ga, kBtLaneBytes, n_chunks, pool_blocks, budget, stream);
+        pd.total_at = cx->d_chunk_base + n_chunks;
+    } else if (family == TRRE_KERNEL_BYTEMAP) {
         args.nul_list = cx->d_status + 4;
         launch_bytemap(args, stream);
     } else if (family == TRRE_KERNEL_TILE_LP) {
@@ -877,10 +915,11 @@ int finish(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
         // (guided_build.cpp), the count pass names the first such lane in stream order and knows every lane's size: the
         // output up to that point is in the buffer and its length is reported with the error.  (The DFT binary dies of
         // unbounded recursion, its buffered output is lost: nothing to reproduce, *out_len = 0.)
-        if (p->engine != TRRE_ENGINE_NFT || !p->gt.ok) return fail(TRRE_E_DIVERGES, msg);
-        if (was.family != TRRE_KERNEL_GUIDED_GEN || was.patched) {
+        const bool knows_lane = (was.family == TRRE_KERNEL_GUIDED_GEN && !was.patched) || was.family == TRRE_KERNEL_BACKTRACK;
+        if (p->engine != TRRE_ENGINE_NFT || (!p->gt.ok && !p->bt_ok)) return fail(TRRE_E_DIVERGES, msg);
+        if (!knows_lane) {
             cx->patch_off = true;                              // (the count / emit pair knows every lane's size)
-            const int rc = again(TRRE_KERNEL_GUIDED_GEN);      // (comes back here through the branch below)
+            const int rc = again(p->gt.ok ? TRRE_KERNEL_GUIDED_GEN : TRRE_KERNEL_BACKTRACK);      // (comes back here through the branch below)
             cx->patch_off = false;
             return rc == TRRE_OK ? fail(TRRE_E_DEVICE, "error: a diverging scan did not diverge when it was run again") : rc;
         }
@@ -900,6 +939,10 @@ int finish(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
         }
         if (out_len) *out_len = (size_t)upto;
         return fail(TRRE_E_DIVERGES, msg);
+    }
+    if (was.family == TRRE_KERNEL_BACKTRACK && (status & kStEditOverflow)) {
+        if (out_len) *out_len = 0;
+        return fail(TRRE_E_UNSUPPORTED, "error: the search exceeds the backtracking fallback's limits on this input (steps per KiB, depth of an attempt or its output)");
     }
     if (status & kStNeedScratch) {
         // a line longer than the LDS tile met the non-deterministic engine: give it
@@ -1033,8 +1076,16 @@ int compile_impl(const std::string& pattern, int engine, trre_prog** out, int mo
             trace("guided tables");
             p->gt = build_guided_nft(nodes);
             trace("done");
-            // no kernel family can run this pattern (a bounded stream table needs general kernels behind it)
-            if (deferred && !p->gt.ok && (!p->stt.ok || p->stt.bounded)) throw *deferred;
+            // The backtracking fallback (gen_block.hpp: bt_lane) runs what no table form holds — more than 64 nodes with a backward
+            // automaton beyond the guided limits and no fold (round 3: TRRE_E_UNSUPPORTED) — and can be asked for on any pattern
+            // (trre_set_kernel: the differential tests do).  Its tables are the follow lists themselves.
+            {
+                GenTables lists;
+                lists.nodes = nodes;
+                lists.ok = true;
+                serialize_gen(lists, p->nblob);
+                p->bt_ok = true;
+            }
         }
         if (p->stt.ok) serialize_stream(p->stt, p->sblob);
         if (p->gt.ok) { serialize_stream(p->gt.fwd, p->gblob); serialize_rev(p->gt, p->rblob); }

@@ -1000,6 +1000,59 @@ __global__ __launch_bounds__(kGenThreads) void k_gen(ScanArgs a, GenArgs ga, int
     if (st && (threadIdx.x & (kWave - 1)) == 0) atomicOr(a.status, st);
 }
 
+// The backtracking fallback (gen_block.hpp: bt_lane): persistent workgroups, one chunk of 256 lanes per turn — a thread's
+// stack and path buffer are its own for the whole launch.
+template <int kMode>
+__global__ __launch_bounds__(kGenThreads) void k_bt(ScanArgs a, GenArgs ga, int64_t lane_bytes, int64_t n_chunks, uint32_t budget) {
+    __shared__ uint64_t part[kGenThreads / kWave];
+    __shared__ uint32_t wpart[kGenThreads / kWave];
+    const GenView G = gen_view(a.blob);
+    const int64_t slot = (int64_t)blockIdx.x * kGenThreads + threadIdx.x;
+    __shared__ uint32_t seen_status;
+    uint32_t st = 0;
+    for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        // (a sub-range gave up: the launch is an error whatever the others find — leave)
+        if (threadIdx.x == 0) seen_status = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (seen_status & kStEditOverflow) break;
+        const int64_t lane = chunk * kGenThreads + threadIdx.x;
+        uint64_t base = 0;
+        bool skip = false;
+        if (kMode == 2) {
+            const uint32_t mine = a.lane_counts[lane];
+            const uint32_t incl = wave_scan_incl(mine);
+            __syncthreads();
+            if ((threadIdx.x & (kWave - 1)) == kWave - 1) wpart[threadIdx.x / kWave] = incl;
+            __syncthreads();
+            uint32_t wbase = 0;
+            for (int w = 0; w < (int)threadIdx.x / kWave; ++w) wbase += wpart[w];
+            base = a.chunk_base[chunk] + wbase + incl - mine;
+            if (a.chunk_base[chunk] + a.chunk_total[chunk] > a.cap) { st |= kStCapacity; skip = true; }
+        }
+        DirectLane L;
+        uint32_t lst = 0;
+        if (!skip) bt_lane<kMode>(a, G, ga, slot, lane, lane_bytes, base, budget, L, lst);
+        if (lst & kStEditOverflow) atomicOr(a.status, kStEditOverflow);
+        if (kMode == 1 && (lst & kStDiverge)) atomicMax(a.status + 1, 0xffffffffu - (uint32_t)lane);     // (see k_stream_direct)
+        st |= lst;
+        if (kMode == 1) {
+            if (L.count > 0xffffffffull) { st |= kStCapacity; L.count = 0xffffffffull; }
+            a.lane_counts[lane] = (uint32_t)L.count;
+            const uint64_t wsum = wave_sum(L.count);
+            __syncthreads();
+            if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = wsum;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint64_t t = 0;
+                for (int w = 0; w < kGenThreads / kWave; ++w) t += part[w];
+                a.chunk_total[chunk] = t;
+            }
+        }
+    }
+    st = wave_or(st);
+    if (st && (threadIdx.x & (kWave - 1)) == 0) atomicOr(a.status, st);
+}
+
 // ------------------------------------------------------------------------------------------
 // memoryless byte map: out[v] = map[in[v]], 16 bytes per lane per step
 constexpr int kMapThreads = 256;
@@ -1491,6 +1544,12 @@ void launch_gen(int which, const ScanArgs& a, const GenArgs& ga, int64_t lane_by
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (which == 1) hipLaunchKernelGGL(k_gen<1>, dim3((unsigned)n_chunks), dim3(kGenThreads), 0, s, a, ga, lane_bytes);
     else hipLaunchKernelGGL(k_gen<2>, dim3((unsigned)n_chunks), dim3(kGenThreads), 0, s, a, ga, lane_bytes);
+}
+void launch_bt(int which, const ScanArgs& a, const GenArgs& ga, int64_t lane_bytes, int64_t n_chunks, int64_t pool_blocks, uint32_t budget, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned grid = (unsigned)(n_chunks < pool_blocks ? n_chunks : pool_blocks);
+    if (which == 1) hipLaunchKernelGGL(k_bt<1>, dim3(grid), dim3(kGenThreads), 0, s, a, ga, lane_bytes, n_chunks, budget);
+    else hipLaunchKernelGGL(k_bt<2>, dim3(grid), dim3(kGenThreads), 0, s, a, ga, lane_bytes, n_chunks, budget);
 }
 // the copy form's LDS fits
 bool fb_copy_fits(const void* hdr) {
