@@ -1,6 +1,12 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-for lb in 0 8192 16384 32768; do
-echo "== TRRE_LANE_BYTES=$lb"
-TRRE_LANE_BYTES=$lb python tools/kbench.py --case 'a:xyz;;dft;;printable;;auto' --case ' +: ;;nft;;printable;;auto' --case '(cat:dog|dog:cat);;nft;;catdog;;stream_gen' --bytes 8589934592 --steps 3 2>&1 | grep pattern | cut -c1-60,100-200
-done
+mkdir -p gpurun_out
+python bench.py > gpurun_out/bench_r04c.json 2> gpurun_out/bench_r04c.err
+tail -c 600 gpurun_out/bench_r04c.err
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/bench_r04c.json').read().strip().splitlines()[-1])
+print(d['value'], d['roofline']['frac'], d['cpu_baseline'])
+for k,v in d.get('other_configs',{}).items():
+    print(k, {kk:v[kk] for kk in v if kk in ('gbps_in','value','kernel','verified','verified_full','gbps','kernel_family','frac')})
+PY

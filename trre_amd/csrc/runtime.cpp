@@ -519,6 +519,7 @@ int ensure_patch_workspace(ScanCtx* c, int64_t n_pieces) {
 }
 
 constexpr uint32_t kCopyEvCap = 256;       // events per lane of the copy form (a 2 KiB sub-range of the dictionary corpus holds ~120)
+// (n_lanes counts rows of kCopyEvCap events: a lane of more than 2 KiB takes several)
 int ensure_copy_workspace(ScanCtx* c, int64_t n_lanes) {
     if (n_lanes <= c->copy_lanes) return TRRE_OK;
     (void)hipFree(c->d_cevents); (void)hipFree(c->d_chdr);
@@ -593,10 +594,9 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
     if (window)
         while (lane_auto < 16384 && (int64_t)n / (lane_auto * 2) >= 524288) lane_auto *= 2;
     // (the count / emit pair on the 16-byte entries gains too — 'a:xyz' at 8 GiB: 920 GB/s with 2 KiB lanes, 967 with 8 KiB, 946 with
-    // 32 KiB; ' +: ' 896 / 947 / 805 — the guided families do not: 647 / 641; the large-table forms keep 2 KiB, what their event lists
-    // are sized for)
-    static const bool no_fb_env0 = getenv("TRRE_NO_FB") != nullptr;
-    if (family == TRRE_KERNEL_STREAM_GEN && stream_impl >= 1 && p->stt.g16_ok && !(p->stt.fb_ok && !no_fb_env0))
+    // 32 KiB; ' +: ' 896 / 947 / 805 — and so does the mark + splice pair of a large table, its event lists growing with the sub-range:
+    // cfg 5 at 4 GiB 594 / 663 (4 KiB) / 675; the guided families do not: 647 / 641)
+    if (family == TRRE_KERNEL_STREAM_GEN && stream_impl >= 1 && (p->stt.g16_ok || p->stt.fb_ok))
         while (lane_auto < 8192 && (int64_t)n / (lane_auto * 2) >= 262144) lane_auto *= 2;
     const int64_t lane_bytes = lane_bytes_env > 0 ? (lane_bytes_env + 127) / 128 * 128 : lane_auto;
     const bool direct = (is_stream(family) && stream_impl >= 1) || is_guided(family);
@@ -709,12 +709,13 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
         static const bool no_copy_env = getenv("TRRE_NO_FB_COPY") != nullptr;
         if (!no_copy_env && !fb_emit_env && !cx->patch_off && !p->copy_form_off.load() && lane_bytes % 64 == 0 && fb_copy_fits(p->sblob.data())) {
             const int64_t n_lanes = n_chunks * direct_block_threads();
-            rc = ensure_copy_workspace(cx, n_lanes);
+            const int64_t ev_rows = (lane_bytes + 2047) / 2048;                  // (the event list grows with the sub-range)
+            rc = ensure_copy_workspace(cx, n_lanes * ev_rows);
             if (rc) return rc;
             FbCopyArgs ca{};
             ca.events = cx->d_cevents;
             ca.lane_hdr = cx->d_chdr;
-            ca.ev_cap = kCopyEvCap;
+            ca.ev_cap = kCopyEvCap * (uint32_t)ev_rows;
             launch_fb_mark(args, ca, p->sblob.data(), lane_bytes, n_chunks, stream);
             launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);
             // second pass: the wave-cooperative splice (splice_block.hpp; round 4), or — TRRE_NO_FB_SPLICE=1 for A/B runs, and for tables
