@@ -596,10 +596,13 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
     // (the count / emit pair on the 16-byte entries gains too — 'a:xyz' at 8 GiB: 920 GB/s with 2 KiB lanes, 967 with 8 KiB, 946 with
     // 32 KiB; ' +: ' 896 / 947 / 805 — and so does the mark + splice pair of a large table, its event lists growing with the sub-range:
     // cfg 5 at 4 GiB 594 / 663 (4 KiB) / 675; the guided families do not: 647 / 641)
-    if (family == TRRE_KERNEL_STREAM_GEN && stream_impl >= 1 && (p->stt.g16_ok || p->stt.fb_ok))
+    // (the guided families' forward passes gain 2 % at 8 GiB, their backward pass loses 15 %: it keeps 2 KiB)
+    if ((family == TRRE_KERNEL_STREAM_GEN && stream_impl >= 1 && (p->stt.g16_ok || p->stt.fb_ok)) || (is_guided(family) && !p->gt.wide))
         while (lane_auto < 8192 && (int64_t)n / (lane_auto * 2) >= 262144) lane_auto *= 2;
     const int64_t lane_bytes = lane_bytes_env > 0 ? (lane_bytes_env + 127) / 128 * 128 : lane_auto;
     const bool direct = (is_stream(family) && stream_impl >= 1) || is_guided(family);
+    static const int64_t rev_lane_env = getenv("TRRE_REV_LANE_BYTES") ? atoll(getenv("TRRE_REV_LANE_BYTES")) : 0;      // (A/B runs: the backward pass's sub-ranges)
+    const int64_t rev_lane_bytes = rev_lane_env > 0 ? (rev_lane_env + 127) / 128 * 128 : (lane_bytes_env > 0 ? lane_bytes : 2048);
     const bool direct_ent_lds = stt.ok && stt.ent.size() * 8 <= (size_t)direct_ent_lds_bytes();
     const bool g16_slow = (stt.flags & kFlagG16Slow) != 0;
     static const bool no_nib = getenv("TRRE_NO_NIBBLES") != nullptr;      // A/B: one symbol per byte
@@ -686,7 +689,7 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
         // them (TRRE_LP_RING=1: the older in-place walker with an LDS ring, 2.3x slower; kept for A/B runs)
         static const bool lp_ring = getenv("TRRE_LP_RING") != nullptr;
         const int g16 = stt.g16_ok && !no_g16_env ? (int)(align_up(stt.g16.size() * 4, 16) + stt.p32.size() * 4) : 0;   // LDS room: 16-byte + pair forms
-        if (is_guided(family)) launch_rev_sweep(args, (int)p->gt.n_rev * 256, lane_bytes, stream, sym_mode == 2);
+        if (is_guided(family)) launch_rev_sweep(args, (int)p->gt.n_rev * 256, rev_lane_bytes, stream, sym_mode == 2);
         static const bool rev_only = getenv("TRRE_REV_DBG") != nullptr;       // experiments on the backward pass alone (its output may be void)
         if (is_guided(family) && rev_only) {
         } else if (lp_ring) {
@@ -736,7 +739,7 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
         }
     } else if (direct) {
         const int g16 = stt.g16_ok && !no_g16_env ? (int)(align_up(stt.g16.size() * 4, 16) + stt.p32.size() * 4) : 0;   // LDS room: 16-byte + pair forms
-        if (is_guided(family)) launch_rev_sweep(args, (int)p->gt.n_rev * 256, lane_bytes, stream, sym_mode == 2);
+        if (is_guided(family)) launch_rev_sweep(args, (int)p->gt.n_rev * 256, rev_lane_bytes, stream, sym_mode == 2);
         // TRRE_PATCH=1 (experimental, off by default): ONE walk that lists the edits per 64-byte piece, then a patch pass that
         // copies the input around them (patch_block.hpp) — instead of a count walk and an emit walk that appends byte by byte.
         // Correct (parity-tested on the host shim and on the GPU) but slower as it stands: 'a:xyz' at 1 GiB record 0.78 ms +
