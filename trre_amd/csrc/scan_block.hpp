@@ -725,6 +725,13 @@ constexpr int kRingStride = 132;
 constexpr uint32_t kRingBytes = 128;
 constexpr uint32_t kUnitBytes = 64;
 constexpr int kWaveScratchBytes = 16 * 16;     // per wave: 16 posted units x {ring position, address lo, address hi, -}
+// (the ablation switches of TRRE_EMIT_DBG sit on the per-byte path: a scalar test and a branch per append — they exist in builds
+// with -DTRRE_DBG_SWITCHES only)
+#if defined(TRRE_DBG_SWITCHES)
+#define TRRE_STAGE_DBG(s, bit) ((s).dbg & (bit))
+#else
+#define TRRE_STAGE_DBG(s, bit) 0u
+#endif
 struct Stage {
     uint8_t* buf;        // the lane's ring: kRingBytes, 4-byte aligned
     uint8_t* g0;         // 64-byte aligned output address of stream offset 0
@@ -772,7 +779,7 @@ struct __attribute__((packed)) UnalignedU64 { uint64_t v; };
 // 8 bytes at the fill position, of which the first n (0..8) count
 TRRE_HD void bstage_put8(BStage& s, uint64_t v, uint32_t n) {
     const uint32_t o = s.wp & (kRingBytes - 1u);
-    if (!(s.dbg & 2u)) {
+    if (!TRRE_STAGE_DBG(s, 2u)) {
         // (an LDS store off its natural alignment is replayed at 64 cycles per wave instruction — two 4-byte stores
         // instead of one 8-byte store were measured slower still: 5.4 ms against 3.8 ms for the pass)
         reinterpret_cast<UnalignedU64*>(s.buf + o)->v = v;
@@ -784,7 +791,7 @@ TRRE_HD void bstage_put8(BStage& s, uint64_t v, uint32_t n) {
 }
 // one byte at the fill position, counted or not
 TRRE_HD void bstage_put1(BStage& s, uint32_t b, uint32_t n) {
-    if (!(s.dbg & 2u)) s.buf[s.wp & (kRingBytes - 1u)] = (uint8_t)b;
+    if (!TRRE_STAGE_DBG(s, 2u)) s.buf[s.wp & (kRingBytes - 1u)] = (uint8_t)b;
     s.wp += n;
 }
 TRRE_HD uint32_t stage_fill_end(const Stage& s) { return s.wp + (s.sh >> 3); }     // stream offset of the next byte
@@ -797,15 +804,16 @@ TRRE_HD uint8_t* stage_out_ptr(const St& s) { return s.g0 + stage_fill_end(s); }
 // No branch: the dword being filled goes to the ring on every append (complete or not — it is written again until it
 // is), and what it could not take starts the next one.  (The first version kept a 64-bit window and stored a dword when
 // it was complete: a compare, an exec mask and two moves more per append — 15 instructions against 11.)
-TRRE_HD void stage_append_n4(Stage& s, uint32_t v, uint32_t n) {
+TRRE_HD void stage_append_bits(Stage& s, uint32_t v, uint32_t n8) {     // n8 = 8 x the bytes that count
     const uint64_t vv = (uint64_t)v << s.sh;
     const uint32_t x = s.lo | (uint32_t)vv;
-    if (!(s.dbg & 2u)) *reinterpret_cast<uint32_t*>(s.buf + (s.wp & (kRingBytes - 1u))) = x;
-    const uint32_t t = s.sh + 8u * n;     // <= 56: at most one dword completed
+    if (!TRRE_STAGE_DBG(s, 2u)) *reinterpret_cast<uint32_t*>(s.buf + (s.wp & (kRingBytes - 1u))) = x;
+    const uint32_t t = s.sh + n8;         // <= 56: at most one dword completed
     s.lo = t >= 32u ? (uint32_t)(vv >> 32) : x;
     s.wp += (t >> 5) << 2;
     s.sh = t & 31u;
 }
+TRRE_HD void stage_append_n4(Stage& s, uint32_t v, uint32_t n) { stage_append_bits(s, v, 8u * n); }
 TRRE_HD void stage_append4(Stage& s, uint32_t v, uint32_t n) { stage_append_n4(s, v, n); }
 // the same for up to 8 bytes (the second half only when some lane of the wave has more than 4)
 TRRE_HD void stage_append(Stage& s, uint64_t v, uint32_t n) {
@@ -837,7 +845,7 @@ TRRE_HD void stage_store_own_unit(St& s) {        // the unit at stream offset f
     } else {
         const uint32_t* s32 = reinterpret_cast<const uint32_t*>(s.buf + (s.fp & (kRingBytes - 1u)));
         U128* dst = reinterpret_cast<U128*>(s.g0 + s.fp);
-        if (!(s.dbg & 1u)) {
+        if (!TRRE_STAGE_DBG(s, 1u)) {
             dst[0] = U128{s32[0], s32[1], s32[2], s32[3]};
             dst[1] = U128{s32[4], s32[5], s32[6], s32[7]};
             dst[2] = U128{s32[8], s32[9], s32[10], s32[11]};
@@ -896,7 +904,7 @@ TRRE_HD void stage_flush(St& s) {
                 const uint32_t* src = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(s.wsc) + (ptrdiff_t)(int32_t)slot[0] + 16 * (ptrdiff_t)(lid & 3u));
                 uint8_t* dst = reinterpret_cast<uint8_t*>((uintptr_t)((uint64_t)slot[2] << 32 | slot[1])) + 16u * (lid & 3u);
                 const U128 q{src[0], src[1], src[2], src[3]};
-                if (!(s.dbg & 1u)) *reinterpret_cast<U128*>(dst) = q;
+                if (!TRRE_STAGE_DBG(s, 1u)) *reinterpret_cast<U128*>(dst) = q;
             }
             __builtin_amdgcn_wave_barrier();
             if (post) s.fp += kUnitBytes;
@@ -1545,7 +1553,7 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const U128 g = *reinterpret_cast<const U128*>(T.g16 + row + (kk[j] << 4));
-                stage_append_n4(S, perm_b32(w >> (8 * j), g.z, g.w), g.y & 7u);
+                stage_append_bits(S, perm_b32(w >> (8 * j), g.z, g.w), g.y >> 24);      // ([31:24] of the entry: 8 x the bytes it emits)
                 seen |= g.y;
                 if (kHasSlow) {
                     if (TRRE_WAVE_ANY(g.y & 128u)) {
@@ -1562,7 +1570,7 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
     uint32_t seen2 = 0;                           // metas of pair entries (their flag bits differ from the 16-byte form's)
     auto single_emit = [&](const uint32_t wj, const uint32_t k) {       // one byte through the 16-byte entries, no end-of-lane test
         const U128 g = *reinterpret_cast<const U128*>(T.g16 + row + (k << 4));
-        stage_append_n4(S, perm_b32(wj, g.z, g.w), g.y & 7u);
+        stage_append_bits(S, perm_b32(wj, g.z, g.w), g.y >> 24);
         seen |= g.y;
         if (kHasSlow) {
             if (TRRE_WAVE_ANY(g.y & 128u)) {
@@ -1652,7 +1660,9 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
                         const uint64_t e2 = *reinterpret_cast<const uint64_t*>(ep + 16);
                         hi4 = perm_b32(ws, (uint32_t)e2, (uint32_t)(e2 >> 32));
                     }
-                    stage_append(S, (uint64_t)perm_b32(ws, e.z, e.w) | (uint64_t)hi4 << 32, n);
+                    // ([31:24] of the entry: 8 x the bytes of its first half that count)
+                    stage_append_bits(S, perm_b32(ws, e.z, e.w), e.y >> 24);
+                    if (TRRE_WAVE_ANY(n > 4u)) stage_append_n4(S, hi4, n > 4u ? n - 4u : 0u);
                     seen2 |= e.y;
                     row = e.x;
                 }

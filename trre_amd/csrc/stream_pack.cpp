@@ -119,7 +119,9 @@ void build_gen16(StreamTables& t, const StreamPackInput& in) {
                    // [10] a transition of SKIP / DONE (nobody's bytes), [11] an edit for the mark pass of the splice form: [9] and not [10]
                    (silent ? 1024u : 0u) | (!silent && !(ident && !x.ovf && !x.diverge) ? 2048u : 0u) |
                    // [9] an edit (not the identity), [23:16] what it adds: bytes emitted - 1 (signed; a slow entry counts as 0 here)
-                   (((uint32_t)(int32_t)((slow ? 0 : (int)n) - 1) & 0xffu) << 16);
+                   (((uint32_t)(int32_t)((slow ? 0 : (int)n) - 1) & 0xffu) << 16) |
+                   // [31:24] 8 x the bytes a fast entry emits (the emit walk adds it to its bit position as it is)
+                   ((slow ? 0u : 8u * (uint32_t)n) << 24);
             uint32_t bytes = 0, sel = 0x0c0c0c0cu;                       // constant 0x00 everywhere
             if (!slow) {
                 sel = 0;
@@ -166,7 +168,9 @@ void build_pairs(StreamTables& t, const StreamPackInput& in) {
                 const bool edit = (!silent_a && !ident(a, k0)) || (!silent_b && !ident(b, k1));
                 e[1] = (slow ? 128u : (uint32_t)seq.size()) | ((a.diverge || b.diverge) ? 16u : 0u) | ((a.eol || b.eol) ? 32u : 0u) |
                        ((a.ovf || b.ovf) ? 64u : 0u) | (edit ? 512u : 0u) | (silent_a ? 1024u : 0u) |
-                       (((in.col_kind[k0] == kColNul && !silent_a) || (in.col_kind[k1] == kColNul && !silent_b)) ? 256u : 0u);
+                       (((in.col_kind[k0] == kColNul && !silent_a) || (in.col_kind[k1] == kColNul && !silent_b)) ? 256u : 0u) |
+                       // [31:24] 8 x the bytes of the first half that count (the emit walk adds it to its bit position as it is)
+                       ((slow ? 0u : 8u * (uint32_t)std::min<size_t>(seq.size(), 4)) << 24);
                 if (slow) t.p32_slow = true;
                 for (int half = 0; half < 2; ++half) {
                     uint32_t bytes = 0, sel = 0;
