@@ -18,6 +18,7 @@
 #include "../trre_amd/csrc/scan_block.hpp"
 #include "../trre_amd/csrc/splice_block.hpp"
 #include "../trre_amd/csrc/gen_block.hpp"
+#include "../trre_amd/csrc/guard_block.hpp"
 
 using namespace trre;
 
@@ -899,6 +900,64 @@ int shim_backtrack(const uint8_t* nblob, int geo, const uint8_t* in, size_t n, i
         if (L.count != cnt[lane]) status |= 1u << 30;                     // count and emit passes disagree
     }
     *status_out = status;
+    return 0;
+}
+
+// The stack guard as the runtime drives it (guard_block.hpp): probe the windows, the runs of flagged windows, the reference's
+// search on the lines that cover them; the first line that overflows again with its output.  *hit: 0 none, 1 a line overflowed
+// (*line_start, out[0, *part) = what the reference had printed of it), 2 a line was not decided.
+int shim_guard(const uint8_t* kblob, const uint8_t* in, size_t n, int in_mis, uint64_t budget, int* hit, uint64_t* line_start, uint8_t* out, size_t cap,
+               size_t* part) {
+    *hit = 0; *line_start = 0; *part = 0;
+    if (n == 0) return 0;
+    const GuardBlobHeader& h = *reinterpret_cast<const GuardBlobHeader*>(kblob);
+    std::vector<uint8_t> ibuf(n + 64, 0xAA);
+    uint8_t* ia = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(ibuf.data()) + 15) & ~(uintptr_t)15) + in_mis;
+    std::memcpy(ia, in, n);
+    ScanArgs a{};
+    const int64_t al = (int64_t)(reinterpret_cast<uintptr_t>(ia) & 15u);
+    a.in_v0 = ia - al;
+    a.vbeg = al;
+    a.vend = al + (int64_t)n;
+    const int64_t n_win = ((int64_t)n + h.window - 1) / h.window;
+    std::vector<GuardRun> runs;
+    for (int64_t w = 0; w < n_win;) {
+        if (!guard_probe(a, a.vbeg + w * h.window, a.vbeg + (w + 1) * h.window)) { ++w; continue; }
+        int64_t e = w;
+        while (e + 1 < n_win && guard_probe(a, a.vbeg + (e + 1) * h.window, a.vbeg + (e + 2) * h.window)) ++e;
+        runs.push_back(GuardRun{(uint32_t)w, (uint32_t)e});
+        w = e + 1;
+    }
+    if (runs.empty()) return 0;
+    std::vector<GuardResult> res(runs.size());
+    std::vector<uint32_t> stack((size_t)kGuardStackMax * 3 * 2);
+    GuardArgs ga{};
+    ga.blob = kblob;
+    ga.runs = runs.data();
+    ga.results = res.data();
+    ga.stack = stack.data();
+    ga.budget = budget;
+    ga.obuf = nullptr;
+    ga.obuf_cap = 0xffffffffu;
+    for (size_t r = 0; r < runs.size(); ++r) guard_line<false>(a, ga, (int64_t)(r & 1), (int64_t)r);
+    size_t bad = runs.size();
+    for (size_t r = 0; r < runs.size(); ++r) {
+        if (res[r].status == 1u) { bad = r; break; }
+        if (res[r].status == 2u) *hit = 2;
+    }
+    if (bad == runs.size()) return 0;
+    *hit = 1;
+    *line_start = res[bad].line_start;
+    std::vector<uint8_t> obuf(16 * ((size_t)res[bad].out_len + 1) + 65536);
+    ga.runs = runs.data() + bad;
+    ga.results = res.data() + bad;
+    ga.obuf = obuf.data();
+    ga.obuf_cap = (uint32_t)obuf.size();
+    ga.out = out;
+    ga.out_cap = cap;
+    guard_line<true>(a, ga, 0, 0);
+    if (res[bad].status != 1u) return 3;
+    *part = res[bad].out_len;
     return 0;
 }
 

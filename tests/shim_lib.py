@@ -13,7 +13,7 @@ ST_NUL, ST_DIVERGE, ST_CAPACITY, ST_LONGLINE, ST_NEEDSCRATCH, ST_OVERFLOW, ST_MI
 
 
 def build():
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("scan_block.hpp", "scan_core.hpp", "device_blob.hpp", "splice_block.hpp", "patch_block.hpp", "gen_block.hpp")]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("scan_block.hpp", "scan_core.hpp", "device_blob.hpp", "splice_block.hpp", "patch_block.hpp", "gen_block.hpp", "guard_block.hpp")]
     if os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(d) for d in deps):
         return SO
     os.makedirs(os.path.dirname(SO), exist_ok=True)
@@ -40,6 +40,8 @@ def lib():
                                     ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_uint32)]
         L.shim_backtrack.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
                                      ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_uint32)]
+        L.shim_guard.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(ctypes.c_int),
+                                 ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
         _lib = L
     return _lib
 
@@ -192,6 +194,21 @@ def scan_like_runtime(prog, data, geo=1, family=None, in_mis=0, out_mis=0):
         if st & ST_DIVERGE:
             raise RuntimeError("diverges")
     return out
+
+
+def stack_guard(prog, data, in_mis=0, budget=1 << 27):
+    """the stack guard's bodies on the host, as the runtime drives them: None when the pattern has no guard; else (hit, line_start,
+    the part of that line's output the reference had printed) — hit 0: no line overflows, 1: one does, 2: a line was not decided"""
+    kblob = prog.export_guard_tables()
+    if not kblob:
+        return None
+    cap = 16 * len(data) + 65536
+    out = ctypes.create_string_buffer(cap)
+    hit, ls, part = ctypes.c_int(), ctypes.c_uint64(), ctypes.c_size_t()
+    rc = lib().shim_guard(kblob, data, len(data), in_mis, budget, ctypes.byref(hit), ctypes.byref(ls), out, cap, ctypes.byref(part))
+    if rc:
+        raise RuntimeError("shim rc %d" % rc)
+    return hit.value, ls.value, out.raw[:part.value]
 
 
 BACKTRACK = 30                                       # the backtracking fallback (ABI family 9)

@@ -148,26 +148,70 @@ def test_divergence_leaves_what_the_reference_had_printed():
             assert e.value.code == trre_amd.api.E_DIVERGES and e.value.partial == o_head * 11 + want, (pat, kw, "second chunk")
 
 
-def test_stack_limit_is_a_documented_difference():
-    """The reference's backtracking stack holds at most 65 536 live alternatives (trre_nft.c:35-36,548-556): a greedy
-    loop over a run of 65 536 bytes exits 1 ("stack max capacity reached") although the search would succeed.  The GPU
-    path never explores failing alternatives and has no such stack: it prints the match the unbounded search finds.
-    include/trre_mi355x.h documents the difference; this test pins both sides of it."""
+def test_stack_limit_of_the_reference_search():
+    """The reference's backtracking stack holds at most 65 536 live alternatives (trre_nft.c:35-36,548-556): a greedy loop over a
+    run of 65 536 bytes exits 1 ("stack max capacity reached") with what it had printed, although the search would succeed.
+    Rounds 1-3 printed the match (a documented deviation); the stack guard (guard_block.hpp) finds the lines long enough for
+    that, runs the reference's search on them and answers like the reference: every family, device and host buffers, in place."""
+    import torch
     from oracle_lib import OracleError
-    short, long_ = b"x" + b" " * 65535 + b"y\n", b"x" + b" " * 70000 + b"y\n"
-    o = Oracle(" +: ", "nft")
-    assert o.scan(short) == b"x y\n"
-    with pytest.raises(OracleError):                     # the oracle models the limit (and so does the reference binary)
-        o.scan(long_)
-    p = prog(" +: ", "nft")
-    assert gpu_scan(p, short) == b"x y\n"
-    assert gpu_scan(p, long_) == b"x y\n"               # the documented deviation
-    if ref_available():
-        import subprocess
-        import os
-        from oracle_lib import REF_DIR
-        r = subprocess.run([os.path.join(REF_DIR, "trre"), " +: "], input=long_, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-        assert r.returncode == 1 and r.stderr.startswith(b"error: stack max capacity reached")
+    for pat, run, close in [(" +: ", b" ", b"y"), ("(a|b)*c:x", b"ab", b"c"), ("[a-z]+ing:X", b"q", b"ing")]:
+        o = Oracle(pat, "nft")
+        p = prog(pat, "nft")
+        rng = random.Random(5)
+        head = corpus.word_soup(rng, 200000)
+        short = head + b"x" + run * (30000 // len(run)) + close + b"\n" + head
+        assert gpu_scan(p, short) == o.scan(short), pat
+        long_ = head + b"x" + run * (70000 // len(run)) + close + b"\nmore lines\n" + b"x" + run * (80000 // len(run)) + close + b"\n" + head
+        with pytest.raises(OracleError) as oe:              # the oracle models the limit (and so does the reference binary)
+            o.scan(long_)
+        want = oe.value.partial
+        assert want.startswith(o.scan(head)) and len(want) < len(head) + 200000
+        for fam in [trre_amd.KERNEL_AUTO] + [f for f in p.allowed_kernels() if f != trre_amd.KERNEL_BACKTRACK]:
+            with pytest.raises(trre_amd.TrreError) as e:
+                gpu_scan(p, long_, fam)
+            assert e.value.code == trre_amd.api.E_DIVERGES and "stack max capacity reached" in e.value.message, (pat, fam)
+            assert e.value.partial.cpu().numpy().tobytes() == want, (pat, fam)
+        for kw in ({}, {"device_mask": 0}):                  # host buffers, chunks and shards
+            with pytest.raises(trre_amd.TrreError) as e:
+                p.scan(long_, **kw)
+            assert e.value.code == trre_amd.api.E_DIVERGES and e.value.partial == want, (pat, kw)
+            with pytest.raises(trre_amd.TrreError) as e:
+                p.scan(head * 200 + long_, **kw)             # the bad line in a later chunk (40 MB of clean lines first)
+            assert e.value.partial == o.scan(head) * 200 + want, (pat, kw)
+        if ref_available() and pat == " +: ":
+            import subprocess
+            import os
+            from oracle_lib import REF_DIR
+            r = subprocess.run([os.path.join(REF_DIR, "trre"), pat], input=long_, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert r.returncode == 1 and r.stderr.startswith(b"error: stack max capacity reached") and r.stdout == want
+    # in place (a length-preserving pattern with a loop): the guard looks before the launch, the lines before the bad one are
+    # scanned in place, the bad line's part follows them
+    pat = "(a:x)*b"
+    p = prog(pat, "nft")
+    data = b"aab ab\n" * 1000 + b"a" * 70000 + b"b\n" + b"tail\n"
+    with pytest.raises(OracleError) as oe:
+        Oracle(pat, "nft").scan(data)
+    if trre_amd.KERNEL_STREAM_LP in p.allowed_kernels() or trre_amd.KERNEL_GUIDED_LP in p.allowed_kernels():
+        t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+        with pytest.raises(trre_amd.TrreError) as e:
+            p.scan_tensor(t, out=t)
+        assert e.value.code == trre_amd.api.E_DIVERGES and e.value.partial.cpu().numpy().tobytes() == oe.value.partial
+    with pytest.raises(trre_amd.TrreError) as e:
+        gpu_scan(p, data)
+    assert e.value.partial.cpu().numpy().tobytes() == oe.value.partial
+    # match mode (trre -m) runs the same search: one attempt per line
+    pat = "(a|b)*c"
+    pm = trre_amd.Program(pat, "nft", mode="match")
+    data = b"abc\nxx\nbbac\n" * 500 + b"ab" * 35000 + b"c\nabc\n"
+    with pytest.raises(OracleError) as oe:
+        Oracle(pat, "nft").match(data)
+    assert oe.value.partial == b"abc\nbbac\n" * 500
+    with pytest.raises(trre_amd.TrreError) as e:
+        gpu_scan(pm, data)
+    assert e.value.code == trre_amd.api.E_DIVERGES and e.value.partial.cpu().numpy().tobytes() == oe.value.partial
+    ok = b"abc\nxx\nbbac\n" * 500 + b"ab" * 15000 + b"c\nabc\n"
+    assert gpu_scan(pm, ok) == Oracle(pat, "nft").match(ok)
 
 
 def test_every_kernel_family_agrees_on_gpu():

@@ -169,6 +169,13 @@ class Program:
         lib().trre_export_guided_tables(self._h, 2, buf, n)
         return buf.raw[:n]
 
+    def export_guard_tables(self):
+        """the stack guard's tables (guard_block.hpp), or b"" when the pattern cannot exhaust the reference's stack"""
+        n = lib().trre_export_guided_tables(self._h, 3, None, 0)
+        buf = ctypes.create_string_buffer(max(n, 1))
+        lib().trre_export_guided_tables(self._h, 3, buf, n)
+        return buf.raw[:n]
+
     def allowed_kernels(self):
         ok = []
         for fam in (KERNEL_BYTEMAP, KERNEL_TILE_LP, KERNEL_TILE_GEN, KERNEL_STREAM_LP, KERNEL_STREAM_GEN, KERNEL_GUIDED_LP,

@@ -371,6 +371,17 @@ struct GenTables {
     std::vector<uint64_t> viable;             // [n_rev][viable_words]: bit t = node t is worth entering at a position with this symbol
 };
 GenTables build_gen_tables(const Nft& nft, bool match_mode);
+
+// ---- the stack guard (stack_guard.cpp, guard_block.hpp): which lines can exhaust the reference's 65 536-item stack ----
+struct GuardTables {
+    bool on = false;                 // the pattern can fill the stack on a long enough line
+    bool too_deep = false;           // ... but lines of under 1 KiB could: not guarded (documented deviation)
+    uint32_t d = 0;                  // items per consumed byte, at most
+    uint32_t l_min = 0, window = 0;  // lines shorter than l_min cannot overflow; the probe's window
+    uint32_t start = 0;
+    std::vector<uint32_t> states;    // [n][4]: kind | val << 8, a, b, 0 (NKind order)
+};
+GuardTables build_guard(const Nft& nft);
 // in[0, n): the whole buffer (records end at '\n'; the last byte of the buffer ends its record whatever it is, trre_nft.c:777);
 // sym[i]: the backward pass's symbol of byte i.  Appends what the reference prints; false: a path ran into an epsilon cycle
 // (the reference exits 1 there, `out` holds what it had printed).

@@ -8,6 +8,7 @@ struct ScanArgs;
 struct PatchArgs;
 struct FbCopyArgs;
 struct GenArgs;
+struct GuardArgs;
 
 constexpr int kEngineNft = 0, kEngineDft = 1;
 
@@ -53,6 +54,10 @@ bool fb_splice_fits(const void* hdr);
 void launch_g16_splice(const ScanArgs& a, const FbCopyArgs& ca, int g16_bytes, int p32_bytes, int64_t lane_bytes, int64_t n_chunks, void* stream);
 // generator modes (gen_block.hpp): which 1 count, 2 emit; a.blob = the tables of serialize_gen (runtime.cpp), chunks of 256 lanes
 void launch_gen(int which, const ScanArgs& a, const GenArgs& ga, int64_t lane_bytes, int64_t n_chunks, void* stream);
+// the stack guard (guard_block.hpp): flags = a bit per window of `window` bytes without a '\n' (u64 per 64 windows, room for a multiple
+// of 256 windows); then the reference's search on the lines that cover the runs of such windows — `slots` stacks, a thread each
+void launch_guard_probe(const ScanArgs& a, int64_t window, int64_t n_windows, uint64_t* flags, void* stream);
+void launch_guard(bool out, const ScanArgs& a, const GuardArgs& ga, int64_t n_runs, int64_t slots, void* stream);
 // the backtracking fallback (gen_block.hpp: bt_lane): which 1 count, 2 emit; pool_blocks workgroups of 256 threads take the chunks in turn (ga holds
 // pool_blocks * 256 stacks and path buffers)
 void launch_bt(int which, const ScanArgs& a, const GenArgs& ga, int64_t lane_bytes, int64_t n_chunks, int64_t pool_blocks, uint32_t budget, void* stream);

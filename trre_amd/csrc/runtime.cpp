@@ -26,6 +26,7 @@
 #include "scan_block.hpp"
 #include "splice_block.hpp"
 #include "gen_block.hpp"
+#include "guard_block.hpp"
 
 namespace {
 
@@ -55,6 +56,10 @@ struct Pending {
     int count = 0;          // launches in the current batch
     const uint64_t* total_at = nullptr;   // general families: where the launch leaves its output size
     bool patched = false;                 // the launch was a record + patch pair (patch_block.hpp), not a count / emit pair
+    // the stack guard found, before an in-place launch, a line on which the reference's search runs out of stack: nothing was launched
+    bool guard_hit = false;
+    uint64_t guard_line = 0;              // where that line starts
+    uint32_t guard_part = 0;              // bytes of its output the reference had printed (in ScanCtx::d_gout), or ~0u: not available
 };
 
 // Everything ONE in-flight scan needs on a device besides the tables: status words, the workspaces of the
@@ -88,6 +93,17 @@ struct ScanCtx {
     uint32_t* d_cevents = nullptr;
     uint32_t* d_chdr = nullptr;
     int64_t copy_lanes = 0;
+    // the stack guard (guard_block.hpp): window flags, runs of flagged windows, results, the pool of stacks, the one line's output
+    uint64_t* d_gflags = nullptr;
+    size_t gflags_words = 0;
+    uint8_t* d_gruns = nullptr;       // GuardRun[gruns_cap], then GuardResult[gruns_cap]
+    size_t gruns_cap = 0;
+    uint32_t* d_gstack = nullptr;     // [kGuardSlots][65 536][3]
+    uint8_t* d_gobuf = nullptr;
+    size_t gobuf_cap = 0;
+    uint8_t* d_gout = nullptr;
+    size_t gout_cap = 0;
+    bool guard_off = false;           // finish() scans the lines before a line the guard stopped at: not to be guarded again
     bool patch_off = false;           // finish() runs the scan again as a count / emit pair (diverged, or out of overflow records)
     int relaunches = 0;               // finish() ran the scan again (scratch, NUL, overflow): whatever was downloaded early is stale
     Pending pend;
@@ -103,6 +119,7 @@ struct DeviceState {
     uint8_t* d_gblob = nullptr;       // guided families: forward tables (stream form) ...
     uint8_t* d_rblob = nullptr;       // ... and the backward DFA
     uint8_t* d_nblob = nullptr;       // generator modes: the enumeration's tables
+    uint8_t* d_kblob = nullptr;       // the stack guard's tables (the NFT itself)
     ScanCtx ctx;
     struct HostSlot {
         uint8_t *pin_in = nullptr, *pin_out = nullptr, *d_in = nullptr, *d_out = nullptr;
@@ -138,6 +155,8 @@ struct trre_prog {
     std::vector<uint8_t> gblob, rblob;
     std::vector<uint8_t> nblob;       // generator modes: the enumeration's tables (gen_block.hpp); scan mode, NFT engine: the same lists for the backtracking fallback
     bool bt_ok = false;               // scan mode, NFT engine: nblob holds the backtracking fallback's tables
+    trre::GuardTables guard;          // scan mode, NFT engine: which lines can exhaust the reference's stack (stack_guard.cpp)
+    std::vector<uint8_t> kblob;
     int mask_bytes = 0;
     bool profiling = false;
     std::atomic<float> last_ms{-1.f};
@@ -450,6 +469,7 @@ void ctx_free(ScanCtx& c) {
     (void)hipFree(c.d_redo);
     (void)hipFree(c.d_sym);
     (void)hipFree(c.d_gen_out);
+    (void)hipFree(c.d_gflags); (void)hipFree(c.d_gruns); (void)hipFree(c.d_gstack); (void)hipFree(c.d_gobuf); (void)hipFree(c.d_gout);
     (void)hipFree(c.d_slots);
     (void)hipFree(c.d_ovf);
     (void)hipFree(c.d_ovf_count);
@@ -480,6 +500,7 @@ int device_state(trre_prog* p, int dev, DeviceState** out) {
         if (!rc) rc = upload(p->gblob, &st->d_gblob);
         if (!rc) rc = upload(p->rblob, &st->d_rblob);
         if (!rc) rc = upload(p->nblob, &st->d_nblob);
+        if (!rc) rc = upload(p->kblob, &st->d_kblob);
         if (!rc) rc = ctx_init(st->ctx);
         if (rc) return rc;
         it = p->dev.emplace(dev, std::move(st)).first;
@@ -532,6 +553,112 @@ int ensure_copy_workspace(ScanCtx* c, int64_t n_lanes) {
     return TRRE_OK;
 }
 
+// ---- the stack guard (guard_block.hpp) --------------------------------------------------------------------------------
+constexpr int64_t kGuardSlots = 256;                       // lines searched at a time (a stack of 65 536 items each: 192 MiB in all)
+constexpr size_t kGuardMaxRuns = 1u << 20;
+constexpr uint64_t kGuardBudget = 1ull << 27;              // search steps per line; beyond: not decided (the scan's output stands)
+constexpr const char* kStackMsg = "error: stack max capacity reached";
+bool guard_applies(const trre_prog& p, const ScanCtx& cx, size_t n) {
+    static const bool off = getenv("TRRE_NO_STACK_GUARD") != nullptr;
+    return !off && p.guard.on && !cx.guard_off && (p.mode == TRRE_MODE_SCAN || p.mode == TRRE_MODE_MATCH) && n + 1 >= p.guard.l_min;
+}
+struct GuardHit {
+    bool hit = false;
+    uint64_t line_start = 0;
+    uint32_t part = 0;         // bytes of the line's output in cx->d_gout, or ~0u: they could not be produced
+};
+template <class T>
+int guard_room(T** d, size_t* have, size_t want) {
+    if (*have >= want) return TRRE_OK;
+    if (*d) (void)hipFree(*d);
+    *d = nullptr; *have = 0;
+    if (hipMalloc(reinterpret_cast<void**>(d), want * sizeof(T)) != hipSuccess) return fail(TRRE_E_TOO_BIG, "error: out of device memory (stack guard)");
+    *have = want;
+    return TRRE_OK;
+}
+// Looks for lines long enough to exhaust the reference's stack and runs the reference's search on them.  Synchronous: it ends
+// with the stream idle.  hit: the first line (in input order) on which the search overflows, and what the reference had printed of it.
+int guard_check(trre_prog* p, DeviceState* st, ScanCtx* cx, const uint8_t* d_in, size_t n, hipStream_t stream, GuardHit* hit) {
+    using namespace trre;
+    const GuardTables& g = p->guard;
+    const int64_t al = (int64_t)(reinterpret_cast<uintptr_t>(d_in) & 15u);
+    ScanArgs args{};
+    args.in_v0 = d_in - al;
+    args.vbeg = al;
+    args.vend = al + (int64_t)n;
+    const int64_t n_win = ((int64_t)n + g.window - 1) / g.window;
+    const size_t n_words = (size_t)(n_win + 255) / 256 * 4;
+    int rc = guard_room(&cx->d_gflags, &cx->gflags_words, n_words);
+    if (rc) return rc;
+    launch_guard_probe(args, g.window, n_win, cx->d_gflags, stream);
+    HIP_TRY(hipGetLastError());
+    std::vector<uint64_t> flags(n_words);
+    HIP_TRY(hipMemcpyAsync(flags.data(), cx->d_gflags, n_words * 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    std::vector<GuardRun> runs;
+    for (int64_t w = 0; w < n_win && runs.size() < kGuardMaxRuns;) {
+        const uint64_t word = flags[(size_t)(w >> 6)] >> (w & 63);
+        if (!word) { w = (w | 63) + 1; continue; }
+        if (!(word & 1u)) { w += __builtin_ctzll(word); continue; }
+        int64_t e = w;
+        while (e + 1 < n_win && ((flags[(size_t)((e + 1) >> 6)] >> ((e + 1) & 63)) & 1u)) ++e;
+        runs.push_back(GuardRun{(uint32_t)w, (uint32_t)e});
+        w = e + 1;
+    }
+    if (runs.empty()) return TRRE_OK;
+    const size_t n_runs = runs.size();
+    {   // runs and results share one allocation
+        const size_t want = n_runs * (sizeof(GuardRun) + sizeof(GuardResult));
+        rc = guard_room(&cx->d_gruns, &cx->gruns_cap, want);
+        if (rc) return rc;
+    }
+    if (!cx->d_gstack && hipMalloc(reinterpret_cast<void**>(&cx->d_gstack), (size_t)kGuardSlots * kGuardStackMax * 12) != hipSuccess)
+        return fail(TRRE_E_TOO_BIG, "error: out of device memory (stack guard)");
+    GuardResult* d_res = reinterpret_cast<GuardResult*>(cx->d_gruns);
+    GuardRun* d_runs = reinterpret_cast<GuardRun*>(cx->d_gruns + n_runs * sizeof(GuardResult));
+    HIP_TRY(hipMemcpyAsync(d_runs, runs.data(), n_runs * sizeof(GuardRun), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemsetAsync(d_res, 0, n_runs * sizeof(GuardResult), stream));
+    GuardArgs ga{};
+    ga.blob = st->d_kblob;
+    ga.runs = d_runs;
+    ga.results = d_res;
+    ga.stack = cx->d_gstack;
+    static const uint64_t budget = getenv("TRRE_GUARD_BUDGET") ? (uint64_t)atoll(getenv("TRRE_GUARD_BUDGET")) : kGuardBudget;
+    ga.budget = budget;
+    ga.obuf = nullptr;                    // (the search alone: PROD writes nothing, FINAL prints nothing)
+    ga.obuf_cap = 0xffffffffu;
+    launch_guard(false, args, ga, (int64_t)n_runs, kGuardSlots, stream);
+    HIP_TRY(hipGetLastError());
+    std::vector<GuardResult> res(n_runs);
+    HIP_TRY(hipMemcpyAsync(res.data(), d_res, n_runs * sizeof(GuardResult), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    size_t bad = n_runs;
+    for (size_t k = 0; k < n_runs; ++k)
+        if (res[k].status == 1u) { bad = k; break; }
+    if (bad == n_runs) return TRRE_OK;
+    hit->hit = true;
+    hit->line_start = res[bad].line_start;
+    hit->part = 0xffffffffu;
+    // the same line again, printing: what the reference had printed of it when it gave up
+    const uint64_t line_len = res[bad].out_len;             // (the search pass leaves the line's length here)
+    const uint64_t obuf_want = 16 * (line_len + 1) + 65536, out_want = 16 * (res[bad].bad_at + 1) + 65536;
+    if (obuf_want > (1ull << 30) || out_want > (1ull << 30)) return TRRE_OK;
+    if (guard_room(&cx->d_gobuf, &cx->gobuf_cap, (size_t)obuf_want) || guard_room(&cx->d_gout, &cx->gout_cap, (size_t)out_want)) return TRRE_OK;
+    ga.runs = d_runs + bad;
+    ga.results = d_res + bad;
+    ga.obuf = cx->d_gobuf;
+    ga.obuf_cap = (uint32_t)std::min<uint64_t>(cx->gobuf_cap, 0xfffffff0u);
+    ga.out = cx->d_gout;
+    ga.out_cap = cx->gout_cap;
+    launch_guard(true, args, ga, 1, 1, stream);
+    HIP_TRY(hipGetLastError());
+    GuardResult again{};
+    HIP_TRY(hipMemcpyAsync(&again, d_res + bad, sizeof again, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (again.status == 1u) hit->part = again.out_len;
+    return TRRE_OK;
+}
+
 // the backtracking fallback: sub-range per thread, frames (= bytes an attempt may consume) and path bytes per thread, workgroups in the pool, steps per sub-range
 constexpr int64_t kBtLaneBytes = 1024, kBtPoolBlocks = 256;
 constexpr uint32_t kBtFrames = 1024, kBtPathCap = 2048, kBtBudget = 16u << 20;
@@ -546,6 +673,21 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
     if (pd.active && (pd.family != family || pd.d_in != d_in || pd.d_out != d_out || pd.n != n || pd.cap != cap || pd.stream != stream))
         return fail(TRRE_E_ARG, "error: a different scan is still in flight on this device: call trre_scan_finish first");
     const int batch_count = batch ? pd.count : 0;
+    // an in-place scan destroys what the stack guard would look at: it looks first (the first launch of a batch only — the rest
+    // are the same scan).  A line the reference's search fails on: nothing is launched, finish() answers.
+    if (!batch && n && d_in == d_out && guard_applies(*p, *cx, n)) {
+        GuardHit hit;
+        const int grc = guard_check(p, st, cx, d_in, n, stream, &hit);
+        if (grc) return grc;
+        if (hit.hit) {
+            pd = Pending();
+            pd.active = true;
+            pd.family = family;
+            pd.d_in = d_in; pd.d_out = d_out; pd.n = n; pd.cap = cap; pd.stream = stream;
+            pd.guard_hit = true; pd.guard_line = hit.line_start; pd.guard_part = hit.part;
+            return TRRE_OK;
+        }
+    }
     pd = Pending();
     pd.active = true;
     pd.count = batch_count;
@@ -881,7 +1023,7 @@ int repair_bytemap_nuls(DeviceState* st, ScanCtx* cx, const Pending& was, size_t
     return TRRE_OK;
 }
 
-int finish(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
+int finish_inner(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
     using namespace trre;
     Pending& pd = cx->pend;
     if (!pd.active) return fail(TRRE_E_ARG, "error: no scan in flight");
@@ -906,7 +1048,7 @@ int finish(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
         cx->relaunches += 1;
         int rc = enqueue(p, st, cx, family, was.d_in, was.n, was.d_out, was.cap, was.stream);
         if (rc) return rc;
-        return finish(p, st, cx, out_len);
+        return finish_inner(p, st, cx, out_len);
     };
     // (a length-preserving launch that met a NUL is void — it went on walking behind the NUL, where the reference never
     // looks — and so is whatever else it reports: the general family decides, below)
@@ -999,6 +1141,43 @@ int finish(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
     return TRRE_OK;
 }
 
+// finish_inner, then the stack guard: a scan that went through may have met a line on which the reference's search runs out of
+// stack (guard_block.hpp) — then the answer is what the reference gives: an error, and the output up to the attempt that
+// overflowed (the lines before that line from a scan of exactly those lines, the line's own part from the guard's search).
+int finish(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
+    using namespace trre;
+    const Pending was = cx->pend;
+    GuardHit hit;
+    if (was.active && was.guard_hit) {                     // found before an in-place launch: nothing has run yet
+        cx->pend = Pending();
+        hit.hit = true; hit.line_start = was.guard_line; hit.part = was.guard_part;
+    } else {
+        const int rc = finish_inner(p, st, cx, out_len);
+        if (rc != TRRE_OK || !was.active || was.n == 0 || !guard_applies(*p, *cx, was.n) || was.d_in == was.d_out) return rc;
+        const int grc = guard_check(p, st, cx, was.d_in, was.n, was.stream, &hit);
+        if (grc) return grc;
+        if (!hit.hit) return rc;
+    }
+    size_t pre = 0;
+    if (hit.line_start > 0) {
+        cx->guard_off = true;
+        int rc = enqueue(p, st, cx, was.family, was.d_in, (size_t)hit.line_start, was.d_out, was.cap, was.stream);
+        if (!rc) rc = finish_inner(p, st, cx, &pre);
+        cx->guard_off = false;
+        cx->relaunches += 1;
+        if (rc) { if (out_len) *out_len = pre; return rc; }
+    }
+    const size_t part = hit.part == 0xffffffffu ? 0 : hit.part;
+    if (out_len) *out_len = pre + part;
+    if (pre + part > was.cap) return fail(TRRE_E_CAPACITY, "error: output buffer too small");
+    if (part) {
+        HIP_TRY(hipMemcpyAsync(was.d_out + pre, cx->d_gout, part, hipMemcpyDeviceToDevice, was.stream));
+        HIP_TRY(hipStreamSynchronize(was.stream));
+    }
+    cx->relaunches += 1;
+    return fail(TRRE_E_DIVERGES, kStackMsg);
+}
+
 
 int compile_impl(const std::string& pattern, int engine, trre_prog** out, int mode = TRRE_MODE_SCAN) {
     using namespace trre;
@@ -1017,6 +1196,23 @@ int compile_impl(const std::string& pattern, int engine, trre_prog** out, int mo
         Nft nft = build_nft(ast, engine == TRRE_ENGINE_DFT);
         p->nft_states = (uint32_t)nft.st.size();
         p->nft_cons = (uint32_t)nft.n_cons;
+        // the stack guard (guard_block.hpp): the NFT itself, for the lines long enough to exhaust the reference's stack
+        auto make_guard = [&](bool match) {
+            p->guard = build_guard(nft);
+            if (!p->guard.on) return;
+            GuardBlobHeader gh{};
+            gh.magic = kMagicGuard;
+            gh.n_states = (uint32_t)nft.st.size();
+            gh.start = p->guard.start;
+            gh.d = p->guard.d;
+            gh.l_min = p->guard.l_min;
+            gh.window = p->guard.window;
+            gh.off_states = (uint32_t)sizeof gh;
+            gh.total_bytes = (uint32_t)(sizeof gh + p->guard.states.size() * 4);
+            gh.match = match ? 1u : 0u;
+            put(p->kblob, 0, &gh, 1);
+            put(p->kblob, gh.off_states, p->guard.states.data(), p->guard.states.size());
+        };
         if (engine == TRRE_ENGINE_DFT) {
             Dft dft = determinize(nft);
             p->dt = flatten_dft(dft);
@@ -1042,6 +1238,7 @@ int compile_impl(const std::string& pattern, int engine, trre_prog** out, int mo
             p->gt = build_guided_nft(nodes);
             if (!p->gt.ok)
                 throw Error(kErrUnsupported, "error: the backward automaton of this pattern has too many states (match mode runs on the guided tables only)");
+            make_guard(true);
         } else {
             // TRRE_COMPILE_TRACE=1: the stages of the NFT compile on stderr as they start (to find the one a pattern is slow in)
             static const bool trace_on = getenv("TRRE_COMPILE_TRACE") != nullptr;
@@ -1090,6 +1287,7 @@ int compile_impl(const std::string& pattern, int engine, trre_prog** out, int mo
                 serialize_gen(lists, p->nblob);
                 p->bt_ok = true;
             }
+            make_guard(false);
         }
         if (p->stt.ok) serialize_stream(p->stt, p->sblob);
         if (p->gt.ok) { serialize_stream(p->gt.fwd, p->gblob); serialize_rev(p->gt, p->rblob); }
@@ -1133,6 +1331,7 @@ void trre_free(trre_prog* p) {
         (void)hipFree(st.d_gblob);
         (void)hipFree(st.d_rblob);
         (void)hipFree(st.d_nblob);
+        (void)hipFree(st.d_kblob);
         ctx_free(st.ctx);
         for (auto& hs : st.slot) {
             if (hs.pin_in) (void)hipHostFree(hs.pin_in);
@@ -1197,7 +1396,7 @@ size_t trre_export_stream_tables(const trre_prog* p, void* buf, size_t cap) {
 
 size_t trre_export_guided_tables(const trre_prog* p, int which, void* buf, size_t cap) {
     if (!p) return 0;
-    const std::vector<uint8_t>& b = which == 0 ? p->rblob : (which == 2 ? p->nblob : p->gblob);   // (2: generator modes, the enumeration's tables)
+    const std::vector<uint8_t>& b = which == 0 ? p->rblob : (which == 2 ? p->nblob : (which == 3 ? p->kblob : p->gblob));   // (2: the enumeration's / the backtracking fallback's tables, 3: the stack guard's)
     if (buf && cap) std::memcpy(buf, b.data(), cap < b.size() ? cap : b.size());
     return b.size();
 }

@@ -24,6 +24,7 @@
 #include "scan_block.hpp"
 #include "splice_block.hpp"
 #include "gen_block.hpp"
+#include "guard_block.hpp"
 
 namespace trre {
 namespace {
@@ -1053,6 +1054,21 @@ __global__ __launch_bounds__(kGenThreads) void k_bt(ScanArgs a, GenArgs ga, int6
     if (st && (threadIdx.x & (kWave - 1)) == 0) atomicOr(a.status, st);
 }
 
+// The stack guard (guard_block.hpp): windows without a '\n' (a bit per window, a wave per 64 of them), then the reference's
+// search itself on the lines that cover them, a thread per line from a pool of stacks.
+__global__ __launch_bounds__(256) void k_guard_probe(ScanArgs a, int64_t window, int64_t n_windows, uint64_t* flags) {
+    const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool none = false;
+    if (w < n_windows) none = guard_probe(a, a.vbeg + w * window, a.vbeg + (w + 1) * window);
+    const uint64_t m = __ballot(none);
+    if ((threadIdx.x & (kWave - 1)) == 0) flags[w >> 6] = m;
+}
+template <bool kOut>
+__global__ __launch_bounds__(64) void k_guard(ScanArgs a, GuardArgs ga, int64_t n_runs) {
+    const int64_t slot = (int64_t)blockIdx.x * 64 + threadIdx.x, stride = (int64_t)gridDim.x * 64;
+    for (int64_t r = slot; r < n_runs; r += stride) guard_line<kOut>(a, ga, slot, r);
+}
+
 // ------------------------------------------------------------------------------------------
 // memoryless byte map: out[v] = map[in[v]], 16 bytes per lane per step
 constexpr int kMapThreads = 256;
@@ -1544,6 +1560,16 @@ void launch_gen(int which, const ScanArgs& a, const GenArgs& ga, int64_t lane_by
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (which == 1) hipLaunchKernelGGL(k_gen<1>, dim3((unsigned)n_chunks), dim3(kGenThreads), 0, s, a, ga, lane_bytes);
     else hipLaunchKernelGGL(k_gen<2>, dim3((unsigned)n_chunks), dim3(kGenThreads), 0, s, a, ga, lane_bytes);
+}
+void launch_guard_probe(const ScanArgs& a, int64_t window, int64_t n_windows, uint64_t* flags, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_guard_probe, dim3((unsigned)((n_windows + 255) / 256)), dim3(256), 0, s, a, window, n_windows, flags);
+}
+void launch_guard(bool out, const ScanArgs& a, const GuardArgs& ga, int64_t n_runs, int64_t slots, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned grid = (unsigned)((std::min<int64_t>(n_runs, slots) + 63) / 64);
+    if (out) hipLaunchKernelGGL(k_guard<true>, dim3(grid), dim3(64), 0, s, a, ga, n_runs);
+    else hipLaunchKernelGGL(k_guard<false>, dim3(grid), dim3(64), 0, s, a, ga, n_runs);
 }
 void launch_bt(int which, const ScanArgs& a, const GenArgs& ga, int64_t lane_bytes, int64_t n_chunks, int64_t pool_blocks, uint32_t budget, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
