@@ -922,9 +922,9 @@ int shim_guard(const uint8_t* kblob, const uint8_t* in, size_t n, int in_mis, ui
     const int64_t n_win = ((int64_t)n + h.window - 1) / h.window;
     std::vector<GuardRun> runs;
     for (int64_t w = 0; w < n_win;) {
-        if (!guard_probe(a, a.vbeg + w * h.window, a.vbeg + (w + 1) * h.window)) { ++w; continue; }
+        if (!guard_probe(a, h.bset, a.vbeg + w * h.window, a.vbeg + (w + 1) * h.window)) { ++w; continue; }
         int64_t e = w;
-        while (e + 1 < n_win && guard_probe(a, a.vbeg + (e + 1) * h.window, a.vbeg + (e + 2) * h.window)) ++e;
+        while (e + 1 < n_win && guard_probe(a, h.bset, a.vbeg + (e + 1) * h.window, a.vbeg + (e + 2) * h.window)) ++e;
         runs.push_back(GuardRun{(uint32_t)w, (uint32_t)e});
         w = e + 1;
     }

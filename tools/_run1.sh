@@ -1,3 +1,5 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "stack_limit or match_mode" 2>&1 | tail -30
+timeout 600 python tools/_run2.py 2>&1 | tail -12
+echo "== guard off"
+TRRE_NO_STACK_GUARD=1 timeout 600 python tools/_run2.py 2>&1 | tail -8

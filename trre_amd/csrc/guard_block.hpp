@@ -6,9 +6,10 @@
 // ' +: ' on 70 000 spaces — and the table kernels, which never hold failing alternatives, print the match instead.
 //
 // Only a long line can do it: an attempt that has consumed k bytes holds at most D * (k + 1) items, D = the deepest nest of
-// first-tried branches between two reads (a pattern constant, stack_guard.cpp).  So the runtime looks for lines of at least
-// 65 536 / D bytes (guard_probe: windows of half that size with no '\n' in them — a few hundred bytes read per window on
-// ordinary text) and, for the lines it finds, runs the reference's search as it is, state by state over the NFT the front end
+// first-tried branches between two reads (a pattern constant, stack_guard.cpp) — and all of those k bytes but a handful were read
+// inside loops: the line holds a long run of bytes the pattern's loops can read.  So the runtime looks for windows that consist of
+// such bytes only (guard_probe: on ordinary text a window is left after a few bytes) and, for the lines that hold one, runs the
+// reference's search as it is, state by state over the NFT the front end
 // built (front.hpp: Nft mirrors create_nft), counting the stack: guard_line.  An overflow is reported like the reference
 // reports it — TRRE_E_DIVERGES, "stack max capacity reached", the output up to the attempt that overflowed.
 //
@@ -28,26 +29,22 @@ struct GuardBlobHeader {
     uint32_t total_bytes;
     uint32_t match;                          // trre -m: one attempt per line, FINAL accepts at the end of the line only
     uint32_t pad;
+    uint32_t bset[8];                        // the bytes a window must consist of to be a suspect (never '\n', never NUL)
 };
-static_assert(sizeof(GuardBlobHeader) == 40, "header layout");
+static_assert(sizeof(GuardBlobHeader) == 72, "header layout");
 constexpr uint32_t kGuardProd = 0, kGuardCons = 1, kGuardSplit = 2, kGuardSplitNg = 3, kGuardJoin = 4, kGuardFinal = 5;   // (front.hpp: NKind)
 constexpr uint32_t kGuardStackMax = 65536;   // live items (trre_nft.c:551: capacity * 2 > STACK_MAX_CAPACITY at capacity 65 536)
 
-// a window of the input holds no '\n': 16 bytes at a time, leaving at the first one found
-TRRE_HD bool guard_probe(const ScanArgs& a, int64_t lo, int64_t hi) {
+// a window of the input consists of bytes of the set only (the set never holds '\n'): leaving at the first other byte — on
+// ordinary text after a few bytes
+TRRE_HD bool guard_probe(const ScanArgs& a, const uint32_t (&bset)[8], int64_t lo, int64_t hi) {
     if (hi > a.vend - 1) hi = a.vend - 1;                         // (the last byte ends its record whatever it is: Q1)
-    for (int64_t v = lo; v < hi;) {
-        if ((v & 15) == 0 && v + 16 <= hi) {
-            const U128 b = *reinterpret_cast<const U128*>(a.in_v0 + v);
-            const uint32_t w[4] = {b.x ^ 0x0a0a0a0au, b.y ^ 0x0a0a0a0au, b.z ^ 0x0a0a0a0au, b.w ^ 0x0a0a0a0au};
-            uint32_t z = 0;
-            for (int i = 0; i < 4; ++i) z |= (w[i] - 0x01010101u) & ~w[i] & 0x80808080u;
-            if (z) return false;
-            v += 16;
-        } else {
-            if (a.in_v0[v] == (uint8_t)'\n') return false;
-            ++v;
-        }
+    for (int64_t v = lo; v < hi; ++v) {
+        const uint32_t c = a.in_v0[v];
+        uint32_t w = bset[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) w = (c >> 5) == (uint32_t)k ? bset[k] : w;
+        if (!((w >> (c & 31u)) & 1u)) return false;
     }
     return lo < hi;
 }
@@ -82,6 +79,7 @@ TRRE_HD void guard_line(const ScanArgs& a, const GuardArgs& ga, int64_t slot, in
     const GuardRun run = ga.runs[run_index];
     GuardResult R{};
     // the line: from behind the last '\n' before the run to the first one after it (the last byte of the input ends its record)
+    // (the windows next to a run need not hold a '\n' — only a byte outside the set: the walk to the line's ends is as long as the line)
     int64_t ls = a.vbeg + (int64_t)run.first * h.window;
     while (ls > a.vbeg && a.in_v0[ls - 1] != (uint8_t)'\n') --ls;
     int64_t le = a.vbeg + ((int64_t)run.last + 1) * h.window;

@@ -556,7 +556,7 @@ int ensure_copy_workspace(ScanCtx* c, int64_t n_lanes) {
 // ---- the stack guard (guard_block.hpp) --------------------------------------------------------------------------------
 constexpr int64_t kGuardSlots = 256;                       // lines searched at a time (a stack of 65 536 items each: 192 MiB in all)
 constexpr size_t kGuardMaxRuns = 1u << 20;
-constexpr uint64_t kGuardBudget = 1ull << 27;              // search steps per line; beyond: not decided (the scan's output stands)
+constexpr uint64_t kGuardBudget = 1ull << 24;              // search steps per line; beyond: not decided (the scan's output stands)
 constexpr const char* kStackMsg = "error: stack max capacity reached";
 bool guard_applies(const trre_prog& p, const ScanCtx& cx, size_t n) {
     static const bool off = getenv("TRRE_NO_STACK_GUARD") != nullptr;
@@ -590,6 +590,7 @@ int guard_check(trre_prog* p, DeviceState* st, ScanCtx* cx, const uint8_t* d_in,
     const size_t n_words = (size_t)(n_win + 255) / 256 * 4;
     int rc = guard_room(&cx->d_gflags, &cx->gflags_words, n_words);
     if (rc) return rc;
+    args.blob = st->d_kblob;
     launch_guard_probe(args, g.window, n_win, cx->d_gflags, stream);
     HIP_TRY(hipGetLastError());
     std::vector<uint64_t> flags(n_words);
@@ -1210,6 +1211,7 @@ int compile_impl(const std::string& pattern, int engine, trre_prog** out, int mo
             gh.off_states = (uint32_t)sizeof gh;
             gh.total_bytes = (uint32_t)(sizeof gh + p->guard.states.size() * 4);
             gh.match = match ? 1u : 0u;
+            for (int k = 0; k < 8; ++k) gh.bset[k] = p->guard.bset[k];
             put(p->kblob, 0, &gh, 1);
             put(p->kblob, gh.off_states, p->guard.states.data(), p->guard.states.size());
         };

@@ -1058,8 +1058,10 @@ __global__ __launch_bounds__(kGenThreads) void k_bt(ScanArgs a, GenArgs ga, int6
 // search itself on the lines that cover them, a thread per line from a pool of stacks.
 __global__ __launch_bounds__(256) void k_guard_probe(ScanArgs a, int64_t window, int64_t n_windows, uint64_t* flags) {
     const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const GuardBlobHeader& h = *reinterpret_cast<const GuardBlobHeader*>(a.blob);
+    const uint32_t bset[8] = {h.bset[0], h.bset[1], h.bset[2], h.bset[3], h.bset[4], h.bset[5], h.bset[6], h.bset[7]};
     bool none = false;
-    if (w < n_windows) none = guard_probe(a, a.vbeg + w * window, a.vbeg + (w + 1) * window);
+    if (w < n_windows) none = guard_probe(a, bset, a.vbeg + w * window, a.vbeg + (w + 1) * window);
     const uint64_t m = __ballot(none);
     if ((threadIdx.x & (kWave - 1)) == 0) flags[w >> 6] = m;
 }

@@ -99,7 +99,69 @@ GuardTables build_guard(const Nft& nft) {
     if (d > 64) { g.too_deep = true; return g; }                                       // (lines of under 1 KiB would be suspects: the deviation stays)
     g.on = true;
     g.l_min = 65536u / (uint32_t)d - 1u;
-    g.window = (g.l_min / 2u) & ~15u;
+    // The bytes of such an attempt are consecutive bytes of the line, and all but a few were read by CONS states that lie on a
+    // cycle: a state on no cycle is passed once.  So the line holds l_min consecutive bytes of which at most n_once are not
+    // bytes such a state reads — a run of (l_min - n_once) / (n_once + 1) bytes of the set somewhere — and a run that long
+    // covers a whole window of half its size.  (Strongly connected components, Tarjan's, iteratively.)
+    std::vector<uint8_t> cyclic(n, 0);
+    {
+        std::vector<int32_t> idx(n, -1), low(n, 0), comp_stack;
+        std::vector<uint8_t> on_cs(n, 0);
+        std::vector<std::pair<int32_t, int>> st;
+        int32_t counter = 0;
+        for (int32_t r = 0; r < n; ++r) {
+            if (idx[r] >= 0) continue;
+            st.push_back({r, 0});
+            idx[r] = low[r] = counter++;
+            comp_stack.push_back(r); on_cs[r] = 1;
+            while (!st.empty()) {
+                const int32_t s = st.back().first;
+                const NState& x = nft.st[s];
+                const int32_t succ[2] = {x.a, (x.kind == NKind::Split || x.kind == NKind::SplitNg) ? x.b : -1};
+                if (st.back().second < 2) {
+                    const int32_t t = succ[st.back().second++];
+                    if (t < 0) continue;
+                    if (t == s) cyclic[s] = 1;
+                    if (idx[t] < 0) {
+                        idx[t] = low[t] = counter++;
+                        comp_stack.push_back(t); on_cs[t] = 1;
+                        st.push_back({t, 0});
+                    } else if (on_cs[t]) {
+                        low[s] = std::min(low[s], idx[t]);
+                    }
+                } else {
+                    if (low[s] == idx[s]) {
+                        size_t first = comp_stack.size();
+                        while (comp_stack[first - 1] != s) --first;
+                        --first;
+                        const bool many = comp_stack.size() - first > 1;
+                        for (size_t k = first; k < comp_stack.size(); ++k) { if (many) cyclic[comp_stack[k]] = 1; on_cs[comp_stack[k]] = 0; }
+                        comp_stack.resize(first);
+                    }
+                    st.pop_back();
+                    if (!st.empty()) low[st.back().first] = std::min(low[st.back().first], low[s]);
+                }
+            }
+        }
+    }
+    uint64_t n_once = 0;
+    for (int32_t s = 0; s < n; ++s) {
+        if (nft.st[s].kind != NKind::Cons) continue;
+        const uint8_t c = nft.st[s].val;
+        if (!cyclic[s]) { ++n_once; continue; }
+        if (c != 0 && c != (uint8_t)'\n') g.bset[c >> 5] |= 1u << (c & 31);
+    }
+    const uint64_t run_min = n_once >= g.l_min ? 0 : ((uint64_t)g.l_min - n_once) / (n_once + 1);
+    if (run_min >= 64) {
+        g.run_min = (uint32_t)run_min;
+        g.window = ((uint32_t)run_min / 2u) & ~15u;
+    } else {
+        // (so many states outside the loops that short runs would do: any line of l_min bytes is a suspect — windows without a '\n')
+        for (int k = 0; k < 8; ++k) g.bset[k] = 0xffffffffu;
+        g.bset[0] &= ~((1u << 10) | 1u);
+        g.run_min = g.l_min;
+        g.window = (g.l_min / 2u) & ~15u;
+    }
     g.start = (uint32_t)nft.start;
     g.states.resize((size_t)n * 4);
     for (int32_t s = 0; s < n; ++s) {
