@@ -66,9 +66,13 @@ extern "C" {
                                    with everything it had printed so far — the lines before the bad one and the bad line's output up
                                    to the attempt that does not return (trre_nft.c:551-553, exit() flushes stdout) — and so does the
                                    scan: those bytes are in the output buffer and *out_len is their count.  DFT engine: the
-                                   reference's buffered output dies with it; *out_len = 0.  Not modelled: the reference's limit of
-                                   65 536 live backtrack items in one attempt (a greedy loop over a run of 65 536 bytes exits 1
-                                   there; here it is matched: tests/test_gpu_parity.py pins the difference) */
+                                   reference's buffered output dies with it; *out_len = 0.  The same error, with the same bytes, when
+                                   an attempt of the NFT engine's search would hold more than 65 536 untried alternatives
+                                   (trre_nft.c:35-36,548-556: a greedy loop over a run of 65 536 bytes): the stack guard (round 4;
+                                   rounds 1-3 printed the match) finds the lines long enough for that and runs the reference's search
+                                   on them, scan and match modes; TRRE_NO_STACK_GUARD=1 switches it off.  Not decided, and left as
+                                   the table kernels print it: a line whose search takes more than 16 M steps, patterns whose loops
+                                   nest more than 64 first-tried branches between two reads, generator modes */
 #define TRRE_E_CAPACITY (-9)    /* output buffer too small; *out_len holds the size needed */
 
 /* kernel families (trre_info.kernel, trre_set_kernel) */

@@ -90,7 +90,7 @@ def test_random_patterns_on_the_backtracking_fallback():
     rng = random.Random(77)
     n = n_div = 0
     t_end = time.time() + 40
-    for _ in range(300):
+    for _ in range(270):                     # (pattern 281 of this seed is exponential for the reference's search: minutes)
         if time.time() > t_end:
             break
         pat = F.gen_soup(rng) if rng.random() < 0.2 else F.gen_expr(rng)

@@ -127,3 +127,10 @@ def test_cli_reports_divergence_like_the_reference():
         if ref_available():
             rrc, rout, rerr = run(REF["nft"], [pat], data)
             assert (rrc, rout) == (1, printed) and rerr == b"error: stack max capacity reached\n"
+    # the search's 65 536-item stack (round 4: the stack guard): a line that exhausts it, in a stream of ordinary lines
+    data = b"a  b c\n" * 3000 + b"x" + b" " * 70000 + b"y\n" + b"d  e\n" * 10
+    for env in ({}, {"TRRE_CLI_BLOCK": "65536"}):
+        rc, out, err = run(BIN["nft"], [" +: "], data, env)
+        assert rc == 1 and err.startswith(b"error: stack max capacity reached") and out == b"a b c\n" * 3000 + b"x", (env, rc, err, len(out))
+    if ref_available():
+        assert run(REF["nft"], [" +: "], data) == (1, b"a b c\n" * 3000 + b"x", b"error: stack max capacity reached\n")
