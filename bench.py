@@ -50,7 +50,8 @@ HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~630
 KERNEL_OF = {"generate": "k_rev_sweep (viability symbols) + k_gen<count> + k_gen<emit>", "bytemap": "k_bytemap", "tile_lp": "k_scan_lp", "tile_gen": "k_scan_count + k_scan_emit",
              "stream_lp": "k_stream_lpw (window form) / k_stream_g16<emit> alone",
              "stream_gen": "k_stream_g16<count> + <emit> (small tables) / k_fb_mark + k_fb_splice (large tables: the copy form)",
-             "guided_lp": "k_rev_sweep + k_stream_g16<emit, sym>", "guided_gen": "k_rev_sweep + k_stream_g16<count, sym> + <emit, sym>"}
+             "guided_lp": "k_rev_sweep + k_stream_g16<emit, sym>", "guided_gen": "k_rev_sweep + k_stream_g16<count, sym> + <emit, sym>",
+             "backtrack": "k_bt<count> + k_chunk_scan + k_bt<emit>"}
 
 
 def synth_lines(n, seed, device):
@@ -666,6 +667,41 @@ def main():
         configs.append(run_config(trre_amd, {"name": "tile_fallback", "pattern": "a:xyz", "engine": "dft", "steps": 3, "force": "tile_gen",
                                              "workload": "the LDS-tile kernels (fallback of last resort for DFT patterns that do not fold): 'a:xyz' forced "
                                                          "through tile_gen, %.0f GiB" % (nt / 2**30)}, inp[:nt], out, tmp, False))
+        # the fallback of the NFT engine (round 4): a pattern beyond every table form (98 nodes, a backward automaton of more than
+        # 16 384 states, no fold; round 3: TRRE_E_UNSUPPORTED) — the reference's search on the device, a thread per KiB
+        nb = min(n, 256 << 20)
+        configs.append(run_config(trre_amd, {"name": "backtrack_fallback", "pattern": "a(a|b|c|d|e|f|g|h){12}c:x", "engine": "nft", "steps": 3, "full_oracle": 1 << 62,
+                                             "workload": "the backtracking fallback (NFT patterns beyond every table form): 'a(a|...|h){12}c:x', %.2f GiB"
+                                                         % (nb / 2**30)}, inp[:nb], out, tmp, False))
+        # the reference's stack limit (round 4: the stack guard): one line of 70 000 spaces in the buffer — the scan runs, the guard's
+        # probe finds the line, the reference's search on it overflows, the lines before it are scanned again: the whole error path
+        if n > (64 << 20):
+            p0 = n // 2
+            saved = inp[p0:p0 + 70000].clone()
+            inp[p0:p0 + 70000] = 32
+            prog = trre_amd.Program(" +: ", "nft")
+            t0 = time.perf_counter()
+            err = None
+            try:
+                prog.scan_tensor(inp, out=out)
+            except trre_amd.TrreError as e:
+                err = e
+            dt = time.perf_counter() - t0
+            ok = err is not None and err.code == trre_amd.api.E_DIVERGES and "stack max capacity reached" in err.message
+            part = int(err.partial.numel()) if ok else 0
+            # what the reference had printed: the lines before that line, scanned, and the line up to the run (the run is where its search overflows)
+            line0 = p0 - (1 << 20) + int((inp[p0 - (1 << 20):p0] == 10).nonzero()[-1]) + 1
+            good = trre_amd.Program(" +: ", "nft").scan_tensor(inp[:line0])
+            head = trre_amd.Program(" +: ", "nft").scan_tensor(torch.cat([inp[line0:p0], torch.tensor([10], dtype=torch.uint8, device=dev)]))[:-1]
+            want = torch.cat([good, head])
+            same = ok and part == int(want.numel()) and bool(torch.equal(err.partial, want))
+            configs.append({"name": "stack_limit", "pattern": " +: ", "engine": "nft", "bytes": n, "verified": bool(same), "output_bytes": part, "ms_per_step": round(dt * 1e3, 2),
+                            "workload": "' +: ' NFT with ONE run of 70 000 spaces in the %.0f GiB (trre_nft.c:548-556: the reference's search runs out of its 65 536-item stack "
+                                        "there and exits 1 with what it had printed): the scan, the stack guard's probe, the reference's search on the one suspect line, the "
+                                        "scan of the lines before it; TRRE_E_DIVERGES with the reference's partial output (checked here against a scan of exactly those "
+                                        "lines); ms_per_step = the whole call, host-timed" % (n / 2**30)})
+            inp[p0:p0 + 70000] = saved
+            del saved, good, head, want
         del inp
         inp = corpora.cat_dog_soup(n, corpora.SEED0 + 4, dev)
         lines = int((inp == 10).sum())

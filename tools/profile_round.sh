@@ -40,6 +40,7 @@ nft_loop_guided|--case (a|b)*c:x;;nft;;printable;;auto
 dft_loop_guided|--case (a|b)*c:x;;dft;;printable;;auto
 tile_dft|--case a:xyz;;dft;;printable;;tile_gen --bytes 268435456
 wide_guided|--case a(a|b|c|d|e|f|g|h){9}c:x;;nft;;printable;;auto --bytes 268435456
+backtrack|--case a(a|b|c|d|e|f|g|h){12}c:x;;nft;;printable;;auto --bytes 268435456
 CASES
 # 4. the splice form of a small table (TRRE_G16_SPLICE=1; off by default: round 4 built it and it loses): kernel stats, traffic, SQ counters
 TRRE_G16_SPLICE=1 timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/raw/st_spl -o s -- python tools/kbench.py --case 'a:xyz;;dft;;printable;;auto' --steps 5 > gpurun_out/raw/st_spl.log 2>&1
