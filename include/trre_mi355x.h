@@ -91,7 +91,7 @@ extern "C" {
 #define TRRE_KERNEL_BACKTRACK 9   /* NFT engine, scan mode, any pattern: the reference's depth-first search itself, a lane per sub-range with an
                                      explicit stack (round 4).  What a pattern beyond the limits of every other family runs on (round 3:
                                      TRRE_E_UNSUPPORTED); exponential where the reference is.  A 1 KiB sub-range whose search takes more than 16 M steps, an
-                                     attempt that consumes more than 1 024 bytes or builds more than 2 KiB of output: TRRE_E_UNSUPPORTED at run time */
+                                     attempt that consumes more than 4 096 bytes or builds more than 4 KiB of output: TRRE_E_UNSUPPORTED at run time */
 
 typedef struct trre_prog trre_prog;
 

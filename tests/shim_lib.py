@@ -214,7 +214,7 @@ def stack_guard(prog, data, in_mis=0, budget=1 << 27):
 BACKTRACK = 30                                       # the backtracking fallback (ABI family 9)
 
 
-def scan_backtrack(prog, data, geo=1, in_mis=0, frames=1024, path_cap=2048, budget=16 << 20):
+def scan_backtrack(prog, data, geo=1, in_mis=0, frames=4096, path_cap=4096, budget=16 << 20):
     """the backtracking fallback's lane body on the host, as the runtime drives it: (output, status) — with ST_DIVERGE the output is
     what the reference had printed when it gave up"""
     nblob = prog.export_gen_tables()

@@ -185,7 +185,6 @@ TRRE_HD void bt_lane(const ScanArgs& a, const GenView& G, const GenArgs& ga, int
     uint32_t* const stack = ga.stack + (size_t)slot * ga.frames * 4;
     uint8_t* const path = ga.path + (size_t)slot * ga.path_cap;
     uint8_t* op = kMode == 2 ? a.out + out_base : nullptr;
-    auto byte_at = [&](int64_t v) -> uint8_t { return v >= a.vend - 1 ? (uint8_t)'\n' : a.in_v0[v]; };
     auto put = [&](const uint8_t* src, uint32_t n) {
         if (kMode == 2) { for (uint32_t i = 0; i < n; ++i) op[cnt + i] = src[i]; }
         cnt += n;
@@ -196,9 +195,12 @@ TRRE_HD void bt_lane(const ScanArgs& a, const GenView& G, const GenArgs& ga, int
     };
     // the first accepting path of ONE attempt at position p: prints its output; returns the bytes it consumed, -1: no path, -2: gave up
     uint32_t steps = 0;                                                             // (of the whole sub-range: the launch ends in bounded time)
-    auto attempt = [&](int64_t rec, uint32_t len, uint32_t p) -> int64_t {
+    // (a record's content ends at its '\n', at a NUL before it (Q2) or at the last byte of the input, which ends its record
+    // whatever it is (Q1): looked at as the walk gets there — no pass over the line beforehand)
+    auto ends = [&](int64_t v, uint8_t c) -> bool { return c == (uint8_t)'\n' || c == 0 || v >= a.vend - 1; };
+    auto attempt = [&](int64_t v0) -> int64_t {                                     // at position v0 of the input
         uint32_t sp = 1;
-        stack[0] = G.n_nodes; stack[1] = 0; stack[2] = p; stack[3] = 0;
+        stack[0] = G.n_nodes; stack[1] = 0; stack[2] = 0; stack[3] = 0;
         while (sp) {
             if (++steps > budget) { status |= kStEditOverflow; return -2; }
             uint32_t* f = stack + 4 * (sp - 1);
@@ -213,10 +215,10 @@ TRRE_HD void bt_lane(const ScanArgs& a, const GenView& G, const GenArgs& ga, int
             if (target == kGenTgtFinal) {                                           // trre_nft.c:643-648: print, return the offset
                 put(path, olen);
                 if (!muted) put(G.pool + out_off, out_len);
-                return (int64_t)fi - (int64_t)p;
+                return (int64_t)fi;
             }
-            if (fi >= len) continue;
-            const uint8_t c = a.in_v0[rec + fi];
+            const uint8_t c = a.in_v0[v0 + fi];
+            if (ends(v0 + fi, c)) continue;
             if (!((G.bytes[8 * (size_t)target + (c >> 5)] >> (c & 31u)) & 1u)) continue;
             uint32_t nlen = olen, nmuted = muted;
             if (!muted) {
@@ -240,37 +242,39 @@ TRRE_HD void bt_lane(const ScanArgs& a, const GenView& G, const GenArgs& ga, int
         const uint32_t target = G.follow[3 * (size_t)k];
         for (int w = 0; w < 8; ++w) first[w] |= target >= kGenTgtDiverge ? 0xffffffffu : G.bytes[8 * (size_t)target + w];
     }
-    int64_t pos = lo;
-    if (!(lo == a.vbeg || (lo > a.vbeg && a.in_v0[lo - 1] == (uint8_t)'\n'))) pos = lo < a.vbeg ? a.vbeg : first_line_start_safe(a, lo, hi);
-    while (pos < hi) {
-        int64_t e = pos;
-        uint32_t len = 0xffffffffu;
-        for (;; ++e) {
-            const uint8_t c = byte_at(e);
-            if (c == (uint8_t)'\n') break;
-            if (c == 0 && len == 0xffffffffu) len = (uint32_t)(e - pos);            // cut at the first NUL (Q2)
+    int64_t v = lo;
+    if (!(lo == a.vbeg || (lo > a.vbeg && a.in_v0[lo - 1] == (uint8_t)'\n'))) v = lo < a.vbeg ? a.vbeg : first_line_start_safe(a, lo, hi);
+    // the lines that START in [lo, hi), byte by byte; 16 input bytes at a time in registers
+    U128 blk{};
+    int64_t blk_at = -16;
+    bool open = false;                                                              // inside a line of this lane's
+    for (;;) {
+        if (!open) {
+            if (v >= hi) break;
+            open = true;
         }
-        if (len == 0xffffffffu) {
-            if (e - pos > 0x7ffffff0ll) { status |= kStEditOverflow; break; }
-            len = (uint32_t)(e - pos);
+        if ((v & ~(int64_t)15) != blk_at) { blk_at = v & ~(int64_t)15; blk = *reinterpret_cast<const U128*>(a.in_v0 + blk_at); }
+        const uint32_t q = (uint32_t)(v >> 2) & 3u;
+        const uint32_t dw = q == 0 ? blk.x : (q == 1 ? blk.y : (q == 2 ? blk.z : blk.w));
+        const uint8_t c0 = (uint8_t)(dw >> (8u * ((uint32_t)v & 3u)));
+        if (ends(v, c0)) {
+            if (attempt(v) == -2) break;                                            // the empty tail (trre_nft.c:788)
+            put1((uint8_t)'\n');
+            if (c0 != (uint8_t)'\n') {                                              // behind a NUL: the rest of the record is nobody's
+                while (v < a.vend - 1 && a.in_v0[v] != (uint8_t)'\n') ++v;
+            }
+            ++v;
+            open = false;
+            continue;
         }
-        bool ok = true;
-        uint32_t p = 0;
-        while (p < len) {                                                           // trre_nft.c:780-786
-            const uint8_t c0 = a.in_v0[pos + p];
-            uint32_t fw = first[0];
+        uint32_t fw = first[0];
 #pragma unroll
-            for (int w = 1; w < 8; ++w) fw = (c0 >> 5) == w ? first[w] : fw;
-            if (!((fw >> (c0 & 31u)) & 1u)) { put1(c0); ++p; continue; }
-            const int64_t r = attempt(pos, len, p);
-            if (r == -2) { ok = false; break; }
-            if (r > 0) p += (uint32_t)r;
-            else { put1(a.in_v0[pos + p]); ++p; }                                   // no match, or an empty one (its output is printed: Q3)
-        }
-        if (ok && attempt(pos, len, len) == -2) ok = false;                         // the empty tail (trre_nft.c:788)
-        if (!ok) break;
-        put1((uint8_t)'\n');
-        pos = e + 1;
+        for (int w = 1; w < 8; ++w) fw = (c0 >> 5) == w ? first[w] : fw;
+        if (!((fw >> (c0 & 31u)) & 1u)) { put1(c0); ++v; continue; }               // trre_nft.c:780-786
+        const int64_t r = attempt(v);
+        if (r == -2) break;
+        if (r > 0) v += r;
+        else { put1(c0); ++v; }                                                     // no match, or an empty one (its output is printed: Q3)
     }
     L.count = cnt;
 }

@@ -662,7 +662,7 @@ int guard_check(trre_prog* p, DeviceState* st, ScanCtx* cx, const uint8_t* d_in,
 
 // the backtracking fallback: sub-range per thread, frames (= bytes an attempt may consume) and path bytes per thread, workgroups in the pool, steps per sub-range
 constexpr int64_t kBtLaneBytes = 1024, kBtPoolBlocks = 256;
-constexpr uint32_t kBtFrames = 1024, kBtPathCap = 2048, kBtBudget = 16u << 20;
+constexpr uint32_t kBtFrames = 4096, kBtPathCap = 4096, kBtBudget = 16u << 20;
 int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap,
             hipStream_t stream) {
     using namespace trre;
