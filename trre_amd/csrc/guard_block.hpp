@@ -79,12 +79,15 @@ TRRE_HD void guard_line(const ScanArgs& a, const GuardArgs& ga, int64_t slot, in
     const GuardRun run = ga.runs[run_index];
     GuardResult R{};
     // the line: from behind the last '\n' before the run to the first one after it (the last byte of the input ends its record)
-    // (the windows next to a run need not hold a '\n' — only a byte outside the set: the walk to the line's ends is as long as the line)
+    // (the windows next to a run need not hold a '\n' — only a byte outside the set: the walk to the line's ends is as long as the line
+    // — up to 4 GiB either way: a longer line is not decided)
     int64_t ls = a.vbeg + (int64_t)run.first * h.window;
-    while (ls > a.vbeg && a.in_v0[ls - 1] != (uint8_t)'\n') --ls;
+    const int64_t ls_stop = ls - 0xffffffffll > a.vbeg ? ls - 0xffffffffll : a.vbeg;
+    while (ls > ls_stop && a.in_v0[ls - 1] != (uint8_t)'\n') --ls;
     int64_t le = a.vbeg + ((int64_t)run.last + 1) * h.window;
     if (le > a.vend - 1) le = a.vend - 1;
-    while (le < a.vend - 1 && a.in_v0[le] != (uint8_t)'\n') ++le;
+    const int64_t le_stop = le + 0xffffffffll < a.vend - 1 ? le + 0xffffffffll : a.vend - 1;
+    while (le < le_stop && a.in_v0[le] != (uint8_t)'\n') ++le;
     R.line_start = (uint64_t)(ls - a.vbeg);
     int64_t len = le - ls;
     for (int64_t v = ls; v < le; ++v)

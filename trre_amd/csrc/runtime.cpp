@@ -596,47 +596,53 @@ int guard_check(trre_prog* p, DeviceState* st, ScanCtx* cx, const uint8_t* d_in,
     std::vector<uint64_t> flags(n_words);
     HIP_TRY(hipMemcpyAsync(flags.data(), cx->d_gflags, n_words * 8, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    // the runs of flagged windows, a batch at a time (input order: the first line that overflows is the one that counts)
     std::vector<GuardRun> runs;
-    for (int64_t w = 0; w < n_win && runs.size() < kGuardMaxRuns;) {
-        const uint64_t word = flags[(size_t)(w >> 6)] >> (w & 63);
-        if (!word) { w = (w | 63) + 1; continue; }
-        if (!(word & 1u)) { w += __builtin_ctzll(word); continue; }
-        int64_t e = w;
-        while (e + 1 < n_win && ((flags[(size_t)((e + 1) >> 6)] >> ((e + 1) & 63)) & 1u)) ++e;
-        runs.push_back(GuardRun{(uint32_t)w, (uint32_t)e});
-        w = e + 1;
-    }
-    if (runs.empty()) return TRRE_OK;
-    const size_t n_runs = runs.size();
-    {   // runs and results share one allocation
-        const size_t want = n_runs * (sizeof(GuardRun) + sizeof(GuardResult));
-        rc = guard_room(&cx->d_gruns, &cx->gruns_cap, want);
-        if (rc) return rc;
-    }
-    if (!cx->d_gstack && hipMalloc(reinterpret_cast<void**>(&cx->d_gstack), (size_t)kGuardSlots * kGuardStackMax * 12) != hipSuccess)
-        return fail(TRRE_E_TOO_BIG, "error: out of device memory (stack guard)");
-    GuardResult* d_res = reinterpret_cast<GuardResult*>(cx->d_gruns);
-    GuardRun* d_runs = reinterpret_cast<GuardRun*>(cx->d_gruns + n_runs * sizeof(GuardResult));
-    HIP_TRY(hipMemcpyAsync(d_runs, runs.data(), n_runs * sizeof(GuardRun), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemsetAsync(d_res, 0, n_runs * sizeof(GuardResult), stream));
+    std::vector<GuardResult> res;
     GuardArgs ga{};
-    ga.blob = st->d_kblob;
-    ga.runs = d_runs;
-    ga.results = d_res;
-    ga.stack = cx->d_gstack;
-    static const uint64_t budget = getenv("TRRE_GUARD_BUDGET") ? (uint64_t)atoll(getenv("TRRE_GUARD_BUDGET")) : kGuardBudget;
-    ga.budget = budget;
-    ga.obuf = nullptr;                    // (the search alone: PROD writes nothing, FINAL prints nothing)
-    ga.obuf_cap = 0xffffffffu;
-    launch_guard(false, args, ga, (int64_t)n_runs, kGuardSlots, stream);
-    HIP_TRY(hipGetLastError());
-    std::vector<GuardResult> res(n_runs);
-    HIP_TRY(hipMemcpyAsync(res.data(), d_res, n_runs * sizeof(GuardResult), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    size_t bad = n_runs;
-    for (size_t k = 0; k < n_runs; ++k)
-        if (res[k].status == 1u) { bad = k; break; }
-    if (bad == n_runs) return TRRE_OK;
+    GuardResult* d_res = nullptr;
+    GuardRun* d_runs = nullptr;
+    size_t bad = 0;
+    bool found = false;
+    for (int64_t w = 0; w < n_win && !found;) {
+        runs.clear();
+        while (w < n_win && runs.size() < kGuardMaxRuns) {
+            const uint64_t word = flags[(size_t)(w >> 6)] >> (w & 63);
+            if (!word) { w = (w | 63) + 1; continue; }
+            if (!(word & 1u)) { w += __builtin_ctzll(word); continue; }
+            int64_t e = w;
+            while (e + 1 < n_win && ((flags[(size_t)((e + 1) >> 6)] >> ((e + 1) & 63)) & 1u)) ++e;
+            runs.push_back(GuardRun{(uint32_t)w, (uint32_t)e});
+            w = e + 1;
+        }
+        if (runs.empty()) break;
+        const size_t n_runs = runs.size();
+        rc = guard_room(&cx->d_gruns, &cx->gruns_cap, n_runs * (sizeof(GuardRun) + sizeof(GuardResult)));      // (runs and results share one allocation)
+        if (rc) return rc;
+        if (!cx->d_gstack && hipMalloc(reinterpret_cast<void**>(&cx->d_gstack), (size_t)kGuardSlots * kGuardStackMax * 12) != hipSuccess)
+            return fail(TRRE_E_TOO_BIG, "error: out of device memory (stack guard)");
+        d_res = reinterpret_cast<GuardResult*>(cx->d_gruns);
+        d_runs = reinterpret_cast<GuardRun*>(cx->d_gruns + n_runs * sizeof(GuardResult));
+        HIP_TRY(hipMemcpyAsync(d_runs, runs.data(), n_runs * sizeof(GuardRun), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemsetAsync(d_res, 0, n_runs * sizeof(GuardResult), stream));
+        ga = GuardArgs{};
+        ga.blob = st->d_kblob;
+        ga.runs = d_runs;
+        ga.results = d_res;
+        ga.stack = cx->d_gstack;
+        static const uint64_t budget = getenv("TRRE_GUARD_BUDGET") ? (uint64_t)atoll(getenv("TRRE_GUARD_BUDGET")) : kGuardBudget;
+        ga.budget = budget;
+        ga.obuf = nullptr;                    // (the search alone: PROD writes nothing, FINAL prints nothing)
+        ga.obuf_cap = 0xffffffffu;
+        launch_guard(false, args, ga, (int64_t)n_runs, kGuardSlots, stream);
+        HIP_TRY(hipGetLastError());
+        res.resize(n_runs);
+        HIP_TRY(hipMemcpyAsync(res.data(), d_res, n_runs * sizeof(GuardResult), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (size_t k = 0; k < n_runs && !found; ++k)
+            if (res[k].status == 1u) { bad = k; found = true; }
+    }
+    if (!found) return TRRE_OK;
     hit->hit = true;
     hit->line_start = res[bad].line_start;
     hit->part = 0xffffffffu;
