@@ -77,11 +77,16 @@ def main():
                 p = trre_amd.Program(pat, eng)
             except trre_amd.TrreError:
                 continue
-            for fam in T.shim_families(p):
+            fams = T.shim_families(p)
+            if eng == "nft" and trre_amd.KERNEL_BACKTRACK in p.allowed_kernels():
+                fams = fams + [shim_lib.BACKTRACK]         # (round 4: the backtracking fallback runs any NFT pattern)
+            for fam in fams:
                 for geo in (1, 0):
                     try:
                         got = shim_lib.scan_like_runtime(p, data, geo=geo, family=fam)
-                    except RuntimeError:
+                    except RuntimeError as e:
+                        if "limits" in str(e):
+                            continue              # the fallback's step budget / stack depth: an error at run time, not an answer
                         got = None                # diverges
                     if want is None:
                         continue
