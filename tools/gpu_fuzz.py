@@ -170,6 +170,8 @@ def main():
             buf[mis_in:mis_in + len(data)] = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
             tin = buf[mis_in:mis_in + len(data)]
             for fam in p.allowed_kernels():
+                if fam == trre_amd.KERNEL_BACKTRACK and len(data) > 70000:
+                    continue                       # (the fallback on megabytes: seconds per case where the search backtracks)
                 p.set_kernel(fam)
                 if a.verbose:
                     print("case pat=%r eng=%s fam=%d n=%d mis=(%d,%d)" % (pat, eng, fam, len(data), mis_in, mis_out), flush=True)
