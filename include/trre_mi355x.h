@@ -71,7 +71,8 @@ extern "C" {
                                    (trre_nft.c:35-36,548-556: a greedy loop over a run of 65 536 bytes): the stack guard (round 4;
                                    rounds 1-3 printed the match) finds the lines long enough for that and runs the reference's search
                                    on them, scan and match modes; TRRE_NO_STACK_GUARD=1 switches it off.  Not decided, and left as
-                                   the table kernels print it: a line whose search takes more than 16 M steps, patterns whose loops
+                                   the table kernels print it: a line whose search takes more than 8 M steps (or what 20 s of such
+                                   searches per call leave over: TRRE_GUARD_SECONDS), patterns whose loops
                                    nest more than 64 first-tried branches between two reads, generator modes */
 #define TRRE_E_CAPACITY (-9)    /* output buffer too small; *out_len holds the size needed */
 

@@ -122,3 +122,21 @@ def test_match_mode_runs_the_same_search():
     assert (hit, ls, part) == (1, 7 * 50, b"") and e.value.partial == b"abc\n" * 50
     ok = b"abc\nxx\n" * 50 + b"ab" * 16000 + b"c\nabc\n"
     assert shim_lib.stack_guard(p, ok)[0] == 0 and Oracle(pat, "nft").match(ok).endswith(b"c\nabc\n")
+
+
+def test_a_run_too_short_to_overflow_is_not_searched():
+    """the probe's windows are half the run an overflow needs at least: a line may hold whole windows of loop bytes and still no
+    stretch on which an attempt could hold 65 536 items — one pass over the line says so, nothing is searched (a search of such
+    lines, quadratic where every attempt fails at the end of the run, was the guard's worst case: 14 s a line)"""
+    pat = "(a|b)*c:x"
+    p = trre_amd.Program(pat, "nft")
+    g = guard_info(p)
+    for tail in (b"c", b""):
+        data = b"head\n" + b"x" + b"ab" * ((g["l_min"] - 100) // 2) + tail + b"\nafter\n"
+        assert shim_lib.stack_guard(p, data, budget=1000) == (0, 0, b""), tail      # (budget 1000: a search would be "not decided")
+    data = b"head\n" + b"x" + b"ab" * ((g["l_min"] - 100) // 2) + b"c\nafter\n"
+    assert guarded_scan(p, pat, data) == (Oracle(pat, "nft").scan(data), None)
+    # two such runs in one line, two bytes of another kind between them (one could be the byte of the one state outside the loop): none long enough
+    data = b"ab" * 12000 + b"--" + b"ab" * 12000 + b"c\n"
+    assert shim_lib.stack_guard(p, data, budget=1000) == (0, 0, b"")
+    assert guarded_scan(p, pat, data) == (Oracle(pat, "nft").scan(data), None)

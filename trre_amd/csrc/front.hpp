@@ -379,6 +379,7 @@ struct GuardTables {
     uint32_t d = 0;                  // items per consumed byte, at most
     uint32_t l_min = 0, window = 0;  // lines shorter than l_min cannot overflow; the probe's window
     uint32_t run_min = 0;            // ... nor lines without a run of this many bytes of `bset`
+    uint32_t n_once = 0;             // CONS states on no cycle
     uint32_t bset[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the bytes the pattern's loops read (never '\n', never NUL)
     uint32_t start = 0;
     std::vector<uint32_t> states;    // [n][4]: kind | val << 8, a, b, 0 (NKind order)

@@ -28,7 +28,7 @@ struct GuardBlobHeader {
     uint32_t off_states;                     // u32[n_states][4]: {kind | val << 8, a, b, 0}
     uint32_t total_bytes;
     uint32_t match;                          // trre -m: one attempt per line, FINAL accepts at the end of the line only
-    uint32_t pad;
+    uint32_t n_once;                         // CONS states on no cycle: the bytes of an attempt that need not be of the set
     uint32_t bset[8];                        // the bytes a window must consist of to be a suspect (never '\n', never NUL)
 };
 static_assert(sizeof(GuardBlobHeader) == 72, "header layout");
@@ -100,6 +100,26 @@ TRRE_HD void guard_line(const ScanArgs& a, const GuardArgs& ga, int64_t slot, in
     uint32_t* const stk = ga.stack + (size_t)slot * kGuardStackMax * 3;
     uint8_t* const ob = ga.obuf + (size_t)slot * ga.obuf_cap;
     const uint8_t* const in = a.in_v0 + ls;
+    // Where an attempt that overflows can begin: it consumes at least l_min bytes of the line, all but n_once of them bytes of the
+    // set — the last such position (one pass over the line, the window's far end running l_min bytes ahead of its near end).
+    // None: the line cannot overflow, nothing is searched.  Attempts that begin behind the last one are not searched either.
+    int64_t last_start = -1;
+    {
+        const uint32_t bs[8] = {h.bset[0], h.bset[1], h.bset[2], h.bset[3], h.bset[4], h.bset[5], h.bset[6], h.bset[7]};
+        auto outside = [&](int64_t k) -> uint32_t { const uint32_t c = in[k]; return ((bs[c >> 5] >> (c & 31u)) & 1u) ^ 1u; };
+        const int64_t w = (int64_t)h.l_min;
+        uint64_t bad = 0;
+        for (int64_t k = 0; k < len; ++k) {
+            bad += outside(k);
+            if (k >= w) bad -= outside(k - w);
+            if (k + 1 >= w && bad <= (uint64_t)h.n_once) last_start = k + 1 - w;
+        }
+    }
+    if (last_start < 0) {
+        R.out_len = kOut ? 0u : (uint32_t)len;
+        ga.results[run_index] = R;
+        return;
+    }
     uint64_t steps = 0, printed = 0;
     auto put = [&](uint8_t c) {
         if (kOut) {
@@ -159,12 +179,13 @@ TRRE_HD void guard_line(const ScanArgs& a, const GuardArgs& ga, int64_t slot, in
         return;
     }
     while (p < (uint32_t)len) {                                             // trre_nft.c:778-784
+        if (!kOut && (int64_t)p > last_start) { r = 0; break; }             // (no attempt from here on can hold that many items)
         r = attempt(p);
         if (r <= -2) break;
         if (r > 0) p += (uint32_t)r;
         else { put(in[p]); ++p; }
     }
-    if (r > -2) r = attempt((uint32_t)len);                                 // the empty tail (trre_nft.c:786)
+    if (r > -2 && p >= (uint32_t)len) r = attempt((uint32_t)len);            // the empty tail (trre_nft.c:786)
     if (r == -2) { R.status = 1u; R.bad_at = p; }
     else if (r == -3) R.status = 2u;
     R.out_len = kOut ? (uint32_t)(printed > 0xffffffffull ? 0xffffffffull : printed) : (uint32_t)len;    // (the search alone: the line's length)

@@ -6,6 +6,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <algorithm>
 #include <atomic>
@@ -555,8 +556,9 @@ int ensure_copy_workspace(ScanCtx* c, int64_t n_lanes) {
 
 // ---- the stack guard (guard_block.hpp) --------------------------------------------------------------------------------
 constexpr int64_t kGuardSlots = 256;                       // lines searched at a time (a stack of 65 536 items each: 192 MiB in all)
-constexpr size_t kGuardMaxRuns = 1u << 20;
-constexpr uint64_t kGuardBudget = 1ull << 24;              // search steps per line; beyond: not decided (the scan's output stands)
+constexpr size_t kGuardMaxRuns = 1024;                     // suspects per batch (the clock is looked at between batches)
+constexpr double kGuardSeconds = 20.0;                     // ... and what the guard may spend on one scan; the lines behind that are not decided
+constexpr uint64_t kGuardBudget = 1ull << 23;              // search steps per line; beyond: not decided (the scan's output stands)
 constexpr const char* kStackMsg = "error: stack max capacity reached";
 bool guard_applies(const trre_prog& p, const ScanCtx& cx, size_t n) {
     static const bool off = getenv("TRRE_NO_STACK_GUARD") != nullptr;
@@ -604,7 +606,10 @@ int guard_check(trre_prog* p, DeviceState* st, ScanCtx* cx, const uint8_t* d_in,
     GuardRun* d_runs = nullptr;
     size_t bad = 0;
     bool found = false;
+    const auto t_begin = std::chrono::steady_clock::now();
+    static const double seconds = getenv("TRRE_GUARD_SECONDS") ? atof(getenv("TRRE_GUARD_SECONDS")) : kGuardSeconds;
     for (int64_t w = 0; w < n_win && !found;) {
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > seconds) break;
         runs.clear();
         while (w < n_win && runs.size() < kGuardMaxRuns) {
             const uint64_t word = flags[(size_t)(w >> 6)] >> (w & 63);
@@ -1217,6 +1222,7 @@ int compile_impl(const std::string& pattern, int engine, trre_prog** out, int mo
             gh.off_states = (uint32_t)sizeof gh;
             gh.total_bytes = (uint32_t)(sizeof gh + p->guard.states.size() * 4);
             gh.match = match ? 1u : 0u;
+            gh.n_once = p->guard.n_once;
             for (int k = 0; k < 8; ++k) gh.bset[k] = p->guard.bset[k];
             put(p->kblob, 0, &gh, 1);
             put(p->kblob, gh.off_states, p->guard.states.data(), p->guard.states.size());

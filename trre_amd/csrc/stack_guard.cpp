@@ -151,6 +151,7 @@ GuardTables build_guard(const Nft& nft) {
         if (!cyclic[s]) { ++n_once; continue; }
         if (c != 0 && c != (uint8_t)'\n') g.bset[c >> 5] |= 1u << (c & 31);
     }
+    g.n_once = (uint32_t)std::min<uint64_t>(n_once, 0xffffffffu);
     const uint64_t run_min = n_once >= g.l_min ? 0 : ((uint64_t)g.l_min - n_once) / (n_once + 1);
     if (run_min >= 64) {
         g.run_min = (uint32_t)run_min;
