@@ -140,3 +140,15 @@ def test_a_run_too_short_to_overflow_is_not_searched():
     data = b"ab" * 12000 + b"--" + b"ab" * 12000 + b"c\n"
     assert shim_lib.stack_guard(p, data, budget=1000) == (0, 0, b"")
     assert guarded_scan(p, pat, data) == (Oracle(pat, "nft").scan(data), None)
+
+
+def test_random_looping_patterns_at_their_thresholds():
+    """a short run of tools/guard_fuzz.py: random looping patterns, lines with runs of their loop bytes around the lengths at which
+    the reference's search overflows — the guard stops a scan exactly where the oracle fails, with the same partial output"""
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "guard_fuzz.py")
+    r = subprocess.run([sys.executable, script, "20250928", "15"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=200)
+    out = r.stdout.decode("latin-1")
+    assert r.returncode == 0 and " 0 mismatches" in out, out[-2000:]
