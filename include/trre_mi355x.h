@@ -56,7 +56,9 @@ extern "C" {
 #define TRRE_E_SYNTAX (-1)      /* the reference prints "error: ..." and exits 1 (message kept) */
 #define TRRE_E_UNDEFINED (-2)   /* the reference reads outside its buffers on this pattern */
 #define TRRE_E_EPS_CYCLE (-3)   /* epsilon cycle: the reference recurses without bound (DFT) */
-#define TRRE_E_TOO_BIG (-4)     /* determinisation exceeds the state/residual caps */
+#define TRRE_E_TOO_BIG (-4)     /* DFT engine, at run time: the determinised states THIS INPUT visits do not fit the memory limit of the lazy
+                                   tables (TRRE_LAZY_MAX_BYTES, 16 GiB; the reference keeps every state it meets, too).  Rounds 1-4 returned it
+                                   at compile time for every pattern beyond the eager construction's caps. */
 #define TRRE_E_UNSUPPORTED (-5) /* legal pattern, outside this engine's GPU limits (modes other than scan: a backward DFA beyond the guided
                                    families' limits; scan mode, NFT engine, at run time: an attempt beyond the backtracking fallback's limits) */
 #define TRRE_E_DEVICE (-6)      /* HIP runtime failure / no GPU */
@@ -93,6 +95,11 @@ extern "C" {
                                      explicit stack (round 4).  What a pattern beyond the limits of every other family runs on (round 3:
                                      TRRE_E_UNSUPPORTED); exponential where the reference is.  A 1 KiB sub-range whose search takes more than 16 M steps, an
                                      attempt that consumes more than 4 096 bytes or builds more than 4 KiB of output: TRRE_E_UNSUPPORTED at run time */
+
+#define TRRE_KERNEL_DFT_LAZY 10   /* DFT engine, scan mode, any pattern: determinisation on the fly as in the reference (trre_dft.c:1135-1175) — a lane per
+                                     sub-range walks the rows that exist, an edge nobody has explored yet is listed and built on the host, the lanes that met
+                                     it run again (round 5).  What a pattern beyond the eager construction's caps runs on ('((a:x)*b)|((a:y)*c)',
+                                     '(a|b)*a(a|b){18}:x'; rounds 1-4: TRRE_E_TOO_BIG at compile time) */
 
 typedef struct trre_prog trre_prog;
 
@@ -180,6 +187,12 @@ int trre_last_kernel_ms(trre_prog* p, float* ms);
  * byte i; tests/cpu_shim.cpp runs the backward kernel's per-thread body on the host).  Host-only, no device involved; not a
  * replacement for trre_scan_host, which computes the symbols on the GPU. */
 int trre_debug_generate(trre_prog* p, const uint8_t* in, size_t n, const uint8_t* sym, uint8_t* out, size_t cap, size_t* out_len);
+
+/* Diagnostics / CPU test tier: the lazily determinised tables as they stand (which 0: u32 n_cls, u32 rows, u8 cls[256]; 1: the entries
+ * [rows][n_cls] of 8 bytes; 2: the pool of texts) and the exploration of a list of n miss records (16 words: row, class, m, 0, the m <= 48 bytes behind the byte that missed) plus up to spec_states states
+ * ahead — what trre_scan_* does between two rounds of a launch of TRRE_KERNEL_DFT_LAZY.  Host-only. */
+size_t trre_debug_lazy_tables(trre_prog* p, int which, void* buf, size_t cap);
+int trre_debug_lazy_explore(trre_prog* p, const uint32_t* misses, size_t n, size_t spec_states);
 
 /* Line sharding (multi-GPU, trre has no exchange step: lines are independent).
  * Fills bounds[0..nshards] with byte offsets such that every shard but the

@@ -18,6 +18,7 @@
 #include "../trre_amd/csrc/scan_block.hpp"
 #include "../trre_amd/csrc/splice_block.hpp"
 #include "../trre_amd/csrc/gen_block.hpp"
+#include "../trre_amd/csrc/lazy_block.hpp"
 #include "../trre_amd/csrc/guard_block.hpp"
 
 using namespace trre;
@@ -898,6 +899,57 @@ int shim_backtrack(const uint8_t* nblob, int geo, const uint8_t* in, size_t n, i
         uint32_t lst = 0;
         bt_lane<2>(a, G, ga, lane % pool, lane, lane_bytes, base[lane], budget, L, lst);
         if (L.count != cnt[lane]) status |= 1u << 30;                     // count and emit passes disagree
+    }
+    *status_out = status;
+    return 0;
+}
+
+// One round of the lazy family as the runtime runs it (lazy_block.hpp; runtime.cpp: lazy_round): the count pass for the lanes that have no
+// result yet (lane_counts[lane] == kLazyVoid), and — when no lane met an unexplored edge — the exclusive sum and the emit pass.  The caller
+// (tests/shim_lib.py) has the library explore the listed misses and comes back with the grown tables.  ent: the caller's copy (lanes mark
+// the misses they list).
+int shim_lazy_round(const uint8_t* cls, uint64_t* ent, const uint8_t* pool, uint32_t n_cls, int geo, const uint8_t* in, size_t n, int in_mis,
+                    uint32_t* lane_counts, uint32_t* miss, uint32_t miss_cap, uint64_t budget, uint8_t* out, size_t cap, size_t* m, uint32_t* status_out) {
+    *m = 0; *status_out = 0;
+    miss[0] = 0;
+    if (n == 0) return 0;
+    std::vector<uint8_t> ibuf(n + 64, 0xAA);
+    uint8_t* ia = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(ibuf.data()) + 15) & ~(uintptr_t)15) + in_mis;
+    std::memcpy(ia, in, n);
+    ScanArgs a{};
+    const int64_t al = (int64_t)(reinterpret_cast<uintptr_t>(ia) & 15u);
+    a.in_v0 = ia - al;
+    a.vbeg = al;
+    a.vend = al + (int64_t)n;
+    uint32_t status = 0;
+    a.status = &status;
+    a.out = out;
+    a.cap = cap;
+    LazyArgs la{cls, ent, pool, n_cls, miss, miss_cap, budget};
+    const int64_t lane_bytes = geo == 0 ? 1024 : 64;
+    const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
+    for (int64_t lane = n_lanes - 1; lane >= 0; --lane) {
+        if (lane_counts[lane] != kLazyVoid) continue;
+        DirectLane L;
+        uint32_t lst = 0;
+        bool voided = false;
+        lazy_lane<1>(a, la, lane, lane_bytes, 0, L, lst, voided);
+        status |= lst;
+        if (!voided && !(lst & (kStEditOverflow | kStDiverge))) lane_counts[lane] = (uint32_t)L.count;
+    }
+    *status_out = status;
+    if (status & (kStMiss | kStEditOverflow | kStDiverge)) return 0;
+    uint64_t run = 0;
+    std::vector<uint64_t> base(n_lanes);
+    for (int64_t lane = 0; lane < n_lanes; ++lane) { base[lane] = run; run += lane_counts[lane]; }
+    *m = (size_t)run;
+    if (run > cap) { *status_out = status | kStCapacity; return 0; }
+    for (int64_t lane = 0; lane < n_lanes; ++lane) {
+        DirectLane L;
+        uint32_t lst = 0;
+        bool voided = false;
+        lazy_lane<2>(a, la, lane, lane_bytes, base[lane], L, lst, voided);
+        if (L.count != lane_counts[lane] || voided) status |= 1u << 30;    // count and emit passes disagree
     }
     *status_out = status;
     return 0;

@@ -182,8 +182,41 @@ def main():
         for pat in corpus.GEN_SCAN_PATTERNS:
             for name in ("gen_lines", "gen_text", "gen_nul", "no_trailing_newline", "only_newlines", "empty", "eps_with_a"):
                 add_all(pat, name, ["-a"])
+        # 6. (round 5) DFT patterns beyond any eager determinisation — a state per run length (two loops that print different texts
+        #    before the byte that decides between them: the residuals grow with the run), 2^19 states (which of the last 19 bytes was
+        #    an 'a') — the reference builds only the states its input visits (trre_dft.c:1135-1175).  ./trre_dft only.
+        rng = random.Random(77)
+
+        def soup(alpha, n_lines, top):
+            return b"".join(bytes(rng.choice(alpha) for _ in range(rng.randint(0, top))) + b"\n" for _ in range(n_lines))
+        inputs.update({
+            "lazy_runs": b"aaab\naaac\nb\nc\n\naaaa\nxaaabyaacz\nab ac aab aac\n" + b"a" * 700 + b"b\n" + b"a" * 900 + b"c tail\n" + b"a" * 1200 + b"\n" +
+                         soup(b"aaaaabc x", 120, 60) + b"aab\0aac\naac",
+            "lazy_ab": soup(b"ab", 60, 90) + soup(b"aabbc ", 60, 70) + b"a" * 300 + b"\n" + b"ab" * 200 + b"\n" + b"abba\0abab\nbaab",
+            "lazy_abcde": soup(b"abcde", 80, 60) + soup(b"abcdexy ", 80, 60) + b"abcabcabcabcd\nabcabce\nabc",
+        })
+        for name in ("lazy_runs", "lazy_ab", "lazy_abcde"):
+            paths[name] = os.path.join(td, name)
+            with open(paths[name], "wb") as f:
+                f.write(inputs[name])
+        lazy_cases = []
+        for pat, names in [("((a:x)*b)|((a:y)*c)", ("lazy_runs", "lazy_ab", "words")),
+                           ("((a:x)*b)|((a:yy)*c)", ("lazy_runs",)),
+                           ("(a:x)*b|(a:y)*c|(a:z)*", ("lazy_runs",)),
+                           ("(a:x|b:y)*c|(a:p|b:q)*d", ("lazy_abcde", "lazy_ab")),
+                           ("([a-c]:x)*d|([a-c]:y)*e", ("lazy_abcde",)),
+                           ("(.:x)*d|(.:y)*e", ("lazy_abcde", "words")),
+                           ("(a|b)*a(a|b){14}:x", ("lazy_ab", "lazy_runs")),
+                           ("(a|b)*a(a|b){18}:x", ("lazy_ab", "lazy_runs")),
+                           ("(a|b)*a(a|b){22}:x", ("lazy_ab",)),
+                           ("(a|b)*a(a|b){18}:x|((a:x)*c)|((a:y)*d)", ("lazy_ab", "lazy_abcde"))]:
+            for name in names:
+                rc, got, err = run_ref_full("dft", pat, paths[name])
+                assert rc == 0, (pat, name, rc, err)
+                lazy_cases.append({"pattern": pat, "input": name, "dft": enc(got)})
     doc = {"about": "scan-mode (and `-m`) outputs of the compiled reference (c0stya/trre @ 2025-05-23), see make_golden.py",
-           "inputs": {k: enc(v) for k, v in inputs.items()}, "cases": out_cases, "match_cases": match_cases, "all_cases": all_cases}
+           "inputs": {k: enc(v) for k, v in inputs.items()}, "cases": out_cases, "match_cases": match_cases, "all_cases": all_cases,
+           "lazy_cases": lazy_cases}
     os.makedirs(os.path.join(HERE, "golden"), exist_ok=True)
     path = os.path.join(HERE, "golden", "golden.json")
     with open(path, "w") as f:

@@ -13,7 +13,7 @@ ST_NUL, ST_DIVERGE, ST_CAPACITY, ST_LONGLINE, ST_NEEDSCRATCH, ST_OVERFLOW, ST_MI
 
 
 def build():
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("scan_block.hpp", "scan_core.hpp", "device_blob.hpp", "splice_block.hpp", "patch_block.hpp", "gen_block.hpp", "guard_block.hpp")]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("scan_block.hpp", "scan_core.hpp", "device_blob.hpp", "splice_block.hpp", "patch_block.hpp", "gen_block.hpp", "lazy_block.hpp", "guard_block.hpp")]
     if os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(d) for d in deps):
         return SO
     os.makedirs(os.path.dirname(SO), exist_ok=True)
@@ -42,6 +42,9 @@ def lib():
                                      ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_uint32)]
         L.shim_guard.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(ctypes.c_int),
                                  ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+        L.shim_lazy_round.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t,
+                                      ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_size_t,
+                                      ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_uint32)]
         _lib = L
     return _lib
 
@@ -159,6 +162,13 @@ def scan_like_runtime(prog, data, geo=1, family=None, in_mis=0, out_mis=0):
         fam = {6: GUIDED_LP, 7: GUIDED_GEN}.get(info.kernel, info.kernel)
     if fam in (GUIDED_LP, GUIDED_GEN, GUIDED_GEN8, GUIDED_LP_RING, GUIDED_LP8, GUIDED_GEN_SPLICE):
         return scan_guided_like_runtime(prog, data, geo, fam, in_mis, out_mis)
+    if family == DFT_LAZY or (not family and info.kernel == 10):
+        out, st, _ = scan_lazy(prog, data, geo, in_mis)
+        if st & ST_EDIT_OVERFLOW:
+            raise RuntimeError("limits")
+        if st & ST_DIVERGE:
+            raise RuntimeError("diverges")
+        return out
     if family == BACKTRACK or (not family and info.kernel == 9):       # (ABI family 9; the shim's own 9 is a direct walker of the stream family)
         out, st = scan_backtrack(prog, data, geo, in_mis)
         if st & ST_EDIT_OVERFLOW:
@@ -233,6 +243,47 @@ def scan_backtrack(prog, data, geo=1, in_mis=0, frames=4096, path_cap=4096, budg
             continue
         return out.raw[:m.value], st.value
     raise RuntimeError("capacity")
+
+
+DFT_LAZY = 31                                        # the deterministic engine on tables still being built (ABI family 10)
+ST_MISS = 128
+
+
+def scan_lazy(prog, data, geo=1, in_mis=0, miss_cap=1 << 16, spec=64, budget=1 << 32, max_rounds=100000):
+    """the lazy family as the runtime runs it: rounds of (count pass for the lanes without a result; the library explores the edges
+    the round listed) until a round lists none, then the emit pass.  Returns (output, status, rounds); ST_DIVERGE: the reference dies here"""
+    import numpy as np
+    lane_bytes = 1024 if geo == 0 else 64
+    n_lanes = ((in_mis + 15) + len(data) + lane_bytes - 1) // lane_bytes + 2
+    lane_counts = np.full(n_lanes, 0xffffffff, dtype=np.uint32)
+    miss = np.zeros(2 + 16 * miss_cap, dtype=np.uint32)
+    cap = max(1 << 16, 4 * len(data))
+    rounds = 0
+    while True:
+        head, ent, pool = prog.lazy_tables()
+        n_cls, cls = struct.unpack_from("<I", head, 0)[0], head[8:8 + 256]
+        entb = np.frombuffer(bytearray(ent), dtype=np.uint64).copy()
+        out = ctypes.create_string_buffer(cap)
+        m = ctypes.c_size_t()
+        st = ctypes.c_uint32()
+        rc = lib().shim_lazy_round(cls, entb.ctypes.data, pool if pool else b"\0", n_cls, geo, data, len(data), in_mis, lane_counts.ctypes.data,
+                                   miss.ctypes.data, miss_cap, budget, out, cap, ctypes.byref(m), ctypes.byref(st))
+        if rc:
+            raise RuntimeError("shim rc %d" % rc)
+        rounds += 1
+        assert not st.value & ST_MISMATCH, "count and emit passes disagree"
+        if st.value & (ST_DIVERGE | ST_EDIT_OVERFLOW):
+            return b"", st.value, rounds
+        if st.value & ST_MISS:
+            n = min(int(miss[0]), miss_cap)
+            assert n > 0, "a void round listed no miss"
+            assert rounds < max_rounds
+            prog.lazy_explore(miss[2:2 + 16 * n], spec)
+            continue
+        if st.value & ST_CAPACITY:
+            cap = m.value + 64
+            continue
+        return out.raw[:m.value], st.value, rounds
 
 
 def rev_symbols(rblob, data, geo=1, in_mis=0):

@@ -25,8 +25,9 @@ KERNEL_AUTO, KERNEL_BYTEMAP, KERNEL_TILE_LP, KERNEL_TILE_GEN, KERNEL_STREAM_LP, 
 KERNEL_GUIDED_LP, KERNEL_GUIDED_GEN = 6, 7
 KERNEL_GENERATE = 8
 KERNEL_BACKTRACK = 9
+KERNEL_DFT_LAZY = 10
 KERNEL_NAMES = {0: "auto", 1: "bytemap", 2: "tile_lp", 3: "tile_gen", 4: "stream_lp", 5: "stream_gen", 6: "guided_lp",
-                7: "guided_gen", 8: "generate", 9: "backtrack"}
+                7: "guided_gen", 8: "generate", 9: "backtrack", 10: "dft_lazy"}
 
 FLAG_LENGTH_PRESERVING, FLAG_MEMORYLESS, FLAG_NO_OVERRUN = 1, 2, 4
 
@@ -98,6 +99,9 @@ def lib():
         L.trre_set_profiling.argtypes = [vp, ctypes.c_int]
         L.trre_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         L.trre_debug_generate.argtypes = [vp, ctypes.c_char_p, sz, ctypes.c_char_p, vp, sz, ctypes.POINTER(sz)]
+        L.trre_debug_lazy_tables.argtypes = [vp, ctypes.c_int, vp, sz]
+        L.trre_debug_lazy_tables.restype = sz
+        L.trre_debug_lazy_explore.argtypes = [vp, vp, sz, sz]
         L.trre_shard_bounds.argtypes = [ctypes.c_char_p, sz, ctypes.c_int, ctypes.POINTER(sz)]
         _lib = L
     return _lib
@@ -176,10 +180,26 @@ class Program:
         lib().trre_export_guided_tables(self._h, 3, buf, n)
         return buf.raw[:n]
 
+    def lazy_tables(self):
+        """DFT engine (CPU test tier): the lazily determinised tables as they stand: (header, entries, pool)"""
+        parts = []
+        for which in (0, 1, 2):
+            n = lib().trre_debug_lazy_tables(self._h, which, None, 0)
+            buf = ctypes.create_string_buffer(max(n, 1))
+            lib().trre_debug_lazy_tables(self._h, which, buf, n)
+            parts.append(buf.raw[:n])
+        return tuple(parts)
+
+    def lazy_explore(self, misses, spec_states=0):
+        """... and the exploration of a list of misses (numpy uint32, 16 words per record)"""
+        import numpy as np
+        m = np.ascontiguousarray(misses, dtype=np.uint32)
+        _check(lib().trre_debug_lazy_explore(self._h, m.ctypes.data, len(m) // 16, spec_states))
+
     def allowed_kernels(self):
         ok = []
         for fam in (KERNEL_BYTEMAP, KERNEL_TILE_LP, KERNEL_TILE_GEN, KERNEL_STREAM_LP, KERNEL_STREAM_GEN, KERNEL_GUIDED_LP,
-                    KERNEL_GUIDED_GEN, KERNEL_BACKTRACK):
+                    KERNEL_GUIDED_GEN, KERNEL_BACKTRACK, KERNEL_DFT_LAZY):
             if lib().trre_set_kernel(self._h, fam) == 0:
                 ok.append(fam)
         lib().trre_set_kernel(self._h, KERNEL_AUTO)

@@ -7,6 +7,7 @@
 #pragma once
 #include <array>
 #include <cstdint>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -144,6 +145,49 @@ struct DftTables {
     uint32_t n_states = 0;               // determinised states incl. final ones
 };
 DftTables flatten_dft(const Dft& dft);
+
+// ---- the same construction one table miss at a time (dft_build.cpp: LazyDft; round 5) --------------------------------
+// What the reference does (trre_dft.c:1135-1175: a dstate is built when the input first takes an edge to it), for the
+// patterns whose eager construction does not end within DftLimits — '((a:x)*b)|((a:y)*c)' has a state per run length,
+// '(a|b)*a(a|b){18}:x' 2^19 of them — and, on request, for any pattern (the parity tests).  The tables are the device's
+// (same entries as DftTables, rows of n_cls entries, classes fixed up front: a class per byte some CONS state reads, one
+// for all the others, one for the line terminators) plus a third kind of dead entry:
+constexpr uint64_t kEntUnexplored = 6u << 2;   // nobody has looked at this edge yet (kind "dead", ilen 6)
+constexpr uint64_t kEntMissNoted = 5u << 2;    // device copy only: a lane has listed the edge among its launch's misses
+// A scan walks what exists; a lane that meets an unexplored edge lists it {row, class} and is void; explore() builds the
+// listed edges (and, breadth first from the states they led to, up to `spec_states` more: fewer rounds), the runtime
+// uploads rows [first_dirty_row(), n_rows()) and the pool's new bytes and runs the void lanes again.
+constexpr uint32_t kLazyMissWords = 16;
+struct LazyLimits {
+    size_t max_residual = (size_t)1 << 20;      // bytes of pending output in one item
+    uint64_t max_edge_work = 400000000ull;      // closure steps for ONE edge the input takes
+    uint64_t spec_edge_work = 200000;           // ... for one edge explored ahead of the input (beyond: left unexplored)
+    size_t max_bytes = (size_t)16 << 30;        // host memory of the tables and the item lists (TRRE_LAZY_MAX_BYTES)
+    size_t seed_states = 2048;                  // states built at compile time, breadth first from the start
+};
+class LazyDft {
+public:
+    explicit LazyDft(const Nft& nft, const LazyLimits& lim = LazyLimits());
+    ~LazyDft();
+    LazyDft(const LazyDft&) = delete;
+    LazyDft& operator=(const LazyDft&) = delete;
+    uint32_t n_cls() const;
+    const uint8_t* cls() const;                 // [256]; class 0 = '\n' and NUL
+    uint32_t n_rows() const;
+    uint32_t n_states() const;                  // determinised states incl. final ones
+    const uint64_t* ent() const;                // [n_rows][n_cls]
+    const uint8_t* pool() const;
+    size_t pool_bytes() const;
+    // misses: n records of kLazyMissWords words {row, class, m, 0, the m <= 48 bytes of the line behind the byte that missed}: the edge is
+    // built, then the attempt is followed along those bytes.  Throws Error(kErrTooBig) when an edge the INPUT takes cannot be built (the tables the
+    // reference itself would need do not fit); edges explored ahead of the input never throw.
+    void explore(const uint32_t* misses, size_t n, size_t spec_states);
+    uint32_t epoch() const;                     // counts explore() calls that changed something
+    uint32_t first_dirty_row(uint32_t since_epoch) const;   // first row changed after that epoch (n_rows(): none)
+private:
+    struct Impl;
+    std::unique_ptr<Impl> impl_;
+};
 
 // Stream tables: the scan line loop folded into one deterministic transducer over
 // the raw byte stream (stream_build.cpp).  Entry (64 bit):

@@ -9,6 +9,7 @@ struct PatchArgs;
 struct FbCopyArgs;
 struct GenArgs;
 struct GuardArgs;
+struct LazyArgs;
 
 constexpr int kEngineNft = 0, kEngineDft = 1;
 
@@ -61,6 +62,9 @@ void launch_guard(bool out, const ScanArgs& a, const GuardArgs& ga, int64_t n_ru
 // the backtracking fallback (gen_block.hpp: bt_lane): which 1 count, 2 emit; pool_blocks workgroups of 256 threads take the chunks in turn (ga holds
 // pool_blocks * 256 stacks and path buffers)
 void launch_bt(int which, const ScanArgs& a, const GenArgs& ga, int64_t lane_bytes, int64_t n_chunks, int64_t pool_blocks, uint32_t budget, void* stream);
+// the deterministic engine on tables still being built (lazy_block.hpp): which 1 count (lanes whose lane_counts entry is not kLazyVoid keep
+// it), 2 emit (leaves at once when the count pass was not final); chunks of 256 lanes
+void launch_lazy(int which, const ScanArgs& a, const LazyArgs& la, int64_t lane_bytes, int64_t n_chunks, void* stream);
 void launch_chunk_scan(const uint64_t* total, uint64_t* base, int64_t n_chunks, void* stream);
 void launch_bytemap(const ScanArgs& a, void* stream);
 void launch_nul_eol(const uint8_t* in, int64_t n, const uint64_t* pos, uint64_t* eol, uint32_t count, void* stream);

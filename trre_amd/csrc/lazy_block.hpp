@@ -1,0 +1,171 @@
+// lazy_block.hpp — the deterministic engine on tables that are still being built (round 5; front.hpp: LazyDft).
+//
+// The reference determinises on the fly: infer_dft builds a dstate when the input first takes an edge to it
+// (trre_dft.c:1135-1175), so it runs every pattern on every finite input — also '((a:x)*b)|((a:y)*c)', whose eager
+// construction never ends (a state per run length), and '(a|b)*a(a|b){18}:x' with its 2^19 states.  Rounds 1-4 determinised
+// eagerly and refused what did not fit (TRRE_E_TOO_BIG).  This family is the reference's scheme with the roles split: a
+// lane walks the scan loop (trre_dft.c:1272-1286, 1110-1196) over the rows that exist, in HBM; an edge nobody has explored yet
+// is listed {row, class} — the first lane that meets it marks the entry so that it is listed once — and the lane's result is
+// void; the host builds the listed edges, uploads the new rows and the launch runs again for the void lanes.  A round without
+// misses is the answer.  Count, exclusive sum, emit as in every general family; a thread per sub-range (the lines that start
+// in it), byte loads — a last resort like the backtracking fallback of the other engine, not a fast path.
+//
+// The lane body is TRRE_HD: tests/cpu_shim.cpp runs it lane by lane on the host, with the library's explore() in between.
+#pragma once
+#include "scan_block.hpp"
+
+namespace trre {
+
+constexpr uint32_t kStMiss = 1u << 7;          // a lane met an unexplored edge: the launch is not final
+constexpr uint32_t kLazyVoid = 0xffffffffu;    // lane_counts: this lane has no result yet
+constexpr uint64_t kLazyUnexplored = 6u << 2, kLazyNoted = 5u << 2;   // (front.hpp: kEntUnexplored, kEntMissNoted)
+#ifndef TRRE_LAZY_MISS_WORDS
+#define TRRE_LAZY_MISS_WORDS 16
+#endif
+constexpr uint32_t kLazyRecWords = TRRE_LAZY_MISS_WORDS;            // (front.hpp: kLazyMissWords — this header does not include the front end)
+
+struct LazyArgs {
+    const uint8_t* cls;        // [256]
+    uint64_t* ent;             // [n_rows][n_cls] (the device's copy: lanes mark the misses they list)
+    const uint8_t* pool;
+    uint32_t n_cls;
+    uint32_t* miss;            // [0] = misses listed, [1] = unused, then records of kLazyRecWords (16) words: {row, class, n, 0, the n <= 48 bytes
+                               // of the line behind the byte that missed} — the host builds the edge and follows the attempt along those bytes
+                               // (trre_dft.c:1135-1175 goes on from a miss the same way), so that a deep walk costs a round per 49 states, not one each
+    uint32_t miss_cap;
+    uint64_t budget;           // table steps per sub-range
+};
+
+constexpr uint32_t kLazyFollow = 48;     // (kLazyMissWords: front.hpp / below)
+template <class ByteAt>
+TRRE_HD void lazy_note_miss(const LazyArgs& la, uint32_t row, uint32_t k, int64_t behind, ByteAt byte_at) {
+    uint64_t* e = la.ent + (uint64_t)row * la.n_cls + k;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (atomicCAS(reinterpret_cast<unsigned long long*>(e), (unsigned long long)kLazyUnexplored, (unsigned long long)kLazyNoted) != kLazyUnexplored) return;
+    const uint32_t at = atomicAdd(la.miss, 1u);
+#else
+    if (*e != kLazyUnexplored) return;
+    *e = kLazyNoted;
+    const uint32_t at = la.miss[0]++;
+#endif
+    if (at < la.miss_cap) {
+        uint32_t* r = la.miss + 2 + (size_t)kLazyRecWords * at;
+        uint32_t n = 0, w = 0;
+        for (; n < kLazyFollow; ++n) {
+            const uint8_t c = byte_at(behind + n);
+            if (c == (uint8_t)'\n' || c == 0) break;
+            w |= (uint32_t)c << (8u * (n & 3u));
+            if ((n & 3u) == 3u) { r[4 + (n >> 2)] = w; w = 0; }
+        }
+        if (n & 3u) r[4 + (n >> 2)] = w;
+        r[0] = row; r[1] = k; r[2] = n; r[3] = 0;
+        return;
+    }
+    // the list is full: the edge stays unexplored for the next round
+#if defined(__HIP_DEVICE_COMPILE__)
+    __hip_atomic_store(e, kLazyUnexplored, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    *e = kLazyUnexplored;
+#endif
+}
+
+// kMode 1: count (L.count; void: kLazyVoid is the caller's business — `voided` says so); 2: emit at a.out + out_base
+template <int kMode>
+TRRE_HD void lazy_lane(const ScanArgs& a, const LazyArgs& la, int64_t lane, int64_t lane_bytes, uint64_t out_base, DirectLane& L, uint32_t& status,
+                       bool& voided) {
+    const int64_t lo = lane * lane_bytes;
+    int64_t hi = lo + lane_bytes;
+    if (hi > a.vend) hi = a.vend;
+    uint64_t cnt = 0, steps = 0;
+    L.count = 0;
+    voided = false;
+    if (lo >= hi) return;
+    uint8_t* const op = kMode == 2 ? a.out + out_base : nullptr;
+    auto put1 = [&](uint8_t c) {
+        if (kMode == 2) op[cnt] = c;
+        cnt += 1;
+    };
+    // a record's content ends at its '\n', at a NUL before it (Q2) or at the last byte of the input, which ends its record
+    // whatever it is (Q1)
+    auto byte_at = [&](int64_t v) -> uint8_t { return v >= a.vend - 1 ? (uint8_t)'\n' : a.in_v0[v]; };
+    auto entry = [&](uint32_t row, uint8_t c, uint32_t& k) -> uint64_t {
+        k = la.cls[c];
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __hip_atomic_load(la.ent + (uint64_t)row * la.n_cls + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        return la.ent[(uint64_t)row * la.n_cls + k];
+#endif
+    };
+    auto out_len = [&](uint64_t e) -> uint32_t {
+        const uint32_t il = ent_ilen(e);
+        if (il != 7u) return il;
+        const uint8_t* r = la.pool + ent_hi(e);
+        return (uint32_t)r[0] | (uint32_t)r[1] << 8 | (uint32_t)r[2] << 16 | (uint32_t)r[3] << 24;
+    };
+    int64_t v = lo;
+    if (!(lo == a.vbeg || (lo > a.vbeg && a.in_v0[lo - 1] == (uint8_t)'\n'))) v = lo < a.vbeg ? a.vbeg : first_line_start_safe(a, lo, hi);
+    // the lines that START in [lo, hi)
+    while (v < hi) {
+        bool dry = false;                                   // the line met a miss: nothing more to learn from it
+        for (;;) {
+            const uint8_t c0 = byte_at(v);
+            if (c0 == (uint8_t)'\n' || c0 == 0 || dry) {
+                // (the attempt on the empty tail — trre_dft.c:1284 — looks at no byte and the start state is never final: it prints nothing)
+                put1((uint8_t)'\n');
+                while (byte_at(v) != (uint8_t)'\n') ++v;    // behind a NUL (or a miss): the rest of the record is nobody's
+                ++v;
+                break;
+            }
+            // one attempt from v (infer_dft): walk until the first final state; a dead edge or the end of the line discards it
+            uint32_t row = 0, k;
+            int64_t i = v;
+            uint64_t e = entry(0, c0, k), acc = 0;
+            bool ok = false, miss = false;
+            for (;;) {
+                if (++steps > la.budget) { status |= kStEditOverflow; L.count = cnt; return; }
+                if (e == kLazyUnexplored || e == kLazyNoted) {
+                    if (e == kLazyUnexplored) lazy_note_miss(la, row, k, i + 1, byte_at);
+                    miss = true;
+                    break;
+                }
+                const uint32_t kind = ent_kind(e);
+                if (kind == 3u) { status |= kStDiverge; L.count = cnt; return; }     // the reference's closure never returns from this edge
+                if (kind == 0u) break;
+                if (kMode == 1) acc += out_len(e);
+                ++i;
+                if (kind == 2u) { ok = true; break; }
+                row = ent_next(e);
+                e = entry(row, byte_at(i), k);
+            }
+            if (miss) { voided = true; status |= kStMiss; dry = true; continue; }
+            if (!ok) { put1(c0); ++v; continue; }           // trre_dft.c:1281-1282
+            if (kMode == 1) {
+                cnt += acc;
+            } else {                                        // the attempt again, this time printing (trre_dft.c:1121-1122)
+                uint32_t r2 = 0, k2;
+                int64_t j = v;
+                uint64_t e2 = entry(0, c0, k2);
+                for (;;) {
+                    const uint32_t il = ent_ilen(e2);
+                    if (il != 7u) {
+                        uint32_t w = ent_hi(e2);
+                        for (uint32_t b = 0; b < il; ++b) { op[cnt++] = (uint8_t)w; w >>= 8; }
+                    } else {
+                        const uint8_t* r = la.pool + ent_hi(e2);
+                        const uint32_t len = (uint32_t)r[0] | (uint32_t)r[1] << 8 | (uint32_t)r[2] << 16 | (uint32_t)r[3] << 24;
+                        for (uint32_t b = 0; b < len; ++b) op[cnt + b] = r[4 + b];
+                        cnt += len;
+                    }
+                    ++j;
+                    if (ent_kind(e2) == 2u) break;
+                    r2 = ent_next(e2);
+                    e2 = entry(r2, byte_at(j), k2);
+                }
+            }
+            v = i;
+        }
+    }
+    L.count = cnt;
+}
+
+}  // namespace trre

@@ -27,6 +27,7 @@
 #include "scan_block.hpp"
 #include "splice_block.hpp"
 #include "gen_block.hpp"
+#include "lazy_block.hpp"
 #include "guard_block.hpp"
 
 namespace {
@@ -104,6 +105,7 @@ struct ScanCtx {
     size_t gobuf_cap = 0;
     uint8_t* d_gout = nullptr;
     size_t gout_cap = 0;
+    uint32_t* d_miss = nullptr;       // lazy tables (lazy_block.hpp): [0] misses listed, then {row, class} pairs
     bool guard_off = false;           // finish() scans the lines before a line the guard stopped at: not to be guarded again
     bool patch_off = false;           // finish() runs the scan again as a count / emit pair (diverged, or out of overflow records)
     int relaunches = 0;               // finish() ran the scan again (scratch, NUL, overflow): whatever was downloaded early is stale
@@ -121,6 +123,15 @@ struct DeviceState {
     uint8_t* d_rblob = nullptr;       // ... and the backward DFA
     uint8_t* d_nblob = nullptr;       // generator modes: the enumeration's tables
     uint8_t* d_kblob = nullptr;       // the stack guard's tables (the NFT itself)
+    // the deterministic engine's tables while they are being built (front.hpp: LazyDft): this device's copy and how much of the host's it holds.
+    // A buffer that has to grow is replaced, not freed: scans of other chunks may still be reading it (freed with the state).
+    uint64_t* d_lent = nullptr;
+    uint8_t* d_lpool = nullptr;
+    uint8_t* d_lcls = nullptr;
+    size_t lent_cap = 0, lpool_cap = 0;        // rows / bytes
+    uint32_t lazy_rows_up = 0, lazy_epoch_up = 0;
+    size_t lazy_pool_up = 0;
+    std::vector<void*> retired;
     ScanCtx ctx;
     struct HostSlot {
         uint8_t *pin_in = nullptr, *pin_out = nullptr, *d_in = nullptr, *d_out = nullptr;
@@ -156,6 +167,10 @@ struct trre_prog {
     std::vector<uint8_t> gblob, rblob;
     std::vector<uint8_t> nblob;       // generator modes: the enumeration's tables (gen_block.hpp); scan mode, NFT engine: the same lists for the backtracking fallback
     bool bt_ok = false;               // scan mode, NFT engine: nblob holds the backtracking fallback's tables
+    trre::Nft dft_nft;                // DFT engine: the automaton the lazy tables are built from
+    std::unique_ptr<trre::LazyDft> lazy;   // DFT engine: the tables one miss at a time (front.hpp) — a pattern beyond the eager caps, or on request
+    bool lazy_only = false;           // ... the eager construction gave up: nothing else exists
+    std::mutex lazy_mu;               // explore() and the uploads
     trre::GuardTables guard;          // scan mode, NFT engine: which lines can exhaust the reference's stack (stack_guard.cpp)
     std::vector<uint8_t> kblob;
     int mask_bytes = 0;
@@ -390,11 +405,14 @@ void serialize_gen(const trre::GenTables& g, std::vector<uint8_t>& b) {
 bool is_generate(int mode) { return mode == TRRE_MODE_SCAN_ALL || mode == TRRE_MODE_MATCH_ALL; }
 bool is_stream(int fam) { return fam == TRRE_KERNEL_STREAM_LP || fam == TRRE_KERNEL_STREAM_GEN; }
 bool is_guided(int fam) { return fam == TRRE_KERNEL_GUIDED_LP || fam == TRRE_KERNEL_GUIDED_GEN; }
-bool is_gen(int fam) { return fam == TRRE_KERNEL_TILE_GEN || fam == TRRE_KERNEL_STREAM_GEN || fam == TRRE_KERNEL_GUIDED_GEN || fam == TRRE_KERNEL_BACKTRACK; }
+bool is_gen(int fam) {
+    return fam == TRRE_KERNEL_TILE_GEN || fam == TRRE_KERNEL_STREAM_GEN || fam == TRRE_KERNEL_GUIDED_GEN || fam == TRRE_KERNEL_BACKTRACK || fam == TRRE_KERNEL_DFT_LAZY;
+}
 bool is_guided_wide(const trre_prog& p, int fam) { return (fam == TRRE_KERNEL_GUIDED_LP || fam == TRRE_KERNEL_GUIDED_GEN) && p.gt.wide; }
 bool lp_inplace(uint32_t flags) { return (flags & trre::kFlagLengthPreserving) && (flags & trre::kFlagNoOverrun); }
 // the family that takes over when a length-preserving launch met a NUL, or a bounded stream table a long run
 int general_family(const trre_prog& p, bool stream_ok) {
+    if (p.lazy_only) return TRRE_KERNEL_DFT_LAZY;
     if (stream_ok && p.stt.ok) return TRRE_KERNEL_STREAM_GEN;
     if (p.gt.ok) return TRRE_KERNEL_GUIDED_GEN;
     return p.has_engine_tables ? TRRE_KERNEL_TILE_GEN : TRRE_KERNEL_BACKTRACK;
@@ -402,6 +420,7 @@ int general_family(const trre_prog& p, bool stream_ok) {
 
 int auto_family(const trre_prog& p) {
     using namespace trre;
+    if (p.lazy_only) return TRRE_KERNEL_DFT_LAZY;      // beyond the eager construction's caps: the tables grow with the input (lazy_block.hpp)
     if (p.engine == TRRE_ENGINE_DFT && (p.dt.flags & kFlagMemoryless)) return TRRE_KERNEL_BYTEMAP;
     // a stream table too large for LDS is walked through L1/L2 (<= 0.35 TB/s); guided tables with a small forward table
     // run at 0.6-0.8 TB/s: prefer them then (patterns with `.` or wide ranges before a literal fold into hundreds of
@@ -435,6 +454,8 @@ int scan_family(const trre_prog& p) {
 
 bool family_allowed(const trre_prog& p, int fam) {
     using namespace trre;
+    if (fam == TRRE_KERNEL_DFT_LAZY) return p.engine == TRRE_ENGINE_DFT && p.mode == TRRE_MODE_SCAN;
+    if (p.lazy_only) return false;
     if (fam == TRRE_KERNEL_STREAM_GEN) return p.stt.ok;
     if (fam == TRRE_KERNEL_STREAM_LP) return p.stt.ok && lp_inplace(p.stt.flags);
     if (fam == TRRE_KERNEL_GUIDED_GEN) return p.gt.ok;
@@ -471,6 +492,7 @@ void ctx_free(ScanCtx& c) {
     (void)hipFree(c.d_sym);
     (void)hipFree(c.d_gen_out);
     (void)hipFree(c.d_gflags); (void)hipFree(c.d_gruns); (void)hipFree(c.d_gstack); (void)hipFree(c.d_gobuf); (void)hipFree(c.d_gout);
+    (void)hipFree(c.d_miss);
     (void)hipFree(c.d_slots);
     (void)hipFree(c.d_ovf);
     (void)hipFree(c.d_ovf_count);
@@ -674,6 +696,100 @@ int guard_check(trre_prog* p, DeviceState* st, ScanCtx* cx, const uint8_t* d_in,
 // the backtracking fallback: sub-range per thread, frames (= bytes an attempt may consume) and path bytes per thread, workgroups in the pool, steps per sub-range
 constexpr int64_t kBtLaneBytes = 1024, kBtPoolBlocks = 256;
 constexpr uint32_t kBtFrames = 4096, kBtPathCap = 4096, kBtBudget = 16u << 20;
+// ---- the deterministic engine on tables still being built (front.hpp: LazyDft, lazy_block.hpp) ----
+constexpr int64_t kLazyLaneBytes = 1024;
+constexpr uint32_t kLazyMissCap = 1u << 16;
+static_assert(trre::kLazyMissWords == trre::kLazyRecWords, "miss record layout");
+constexpr uint64_t kLazyBudget = 1ull << 32;             // table steps per sub-range (an attempt per byte of a long line is quadratic, as in the reference)
+
+int lazy_ensure(trre_prog* p) {
+    std::lock_guard<std::mutex> lock(p->lazy_mu);
+    if (p->lazy) return TRRE_OK;
+    try {
+        trre::LazyLimits lim;
+        if (const char* mb = getenv("TRRE_LAZY_MAX_BYTES")) lim.max_bytes = (size_t)atoll(mb);
+        if (const char* ss = getenv("TRRE_LAZY_SEED_STATES")) lim.seed_states = (size_t)atoll(ss);
+        p->lazy.reset(new trre::LazyDft(p->dft_nft, lim));
+    } catch (const trre::Error& e) {
+        return fail(e.code, e.what());
+    } catch (const std::bad_alloc&) {
+        return fail(TRRE_E_TOO_BIG, "error: out of memory while determinising");
+    }
+    return TRRE_OK;
+}
+
+// brings the device's copy of the tables up to the host's: the pool's new bytes, then the new rows, then the old rows that changed (an entry
+// must never name a row or a text the device does not hold yet — scans of other chunks may be reading the tables meanwhile)
+int lazy_sync(trre_prog* p, DeviceState* st) {
+    std::lock_guard<std::mutex> lock(p->lazy_mu);
+    const trre::LazyDft& z = *p->lazy;
+    const uint32_t n_cls = z.n_cls(), rows = z.n_rows();
+    const size_t pool = z.pool_bytes();
+    if (!st->d_lcls) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st->d_lcls), 256));
+        HIP_TRY(hipMemcpy(st->d_lcls, z.cls(), 256, hipMemcpyHostToDevice));
+    }
+    if (pool > st->lpool_cap) {
+        size_t cap = st->lpool_cap ? st->lpool_cap : (size_t)1 << 20;
+        while (cap < pool) cap *= 2;
+        uint8_t* fresh = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&fresh), cap));
+        if (st->d_lpool) st->retired.push_back(st->d_lpool);
+        st->d_lpool = fresh;
+        st->lpool_cap = cap;
+        st->lazy_pool_up = 0;
+    }
+    if (rows > st->lent_cap) {
+        size_t cap = st->lent_cap ? st->lent_cap : 4096;
+        while (cap < rows) cap *= 2;
+        uint64_t* fresh = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&fresh), cap * n_cls * 8));
+        if (st->d_lent) st->retired.push_back(st->d_lent);
+        st->d_lent = fresh;
+        st->lent_cap = cap;
+        st->lazy_rows_up = 0;
+    }
+    if (pool > st->lazy_pool_up) {
+        HIP_TRY(hipMemcpy(st->d_lpool + st->lazy_pool_up, z.pool() + st->lazy_pool_up, pool - st->lazy_pool_up, hipMemcpyHostToDevice));
+        st->lazy_pool_up = pool;
+    }
+    if (rows > st->lazy_rows_up) {
+        HIP_TRY(hipMemcpy(st->d_lent + (size_t)st->lazy_rows_up * n_cls, z.ent() + (size_t)st->lazy_rows_up * n_cls, (size_t)(rows - st->lazy_rows_up) * n_cls * 8,
+                          hipMemcpyHostToDevice));
+    }
+    const uint32_t dirty = z.first_dirty_row(st->lazy_epoch_up);
+    if (dirty < st->lazy_rows_up)
+        HIP_TRY(hipMemcpy(st->d_lent + (size_t)dirty * n_cls, z.ent() + (size_t)dirty * n_cls, (size_t)(st->lazy_rows_up - dirty) * n_cls * 8, hipMemcpyHostToDevice));
+    st->lazy_rows_up = rows;
+    st->lazy_epoch_up = z.epoch();
+    return TRRE_OK;
+}
+
+// one round: the count pass (fresh: every lane; else the lanes that are still void), the exclusive sum, the emit pass (which leaves at once
+// when the count pass met a miss)
+int lazy_round(trre_prog* p, DeviceState* st, ScanCtx* cx, const trre::ScanArgs& args, int64_t n_chunks, bool fresh, hipStream_t stream) {
+    using namespace trre;
+    int rc = lazy_sync(p, st);
+    if (rc) return rc;
+    if (!cx->d_miss) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&cx->d_miss), (size_t)(2 + trre::kLazyMissWords * kLazyMissCap) * 4));
+    HIP_TRY(hipMemsetAsync(cx->d_miss, 0, 8, stream));
+    if (fresh) HIP_TRY(hipMemsetAsync(cx->d_lane_counts, 0xff, (size_t)n_chunks * 256 * 4, stream));
+    LazyArgs la{};
+    la.cls = st->d_lcls;
+    la.ent = st->d_lent;
+    la.pool = st->d_lpool;
+    la.n_cls = p->lazy->n_cls();
+    la.miss = cx->d_miss;
+    la.miss_cap = kLazyMissCap;
+    static const uint64_t budget = getenv("TRRE_LAZY_BUDGET") ? (uint64_t)atoll(getenv("TRRE_LAZY_BUDGET")) : kLazyBudget;
+    la.budget = budget;
+    launch_lazy(1, args, la, kLazyLaneBytes, n_chunks, stream);
+    launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);
+    launch_lazy(2, args, la, kLazyLaneBytes, n_chunks, stream);
+    HIP_TRY(hipGetLastError());
+    return TRRE_OK;
+}
+
 int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap,
             hipStream_t stream) {
     using namespace trre;
@@ -724,10 +840,12 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
     // a mask scratch left by an earlier, smaller scan must not be used: the kernel asks for one again
     args.gscratch = cx->scratch_bytes >= (n + 32) * (size_t)p->mask_bytes ? cx->d_scratch : nullptr;
     const bool backtrack = family == TRRE_KERNEL_BACKTRACK;
-    const int chunk = backtrack ? (int)kBtLaneBytes * 256
+    const bool lazy = family == TRRE_KERNEL_DFT_LAZY;
+    if (lazy) { rc = lazy_ensure(p); if (rc) return rc; }
+    const int chunk = backtrack ? (int)kBtLaneBytes * 256 : lazy ? (int)kLazyLaneBytes * 256
                       : is_stream(family) ? stream_chunk_bytes(family == TRRE_KERNEL_STREAM_LP ? 0 : 1)
                                           : chunk_bytes(p->engine, p->mask_bytes);
-    const int threads = backtrack ? 256
+    const int threads = backtrack || lazy ? 256
                         : is_stream(family) ? stream_block_threads(family == TRRE_KERNEL_STREAM_LP ? 0 : 1)
                                             : block_threads(p->engine, p->mask_bytes);
     int64_t n_chunks = (args.vend + chunk - 1) / chunk;
@@ -790,7 +908,12 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
         if (p->profiling) HIP_TRY(hipEventRecord(cx->ev0, stream));
     }
     pd.timed = p->profiling;
-    if (backtrack) {
+    if (lazy) {
+        // tables still being built (lazy_block.hpp): the first round; finish() builds what it missed and runs the next ones
+        rc = lazy_round(p, st, cx, args, n_chunks, true, stream);
+        if (rc) return rc;
+        pd.total_at = cx->d_chunk_base + n_chunks;
+    } else if (backtrack) {
         // the search itself (gen_block.hpp: bt_lane): a pool of workgroups takes the chunks of 256 sub-ranges in turn, each thread
         // with a stack and a path buffer of its own for the whole launch
         const int64_t pool_blocks = n_chunks < kBtPoolBlocks ? n_chunks : kBtPoolBlocks;
@@ -1055,7 +1178,65 @@ int finish_inner(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
         HIP_TRY(hipEventElapsedTime(&ms, cx->ev0, cx->ev1));
         p->last_ms = ms / (float)(was.count > 0 ? was.count : 1);   // average per launch of the batch
     }
-    const uint32_t status = cx->h_status[0];
+    uint32_t status = cx->h_status[0];
+    if (was.family == TRRE_KERNEL_DFT_LAZY) {
+        // Rounds (lazy_block.hpp): the edges the launch listed are built on the host (trre_dft.c:1135-1175: nft_step, truncate_lcp, the
+        // lookup, the finality probe), the new rows go up, the lanes that were void walk again.  Every round explores at least one edge
+        // of a finite table over a finite input, so this ends — with the answer, or with the memory limit of the tables.
+        const int64_t a0 = (int64_t)(reinterpret_cast<uintptr_t>(was.d_in) & 15u);
+        ScanArgs args{};
+        args.in_v0 = was.d_in - a0;
+        args.out_v0 = was.d_out - a0;
+        args.out = was.d_out;
+        args.vbeg = a0;
+        args.vend = a0 + (int64_t)was.n;
+        args.status = cx->d_status;
+        args.cap = was.cap;
+        args.lane_counts = cx->d_lane_counts;
+        args.chunk_total = cx->d_chunk_total;
+        args.chunk_base = cx->d_chunk_base;
+        const int64_t n_chunks = (args.vend + kLazyLaneBytes * 256 - 1) / (kLazyLaneBytes * 256);
+        std::vector<uint32_t> miss;
+        size_t spec = 1024;
+        static const bool lazy_trace = getenv("TRRE_LAZY_TRACE") != nullptr;
+        for (int round = 1; (status & kStMiss) && !(status & (kStEditOverflow | kStDiverge)); ++round) {
+            uint32_t head[2] = {0, 0};
+            HIP_TRY(hipMemcpyAsync(head, cx->d_miss, 8, hipMemcpyDeviceToHost, was.stream));
+            HIP_TRY(hipStreamSynchronize(was.stream));
+            const uint32_t n_miss = head[0] < kLazyMissCap ? head[0] : kLazyMissCap;
+            miss.resize((size_t)trre::kLazyMissWords * n_miss + 2);
+            if (n_miss) HIP_TRY(hipMemcpyAsync(miss.data(), cx->d_miss + 2, (size_t)n_miss * trre::kLazyMissWords * 4, hipMemcpyDeviceToHost, was.stream));
+            HIP_TRY(hipStreamSynchronize(was.stream));
+            try {
+                std::lock_guard<std::mutex> lock(p->lazy_mu);
+                p->lazy->explore(miss.data(), n_miss, spec);
+            } catch (const trre::Error& e) {
+                if (out_len) *out_len = 0;
+                return fail(e.code, e.what());
+            } catch (const std::bad_alloc&) {
+                if (out_len) *out_len = 0;
+                return fail(TRRE_E_TOO_BIG, "error: out of memory while determinising");
+            }
+            if (lazy_trace) fprintf(stderr, "trre: lazy round %d: %u misses, %u rows, %u states\n", round, n_miss, p->lazy->n_rows(), p->lazy->n_states());
+            if (spec < (1u << 16)) spec *= 2;                      // (the deeper the input digs, the further ahead the host looks)
+            HIP_TRY(hipMemsetAsync(cx->d_status, 0, 8, was.stream));
+            cx->relaunches += 1;
+            const int rc = lazy_round(p, st, cx, args, n_chunks, false, was.stream);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(cx->h_status, cx->d_status, 8, hipMemcpyDeviceToHost, was.stream));
+            HIP_TRY(hipMemcpyAsync(cx->h_status + 2, was.total_at, 8, hipMemcpyDeviceToHost, was.stream));
+            HIP_TRY(hipStreamSynchronize(was.stream));
+            status = cx->h_status[0];
+        }
+        if (status & kStDiverge) {      // an edge whose closure runs round an epsilon cycle: the reference dies there with its output unflushed
+            if (out_len) *out_len = 0;
+            return fail(TRRE_E_DIVERGES, "error: stack max capacity reached (the reference's search does not terminate on this input)");
+        }
+        if (status & kStEditOverflow) {
+            if (out_len) *out_len = 0;
+            return fail(TRRE_E_UNSUPPORTED, "error: a sub-range of 1 KiB takes more than 2^32 table steps (TRRE_LAZY_BUDGET): lines of megabytes with an attempt per byte");
+        }
+    }
     auto again = [&](int family) -> int {
         cx->relaunches += 1;
         int rc = enqueue(p, st, cx, family, was.d_in, was.n, was.d_out, was.cap, was.stream);
@@ -1228,7 +1409,24 @@ int compile_impl(const std::string& pattern, int engine, trre_prog** out, int mo
             put(p->kblob, gh.off_states, p->guard.states.data(), p->guard.states.size());
         };
         if (engine == TRRE_ENGINE_DFT) {
-            Dft dft = determinize(nft);
+            p->dft_nft = nft;
+            std::unique_ptr<Dft> eager;
+            try {
+                eager.reset(new Dft(determinize(nft)));
+            } catch (const Error& e) {
+                if (e.code != kErrTooBig) throw;
+                // The eager construction does not end within its caps — a state per run length ('((a:x)*b)|((a:y)*c)'), 2^19 states
+                // ('(a|b)*a(a|b){18}:x').  The reference builds only the states its input visits (trre_dft.c:1135-1175) and so does
+                // the lazy family (lazy_block.hpp; rounds 1-4: TRRE_E_TOO_BIG).
+            }
+            if (!eager) {
+                p->lazy_only = true;
+                const int lrc = lazy_ensure(p.get());
+                if (lrc) return lrc;
+                *out = p.release();
+                return TRRE_OK;
+            }
+            Dft& dft = *eager;
             p->dt = flatten_dft(dft);
             serialize_dft(*p);
             p->has_engine_tables = true;
@@ -1346,6 +1544,8 @@ void trre_free(trre_prog* p) {
         (void)hipFree(st.d_rblob);
         (void)hipFree(st.d_nblob);
         (void)hipFree(st.d_kblob);
+        (void)hipFree(st.d_lent); (void)hipFree(st.d_lpool); (void)hipFree(st.d_lcls);
+        for (void* r : st.retired) (void)hipFree(r);
         ctx_free(st.ctx);
         for (auto& hs : st.slot) {
             if (hs.pin_in) (void)hipHostFree(hs.pin_in);
@@ -1374,6 +1574,11 @@ int trre_get_info(const trre_prog* p, trre_info* info) {
         info->table_rows = p->dt.n_rows;
         info->table_classes = p->dt.n_cls;
         info->flags = p->dt.flags;
+        if (p->lazy_only) {       // (the tables grow with the inputs: what exists now)
+            info->dft_states = p->lazy->n_states();
+            info->table_rows = p->lazy->n_rows();
+            info->table_classes = p->lazy->n_cls();
+        }
     } else {
         info->table_rows = p->nt.n_cons;
         info->flags = p->nt.flags;
@@ -1413,6 +1618,43 @@ size_t trre_export_guided_tables(const trre_prog* p, int which, void* buf, size_
     const std::vector<uint8_t>& b = which == 0 ? p->rblob : (which == 2 ? p->nblob : (which == 3 ? p->kblob : p->gblob));   // (2: the enumeration's / the backtracking fallback's tables, 3: the stack guard's)
     if (buf && cap) std::memcpy(buf, b.data(), cap < b.size() ? cap : b.size());
     return b.size();
+}
+
+// CPU test tier (tests/cpu_shim.cpp runs lazy_block.hpp's lane body on the host): the lazy tables as they stand — which 0: u32 n_cls, u32 rows,
+// then cls[256]; 1: the entries; 2: the pool — and the exploration of a list of misses.  Host only.
+size_t trre_debug_lazy_tables(trre_prog* p, int which, void* buf, size_t cap) {
+    if (!p || p->engine != TRRE_ENGINE_DFT || p->mode != TRRE_MODE_SCAN || lazy_ensure(p)) return 0;
+    std::lock_guard<std::mutex> lock(p->lazy_mu);
+    const trre::LazyDft& z = *p->lazy;
+    std::vector<uint8_t> head;
+    const void* src;
+    size_t n;
+    if (which == 0) {
+        const uint32_t w[2] = {z.n_cls(), z.n_rows()};
+        put(head, 0, w, 2);
+        put(head, 8, z.cls(), 256);
+        src = head.data(); n = head.size();
+    } else if (which == 1) {
+        src = z.ent(); n = (size_t)z.n_rows() * z.n_cls() * 8;
+    } else {
+        src = z.pool(); n = z.pool_bytes();
+    }
+    if (buf && cap) std::memcpy(buf, src, cap < n ? cap : n);
+    return n;
+}
+int trre_debug_lazy_explore(trre_prog* p, const uint32_t* misses, size_t n, size_t spec_states) {
+    if (!p || p->engine != TRRE_ENGINE_DFT || p->mode != TRRE_MODE_SCAN) return fail(TRRE_E_ARG, "error: no lazy tables");
+    const int rc = lazy_ensure(p);
+    if (rc) return rc;
+    try {
+        std::lock_guard<std::mutex> lock(p->lazy_mu);
+        p->lazy->explore(misses, n, spec_states);
+    } catch (const trre::Error& e) {
+        return fail(e.code, e.what());
+    } catch (const std::bad_alloc&) {
+        return fail(TRRE_E_TOO_BIG, "error: out of memory while determinising");
+    }
+    return TRRE_OK;
 }
 
 // the prog's state on the calling thread's current device

@@ -24,6 +24,7 @@
 #include "scan_block.hpp"
 #include "splice_block.hpp"
 #include "gen_block.hpp"
+#include "lazy_block.hpp"
 #include "guard_block.hpp"
 
 namespace trre {
@@ -1054,6 +1055,57 @@ __global__ __launch_bounds__(kGenThreads) void k_bt(ScanArgs a, GenArgs ga, int6
     if (st && (threadIdx.x & (kWave - 1)) == 0) atomicOr(a.status, st);
 }
 
+// The deterministic engine on tables still being built (lazy_block.hpp): a thread per sub-range; a lane with a result from an
+// earlier round of the same scan keeps it (the tables only grow), the others walk again.
+template <int kMode>
+__global__ __launch_bounds__(kGenThreads) void k_lazy(ScanArgs a, LazyArgs la, int64_t lane_bytes) {
+    __shared__ uint64_t part[kGenThreads / kWave];
+    __shared__ uint32_t wpart[kGenThreads / kWave];
+    const int64_t lane = (int64_t)blockIdx.x * kGenThreads + threadIdx.x;
+    uint64_t base = 0;
+    if (kMode == 2) {
+        // the count pass met an unexplored edge (or gave up): its sizes are not final, nothing is written — finish() runs the next round
+        if (*a.status & (kStMiss | kStEditOverflow | kStDiverge)) return;
+        const uint32_t mine = a.lane_counts[lane];
+        const uint32_t incl = wave_scan_incl(mine);
+        if ((threadIdx.x & (kWave - 1)) == kWave - 1) wpart[threadIdx.x / kWave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (int w = 0; w < (int)threadIdx.x / kWave; ++w) wbase += wpart[w];
+        base = a.chunk_base[blockIdx.x] + wbase + incl - mine;
+        if (a.chunk_base[blockIdx.x] + a.chunk_total[blockIdx.x] > a.cap) {
+            if (threadIdx.x == 0) atomicOr(a.status, kStCapacity);
+            return;
+        }
+    }
+    DirectLane L;
+    uint32_t st = 0;
+    bool voided = false;
+    if (kMode == 1) {
+        const uint32_t have = a.lane_counts[lane];
+        if (have != kLazyVoid) {
+            L.count = have;
+        } else {
+            lazy_lane<1>(a, la, lane, lane_bytes, 0, L, st, voided);
+            if (L.count >= kLazyVoid) { st |= kStCapacity; L.count = kLazyVoid - 1u; }
+            a.lane_counts[lane] = voided || (st & (kStEditOverflow | kStDiverge)) ? kLazyVoid : (uint32_t)L.count;
+            if (voided) L.count = 0;
+        }
+        const uint64_t wsum = wave_sum(L.count);
+        if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = wsum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t t = 0;
+            for (int w = 0; w < kGenThreads / kWave; ++w) t += part[w];
+            a.chunk_total[blockIdx.x] = t;
+        }
+    } else {
+        lazy_lane<2>(a, la, lane, lane_bytes, base, L, st, voided);
+    }
+    st = wave_or(st);
+    if (st && (threadIdx.x & (kWave - 1)) == 0) atomicOr(a.status, st);
+}
+
 // The stack guard (guard_block.hpp): windows without a '\n' (a bit per window, a wave per 64 of them), then the reference's
 // search itself on the lines that cover them, a thread per line from a pool of stacks.
 __global__ __launch_bounds__(256) void k_guard_probe(ScanArgs a, int64_t window, int64_t n_windows, uint64_t* flags) {
@@ -1562,6 +1614,11 @@ void launch_gen(int which, const ScanArgs& a, const GenArgs& ga, int64_t lane_by
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (which == 1) hipLaunchKernelGGL(k_gen<1>, dim3((unsigned)n_chunks), dim3(kGenThreads), 0, s, a, ga, lane_bytes);
     else hipLaunchKernelGGL(k_gen<2>, dim3((unsigned)n_chunks), dim3(kGenThreads), 0, s, a, ga, lane_bytes);
+}
+void launch_lazy(int which, const ScanArgs& a, const LazyArgs& la, int64_t lane_bytes, int64_t n_chunks, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (which == 1) hipLaunchKernelGGL(k_lazy<1>, dim3((unsigned)n_chunks), dim3(kGenThreads), 0, s, a, la, lane_bytes);
+    else hipLaunchKernelGGL(k_lazy<2>, dim3((unsigned)n_chunks), dim3(kGenThreads), 0, s, a, la, lane_bytes);
 }
 void launch_guard_probe(const ScanArgs& a, int64_t window, int64_t n_windows, uint64_t* flags, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
