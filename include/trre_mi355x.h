@@ -73,9 +73,11 @@ extern "C" {
                                    (trre_nft.c:35-36,548-556: a greedy loop over a run of 65 536 bytes): the stack guard (round 4;
                                    rounds 1-3 printed the match) finds the lines long enough for that and runs the reference's search
                                    on them, scan and match modes; TRRE_NO_STACK_GUARD=1 switches it off.  Not decided, and left as
-                                   the table kernels print it: a line whose search takes more than 8 M steps (or what 20 s of such
-                                   searches per call leave over: TRRE_GUARD_SECONDS), patterns whose loops
-                                   nest more than 64 first-tried branches between two reads, generator modes */
+                                   the table kernels print it: a line whose search takes more than 8 M steps (TRRE_GUARD_BUDGET), the
+                                   suspect lines behind the first 2^35 steps of such searches in one call (TRRE_GUARD_CALL_BUDGET) —
+                                   step counts, not a clock (round 4: 20 s): the same input gives the same answer whatever the host is
+                                   busy with, and the call SAYS so: TRRE_SCAN_GUARD_UNDECIDED in trre_last_scan_flags() —, patterns
+                                   whose loops nest more than 64 first-tried branches between two reads, generator modes */
 #define TRRE_E_CAPACITY (-9)    /* output buffer too small; *out_len holds the size needed */
 
 /* kernel families (trre_info.kernel, trre_set_kernel) */
@@ -151,6 +153,13 @@ size_t trre_export_guided_tables(const trre_prog* p, int which, void* buf, size_
 int trre_scan_device(trre_prog* p, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, size_t* out_len,
                      void* stream);
 
+/* What the last trre_scan_* call on the calling thread has to say beside its return code (thread-local, like trre_last_error;
+ * trre_scan_finish adds to what its trre_scan_enqueue found). */
+#define TRRE_SCAN_GUARD_UNDECIDED 1u /* NFT engine: the input holds a line long enough to exhaust the reference's 65 536-item stack
+                                        (trre_nft.c:35-36,548-556) whose search the stack guard did not finish within its step budgets: the
+                                        output is what the table kernels print — the match — where the reference MAY have exited 1 */
+uint32_t trre_last_scan_flags(void);
+
 /* Split form for back-to-back launches: enqueue only (no host sync), then collect status/size once.
  * One scan may be in flight per (prog, device); enqueues repeated before the finish must be the same
  * scan (same buffers, size and stream: a benchmark loop) — anything else returns TRRE_E_ARG.  The split
@@ -193,6 +202,13 @@ int trre_debug_generate(trre_prog* p, const uint8_t* in, size_t n, const uint8_t
  * ahead — what trre_scan_* does between two rounds of a launch of TRRE_KERNEL_DFT_LAZY.  Host-only. */
 size_t trre_debug_lazy_tables(trre_prog* p, int which, void* buf, size_t cap);
 int trre_debug_lazy_explore(trre_prog* p, const uint32_t* misses, size_t n, size_t spec_states);
+
+/* Diagnostics / CPU test tier: the sharding and reassembly of trre_scan_host_multi — n_shards shards cut at line ends, a host thread each, outputs
+ * concatenated in shard order, a shard that returns TRRE_E_DIVERGES ends the output, TRRE_E_CAPACITY asks for room — with the caller's function in
+ * place of the per-shard device call (fixed_len: the stand-in is length-preserving, shards go straight to their place).  Host-only. */
+typedef int (*trre_debug_shard_fn)(void* user, int shard, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_len);
+int trre_debug_scan_host_multi(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_len, int n_shards, int fixed_len,
+                               trre_debug_shard_fn fn, void* user);
 
 /* Line sharding (multi-GPU, trre has no exchange step: lines are independent).
  * Fills bounds[0..nshards] with byte offsets such that every shard but the

@@ -882,7 +882,8 @@ int shim_backtrack(const uint8_t* nblob, int geo, const uint8_t* in, size_t n, i
     for (int64_t lane = n_lanes - 1; lane >= 0; --lane) {
         DirectLane L;
         uint32_t lst = 0;
-        bt_lane<1>(a, G, ga, lane % pool, lane, lane_bytes, 0, budget, L, lst);
+        uint32_t why = 0;
+        bt_lane<1>(a, G, ga, lane % pool, lane, lane_bytes, 0, budget, L, lst, why);
         cnt[lane] = L.count;
         if (lst & kStDiverge) first_div = lane;
         status |= lst;
@@ -897,7 +898,8 @@ int shim_backtrack(const uint8_t* nblob, int geo, const uint8_t* in, size_t n, i
     for (int64_t lane = 0; lane < n_lanes && (first_div < 0 || lane <= first_div); ++lane) {
         DirectLane L;
         uint32_t lst = 0;
-        bt_lane<2>(a, G, ga, lane % pool, lane, lane_bytes, base[lane], budget, L, lst);
+        uint32_t why = 0;
+        bt_lane<2>(a, G, ga, lane % pool, lane, lane_bytes, base[lane], budget, L, lst, why);
         if (L.count != cnt[lane]) status |= 1u << 30;                     // count and emit passes disagree
     }
     *status_out = status;

@@ -117,3 +117,68 @@ def test_random_patterns_on_the_backtracking_fallback():
         assert not st & shim_lib.ST_DIVERGE and out == want, (pat, data)
         n += 1
     assert n > 80, (n, n_div)
+
+
+def test_match_mode_through_the_backtracking_fallback():
+    """round 5: `trre -m` on a pattern beyond the guided tables runs the search in match form (FINAL accepts at the end of the
+    line only, trre_nft.c:635-642) — every match vector of the compiled reference through it, and a pattern nothing else runs"""
+    n = 0
+    for pat, name, data, exp in golden_lib.match_cases():
+        p = trre_amd.Program(pat, "nft", mode="match")
+        assert trre_amd.KERNEL_BACKTRACK in p.allowed_kernels()
+        for geo in (0, 1):
+            out, st = shim_lib.scan_backtrack(p, data, geo)
+            if exp is None:
+                assert st & shim_lib.ST_DIVERGE, (pat, name)
+            else:
+                assert not st and out == exp, (pat, name, geo)
+        n += 1
+    assert n >= 120
+    # (read right to left, the automaton has to know which of the next 16 bytes is a 'c': 2^16 states, the guided tables stop at 16 384)
+    pat = "(a|b|c){15}c(a|b|c)*:x"
+    p = trre_amd.Program(pat, "nft", mode="match")
+    assert p.info.kernel == trre_amd.KERNEL_BACKTRACK and p.info.guided_rev_states == 0
+    rng = random.Random(5)
+    lines = [bytes(rng.choice(b"abcc") for _ in range(rng.choice((3, 15, 16, 17, 20, 40)))) for _ in range(80)]
+    data = b"\n".join(lines) + b"\n"
+    want = Oracle(pat, "nft").match(data)
+    assert 10 < want.count(b"\n") < 80
+    for geo in (0, 1):
+        out, st = shim_lib.scan_backtrack(p, data, geo)
+        assert not st and out == want
+
+
+@pytest.mark.gpu
+def test_match_mode_backtracking_and_the_larger_stacks_on_gpu():
+    import torch
+
+    def dev(p, data, fam=trre_amd.KERNEL_AUTO):
+        p.set_kernel(fam)
+        try:
+            return p.scan_tensor(torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()).cpu().numpy().tobytes()
+        finally:
+            p.set_kernel(trre_amd.KERNEL_AUTO)
+    for pat, name, data, exp in list(golden_lib.match_cases())[::2]:
+        if exp is None or not data:
+            continue
+        p = trre_amd.Program(pat, "nft", mode="match")
+        assert dev(p, data, trre_amd.KERNEL_BACKTRACK) == exp, (pat, name)
+    pat = "(a|b|c){15}c(a|b|c)*:x"
+    p = trre_amd.Program(pat, "nft", mode="match")
+    assert p.info.kernel == trre_amd.KERNEL_BACKTRACK
+    rng = random.Random(6)
+    lines = [bytes(rng.choice(b"abcc") for _ in range(rng.choice((3, 15, 16, 17, 20, 40)))) for _ in range(20000)]
+    data = b"\n".join(lines) + b"\n"
+    assert dev(p, data) == Oracle(pat, "nft").match(data) and p.scan(data) == Oracle(pat, "nft").match(data)
+    # attempts deeper than the first tier's stacks (4 096 frames) and path buffers (4 KiB): round 4 gave TRRE_E_UNSUPPORTED
+    q = trre_amd.Program("(a:xy)*b", "nft")
+    data = b"cat\n" * 3000 + b"a" * 30000 + b"b tail\n" + b"dog\n" * 3000 + b"a" * 5000 + b"b\n"
+    assert dev(q, data, trre_amd.KERNEL_BACKTRACK) == Oracle("(a:xy)*b", "nft").scan(data)
+    data = b"a" * 300000 + b"b\n"                      # ... and than the second tier's (65 536 / 64 KiB)
+    try:
+        import os
+        os.environ["TRRE_NO_STACK_GUARD"] = "1"        # (the reference itself runs out of stack on this line; what is tested is the fallback's own limit)
+        q2 = trre_amd.Program("(a:xy)*b", "nft")
+        assert dev(q2, data, trre_amd.KERNEL_BACKTRACK) == b"xy" * 300000 + b"b\n"
+    finally:
+        os.environ.pop("TRRE_NO_STACK_GUARD", None)

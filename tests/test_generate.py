@@ -102,6 +102,39 @@ def test_generator_mode_enumeration_kernel_body_on_the_host():
         assert out == oracle_run(pat, flags, data) and not host, (pat, flags)
 
 
+def test_generator_mode_without_a_viability_filter(monkeypatch):
+    """round 5: a viability automaton of more than 256 states (symbols are bytes) no longer refuses the pattern: the filter lets
+    every node through and the enumeration walks the failing branches too, as the reference does.  Every vector again with the
+    limit at 3 states, and a pattern that is over the real one."""
+    monkeypatch.setenv("TRRE_GEN_MAX_REV", "3")
+    n = 0
+    for pat, flags, name, data, exp, printed in golden_lib.all_cases():
+        if len(data) > 4000:
+            continue
+        p = trre_amd.Program(pat, "nft", mode=mode_of(flags))
+        assert p.info.guided_rev_states == 3
+        if exp is None:
+            if printed is None:
+                continue
+            with pytest.raises(trre_amd.TrreError) as e:
+                shim_lib.generate_on_device_like_runtime(p, data, 1)
+            assert e.value.code == trre_amd.api.E_DIVERGES and e.value.partial == printed, (pat, flags, name)
+        else:
+            out, _ = shim_lib.generate_on_device_like_runtime(p, data, 1)
+            assert out == exp, (pat, flags, name)
+            assert shim_lib.generate_like_runtime(p, data, 0, 3) == exp, (pat, flags, name, "host enumeration")
+        n += 1
+    assert n >= 190
+    monkeypatch.delenv("TRRE_GEN_MAX_REV")
+    # (which of the next ten / sixteen bytes is a 'c': thousands of viability states)
+    data = b"abcabcabcabcabcabcabcabcabc\nacccccccccc acbacbacbacbacbacb\nabcabcabcabcabcc\nabcabcabcabcabccabc\n"
+    for pat, flags in (("a(a|b|c){9}c:x", "-a"), ("(a|b|c){15}c(a|b|c)*:x", "-ma")):
+        p = trre_amd.Program(pat, "nft", mode=mode_of(flags))
+        assert p.info.guided_rev_states == 3
+        out, _ = shim_lib.generate_on_device_like_runtime(p, data, 1)
+        assert out == oracle_run(pat, flags, data), flags
+
+
 def test_generator_mode_on_larger_inputs_against_the_oracle():
     rng = random.Random(19)
     data = corpus.word_soup(rng, 40000, max_len=40) + b"nul\0cat\n" + b"cat cat"

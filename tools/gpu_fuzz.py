@@ -73,7 +73,7 @@ def gen_dictionary(rng):
     n = rng.randint(80, 250)
     while len(keys) < n:
         keys.add(bytes(rng.choice(DICT_ALPHA) for _ in range(rng.randint(2, 8))))
-    keys = list(keys)
+    keys = sorted(keys)             # (never the set's own order: it depends on PYTHONHASHSEED — a seed must name ONE run)
     order = rng.random()
     if order < 0.4:
         keys.sort(key=lambda k: (-len(k), k))           # the longer key first: NFT priority waits for it

@@ -9,16 +9,31 @@
 // reference's CPU binaries and are refused rather than emulated; trre_dft -a answers "Not supported
 // yet" like the reference (trre_dft.c:1227-1229).
 //
-// Like the reference's getline loop the input is streamed: it is read in blocks
-// of up to 256 MiB, every block is cut after its last '\n' (the rest is carried
-// into the next block), scanned line-sharded on all visible GPUs
-// (trre_scan_host_multi) and written out, so neither the input nor the output
-// has to fit in host memory.  TRRE_DEVICES=<mask> restricts the GPUs used.
+// Like the reference's getline loop (trre_nft.c:776-790) the input is streamed, neither the input nor the output has to
+// fit in host memory — as a three-stage pipeline (round 5; round 4 read, scanned and wrote one block after the other):
+//   reader   fills block buffers: a regular file by parallel pread()s (one thread moves ~6 GB/s out of the page cache, the link
+//            takes 28 each way), a pipe or a terminal by read() — whatever has arrived goes on as soon as it ends in a '\n', so
+//            that an interactive producer sees its lines answered (the reference prints per getline);
+//   scan     every block is cut after its last '\n' (the rest is carried into the next block) and scanned line-sharded on all
+//            visible GPUs (trre_scan_host_multi).  The block buffers are pinned (hipHostMalloc): the library sends them over the
+//            link as they are, without its staging copies;
+//   writer   write()s the finished blocks in order.
+// Buffers are reused, never zero-filled, and sized by the input (a 1 MB file does not pin 256 MiB).  TRRE_DEVICES=<mask>
+// restricts the GPUs used, TRRE_CLI_BLOCK=<bytes> sets the block size (default 256 MiB).
+#include <fcntl.h>
+#include <hip/hip_runtime_api.h>
+#include <poll.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/trre_mi355x.h"
@@ -26,6 +41,98 @@
 #ifndef TRRE_CLI_ENGINE
 #define TRRE_CLI_ENGINE TRRE_ENGINE_NFT
 #endif
+
+namespace {
+
+// a buffer the link can read and write directly; plain memory when there is no device to pin it for (the scan will say so)
+struct Block {
+    uint8_t* p = nullptr;
+    size_t cap = 0;
+    bool pinned = false;
+    size_t n = 0;          // bytes that go to the scan (whole records)
+    size_t have = 0;       // bytes filled (n + the carried partial line)
+    bool last = false;
+    void reserve(size_t want) {
+        if (cap >= want) return;
+        uint8_t* q = nullptr;
+        bool pin = hipHostMalloc(reinterpret_cast<void**>(&q), want, hipHostMallocDefault) == hipSuccess;
+        if (!pin) {
+            (void)hipGetLastError();
+            q = static_cast<uint8_t*>(std::malloc(want));
+            if (!q) { std::fprintf(stderr, "error: out of memory\n"); std::_Exit(EXIT_FAILURE); }
+        }
+        if (p && have) std::memcpy(q, p, have);
+        release();
+        p = q; cap = want; pinned = pin;
+    }
+    void release() {
+        if (!p) return;
+        if (pinned) (void)hipHostFree(p); else std::free(p);
+        p = nullptr; cap = 0;
+    }
+};
+
+template <class T>
+class Channel {            // a bounded hand-over between two stages
+public:
+    void push(T v) {
+        std::unique_lock<std::mutex> lk(mu_);
+        q_.push_back(v);
+        cv_.notify_all();
+    }
+    T pop() {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return !q_.empty(); });
+        T v = q_.front();
+        q_.pop_front();
+        return v;
+    }
+private:
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<T> q_;
+};
+
+bool write_all(int fd, const uint8_t* p, size_t n) {
+    while (n) {
+        const ssize_t k = ::write(fd, p, n > ((size_t)1 << 30) ? (size_t)1 << 30 : n);
+        if (k < 0) { if (errno == EINTR) continue; return false; }
+        p += k; n -= (size_t)k;
+    }
+    return true;
+}
+
+// [off, off + len) of a regular file into dst, a few threads at a time
+bool pread_parallel(int fd, uint8_t* dst, off_t off, size_t len) {
+    const size_t piece = (size_t)16 << 20;
+    const int ways = (int)std::min<size_t>(8, (len + piece - 1) / piece);
+    if (ways <= 1) {
+        for (size_t got = 0; got < len;) {
+            const ssize_t k = ::pread(fd, dst + got, len - got, off + (off_t)got);
+            if (k < 0) { if (errno == EINTR) continue; return false; }
+            if (k == 0) return false;
+            got += (size_t)k;
+        }
+        return true;
+    }
+    std::vector<std::thread> th;
+    std::vector<char> ok((size_t)ways, 1);
+    const size_t per = ((len / (size_t)ways) + 4095) & ~(size_t)4095;
+    for (int t = 0; t < ways; ++t)
+        th.emplace_back([&, t] {
+            const size_t lo = per * (size_t)t, hi = std::min(len, lo + per);
+            for (size_t got = lo; got < hi;) {
+                const ssize_t k = ::pread(fd, dst + got, hi - got, off + (off_t)got);
+                if (k < 0 && errno == EINTR) continue;
+                if (k <= 0) { ok[(size_t)t] = 0; return; }
+                got += (size_t)k;
+            }
+        });
+    for (auto& x : th) x.join();
+    return std::all_of(ok.begin(), ok.end(), [](char c) { return c != 0; });
+}
+
+}  // namespace
 
 int main(int argc, char** argv) {
     int opt;
@@ -59,57 +166,143 @@ int main(int argc, char** argv) {
         std::fprintf(stderr, "%s\n", trre_last_error());
         return EXIT_FAILURE;
     }
-    FILE* fp = stdin;
+    int fd = 0;
     if (optind == argc - 2) {
-        fp = std::fopen(argv[optind + 1], "rb");
-        if (!fp) {
+        fd = ::open(argv[optind + 1], O_RDONLY);
+        if (fd < 0) {
             std::fprintf(stderr, "error: can not open file %s\n", argv[optind + 1]);
             return EXIT_FAILURE;
         }
     }
     const uint32_t mask = std::getenv("TRRE_DEVICES") ? (uint32_t)std::strtoul(std::getenv("TRRE_DEVICES"), nullptr, 0) : 0u;
-    const size_t block = std::getenv("TRRE_CLI_BLOCK") ? (size_t)std::strtoull(std::getenv("TRRE_CLI_BLOCK"), nullptr, 0) : (size_t)256 << 20;
-    std::vector<uint8_t> in, out;
-    size_t have = 0;                   // bytes of `in` that are filled (a carried partial line first)
-    bool eof = false;
-    while (!eof) {
-        if (in.size() < have + block) in.resize(have + block);
-        size_t k;
-        while (have < in.size() && (k = std::fread(in.data() + have, 1, in.size() - have, fp)) > 0) have += k;
-        eof = have < in.size();
-        // scan up to the last record end; the very last block goes as it is (a final record without '\n'
-        // loses its last byte, like every record: trre_nft.c:777)
-        size_t n = have;
-        if (!eof) {
-            while (n > 0 && in[n - 1] != '\n') --n;
-            if (n == 0) continue;      // one line longer than the block: keep reading
+    size_t block = std::getenv("TRRE_CLI_BLOCK") ? (size_t)std::strtoull(std::getenv("TRRE_CLI_BLOCK"), nullptr, 0) : (size_t)256 << 20;
+    if (block < 64) block = 64;
+    struct stat sb;
+    const bool regular = ::fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
+    off_t file_off = regular ? ::lseek(fd, 0, SEEK_CUR) : 0;
+    if (file_off < 0) file_off = 0;
+    const size_t file_left0 = regular && sb.st_size > file_off ? (size_t)(sb.st_size - file_off) : 0;
+
+    constexpr int kIn = 3, kOut = 2;
+    Block inb[kIn], outb[kOut];
+    Channel<int> in_free, in_full, out_free, out_full;      // indices; -1 ends a stage
+    for (int k = 0; k < kIn; ++k) in_free.push(k);
+    for (int k = 0; k < kOut; ++k) out_free.push(k);
+    struct OutJob { int buf; size_t m; };
+    Channel<OutJob> jobs;
+    bool write_failed = false;
+
+    // ---- reader ----------------------------------------------------------------------------------------------------------------
+    std::thread reader([&] {
+        std::vector<uint8_t> carry;
+        size_t cur = regular ? block : std::min(block, (size_t)1 << 20);     // a pipe starts small (its first answer is not 256 MiB away) and grows
+        size_t left = file_left0;
+        off_t off = file_off;
+        bool eof = false;
+        while (!eof) {
+            const int b = in_free.pop();
+            Block& B = inb[b];
+            B.have = 0; B.n = 0; B.last = false;
+            for (;;) {
+                // room: the carried bytes and a block's worth (a regular file: no more than it still holds)
+                const size_t want = regular ? std::min(block, left) : cur;
+                B.reserve(std::max<size_t>(carry.size() + want + 64, 4096));
+                if (!carry.empty()) { std::memcpy(B.p, carry.data(), carry.size()); B.have = carry.size(); carry.clear(); }
+                if (regular) {
+                    if (want && !pread_parallel(fd, B.p + B.have, off, want)) { std::fprintf(stderr, "error: read failed\n"); std::_Exit(EXIT_FAILURE); }
+                    B.have += want; off += (off_t)want; left -= want;
+                    eof = left == 0;
+                } else {
+                    // a pipe or a terminal: block for the first bytes, then take what is there without waiting — until the block is
+                    // full — and go on as soon as the bytes end in a record
+                    while (B.have < B.cap - 64) {
+                        const ssize_t k = ::read(fd, B.p + B.have, std::min(B.cap - 64 - B.have, (size_t)1 << 30));
+                        if (k < 0) { if (errno == EINTR) continue; std::fprintf(stderr, "error: read failed\n"); std::_Exit(EXIT_FAILURE); }
+                        if (k == 0) { eof = true; break; }
+                        B.have += (size_t)k;
+                        struct pollfd pf{fd, POLLIN, 0};
+                        if (B.p[B.have - 1] == '\n' && ::poll(&pf, 1, 0) <= 0) break;
+                    }
+                    if (B.have >= B.cap - 64) cur = std::min(block, cur * 4);
+                }
+                // up to the last record end; the very last block goes as it is (a final record without '\n' loses its last byte,
+                // like every record: trre_nft.c:777)
+                size_t n = B.have;
+                if (!eof) {
+                    const void* nl = ::memrchr(B.p, '\n', n);
+                    n = nl ? (size_t)(static_cast<const uint8_t*>(nl) - B.p) + 1 : 0;
+                }
+                if (n == 0 && !eof) {                  // one line longer than the block: keep reading into a larger buffer
+                    carry.assign(B.p, B.p + B.have);
+                    B.have = 0;
+                    if (!regular) { cur *= 2; if (block < cur) block = cur; }
+                    continue;
+                }
+                B.n = n;
+                carry.assign(B.p + n, B.p + B.have);
+                B.last = eof;
+                break;
+            }
+            in_full.push(b);
         }
-        if (n) {
-            if (out.size() < n + 64) out.resize(n + 64);
+        in_full.push(-1);
+    });
+
+    // ---- writer ----------------------------------------------------------------------------------------------------------------
+    std::thread writer([&] {
+        for (;;) {
+            const OutJob j = jobs.pop();
+            if (j.buf < 0) break;
+            if (!write_failed && !write_all(1, outb[j.buf].p, j.m)) write_failed = true;
+            out_free.push(j.buf);
+        }
+    });
+
+    // ---- scan ------------------------------------------------------------------------------------------------------------------
+    int status = 0;
+    bool undecided = false;
+    for (;;) {
+        const int b = in_full.pop();
+        if (b < 0) break;
+        Block& B = inb[b];
+        if (B.n && !status) {
+            const int o = out_free.pop();
+            Block& O = outb[o];
+            O.have = 0;
+            O.reserve(B.n + 64);
             size_t m = 0;
-            int rc = trre_scan_host_multi(prog, in.data(), n, out.data(), out.size(), &m, mask);
+            int rc = trre_scan_host_multi(prog, B.p, B.n, O.p, O.cap, &m, mask);
             if (rc == TRRE_E_CAPACITY) {
-                out.resize(m + 64);
-                rc = trre_scan_host_multi(prog, in.data(), n, out.data(), out.size(), &m, mask);
+                O.reserve(m + 64);
+                rc = trre_scan_host_multi(prog, B.p, B.n, O.p, O.cap, &m, mask);
             }
-            if (rc == TRRE_E_DIVERGES && m) {
-                // the reference has printed everything up to the attempt it does not come back from (exit() flushes stdout,
-                // trre_nft.c:551-553): so has the library (NFT engine), m bytes
-                (void)std::fwrite(out.data(), 1, m, stdout);
-                std::fflush(stdout);
-            }
+            undecided = undecided || (trre_last_scan_flags() & TRRE_SCAN_GUARD_UNDECIDED);
+            // a scan the reference does not survive: it has printed everything up to the attempt it does not come back from (exit()
+            // flushes stdout, trre_nft.c:551-553) — so has the library (NFT engine), m bytes
+            if (rc == TRRE_OK || (rc == TRRE_E_DIVERGES && m)) jobs.push(OutJob{o, m});
+            else out_free.push(o);
             if (rc != TRRE_OK) {
+                jobs.push(OutJob{-1, 0});
+                writer.join();
                 std::fprintf(stderr, "%s\n", trre_last_error());
-                return EXIT_FAILURE;
-            }
-            if (std::fwrite(out.data(), 1, m, stdout) != m) {
-                std::fprintf(stderr, "error: write failed\n");
-                return EXIT_FAILURE;
+                std::fflush(stderr);
+                std::_Exit(EXIT_FAILURE);          // (the reader may be waiting for input that will never be looked at)
             }
         }
-        std::memmove(in.data(), in.data() + n, have - n);
-        have -= n;
+        in_free.push(b);
     }
+    jobs.push(OutJob{-1, 0});
+    writer.join();
+    reader.join();
+    if (write_failed) {
+        std::fprintf(stderr, "error: write failed\n");
+        status = EXIT_FAILURE;
+    }
+    if (undecided)
+        std::fprintf(stderr, "trre: warning: a line long enough to exhaust the reference's stack was not searched to the end (step budget): "
+                             "where the reference may have exited with \"stack max capacity reached\" the match is printed\n");
+    for (Block& B : inb) B.release();
+    for (Block& B : outb) B.release();
     trre_free(prog);
-    return 0;
+    return status;
 }

@@ -407,6 +407,7 @@ GuidedTables build_guided_dft(const Dft& dft, const GuidedLimits& lim = GuidedLi
 struct GenTables {
     bool ok = false;
     bool match_mode = false;
+    bool pass_all = false;                    // the viability automaton has more than 256 states: the filter lets every node through (generate.cpp)
     NftNodes nodes;                           // follow lists with every epsilon path
     uint32_t n_rev = 0, n_cls = 0;            // backward DFA: states (= symbols; 0 dead, 1 at '\n', 2 at a NUL) x byte classes
     std::array<uint8_t, 256> cls{};

@@ -171,11 +171,17 @@ TRRE_HD void gen_lane(const ScanArgs& a, const GenView& G, const GenArgs& ga, in
 // TRRE_E_UNSUPPORTED): the engine then runs every pattern the reference runs.  Tables: the follow lists of nft_tables.cpp
 // (first occurrence of a target per list, a list ends at its first FINAL) in the generator modes' blob form; no symbols.
 // An attempt that takes more than `budget` steps, goes deeper than the lane's stack or builds more output than its path
-// buffer gives up (kStCapacity is not it: kStEditOverflow) — an error, not a hang; an epsilon cycle is kStDiverge.
+// buffer gives up (kStCapacity is not it: kStEditOverflow) — an error, not a hang; an epsilon cycle is kStDiverge.  `why` says
+// which limit it was (kBtWhy*): the runtime runs the buffer again with fewer, larger stacks and path buffers when it was one of
+// those two (round 5: attempts of up to 1 M bytes / 1 MiB of output; round 4 gave up at 4 096 / 4 KiB).
+// With tables in match form (G.match, round 5: `trre -m` on a pattern beyond the guided tables' limits): one attempt per line
+// from its first byte, FINAL accepts only with the whole line consumed and the search goes on past it otherwise
+// (trre_nft.c:635-642); an accepted line prints its output and '\n', a rejected one nothing (trre_nft.c:791-797).
 // =============================================================================================
+constexpr uint32_t kBtWhyBudget = 1u, kBtWhyFrames = 2u, kBtWhyPath = 4u;
 template <int kMode>
 TRRE_HD void bt_lane(const ScanArgs& a, const GenView& G, const GenArgs& ga, int64_t slot, int64_t lane, int64_t lane_bytes, uint64_t out_base,
-                     uint32_t budget, DirectLane& L, uint32_t& status) {
+                     uint32_t budget, DirectLane& L, uint32_t& status, uint32_t& why) {
     const int64_t lo = lane * lane_bytes;
     int64_t hi = lo + lane_bytes;
     if (hi > a.vend) hi = a.vend;
@@ -202,7 +208,7 @@ TRRE_HD void bt_lane(const ScanArgs& a, const GenView& G, const GenArgs& ga, int
         uint32_t sp = 1;
         stack[0] = G.n_nodes; stack[1] = 0; stack[2] = 0; stack[3] = 0;
         while (sp) {
-            if (++steps > budget) { status |= kStEditOverflow; return -2; }
+            if (++steps > budget) { status |= kStEditOverflow; why |= kBtWhyBudget; return -2; }
             uint32_t* f = stack + 4 * (sp - 1);
             const uint32_t list = f[0], idx = f[1], fi = f[2], fo = f[3];
             const uint32_t beg = G.foff[list], end = G.foff[list + 1];
@@ -213,6 +219,7 @@ TRRE_HD void bt_lane(const ScanArgs& a, const GenView& G, const GenArgs& ga, int
             const uint32_t olen = fo & 0x7fffffffu, muted = fo >> 31;
             if (target == kGenTgtDiverge) { status |= kStDiverge; return -2; }
             if (target == kGenTgtFinal) {                                           // trre_nft.c:643-648: print, return the offset
+                if (G.match && !ends(v0 + fi, a.in_v0[v0 + fi])) continue;          // trre_nft.c:636: only with the whole line consumed
                 put(path, olen);
                 if (!muted) put(G.pool + out_off, out_len);
                 return (int64_t)fi;
@@ -222,19 +229,33 @@ TRRE_HD void bt_lane(const ScanArgs& a, const GenView& G, const GenArgs& ga, int
             if (!((G.bytes[8 * (size_t)target + (c >> 5)] >> (c & 31u)) & 1u)) continue;
             uint32_t nlen = olen, nmuted = muted;
             if (!muted) {
-                if (olen + out_len + 1u > ga.path_cap) { status |= kStEditOverflow; return -2; }
+                if (olen + out_len + 1u > ga.path_cap) { status |= kStEditOverflow; why |= kBtWhyPath; return -2; }
                 for (uint32_t i = 0; i < out_len; ++i) path[olen + i] = G.pool[out_off + i];
                 nlen = olen + out_len;
                 if (mute) nmuted = 1;
                 else if (G.echo[target]) path[nlen++] = c;
             }
-            if (sp >= ga.frames) { status |= kStEditOverflow; return -2; }
+            if (sp >= ga.frames) { status |= kStEditOverflow; why |= kBtWhyFrames; return -2; }
             uint32_t* nf = stack + 4 * sp;
             nf[0] = target; nf[1] = 0; nf[2] = fi + 1; nf[3] = nlen | nmuted << 31;
             ++sp;
         }
         return -1;
     };
+    if (G.match) {
+        // `trre -m`: the lines that START in [lo, hi), one attempt each
+        int64_t v = lo;
+        if (!(lo == a.vbeg || (lo > a.vbeg && a.in_v0[lo - 1] == (uint8_t)'\n'))) v = lo < a.vbeg ? a.vbeg : first_line_start_safe(a, lo, hi);
+        while (v < hi) {
+            const int64_t r = attempt(v);
+            if (r == -2) break;
+            if (r >= 0) put1((uint8_t)'\n');
+            while (v < a.vend - 1 && a.in_v0[v] != (uint8_t)'\n') ++v;
+            ++v;
+        }
+        L.count = cnt;
+        return;
+    }
     // the bytes an attempt can begin with (all of them when the start's list reaches FINAL or a cycle without reading): elsewhere the
     // attempt is known to fail and the byte is copied without a search
     uint32_t first[8] = {0, 0, 0, 0, 0, 0, 0, 0};

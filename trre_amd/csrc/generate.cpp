@@ -18,6 +18,7 @@
 // reached", exit 1, what was printed stays printed).  Not modelled, as in scan mode: the reference's limit of
 // 65 536 live stack items.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <thread>
@@ -33,6 +34,22 @@ struct AnySets {
 };
 bool has(const std::vector<uint32_t>& v, uint32_t x) { return std::binary_search(v.begin(), v.end(), x); }
 
+}  // namespace
+
+namespace {
+// The filter that filters nothing: one state inside a line, every node "viable" — what a pattern gets whose viability automaton has more
+// than 256 states (symbols are bytes).  The enumeration then walks the failing branches too, exactly as the reference's search does
+// (trre_nft.c:593-657); what it prints is the same (a branch the filter skips prints nothing).  Round 4: TRRE_E_UNSUPPORTED.
+void pass_all_filter(GenTables& g) {
+    const size_t words = (g.nodes.node.size() + 63) / 64;
+    g.n_rev = 3;
+    g.rev.assign((size_t)3 * g.n_cls, (uint8_t)kSymDead);
+    for (uint32_t r = 0; r < 3; ++r) { g.rev[(size_t)r * g.n_cls + 0] = (uint8_t)kSymEol; g.rev[(size_t)r * g.n_cls + 1] = (uint8_t)kSymNul; }
+    g.viable_words = (uint32_t)words;
+    g.viable.assign(3 * words, ~0ull);
+    g.pass_all = true;
+    g.ok = true;
+}
 }  // namespace
 
 GenTables build_gen_tables(const Nft& nft, bool match_mode) {
@@ -53,13 +70,15 @@ GenTables build_gen_tables(const Nft& nft, bool match_mode) {
             if (nd.node[t].reads((uint8_t)c)) sig.push_back(t);
         auto hit = index.find(sig);
         if (hit == index.end()) {
-            if (readers.size() >= 256) return g;
+            if (readers.size() >= 256) throw Error(kErrTooBig, "error: more than 256 byte classes (generator mode)");   // (2 + 254 at most: not reachable)
             hit = index.emplace(sig, (uint8_t)readers.size()).first;
             readers.push_back(sig);
         }
         g.cls[c] = hit->second;
     }
     g.n_cls = (uint32_t)readers.size();
+    // (TRRE_GEN_MAX_REV: a smaller limit, for the tests of the filter that lets everything through)
+    const size_t max_rev = getenv("TRRE_GEN_MAX_REV") ? (size_t)std::max(3, atoi(getenv("TRRE_GEN_MAX_REV"))) : 256;
     // subset construction, right to left.  States 0..2: nothing viable — inside a line, at its '\n', at a NUL
     std::vector<AnySets> rev(3);
     std::map<std::vector<uint32_t>, uint32_t> rev_index;
@@ -87,7 +106,7 @@ GenTables build_gen_tables(const Nft& nft, bool match_mode) {
             key.insert(key.end(), nx.div.begin(), nx.div.end());
             auto hit = rev_index.find(key);
             if (hit == rev_index.end()) {
-                if (rev.size() >= 256) return g;                             // symbols are bytes
+                if (rev.size() >= max_rev) { pass_all_filter(g); return g; } // symbols are bytes
                 hit = rev_index.emplace(std::move(key), (uint32_t)rev.size()).first;
                 rev.push_back(std::move(nx));
             }

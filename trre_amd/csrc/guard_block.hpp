@@ -54,7 +54,8 @@ struct GuardRun {            // a stretch of windows without a '\n': [first, las
 };
 struct GuardResult {
     uint64_t line_start;     // (v coordinates minus vbeg: offsets into the caller's buffer)
-    uint64_t bad_at;         // offset, in the line, of the attempt that overflowed
+    uint64_t bad_at;         // status 1: offset, in the line, of the attempt that overflowed; otherwise: the search steps the line took (the runtime
+                             // adds them up against the call's budget)
     uint32_t status;         // 0 fine (or not a line of l_min bytes), 1 overflow, 2 gave up (budget / output room)
     uint32_t out_len;        // kOut: bytes of the line's output before that attempt; the search alone: the line's length
 };
@@ -172,6 +173,7 @@ TRRE_HD void guard_line(const ScanArgs& a, const GuardArgs& ga, int64_t slot, in
     int64_t r = 0;
     if (h.match) {                                                          // trre_nft.c:790-793: one attempt; what it prints is the whole line's output
         r = attempt(0);
+        R.bad_at = steps;
         if (r == -2) { R.status = 1u; R.bad_at = 0; }
         else if (r == -3) R.status = 2u;
         R.out_len = kOut ? 0u : (uint32_t)len;
@@ -186,6 +188,7 @@ TRRE_HD void guard_line(const ScanArgs& a, const GuardArgs& ga, int64_t slot, in
         else { put(in[p]); ++p; }
     }
     if (r > -2 && p >= (uint32_t)len) r = attempt((uint32_t)len);            // the empty tail (trre_nft.c:786)
+    R.bad_at = steps;
     if (r == -2) { R.status = 1u; R.bad_at = p; }
     else if (r == -3) R.status = 2u;
     R.out_len = kOut ? (uint32_t)(printed > 0xffffffffull ? 0xffffffffull : printed) : (uint32_t)len;    // (the search alone: the line's length)

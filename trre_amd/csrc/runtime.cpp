@@ -33,6 +33,7 @@
 namespace {
 
 thread_local std::string g_error;
+thread_local uint32_t g_scan_flags = 0;       // TRRE_SCAN_*: what the last scan call on this thread has to add to its return code
 
 int fail(int code, const std::string& msg) {
     g_error = msg;
@@ -106,6 +107,7 @@ struct ScanCtx {
     uint8_t* d_gout = nullptr;
     size_t gout_cap = 0;
     uint32_t* d_miss = nullptr;       // lazy tables (lazy_block.hpp): [0] misses listed, then {row, class} pairs
+    int bt_tier = 0;                  // the backtracking fallback: which size of stacks and path buffers the next launch uses (kBtTiers)
     bool guard_off = false;           // finish() scans the lines before a line the guard stopped at: not to be guarded again
     bool patch_off = false;           // finish() runs the scan again as a count / emit pair (diverged, or out of overflow records)
     int relaunches = 0;               // finish() ran the scan again (scratch, NUL, overflow): whatever was downloaded early is stale
@@ -434,6 +436,7 @@ int auto_family(const trre_prog& p) {
     // (wide guided tables — 16-bit symbols, both tables through L1 / L2 — still beat the bitmask tile kernels: 37 against 17 GB/s
     // on 'a(a|b|c){9}c:x', 256 MiB of printable lines)
     if (p.gt.ok) return lp_inplace(p.gt.fwd.flags) && !p.gt.wide ? TRRE_KERNEL_GUIDED_LP : TRRE_KERNEL_GUIDED_GEN;
+    if (p.mode == TRRE_MODE_MATCH) return TRRE_KERNEL_BACKTRACK;
     if (p.engine == TRRE_ENGINE_DFT) {
         if ((p.dt.flags & kFlagLengthPreserving) && (p.dt.flags & kFlagNoOverrun)) return TRRE_KERNEL_TILE_LP;
         return TRRE_KERNEL_TILE_GEN;
@@ -578,9 +581,12 @@ int ensure_copy_workspace(ScanCtx* c, int64_t n_lanes) {
 
 // ---- the stack guard (guard_block.hpp) --------------------------------------------------------------------------------
 constexpr int64_t kGuardSlots = 256;                       // lines searched at a time (a stack of 65 536 items each: 192 MiB in all)
-constexpr size_t kGuardMaxRuns = 1024;                     // suspects per batch (the clock is looked at between batches)
-constexpr double kGuardSeconds = 20.0;                     // ... and what the guard may spend on one scan; the lines behind that are not decided
+constexpr size_t kGuardMaxRuns = 1024;                     // suspects per batch (the call's budget is looked at between batches)
 constexpr uint64_t kGuardBudget = 1ull << 23;              // search steps per line; beyond: not decided (the scan's output stands)
+// ... and per scan call, summed over its suspect lines in input order, batch by batch (TRRE_GUARD_CALL_BUDGET).  Steps, not seconds:
+// the same input gives the same answer on a loaded host and on an idle one (round 4 stopped after 20 s of wall clock).  What the budgets
+// leave undecided is SAID: TRRE_SCAN_GUARD_UNDECIDED in trre_last_scan_flags().
+constexpr uint64_t kGuardCallBudget = 1ull << 35;
 constexpr const char* kStackMsg = "error: stack max capacity reached";
 bool guard_applies(const trre_prog& p, const ScanCtx& cx, size_t n) {
     static const bool off = getenv("TRRE_NO_STACK_GUARD") != nullptr;
@@ -628,10 +634,15 @@ int guard_check(trre_prog* p, DeviceState* st, ScanCtx* cx, const uint8_t* d_in,
     GuardRun* d_runs = nullptr;
     size_t bad = 0;
     bool found = false;
-    const auto t_begin = std::chrono::steady_clock::now();
-    static const double seconds = getenv("TRRE_GUARD_SECONDS") ? atof(getenv("TRRE_GUARD_SECONDS")) : kGuardSeconds;
+    static const uint64_t call_budget = getenv("TRRE_GUARD_CALL_BUDGET") ? (uint64_t)atoll(getenv("TRRE_GUARD_CALL_BUDGET")) : kGuardCallBudget;
+    uint64_t steps_spent = 0;
+    bool undecided = false;
     for (int64_t w = 0; w < n_win && !found;) {
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > seconds) break;
+        if (steps_spent > call_budget) {            // suspects are left and the call's budget is spent: they are not decided — and the caller is told
+            for (int64_t x = w; x < n_win && !undecided; x = (x | 63) + 1)
+                if (flags[(size_t)(x >> 6)] >> (x & 63)) undecided = true;
+            break;
+        }
         runs.clear();
         while (w < n_win && runs.size() < kGuardMaxRuns) {
             const uint64_t word = flags[(size_t)(w >> 6)] >> (w & 63);
@@ -666,9 +677,14 @@ int guard_check(trre_prog* p, DeviceState* st, ScanCtx* cx, const uint8_t* d_in,
         res.resize(n_runs);
         HIP_TRY(hipMemcpyAsync(res.data(), d_res, n_runs * sizeof(GuardResult), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        for (size_t k = 0; k < n_runs && !found; ++k)
-            if (res[k].status == 1u) { bad = k; found = true; }
+        for (size_t k = 0; k < n_runs && !found; ++k) {
+            if (res[k].status == 1u) { bad = k; found = true; break; }
+            if (res[k].status == 2u) undecided = true;          // this line's search outran its budget (or the line has more than 4 GiB)
+            steps_spent += res[k].bad_at;                       // (a line that did not overflow leaves its step count there)
+        }
     }
+    // (lines BEFORE a line that overflows and not decided themselves: the answer given is the first overflow found — flagged too)
+    if (undecided) g_scan_flags |= TRRE_SCAN_GUARD_UNDECIDED;
     if (!found) return TRRE_OK;
     hit->hit = true;
     hit->line_start = res[bad].line_start;
@@ -694,8 +710,12 @@ int guard_check(trre_prog* p, DeviceState* st, ScanCtx* cx, const uint8_t* d_in,
 }
 
 // the backtracking fallback: sub-range per thread, frames (= bytes an attempt may consume) and path bytes per thread, workgroups in the pool, steps per sub-range
-constexpr int64_t kBtLaneBytes = 1024, kBtPoolBlocks = 256;
-constexpr uint32_t kBtFrames = 4096, kBtPathCap = 4096, kBtBudget = 16u << 20;
+constexpr int64_t kBtLaneBytes = 1024;
+constexpr uint32_t kBtBudget = 16u << 20;
+// The pool of stacks and path buffers sizes the scratch, not the input: 4.3-4.6 GB in every tier.  A launch in which an attempt outgrew its
+// stack or its path buffer runs again on the next tier (round 4 gave up at the first: attempts of 4 096 bytes / 4 KiB of output).
+struct BtTier { int64_t pool_blocks; uint32_t frames, path_cap; };
+constexpr BtTier kBtTiers[3] = {{256, 4096, 4096}, {16, 65536, 65536}, {1, 1u << 20, 1u << 20}};
 // ---- the deterministic engine on tables still being built (front.hpp: LazyDft, lazy_block.hpp) ----
 constexpr int64_t kLazyLaneBytes = 1024;
 constexpr uint32_t kLazyMissCap = 1u << 16;
@@ -916,7 +936,9 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
     } else if (backtrack) {
         // the search itself (gen_block.hpp: bt_lane): a pool of workgroups takes the chunks of 256 sub-ranges in turn, each thread
         // with a stack and a path buffer of its own for the whole launch
-        const int64_t pool_blocks = n_chunks < kBtPoolBlocks ? n_chunks : kBtPoolBlocks;
+        const BtTier& tier = kBtTiers[cx->bt_tier];
+        const int64_t pool_blocks = n_chunks < tier.pool_blocks ? n_chunks : tier.pool_blocks;
+        const uint32_t kBtFrames = tier.frames, kBtPathCap = tier.path_cap;
         const size_t need = (size_t)pool_blocks * 256 * ((size_t)kBtFrames * 16 + kBtPathCap);
         if (cx->scratch_bytes < need) {
             if (cx->d_scratch) (void)hipFree(cx->d_scratch);
@@ -1280,8 +1302,21 @@ int finish_inner(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
         return fail(TRRE_E_DIVERGES, msg);
     }
     if (was.family == TRRE_KERNEL_BACKTRACK && (status & kStEditOverflow)) {
+        // which limit: an attempt deeper than a lane's stack or with more output than its path buffer runs again with fewer, larger ones;
+        // the step budget is final (the reference's search is exponential here too)
+        uint32_t why = 0;
+        HIP_TRY(hipMemcpyAsync(&why, cx->d_status + 2, 4, hipMemcpyDeviceToHost, was.stream));
+        HIP_TRY(hipStreamSynchronize(was.stream));
+        if (!(why & kBtWhyBudget) && cx->bt_tier < 2) {
+            const int tier = cx->bt_tier;
+            cx->bt_tier = tier + 1;
+            const int rc = again(was.family);
+            cx->bt_tier = tier;
+            return rc;
+        }
         if (out_len) *out_len = 0;
-        return fail(TRRE_E_UNSUPPORTED, "error: the search exceeds the backtracking fallback's limits on this input (steps per KiB, depth of an attempt or its output)");
+        return fail(TRRE_E_UNSUPPORTED, (why & kBtWhyBudget) ? "error: the search takes more than 16 M steps in 1 KiB of this input (TRRE_BT_BUDGET; the backtracking fallback)"
+                                                              : "error: an attempt of the search consumes more than 1 M bytes or prints more than 1 MiB (the backtracking fallback)");
     }
     if (status & kStNeedScratch) {
         // a line longer than the LDS tile met the non-deterministic engine: give it
@@ -1437,9 +1472,7 @@ int compile_impl(const std::string& pattern, int engine, trre_prog** out, int mo
             if (!(p->dt.flags & kFlagMemoryless)) p->gt = build_guided_dft(dft);
         } else if (is_generate(mode)) {
             // trre -a / -ma: every accepting path prints (generate.cpp): a viability DFA for the device, the lists for the host
-            p->gen = build_gen_tables(nft, mode == TRRE_MODE_MATCH_ALL);
-            if (!p->gen.ok)
-                throw Error(kErrUnsupported, "error: the viability automaton of this pattern has more than 256 states (generator mode)");
+            p->gen = build_gen_tables(nft, mode == TRRE_MODE_MATCH_ALL);      // (always ok since round 5: beyond 256 viability states the filter lets everything through)
             p->nft_nodes = (uint32_t)p->gen.nodes.node.size();
             serialize_rev_table(p->gen.n_rev, p->gen.n_cls, 8, p->gen.cls, p->gen.rev, p->rblob);
             serialize_gen(p->gen, p->nblob);
@@ -1448,8 +1481,16 @@ int compile_impl(const std::string& pattern, int engine, trre_prog** out, int mo
             const NftNodes nodes = build_nft_nodes(nft, true);
             p->nft_nodes = (uint32_t)nodes.node.size();
             p->gt = build_guided_nft(nodes);
-            if (!p->gt.ok)
-                throw Error(kErrUnsupported, "error: the backward automaton of this pattern has too many states (match mode runs on the guided tables only)");
+            // beyond the guided tables' limits (a backward automaton of more than 16 384 states): the search itself in match form
+            // (gen_block.hpp: bt_lane; round 4: TRRE_E_UNSUPPORTED) — and on request for any pattern (the parity tests)
+            {
+                GenTables lists;
+                lists.nodes = nodes;
+                lists.match_mode = true;
+                lists.ok = true;
+                serialize_gen(lists, p->nblob);
+                p->bt_ok = true;
+            }
             make_guard(true);
         } else {
             // TRRE_COMPILE_TRACE=1: the stages of the NFT compile on stderr as they start (to find the one a pattern is slow in)
@@ -1665,6 +1706,7 @@ static int current_state(trre_prog* p, DeviceState** st) {
 }
 
 int trre_scan_enqueue(trre_prog* p, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, void* stream) {
+    g_scan_flags = 0;
     if (!p || (n && (!d_in || !d_out))) return fail(TRRE_E_ARG, "error: null argument");
     DeviceState* st;
     int rc = current_state(p, &st);
@@ -1683,7 +1725,7 @@ int trre_scan_finish(trre_prog* p, size_t* out_len) {
 }
 
 namespace {
-int slot_reserve(DeviceState::HostSlot& hs, bool input, size_t bytes);
+int slot_reserve(DeviceState::HostSlot& hs, bool input, size_t bytes, bool need_pin = true);
 constexpr size_t kGenChunk = (size_t)16 << 20;
 constexpr int64_t kGenLaneBytes = 512;          // generator modes on the device: a lane per 512 bytes of input (the records that start there),
 constexpr uint32_t kGenFrames = 512, kGenPathCap = 2048;   // a stack of 512 frames and 2 KiB of path output each (deeper / longer: the host enumeration)
@@ -1812,8 +1854,11 @@ int trre_debug_generate(trre_prog* p, const uint8_t* in, size_t n, const uint8_t
     return ok ? TRRE_OK : fail(TRRE_E_DIVERGES, kDivergeMsg);
 }
 
+uint32_t trre_last_scan_flags(void) { return g_scan_flags; }
+
 int trre_scan_device(trre_prog* p, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, size_t* out_len,
                      void* stream) {
+    g_scan_flags = 0;
     if (!p || (n && (!d_in || !d_out))) return fail(TRRE_E_ARG, "error: null argument");
     DeviceState* st;
     int rc = current_state(p, &st);
@@ -1848,19 +1893,22 @@ int trre_scan_device(trre_prog* p, const uint8_t* d_in, size_t n, uint8_t* d_out
 }
 
 namespace {
-// grow one direction of a host slot (pinned staging + device buffer)
-int slot_reserve(DeviceState::HostSlot& hs, bool input, size_t bytes) {
+// grow one direction of a host slot (pinned staging + device buffer); need_pin false: the caller's own buffer is pinned, no staging on this side
+int slot_reserve(DeviceState::HostSlot& hs, bool input, size_t bytes, bool need_pin) {
     uint8_t*& pin = input ? hs.pin_in : hs.pin_out;
     uint8_t*& dev = input ? hs.d_in : hs.d_out;
     size_t& have = input ? hs.in_cap : hs.out_cap;
-    if (have >= bytes) return TRRE_OK;
-    if (pin) (void)hipHostFree(pin);
-    if (dev) (void)hipFree(dev);
-    pin = nullptr; dev = nullptr; have = 0;
-    bytes += bytes / 8;                                   // (head room: the next chunk is rarely the same size)
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&pin), bytes + 64, hipHostMallocDefault));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), bytes + 64));
-    have = bytes;
+    if (have >= bytes && (pin || !need_pin)) return TRRE_OK;
+    const bool grow = have < bytes;
+    const size_t want = grow ? bytes + bytes / 8 : have;  // (head room: the next chunk is rarely the same size)
+    if (grow) {
+        if (dev) (void)hipFree(dev);
+        if (pin) (void)hipHostFree(pin);
+        pin = nullptr; dev = nullptr; have = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), want + 64));
+    }
+    if (need_pin && !pin) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&pin), want + 64, hipHostMallocDefault));
+    have = want;
     return TRRE_OK;
 }
 constexpr size_t kHostChunk = (size_t)32 << 20;
@@ -1939,8 +1987,20 @@ int scan_host_on(trre_prog* p, DeviceState* st, const uint8_t* in, size_t n, uin
     }
     const int fam = scan_family(*p);
     const bool fixed_len = !is_gen(fam);              // output size == input size (unless a NUL forces a general family)
+    // A caller's buffer that is pinned already (hipHostMalloc / hipHostRegister: the CLI's block buffers are) goes over the link as it
+    // is: no staging copy on that side (round 5; the copies run at 116 GB/s on 8 threads of one pool, which eight devices share).
+    auto is_pinned = [](const void* ptr, size_t len) -> bool {
+        if (!ptr || !len) return false;
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, ptr) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (at.type != hipMemoryTypeHost) return false;
+        if (hipPointerGetAttributes(&at, static_cast<const uint8_t*>(ptr) + len - 1) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return at.type == hipMemoryTypeHost;
+    };
+    static const bool no_direct = getenv("TRRE_NO_PINNED_DIRECT") != nullptr;      // (A/B runs)
+    const bool in_direct = !no_direct && is_pinned(in, n), out_direct = !no_direct && cap && is_pinned(out, cap);
 
-    struct Chunk { size_t off = 0, len = 0, out_at = 0, m = 0; bool submitted = false, copying = false, leaving = false, early = false; CopyPool::Job job; };
+    struct Chunk { size_t off = 0, len = 0, out_at = 0, m = 0, early_at = 0; bool submitted = false, copying = false, leaving = false, early = false; CopyPool::Job job; };
     Chunk ch[kHostSlots];
     size_t off = 0, total = 0;                        // input consumed, output produced (or needed)
     size_t total_bound = 0;                           // length-preserving: output of everything submitted so far
@@ -1957,20 +2017,26 @@ int scan_host_on(trre_prog* p, DeviceState* st, const uint8_t* in, size_t n, uin
     // stage chunk k in and queue its upload + scan (and, when the output size is known beforehand, its download)
     auto submit = [&](int b, size_t at, size_t len) -> int {
         DeviceState::HostSlot& hs = st->slot[b];
-        int r = slot_reserve(hs, true, len);
+        int r = slot_reserve(hs, true, len, !in_direct);
         if (r) return r;
-        r = slot_reserve(hs, false, fixed_len ? len : len + len / 2 + 4096);
+        r = slot_reserve(hs, false, fixed_len ? len : len + len / 2 + 4096, !out_direct);
         if (r) return r;
-        CopyPool::get().copy(hs.pin_in, in + at, len, kCopyWays);
-        HIP_TRY(hipMemcpyAsync(hs.d_in, hs.pin_in, len, hipMemcpyHostToDevice, hs.stream));
+        if (in_direct) {
+            HIP_TRY(hipMemcpyAsync(hs.d_in, in + at, len, hipMemcpyHostToDevice, hs.stream));
+        } else {
+            CopyPool::get().copy(hs.pin_in, in + at, len, kCopyWays);
+            HIP_TRY(hipMemcpyAsync(hs.d_in, hs.pin_in, len, hipMemcpyHostToDevice, hs.stream));
+        }
         ch[b].off = at; ch[b].len = len; ch[b].out_at = 0; ch[b].m = 0; ch[b].submitted = true; ch[b].early = false;
         hs.ctx.relaunches = 0;
         r = enqueue(p, st, &hs.ctx, fam, hs.d_in, len, hs.d_out, hs.out_cap, hs.stream);
         if (r) return r;
         if (fixed_len && !overflow && total_bound + len <= cap) {
-            // length-preserving: the output is `len` bytes unless a NUL turns up (then complete() downloads again)
-            HIP_TRY(hipMemcpyAsync(hs.pin_out, hs.d_out, len, hipMemcpyDeviceToHost, hs.stream));
+            // length-preserving: the output is `len` bytes unless a NUL turns up (then complete() downloads again).  (Straight to its
+            // place when the caller's buffer is pinned — if the chunks before it come out shorter after all, complete() downloads again.)
+            HIP_TRY(hipMemcpyAsync(out_direct ? out + total_bound : hs.pin_out, hs.d_out, len, hipMemcpyDeviceToHost, hs.stream));
             ch[b].early = true;
+            ch[b].early_at = total_bound;
         }
         total_bound += len;
         return TRRE_OK;
@@ -1982,7 +2048,7 @@ int scan_host_on(trre_prog* p, DeviceState* st, const uint8_t* in, size_t n, uin
         int r = finish(p, st, &hs.ctx, &m);
         bool again = false;
         while (r == TRRE_E_CAPACITY) {                // the general families report the size they need
-            r = slot_reserve(hs, false, m + 4096);
+            r = slot_reserve(hs, false, m + 4096, !out_direct);
             if (r) return r;
             r = enqueue(p, st, &hs.ctx, fam, hs.d_in, ch[b].len, hs.d_out, hs.out_cap, hs.stream);
             if (!r) r = finish(p, st, &hs.ctx, &m);
@@ -2001,8 +2067,8 @@ int scan_host_on(trre_prog* p, DeviceState* st, const uint8_t* in, size_t n, uin
         if (!overflow && m) {
             // (the early download holds the FIRST launch's bytes: a relaunch inside finish() — mask scratch for a long
             // line, a NUL, a bounded fold that overflowed — rewrote d_out afterwards)
-            if (!(ch[b].early && m == ch[b].len && !again && hs.ctx.relaunches == 0))
-                HIP_TRY(hipMemcpyAsync(hs.pin_out, hs.d_out, m, hipMemcpyDeviceToHost, hs.stream));
+            if (!(ch[b].early && m == ch[b].len && !again && hs.ctx.relaunches == 0 && (!out_direct || ch[b].early_at == total)))
+                HIP_TRY(hipMemcpyAsync(out_direct ? out + total : hs.pin_out, hs.d_out, m, hipMemcpyDeviceToHost, hs.stream));
             ch[b].copying = true;
         }
         total += m;
@@ -2014,8 +2080,9 @@ int scan_host_on(trre_prog* p, DeviceState* st, const uint8_t* in, size_t n, uin
     auto drain = [&](int b) -> int {
         if (!ch[b].copying) return TRRE_OK;
         HIP_TRY(hipStreamSynchronize(st->slot[b].stream));
-        CopyPool::get().start(ch[b].job, out + ch[b].out_at, st->slot[b].pin_out, ch[b].m, kCopyWays);
         ch[b].copying = false;
+        if (out_direct) return TRRE_OK;            // (the download went to its place)
+        CopyPool::get().start(ch[b].job, out + ch[b].out_at, st->slot[b].pin_out, ch[b].m, kCopyWays);
         ch[b].leaving = true;
         return TRRE_OK;
     };
@@ -2082,6 +2149,7 @@ struct DeviceScope {
 }  // namespace
 
 int trre_scan_host(trre_prog* p, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_len, int device) {
+    g_scan_flags = 0;
     if (!p || (n && !in) || (cap && !out)) return fail(TRRE_E_ARG, "error: null argument");
     if (out_len) *out_len = 0;
     if (n == 0) return TRRE_OK;
@@ -2109,7 +2177,81 @@ int trre_scan_host(trre_prog* p, const uint8_t* in, size_t n, uint8_t* out, size
 // cut at line ends into one contiguous shard per device (trre_shard_bounds), every device scans its shard on
 // its own host thread and streams, and the outputs are concatenated in shard order — an exclusive sum of G
 // sizes on the host, no collective.
+namespace {
+// The shards of one call: cut at line ends, every shard scanned by `scan_shard` on a host thread of its own, the outputs put together in
+// shard order.  (A function of its own so that the CPU test tier can drive the reassembly — eight shards, one of them ending the output —
+// with a stand-in for the device call: trre_debug_scan_host_multi.)
+using ShardFn = std::function<int(int shard, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_len)>;
+int scan_shards(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_len, int G, bool fixed_len, const ShardFn& scan_shard) {
+    std::vector<size_t> bounds((size_t)G + 1);
+    int rc = trre_shard_bounds(in, n, G, bounds.data());
+    if (rc) return rc;
+    // A length-preserving program writes every shard straight to its place (output offset == input offset);
+    // otherwise a shard's offset is known only when the shards before it are done: each goes to a buffer of its
+    // own and is moved into place afterwards.
+    struct Shard { int rc = TRRE_OK; size_t m = 0; std::string err; std::vector<uint8_t> buf; bool own = false; uint32_t flags = 0; };
+    std::vector<Shard> sh((size_t)G);
+    std::vector<std::thread> th;
+    for (int g = 0; g < G; ++g) {
+        th.emplace_back([&, g] {
+            Shard& s = sh[(size_t)g];
+            try {
+                const size_t lo = bounds[(size_t)g], len = bounds[(size_t)g + 1] - lo;
+                if (len == 0) return;
+                const bool direct = fixed_len && lo + len <= cap;
+                uint8_t* dst = nullptr;
+                size_t room = 0;
+                // cap == 0 is a size query; otherwise a shard that cannot go straight to its place gets a buffer of its
+                // own — also for a length-preserving program whose place lies beyond `cap`: NUL bytes may shorten the
+                // shards before it, and the call must succeed whenever the TOTAL fits
+                if (direct) { dst = out + lo; room = len; }
+                else if (cap > 0) { s.buf.resize(fixed_len ? len + 64 : len + len / 2 + 4096); s.own = true; dst = s.buf.data(); room = s.buf.size(); }
+                g_scan_flags = 0;
+                s.rc = scan_shard(g, in + lo, len, dst, room, &s.m);
+                if (s.rc == TRRE_E_CAPACITY && s.own) {          // the shard needs s.m bytes
+                    s.buf.resize(s.m + 64);
+                    s.rc = scan_shard(g, in + lo, len, s.buf.data(), s.buf.size(), &s.m);
+                }
+                if (s.rc && s.rc != TRRE_E_CAPACITY) s.err = trre_last_error();
+                s.flags = g_scan_flags;                          // (this thread's: handed to the caller's below)
+            } catch (const std::bad_alloc&) {                    // a multi-GB shard buffer: an error code, not std::terminate
+                s.rc = TRRE_E_TOO_BIG;
+                s.err = "error: out of host memory for a shard's output buffer";
+            } catch (const std::exception& e) {
+                s.rc = TRRE_E_DEVICE;
+                s.err = std::string("error: ") + e.what();
+            }
+        });
+    }
+    for (auto& t : th) t.join();
+    for (int g = 0; g < G; ++g) g_scan_flags |= sh[(size_t)g].flags;
+    size_t total = 0;
+    bool short_cap = false;
+    int last = G, diverged_at = -1;                   // shards [0, last) count; a shard on which the reference stops is the last one
+    for (int g = 0; g < G; ++g) {
+        const Shard& s = sh[(size_t)g];
+        if (s.rc == TRRE_E_DIVERGES) { diverged_at = g; last = g + 1; total += s.m; break; }
+        if (s.rc && s.rc != TRRE_E_CAPACITY) return fail(s.rc, s.err);
+        if (s.rc == TRRE_E_CAPACITY) short_cap = true;
+        total += s.m;
+    }
+    if (out_len) *out_len = total;
+    if (short_cap || total > cap) return fail(TRRE_E_CAPACITY, "error: output buffer too small");   // (short_cap: a size query, cap == 0)
+    // move the shards into place, in order (a direct shard that came out shorter — NUL bytes — moves down)
+    size_t at = 0;
+    for (int g = 0; g < last; ++g) {
+        const Shard& s = sh[(size_t)g];
+        const uint8_t* src = s.own ? s.buf.data() : out + bounds[(size_t)g];
+        if (s.m && src != out + at) std::memmove(out + at, src, s.m);
+        at += s.m;
+    }
+    if (diverged_at >= 0) return fail(TRRE_E_DIVERGES, sh[(size_t)diverged_at].err);
+    return TRRE_OK;
+}
+}  // namespace
+
 int trre_scan_host_multi(trre_prog* p, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_len, uint32_t device_mask) {
+    g_scan_flags = 0;
     if (!p || (n && !in) || (cap && !out)) return fail(TRRE_E_ARG, "error: null argument");
     if (out_len) *out_len = 0;
     int n_dev = 0;
@@ -2129,67 +2271,23 @@ int trre_scan_host_multi(trre_prog* p, const uint8_t* in, size_t n, uint8_t* out
     }
     const int G = (int)devs.size();
     if (G == 1) return trre_scan_host(p, in, n, out, cap, out_len, devs[0]);
-    std::vector<size_t> bounds(G + 1);
-    int rc = trre_shard_bounds(in, n, G, bounds.data());
-    if (rc) return rc;
     const int fam = scan_family(*p);
     const bool fixed_len = !is_gen(fam) && !is_generate(p->mode);
-    // A length-preserving program writes every shard straight to its place (output offset == input offset);
-    // otherwise a shard's offset is known only when the shards before it are done: each goes to a buffer of its
-    // own and is moved into place afterwards.
-    struct Shard { int rc = TRRE_OK; size_t m = 0; std::string err; std::vector<uint8_t> buf; bool own = false; };
-    std::vector<Shard> sh(G);
-    std::vector<std::thread> th;
-    for (int g = 0; g < G; ++g) {
-        th.emplace_back([&, g] {
-            Shard& s = sh[g];
-            try {
-                const size_t lo = bounds[g], len = bounds[g + 1] - lo;
-                if (len == 0) return;
-                const bool direct = fixed_len && lo + len <= cap;
-                uint8_t* dst = nullptr;
-                size_t room = 0;
-                // cap == 0 is a size query; otherwise a shard that cannot go straight to its place gets a buffer of its
-                // own — also for a length-preserving program whose place lies beyond `cap`: NUL bytes may shorten the
-                // shards before it, and the call must succeed whenever the TOTAL fits
-                if (direct) { dst = out + lo; room = len; }
-                else if (cap > 0) { s.buf.resize(fixed_len ? len + 64 : len + len / 2 + 4096); s.own = true; dst = s.buf.data(); room = s.buf.size(); }
-                s.rc = trre_scan_host(p, in + lo, len, dst, room, &s.m, devs[g]);
-                if (s.rc == TRRE_E_CAPACITY && s.own) {          // the shard needs s.m bytes
-                    s.buf.resize(s.m + 64);
-                    s.rc = trre_scan_host(p, in + lo, len, s.buf.data(), s.buf.size(), &s.m, devs[g]);
-                }
-                if (s.rc && s.rc != TRRE_E_CAPACITY) s.err = trre_last_error();
-            } catch (const std::bad_alloc&) {                    // a multi-GB shard buffer: an error code, not std::terminate
-                s.rc = TRRE_E_TOO_BIG;
-                s.err = "error: out of host memory for a shard's output buffer";
-            } catch (const std::exception& e) {
-                s.rc = TRRE_E_DEVICE;
-                s.err = std::string("error: ") + e.what();
-            }
-        });
-    }
-    for (auto& t : th) t.join();
-    size_t total = 0;
-    bool short_cap = false;
-    int last = G, diverged_at = -1;                   // shards [0, last) count; a shard on which the reference stops is the last one
-    for (int g = 0; g < G; ++g) {
-        if (sh[g].rc == TRRE_E_DIVERGES) { diverged_at = g; last = g + 1; total += sh[g].m; break; }
-        if (sh[g].rc && sh[g].rc != TRRE_E_CAPACITY) return fail(sh[g].rc, sh[g].err);
-        if (sh[g].rc == TRRE_E_CAPACITY) short_cap = true;
-        total += sh[g].m;
-    }
-    if (out_len) *out_len = total;
-    if (short_cap || total > cap) return fail(TRRE_E_CAPACITY, "error: output buffer too small");   // (short_cap: a size query, cap == 0)
-    // move the shards into place, in order (a direct shard that came out shorter — NUL bytes — moves down)
-    size_t at = 0;
-    for (int g = 0; g < last; ++g) {
-        const uint8_t* src = sh[g].own ? sh[g].buf.data() : out + bounds[g];
-        if (sh[g].m && src != out + at) std::memmove(out + at, src, sh[g].m);
-        at += sh[g].m;
-    }
-    if (diverged_at >= 0) return fail(TRRE_E_DIVERGES, sh[diverged_at].err);
-    return TRRE_OK;
+    const uint32_t flags0 = g_scan_flags;
+    const int rc = scan_shards(in, n, out, cap, out_len, G, fixed_len,
+                               [&](int g, const uint8_t* sin, size_t sn, uint8_t* sout, size_t scap, size_t* sm) { return trre_scan_host(p, sin, sn, sout, scap, sm, devs[(size_t)g]); });
+    g_scan_flags |= flags0;
+    return rc;
+}
+
+// CPU test tier: the sharding and the reassembly of trre_scan_host_multi with the caller's stand-in for the per-shard device call.
+int trre_debug_scan_host_multi(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_len, int n_shards, int fixed_len, trre_debug_shard_fn fn, void* user) {
+    g_scan_flags = 0;
+    if ((n && !in) || (cap && !out) || n_shards < 1 || !fn) return fail(TRRE_E_ARG, "error: null argument");
+    if (out_len) *out_len = 0;
+    if (n == 0) return TRRE_OK;
+    return scan_shards(in, n, out, cap, out_len, n_shards, fixed_len != 0,
+                       [&](int g, const uint8_t* sin, size_t sn, uint8_t* sout, size_t scap, size_t* sm) { return fn(user, g, sin, sn, sout, scap, sm); });
 }
 
 int trre_set_profiling(trre_prog* p, int on) {

@@ -1033,8 +1033,9 @@ __global__ __launch_bounds__(kGenThreads) void k_bt(ScanArgs a, GenArgs ga, int6
         }
         DirectLane L;
         uint32_t lst = 0;
-        if (!skip) bt_lane<kMode>(a, G, ga, slot, lane, lane_bytes, base, budget, L, lst);
-        if (lst & kStEditOverflow) atomicOr(a.status, kStEditOverflow);
+        uint32_t why = 0;
+        if (!skip) bt_lane<kMode>(a, G, ga, slot, lane, lane_bytes, base, budget, L, lst, why);
+        if (lst & kStEditOverflow) { atomicOr(a.status + 2, why); atomicOr(a.status, kStEditOverflow); }      // (status[2]: which limit, for the runtime's next try)
         if (kMode == 1 && (lst & kStDiverge)) atomicMax(a.status + 1, 0xffffffffu - (uint32_t)lane);     // (see k_stream_direct)
         st |= lst;
         if (kMode == 1) {
