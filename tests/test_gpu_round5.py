@@ -1,0 +1,187 @@
+"""GPU tier, round 5: what changed around the kernels — the stack guard on step budgets with a visible "undecided" flag, the
+command-line pipeline (pinned blocks, pipes answered as their lines arrive, the lazy family through trre_dft), pinned caller
+buffers going over the link without staging copies."""
+import ctypes
+import os
+import random
+import subprocess
+import sys
+import time
+
+import pytest
+
+import corpus
+import golden_lib
+import trre_amd
+from oracle_lib import Oracle, ref_available
+from test_cli import BIN, REF, run
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+GUARD_SCRIPT = r'''
+import ctypes, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch, trre_amd
+from trre_amd import api
+L = api.lib()
+L.trre_last_scan_flags.restype = ctypes.c_uint32
+p = trre_amd.Program(" +: ", "nft")
+data = b"a  b c\n" * 3000 + b"x" + b" " * 70000 + b"y\n" + b"d  e\n" * 10
+t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+res = []
+for rep in range(3):
+    try:
+        out = p.scan_tensor(t).cpu().numpy().tobytes()
+        res.append(("ok", len(out), L.trre_last_scan_flags()))
+    except trre_amd.TrreError as e:
+        res.append(("err", e.code, int(e.partial.numel()), L.trre_last_scan_flags()))
+try:
+    out = p.scan(data)
+    res.append(("host-ok", len(out), L.trre_last_scan_flags()))
+except trre_amd.TrreError as e:
+    res.append(("host-err", e.code, len(e.partial), L.trre_last_scan_flags()))
+q = trre_amd.Program("cat:dog", "nft")
+q.scan_tensor(torch.frombuffer(bytearray(b"cat\n"), dtype=torch.uint8).cuda())
+res.append(("plain", L.trre_last_scan_flags()))
+print(repr(res))
+'''
+
+
+def _guard_run(env):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", GUARD_SCRIPT % (ROOT, os.path.join(ROOT, "tests"))], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    return eval(r.stdout.decode().strip().splitlines()[-1])
+
+
+def test_the_stack_guard_counts_steps_not_seconds_and_says_what_it_left_undecided():
+    """(a wall clock decided; an undecided line was a silent TRRE_OK.)  Default budgets: the line of 70 000 spaces is decided —
+    the reference's error with its partial output, every time, no flag.  A step budget the line's search does not fit in: the scan's own
+    output stands, TRRE_OK — and trre_last_scan_flags() says TRRE_SCAN_GUARD_UNDECIDED, every time, device and host paths; the flag is
+    per call (a scan after it is clean).  The same under a busy host: the budgets are steps."""
+    pre = len(b"a b c\n" * 3000 + b"x")
+    full = len(b"a b c\n" * 3000 + b"x y\n" + b"d e\n" * 10)
+    want_decided = [("err", trre_amd.api.E_DIVERGES, pre, 0)] * 3 + [("host-err", trre_amd.api.E_DIVERGES, pre, 0), ("plain", 0)]
+    want_undecided = [("ok", full, 1)] * 3 + [("host-ok", full, 1), ("plain", 0)]
+    assert _guard_run({}) == want_decided
+    assert _guard_run({"TRRE_GUARD_BUDGET": "1000"}) == want_undecided
+    assert _guard_run({"TRRE_GUARD_CALL_BUDGET": "0", "TRRE_GUARD_BUDGET": "100000000"}) == want_decided       # (the first batch is always searched)
+    # a host with every core busy: same answers
+    burners = [subprocess.Popen([sys.executable, "-c", "while True: pass"]) for _ in range(min(64, os.cpu_count() or 8))]
+    try:
+        time.sleep(0.5)
+        assert _guard_run({}) == want_decided
+        assert _guard_run({"TRRE_GUARD_BUDGET": "1000"}) == want_undecided
+    finally:
+        for b in burners:
+            b.kill()
+        for b in burners:
+            b.wait()
+    # the command line says it too (stderr), and prints what the table kernels print
+    data = b"a  b c\n" * 3000 + b"x" + b" " * 70000 + b"y\n" + b"d  e\n" * 10
+    rc, out, err = run(BIN["nft"], [" +: "], data, {"TRRE_GUARD_BUDGET": "1000"})
+    assert rc == 0 and len(out) == full and err.startswith(b"trre: warning: a line long enough to exhaust the reference's stack")
+
+
+def test_cli_runs_the_patterns_beyond_the_eager_determinisation():
+    """`trre_dft` on the patterns rounds 1-4 refused at compile time (TRRE_E_TOO_BIG): stdin and FILE, small blocks, beside the compiled reference"""
+    import tempfile
+    n = 0
+    for pat, name, data, exp in golden_lib.lazy_cases():
+        for env in ({}, {"TRRE_CLI_BLOCK": "4096", "TRRE_SHARDS_PER_DEVICE": "2"}):
+            assert run(BIN["dft"], [pat], data, env) == (0, exp, b""), (pat, name, env)
+        if n % 4 == 0:
+            with tempfile.NamedTemporaryFile() as tf:
+                tf.write(data)
+                tf.flush()
+                assert run(BIN["dft"], [pat, tf.name]) == (0, exp, b""), (pat, name, "FILE")
+                if ref_available():
+                    assert run(REF["dft"], [pat, tf.name]) == (0, exp, b"")
+        n += 1
+    assert n >= 17
+    assert run(BIN["dft"], ["((a:x)*b)|((a:y)*c)"], b"aaab\naaac\n") == (0, b"xxxb\nyyyc\n", b"")
+
+
+def test_cli_answers_a_pipe_as_its_lines_arrive():
+    """the reference prints per getline (trre_nft.c:776-789): a producer that writes a line and waits sees it answered before it writes
+    the next (round 4 printed nothing before 256 MiB or EOF)"""
+    p = subprocess.Popen([BIN["nft"], "(cat:dog|dog:cat)"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    try:
+        for k, (line, want) in enumerate([(b"a cat\n", b"a dog\n"), (b"dog and cat\nsecond line\n", b"cat and dog\nsecond line\n"), (b"\n", b"\n")]):
+            p.stdin.write(line)
+            p.stdin.flush()
+            got = b""
+            t_end = time.time() + 60
+            os.set_blocking(p.stdout.fileno(), False)
+            while len(got) < len(want) and time.time() < t_end:
+                chunk = p.stdout.read()
+                if chunk:
+                    got += chunk
+                else:
+                    time.sleep(0.01)
+            assert got == want, (k, got)
+        p.stdin.write(b"no newline at the end: the last byte goes, as in the reference")
+        p.stdin.close()
+        os.set_blocking(p.stdout.fileno(), True)
+        assert p.stdout.read() == b"no newline at the end: the last byte goes, as in the referenc\n"
+        assert p.wait(timeout=60) == 0
+    finally:
+        p.kill()
+
+
+def test_cli_pipeline_on_a_large_file_and_a_large_pipe():
+    """several blocks in flight (reader, scan, writer), a line that straddles every block end, file and pipe, general and length-preserving"""
+    import tempfile
+    rng = random.Random(8)
+    data = corpus.word_soup(rng, 40 << 20) + b"x" * 300000 + b" cat\n" + corpus.word_soup(rng, 8 << 20) + b"tail cat"
+    for pat, eng in [("(cat:dog|dog:cat)", "nft"), ("a:xyz", "dft")]:
+        want = Oracle(pat, eng).scan(data)
+        with tempfile.NamedTemporaryFile(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as tf:
+            tf.write(data)
+            tf.flush()
+            for env in ({}, {"TRRE_CLI_BLOCK": str(3 << 20)}, {"TRRE_CLI_BLOCK": str(1 << 20), "TRRE_SHARDS_PER_DEVICE": "2"}):
+                rc, out, err = run(BIN[eng], [pat, tf.name], b"", env)
+                assert (rc, err) == (0, b"") and out == want, (pat, env, "file")
+            rc, out, err = run(BIN[eng], [pat], data, {"TRRE_CLI_BLOCK": str(2 << 20)})
+            assert (rc, err) == (0, b"") and out == want, (pat, "pipe")
+
+
+def test_pinned_caller_buffers_go_over_the_link_as_they_are():
+    """trre_scan_host with hipHostMalloc'd buffers (torch.pin_memory): no staging copies — same bytes as with pageable buffers; several
+    chunks in flight, NULs that shorten a length-preserving chunk's output (the early download has to be taken again, at another place),
+    variable-length output, a size query, a buffer one byte short"""
+    import torch
+    rng = random.Random(4)
+    base = corpus.word_soup(rng, 1 << 20)
+    data = bytearray(base * 100)                                   # ~100 MiB: four chunks of 32 MiB
+    for at in (5 << 20, (40 << 20) + 17, 99 << 20):
+        data[at] = 0
+    data = bytes(data) + b"last cat"
+    L = trre_amd.api.lib()
+    pin_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).pin_memory()
+    for pat, eng in [("(cat:dog|dog:cat)", "nft"), ("[a:A-z:Z]", "dft"), ("a:xyz", "dft"), ("[aie]:", "nft")]:
+        p = trre_amd.Program(pat, eng)
+        want = p.scan(data)                                        # pageable in, pageable out
+        assert want[:1 << 20] == Oracle(pat, eng).scan(data[:data.rfind(b"\n", 0, 1 << 20) + 1] )[:1 << 20]
+        m = ctypes.c_size_t()
+        pin_out = torch.empty(len(want) + 64, dtype=torch.uint8).pin_memory()
+        for cap in (len(want) + 64, len(want)):
+            pin_out.fill_(0xEE)
+            rc = L.trre_scan_host(p._h, ctypes.c_char_p(pin_in.data_ptr()), len(data), ctypes.c_char_p(pin_out.data_ptr()), cap, ctypes.byref(m), 0)
+            assert rc == 0 and m.value == len(want) and pin_out[:m.value].numpy().tobytes() == want, (pat, cap)
+        rc = L.trre_scan_host(p._h, ctypes.c_char_p(pin_in.data_ptr()), len(data), ctypes.c_char_p(pin_out.data_ptr()), len(want) - 1, ctypes.byref(m), 0)
+        assert rc == trre_amd.api.E_CAPACITY and m.value == len(want), pat
+        rc = L.trre_scan_host(p._h, ctypes.c_char_p(pin_in.data_ptr()), len(data), None, 0, ctypes.byref(m), 0)
+        assert rc == trre_amd.api.E_CAPACITY and m.value == len(want), pat
+        # pinned in, pageable out and the other way round
+        import numpy as np
+        out = np.empty(len(want) + 64, dtype=np.uint8)
+        rc = L.trre_scan_host(p._h, ctypes.c_char_p(pin_in.data_ptr()), len(data), out.ctypes.data_as(ctypes.c_char_p), out.size, ctypes.byref(m), 0)
+        assert rc == 0 and out[:m.value].tobytes() == want, pat
+        rc = L.trre_scan_host(p._h, data, len(data), ctypes.c_char_p(pin_out.data_ptr()), len(want) + 64, ctypes.byref(m), 0)
+        assert rc == 0 and pin_out[:m.value].numpy().tobytes() == want, pat
+        os.environ["TRRE_SHARDS_PER_DEVICE"] = "1"
+        rc = L.trre_scan_host_multi(p._h, ctypes.c_char_p(pin_in.data_ptr()), len(data), ctypes.c_char_p(pin_out.data_ptr()), len(want) + 64, ctypes.byref(m), 0)
+        assert rc == 0 and pin_out[:m.value].numpy().tobytes() == want, pat
