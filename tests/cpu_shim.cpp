@@ -25,6 +25,8 @@ using namespace trre;
 
 namespace {
 
+int g_last_rounds = 0;       // repair rounds of the last exact-sub-range run (shim_last_rounds)
+
 constexpr uint32_t kFlagG16SlowBit = 1u << 3;    // front.hpp: kFlagG16Slow
 using GeoTiny = Geometry<4, 64, 32>;
 using GeoTinyStream = Geometry<4, 4 * 20, 32>;   // SUB = 20 bytes = 5 dwords (odd), like the production stream geometry
@@ -253,6 +255,68 @@ void run_direct_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uin
         if (g16 && (h.flags & kFlagG16SlowBit)) g16_lane<2, kSym, true>(a, T, h.n_cls, lane, lane_bytes, ring, base[lane], L, status);
         else if (g16) g16_lane<2, kSym, false>(a, T, h.n_cls, lane, lane_bytes, ring, base[lane], L, status);
         else stream_direct_lane<2, false, (kSym != 0)>(a, T, h.n_cls, lane, lane_bytes, ring, base[lane], L, status);
+    }
+}
+
+// The same with EXACT SUB-RANGES (round 5; scan_block.hpp: ScanArgs::exact), as runtime.cpp drives it: the count pass guesses every lane's
+// entry state from `look` bytes before its sub-range, k_spec_verify's rule flags the lanes whose guess is not the exit state of the lane
+// before them, repair rounds (a flagged lane walks again, and on into the lanes behind it within its workgroup of `group` lanes) until
+// none is flagged, then the emit pass from the verified states.  *rounds: repair rounds it took.
+template <int kSym = 0>
+void run_direct_gen_exact(ScanArgs a, int64_t lane_bytes, uint32_t& status, uint64_t& total_out, uint32_t look, int64_t group, int& rounds) {
+    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
+    const StreamView T = direct_view(a);
+    const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
+    alignas(16) uint8_t ring[kRingStride];
+    std::vector<uint64_t> cnt(n_lanes);
+    std::vector<uint32_t> entry(n_lanes, 0xEEEEEEE0u), exits(n_lanes, 0xDDDDDDD0u), flags(n_lanes, 0);
+    a.entry_rows = entry.data(); a.exit_rows = exits.data(); a.spec_flags = flags.data();
+    a.spec_look = look;
+    const bool slow = (h.flags & kFlagG16SlowBit) != 0;
+    auto count_lane = [&](int64_t lane) {
+        DirectLane L;
+        if (slow) g16_lane<1, kSym, true>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
+        else g16_lane<1, kSym, false>(a, T, h.n_cls, lane, lane_bytes, ring, 0, L, status);
+        cnt[lane] = L.count;
+    };
+    a.exact = 1;
+    for (int64_t lane = n_lanes - 1; lane >= 0; --lane) count_lane(lane);
+    rounds = 0;
+    for (;;) {
+        int64_t bad = 0;
+        for (int64_t lane = 1; lane < n_lanes; ++lane) {
+            flags[lane] = !(entry[lane] & 1u) && (entry[lane] & ~1u) != exits[lane - 1];
+            bad += flags[lane];
+        }
+        if (!bad) break;
+        ++rounds;
+        if (rounds > n_lanes + 8) { status |= 1u << 29; return; }      // must not happen
+        a.exact = 3;
+        const std::vector<uint32_t> exits_before = exits;               // (what the threads of one launch read of the lanes before them: maybe stale)
+        for (int64_t lane = n_lanes - 1; lane >= 1; --lane) {
+            if (!flags[lane]) continue;
+            const int64_t block_end = std::min(n_lanes, (lane / group + 1) * group);
+            uint32_t state = (lane % 2) ? exits[lane - 1] : exits_before[lane - 1];
+            for (int64_t j = lane;;) {
+                entry[j] = state;
+                count_lane(j);
+                state = exits[j];
+                ++j;
+                if (j >= block_end || flags[j]) break;
+                if ((entry[j] & 1u) || (entry[j] & ~1u) == state) break;
+            }
+        }
+    }
+    uint64_t run = 0;
+    std::vector<uint64_t> base(n_lanes);
+    for (int64_t lane = 0; lane < n_lanes; ++lane) { base[lane] = run; run += cnt[lane]; }
+    total_out = run;
+    if (run > a.cap) { status |= kStCapacity; return; }
+    a.exact = 2;
+    for (int64_t lane = n_lanes - 1; lane >= 0; --lane) {
+        DirectLane L;
+        if (slow) g16_lane<2, kSym, true>(a, T, h.n_cls, lane, lane_bytes, ring, base[lane], L, status);
+        else g16_lane<2, kSym, false>(a, T, h.n_cls, lane, lane_bytes, ring, base[lane], L, status);
     }
 }
 
@@ -668,6 +732,12 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
         const bool g16 = family == 7 && reinterpret_cast<const StreamBlobHeader*>(blob)->g16_bytes != 0;
         run_direct_gen<>(a, geo == 0 ? 2048 : 48, status, total, g16);
     }
+    else if (family == 32 || family == 33) {          // ... with exact sub-ranges (33: a look-back of 4 bytes: wrong guesses, repair rounds)
+        if (reinterpret_cast<const StreamBlobHeader*>(blob)->g16_bytes == 0) return -5;
+        int rounds = 0;
+        run_direct_gen_exact<>(a, geo == 0 ? 2048 : 64, status, total, family == 33 ? 4u : (uint32_t)kSpecLook, geo == 0 ? 256 : 3, rounds);
+        g_last_rounds = rounds;
+    }
     else if (family == 4) {
         if (geo == 0) run_stream_lp<GeoStream>(a, status); else run_stream_lp<GeoTinyStream>(a, status);
         total = n;
@@ -752,7 +822,7 @@ int shim_scan_guided(const uint8_t* rblob, const uint8_t* gblob, int family, int
     if ((family == 10 || family == 13 || family == 14) && cap < n) return -9;
     // like the runtime: symbols are packed two per byte when the backward DFA allows it and the walk uses the 16-byte entries
     const bool has_g16 = reinterpret_cast<const StreamBlobHeader*>(gblob)->g16_bytes != 0;
-    const bool packed = reinterpret_cast<const RevBlobHeader*>(rblob)->sym_bits == 4 && has_g16 && (family == 10 || family == 11 || family == 15);
+    const bool packed = reinterpret_cast<const RevBlobHeader*>(rblob)->sym_bits == 4 && has_g16 && (family == 10 || family == 11 || family == 15 || family == 17 || family == 18);
     if (reinterpret_cast<const RevBlobHeader*>(rblob)->sym_bits == 16) {
         // wide guided tables (more than 256 backward states): k_rev_wide, k_wide_fwd<count>, scan, k_wide_fwd<emit>
         if (family == 10 || family == 13 || family == 14) return -5;
@@ -788,6 +858,14 @@ int shim_scan_guided(const uint8_t* rblob, const uint8_t* gblob, int family, int
         if (!has_g16) return -5;
         if (packed) run_g16_splice<2>(a, lane_bytes, status, total, geo == 0 ? 256u : 64u);
         else run_g16_splice<1>(a, lane_bytes, status, total, geo == 0 ? 256u : 64u);
+    }
+    else if (family == 17 || family == 18) {
+        // general guided family with exact sub-ranges (18: a look-back of 4 bytes: wrong guesses, repair rounds)
+        if (!has_g16) return -5;
+        int rounds = 0;
+        if (packed) run_direct_gen_exact<2>(a, lane_bytes, status, total, family == 18 ? 4u : (uint32_t)kSpecLook, geo == 0 ? 256 : 3, rounds);
+        else run_direct_gen_exact<1>(a, lane_bytes, status, total, family == 18 ? 4u : (uint32_t)kSpecLook, geo == 0 ? 256 : 3, rounds);
+        g_last_rounds = rounds;
     }
     else if (family == 15) {
         if (!has_g16 || al != 0) return -5;
@@ -1014,6 +1092,8 @@ int shim_guard(const uint8_t* kblob, const uint8_t* in, size_t n, int in_mis, ui
     *part = res[bad].out_len;
     return 0;
 }
+
+int shim_last_rounds() { return g_last_rounds; }
 
 int shim_rev_sweep(const uint8_t* rblob, int geo, const uint8_t* in, size_t n, int in_mis, uint8_t* sym_out) {
     if (n == 0) return 0;

@@ -59,7 +59,7 @@ def mask_bytes_of(blob, engine):
 def shim_scan(blob, engine, family, data, geo=1, in_mis=0, out_mis=0, scratch=True, cap=None):
     """Run one kernel family of the device code on the host.  Returns (output bytes, status)."""
     if cap is None:
-        cap = len(data) * 8 + 64 if family in (3, 5, 7, 9, 22, 23, 24, 25, 27, 28, 29) else len(data)     # (20, 21: length-preserving)
+        cap = len(data) * 8 + 64 if family in (3, 5, 7, 9, 22, 23, 24, 25, 27, 28, 29, 32, 33) else len(data)     # (20, 21: length-preserving)
     out = ctypes.create_string_buffer(max(cap, 1))
     m = ctypes.c_size_t()
     st = ctypes.c_uint32()
@@ -70,6 +70,15 @@ def shim_scan(blob, engine, family, data, geo=1, in_mis=0, out_mis=0, scratch=Tr
     if rc:
         raise RuntimeError("shim rc %d" % rc)
     return out.raw[:m.value], st.value
+
+
+def has_g16(stream_blob):
+    """a stream-form blob carries the 16-byte entries (StreamBlobHeader::g16_bytes)"""
+    return bool(stream_blob) and len(stream_blob) >= 144 and _g16_bytes(stream_blob) != 0
+
+
+def _g16_bytes(blob):
+    return struct.unpack_from("<I", blob, 60)[0]          # (device_blob.hpp: the 16th word of StreamBlobHeader)
 
 
 def has_fallback_form(prog):
@@ -97,6 +106,8 @@ ST_EDIT_OVERFLOW = 64
 # shim ids of the guided families (ABI ids 6, 7): LP by the emit pass alone on the 16-byte entries (as the runtime
 # launches it), general on the 16-byte / 8-byte entries, LP by the older LDS-ring walker, LP emit on the 8-byte entries
 GUIDED_LP, GUIDED_GEN, GUIDED_GEN8, GUIDED_LP_RING, GUIDED_LP8 = 10, 11, 12, 13, 14
+GUIDED_GEN_EXACT, GUIDED_GEN_EXACT_MISS = 17, 18     # general guided family with exact sub-ranges (round 5); 18: a look-back of 4 bytes (repair rounds)
+STREAM_G16_EXACT, STREAM_G16_EXACT_MISS = 32, 33     # stream general family, the same
 GUIDED_GEN_SPLICE = 16                               # general guided family by the splice form of its 16-byte entries (mark + splice: the runtime's default)
 STREAM_G16_SPLICE = 28                               # stream general family, the same
 GUIDED_LP_ALL = (GUIDED_LP, GUIDED_LP_RING, GUIDED_LP8)
@@ -125,7 +136,29 @@ def shim_scan_guided(prog, family, data, geo=1, in_mis=0, out_mis=0):
     return out.raw[:m.value], st.value
 
 
+def last_rounds():
+    """repair rounds of the last exact-sub-range run on the shim"""
+    return lib().shim_last_rounds()
+
+
 def scan_guided_like_runtime(prog, data, geo=1, family=GUIDED_LP, in_mis=0, out_mis=0):
+    if family in (GUIDED_GEN_EXACT, GUIDED_GEN_EXACT_MISS):
+        lib()
+        rblob, gblob = prog.export_guided_tables()
+        cap = len(data) * 8 + 64
+        o = ctypes.create_string_buffer(max(cap, 1))
+        m = ctypes.c_size_t()
+        stt = ctypes.c_uint32()
+        rc = lib().shim_scan_guided(rblob, gblob, family, geo, data, len(data), in_mis, o, cap, out_mis, ctypes.byref(m), ctypes.byref(stt))
+        if rc == -5:
+            family = GUIDED_GEN
+        elif rc:
+            raise RuntimeError("shim rc %d" % rc)
+        elif stt.value & (ST_DIVERGE | ST_OVERFLOW):
+            family = GUIDED_GEN              # (an attempt that does not return: the old way names the first such lane)
+        else:
+            assert not stt.value & (1 << 29), "the repair rounds did not converge"
+            return o.raw[:m.value]
     if family == GUIDED_GEN_SPLICE:
         lib().shim_scan_guided          # (argtypes set)
         rblob, gblob = prog.export_guided_tables()
@@ -160,7 +193,7 @@ def scan_like_runtime(prog, data, geo=1, family=None, in_mis=0, out_mis=0):
     fam = family
     if not fam:                       # ABI ids -> shim ids (the shim's 6..9 are the direct walkers of the stream families)
         fam = {6: GUIDED_LP, 7: GUIDED_GEN}.get(info.kernel, info.kernel)
-    if fam in (GUIDED_LP, GUIDED_GEN, GUIDED_GEN8, GUIDED_LP_RING, GUIDED_LP8, GUIDED_GEN_SPLICE):
+    if fam in (GUIDED_LP, GUIDED_GEN, GUIDED_GEN8, GUIDED_LP_RING, GUIDED_LP8, GUIDED_GEN_SPLICE, GUIDED_GEN_EXACT, GUIDED_GEN_EXACT_MISS):
         return scan_guided_like_runtime(prog, data, geo, fam, in_mis, out_mis)
     if family == DFT_LAZY or (not family and info.kernel == 10):
         out, st, _ = scan_lazy(prog, data, geo, in_mis)
@@ -176,7 +209,13 @@ def scan_like_runtime(prog, data, geo=1, family=None, in_mis=0, out_mis=0):
         if st & ST_DIVERGE:
             raise RuntimeError("diverges")
         return out
-    blob = prog.export_stream_tables() if fam in (4, 5, 6, 7, 8, 9, 20, 21, 22, 23, 25, 27, 28, STREAM_LPW_PAIR) else prog.export_tables()
+    blob = prog.export_stream_tables() if fam in (4, 5, 6, 7, 8, 9, 20, 21, 22, 23, 25, 27, 28, 32, 33, STREAM_LPW_PAIR) else prog.export_tables()
+    if fam in (STREAM_G16_EXACT, STREAM_G16_EXACT_MISS):
+        out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
+        if out is not None and not st & (ST_DIVERGE | ST_OVERFLOW):
+            assert not st & (1 << 29), "the repair rounds did not converge"
+            return out
+        fam = 7                             # no 16-byte entries, a bounded fold that overflowed, an attempt that does not return: the old way
     if fam == STREAM_G16_SPLICE:
         out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
         if out is not None and not st & (ST_EDIT_OVERFLOW | ST_NUL | ST_DIVERGE | ST_OVERFLOW):

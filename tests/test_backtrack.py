@@ -174,11 +174,9 @@ def test_match_mode_backtracking_and_the_larger_stacks_on_gpu():
     q = trre_amd.Program("(a:xy)*b", "nft")
     data = b"cat\n" * 3000 + b"a" * 30000 + b"b tail\n" + b"dog\n" * 3000 + b"a" * 5000 + b"b\n"
     assert dev(q, data, trre_amd.KERNEL_BACKTRACK) == Oracle("(a:xy)*b", "nft").scan(data)
-    data = b"a" * 300000 + b"b\n"                      # ... and than the second tier's (65 536 / 64 KiB)
-    try:
-        import os
-        os.environ["TRRE_NO_STACK_GUARD"] = "1"        # (the reference itself runs out of stack on this line; what is tested is the fallback's own limit)
-        q2 = trre_amd.Program("(a:xy)*b", "nft")
-        assert dev(q2, data, trre_amd.KERNEL_BACKTRACK) == b"xy" * 300000 + b"b\n"
-    finally:
-        os.environ.pop("TRRE_NO_STACK_GUARD", None)
+    # ... and than the second tier's (65 536 / 64 KiB): an attempt of 320 000 bytes whose search holds 40 000 items — the reference runs it
+    q2 = trre_amd.Program("(aaaaaaaa:xy)*b", "nft")
+    data = b"zz\n" + b"a" * 320000 + b"b\n"
+    want = b"zz\n" + b"xy" * 40000 + b"b\n"
+    assert Oracle("(aaaaaaaa:xy)*b", "nft").scan(data) == want
+    assert dev(q2, data, trre_amd.KERNEL_BACKTRACK) == want

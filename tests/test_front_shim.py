@@ -618,3 +618,41 @@ def test_wide_guided_tables():
     assert pm.info.guided_rev_states > 256
     out, st = shim_lib.shim_scan_guided(pm, shim_lib.GUIDED_GEN, data, 0)
     assert st == 0 and out == Oracle("[a-h]{8}(a|b)[a-z ]*", "nft").match(data)
+
+
+def test_exact_sub_ranges_on_every_golden_vector():
+    """round 5 (scan_block.hpp: ScanArgs::exact): a lane walks the bytes of its sub-range from the state the transducer is in there —
+    guessed from the bytes before it, verified against the lane before, repaired where the guess was wrong — instead of the lines
+    that start in the sub-range.  Every golden vector through the count / emit pair of the small tables that way, stream and guided
+    tables, tiny and production geometry, with the production look-back and with one of 4 bytes (wrong guesses: repair rounds)."""
+    n = n_rounds = 0
+    for k, (pat, name, data, eng, exp) in enumerate(golden_lib.cases()):
+        if exp is None or len(data) > 30000 or k % 2:
+            continue
+        p = prog(pat, eng)
+        info = p.info
+        fams = []
+        if info.stream_states and shim_lib.has_g16(p.export_stream_tables()):
+            fams += [shim_lib.STREAM_G16_EXACT, shim_lib.STREAM_G16_EXACT_MISS]
+        if info.guided_rev_states and info.guided_rev_states <= 256 and shim_lib.has_g16(p.export_guided_tables()[1]):
+            fams += [shim_lib.GUIDED_GEN_EXACT, shim_lib.GUIDED_GEN_EXACT_MISS]
+        for fam in fams:
+            for geo, mis in ((1, 0), (0, 7)):
+                got = shim_lib.scan_like_runtime(p, data, geo=geo, family=fam, in_mis=mis)
+                assert got == exp, (pat, name, eng, fam, geo)
+                n_rounds += shim_lib.last_rounds()
+                n += 1
+    assert n > 1200 and n_rounds > 3, (n, n_rounds)
+    # long lines (what the form is for), a NUL in front of one (the SKIP state has to travel through every lane of the line)
+    rng = random.Random(5)
+    text = b"".join(bytes(rng.choice(b"abc  xyz,cat dog") for _ in range(rng.randint(800, 4000))) + b"\n" for _ in range(12))
+    data = text + b"aa\0bbb" + text[:9000] + b"tail   x"
+    for pat, eng in [(" +: ", "nft"), ("a:xyz", "dft"), ("(a|b)*c:x", "nft"), ("(cat:dog|dog:cat)", "nft"), ("[a-z]+g:X", "dft"), ("(a|b)*c:x", "dft"), ("[aie]:", "nft")]:
+        p = prog(pat, eng)
+        want = Oracle(pat, eng).scan(data)
+        fams = (shim_lib.STREAM_G16_EXACT, shim_lib.STREAM_G16_EXACT_MISS) if p.info.kernel in (4, 5) else (shim_lib.GUIDED_GEN_EXACT, shim_lib.GUIDED_GEN_EXACT_MISS)
+        for fam in fams:
+            for geo in (0, 1):
+                assert shim_lib.scan_like_runtime(p, data, geo=geo, family=fam, in_mis=3) == want, (pat, eng, fam, geo)
+                n_rounds += shim_lib.last_rounds()
+    assert n_rounds > 40, n_rounds

@@ -164,7 +164,8 @@ def test_pinned_caller_buffers_go_over_the_link_as_they_are():
     for pat, eng in [("(cat:dog|dog:cat)", "nft"), ("[a:A-z:Z]", "dft"), ("a:xyz", "dft"), ("[aie]:", "nft")]:
         p = trre_amd.Program(pat, eng)
         want = p.scan(data)                                        # pageable in, pageable out
-        assert want[:1 << 20] == Oracle(pat, eng).scan(data[:data.rfind(b"\n", 0, 1 << 20) + 1] )[:1 << 20]
+        head = Oracle(pat, eng).scan(data[:data.rfind(b"\n", 0, 1 << 20) + 1])
+        assert want[:len(head)] == head
         m = ctypes.c_size_t()
         pin_out = torch.empty(len(want) + 64, dtype=torch.uint8).pin_memory()
         for cap in (len(want) + 64, len(want)):

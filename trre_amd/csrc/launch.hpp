@@ -65,6 +65,11 @@ void launch_bt(int which, const ScanArgs& a, const GenArgs& ga, int64_t lane_byt
 // the deterministic engine on tables still being built (lazy_block.hpp): which 1 count (lanes whose lane_counts entry is not kLazyVoid keep
 // it), 2 emit (leaves at once when the count pass was not final); chunks of 256 lanes
 void launch_lazy(int which, const ScanArgs& a, const LazyArgs& la, int64_t lane_bytes, int64_t n_chunks, void* stream);
+// exact sub-ranges (scan_block.hpp: ScanArgs::exact): flags the lanes whose guessed entry state is not the exit state of the lane before
+// them (a.spec_flags, a.status[3] counts them); the repair round is launch_direct_kernel(1, ...) with a.exact == 3
+void launch_spec_verify(const ScanArgs& a, int64_t n_lanes, void* stream);
+// 4 096 samples: how many find no '\n' within `window` bytes (added to *out)
+void launch_line_probe(const ScanArgs& a, int64_t window, uint32_t* out, void* stream);
 void launch_chunk_scan(const uint64_t* total, uint64_t* base, int64_t n_chunks, void* stream);
 void launch_bytemap(const ScanArgs& a, void* stream);
 void launch_nul_eol(const uint8_t* in, int64_t n, const uint64_t* pos, uint64_t* eol, uint32_t count, void* stream);

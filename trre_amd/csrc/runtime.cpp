@@ -60,6 +60,12 @@ struct Pending {
     const uint64_t* total_at = nullptr;   // general families: where the launch leaves its output size
     bool patched = false;                 // the launch was a record + patch pair (patch_block.hpp), not a count / emit pair
     // the stack guard found, before an in-place launch, a line on which the reference's search runs out of stack: nothing was launched
+    // exact sub-ranges (scan_block.hpp: ScanArgs::exact): what finish() needs to run repair rounds and the emit pass again
+    bool exact = false;
+    trre::ScanArgs xargs{};
+    int64_t x_lane_bytes = 0, x_n_chunks = 0;
+    int x_g16 = 0, x_sym = 0;
+    bool x_slow = false, x_ent_lds = false;
     bool guard_hit = false;
     uint64_t guard_line = 0;              // where that line starts
     uint32_t guard_part = 0;              // bytes of its output the reference had printed (in ScanCtx::d_gout), or ~0u: not available
@@ -106,6 +112,14 @@ struct ScanCtx {
     size_t gobuf_cap = 0;
     uint8_t* d_gout = nullptr;
     size_t gout_cap = 0;
+    // exact sub-ranges: entry / exit states and flags per lane; the long-line probe and what it said about which buffer
+    uint32_t* d_spec = nullptr;
+    int64_t spec_lanes = 0;
+    uint32_t* d_probe = nullptr;
+    const uint8_t* probe_in = nullptr;
+    size_t probe_n = 0;
+    bool long_lines = false;
+    bool exact_off = false;           // finish() runs a scan again the old way (a diverging attempt: the first lane in stream order has to be named)
     uint32_t* d_miss = nullptr;       // lazy tables (lazy_block.hpp): [0] misses listed, then {row, class} pairs
     int bt_tier = 0;                  // the backtracking fallback: which size of stacks and path buffers the next launch uses (kBtTiers)
     bool guard_off = false;           // finish() scans the lines before a line the guard stopped at: not to be guarded again
@@ -496,6 +510,8 @@ void ctx_free(ScanCtx& c) {
     (void)hipFree(c.d_gen_out);
     (void)hipFree(c.d_gflags); (void)hipFree(c.d_gruns); (void)hipFree(c.d_gstack); (void)hipFree(c.d_gobuf); (void)hipFree(c.d_gout);
     (void)hipFree(c.d_miss);
+    (void)hipFree(c.d_spec);
+    (void)hipFree(c.d_probe);
     (void)hipFree(c.d_slots);
     (void)hipFree(c.d_ovf);
     (void)hipFree(c.d_ovf_count);
@@ -1097,10 +1113,49 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
             pd.total_at = cx->d_group_base + n_groups;
             pd.patched = true;
         } else {
+        // Exact sub-ranges (round 5): every lane walks the bytes of its sub-range and nothing else, from the state the transducer is in
+        // there — what makes a line of 400 KB as parallel as 4 000 lines of 100 bytes (rounds 1-4: a lane owns the lines that START in its
+        // sub-range and walks them to their end alone: 5.8-9.0 GB/s on such lines).  TRRE_EXACT=1 always, 0 never; default: when the
+        // probe finds a sample without a line end within four sub-ranges.
+        static const int exact_env = getenv("TRRE_EXACT") ? atoi(getenv("TRRE_EXACT")) : -1;
+        bool use_exact = g16 > 0 && !cx->exact_off && exact_env != 0 && lane_bytes % 64 == 0 && !is_guided_wide(*p, family);
+        if (use_exact && exact_env < 0) {
+            if (cx->probe_in != d_in || cx->probe_n != n) {
+                if (!cx->d_probe) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&cx->d_probe), 16));
+                uint32_t misses = 0;
+                HIP_TRY(hipMemsetAsync(cx->d_probe, 0, 4, stream));
+                launch_line_probe(args, 4 * lane_bytes, cx->d_probe, stream);
+                HIP_TRY(hipMemcpyAsync(&misses, cx->d_probe, 4, hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                cx->probe_in = d_in; cx->probe_n = n;
+                cx->long_lines = misses != 0;
+            }
+            use_exact = cx->long_lines;
+        }
+        if (use_exact) {
+            const int64_t n_lanes = n_chunks * direct_block_threads();
+            if (cx->spec_lanes < n_lanes) {
+                if (cx->d_spec) (void)hipFree(cx->d_spec);
+                cx->d_spec = nullptr; cx->spec_lanes = 0;
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&cx->d_spec), (size_t)n_lanes * 12));
+                cx->spec_lanes = n_lanes;
+            }
+            args.entry_rows = cx->d_spec;
+            args.exit_rows = cx->d_spec + n_lanes;
+            args.spec_flags = cx->d_spec + 2 * n_lanes;
+            args.exact = 1;
+            args.spec_look = (uint32_t)kSpecLook;
+        }
         launch_direct_kernel(1, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, sym_mode, g16_slow);
+        if (use_exact) launch_spec_verify(args, (args.vend + lane_bytes - 1) / lane_bytes, stream);
         launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);
+        if (use_exact) args.exact = 2;
         launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, sym_mode, g16_slow);
         pd.total_at = cx->d_chunk_base + n_chunks;
+        if (use_exact) {
+            pd.exact = true;
+            pd.xargs = args; pd.x_lane_bytes = lane_bytes; pd.x_n_chunks = n_chunks; pd.x_g16 = g16; pd.x_sym = sym_mode; pd.x_slow = g16_slow; pd.x_ent_lds = direct_ent_lds;
+        }
         }
     } else if (family == TRRE_KERNEL_STREAM_LP) {
         launch_stream_kernel(0, ent_lds, args, n_chunks, stream);
@@ -1258,6 +1313,52 @@ int finish_inner(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
             if (out_len) *out_len = 0;
             return fail(TRRE_E_UNSUPPORTED, "error: a sub-range of 1 KiB takes more than 2^32 table steps (TRRE_LAZY_BUDGET): lines of megabytes with an attempt per byte");
         }
+    }
+    if (was.exact && !(status & (kStOverflow | kStDiverge))) {
+        // exact sub-ranges: lanes whose guessed entry state was not the exit state of the lane before them walk again (and on, while
+        // their exit keeps differing from what the next lane assumed), until k_spec_verify finds none; then the sizes are final
+        uint32_t misses = 0;
+        HIP_TRY(hipMemcpyAsync(&misses, cx->d_status + 3, 4, hipMemcpyDeviceToHost, was.stream));
+        HIP_TRY(hipStreamSynchronize(was.stream));
+        if (misses) {
+            ScanArgs xa = was.xargs;
+            const int64_t n_lanes = (xa.vend + was.x_lane_bytes - 1) / was.x_lane_bytes;
+            static const bool spec_trace = getenv("TRRE_SPEC_TRACE") != nullptr;
+            for (int64_t round = 0; misses; ++round) {
+                if (spec_trace) fprintf(stderr, "trre: exact sub-ranges: round %lld, %u lane(s) to repair\n", (long long)round, misses);
+                if (round > was.x_n_chunks + 64) {           // (every round settles at least the first flagged lane's workgroup: cannot happen)
+                    cx->exact_off = true;
+                    const int rc = enqueue(p, st, cx, was.family, was.d_in, was.n, was.d_out, was.cap, was.stream);
+                    cx->exact_off = false;
+                    cx->relaunches += 1;
+                    return rc ? rc : finish_inner(p, st, cx, out_len);
+                }
+                HIP_TRY(hipMemsetAsync(cx->d_status + 3, 0, 4, was.stream));
+                xa.exact = 3;
+                launch_direct_kernel(1, was.x_ent_lds, xa, was.x_lane_bytes, was.x_n_chunks, was.stream, was.x_g16, was.x_sym, was.x_slow);
+                launch_spec_verify(xa, n_lanes, was.stream);
+                HIP_TRY(hipMemcpyAsync(&misses, cx->d_status + 3, 4, hipMemcpyDeviceToHost, was.stream));
+                HIP_TRY(hipStreamSynchronize(was.stream));
+            }
+            launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, was.x_n_chunks, was.stream);
+            xa.exact = 2;
+            launch_direct_kernel(2, was.x_ent_lds, xa, was.x_lane_bytes, was.x_n_chunks, was.stream, was.x_g16, was.x_sym, was.x_slow);
+            HIP_TRY(hipGetLastError());
+            cx->relaunches += 1;
+            HIP_TRY(hipMemcpyAsync(cx->h_status, cx->d_status, 8, hipMemcpyDeviceToHost, was.stream));
+            HIP_TRY(hipMemcpyAsync(cx->h_status + 2, was.total_at, 8, hipMemcpyDeviceToHost, was.stream));
+            HIP_TRY(hipStreamSynchronize(was.stream));
+            status = cx->h_status[0];
+        }
+    }
+    if (was.exact && (status & kStDiverge)) {
+        // an attempt that does not return: the lane bookkeeping of the error path (the first such lane in stream order, the sizes of the lanes
+        // before it) is that of lanes that own lines — the same scan again, the old way
+        cx->exact_off = true;
+        const int rc = enqueue(p, st, cx, was.family, was.d_in, was.n, was.d_out, was.cap, was.stream);
+        cx->exact_off = false;
+        cx->relaunches += 1;
+        return rc ? rc : finish_inner(p, st, cx, out_len);
     }
     auto again = [&](int family) -> int {
         cx->relaunches += 1;

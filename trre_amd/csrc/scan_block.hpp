@@ -64,7 +64,19 @@ struct ScanArgs {
                              // backward pass fills [0, round_up(vend, 64)), the forward pass reads it
     uint32_t* nul_list;      // byte map: [0] = NUL bytes met, from [2] on their offsets in the input (64 bits each, the first
                              // kNulCap of them), or null: what finish() repairs the output from (runtime.cpp)
+    // Exact sub-ranges (round 5; g16_lane): a lane walks the bytes [lo, hi) of its sub-range and nothing else, from the state the
+    // transducer is in at lo — not "the lines that start in the sub-range", whose walk is as long as the longest of them (a line of
+    // 400 KB: one lane walks it all, its neighbours idle).  The state at lo is what the count pass GUESSES from the kSpecLook bytes
+    // before lo (exact when a line starts among them) and k_spec_verify / k_spec_repair make true: lane i's entry must be lane
+    // i - 1's exit.  exact: 0 off; 1 the count pass (guesses its entry, leaves entry / exit / count); 2 the emit pass (entry given);
+    // 3 a repair walk (entry given, leaves exit / count)
+    uint32_t exact;
+    uint32_t spec_look;      // bytes before lo the count pass looks at for its guess (kSpecLook; the tests use less, to provoke wrong guesses)
+    uint32_t* entry_rows;    // [lanes]: row offset of the state at lo | 1 when it is known to be exact
+    uint32_t* exit_rows;     // [lanes]: row offset of the state at hi
+    uint32_t* spec_flags;    // [lanes]: 1 = the lane's entry is not the exit of the lane before it (k_spec_verify); status[3] counts them
 };
+constexpr int64_t kSpecLook = 256;
 constexpr uint32_t kNulCap = 1024;
 
 // ---- phase: stage the tile -------------------------------------------------------------
@@ -1362,6 +1374,34 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
     if (lo >= hi) row = done_row;
     else if (lo < a.vbeg) row = kSkipState * n_cls * 16u;             // filler then '\n' right before the input
     else row = (lo == a.vbeg || a.in_v0[lo - 1] == (uint8_t)'\n') ? 0u : kSkipState * n_cls * 16u;
+    const uint32_t exact = (kMode == 1 || kMode == 2) ? a.exact : 0u;   // (uniform)
+    uint32_t xrow = row;                                             // exact sub-ranges: the state at hi
+    if (exact && lo < hi) {
+        if (exact >= 2u) {
+            row = a.entry_rows[lane] & ~1u;
+        } else if (lo > a.vbeg && row != 0u) {
+            // the state at lo: from the last line start among the kSpecLook bytes before lo (exact), else a guess — the root state
+            // kSpecLook bytes back, walked up to lo (transducers of this kind forget: the guess is right unless the bytes in between
+            // leave a memory of what was before them; k_spec_verify checks it against the lane before)
+            int64_t s0 = lo - (int64_t)a.spec_look > a.vbeg ? lo - (int64_t)a.spec_look : a.vbeg;
+            uint32_t known = s0 == a.vbeg ? 1u : 0u;
+            for (int64_t v = lo - 1; v >= s0; --v)
+                if (a.in_v0[v] == (uint8_t)'\n') { s0 = v + 1; known = 1u; break; }
+            uint32_t r = 0u;
+            for (int64_t v = s0; v < lo; ++v) {
+                uint32_t k;
+                if (kSym == 2) k = ((uint32_t)a.sym_v0[v >> 1] >> (4u * ((uint32_t)v & 1u))) & 15u;
+                else if (kSym == 1) k = a.sym_v0[v];
+                else k = T.cls[a.in_v0[v]];
+                r = *reinterpret_cast<const uint32_t*>(T.g16 + r + (k << 4));
+            }
+            row = r;
+            a.entry_rows[lane] = r | known;
+        } else {
+            a.entry_rows[lane] = row | 1u;                           // the buffer's first lane, or a line starts exactly at lo
+        }
+        xrow = row;
+    }
     Stage S{};
     S.dbg = a.dbg;
     S.wsc = wave_scratch;
@@ -1445,6 +1485,13 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
             for (int j = 0; j < 4; ++j) {
                 const uint64_t g = *reinterpret_cast<const uint64_t*>(T.g16 + row + (kk[j] << 4));       // {next row, meta}
                 const uint32_t meta = (uint32_t)(g >> 32);
+                if (kEnd && exact) {                                     // exact sub-ranges: the bytes from hi on are the next lane's
+                    const bool take = rp + (uint32_t)j < rhi;
+                    c += take ? (meta & 7u) : 0u;
+                    fl |= take ? meta : 0u;
+                    row = take ? (uint32_t)g : row;
+                    continue;
+                }
                 c += meta & 7u;
                 fl |= meta;
                 row = (kEnd && (meta & 32u) && rp + (uint32_t)j + 1u >= rhi) ? done_row : (uint32_t)g;
@@ -1457,6 +1504,10 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
                         for (int j = 0; j < 4; ++j) {
                             const uint64_t g = *reinterpret_cast<const uint64_t*>(T.g16 + row + (kk[j] << 4));
                             const uint32_t meta = (uint32_t)(g >> 32);
+                            if (kEnd && exact) {
+                                if (rp + (uint32_t)j < rhi) { c += (meta & 128u) ? slow_count(row, kk[j]) : (meta & 7u); row = (uint32_t)g; }
+                                continue;
+                            }
                             c += (meta & 128u) ? slow_count(row, kk[j]) : (meta & 7u);
                             row = (kEnd && (meta & 32u) && rp + (uint32_t)j + 1u >= rhi) ? done_row : (uint32_t)g;
                         }
@@ -1553,6 +1604,18 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const U128 g = *reinterpret_cast<const U128*>(T.g16 + row + (kk[j] << 4));
+                if (kEnd && exact) {                                     // exact sub-ranges: the bytes from hi on are the next lane's
+                    const bool take = rp + (uint32_t)j < rhi;
+                    stage_append_bits(S, take ? perm_b32(w >> (8 * j), g.z, g.w) : 0u, take ? g.y >> 24 : 0u);
+                    seen |= take ? g.y : 0u;
+                    if (kHasSlow) {
+                        if (TRRE_WAVE_ANY(take && (g.y & 128u))) {
+                            if (take && (g.y & 128u)) slow_emit(row, kk[j], (uint8_t)(w >> (8 * j)));
+                        }
+                    }
+                    row = take ? g.x : row;
+                    continue;
+                }
                 stage_append_bits(S, perm_b32(w >> (8 * j), g.z, g.w), g.y >> 24);      // ([31:24] of the entry: 8 x the bytes it emits)
                 seen |= g.y;
                 if (kHasSlow) {
@@ -1764,6 +1827,9 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
                 block(std::true_type{}, b, sym_of(q), rp + 16u * (uint32_t)q);
             }
         }
+        if (exact) {
+            if (rp + 64u >= rhi && row != done_row) { xrow = row; row = done_row; }     // exact sub-ranges: the lane ends at hi
+        }
         if (kMode == 3) {
             // the piece is complete: its slot (if it is this lane's to record), and the lane ends here if its last line has ended
             rec_commit(a, *pa, R, v, walked, (seen & 32u) != 0u, status);
@@ -1792,6 +1858,7 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
         hdr[2] = b_rel < rhi ? e_rel : b_rel;          // (no line starts in the sub-range: the lane has nothing to copy)
         hdr[3] = 0;
     }
+    if (kMode == 1 && exact && lo < hi) a.exit_rows[lane] = xrow;
     if (kMode == 2) stage_flush<true>(S);
     if (kMode == 2 && a.lp_emit && ((seen & 8u) || (seen2 & 256u))) status |= kStNul;
     if ((kMode == 1 || kMode == 3 || kMode == 4) && ((seen | seen2) & 64u)) status |= kStOverflow;            // bounded fold: the launch is void

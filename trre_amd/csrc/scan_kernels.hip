@@ -486,6 +486,33 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_g16(ScanArgs a, int64
     uint64_t base = 0;
     // (a bounded fold that overflowed in the count pass: the launch is void, finish() runs the buffer on another family)
     if (kMode == 2 && !a.lp_emit && (*a.status & kStOverflow)) return;
+    // (exact sub-ranges: some lane's guessed entry state was wrong — finish() repairs the lanes, then this pass runs again)
+    if (kMode == 2 && a.exact == 2u && a.status[3] != 0u) return;
+    if (kMode == 1 && a.exact == 3u) {
+        // A repair round (exact sub-ranges): a flagged lane walks again from the exit state of the lane before it, and on into the
+        // lanes behind it for as long as its exit state is not what they had assumed (within this workgroup's lanes: the next round
+        // sees to the rest).  Everything it leaves is open to the next k_spec_verify.
+        const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
+        const int64_t block_end = ((int64_t)blockIdx.x + 1) * kDirectThreads < n_lanes ? ((int64_t)blockIdx.x + 1) * kDirectThreads : n_lanes;
+        if (lane > 0 && lane < n_lanes && a.spec_flags[lane]) {
+            uint32_t state = a.exit_rows[lane - 1];
+            for (int64_t j = lane;;) {
+                a.entry_rows[j] = state;
+                DirectLane Lj;
+                g16_lane<1, kSym, kHasSlow>(a, T, h.n_cls, j, lane_bytes, ring, 0, Lj, st, nullptr, &pa, nullptr);
+                if (Lj.count > 0xffffffffull) { st |= kStCapacity; Lj.count = 0xffffffffull; }
+                a.lane_counts[j] = (uint32_t)Lj.count;
+                if (kSym != 0 && (st & kStDiverge)) atomicMax(a.status + 1, 0xffffffffu - (uint32_t)j);
+                state = a.exit_rows[j];
+                ++j;
+                if (j >= block_end || a.spec_flags[j]) break;
+                const uint32_t e = a.entry_rows[j];
+                if ((e & 1u) || (e & ~1u) == state) break;
+            }
+        }
+        __syncthreads();
+        L.count = lane < n_lanes ? a.lane_counts[lane] : 0u;
+    } else
     if (kMode == 2 && !a.lp_emit) {
         uint32_t* wpart = reinterpret_cast<uint32_t*>(tail);
         const uint32_t mine = a.lane_counts[lane];
@@ -503,8 +530,10 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_g16(ScanArgs a, int64
     uint32_t* wsc = reinterpret_cast<uint32_t*>(tail + 64) + (threadIdx.x / kWave) * (kWaveScratchBytes / 4);
     // (the mark pass's events and lane headers travel in `pa`: slots = the event rows, ovf = the headers, ovf_cap = events per row)
     const FbCopyArgs ca{pa.slots, pa.ovf, pa.ovf_cap};
-    g16_lane<kMode, kSym, kHasSlow>(a, T, h.n_cls, lane, lane_bytes, ring, base, L, st, kMode == 2 ? wsc : nullptr, &pa, &ca);
-    if (kMode == 1 && kSym != 0 && (st & kStDiverge)) atomicMax(a.status + 1, 0xffffffffu - (uint32_t)lane);     // (see k_stream_direct)
+    if (!(kMode == 1 && a.exact == 3u)) {
+        g16_lane<kMode, kSym, kHasSlow>(a, T, h.n_cls, lane, lane_bytes, ring, base, L, st, kMode == 2 ? wsc : nullptr, &pa, &ca);
+        if (kMode == 1 && kSym != 0 && (st & kStDiverge)) atomicMax(a.status + 1, 0xffffffffu - (uint32_t)lane);     // (see k_stream_direct)
+    }
     if (kMode == 1 || kMode == 4) {
         uint64_t* part = reinterpret_cast<uint64_t*>(tail);
         if (L.count > 0xffffffffull) { st |= kStCapacity; L.count = 0xffffffffull; }
@@ -1107,6 +1136,36 @@ __global__ __launch_bounds__(kGenThreads) void k_lazy(ScanArgs a, LazyArgs la, i
     if (st && (threadIdx.x & (kWave - 1)) == 0) atomicOr(a.status, st);
 }
 
+// Exact sub-ranges (scan_block.hpp: ScanArgs::exact): lane i's entry state must be the exit state of lane i - 1 — an entry that was
+// derived from a line start inside the look-back window is right by construction (bit 0), a guessed one is checked here.
+__global__ __launch_bounds__(256) void k_spec_verify(ScanArgs a, int64_t n_lanes) {
+    const int64_t lane = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool bad = false;
+    if (lane < n_lanes) {
+        const uint32_t e = a.entry_rows[lane];
+        bad = lane > 0 && !(e & 1u) && (e & ~1u) != a.exit_rows[lane - 1];
+        a.spec_flags[lane] = bad ? 1u : 0u;
+    }
+    const uint32_t n = (uint32_t)__popcll(__ballot(bad));
+    if (n && (threadIdx.x & (kWave - 1)) == 0) atomicAdd(a.status + 3, n);
+}
+// Are there long lines?  4 096 samples spread over the input: a thread looks for a '\n' in the `window` bytes behind its sample
+// point; out[0] counts the samples that find none.
+__global__ __launch_bounds__(256) void k_line_probe(ScanArgs a, int64_t window, uint32_t* out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, n_samples = (int64_t)gridDim.x * 256;
+    const int64_t n = a.vend - a.vbeg;
+    int64_t v = (a.vbeg + (int64_t)(((__int128)n * (2 * t + 1)) / (2 * n_samples))) & ~(int64_t)15;
+    const int64_t end = v + window < a.vend ? v + window : a.vend;
+    bool found = v + window > a.vend;                 // (a window that runs into the end of the input says nothing)
+    for (; v < end && !found; v += 16) {
+        const U128 q = direct_load(a, v);
+        const uint32_t x0 = q.x ^ 0x0a0a0a0au, x1 = q.y ^ 0x0a0a0a0au, x2 = q.z ^ 0x0a0a0a0au, x3 = q.w ^ 0x0a0a0a0au;
+        found = (((x0 - 0x01010101u) & ~x0) | ((x1 - 0x01010101u) & ~x1) | ((x2 - 0x01010101u) & ~x2) | ((x3 - 0x01010101u) & ~x3)) & 0x80808080u;
+    }
+    const uint32_t miss = (uint32_t)__popcll(__ballot(!found));
+    if (miss && (threadIdx.x & (kWave - 1)) == 0) atomicAdd(out, miss);
+}
+
 // The stack guard (guard_block.hpp): windows without a '\n' (a bit per window, a wave per 64 of them), then the reference's
 // search itself on the lines that cover them, a thread per line from a pool of stacks.
 __global__ __launch_bounds__(256) void k_guard_probe(ScanArgs a, int64_t window, int64_t n_windows, uint64_t* flags) {
@@ -1620,6 +1679,12 @@ void launch_lazy(int which, const ScanArgs& a, const LazyArgs& la, int64_t lane_
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (which == 1) hipLaunchKernelGGL(k_lazy<1>, dim3((unsigned)n_chunks), dim3(kGenThreads), 0, s, a, la, lane_bytes);
     else hipLaunchKernelGGL(k_lazy<2>, dim3((unsigned)n_chunks), dim3(kGenThreads), 0, s, a, la, lane_bytes);
+}
+void launch_spec_verify(const ScanArgs& a, int64_t n_lanes, void* stream) {
+    hipLaunchKernelGGL(k_spec_verify, dim3((unsigned)((n_lanes + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a, n_lanes);
+}
+void launch_line_probe(const ScanArgs& a, int64_t window, uint32_t* out, void* stream) {
+    hipLaunchKernelGGL(k_line_probe, dim3(16), dim3(256), 0, static_cast<hipStream_t>(stream), a, window, out);
 }
 void launch_guard_probe(const ScanArgs& a, int64_t window, int64_t n_windows, uint64_t* flags, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
