@@ -230,6 +230,36 @@ void run_rev_sweep(const ScanArgs& a, int64_t lane_bytes, bool packed) {
         else rev_sweep_lane<0, false>(a, T, lane, lane_bytes, nullptr, max_look);
     }
 }
+// The backward pass with exact sub-ranges (round 5), as runtime.cpp drives it: every lane from a guessed (or known) state at the end of its
+// sub-range, k_rev_verify's rule, repair rounds until every guess is what the lane to the right found.  Returns the repair rounds.
+int run_rev_sweep_exact(ScanArgs a, int64_t lane_bytes, bool packed, uint32_t look) {
+    const RevBlobHeader& h = *reinterpret_cast<const RevBlobHeader*>(a.rblob);
+    const RevView T{a.rblob + h.off_wide};
+    const int64_t vtop = packed ? (a.vend + 127) & ~(int64_t)127 : (a.vend + 63) & ~(int64_t)63;
+    const int64_t n_lanes = (vtop + lane_bytes - 1) / lane_bytes;
+    std::vector<uint32_t> guess(n_lanes, 0xEEEEEEEu), flags(n_lanes, 0);
+    a.rev_guess = guess.data(); a.rev_flags = flags.data();
+    a.exact = 1; a.spec_look = look;
+    for (int64_t lane = 0; lane < n_lanes; ++lane) {
+        if (packed) rev_sweep_lane<0, true>(a, T, lane, lane_bytes, nullptr);
+        else rev_sweep_lane<0, false>(a, T, lane, lane_bytes, nullptr);
+    }
+    int rounds = 0;
+    for (;;) {
+        int64_t bad = 0;
+        for (int64_t lane = 0; lane < n_lanes; ++lane) {
+            flags[lane] = lane + 1 < n_lanes && (packed ? rev_guess_wrong<true>(a, lane, lane_bytes) : rev_guess_wrong<false>(a, lane, lane_bytes));
+            bad += flags[lane];
+        }
+        if (!bad) return rounds;
+        if (++rounds > n_lanes + 8) return -1;
+        for (int64_t lane = 0; lane < n_lanes; ++lane) {
+            if (!flags[lane]) continue;
+            if (packed) rev_repair_lane<true>(a, T, lane, lane_bytes);
+            else rev_repair_lane<false>(a, T, lane, lane_bytes);
+        }
+    }
+}
 // g16: walk the 16-byte entries (when the tables have them), like k_stream_g16
 template <int kSym = 0>
 void run_direct_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64_t& total_out, bool g16) {
@@ -846,7 +876,13 @@ int shim_scan_guided(const uint8_t* rblob, const uint8_t* gblob, int family, int
         std::memcpy(out, oa, (size_t)total);
         return 0;
     }
-    run_rev_sweep(a, lane_bytes, packed);
+    int rev_rounds = 0;
+    if (family == 17 || family == 18) {
+        rev_rounds = run_rev_sweep_exact(a, lane_bytes, packed, family == 18 ? 4u : (uint32_t)kSpecLook);
+        if (rev_rounds < 0) { *status_out = 1u << 29; *m = 0; return 0; }
+    } else {
+        run_rev_sweep(a, lane_bytes, packed);
+    }
     if (family == 10 || family == 13 || family == 14) {
         if (family == 13) run_direct_lp<1>(a, lane_bytes, status);                  // the LDS-ring walker (A/B variant)
         else if (packed) run_direct_lp_emit<2>(a, lane_bytes, status, true);
@@ -865,7 +901,7 @@ int shim_scan_guided(const uint8_t* rblob, const uint8_t* gblob, int family, int
         int rounds = 0;
         if (packed) run_direct_gen_exact<2>(a, lane_bytes, status, total, family == 18 ? 4u : (uint32_t)kSpecLook, geo == 0 ? 256 : 3, rounds);
         else run_direct_gen_exact<1>(a, lane_bytes, status, total, family == 18 ? 4u : (uint32_t)kSpecLook, geo == 0 ? 256 : 3, rounds);
-        g_last_rounds = rounds;
+        g_last_rounds = rounds + rev_rounds;
     }
     else if (family == 15) {
         if (!has_g16 || al != 0) return -5;

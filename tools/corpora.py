@@ -82,9 +82,24 @@ def dictionary_soup(n, seed, device, keys, key_fraction=0.3):
     return token_soup(n, seed, device, vocab, weights)
 
 
+def long_lines(n, seed, device, line_len):
+    """cfg 2's text with most of its line ends turned into spaces: one line end survives per `line_len` bytes (JSON lines, minified files)"""
+    data = printable_lines(n, seed, device)
+    idx = (data == 10).nonzero().flatten()
+    w = idx // line_len
+    drop = torch.ones_like(idx, dtype=torch.bool)
+    drop[1:] = w[1:] == w[:-1]
+    drop[0] = False
+    data[idx[drop]] = 32
+    data[n - 1] = 10
+    return data
+
+
 def by_name(name, n, seed, device):
     if name == "printable":
         return printable_lines(n, seed, device)
+    if name.startswith("long"):
+        return long_lines(n, seed, device, int(name[4:]))
     if name == "catdog":
         return cat_dog_soup(n, seed, device)
     if name.startswith("dict"):

@@ -68,6 +68,10 @@ void launch_lazy(int which, const ScanArgs& a, const LazyArgs& la, int64_t lane_
 // exact sub-ranges (scan_block.hpp: ScanArgs::exact): flags the lanes whose guessed entry state is not the exit state of the lane before
 // them (a.spec_flags, a.status[3] counts them); the repair round is launch_direct_kernel(1, ...) with a.exact == 3
 void launch_spec_verify(const ScanArgs& a, int64_t n_lanes, void* stream);
+// ... and of the backward pass: a.rev_guess against the symbols the lanes to the right left (a.rev_flags, a.status[2] counts the wrong ones); the
+// flagged lanes sweep again (and on to the left while their result is not what was assumed there)
+void launch_rev_verify(const ScanArgs& a, int64_t lane_bytes, void* stream, bool packed);
+void launch_rev_repair(const ScanArgs& a, int64_t lane_bytes, void* stream, bool packed);
 // 4 096 samples: how many find no '\n' within `window` bytes (added to *out)
 void launch_line_probe(const ScanArgs& a, int64_t window, uint32_t* out, void* stream);
 void launch_chunk_scan(const uint64_t* total, uint64_t* base, int64_t n_chunks, void* stream);

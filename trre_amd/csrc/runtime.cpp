@@ -49,7 +49,8 @@ int fail(int code, const std::string& msg) {
 
 struct Pending {
     bool active = false;
-    int family = 0;
+    int family = 0;         // what runs
+    int asked = 0;          // ... and what the caller's family choice was (a length-preserving family on an input with long lines runs as its general sibling)
     const uint8_t* d_in = nullptr;
     uint8_t* d_out = nullptr;
     size_t n = 0, cap = 0;
@@ -63,7 +64,7 @@ struct Pending {
     // exact sub-ranges (scan_block.hpp: ScanArgs::exact): what finish() needs to run repair rounds and the emit pass again
     bool exact = false;
     trre::ScanArgs xargs{};
-    int64_t x_lane_bytes = 0, x_n_chunks = 0;
+    int64_t x_lane_bytes = 0, x_n_chunks = 0, x_rev_lane_bytes = 0;
     int x_g16 = 0, x_sym = 0;
     bool x_slow = false, x_ent_lds = false;
     bool guard_hit = false;
@@ -834,7 +835,7 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
     // timing events bracket the whole batch and finish() speaks for the last launch — so every launch of
     // a batch must be the same scan (benchmark loops); anything else has to be finished first.
     const bool batch = pd.active && pd.launched;
-    if (pd.active && (pd.family != family || pd.d_in != d_in || pd.d_out != d_out || pd.n != n || pd.cap != cap || pd.stream != stream))
+    if (pd.active && (pd.asked != family || pd.d_in != d_in || pd.d_out != d_out || pd.n != n || pd.cap != cap || pd.stream != stream))
         return fail(TRRE_E_ARG, "error: a different scan is still in flight on this device: call trre_scan_finish first");
     const int batch_count = batch ? pd.count : 0;
     // an in-place scan destroys what the stack guard would look at: it looks first (the first launch of a batch only — the rest
@@ -846,7 +847,7 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
         if (hit.hit) {
             pd = Pending();
             pd.active = true;
-            pd.family = family;
+            pd.family = family; pd.asked = family;
             pd.d_in = d_in; pd.d_out = d_out; pd.n = n; pd.cap = cap; pd.stream = stream;
             pd.guard_hit = true; pd.guard_line = hit.line_start; pd.guard_part = hit.part;
             return TRRE_OK;
@@ -855,10 +856,38 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
     pd = Pending();
     pd.active = true;
     pd.count = batch_count;
-    pd.family = family;
+    pd.family = family; pd.asked = family;
     pd.d_in = d_in; pd.d_out = d_out; pd.n = n; pd.cap = cap; pd.stream = stream;
     if (n == 0) return TRRE_OK;
     int rc;
+    // Long lines (round 5): is there a sample point without a line end within 32 KiB?  Asked once per buffer (a tiny kernel and a wait), for the
+    // families that have the exact sub-ranges to answer with; a length-preserving family then runs as its general sibling (count, exclusive sum,
+    // emit: the exact sub-ranges live there), unless the scan is in place.
+    static const int exact_env0 = getenv("TRRE_EXACT") ? atoi(getenv("TRRE_EXACT")) : -1;
+    {
+        const bool small_tables = (is_stream(family) && p->stt.g16_ok) || (is_guided(family) && p->gt.fwd.g16_ok && !p->gt.wide);
+        if (small_tables && !cx->exact_off && exact_env0 != 0) {
+            if (cx->probe_in != d_in || cx->probe_n != n) {
+                const int64_t a0 = (int64_t)(reinterpret_cast<uintptr_t>(d_in) & 15u);
+                ScanArgs pa{};
+                pa.in_v0 = d_in - a0; pa.vbeg = a0; pa.vend = a0 + (int64_t)n;
+                if (!cx->d_probe) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&cx->d_probe), 16));
+                uint32_t misses = 0;
+                HIP_TRY(hipMemsetAsync(cx->d_probe, 0, 4, stream));
+                launch_line_probe(pa, 32768, cx->d_probe, stream);
+                HIP_TRY(hipMemcpyAsync(&misses, cx->d_probe, 4, hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                cx->probe_in = d_in; cx->probe_n = n;
+                cx->long_lines = misses != 0;
+            }
+            const bool longl = exact_env0 == 2 || cx->long_lines;       // (TRRE_EXACT=1: exact sub-ranges in the general families whatever the lines; =2: everywhere)
+            if (longl && d_in != d_out && cap >= n) {
+                if (family == TRRE_KERNEL_STREAM_LP) family = TRRE_KERNEL_STREAM_GEN;
+                else if (family == TRRE_KERNEL_GUIDED_LP) family = TRRE_KERNEL_GUIDED_GEN;
+                pd.family = family;
+            }
+        }
+    }
 
     const int64_t a = (int64_t)(reinterpret_cast<uintptr_t>(d_in) & 15u);
     ScanArgs args{};
@@ -1054,7 +1083,38 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
         }
     } else if (direct) {
         const int g16 = stt.g16_ok && !no_g16_env ? (int)(align_up(stt.g16.size() * 4, 16) + stt.p32.size() * 4) : 0;   // LDS room: 16-byte + pair forms
-        if (is_guided(family)) launch_rev_sweep(args, (int)p->gt.n_rev * 256, rev_lane_bytes, stream, sym_mode == 2);
+        // Exact sub-ranges (round 5): every lane walks the bytes of its sub-range and nothing else, from the state the transducer is in
+        // there — what makes a line of 400 KB as parallel as 4 000 lines of 100 bytes (rounds 1-4: a lane owns the lines that START in its
+        // sub-range and walks them to their end alone, and the backward pass of the guided families has ONE thread carry the state through
+        // a long line: 5.8-9.0 GB/s on such lines).  TRRE_EXACT=1 always, 0 never; default: when the probe finds a sample without a line
+        // end within four sub-ranges.
+        static const int exact_env = getenv("TRRE_EXACT") ? atoi(getenv("TRRE_EXACT")) : -1;
+        static const bool patch_env = getenv("TRRE_PATCH") != nullptr, g16_splice_env = getenv("TRRE_G16_SPLICE") != nullptr;
+        bool use_exact = g16 > 0 && !cx->exact_off && exact_env != 0 && !patch_env && !g16_splice_env && lane_bytes % 128 == 0 && rev_lane_bytes % 128 == 0 &&
+                         !is_guided_wide(*p, family);
+        if (use_exact && exact_env < 0) use_exact = cx->long_lines && cx->probe_in == d_in && cx->probe_n == n;      // (asked at the top of enqueue)
+        const int64_t rev_lanes = ((((args.vend + 127) & ~(int64_t)127) + rev_lane_bytes - 1) / rev_lane_bytes + 255) / 256 * 256;
+        if (use_exact) {
+            const int64_t n_lanes = n_chunks * direct_block_threads();
+            const int64_t want = 3 * n_lanes + (is_guided(family) ? 2 * rev_lanes : 0);
+            if (cx->spec_lanes < want) {
+                if (cx->d_spec) (void)hipFree(cx->d_spec);
+                cx->d_spec = nullptr; cx->spec_lanes = 0;
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&cx->d_spec), (size_t)want * 4));
+                cx->spec_lanes = want;
+            }
+            args.entry_rows = cx->d_spec;
+            args.exit_rows = cx->d_spec + n_lanes;
+            args.spec_flags = cx->d_spec + 2 * n_lanes;
+            args.rev_guess = cx->d_spec + 3 * n_lanes;
+            args.rev_flags = cx->d_spec + 3 * n_lanes + rev_lanes;
+            args.exact = 1;
+            args.spec_look = (uint32_t)kSpecLook;
+        }
+        if (is_guided(family)) {
+            launch_rev_sweep(args, (int)p->gt.n_rev * 256, rev_lane_bytes, stream, sym_mode == 2);
+            if (use_exact) launch_rev_verify(args, rev_lane_bytes, stream, sym_mode == 2);
+        }
         // TRRE_PATCH=1 (experimental, off by default): ONE walk that lists the edits per 64-byte piece, then a patch pass that
         // copies the input around them (patch_block.hpp) — instead of a count walk and an emit walk that appends byte by byte.
         // Correct (parity-tested on the host shim and on the GPU) but slower as it stands: 'a:xyz' at 1 GiB record 0.78 ms +
@@ -1113,39 +1173,6 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
             pd.total_at = cx->d_group_base + n_groups;
             pd.patched = true;
         } else {
-        // Exact sub-ranges (round 5): every lane walks the bytes of its sub-range and nothing else, from the state the transducer is in
-        // there — what makes a line of 400 KB as parallel as 4 000 lines of 100 bytes (rounds 1-4: a lane owns the lines that START in its
-        // sub-range and walks them to their end alone: 5.8-9.0 GB/s on such lines).  TRRE_EXACT=1 always, 0 never; default: when the
-        // probe finds a sample without a line end within four sub-ranges.
-        static const int exact_env = getenv("TRRE_EXACT") ? atoi(getenv("TRRE_EXACT")) : -1;
-        bool use_exact = g16 > 0 && !cx->exact_off && exact_env != 0 && lane_bytes % 64 == 0 && !is_guided_wide(*p, family);
-        if (use_exact && exact_env < 0) {
-            if (cx->probe_in != d_in || cx->probe_n != n) {
-                if (!cx->d_probe) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&cx->d_probe), 16));
-                uint32_t misses = 0;
-                HIP_TRY(hipMemsetAsync(cx->d_probe, 0, 4, stream));
-                launch_line_probe(args, 4 * lane_bytes, cx->d_probe, stream);
-                HIP_TRY(hipMemcpyAsync(&misses, cx->d_probe, 4, hipMemcpyDeviceToHost, stream));
-                HIP_TRY(hipStreamSynchronize(stream));
-                cx->probe_in = d_in; cx->probe_n = n;
-                cx->long_lines = misses != 0;
-            }
-            use_exact = cx->long_lines;
-        }
-        if (use_exact) {
-            const int64_t n_lanes = n_chunks * direct_block_threads();
-            if (cx->spec_lanes < n_lanes) {
-                if (cx->d_spec) (void)hipFree(cx->d_spec);
-                cx->d_spec = nullptr; cx->spec_lanes = 0;
-                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&cx->d_spec), (size_t)n_lanes * 12));
-                cx->spec_lanes = n_lanes;
-            }
-            args.entry_rows = cx->d_spec;
-            args.exit_rows = cx->d_spec + n_lanes;
-            args.spec_flags = cx->d_spec + 2 * n_lanes;
-            args.exact = 1;
-            args.spec_look = (uint32_t)kSpecLook;
-        }
         launch_direct_kernel(1, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, sym_mode, g16_slow);
         if (use_exact) launch_spec_verify(args, (args.vend + lane_bytes - 1) / lane_bytes, stream);
         launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);
@@ -1155,6 +1182,7 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
         if (use_exact) {
             pd.exact = true;
             pd.xargs = args; pd.x_lane_bytes = lane_bytes; pd.x_n_chunks = n_chunks; pd.x_g16 = g16; pd.x_sym = sym_mode; pd.x_slow = g16_slow; pd.x_ent_lds = direct_ent_lds;
+            pd.x_rev_lane_bytes = is_guided(family) ? rev_lane_bytes : 0;
         }
         }
     } else if (family == TRRE_KERNEL_STREAM_LP) {
@@ -1317,10 +1345,40 @@ int finish_inner(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
     if (was.exact && !(status & (kStOverflow | kStDiverge))) {
         // exact sub-ranges: lanes whose guessed entry state was not the exit state of the lane before them walk again (and on, while
         // their exit keeps differing from what the next lane assumed), until k_spec_verify finds none; then the sizes are final
-        uint32_t misses = 0;
-        HIP_TRY(hipMemcpyAsync(&misses, cx->d_status + 3, 4, hipMemcpyDeviceToHost, was.stream));
+        uint32_t both[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(both, cx->d_status + 2, 8, hipMemcpyDeviceToHost, was.stream));
         HIP_TRY(hipStreamSynchronize(was.stream));
-        if (misses) {
+        uint32_t misses = both[1];
+        static const bool spec_trace0 = getenv("TRRE_SPEC_TRACE") != nullptr;
+        if (both[0] && was.x_rev_lane_bytes) {
+            // the backward pass guessed wrong somewhere: its flagged lanes sweep again (and on to the left while what they arrive with is not what
+            // was assumed there) until every guess is what the lane to the right found; then the forward passes run — they had left at once
+            ScanArgs xa = was.xargs;
+            uint32_t rev_misses = both[0];
+            for (int64_t round = 0; rev_misses; ++round) {
+                if (spec_trace0) fprintf(stderr, "trre: exact sub-ranges, backward pass: round %lld, %u lane(s) to repair\n", (long long)round, rev_misses);
+                HIP_TRY(hipMemsetAsync(cx->d_status + 2, 0, 4, was.stream));
+                launch_rev_repair(xa, was.x_rev_lane_bytes, was.stream, was.x_sym == 2);
+                launch_rev_verify(xa, was.x_rev_lane_bytes, was.stream, was.x_sym == 2);
+                HIP_TRY(hipMemcpyAsync(&rev_misses, cx->d_status + 2, 4, hipMemcpyDeviceToHost, was.stream));
+                HIP_TRY(hipStreamSynchronize(was.stream));
+            }
+            HIP_TRY(hipMemsetAsync(cx->d_status, 0, 16, was.stream));
+            xa.exact = 1;
+            launch_direct_kernel(1, was.x_ent_lds, xa, was.x_lane_bytes, was.x_n_chunks, was.stream, was.x_g16, was.x_sym, was.x_slow);
+            launch_spec_verify(xa, (xa.vend + was.x_lane_bytes - 1) / was.x_lane_bytes, was.stream);
+            launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, was.x_n_chunks, was.stream);
+            xa.exact = 2;
+            launch_direct_kernel(2, was.x_ent_lds, xa, was.x_lane_bytes, was.x_n_chunks, was.stream, was.x_g16, was.x_sym, was.x_slow);
+            HIP_TRY(hipGetLastError());
+            cx->relaunches += 1;
+            HIP_TRY(hipMemcpyAsync(cx->h_status, cx->d_status, 8, hipMemcpyDeviceToHost, was.stream));
+            HIP_TRY(hipMemcpyAsync(cx->h_status + 2, was.total_at, 8, hipMemcpyDeviceToHost, was.stream));
+            HIP_TRY(hipMemcpyAsync(&misses, cx->d_status + 3, 4, hipMemcpyDeviceToHost, was.stream));
+            HIP_TRY(hipStreamSynchronize(was.stream));
+            status = cx->h_status[0];
+        }
+        if (misses && !(status & (kStOverflow | kStDiverge))) {
             ScanArgs xa = was.xargs;
             const int64_t n_lanes = (xa.vend + was.x_lane_bytes - 1) / was.x_lane_bytes;
             static const bool spec_trace = getenv("TRRE_SPEC_TRACE") != nullptr;

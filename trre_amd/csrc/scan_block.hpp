@@ -75,6 +75,11 @@ struct ScanArgs {
     uint32_t* entry_rows;    // [lanes]: row offset of the state at lo | 1 when it is known to be exact
     uint32_t* exit_rows;     // [lanes]: row offset of the state at hi
     uint32_t* spec_flags;    // [lanes]: 1 = the lane's entry is not the exit of the lane before it (k_spec_verify); status[3] counts them
+    // ... and for the backward pass of the guided families (rev_sweep_lane): a lane starts from the state at the end of its sub-range — exact
+    // when a line ends within spec_look bytes behind it, else guessed (as if the line ended spec_look bytes on) and checked against the symbol
+    // the lane to its right leaves at that position (k_rev_verify / k_rev_repair; status[2] counts the wrong guesses)
+    uint32_t* rev_guess;     // [backward lanes]: the state the lane started from | 1 << 31 when it is known to be exact
+    uint32_t* rev_flags;     // [backward lanes]
 };
 constexpr int64_t kSpecLook = 256;
 constexpr uint32_t kNulCap = 1024;
@@ -2899,6 +2904,21 @@ TRRE_HD void rev_sweep_lane(const ScanArgs& a, const RevView& T, int64_t lane, i
     const bool empty = lo >= hi;
     uint32_t r = 1;            // kSymEol, the state right of a '\n': nothing alive (every byte from vend - 1 on reads as '\n')
     int role = 0;              // 0 an ordinary lane, 1 the walker of a long line, 2 inside a long line: the walker does its bytes
+    if (a.exact) {
+        // exact sub-ranges (round 5): no walkers — every lane does its own bytes, from the state at hi: exact when the line that crosses hi
+        // ends within spec_look bytes, else the state it would have if the line ended there (k_rev_verify checks it against the symbol
+        // the lane to the right leaves at hi)
+        uint32_t known = 1u;
+        if (!empty && hi < a.vend - 1 && rev_byte_at(a, hi - 1) != (uint32_t)'\n') {
+            int64_t e = hi + (int64_t)a.spec_look;
+            if (e >= a.vend - 1) e = a.vend - 1;                      // (the last byte of the input ends its record: exact)
+            else known = 0u;
+            for (int64_t v = hi; v < e; ++v)
+                if (a.in_v0[v] == (uint8_t)'\n') { e = v; known = 1u; break; }
+            for (int64_t v = e - 1; v >= hi; --v) r = T.tab[(r << 8) | a.in_v0[v]];
+        }
+        if (!empty) a.rev_guess[lane] = r | known << 31;
+    } else
     if (!empty && hi < a.vend - 1 && rev_byte_at(a, hi - 1) != (uint32_t)'\n') {      // (right of a '\n' the state is known)
         // the line that crosses hi: find its end e (first '\n' at or after hi), then run e - 1 .. hi
         int64_t e = hi;        // hi is a multiple of 16
@@ -3045,6 +3065,32 @@ TRRE_HD void rev_sweep_lane(const ScanArgs& a, const RevView& T, int64_t lane, i
             --k;
             rev_pieces_solo<kNib>(a, T, k * lane_bytes, (k + 1) * lane_bytes, r);
         }
+    }
+}
+
+// exact sub-ranges, the backward pass: the symbol at position v as the sweep left it
+template <bool kNib>
+TRRE_HD uint32_t rev_symbol_at(const ScanArgs& a, int64_t v) {
+    return kNib ? ((uint32_t)a.sym_v0[v >> 1] >> (4u * ((uint32_t)v & 1u))) & 15u : a.sym_v0[v];
+}
+// ... is lane's guess what the lane to its right found?
+template <bool kNib>
+TRRE_HD bool rev_guess_wrong(const ScanArgs& a, int64_t lane, int64_t lane_bytes) {
+    const uint32_t g = a.rev_guess[lane];
+    if (g >> 31) return false;
+    return (g & 0x7fffffffu) != rev_symbol_at<kNib>(a, (lane + 1) * lane_bytes);
+}
+// ... a flagged lane sweeps its sub-range again from the symbol at its end, and on through the lanes to its left for as long as what it
+// arrives with is not what they had assumed (T: the table in global memory — a handful of lanes)
+template <bool kNib>
+TRRE_HD void rev_repair_lane(const ScanArgs& a, const RevView& T, int64_t lane, int64_t lane_bytes) {
+    uint32_t r = rev_symbol_at<kNib>(a, (lane + 1) * lane_bytes);
+    for (int64_t k = lane;; --k) {
+        a.rev_guess[k] = r;                                            // (open to the next verification)
+        rev_pieces_solo<kNib>(a, T, k * lane_bytes, (k + 1) * lane_bytes, r);
+        if (k == 0 || a.rev_flags[k - 1]) break;
+        const uint32_t g = a.rev_guess[k - 1];
+        if ((g >> 31) || (g & 0x7fffffffu) == r) break;
     }
 }
 

@@ -486,8 +486,10 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_g16(ScanArgs a, int64
     uint64_t base = 0;
     // (a bounded fold that overflowed in the count pass: the launch is void, finish() runs the buffer on another family)
     if (kMode == 2 && !a.lp_emit && (*a.status & kStOverflow)) return;
-    // (exact sub-ranges: some lane's guessed entry state was wrong — finish() repairs the lanes, then this pass runs again)
+    // (exact sub-ranges: some lane's guessed entry state was wrong — finish() repairs the lanes, then this pass runs again; with a wrong
+    // guess in the backward pass the symbols are not final: both forward passes wait for finish())
     if (kMode == 2 && a.exact == 2u && a.status[3] != 0u) return;
+    if (kSym != 0 && a.exact != 0u && a.exact != 3u && a.status[2] != 0u) return;
     if (kMode == 1 && a.exact == 3u) {
         // A repair round (exact sub-ranges): a flagged lane walks again from the exit state of the lane before it, and on into the
         // lanes behind it for as long as its exit state is not what they had assumed (within this workgroup's lanes: the next round
@@ -1531,6 +1533,39 @@ __global__ __launch_bounds__(kRevThreads) void k_rev_sweep(ScanArgs a, int64_t l
     // (packed symbols: a 4 KiB tile per wave behind the table, for the unit stores of interior waves)
     uint8_t* tile = (kNib && tile_bytes) ? smem + (((int)h.n_rev * 256 + 15) & ~15) + (threadIdx.x / kWave) * 4096 : nullptr;
     rev_sweep_lane<kDbg, kNib>(a, T, (int64_t)blockIdx.x * kRevThreads + threadIdx.x, lane_bytes, tile);
+}
+// exact sub-ranges, the backward pass (scan_block.hpp: rev_guess_wrong, rev_repair_lane)
+template <bool kNib>
+__global__ __launch_bounds__(256) void k_rev_verify(ScanArgs a, int64_t lane_bytes, int64_t n_lanes) {
+    const int64_t lane = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool bad = false;
+    if (lane < n_lanes) {
+        bad = lane + 1 < n_lanes && rev_guess_wrong<kNib>(a, lane, lane_bytes);
+        a.rev_flags[lane] = bad ? 1u : 0u;
+    }
+    const uint32_t n = (uint32_t)__popcll(__ballot(bad));
+    if (n && (threadIdx.x & (kWave - 1)) == 0) atomicAdd(a.status + 2, n);
+}
+template <bool kNib>
+__global__ __launch_bounds__(256) void k_rev_repair(ScanArgs a, int64_t lane_bytes, int64_t n_lanes) {
+    const int64_t lane = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const RevBlobHeader& h = *reinterpret_cast<const RevBlobHeader*>(a.rblob);
+    const RevView T{a.rblob + h.off_wide};
+    if (lane < n_lanes && a.rev_flags[lane]) rev_repair_lane<kNib>(a, T, lane, lane_bytes);
+}
+void launch_rev_verify(const ScanArgs& a, int64_t lane_bytes, void* stream, bool packed) {
+    const int64_t vtop = packed ? (a.vend + 127) & ~(int64_t)127 : (a.vend + 63) & ~(int64_t)63;
+    const int64_t n_lanes = (vtop + lane_bytes - 1) / lane_bytes;
+    const dim3 grid((unsigned)((n_lanes + 255) / 256));
+    if (packed) hipLaunchKernelGGL(k_rev_verify<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a, lane_bytes, n_lanes);
+    else hipLaunchKernelGGL(k_rev_verify<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a, lane_bytes, n_lanes);
+}
+void launch_rev_repair(const ScanArgs& a, int64_t lane_bytes, void* stream, bool packed) {
+    const int64_t vtop = packed ? (a.vend + 127) & ~(int64_t)127 : (a.vend + 63) & ~(int64_t)63;
+    const int64_t n_lanes = (vtop + lane_bytes - 1) / lane_bytes;
+    const dim3 grid((unsigned)((n_lanes + 255) / 256));
+    if (packed) hipLaunchKernelGGL(k_rev_repair<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a, lane_bytes, n_lanes);
+    else hipLaunchKernelGGL(k_rev_repair<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a, lane_bytes, n_lanes);
 }
 void launch_rev_sweep(const ScanArgs& a, int tab_bytes, int64_t lane_bytes, void* stream, bool packed) {
     hipStream_t s = static_cast<hipStream_t>(stream);
