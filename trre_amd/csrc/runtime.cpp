@@ -880,7 +880,7 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
                 cx->probe_in = d_in; cx->probe_n = n;
                 cx->long_lines = misses != 0;
             }
-            const bool longl = exact_env0 == 2 || cx->long_lines;       // (TRRE_EXACT=1: exact sub-ranges in the general families whatever the lines; =2: everywhere)
+            const bool longl = exact_env0 == 2 || cx->long_lines;       // (TRRE_EXACT=2: the switch whatever the lines, for A/B runs and tests)
             if (longl && d_in != d_out && cap >= n) {
                 if (family == TRRE_KERNEL_STREAM_LP) family = TRRE_KERNEL_STREAM_GEN;
                 else if (family == TRRE_KERNEL_GUIDED_LP) family = TRRE_KERNEL_GUIDED_GEN;
@@ -1086,13 +1086,13 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
         // Exact sub-ranges (round 5): every lane walks the bytes of its sub-range and nothing else, from the state the transducer is in
         // there — what makes a line of 400 KB as parallel as 4 000 lines of 100 bytes (rounds 1-4: a lane owns the lines that START in its
         // sub-range and walks them to their end alone, and the backward pass of the guided families has ONE thread carry the state through
-        // a long line: 5.8-9.0 GB/s on such lines).  TRRE_EXACT=1 always, 0 never; default: when the probe finds a sample without a line
-        // end within four sub-ranges.
+        // a long line: 5.8-9.0 GB/s on such lines; 1 GiB of 400 KB lines now: ' +: ' 6.2 -> 700 GB/s, '(a|b)*c:x' 4.9 -> 520).  On ordinary text the
+        // form costs nothing measurable (1 GiB: 745 against 733 GB/s), so the general families always run it — also what keeps ONE giant line in
+        // a file of short ones from serialising the scan; TRRE_EXACT=0: the old ownership, for A/B runs.
         static const int exact_env = getenv("TRRE_EXACT") ? atoi(getenv("TRRE_EXACT")) : -1;
         static const bool patch_env = getenv("TRRE_PATCH") != nullptr, g16_splice_env = getenv("TRRE_G16_SPLICE") != nullptr;
         bool use_exact = g16 > 0 && !cx->exact_off && exact_env != 0 && !patch_env && !g16_splice_env && lane_bytes % 128 == 0 && rev_lane_bytes % 128 == 0 &&
                          !is_guided_wide(*p, family);
-        if (use_exact && exact_env < 0) use_exact = cx->long_lines && cx->probe_in == d_in && cx->probe_n == n;      // (asked at the top of enqueue)
         const int64_t rev_lanes = ((((args.vend + 127) & ~(int64_t)127) + rev_lane_bytes - 1) / rev_lane_bytes + 255) / 256 * 256;
         if (use_exact) {
             const int64_t n_lanes = n_chunks * direct_block_threads();

@@ -1388,17 +1388,41 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
             // the state at lo: from the last line start among the kSpecLook bytes before lo (exact), else a guess — the root state
             // kSpecLook bytes back, walked up to lo (transducers of this kind forget: the guess is right unless the bytes in between
             // leave a memory of what was before them; k_spec_verify checks it against the lane before)
+            // (16 bytes at a time: the search for the line start first — highest block first —, then the walk; lo is a multiple of 16 and
+            // direct_load shows a '\n' right before the input)
             int64_t s0 = lo - (int64_t)a.spec_look > a.vbeg ? lo - (int64_t)a.spec_look : a.vbeg;
             uint32_t known = s0 == a.vbeg ? 1u : 0u;
-            for (int64_t v = lo - 1; v >= s0; --v)
-                if (a.in_v0[v] == (uint8_t)'\n') { s0 = v + 1; known = 1u; break; }
+            for (int64_t v = lo - 16; v + 16 > s0; v -= 16) {
+                const U128 q = direct_load(a, v);
+                const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+                int found = -1;
+                for (int d = 3; d >= 0 && found < 0; --d) {
+                    const uint32_t x = wd[d] ^ 0x0a0a0a0au;
+                    if ((x - 0x01010101u) & ~x & 0x80808080u) {          // some byte of the dword is a '\n' (which one: looked at byte by byte)
+                        for (int k = 3; k >= 0 && found < 0; --k)
+                            if (((wd[d] >> (8 * k)) & 0xffu) == 0x0au && v + 4 * d + k >= s0 - 1) found = 4 * d + k;
+                    }
+                }
+                if (found >= 0) { s0 = v + found + 1; known = 1u; break; }
+            }
             uint32_t r = 0u;
-            for (int64_t v = s0; v < lo; ++v) {
-                uint32_t k;
-                if (kSym == 2) k = ((uint32_t)a.sym_v0[v >> 1] >> (4u * ((uint32_t)v & 1u))) & 15u;
-                else if (kSym == 1) k = a.sym_v0[v];
-                else k = T.cls[a.in_v0[v]];
-                r = *reinterpret_cast<const uint32_t*>(T.g16 + r + (k << 4));
+            for (int64_t v = s0 & ~(int64_t)15; v < lo; v += 16) {
+                const U128 q = direct_load(a, v);
+                const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+                U128 y{};
+                if (kSym == 1) y = *reinterpret_cast<const U128*>(a.sym_v0 + v);
+                uint64_t yn = 0;
+                if (kSym == 2) yn = *reinterpret_cast<const uint64_t*>(a.sym_v0 + (v >> 1));
+                const uint32_t yd[4] = {y.x, y.y, y.z, y.w};
+#pragma clang loop unroll(disable)
+                for (int k = 0; k < 16; ++k) {
+                    if (v + k < s0) continue;
+                    uint32_t kk;
+                    if (kSym == 2) kk = (uint32_t)(yn >> (4 * k)) & 15u;
+                    else if (kSym == 1) kk = (yd[k >> 2] >> (8 * (k & 3))) & 0xffu;
+                    else kk = T.cls[(wd[k >> 2] >> (8 * (k & 3))) & 0xffu];
+                    r = *reinterpret_cast<const uint32_t*>(T.g16 + r + (kk << 4));
+                }
             }
             row = r;
             a.entry_rows[lane] = r | known;
@@ -2910,12 +2934,33 @@ TRRE_HD void rev_sweep_lane(const ScanArgs& a, const RevView& T, int64_t lane, i
         // the lane to the right leaves at hi)
         uint32_t known = 1u;
         if (!empty && hi < a.vend - 1 && rev_byte_at(a, hi - 1) != (uint32_t)'\n') {
+            // (16 bytes at a time; hi is a multiple of 16, direct_load shows every byte from the input's last one on as '\n')
             int64_t e = hi + (int64_t)a.spec_look;
-            if (e >= a.vend - 1) e = a.vend - 1;                      // (the last byte of the input ends its record: exact)
-            else known = 0u;
-            for (int64_t v = hi; v < e; ++v)
-                if (a.in_v0[v] == (uint8_t)'\n') { e = v; known = 1u; break; }
-            for (int64_t v = e - 1; v >= hi; --v) r = T.tab[(r << 8) | a.in_v0[v]];
+            known = 0u;
+            for (int64_t v = hi; v < e; v += 16) {
+                const U128 q = direct_load(a, v);
+                const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+                int found = -1;
+                for (int d = 0; d < 4 && found < 0; ++d) {
+                    const uint32_t x = wd[d] ^ 0x0a0a0a0au;
+                    const uint32_t m = (x - 0x01010101u) & ~x & 0x80808080u;   // the lowest flag is exact
+                    if (m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                        found = 4 * d + ((__ffs((int)m) - 1) >> 3);
+#else
+                        found = 4 * d + (__builtin_ctz(m) >> 3);
+#endif
+                    }
+                }
+                if (found >= 0 && v + found < e) { e = v + found; known = 1u; break; }
+            }
+            for (int64_t v = (e - 1) & ~(int64_t)15; v >= hi && e > hi; v -= 16) {
+                const U128 q = direct_load(a, v);
+                const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+#pragma clang loop unroll(disable)
+                for (int k = 15; k >= 0; --k)
+                    if (v + k < e) r = T.tab[(r << 8) | ((wd[k >> 2] >> (8 * (k & 3))) & 0xffu)];
+            }
         }
         if (!empty) a.rev_guess[lane] = r | known << 31;
     } else
