@@ -752,6 +752,19 @@ def main():
         ]
         for spec in printable:
             configs.append(run_config(trre_amd, spec, inp, out, tmp, want_cpu))
+        nt = min(n, 1 << 30)
+        # long lines (round 5: exact sub-ranges): the same text with one line end left per 400 KB — JSON lines, minified files
+        try:
+            ll = corpora.long_lines(nt, corpora.SEED0 + 2, dev, 400000)
+            for lname, lpat, leng in (("long_lines_greedy", " +: ", "nft"), ("long_lines_loop", "(a|b)*c:x", "nft"), ("long_lines_cfg4", "(cat:dog|dog:cat)", "nft")):
+                rec = run_config(trre_amd, {"name": lname, "pattern": lpat, "engine": leng, "steps": 10, "cpu_sample": 0,
+                                            "workload": "'%s' on %.0f GiB of text with ONE line end per 400 KB (rounds 1-4: a lane walked every such line alone, "
+                                                        "5.8-9.0 GB/s)" % (lpat, nt / 2**30)}, ll, out, tmp, False)
+                rec["avg_line_bytes"] = round(nt / max(int((ll == 10).sum()), 1))
+                configs.append(rec)
+            del ll
+        except Exception as e:      # (the headline must not depend on it)
+            configs.append({"name": "long_lines", "verified": False, "verify": "failed: %r" % (e,)})
         # the fallbacks, measured rather than assumed: the headline scan on the same corpus with ONE NUL
         # byte per GiB — a NUL cuts its line short (C-string semantics, trre_dft.c:1277), so the positional launch is void and
         # the whole buffer runs again on the general family —, and the tile kernels (what a DFT pattern that does not fold runs on)

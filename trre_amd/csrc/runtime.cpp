@@ -865,8 +865,8 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
     // emit: the exact sub-ranges live there), unless the scan is in place.
     static const int exact_env0 = getenv("TRRE_EXACT") ? atoi(getenv("TRRE_EXACT")) : -1;
     {
-        const bool small_tables = (is_stream(family) && p->stt.g16_ok) || (is_guided(family) && p->gt.fwd.g16_ok && !p->gt.wide);
-        if (small_tables && !cx->exact_off && exact_env0 != 0) {
+        const bool small_tables = (family == TRRE_KERNEL_STREAM_LP && p->stt.g16_ok) || (family == TRRE_KERNEL_GUIDED_LP && p->gt.fwd.g16_ok && !p->gt.wide);
+        if (small_tables && !cx->exact_off && exact_env0 != 0 && d_in != d_out && cap >= n) {
             if (cx->probe_in != d_in || cx->probe_n != n) {
                 const int64_t a0 = (int64_t)(reinterpret_cast<uintptr_t>(d_in) & 15u);
                 ScanArgs pa{};
@@ -881,9 +881,8 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
                 cx->long_lines = misses != 0;
             }
             const bool longl = exact_env0 == 2 || cx->long_lines;       // (TRRE_EXACT=2: the switch whatever the lines, for A/B runs and tests)
-            if (longl && d_in != d_out && cap >= n) {
-                if (family == TRRE_KERNEL_STREAM_LP) family = TRRE_KERNEL_STREAM_GEN;
-                else if (family == TRRE_KERNEL_GUIDED_LP) family = TRRE_KERNEL_GUIDED_GEN;
+            if (longl) {
+                family = family == TRRE_KERNEL_STREAM_LP ? TRRE_KERNEL_STREAM_GEN : TRRE_KERNEL_GUIDED_GEN;
                 pd.family = family;
             }
         }
