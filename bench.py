@@ -358,6 +358,8 @@ def cli_records_for(trre_amd, inp, out, n, want_cpu):
         t_empty = min(wall([dft, "[a:A-z:Z]", empty])[0] for _ in range(3))
         # what the binary prints, checked on the first GiB (file -> file) against the device scan of the same bytes
         vb = min(nb, 1 << 30)
+        if vb < nb:
+            vb = line_start_at_or_after(inp, vb - (1 << 16))          # (whole records: the head file must not end inside one)
         f3, o3 = os.path.join(td, "head.txt"), os.path.join(td, "head.out")
         with open(f3, "wb") as f:
             f.write(inp[:vb].cpu().numpy().tobytes())
@@ -682,6 +684,8 @@ def main():
         import ctypes
         import numpy as np
         hn = min(n, 1 << 30)
+        if hn < n:
+            hn = line_start_at_or_after(inp, hn - (1 << 16))            # (whole records)
         host = inp[:hn].cpu().numpy()
         hout = np.empty(hn + 4096, dtype=np.uint8)
         hm = ctypes.c_size_t()

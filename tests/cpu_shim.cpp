@@ -14,7 +14,6 @@
 #include <cstring>
 #include <vector>
 
-#include "../trre_amd/csrc/patch_block.hpp"
 #include "../trre_amd/csrc/scan_block.hpp"
 #include "../trre_amd/csrc/splice_block.hpp"
 #include "../trre_amd/csrc/gen_block.hpp"
@@ -327,8 +326,17 @@ void run_direct_gen_exact(ScanArgs a, int64_t lane_bytes, uint32_t& status, uint
             if (!flags[lane]) continue;
             const int64_t block_end = std::min(n_lanes, (lane / group + 1) * group);
             uint32_t state = (lane % 2) ? exits[lane - 1] : exits_before[lane - 1];
+            const uint32_t skip_row = kSkipState * h.n_cls * 16u;
             for (int64_t j = lane;;) {
                 entry[j] = state;
+                if (state == skip_row && (j + 1) * lane_bytes < a.vend - 1 && !rev_has_newline(a, j * lane_bytes, (j + 1) * lane_bytes)) {
+                    exits[j] = state;                                    // (as in k_stream_g16's repair round: SKIP travels without a walk)
+                    cnt[j] = 0;
+                    ++j;
+                    if (j >= block_end || flags[j]) break;
+                    if ((entry[j] & 1u) || (entry[j] & ~1u) == state) break;
+                    continue;
+                }
                 count_lane(j);
                 state = exits[j];
                 ++j;
@@ -350,136 +358,6 @@ void run_direct_gen_exact(ScanArgs a, int64_t lane_bytes, uint32_t& status, uint
     }
 }
 
-// The splice form of a small table (k_stream_g16<4> / k_chunk_scan / k_g16_splice): the count walk lists the edits, the
-// wave-cooperative second pass copies the input around them.  ev_cap: events per lane.
-template <int kSym = 0>
-void run_g16_splice(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64_t& total_out, uint32_t ev_cap) {
-    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
-    StreamView T = direct_view(a);              // (with the pair form where the tables have one: the mark pass walks pairs)
-    const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
-    std::vector<uint32_t> hdr((size_t)n_lanes * 4, 0xEEEEEEEEu);
-    std::vector<uint32_t> events((size_t)n_lanes * ev_cap + 4, 0xEEEEEEEEu);
-    FbCopyArgs ca{};
-    ca.events = events.data();
-    ca.lane_hdr = hdr.data();
-    ca.ev_cap = ev_cap;
-    std::vector<uint64_t> cnt(n_lanes), base(n_lanes);
-    uint32_t stage[kMarkStageStride];
-    for (int64_t lane = n_lanes - 1; lane >= 0; --lane) {      // any order
-        DirectLane L;
-        if (h.flags & kFlagG16SlowBit) g16_lane<4, kSym, true>(a, T, h.n_cls, lane, lane_bytes, reinterpret_cast<uint8_t*>(stage), 0, L, status, nullptr, nullptr, &ca);
-        else g16_lane<4, kSym, false>(a, T, h.n_cls, lane, lane_bytes, reinterpret_cast<uint8_t*>(stage), 0, L, status, nullptr, nullptr, &ca);
-        cnt[lane] = L.count;
-    }
-    if (status & (kStEditOverflow | kStNul | kStOverflow | kStDiverge)) return;
-    uint64_t run = 0;
-    for (int64_t lane = 0; lane < n_lanes; ++lane) { base[lane] = run; run += cnt[lane]; }
-    total_out = run;
-    if (run > a.cap) { status |= kStCapacity; return; }
-    std::memset(a.out, 0xEE, (size_t)run);
-    SpliceTables ST;
-    ST.g16 = T.g16;
-    ST.p32 = T.p32;
-    ST.ent8 = T.ent;
-    ST.pool = T.pool;
-    alignas(16) static uint8_t lds[kSpLdsPerWave];
-    for (int64_t first = 0; first < n_lanes; first += 256) {
-        for (int w = 3; w >= 0; --w) {
-            std::memset(lds, 0xEE, sizeof lds);
-            const int64_t left = n_lanes - (first + w);
-            if (left <= 0) continue;
-            const SpliceWork W{first + w, 4, (int)std::min<int64_t>(64, (left + 3) / 4), base.data() + first + w, 4};
-            fb_splice_ranges<true, 1>(a, ST, ca, W, lane_bytes, SpliceLds{lds});
-        }
-    }
-}
-
-// The record + patch form of the general families (patch_block.hpp) as k_stream_g16<3> / k_chunk_scan / k_patch run it:
-// the record pass lane by lane, the exclusive sum of the block totals, then every block's pieces into an emulated LDS tile
-// (same skewed layout) and the tile out.  tile_cap: logical capacity of the tile (smaller than the production one in the
-// tests, so that the straight-to-memory path of large blocks runs too); ovf_cap: overflow records.
-template <int kSym = 0>
-void run_patch_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64_t& total_out, uint32_t tile_cap, uint32_t ovf_cap) {
-    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
-    StreamView T = direct_view(a);
-    T.p32 = nullptr;
-    const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
-    const int64_t n_pieces = (a.vend + kPieceBytes - 1) / kPieceBytes;
-    const int64_t n_blocks = (n_pieces + kBlockPieces - 1) / kBlockPieces;
-    std::vector<uint32_t> slots((size_t)n_pieces * kSlotWords + 8, 0xEEEEEEEEu), ovf((size_t)ovf_cap * kOvfWords + 1);
-    for (int64_t q = 0; q < n_pieces; ++q) slots[(size_t)q * kSlotWords] = 0;       // (unwritten: the written flag must be clear)
-    const int64_t n_groups = (n_blocks + kGroupBlocks - 1) / kGroupBlocks;
-    std::vector<uint64_t> block_total(n_blocks, 0), block_base(n_blocks + 1, 0), group_total(n_groups, 0), group_base(n_groups + 1, 0);
-    uint32_t ovf_count = 0;
-    PatchArgs pa{};
-    pa.slots = slots.data();
-    pa.ovf = ovf.data();
-    pa.ovf_count = &ovf_count;
-    pa.ovf_cap = ovf_cap;
-    pa.block_total = block_total.data();
-    pa.group_total = group_total.data();
-    pa.group_base = group_base.data();
-    pa.n_pieces = n_pieces;
-    alignas(16) uint32_t stage[kRecStageStride];
-    for (int64_t lane = n_lanes - 1; lane >= 0; --lane) {      // any order: every piece has one recorder
-        DirectLane L;
-        if (h.flags & kFlagG16SlowBit) g16_lane<3, kSym, true>(a, T, h.n_cls, lane, lane_bytes, reinterpret_cast<uint8_t*>(stage), 0, L, status, nullptr, &pa);
-        else g16_lane<3, kSym, false>(a, T, h.n_cls, lane, lane_bytes, reinterpret_cast<uint8_t*>(stage), 0, L, status, nullptr, &pa);
-    }
-    if (status & kStEditOverflow) return;
-    uint64_t run = 0;
-    for (int64_t b = 0; b < n_blocks; ++b) group_total[b / kGroupBlocks] += block_total[b];      // (k_group_sum)
-    for (int64_t g = 0; g < n_groups; ++g) { group_base[g] = run; run += group_total[g]; }
-    group_base[n_groups] = run;
-    for (int64_t b = 0; b < n_blocks; ++b) {              // (k_patch: the group's base + the blocks before it in the group)
-        block_base[b] = group_base[b / kGroupBlocks];
-        for (int64_t j = b / kGroupBlocks * kGroupBlocks; j < b; ++j) block_base[b] += block_total[j];
-    }
-    total_out = run;
-    if (run > a.cap) { status |= kStCapacity; return; }
-    PatchTables PT;
-    PT.g16 = a.blob + h.off_g16;
-    PT.ent = reinterpret_cast<const uint64_t*>(a.blob + h.off_ent);
-    PT.pool = a.blob + h.off_pool;
-    std::vector<uint8_t> tin(kPatchInBytes + 16), tout((size_t)tile_cap + tile_cap / 16 + 128);
-    for (int64_t b = 0; b < n_blocks; ++b) {
-        std::memset(tout.data(), 0xEE, tout.size());
-        uint32_t rel[kBlockPieces], valid[kBlockPieces], total = 0;
-        for (int t = 0; t < kBlockPieces; ++t) {
-            const int64_t q = b * kBlockPieces + t;
-            const uint32_t hdr = q < n_pieces ? slots[(size_t)q * kSlotWords] : 0u;
-            int64_t v = a.vend - q * kPieceBytes;
-            valid[t] = (hdr & kSlotWritten) ? (uint32_t)(v < 0 ? 0 : (v > kPieceBytes ? kPieceBytes : v)) : 0u;
-            if (q < n_pieces && !(hdr & kSlotWritten)) status |= 1u << 30;           // every piece of the input has a recorder
-            rel[t] = total;
-            total += (hdr & kSlotWritten) ? (uint32_t)((int32_t)valid[t] + (int32_t)(int16_t)(hdr & 0xffffu)) : 0u;
-        }
-        if (total != block_total[b]) status |= 1u << 30;
-        for (int c = 0; c < 4 * kBlockPieces; ++c) {
-            const int piece = c >> 2, part = c & 3;
-            const U128 w = direct_load(a, (b * kBlockPieces + piece) * (int64_t)kPieceBytes + part * 16);
-            std::memcpy(tin.data() + piece * kPatchInStride + part * 16, &w, 16);
-        }
-        const uint64_t base = block_base[b];
-        const uint32_t L0 = (uint32_t)((reinterpret_cast<uintptr_t>(a.out) + base) & 63u);
-        const bool direct = L0 + total > tile_cap;
-        uint8_t* out0 = a.out + base - L0;
-        for (int t = 0; t < kBlockPieces; ++t) {
-            const int64_t q = b * kBlockPieces + t;
-            if (q >= n_pieces || !(slots[(size_t)q * kSlotWords] & kSlotWritten)) continue;
-            const uint8_t* in_row = tin.data() + t * kPatchInStride;
-            const uint32_t* slot = slots.data() + (size_t)q * kSlotWords;
-            if (direct) { patch_piece_any(pa, PT, MemSink{out0}, in_row, valid[t], slot, L0 + rel[t]); continue; }
-            const TileSink S{tout.data()};
-            if (!patch_piece(PT, PT.g16, S, in_row, valid[t], slot, L0 + rel[t])) patch_piece_any(pa, PT, S, in_row, valid[t], slot, L0 + rel[t]);
-        }
-        if (direct) continue;
-        const uint32_t end = L0 + total;
-        for (uint32_t lo = 0; lo < end; lo += 16u)
-            for (uint32_t k = 0; k < 16u; ++k)
-                if (lo + k >= L0 && lo + k < end) out0[lo + k] = tout[patch_phys(lo + k)];
-    }
-}
 
 // large tables in their fallback form (k_stream_fb): count, scan, emit — lane by lane
 FbView fb_view(const ScanArgs& a) {
@@ -583,7 +461,7 @@ void run_fb_copy(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64
                 const SpliceWork W{first + w, 4, (int)std::min<int64_t>(64, (left + 3) / 4), base.data() + first + w, 4};
                 SpliceTables ST;
                 ST.lit = CT.lit; ST.esc = CT.esc; ST.pool = CT.pool;
-                fb_splice_ranges<false, 2>(a, ST, ca, W, lane_bytes, SpliceLds{lds});
+                fb_splice_ranges<2>(a, ST, ca, W, lane_bytes, SpliceLds{lds});
             }
         }
         return;
@@ -792,16 +670,6 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
         if (!sh.fb_slots || !sh.off_fb_lit_meta) return -5;
         run_fb_copy(a, geo == 0 ? 2048 : 128, status, total, geo == 0 ? 256u : 64u, true, true);
     }
-    else if (family == 28) {
-        // stream general family by the splice form of its 16-byte entries (what the runtime launches by default)
-        if (!reinterpret_cast<const StreamBlobHeader*>(blob)->g16_bytes) return -5;
-        run_g16_splice<0>(a, geo == 0 ? 2048 : 128, status, total, geo == 0 ? 256u : 64u);
-    }
-    else if (family == 24) {
-        // stream general family by record + patch (16-byte entries; 16-byte aligned inputs only, like the runtime)
-        if (!reinterpret_cast<const StreamBlobHeader*>(blob)->g16_bytes || al != 0) return -5;
-        run_patch_gen<0>(a, geo == 0 ? 2048 : 128, status, total, geo == 0 ? (uint32_t)kPatchOutLogical : 700u, geo == 0 ? 4096u : 3u);
-    }
     else if (engine == 1) {
         if (geo == 0) run_family<GeoDft, DftEngine>(family, a, status, total);
         else run_family<GeoTiny, DftEngine>(family, a, status, total);
@@ -852,7 +720,7 @@ int shim_scan_guided(const uint8_t* rblob, const uint8_t* gblob, int family, int
     if ((family == 10 || family == 13 || family == 14) && cap < n) return -9;
     // like the runtime: symbols are packed two per byte when the backward DFA allows it and the walk uses the 16-byte entries
     const bool has_g16 = reinterpret_cast<const StreamBlobHeader*>(gblob)->g16_bytes != 0;
-    const bool packed = reinterpret_cast<const RevBlobHeader*>(rblob)->sym_bits == 4 && has_g16 && (family == 10 || family == 11 || family == 15 || family == 17 || family == 18);
+    const bool packed = reinterpret_cast<const RevBlobHeader*>(rblob)->sym_bits == 4 && has_g16 && (family == 10 || family == 11 || family == 17 || family == 18);
     if (reinterpret_cast<const RevBlobHeader*>(rblob)->sym_bits == 16) {
         // wide guided tables (more than 256 backward states): k_rev_wide, k_wide_fwd<count>, scan, k_wide_fwd<emit>
         if (family == 10 || family == 13 || family == 14) return -5;
@@ -889,12 +757,6 @@ int shim_scan_guided(const uint8_t* rblob, const uint8_t* gblob, int family, int
         else run_direct_lp_emit<1>(a, lane_bytes, status, family == 10 && has_g16);  // 14: on the 8-byte entries
         total = n;
     }
-    else if (family == 16) {
-        // general guided family by the splice form (what the runtime launches by default when the forward table has 16-byte entries)
-        if (!has_g16) return -5;
-        if (packed) run_g16_splice<2>(a, lane_bytes, status, total, geo == 0 ? 256u : 64u);
-        else run_g16_splice<1>(a, lane_bytes, status, total, geo == 0 ? 256u : 64u);
-    }
     else if (family == 17 || family == 18) {
         // general guided family with exact sub-ranges (18: a look-back of 4 bytes: wrong guesses, repair rounds)
         if (!has_g16) return -5;
@@ -902,11 +764,6 @@ int shim_scan_guided(const uint8_t* rblob, const uint8_t* gblob, int family, int
         if (packed) run_direct_gen_exact<2>(a, lane_bytes, status, total, family == 18 ? 4u : (uint32_t)kSpecLook, geo == 0 ? 256 : 3, rounds);
         else run_direct_gen_exact<1>(a, lane_bytes, status, total, family == 18 ? 4u : (uint32_t)kSpecLook, geo == 0 ? 256 : 3, rounds);
         g_last_rounds = rounds + rev_rounds;
-    }
-    else if (family == 15) {
-        if (!has_g16 || al != 0) return -5;
-        if (packed) run_patch_gen<2>(a, lane_bytes, status, total, geo == 0 ? (uint32_t)kPatchOutLogical : 700u, geo == 0 ? 4096u : 3u);
-        else run_patch_gen<1>(a, lane_bytes, status, total, geo == 0 ? (uint32_t)kPatchOutLogical : 700u, geo == 0 ? 4096u : 3u);
     }
     else if (packed) run_direct_gen<2>(a, lane_bytes, status, total, true);
     else run_direct_gen<1>(a, lane_bytes, status, total, family == 11 && has_g16);

@@ -68,7 +68,7 @@ def main():
             if p.scan_tensor(t).cpu().numpy().tobytes() != o.scan(buf):
                 print("MISMATCH dictionary (copy form)", eng, len(buf), skip)
                 bad += 1
-    # the general families whatever implements them (TRRE_PATCH=1: record + patch): small tables, guided tables, edits in
+    # the general families whatever implements them : small tables, guided tables, edits in
     # every byte of a piece (more than 7 per 64 bytes: overflow records), texts longer than a piece, a diverging line
     for pat, eng in [("a:xyz", "dft"), ("a:", "nft"), (" +: ", "nft"), ("(a|b)*c:x", "nft"), ("[0-9]+:N", "nft"), ("[a-z]:xy", "dft"),
                      ("e:a-replacement-text-of-more-than-sixty-four-bytes-0123456789-0123456789-0123456789-0123456789", "dft"), (":=", "nft")]:

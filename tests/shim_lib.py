@@ -13,7 +13,7 @@ ST_NUL, ST_DIVERGE, ST_CAPACITY, ST_LONGLINE, ST_NEEDSCRATCH, ST_OVERFLOW, ST_MI
 
 
 def build():
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("scan_block.hpp", "scan_core.hpp", "device_blob.hpp", "splice_block.hpp", "patch_block.hpp", "gen_block.hpp", "lazy_block.hpp", "guard_block.hpp")]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("scan_block.hpp", "scan_core.hpp", "device_blob.hpp", "splice_block.hpp", "gen_block.hpp", "lazy_block.hpp", "guard_block.hpp")]
     if os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(d) for d in deps):
         return SO
     os.makedirs(os.path.dirname(SO), exist_ok=True)
@@ -59,7 +59,7 @@ def mask_bytes_of(blob, engine):
 def shim_scan(blob, engine, family, data, geo=1, in_mis=0, out_mis=0, scratch=True, cap=None):
     """Run one kernel family of the device code on the host.  Returns (output bytes, status)."""
     if cap is None:
-        cap = len(data) * 8 + 64 if family in (3, 5, 7, 9, 22, 23, 24, 25, 27, 28, 29, 32, 33) else len(data)     # (20, 21: length-preserving)
+        cap = len(data) * 8 + 64 if family in (3, 5, 7, 9, 22, 23, 25, 27, 29, 32, 33) else len(data)     # (20, 21: length-preserving)
     out = ctypes.create_string_buffer(max(cap, 1))
     m = ctypes.c_size_t()
     st = ctypes.c_uint32()
@@ -108,8 +108,6 @@ ST_EDIT_OVERFLOW = 64
 GUIDED_LP, GUIDED_GEN, GUIDED_GEN8, GUIDED_LP_RING, GUIDED_LP8 = 10, 11, 12, 13, 14
 GUIDED_GEN_EXACT, GUIDED_GEN_EXACT_MISS = 17, 18     # general guided family with exact sub-ranges (round 5); 18: a look-back of 4 bytes (repair rounds)
 STREAM_G16_EXACT, STREAM_G16_EXACT_MISS = 32, 33     # stream general family, the same
-GUIDED_GEN_SPLICE = 16                               # general guided family by the splice form of its 16-byte entries (mark + splice: the runtime's default)
-STREAM_G16_SPLICE = 28                               # stream general family, the same
 GUIDED_LP_ALL = (GUIDED_LP, GUIDED_LP_RING, GUIDED_LP8)
 STREAM_LP_EMIT, STREAM_LP_EMIT8 = 20, 21            # stream LP family by the emit pass alone (no window form)
 STREAM_LPW_PAIR = 26                                 # the window kernel on the pair form of its entries (what the runtime launches when the tables have one)
@@ -159,22 +157,6 @@ def scan_guided_like_runtime(prog, data, geo=1, family=GUIDED_LP, in_mis=0, out_
         else:
             assert not stt.value & (1 << 29), "the repair rounds did not converge"
             return o.raw[:m.value]
-    if family == GUIDED_GEN_SPLICE:
-        lib().shim_scan_guided          # (argtypes set)
-        rblob, gblob = prog.export_guided_tables()
-        cap = len(data) * 8 + 64
-        o = ctypes.create_string_buffer(max(cap, 1))
-        m = ctypes.c_size_t()
-        stt = ctypes.c_uint32()
-        rc = lib().shim_scan_guided(rblob, gblob, family, geo, data, len(data), in_mis, o, cap, out_mis, ctypes.byref(m), ctypes.byref(stt))
-        if rc == -5:                         # no 16-byte entries: nothing to splice
-            family = GUIDED_GEN
-        elif rc:
-            raise RuntimeError("shim rc %d" % rc)
-        elif stt.value & (ST_EDIT_OVERFLOW | ST_NUL | ST_DIVERGE | ST_OVERFLOW):
-            family = GUIDED_GEN              # a void launch: the count / emit pair decides (runtime.cpp: finish)
-        else:
-            return o.raw[:m.value]
     out, st = shim_scan_guided(prog, family, data, geo, in_mis, out_mis)
     assert not st & ST_MISMATCH, "count and emit passes disagree"
     if st & ST_DIVERGE and not (family in GUIDED_LP_ALL and st & ST_NUL):      # (void by a NUL: the general family decides)
@@ -193,7 +175,7 @@ def scan_like_runtime(prog, data, geo=1, family=None, in_mis=0, out_mis=0):
     fam = family
     if not fam:                       # ABI ids -> shim ids (the shim's 6..9 are the direct walkers of the stream families)
         fam = {6: GUIDED_LP, 7: GUIDED_GEN}.get(info.kernel, info.kernel)
-    if fam in (GUIDED_LP, GUIDED_GEN, GUIDED_GEN8, GUIDED_LP_RING, GUIDED_LP8, GUIDED_GEN_SPLICE, GUIDED_GEN_EXACT, GUIDED_GEN_EXACT_MISS):
+    if fam in (GUIDED_LP, GUIDED_GEN, GUIDED_GEN8, GUIDED_LP_RING, GUIDED_LP8, GUIDED_GEN_EXACT, GUIDED_GEN_EXACT_MISS):
         return scan_guided_like_runtime(prog, data, geo, fam, in_mis, out_mis)
     if family == DFT_LAZY or (not family and info.kernel == 10):
         out, st, _ = scan_lazy(prog, data, geo, in_mis)
@@ -209,18 +191,13 @@ def scan_like_runtime(prog, data, geo=1, family=None, in_mis=0, out_mis=0):
         if st & ST_DIVERGE:
             raise RuntimeError("diverges")
         return out
-    blob = prog.export_stream_tables() if fam in (4, 5, 6, 7, 8, 9, 20, 21, 22, 23, 25, 27, 28, 32, 33, STREAM_LPW_PAIR) else prog.export_tables()
+    blob = prog.export_stream_tables() if fam in (4, 5, 6, 7, 8, 9, 20, 21, 22, 23, 25, 27, 32, 33, STREAM_LPW_PAIR) else prog.export_tables()
     if fam in (STREAM_G16_EXACT, STREAM_G16_EXACT_MISS):
         out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
         if out is not None and not st & (ST_DIVERGE | ST_OVERFLOW):
             assert not st & (1 << 29), "the repair rounds did not converge"
             return out
         fam = 7                             # no 16-byte entries, a bounded fold that overflowed, an attempt that does not return: the old way
-    if fam == STREAM_G16_SPLICE:
-        out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
-        if out is not None and not st & (ST_EDIT_OVERFLOW | ST_NUL | ST_DIVERGE | ST_OVERFLOW):
-            return out
-        fam = 7                             # no 16-byte entries, or a void launch: the count / emit pair
     out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
     if out is None:                         # family 8 / 26 without a window (pair) form: nothing to run
         fam = 6

@@ -69,7 +69,7 @@ def guided_families(p):
     if trre_amd.KERNEL_GUIDED_LP in allowed:
         fams += list(shim_lib.GUIDED_LP_ALL)
     if trre_amd.KERNEL_GUIDED_GEN in allowed:
-        fams += [shim_lib.GUIDED_GEN, shim_lib.GUIDED_GEN8, shim_lib.GUIDED_GEN_SPLICE]
+        fams += [shim_lib.GUIDED_GEN, shim_lib.GUIDED_GEN8]
     return fams
 
 
@@ -101,7 +101,7 @@ def shim_families(p):
     if 4 in fams:             # (shim ids: 6/8 LDS-ring and window walkers of the stream LP family, 20/21 its emit-only form,
         fams += [6, 8, shim_lib.STREAM_LPW_PAIR, shim_lib.STREAM_LP_EMIT, shim_lib.STREAM_LP_EMIT8]      # 7/9 direct walkers of the general one; 26: window walk, two bytes per step)
     if 5 in fams:
-        fams += [7, 9, shim_lib.STREAM_G16_SPLICE]
+        fams += [7, 9]
         if shim_lib.has_fallback_form(p):      # a large table: the count pass (and, off by default, the emit pass) in LDS
             fams += [shim_lib.STREAM_FB, shim_lib.STREAM_FB_COUNT]
     return fams + guided_families(p)
@@ -554,52 +554,6 @@ print("compiled", n)
     r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     assert r.returncode == 0, r.stdout.decode("latin-1")[-2000:]
     assert int(r.stdout.split()[-1]) > 300
-
-
-def test_record_and_patch_form_of_the_general_families():
-    """The experimental record + patch form (trre_amd/csrc/patch_block.hpp, TRRE_PATCH=1 on the GPU): one walk lists the edits
-    per 64-byte piece, a patch pass copies the input around them.  Every golden vector whose tables have the 16-byte form,
-    byte-class and symbol columns, tiny and production geometry (the tiny one has three overflow records and a 700-byte tile:
-    both escape routes run), against the reference's output; then random inputs with edits in every byte."""
-    import ctypes
-    n = n_over = 0
-    for pat, name, data, engine, exp in golden_lib.cases():
-        p = prog(pat, engine)
-        if isinstance(p, trre_amd.TrreError) or exp is None or len(pat) > 1000:
-            continue
-        info = p.info
-        for geo in (1, 0):
-            if len(data) > 20000 and geo == 1:
-                continue
-            if info.stream_states:
-                out, st = shim_lib.shim_scan(p.export_stream_tables(), info.engine, 24, data, geo)
-                if out is not None and not st & shim_lib.ST_OVERFLOW:
-                    if st & 64:                      # out of overflow records: the runtime runs the count / emit pair
-                        n_over += 1
-                    else:
-                        assert not st & shim_lib.ST_MISMATCH and out == exp, (pat, name, engine, geo, hex(st))
-                        n += 1
-            if engine == "nft" and info.guided_rev_states:
-                rblob, gblob = p.export_guided_tables()
-                cap = len(data) * 8 + 64
-                o = ctypes.create_string_buffer(max(cap, 1))
-                m, stt = ctypes.c_size_t(), ctypes.c_uint32()
-                rc = shim_lib.lib().shim_scan_guided(rblob, gblob, 15, geo, data, len(data), 0, o, cap, 0, ctypes.byref(m), ctypes.byref(stt))
-                if rc == 0 and not stt.value & shim_lib.ST_DIVERGE:
-                    if stt.value & 64:
-                        n_over += 1
-                    else:
-                        assert not stt.value & shim_lib.ST_MISMATCH and o.raw[:m.value] == exp, (pat, name, geo, hex(stt.value))
-                        n += 1
-    assert n > 1500 and n_over > 50
-    rng = random.Random(4)
-    for pat, eng in [("a:xyz", "dft"), ("[a-z]:", "nft"), ("[a-z]:xy", "dft"), (" +: ", "nft"), ("cat:a-text-of-more-than-fourteen-bytes", "dft")]:
-        p = prog(pat, eng)
-        o = Oracle(pat, eng)
-        for k in range(6):
-            data = corpus.word_soup(rng, 3000 + 997 * k, max_len=200) + b"nul\0rest of the record\n" + b"cat aaa" * k
-            out, st = shim_lib.shim_scan(p.export_stream_tables(), p.info.engine, 24, data, 0)
-            assert out is not None and not st & (shim_lib.ST_MISMATCH | 64) and out == o.scan(data), (pat, eng, k)
 
 
 def test_wide_guided_tables():

@@ -42,15 +42,6 @@ tile_dft|--case a:xyz;;dft;;printable;;tile_gen --bytes 268435456
 wide_guided|--case a(a|b|c|d|e|f|g|h){9}c:x;;nft;;printable;;auto --bytes 268435456
 backtrack|--case a(a|b|c|d|e|f|g|h){12}c:x;;nft;;printable;;auto --bytes 268435456
 CASES
-# 4. the splice form of a small table (TRRE_G16_SPLICE=1; off by default: round 4 built it and it loses): kernel stats, traffic, SQ counters
-TRRE_G16_SPLICE=1 timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/raw/st_spl -o s -- python tools/kbench.py --case 'a:xyz;;dft;;printable;;auto' --steps 5 > gpurun_out/raw/st_spl.log 2>&1
-{ echo "# TRRE_G16_SPLICE=1 kbench --case a:xyz;;dft;;printable;;auto --steps 5"; python tools/rocpd_summary.py gpurun_out/raw/st_spl/s_results.db trre; grep '^pattern' gpurun_out/raw/st_spl.log; } > $out/${tag}_g16splice_expand_kernel_stats.txt
-i=0
-for set in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"; do
-    i=$((i+1))
-    TRRE_G16_SPLICE=1 timeout 400 rocprofv3 --pmc $set -d gpurun_out/raw/pm_spl_$i -o p -- python tools/kbench.py --case 'a:xyz;;dft;;printable;;auto' --steps 2 > gpurun_out/raw/pm_spl_$i.log 2>&1
-    { echo "# TRRE_G16_SPLICE=1 kbench --case a:xyz;;dft;;printable;;auto --steps 2   (rocprofv3 --pmc $set)"; python tools/rocpd_summary.py gpurun_out/raw/pm_spl_$i/p_results.db trre; } > $out/${tag}_g16splice_expand_pmc_$i.txt
-done
 # 5. the dictionary configuration: kernel stats with the splice and with the older copy pass, SQ counters and traffic (tools/prof_dict4.sh, tools/pmc_dict4.sh)
 bash tools/prof_dict4.sh $tag > /dev/null 2>&1
 bash tools/pmc_dict4.sh $tag > /dev/null 2>&1

@@ -27,6 +27,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -92,6 +93,8 @@ private:
     std::condition_variable cv_;
     std::deque<T> q_;
 };
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 bool write_all(int fd, const uint8_t* p, size_t n) {
     while (n) {
@@ -191,6 +194,10 @@ int main(int argc, char** argv) {
     struct OutJob { int buf; size_t m; };
     Channel<OutJob> jobs;
     bool write_failed = false;
+    // TRRE_TRACE=1: where the time of the three stages went, on stderr at the end
+    const bool trace = std::getenv("TRRE_TRACE") != nullptr;
+    double t_read = 0, t_alloc = 0, t_scan = 0, t_write = 0, t_wait_in = 0, t_wait_out = 0;
+    const double t_begin = now_s();
 
     // ---- reader ----------------------------------------------------------------------------------------------------------------
     std::thread reader([&] {
@@ -206,7 +213,10 @@ int main(int argc, char** argv) {
             for (;;) {
                 // room: the carried bytes and a block's worth (a regular file: no more than it still holds)
                 const size_t want = regular ? std::min(block, left) : cur;
+                double t0 = now_s();
                 B.reserve(std::max<size_t>(carry.size() + want + 64, 4096));
+                t_alloc += now_s() - t0;
+                t0 = now_s();
                 if (!carry.empty()) { std::memcpy(B.p, carry.data(), carry.size()); B.have = carry.size(); carry.clear(); }
                 if (regular) {
                     if (want && !pread_parallel(fd, B.p + B.have, off, want)) { std::fprintf(stderr, "error: read failed\n"); std::_Exit(EXIT_FAILURE); }
@@ -241,6 +251,7 @@ int main(int argc, char** argv) {
                 B.n = n;
                 carry.assign(B.p + n, B.p + B.have);
                 B.last = eof;
+                t_read += now_s() - t0;
                 break;
             }
             in_full.push(b);
@@ -253,7 +264,9 @@ int main(int argc, char** argv) {
         for (;;) {
             const OutJob j = jobs.pop();
             if (j.buf < 0) break;
+            const double t0 = now_s();
             if (!write_failed && !write_all(1, outb[j.buf].p, j.m)) write_failed = true;
+            t_write += now_s() - t0;
             out_free.push(j.buf);
         }
     });
@@ -262,20 +275,28 @@ int main(int argc, char** argv) {
     int status = 0;
     bool undecided = false;
     for (;;) {
+        double t0 = now_s();
         const int b = in_full.pop();
+        t_wait_in += now_s() - t0;
         if (b < 0) break;
         Block& B = inb[b];
         if (B.n && !status) {
+            t0 = now_s();
             const int o = out_free.pop();
+            t_wait_out += now_s() - t0;
             Block& O = outb[o];
             O.have = 0;
+            t0 = now_s();
             O.reserve(B.n + 64);
+            t_alloc += now_s() - t0;
             size_t m = 0;
+            t0 = now_s();
             int rc = trre_scan_host_multi(prog, B.p, B.n, O.p, O.cap, &m, mask);
             if (rc == TRRE_E_CAPACITY) {
                 O.reserve(m + 64);
                 rc = trre_scan_host_multi(prog, B.p, B.n, O.p, O.cap, &m, mask);
             }
+            t_scan += now_s() - t0;
             undecided = undecided || (trre_last_scan_flags() & TRRE_SCAN_GUARD_UNDECIDED);
             // a scan the reference does not survive: it has printed everything up to the attempt it does not come back from (exit()
             // flushes stdout, trre_nft.c:551-553) — so has the library (NFT engine), m bytes
@@ -301,6 +322,9 @@ int main(int argc, char** argv) {
     if (undecided)
         std::fprintf(stderr, "trre: warning: a line long enough to exhaust the reference's stack was not searched to the end (step budget): "
                              "where the reference may have exited with \"stack max capacity reached\" the match is printed\n");
+    if (trace)
+        std::fprintf(stderr, "trre: %.3f s in all: reader %.3f s reading + %.3f s allocating (both stages), scan calls %.3f s (waited %.3f s for input, %.3f s for an output buffer), writer %.3f s\n",
+                     now_s() - t_begin, t_read, t_alloc, t_scan, t_wait_in, t_wait_out, t_write);
     for (Block& B : inb) B.release();
     for (Block& B : outb) B.release();
     trre_free(prog);

@@ -5,7 +5,6 @@
 namespace trre {
 
 struct ScanArgs;
-struct PatchArgs;
 struct FbCopyArgs;
 struct GenArgs;
 struct GuardArgs;
@@ -28,11 +27,8 @@ int direct_ent_lds_bytes();
 int direct_block_threads();
 // sym: guided families — columns are the symbols of the backward pass (a.sym_v0): 1 one per byte, 2 packed two per byte
 // (16-byte entries only)
-// which 3 (16-byte entries only): the record pass of the record + patch form (patch_block.hpp), `pa` its slots
 void launch_direct_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, void* stream, int g16_bytes = 0,
-                          int sym = 0, bool g16_slow = true, const PatchArgs* pa = nullptr);
-void launch_group_sum(const uint64_t* block_total, uint64_t* group_total, int64_t n_blocks, void* stream);
-void launch_patch(const ScanArgs& a, const PatchArgs& pa, int64_t n_blocks, int g16_bytes, void* stream);
+                          int sym = 0, bool g16_slow = true);
 // backward pass of the guided families: fills a.sym_v0 for positions [0 .. round_up(a.vend, 64)) (packed: round_up(.., 128), two per byte)
 void launch_rev_sweep(const ScanArgs& a, int tab_bytes, int64_t lane_bytes, void* stream, bool packed);
 // wide guided tables (more than 256 backward states: 16-bit symbols at a.sym_v0, both tables through L1 / L2); which: 1 count, 2 emit
@@ -50,9 +46,6 @@ bool fb_copy_fits(const void* hdr);
 // ... its second pass as a wave-cooperative splice (splice_block.hpp); the workspace's chunks must be full (the mark pass fills every lane's header)
 void launch_fb_splice(const ScanArgs& a, const FbCopyArgs& ca, const void* hdr, int64_t lane_bytes, int64_t n_chunks, void* stream);
 bool fb_splice_fits(const void* hdr);
-// the splice form of a SMALL table: launch_direct_kernel(4, ...) marks (its PatchArgs carry the event rows: slots, the lane headers: ovf,
-// and the events per row: ovf_cap), this splices
-void launch_g16_splice(const ScanArgs& a, const FbCopyArgs& ca, int g16_bytes, int p32_bytes, int64_t lane_bytes, int64_t n_chunks, void* stream);
 // generator modes (gen_block.hpp): which 1 count, 2 emit; a.blob = the tables of serialize_gen (runtime.cpp), chunks of 256 lanes
 void launch_gen(int which, const ScanArgs& a, const GenArgs& ga, int64_t lane_bytes, int64_t n_chunks, void* stream);
 // the stack guard (guard_block.hpp): flags = a bit per window of `window` bytes without a '\n' (u64 per 64 windows, room for a multiple

@@ -23,7 +23,6 @@
 #include "device_blob.hpp"
 #include "front.hpp"
 #include "launch.hpp"
-#include "patch_block.hpp"
 #include "scan_block.hpp"
 #include "splice_block.hpp"
 #include "gen_block.hpp"
@@ -59,7 +58,7 @@ struct Pending {
     bool timed = false;
     int count = 0;          // launches in the current batch
     const uint64_t* total_at = nullptr;   // general families: where the launch leaves its output size
-    bool patched = false;                 // the launch was a record + patch pair (patch_block.hpp), not a count / emit pair
+    bool patched = false;                 // the launch was the mark + splice pair of a large table's copy form, not a count / emit pair
     // the stack guard found, before an in-place launch, a line on which the reference's search runs out of stack: nothing was launched
     // exact sub-ranges (scan_block.hpp: ScanArgs::exact): what finish() needs to run repair rounds and the emit pass again
     bool exact = false;
@@ -91,14 +90,6 @@ struct ScanCtx {
     size_t gen_out_cap = 0;
     size_t sym_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // record + patch form of the general families (patch_block.hpp): a 32-byte slot per 64 input bytes, overflow records,
-    // block totals and their exclusive sum
-    uint32_t* d_slots = nullptr;
-    uint32_t* d_ovf = nullptr;
-    uint32_t* d_ovf_count = nullptr;
-    uint64_t* d_block_total = nullptr;   // [n_blocks], then the group totals [n_groups] (zeroed together)
-    uint64_t* d_group_base = nullptr;    // [n_groups + 1]
-    int64_t patch_pieces = 0;         // capacity, in pieces
     // the copy form of a large table (scan_block.hpp fb_lane<3> / fb_copy_lane): events, lane headers
     uint32_t* d_cevents = nullptr;
     uint32_t* d_chdr = nullptr;
@@ -513,11 +504,6 @@ void ctx_free(ScanCtx& c) {
     (void)hipFree(c.d_miss);
     (void)hipFree(c.d_spec);
     (void)hipFree(c.d_probe);
-    (void)hipFree(c.d_slots);
-    (void)hipFree(c.d_ovf);
-    (void)hipFree(c.d_ovf_count);
-    (void)hipFree(c.d_block_total);
-    (void)hipFree(c.d_group_base);
     (void)hipFree(c.d_cevents);
     (void)hipFree(c.d_chdr);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
@@ -562,23 +548,6 @@ int ensure_workspace(ScanCtx* c, int64_t n_chunks, int threads) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_chunk_total), (size_t)n_chunks * 8));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_chunk_base), (size_t)(n_chunks + 1) * 8));
     c->ws_chunks = n_chunks;
-    return TRRE_OK;
-}
-
-int64_t patch_ovf_records(int64_t n_pieces) { return n_pieces / 128 + 1024; }
-int ensure_patch_workspace(ScanCtx* c, int64_t n_pieces) {
-    if (n_pieces <= c->patch_pieces) return TRRE_OK;
-    (void)hipFree(c->d_slots); (void)hipFree(c->d_ovf); (void)hipFree(c->d_ovf_count); (void)hipFree(c->d_block_total); (void)hipFree(c->d_group_base);
-    c->d_slots = nullptr; c->d_ovf = nullptr; c->d_ovf_count = nullptr; c->d_block_total = nullptr; c->d_group_base = nullptr;
-    c->patch_pieces = 0;
-    const int64_t n_blocks = (n_pieces + trre::kBlockPieces - 1) / trre::kBlockPieces;
-    const int64_t n_groups = (n_blocks + trre::kGroupBlocks - 1) / trre::kGroupBlocks;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_slots), (size_t)n_pieces * trre::kSlotWords * 4));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_ovf), (size_t)patch_ovf_records(n_pieces) * trre::kOvfWords * 4));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_ovf_count), 16));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_block_total), (size_t)(n_blocks + n_groups) * 8));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_group_base), (size_t)(n_groups + 1) * 8));
-    c->patch_pieces = n_pieces;
     return TRRE_OK;
 }
 
@@ -1089,8 +1058,7 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
         // form costs nothing measurable (1 GiB: 745 against 733 GB/s), so the general families always run it — also what keeps ONE giant line in
         // a file of short ones from serialising the scan; TRRE_EXACT=0: the old ownership, for A/B runs.
         static const int exact_env = getenv("TRRE_EXACT") ? atoi(getenv("TRRE_EXACT")) : -1;
-        static const bool patch_env = getenv("TRRE_PATCH") != nullptr, g16_splice_env = getenv("TRRE_G16_SPLICE") != nullptr;
-        bool use_exact = g16 > 0 && !cx->exact_off && exact_env != 0 && !patch_env && !g16_splice_env && lane_bytes % 128 == 0 && rev_lane_bytes % 128 == 0 &&
+        bool use_exact = g16 > 0 && !cx->exact_off && exact_env != 0 && lane_bytes % 128 == 0 && rev_lane_bytes % 128 == 0 &&
                          !is_guided_wide(*p, family);
         const int64_t rev_lanes = ((((args.vend + 127) & ~(int64_t)127) + rev_lane_bytes - 1) / rev_lane_bytes + 255) / 256 * 256;
         if (use_exact) {
@@ -1114,64 +1082,8 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
             launch_rev_sweep(args, (int)p->gt.n_rev * 256, rev_lane_bytes, stream, sym_mode == 2);
             if (use_exact) launch_rev_verify(args, rev_lane_bytes, stream, sym_mode == 2);
         }
-        // TRRE_PATCH=1 (experimental, off by default): ONE walk that lists the edits per 64-byte piece, then a patch pass that
-        // copies the input around them (patch_block.hpp) — instead of a count walk and an emit walk that appends byte by byte.
-        // Correct (parity-tested on the host shim and on the GPU) but slower as it stands: 'a:xyz' at 1 GiB record 0.78 ms +
-        // patch 1.61 ms against count 0.42 + emit 0.97.  (Its first lane starts at v = 0: 16-byte aligned
-        // inputs only; a scan that diverges or runs out of overflow records is run again as a count / emit pair.)
-        static const bool no_patch_env = getenv("TRRE_PATCH") == nullptr;
-        // The splice form (round 4; tables with the 16-byte entries): the count walk also lists the lane's edits (the
-        // transitions that do not simply pass on the byte they read), the second pass copies the input around them, a wave per
-        // sub-range, without walking the table again (splice_block.hpp) — instead of the emit walk, the slowest kernel of every
-        // general family.  A NUL, a sub-range with more edits than its list holds (256, or 15 in 64 bytes: a corpus full of
-        // edits), a pooled text of more than 255 bytes send the buffer to the count / emit pair.
-        // (as it stands the form loses on small tables — 'a:xyz', 1 GiB: mark 0.84 + splice 0.76 ms against count 0.45 + emit 1.00 —
-        // so it is OFF by default: TRRE_G16_SPLICE=1 selects it, for A/B runs and the parity tests)
-        static const bool no_g16_splice_env = getenv("TRRE_G16_SPLICE") == nullptr;
-        const bool splice_form = g16 > 0 && no_patch_env && !no_g16_splice_env && !cx->patch_off && !p->copy_form_off.load() && lane_bytes % 64 == 0 &&
-                                 stt.max_out <= kSpMaxText && !is_guided_wide(*p, family);
-        if (splice_form) {
-            const int64_t n_lanes = n_chunks * direct_block_threads();
-            rc = ensure_copy_workspace(cx, n_lanes);
-            if (rc) return rc;
-            FbCopyArgs ca{};
-            ca.events = cx->d_cevents;
-            ca.lane_hdr = cx->d_chdr;
-            ca.ev_cap = kCopyEvCap;
-            PatchArgs pa{};                                   // (how the mark pass receives them: launch.hpp)
-            pa.slots = ca.events;
-            pa.ovf = ca.lane_hdr;
-            pa.ovf_cap = ca.ev_cap;
-            launch_direct_kernel(4, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, sym_mode, g16_slow, &pa);
-            launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);
-            launch_g16_splice(args, ca, (int)(stt.g16.size() * 4), (int)(stt.p32.size() * 4), lane_bytes, n_chunks, stream);
-            pd.total_at = cx->d_chunk_base + n_chunks;
-            pd.patched = true;
-        } else
-        if (g16 > 0 && a == 0 && !no_patch_env && !cx->patch_off && lane_bytes % kPieceBytes == 0) {
-            const int64_t n_pieces = (args.vend + kPieceBytes - 1) / kPieceBytes;
-            const int64_t n_blocks = (n_pieces + kBlockPieces - 1) / kBlockPieces;
-            rc = ensure_patch_workspace(cx, n_pieces);
-            if (rc) return rc;
-            PatchArgs pa{};
-            pa.slots = cx->d_slots;
-            pa.ovf = cx->d_ovf;
-            pa.ovf_count = cx->d_ovf_count;
-            pa.ovf_cap = (uint32_t)patch_ovf_records(cx->patch_pieces);
-            const int64_t n_groups = (n_blocks + kGroupBlocks - 1) / kGroupBlocks;
-            pa.block_total = cx->d_block_total;
-            pa.group_total = cx->d_block_total + n_blocks;
-            pa.group_base = cx->d_group_base;
-            pa.n_pieces = n_pieces;
-            HIP_TRY(hipMemsetAsync(cx->d_block_total, 0, (size_t)(n_blocks + n_groups) * 8, stream));
-            HIP_TRY(hipMemsetAsync(cx->d_ovf_count, 0, 4, stream));
-            launch_direct_kernel(3, direct_ent_lds, args, lane_bytes, n_chunks, stream, (int)align_up(stt.g16.size() * 4, 16), sym_mode, g16_slow, &pa);
-            launch_group_sum(pa.block_total, pa.group_total, n_blocks, stream);
-            launch_chunk_scan(pa.group_total, pa.group_base, n_groups, stream);
-            launch_patch(args, pa, n_blocks, (int)(stt.g16.size() * 4), stream);
-            pd.total_at = cx->d_group_base + n_groups;
-            pd.patched = true;
-        } else {
+        // (Rounds 3 and 4 had two one-walk forms here — record + patch, and mark + splice for small tables; both lost to this pair and were removed
+        // in round 5: DESIGN.md §4.5.)
         launch_direct_kernel(1, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, sym_mode, g16_slow);
         if (use_exact) launch_spec_verify(args, (args.vend + lane_bytes - 1) / lane_bytes, stream);
         launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);
@@ -1182,7 +1094,6 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
             pd.exact = true;
             pd.xargs = args; pd.x_lane_bytes = lane_bytes; pd.x_n_chunks = n_chunks; pd.x_g16 = g16; pd.x_sym = sym_mode; pd.x_slow = g16_slow; pd.x_ent_lds = direct_ent_lds;
             pd.x_rev_lane_bytes = is_guided(family) ? rev_lane_bytes : 0;
-        }
         }
     } else if (family == TRRE_KERNEL_STREAM_LP) {
         launch_stream_kernel(0, ent_lds, args, n_chunks, stream);
@@ -1492,7 +1403,7 @@ int finish_inner(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
     if (trace_void && was.patched && (status & (kStEditOverflow | kStNul | kStOverflow | kStDiverge)))
         fprintf(stderr, "trre: a mark + splice launch of family %d was void: status 0x%x\n", was.family, status);
     if (was.patched && (status & (kStEditOverflow | kStNul))) {
-        // record + patch: more pieces with more than 7 edits than there are overflow records (or an edit text of kilobytes); copy
+        // copy
         // form of a large table: more texts in a sub-range (or in 64 bytes of it) than its event list holds, or a NUL byte —
         // the count / emit pair
         if (status & kStEditOverflow) p->copy_form_off.store(true);      // (a property of the dictionary and its corpus: do not try again)

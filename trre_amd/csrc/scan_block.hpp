@@ -1232,109 +1232,7 @@ TRRE_HD void stream_direct_lane(const ScanArgs& a, const StreamView& T, uint32_t
     L.count = cnt;
 }
 
-// =============================================================================================
-// Record pass of the "record + patch" form of the general families (patch_block.hpp has the whole story): the count walk
-// plus, per 64-byte piece of the input, a slot that lists the transitions which do not simply emit the byte they read.
-// =============================================================================================
-constexpr int kPieceBytes = 64;
-constexpr int kSlotWords = 8;                   // 32 bytes per piece
-constexpr int kSlotEdits = 7;
-constexpr int kBlockPieces = 256;               // pieces per patch workgroup / block total
-constexpr int kGroupBlocks = 1024;              // blocks per group total (16 MiB of input: the exclusive sum runs over groups, a patch
-                                                // workgroup adds the totals of the blocks before it in its group)
-constexpr int kOvfWords = 64;                   // an overflow record: all edits of one piece (at most one per input byte)
-constexpr uint32_t kSlotWritten = 1u << 24;
-constexpr uint32_t kSlotOverflow = 255u;
-constexpr uint32_t kStEditOverflow = 1u << 6;   // the overflow records ran out: the launch is void, the count / emit pair runs instead
-
-// what the record pass and the patch pass share besides ScanArgs
-struct PatchArgs {
-    uint32_t* slots;           // [n_pieces][kSlotWords]
-    uint32_t* ovf;             // [ovf_cap][kOvfWords]
-    uint32_t* ovf_count;       // records handed out so far
-    uint32_t ovf_cap;
-    uint64_t* block_total;     // [n_blocks] output bytes of the block's pieces (record: atomics; zeroed by the runtime)
-    uint64_t* group_total;     // [n_groups] the same per GROUP of kGroupBlocks blocks (k_group_sum; a lane adding to its group's
-                               // total as well would serialise thousands of atomics on one address: measured 5x the whole pass)
-    uint64_t* group_base;      // [n_groups + 1] exclusive sum of the group totals; [n_groups] = size of the whole output
-    int64_t n_pieces;
-};
-
-#if defined(__HIP_DEVICE_COMPILE__)
-#define TRRE_ATOMIC_ADD_U64(p, v) atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)(v))
-#define TRRE_ATOMIC_INC_U32(p) atomicAdd((p), 1u)
-#else
-#define TRRE_ATOMIC_ADD_U64(p, v) (*(p) += (v))
-#define TRRE_ATOMIC_INC_U32(p) ((*(p))++)
-#endif
-
-// ---- record pass: per-lane state ------------------------------------------------------------------------------
-// stage: the lane's edits of the current piece (LDS, kRecStage words: a dword of input adds at most 4, the spill test
-// runs after every dword)
-constexpr int kRecStage = kSlotEdits + 5;
-constexpr int kRecStageStride = kRecStage + 1;   // words between two lanes' stages (13: odd, lanes in step hit distinct banks)
-struct RecState {
-    uint32_t* stage;
-    uint32_t cnt = 0;          // edits staged
-    int32_t dl = 0;            // bytes the piece's edits add
-    bool rec = false;          // the piece being walked is this lane's to record
-    bool fin = false;          // the lane's last line has ended: the lane is done at the end of this piece
-    int32_t ovf = -1;          // overflow record of the current piece
-    uint32_t ovf_n = 0;
-    int64_t acc = 0, acc_block = -1;   // output bytes of recorded pieces not yet added to their block's total
-};
-TRRE_HD void rec_spill(const PatchArgs& pa, RecState& r, uint32_t& status) {
-    if (r.ovf < 0) {
-        const uint32_t idx = TRRE_ATOMIC_INC_U32(pa.ovf_count);
-        if (idx >= pa.ovf_cap) { status |= kStEditOverflow; r.cnt = 0; return; }
-        r.ovf = (int32_t)idx;
-        r.ovf_n = 0;
-    }
-    uint32_t* dst = pa.ovf + (size_t)r.ovf * kOvfWords;
-    for (uint32_t k = 0; k < r.cnt && r.ovf_n < (uint32_t)kOvfWords; ++k) dst[r.ovf_n++] = r.stage[k];
-    r.cnt = 0;
-}
-// end of the piece at v-space offset `v`; walked: the lane was not done when the piece began; saw_eol: a record end has
-// been seen by now (the lane is past its first line start)
-TRRE_HD void rec_commit(const ScanArgs& a, const PatchArgs& pa, RecState& r, int64_t v, bool walked, bool saw_eol, uint32_t& status) {
-    if (walked && r.rec) {
-        const int64_t q = v / kPieceBytes;
-        uint32_t* slot = pa.slots + (size_t)q * kSlotWords;
-        if (r.ovf >= 0 || r.cnt > (uint32_t)kSlotEdits) {
-            rec_spill(pa, r, status);
-            slot[0] = ((uint32_t)r.dl & 0xffffu) | kSlotOverflow << 16 | kSlotWritten;
-            slot[1] = (uint32_t)r.ovf;
-            slot[2] = r.ovf_n;
-        } else {
-            U128 s0, s1;
-            s0.x = ((uint32_t)r.dl & 0xffffu) | r.cnt << 16 | kSlotWritten;
-            s0.y = r.stage[0]; s0.z = r.stage[1]; s0.w = r.stage[2];
-            s1.x = r.stage[3]; s1.y = r.stage[4]; s1.z = r.stage[5]; s1.w = r.stage[6];
-            U128* d = reinterpret_cast<U128*>(slot);
-            d[0] = s0;
-            d[1] = s1;
-        }
-        if (r.dl > 32767 || r.dl < -32768) status |= kStEditOverflow;     // (texts of kilobytes in one piece: not this path)
-        int64_t valid = a.vend - v;
-        valid = valid < 0 ? 0 : (valid > kPieceBytes ? kPieceBytes : valid);
-        const int64_t blk = q / kBlockPieces;
-        if (blk != r.acc_block) {
-            if (r.acc_block >= 0 && r.acc) TRRE_ATOMIC_ADD_U64(pa.block_total + r.acc_block, (uint64_t)r.acc);
-            r.acc_block = blk;
-            r.acc = 0;
-        }
-        r.acc += valid + r.dl;
-    }
-    r.rec = r.rec || saw_eol;
-    r.cnt = 0;
-    r.dl = 0;
-    r.ovf = -1;
-}
-TRRE_HD void rec_finish(const PatchArgs& pa, RecState& r) {
-    if (r.acc_block >= 0 && r.acc) TRRE_ATOMIC_ADD_U64(pa.block_total + r.acc_block, (uint64_t)r.acc);
-    r.acc = 0;
-}
-
+constexpr uint32_t kStEditOverflow = 1u << 6;   // a list is full (the copy form's events, a search's stack): the launch is void, another family or a larger tier runs
 
 // =============================================================================================
 // Small tables (16-byte entries, whole table in LDS): the count and emit passes written for instruction
@@ -1352,13 +1250,9 @@ TRRE_HD void rec_finish(const PatchArgs& pa, RecState& r) {
 // =============================================================================================
 // kSym: 0 columns are byte classes; 1 / 2 (guided families) columns are the symbols the backward pass left, one per
 // byte / packed two per byte (backward DFAs of at most 16 states: half the symbol traffic).
-// kMode 3: the record pass (above): `ring` is the lane's stage of kRecStage words, `pa` the slots.
-// kMode 4: the mark pass of the splice form (round 4; splice_block.hpp): the count walk, which also lists the lane's EDITS —
-// the transitions that do not simply pass on the byte they read (meta bit 11) — as 4-byte events {[15:0] the byte's position
-// in the sub-range, [31:16] the entry's index}, collected in the lane's stage (`ring`: kMarkStage dwords) and moved to its row
-// of `ca` after every 64 input bytes, plus where its first line starts and its last one ends.  The second pass copies the
-// input around the edits without walking the table again.  A NUL (the rest of its record is swallowed), more edits than the
-// lists hold or a line of more than 64 KiB void the launch (kStNul / kStEditOverflow): the count / emit pair runs.
+// (Rounds 3 and 4 had two more modes of this walk — a record pass that listed the edits of every 64-byte piece for a patch pass, and a mark
+// pass that listed a lane's edits for a wave-cooperative splice: ONE walk instead of two.  Both were correct and both lost to the count /
+// emit pair on small tables — listing the edits doubles the count walk: DESIGN.md §4.5 — and were removed in round 5.)
 struct FbCopyArgs;
 TRRE_HD uint32_t* copy_event_row(const FbCopyArgs& ca, int64_t lane);
 TRRE_HD uint32_t copy_event_cap(const FbCopyArgs& ca);
@@ -1367,9 +1261,8 @@ constexpr int kMarkStage = 16;                 // events a lane can collect per 
 constexpr int kMarkStageStride = 17;
 template <int kMode, int kSym, bool kHasSlow>
 TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, int64_t lane, int64_t lane_bytes, uint8_t* ring,
-                      uint64_t out_base, DirectLane& L, uint32_t& status, uint32_t* wave_scratch = nullptr, const PatchArgs* pa = nullptr,
-                      const FbCopyArgs* ca = nullptr) {
-    static_assert(kMode == 1 || kMode == 2 || kMode == 3 || kMode == 4, "count, emit, record or mark");
+                      uint64_t out_base, DirectLane& L, uint32_t& status, uint32_t* wave_scratch = nullptr) {
+    static_assert(kMode == 1 || kMode == 2, "count or emit");
     const uint32_t done_row = kDoneState * n_cls * 16u;
     const int64_t lo = lane * lane_bytes;
     int64_t hi = lo + lane_bytes;
@@ -1446,20 +1339,6 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
     }
     uint64_t cnt = 0;
     uint32_t seen = 0;
-    // kMode 4: the stage, the lane's row of events, its first line start and the end of its last line
-    uint32_t* const stage0 = reinterpret_cast<uint32_t*>(ring);
-    uint32_t si = 0, n_ev = 0, b_rel = 0, e_rel = 0, far = 0;
-    uint32_t* evp = nullptr;
-    if (kMode == 4) {
-        evp = copy_event_row(*ca, lane);
-        if (row != 0u && row != done_row) b_rel = (uint32_t)(first_line_start_safe(a, lo, hi) - lo);
-        if (row == done_row) b_rel = rhi;
-    }
-    RecState R;                                                      // kMode 3
-    R.stage = reinterpret_cast<uint32_t*>(ring);
-    R.rec = row == 0u;                                               // a lane that starts at a line start records from its first piece on
-    bool walked = row != done_row;                                   // the lane was not done when the current piece began
-    const uint32_t vlim = a.vend - lo > 0xffffffffll ? 0xffffffffu : (uint32_t)(a.vend - lo > 0 ? a.vend - lo : 0);   // input ends here
     const int64_t vlast = (a.vend - 1) & ~(int64_t)15;               // the last readable aligned block
     // symbols: per byte — 16 bytes per 16-byte block; packed — 16 bytes per 32 input bytes (fetched for offsets 0 and 32 of a piece)
     const int64_t slast = kSym == 2 ? (((a.vend + 127) & ~(int64_t)127) >> 1) - 16 : ((a.vend + 63) & ~(int64_t)63) - 16;
@@ -1545,90 +1424,6 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
             }
             seen |= fl;
             cnt += c;
-        } else if (kMode == 4) {
-            const uint32_t row0 = row;
-            uint32_t c = 0, fl = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t eoff = row + (kk[j] << 4);
-                const uint64_t g = *reinterpret_cast<const uint64_t*>(T.g16 + eoff);
-                const uint32_t meta = (uint32_t)(g >> 32);
-                c += meta & 7u;
-                fl |= meta;
-                uint32_t edit = (meta >> 11) & 1u;
-                if (kEnd) {
-                    // the last byte of the input ends its record whatever it holds (Q1): what the transition emits there is not
-                    // "the byte it read" unless that byte is the '\n' the walk saw
-                    edit |= (uint32_t)(rp + (uint32_t)j + 1u == vlim) & (((meta >> 10) & 1u) ^ 1u);
-                    if (rp + (uint32_t)j > 0xffffu) far |= edit;
-                }
-                stage0[si] = (rp + (uint32_t)j) | (eoff << 12);              // [15:0] position, [31:16] the entry's index
-                si = si + edit < (uint32_t)kMarkStage - 1u ? si + edit : (uint32_t)kMarkStage - 1u;   // (a full stage: the launch is void)
-                const bool fin = kEnd && (meta & 32u) && rp + (uint32_t)j + 1u >= rhi;
-                if (kEnd && fin && row != done_row) e_rel = rp + (uint32_t)j + 1u;
-                row = fin ? done_row : (uint32_t)g;
-            }
-            if (kHasSlow) {
-                if (TRRE_WAVE_ANY(fl & 128u)) {
-                    if (fl & 128u) {              // count this dword again, slow entries from their 8-byte form
-                        uint32_t r = row0;
-                        c = 0;
-                        for (int j = 0; j < 4; ++j) {
-                            const uint64_t g = *reinterpret_cast<const uint64_t*>(T.g16 + r + (kk[j] << 4));
-                            const uint32_t meta = (uint32_t)(g >> 32);
-                            c += (meta & 128u) ? slow_count(r, kk[j]) : (meta & 7u);
-                            r = (kEnd && (meta & 32u) && rp + (uint32_t)j + 1u >= rhi) ? done_row : (uint32_t)g;
-                        }
-                    }
-                }
-            }
-            seen |= fl;
-            cnt += c;
-        } else if (kMode == 3) {
-            // the count walk, and every transition that does not simply emit the byte it reads is listed as an edit of its
-            // piece: the event word is stored at the stage's fill position whatever the transition, the position moves on
-            // only for an edit (no branch)
-            const uint32_t row0 = row;
-            uint32_t fl = 0;
-            const uint32_t pbase = (rp & (uint32_t)(kPieceBytes - 1)) + 1u;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t eoff = row + (kk[j] << 4);
-                const uint64_t g = *reinterpret_cast<const uint64_t*>(T.g16 + eoff);
-                const uint32_t meta = (uint32_t)(g >> 32);
-                uint32_t edit = (meta >> 9) & 1u;
-                int32_t add = (int32_t)(meta << 8) >> 24;                // [23:16]: bytes emitted - 1
-                if (kEnd) {                                              // (the bytes after the end of the input are nobody's)
-                    const bool inside = rp + (uint32_t)j < vlim;
-                    edit = inside ? edit : 0u;
-                    add = inside ? add : 0;
-                    R.fin = R.fin || ((meta & 32u) && rp + (uint32_t)j + 1u >= rhi);
-                }
-                R.stage[R.cnt] = (pbase + (uint32_t)j) | (eoff << 5);    // [6:0] p, [31:9] the entry's index
-                R.cnt += edit;
-                R.dl += add;
-                fl |= meta;
-                row = (uint32_t)g;
-            }
-            if (kHasSlow) {
-                if (TRRE_WAVE_ANY(fl & 128u)) {
-                    if (fl & 128u) {              // slow entries count 0 above: add their texts' lengths
-                        uint32_t r = row0;
-                        for (int j = 0; j < 4; ++j) {
-                            const uint64_t g = *reinterpret_cast<const uint64_t*>(T.g16 + r + (kk[j] << 4));
-                            if (((uint32_t)(g >> 32) & 128u) && (!kEnd || rp + (uint32_t)j < vlim)) R.dl += (int32_t)slow_count(r, kk[j]);
-                            r = (uint32_t)g;
-                        }
-                    }
-                }
-            }
-            seen |= fl;
-            if (TRRE_WAVE_ANY(R.cnt > (uint32_t)kSlotEdits)) {
-                if (R.cnt > (uint32_t)kSlotEdits) {
-                    if (walked && R.rec) rec_spill(*pa, R, status);
-                    else R.cnt = 0;                                      // (a lane before its first line start, or done: nothing of this is kept)
-                }
-            }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1699,36 +1494,6 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
             row = r;
             seen2 |= fl;
             cnt += c;
-        } else if (kMode == 4) {
-            // the mark pass on pairs: an event per PAIR that holds an edit — [15:0] the position of its first byte, [31:16] 0x8000 | the
-            // pair entry's index (the splice pass reads what the two transitions emit from that entry).  A pair that begins in SKIP /
-            // DONE and holds an edit (a lane's first line start in the middle of it), or whose bytes do not fit its entry: two steps
-            const uint32_t row0 = row;
-            const uint32_t si0 = si;
-            uint32_t c = 0, fl = 0, r = row;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const uint32_t poff = r * pair_mul + ((kk[2 * h] * n_cls + kk[2 * h + 1]) << 5);
-                const uint64_t g = *reinterpret_cast<const uint64_t*>(T.p32 + poff);
-                const uint32_t meta = (uint32_t)(g >> 32);
-                c += meta & 15u;
-                fl |= meta | ((meta & (meta >> 1) & 512u) << 2);                 // (bit 11: [9] and [10] in the same pair)
-                stage0[si] = (rp + 2u * (uint32_t)h) | (0x8000u | (poff >> 5)) << 16;
-                const uint32_t edit = (meta >> 9) & 1u;
-                si = si + edit < (uint32_t)kMarkStage - 1u ? si + edit : (uint32_t)kMarkStage - 1u;
-                r = (uint32_t)g;
-            }
-            if (TRRE_WAVE_ANY(fl & (128u | 2048u))) {
-                if (fl & (128u | 2048u)) {                                        // this dword again, byte by byte
-                    row = row0;
-                    si = si0;
-                    dword(std::false_type{}, w, sw, rp);
-                    return;
-                }
-            }
-            row = r;
-            seen2 |= fl & ~2048u;
-            cnt += c;
         } else {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -1767,18 +1532,7 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
         const uint32_t y0 = kSym == 2 ? (y.x & 0xffffu) : y.x, y1 = kSym == 2 ? (y.x >> 16) : y.y,
                        y2 = kSym == 2 ? (y.y & 0xffffu) : y.z, y3 = kSym == 2 ? (y.y >> 16) : y.w;
         // (between two flushes at most 65 bytes may arrive: 8 transitions of up to 5 bytes, or 4 of up to 9 with slow entries)
-        if (kMode == 4) {
-            // (the mark pass: one copy of the step code, not four — the pair step carries the single step as its way out, and the
-            // unrolled form spilled registers)
-#pragma clang loop unroll(disable)
-            for (int d = 0; d < 4; ++d) {
-                const uint32_t w = d == 0 ? b.x : (d == 1 ? b.y : (d == 2 ? b.z : b.w));
-                const uint32_t yy = d == 0 ? y0 : (d == 1 ? y1 : (d == 2 ? y2 : y3));
-                if (!kEnd && T.p32) dword_pairs(w, yy, rp + 4u * (uint32_t)d);
-                else dword(end_tag, w, yy, rp + 4u * (uint32_t)d);
-            }
-        } else
-        if (!kEnd && T.p32 && kMode != 3) {
+        if (!kEnd && T.p32) {
             dword_pairs(b.x, y0, rp);
             if (kMode == 2 && (kHasSlow || T.p32_slow)) stage_flush<false>(S);
             dword_pairs(b.y, y1, rp + 4u);
@@ -1821,7 +1575,6 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
     };
     for (int64_t v = lo;; v += 64) {
         if (!TRRE_WAVE_ANY(row != done_row)) break;
-        if (kMode == 3) walked = row != done_row;
         const int64_t vn = v + 64;
         const int64_t x0 = vn < vlast ? vn : vlast, x1 = vn + 16 < vlast ? vn + 16 : vlast,
                       x2 = vn + 32 < vlast ? vn + 32 : vlast, x3 = vn + 48 < vlast ? vn + 48 : vlast;
@@ -1859,39 +1612,14 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
         if (exact) {
             if (rp + 64u >= rhi && row != done_row) { xrow = row; row = done_row; }     // exact sub-ranges: the lane ends at hi
         }
-        if (kMode == 3) {
-            // the piece is complete: its slot (if it is this lane's to record), and the lane ends here if its last line has ended
-            rec_commit(a, *pa, R, v, walked, (seen & 32u) != 0u, status);
-            if (R.fin) row = done_row;
-        }
-        if (kMode == 4) {
-            // the piece's events, to the end of the lane's row
-            const uint32_t n_loc = si;
-            if (n_loc >= (uint32_t)kMarkStage - 1u) far = 1;
-            for (uint32_t k = 0; TRRE_WAVE_ANY(k < n_loc); ++k)
-                if (k < n_loc && n_ev + k < copy_event_cap(*ca)) evp[k] = stage0[k];
-            evp += n_loc;
-            n_ev += n_loc;
-            si = 0;
-        }
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         if (kSym) { s0 = t0; s1 = t1; s2 = t2; s3 = t3; }
-    }
-    if (kMode == 3) rec_finish(*pa, R);
-    if (kMode == 4) {
-        if (n_ev > copy_event_cap(*ca) || far) status |= kStEditOverflow;
-        if ((seen & 8u) || (seen2 & 256u)) status |= kStNul;
-        uint32_t* hdr = copy_lane_hdr(*ca, lane);
-        hdr[0] = n_ev < copy_event_cap(*ca) ? n_ev : copy_event_cap(*ca);
-        hdr[1] = b_rel;
-        hdr[2] = b_rel < rhi ? e_rel : b_rel;          // (no line starts in the sub-range: the lane has nothing to copy)
-        hdr[3] = 0;
     }
     if (kMode == 1 && exact && lo < hi) a.exit_rows[lane] = xrow;
     if (kMode == 2) stage_flush<true>(S);
     if (kMode == 2 && a.lp_emit && ((seen & 8u) || (seen2 & 256u))) status |= kStNul;
-    if ((kMode == 1 || kMode == 3 || kMode == 4) && ((seen | seen2) & 64u)) status |= kStOverflow;            // bounded fold: the launch is void
-    if ((kMode == 1 || kMode == 3 || kMode == 4 || a.lp_emit) && ((seen | seen2) & 16u)) status |= kStDiverge;   // guided tables: the reference's search never returns
+    if (kMode == 1 && ((seen | seen2) & 64u)) status |= kStOverflow;            // bounded fold: the launch is void
+    if ((kMode == 1 || a.lp_emit) && ((seen | seen2) & 16u)) status |= kStDiverge;   // guided tables: the reference's search never returns
     L.count = cnt;
 }
 

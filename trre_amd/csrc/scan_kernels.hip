@@ -20,7 +20,6 @@
 #include <cstdlib>
 
 #include "launch.hpp"
-#include "patch_block.hpp"
 #include "scan_block.hpp"
 #include "splice_block.hpp"
 #include "gen_block.hpp"
@@ -441,7 +440,7 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_direct(ScanArgs a, in
 // Count / emit passes over the 16-byte entries of a small table (front.hpp): the whole table in LDS.
 //   smem: cls[256] | g16[g16_room] | pooled text (2 KiB, when the pool fits) | staging[threads] | 64
 template <int kMode, int kSym, bool kHasSlow>
-__global__ __launch_bounds__(kDirectThreads) void k_stream_g16(ScanArgs a, int64_t lane_bytes, int g16_room, PatchArgs pa) {
+__global__ __launch_bounds__(kDirectThreads) void k_stream_g16(ScanArgs a, int64_t lane_bytes, int g16_room) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
     for (int k = threadIdx.x; k < 256; k += kDirectThreads) smem[k] = a.blob[h.off_cls + k];
@@ -467,19 +466,15 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_g16(ScanArgs a, int64
     __syncthreads();
     T.cls = smem;
     T.g16 = smem + 256;
-    if (h.p32_bytes && !(a.dbg & 4u) && kMode != 3) { T.p32 = smem + 256 + ((h.g16_bytes + 15u) & ~15u); T.p32_slow = h.p32_slow; }   // (TRRE_EMIT_DBG=4: A/B without pairs)
+    if (h.p32_bytes && !(a.dbg & 4u)) { T.p32 = smem + 256 + ((h.g16_bytes + 15u) & ~15u); T.p32_slow = h.p32_slow; }   // (TRRE_EMIT_DBG=4: A/B without pairs)
     T.ent = reinterpret_cast<const uint64_t*>(a.blob + h.off_ent);
     T.pool = a.blob + h.off_pool;
     T.long_pool = h.max_out >= 255u;
     // (the count pass has neither pooled texts nor staging buffers in LDS: more resident waves.  With a
     // large table in global memory that does not pay: k_stream_direct's count pass is fastest at the
     // 16 waves per CU its emit-sized LDS allows — 1.63 ms against 1.9 ms at 8 or 28 waves: cache capacity)
-    // (the record pass: a stage of kRecStage words per lane instead of the rings)
-    // (the mark pass: a stage of kMarkStage events per lane)
-    uint8_t* ring = kMode == 1 ? pool_lds : (kMode == 3 ? pool_lds + threadIdx.x * (kRecStageStride * 4) : (kMode == 4 ? pool_lds + threadIdx.x * (kMarkStageStride * 4)
-                               : pool_lds + kDirectPoolSmall + threadIdx.x * kRingStride));
-    uint8_t* tail = kMode == 1 ? pool_lds : (kMode == 3 ? pool_lds + kDirectThreads * (kRecStageStride * 4) : (kMode == 4 ? pool_lds + kDirectThreads * (kMarkStageStride * 4)
-                               : pool_lds + kDirectPoolSmall + kDirectThreads * kRingStride));       // 64 bytes
+    uint8_t* ring = kMode == 1 ? pool_lds : pool_lds + kDirectPoolSmall + threadIdx.x * kRingStride;
+    uint8_t* tail = kMode == 1 ? pool_lds : pool_lds + kDirectPoolSmall + kDirectThreads * kRingStride;       // 64 bytes
     const int64_t lane = (int64_t)blockIdx.x * kDirectThreads + threadIdx.x;
     DirectLane L;
     uint32_t st = 0;
@@ -498,10 +493,21 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_g16(ScanArgs a, int64
         const int64_t block_end = ((int64_t)blockIdx.x + 1) * kDirectThreads < n_lanes ? ((int64_t)blockIdx.x + 1) * kDirectThreads : n_lanes;
         if (lane > 0 && lane < n_lanes && a.spec_flags[lane]) {
             uint32_t state = a.exit_rows[lane - 1];
+            const uint32_t skip_row = kSkipState * h.n_cls * 16u;
             for (int64_t j = lane;;) {
                 a.entry_rows[j] = state;
                 DirectLane Lj;
-                g16_lane<1, kSym, kHasSlow>(a, T, h.n_cls, j, lane_bytes, ring, 0, Lj, st, nullptr, &pa, nullptr);
+                // (behind a NUL the rest of the record is swallowed: a lane without a line end inside stays in SKIP and prints nothing — no walk)
+                if (state == skip_row && (j + 1) * lane_bytes < a.vend - 1 && !rev_has_newline(a, j * lane_bytes, (j + 1) * lane_bytes)) {
+                    a.exit_rows[j] = state;
+                    a.lane_counts[j] = 0u;
+                    ++j;
+                    if (j >= block_end || a.spec_flags[j]) break;
+                    const uint32_t e0 = a.entry_rows[j];
+                    if ((e0 & 1u) || (e0 & ~1u) == state) break;
+                    continue;
+                }
+                g16_lane<1, kSym, kHasSlow>(a, T, h.n_cls, j, lane_bytes, ring, 0, Lj, st);
                 if (Lj.count > 0xffffffffull) { st |= kStCapacity; Lj.count = 0xffffffffull; }
                 a.lane_counts[j] = (uint32_t)Lj.count;
                 if (kSym != 0 && (st & kStDiverge)) atomicMax(a.status + 1, 0xffffffffu - (uint32_t)j);
@@ -530,13 +536,11 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_g16(ScanArgs a, int64
         }
     }
     uint32_t* wsc = reinterpret_cast<uint32_t*>(tail + 64) + (threadIdx.x / kWave) * (kWaveScratchBytes / 4);
-    // (the mark pass's events and lane headers travel in `pa`: slots = the event rows, ovf = the headers, ovf_cap = events per row)
-    const FbCopyArgs ca{pa.slots, pa.ovf, pa.ovf_cap};
     if (!(kMode == 1 && a.exact == 3u)) {
-        g16_lane<kMode, kSym, kHasSlow>(a, T, h.n_cls, lane, lane_bytes, ring, base, L, st, kMode == 2 ? wsc : nullptr, &pa, &ca);
+        g16_lane<kMode, kSym, kHasSlow>(a, T, h.n_cls, lane, lane_bytes, ring, base, L, st, kMode == 2 ? wsc : nullptr);
         if (kMode == 1 && kSym != 0 && (st & kStDiverge)) atomicMax(a.status + 1, 0xffffffffu - (uint32_t)lane);     // (see k_stream_direct)
     }
-    if (kMode == 1 || kMode == 4) {
+    if (kMode == 1) {
         uint64_t* part = reinterpret_cast<uint64_t*>(tail);
         if (L.count > 0xffffffffull) { st |= kStCapacity; L.count = 0xffffffffull; }
         a.lane_counts[lane] = (uint32_t)L.count;
@@ -551,109 +555,6 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_g16(ScanArgs a, int64
     }
     st = wave_or(st);
     if (st && (threadIdx.x & (kWave - 1)) == 0) atomicOr(a.status, st);
-}
-
-// Patch pass of the record + patch form (patch_block.hpp): one workgroup per block of 256 pieces (16 KiB of input), one
-// thread per piece.  No table walk: slots and input in, the pieces' output offsets by a prefix sum, texts and copied bytes
-// into an LDS tile, the tile out in aligned 16-byte rows.
-//   smem: input rows[256 x 68] | slots[256 x 32] | output tile | wave partials
-constexpr int kPatchThreads = kBlockPieces;
-constexpr int kPatchSlotsOff = kPatchInBytes;
-constexpr int kPatchOutOff = kPatchSlotsOff + kBlockPieces * kSlotWords * 4;
-constexpr int kPatchRedOff = kPatchOutOff + kPatchOutBytes;
-constexpr int kPatchTabOff = kPatchRedOff + 64;
-constexpr int kPatchTabMax = 8192;             // the 16-byte entries ride along in LDS when they are this small (else L1 / L2)
-constexpr int kPatchLds = kPatchTabOff;
-__global__ __launch_bounds__(kPatchThreads) void k_patch(ScanArgs a, PatchArgs pa, int tab_bytes) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t* tin = smem;
-    uint32_t* tslot = reinterpret_cast<uint32_t*>(smem + kPatchSlotsOff);
-    uint8_t* tout = smem + kPatchOutOff;
-    uint32_t* wpart = reinterpret_cast<uint32_t*>(smem + kPatchRedOff);
-    const int tid = threadIdx.x;
-    const int64_t q = (int64_t)blockIdx.x * kBlockPieces + tid;
-    // the piece's slot (32 bytes per thread: coalesced) and its size
-    U128 s0{}, s1{};
-    if (q < pa.n_pieces) {
-        const U128* sp = reinterpret_cast<const U128*>(pa.slots + (size_t)q * kSlotWords);
-        s0 = sp[0];
-        s1 = sp[1];
-    }
-    reinterpret_cast<U128*>(tslot + tid * kSlotWords)[0] = s0;
-    reinterpret_cast<U128*>(tslot + tid * kSlotWords)[1] = s1;
-    int64_t valid64 = a.vend - q * kPieceBytes;
-    const uint32_t valid = (s0.x & kSlotWritten) ? (uint32_t)(valid64 < 0 ? 0 : (valid64 > kPieceBytes ? kPieceBytes : valid64)) : 0u;
-    const uint32_t mine = (s0.x & kSlotWritten) ? (uint32_t)((int32_t)valid + (int32_t)(int16_t)(s0.x & 0xffffu)) : 0u;
-    const uint32_t incl = wave_scan_incl(mine);
-    if ((tid & (kWave - 1)) == kWave - 1) wpart[tid / kWave] = incl;
-    // the block's input: 16 bytes per thread and step, rows 68 bytes apart
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = tid + kPatchThreads * i;
-        const int piece = c >> 2, part = c & 3;
-        const U128 w = direct_load(a, ((int64_t)blockIdx.x * kBlockPieces + piece) * kPieceBytes + part * 16);
-        uint32_t* d = reinterpret_cast<uint32_t*>(tin + piece * kPatchInStride + part * 16);
-        d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
-    }
-    __syncthreads();
-    uint32_t wbase = 0, total = 0;
-    for (int w = 0; w < kPatchThreads / kWave; ++w) { if (w < tid / kWave) wbase += wpart[w]; total += wpart[w]; }
-    const uint32_t rel = wbase + incl - mine;
-    // where the block's output starts: its group's base + the totals of the blocks before it in the group
-    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
-    const int64_t g0 = (int64_t)(blockIdx.x / kGroupBlocks) * kGroupBlocks;
-    uint64_t before = 0;
-    for (int64_t j = g0 + tid; j < (int64_t)blockIdx.x; j += kPatchThreads) before += pa.block_total[j];
-    before = wave_sum(before);
-    uint64_t* bpart = reinterpret_cast<uint64_t*>(smem + kPatchRedOff + 16);
-    if ((tid & (kWave - 1)) == 0) bpart[tid / kWave] = before;
-    if (tab_bytes) {                                  // (the table of the edits' texts)
-        const U128* e = reinterpret_cast<const U128*>(a.blob + h.off_g16);
-        U128* d = reinterpret_cast<U128*>(smem + kPatchTabOff);
-        for (int k = tid; k < tab_bytes / 16; k += kPatchThreads) d[k] = e[k];
-    }
-    __syncthreads();
-    uint64_t base = pa.group_base[blockIdx.x / kGroupBlocks];
-    for (int w = 0; w < kPatchThreads / kWave; ++w) base += bpart[w];
-    if (base + total > a.cap) {                       // uniform for the workgroup
-        if (tid == 0) atomicOr(a.status, kStCapacity);
-        return;
-    }
-    const uint32_t L0 = (uint32_t)((reinterpret_cast<uintptr_t>(a.out) + base) & 63u);
-    const bool direct = L0 + total > (uint32_t)kPatchOutLogical;
-    uint8_t* out0 = a.out + base - L0;                // address of logical offset 0
-    PatchTables T;
-    T.g16 = a.blob + h.off_g16;
-    T.ent = reinterpret_cast<const uint64_t*>(a.blob + h.off_ent);
-    T.pool = a.blob + h.off_pool;
-    const bool written = (s0.x & kSlotWritten) != 0;
-    const uint8_t* in_row = tin + tid * kPatchInStride;
-    const uint32_t* slot = tslot + tid * kSlotWords;
-    if (direct) {
-        // (the block's output does not fit the tile: every byte straight to memory)
-        const MemSink S{out0};
-        if (written) patch_piece_any(pa, T, S, in_row, valid, slot, L0 + rel);
-        return;
-    }
-    const TileSink S{tout};
-    bool done = !written;
-    if (written) done = tab_bytes ? patch_piece(T, smem + kPatchTabOff, S, in_row, valid, slot, L0 + rel) : patch_piece(T, T.g16, S, in_row, valid, slot, L0 + rel);
-    if (__any(!done)) {
-        if (!done) patch_piece_any(pa, T, S, in_row, valid, slot, L0 + rel);
-    }
-    __syncthreads();
-    // the tile goes out: aligned 16-byte rows, the ragged ends byte by byte (the neighbouring blocks write their own bytes of
-    // those rows)
-    const uint32_t end = L0 + total;
-    for (uint32_t lo = (uint32_t)tid * 16u; lo < end; lo += kPatchThreads * 16u) {
-        if (lo >= L0 && lo + 16u <= end) {
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(tout + patch_phys(lo));
-            *reinterpret_cast<U128*>(out0 + lo) = U128{src[0], src[1], src[2], src[3]};
-        } else {
-            for (uint32_t k = 0; k < 16u; ++k)
-                if (lo + k >= L0 && lo + k < end) out0[lo + k] = tout[patch_phys(lo + k)];
-        }
-    }
 }
 
 // Count / emit passes over the fallback form of a large table (front.hpp, scan_block.hpp: fb_lane): the comb of entries
@@ -935,61 +836,7 @@ __global__ __launch_bounds__(kThreads) void k_fb_splice(ScanArgs a, FbCopyArgs c
     const SpliceLds L{carve + wave * kSpLdsPerWave};
     // (the chunk's waves take neighbouring sub-ranges at the same time: neighbouring lines of the output)
     const SpliceWork W{lane0 + gwave, kDirectThreads / kWave, kWave, sbase + group * kDirectThreads + gwave, kDirectThreads / kWave};
-    fb_splice_ranges<false, 2>(a, T, ca, W, lane_bytes, L);
-}
-// The same second pass for SMALL tables (the 16-byte entries; mark pass: k_stream_g16<4>): an edit names the entry of its
-// transition.  The entries are looked up in LDS when the table is at most 8 KiB, in memory otherwise (edits are sparse where
-// this pays).   smem: entries (or nothing) | output bases of the sub-ranges (u64) | 64 per chunk | the per-wave carves
-constexpr int kSpliceTabMax = 8192;
-template <int kThreads>
-__global__ __launch_bounds__(kThreads) void k_g16_splice(ScanArgs a, FbCopyArgs ca, int64_t lane_bytes, int64_t n_chunks, int tab_bytes) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
-    const int g16_room = tab_bytes ? (int)((h.g16_bytes + 15u) & ~15u) : 0;     // (tab_bytes: the 16-byte entries and, behind them, the pair form)
-    {
-        const U128* e = reinterpret_cast<const U128*>(a.blob + h.off_g16);
-        U128* d = reinterpret_cast<U128*>(smem);
-        for (int k = threadIdx.x; k < g16_room / 16; k += kThreads) d[k] = e[k];
-        e = reinterpret_cast<const U128*>(a.blob + h.off_p32);
-        d = reinterpret_cast<U128*>(smem + g16_room);
-        for (int k = threadIdx.x; k < (tab_bytes - g16_room) / 16; k += kThreads) d[k] = e[k];
-    }
-    constexpr int kGroups = kThreads / kDirectThreads;
-    uint64_t* sbase = reinterpret_cast<uint64_t*>(smem + tab_bytes);
-    uint32_t* wparts = reinterpret_cast<uint32_t*>(sbase + kThreads);
-    uint8_t* carve = reinterpret_cast<uint8_t*>(wparts + 16 * kGroups);
-    const int group = threadIdx.x / kDirectThreads, gtid = threadIdx.x % kDirectThreads;
-    const int64_t chunk = (int64_t)blockIdx.x * kGroups + group;
-    const bool live = chunk < n_chunks;
-    const int64_t lane0 = chunk * kDirectThreads;
-    uint32_t* wpart = wparts + 16 * group;
-    const uint32_t mine = live ? a.lane_counts[lane0 + gtid] : 0u;
-    const uint32_t incl = wave_scan_incl(mine);
-    if ((threadIdx.x & (kWave - 1)) == kWave - 1) wpart[gtid / kWave] = incl;
-    __syncthreads();
-    uint32_t wbase = 0;
-    for (int w = 0; w < gtid / kWave; ++w) wbase += wpart[w];
-    sbase[threadIdx.x] = live ? a.chunk_base[chunk] + wbase + incl - mine : 0ull;
-    const int64_t last = ((int64_t)blockIdx.x + 1) * kGroups - 1 < n_chunks - 1 ? ((int64_t)blockIdx.x + 1) * kGroups - 1 : n_chunks - 1;
-    if (a.chunk_base[last] + a.chunk_total[last] > a.cap) {               // (uniform for the workgroup)
-        if (threadIdx.x == 0) atomicOr(a.status, kStCapacity);
-        return;
-    }
-    // a void launch (a NUL, more edits than a row holds, a bounded fold that overflowed, an attempt that does not return):
-    // nothing is written, finish() runs the count / emit pair
-    if (*a.status & (kStEditOverflow | kStNul | kStOverflow | kStDiverge)) return;
-    __syncthreads();
-    if (!live) return;
-    SpliceTables T;
-    T.g16 = tab_bytes ? smem : a.blob + h.off_g16;
-    T.p32 = tab_bytes ? smem + g16_room : a.blob + h.off_p32;
-    T.ent8 = reinterpret_cast<const uint64_t*>(a.blob + h.off_ent);
-    T.pool = a.blob + h.off_pool;
-    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x / kWave);
-    const int gwave = wave % (kDirectThreads / kWave);
-    const SpliceLds L{carve + wave * kSpLdsPerWave};
-    const SpliceWork W{lane0 + gwave, kDirectThreads / kWave, kWave, sbase + group * kDirectThreads + gwave, kDirectThreads / kWave};
-    fb_splice_ranges<true, 1>(a, T, ca, W, lane_bytes, L);
+    fb_splice_ranges<2>(a, T, ca, W, lane_bytes, L);
 }
 // Generator modes (gen_block.hpp): count / emit passes of the enumeration, a lane per sub-range of lane_bytes.  Lanes are
 // numbered as everywhere (256 per chunk of the workspace).
@@ -1456,30 +1303,20 @@ void launch_direct_t(bool ent_lds, const ScanArgs& a, int64_t lane_bytes, int64_
 int direct_ent_lds_bytes() { return kDirectEntBytes; }
 int direct_block_threads() { return kDirectThreads; }
 template <int kSym, bool kHasSlow>
-void launch_g16(int which, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, hipStream_t s, int g16_bytes, const PatchArgs* pa) {
+void launch_g16(int which, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, hipStream_t s, int g16_bytes) {
     const int room = (g16_bytes + 15) / 16 * 16;
     const int lds = 256 + room + kDirectPoolSmall + kDirectThreads * kRingStride + 64 + kDirectWsc;
     const int lds_count = 256 + room + 64;
-    const int lds_rec = 256 + room + kDirectThreads * kRecStageStride * 4 + 64 + kDirectWsc;
-    const int lds_mark = 256 + room + kDirectThreads * kMarkStageStride * 4 + 64 + kDirectWsc;
     allow_big_lds<&k_stream_g16<1, kSym, kHasSlow>>();
     allow_big_lds<&k_stream_g16<2, kSym, kHasSlow>>();
-    allow_big_lds<&k_stream_g16<3, kSym, kHasSlow>>();
-    const PatchArgs none{};
-    if (which == 1) hipLaunchKernelGGL((k_stream_g16<1, kSym, kHasSlow>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds_count, s, a, lane_bytes, room, none);
-    else if (which == 3) hipLaunchKernelGGL((k_stream_g16<3, kSym, kHasSlow>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds_rec, s, a, lane_bytes, room, *pa);
-    else if (which == 4) {
-        allow_big_lds<&k_stream_g16<4, kSym, kHasSlow>>();
-        hipLaunchKernelGGL((k_stream_g16<4, kSym, kHasSlow>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds_mark, s, a, lane_bytes, room, *pa);
-    }
-    else hipLaunchKernelGGL((k_stream_g16<2, kSym, kHasSlow>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds, s, a, lane_bytes, room, none);
+    if (which == 1) hipLaunchKernelGGL((k_stream_g16<1, kSym, kHasSlow>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds_count, s, a, lane_bytes, room);
+    else hipLaunchKernelGGL((k_stream_g16<2, kSym, kHasSlow>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds, s, a, lane_bytes, room);
 }
 template <int kSym>
-void launch_direct_sym(int which, bool ent_in_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, hipStream_t s, int g16_bytes, bool g16_slow,
-                       const PatchArgs* pa) {
+void launch_direct_sym(int which, bool ent_in_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, hipStream_t s, int g16_bytes, bool g16_slow) {
     if (g16_bytes > 0 && which != 0) {
-        if (g16_slow) launch_g16<kSym, true>(which, a, lane_bytes, n_blocks, s, g16_bytes, pa);
-        else launch_g16<kSym, false>(which, a, lane_bytes, n_blocks, s, g16_bytes, pa);
+        if (g16_slow) launch_g16<kSym, true>(which, a, lane_bytes, n_blocks, s, g16_bytes);
+        else launch_g16<kSym, false>(which, a, lane_bytes, n_blocks, s, g16_bytes);
         return;
     }
     constexpr bool kS = kSym != 0;       // (the 8-byte-entry walkers know one symbol per byte only: the runtime packs symbols for 16-byte tables)
@@ -1488,34 +1325,11 @@ void launch_direct_sym(int which, bool ent_in_lds, const ScanArgs& a, int64_t la
     else launch_direct_t<2, kS>(ent_in_lds, a, lane_bytes, n_blocks, s);
 }
 void launch_direct_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, void* stream, int g16_bytes, int sym,
-                          bool g16_slow, const PatchArgs* pa) {
+                          bool g16_slow) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (sym == 2 && g16_bytes > 0 && which != 0) launch_direct_sym<2>(which, ent_in_lds, a, lane_bytes, n_blocks, s, g16_bytes, g16_slow, pa);
-    else if (sym) launch_direct_sym<1>(which, ent_in_lds, a, lane_bytes, n_blocks, s, g16_bytes, g16_slow, pa);
-    else launch_direct_sym<0>(which, ent_in_lds, a, lane_bytes, n_blocks, s, g16_bytes, g16_slow, pa);
-}
-
-// totals of the groups of kGroupBlocks blocks (one workgroup per group)
-__global__ __launch_bounds__(256) void k_group_sum(const uint64_t* block_total, uint64_t* group_total, int64_t n_blocks) {
-    __shared__ uint64_t part[4];
-    const int64_t lo = (int64_t)blockIdx.x * kGroupBlocks, hi = lo + kGroupBlocks < n_blocks ? lo + kGroupBlocks : n_blocks;
-    uint64_t s = 0;
-    for (int64_t j = lo + threadIdx.x; j < hi; j += 256) s += block_total[j];
-    s = wave_sum(s);
-    if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) group_total[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
-}
-void launch_group_sum(const uint64_t* block_total, uint64_t* group_total, int64_t n_blocks, void* stream) {
-    const int64_t n_groups = (n_blocks + kGroupBlocks - 1) / kGroupBlocks;
-    hipLaunchKernelGGL(k_group_sum, dim3((unsigned)n_groups), dim3(256), 0, static_cast<hipStream_t>(stream), block_total, group_total, n_blocks);
-}
-
-// patch pass (patch_block.hpp): one workgroup per block of 256 pieces
-void launch_patch(const ScanArgs& a, const PatchArgs& pa, int64_t n_blocks, int g16_bytes, void* stream) {
-    allow_big_lds<&k_patch>();
-    const int tab = g16_bytes <= kPatchTabMax ? (g16_bytes + 15) / 16 * 16 : 0;
-    hipLaunchKernelGGL(k_patch, dim3((unsigned)n_blocks), dim3(kPatchThreads), kPatchLds + tab, static_cast<hipStream_t>(stream), a, pa, tab);
+    if (sym == 2 && g16_bytes > 0 && which != 0) launch_direct_sym<2>(which, ent_in_lds, a, lane_bytes, n_blocks, s, g16_bytes, g16_slow);
+    else if (sym) launch_direct_sym<1>(which, ent_in_lds, a, lane_bytes, n_blocks, s, g16_bytes, g16_slow);
+    else launch_direct_sym<0>(which, ent_in_lds, a, lane_bytes, n_blocks, s, g16_bytes, g16_slow);
 }
 
 // ---- backward pass of the guided families: one symbol per input byte (rev_sweep_lane) -------------------
@@ -1697,14 +1511,6 @@ void launch_fb_splice(const ScanArgs& a, const FbCopyArgs& ca, const void* hdr, 
     }
 }
 bool fb_splice_fits(const void* hdr) { return fb_splice_lds(*static_cast<const StreamBlobHeader*>(hdr), 512, false) <= kLdsLimit; }
-void launch_g16_splice(const ScanArgs& a, const FbCopyArgs& ca, int g16_bytes, int p32_bytes, int64_t lane_bytes, int64_t n_chunks, void* stream) {
-    const int both = (g16_bytes + 15) / 16 * 16 + (p32_bytes + 15) / 16 * 16;
-    const int tab = both <= kSpliceTabMax ? both : 0;
-    constexpr int kT = 512;
-    const int lds = tab + kT * 8 + 64 * (kT / kDirectThreads) + (kT / kWave) * (int)kSpLdsPerWave;
-    allow_big_lds<&k_g16_splice<kT>>();
-    hipLaunchKernelGGL(k_g16_splice<kT>, dim3((unsigned)((n_chunks + 1) / 2)), dim3(kT), lds, static_cast<hipStream_t>(stream), a, ca, lane_bytes, n_chunks, tab);
-}
 void launch_gen(int which, const ScanArgs& a, const GenArgs& ga, int64_t lane_bytes, int64_t n_chunks, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (which == 1) hipLaunchKernelGGL(k_gen<1>, dim3((unsigned)n_chunks), dim3(kGenThreads), 0, s, a, ga, lane_bytes);

@@ -100,19 +100,15 @@ TRRE_HD uint32_t sp_ctz64(uint64_t x) {
 #endif
 }
 
-// what the edits' texts are looked up in.  Large tables (the copy form, scan_block.hpp: fb_lane<3>): an edit names a literal
-// {text, length, input bytes it stands for} or an escape record.  Small tables (the mark pass of g16_lane): an edit names the
-// 16-byte entry of the transition, which stands for the one byte it read and emits the entry's bytes around that byte (or,
-// "slow" entries, a pooled text).
+// what the edits' texts are looked up in (the copy form of a large table, scan_block.hpp: fb_lane<3> / fb_mark4_lane): an edit names a
+// literal {text, length, input bytes it stands for} or an escape record.  (Round 4 also spliced SMALL tables' edits — an edit named the
+// 16-byte entry of its transition; removed in round 5: DESIGN.md §4.5a.)
 struct SpliceTables {
     const U128* lit = nullptr;          // [fb_lits] {text lo, text hi, n | kb << 8, -}  (LDS), or null: ...
     const uint64_t* lit_text = nullptr; // ... the texts and their {n | kb << 8} from memory (the table stays in L1 / L2: more LDS for tiles)
     const uint16_t* lit_meta = nullptr;
     const uint32_t* esc = nullptr;      // escape records (global) ...
-    const uint8_t* pool = nullptr;      // ... and their texts; small tables: the pool of the 8-byte entries
-    const uint8_t* g16 = nullptr;       // small tables: the 16-byte entries (LDS or global)
-    const uint64_t* ent8 = nullptr;     // ... and the 8-byte ones (global; slow entries only)
-    const uint8_t* p32 = nullptr;       // ... and the pair form (an edit of the mark pass's pair steps names a pair entry: id bit 15)
+    const uint8_t* pool = nullptr;      // ... and their texts
 };
 
 struct SpliceLds {            // one wave's share of the workgroup's LDS (kSpLdsPerWave bytes, 16-byte aligned)
@@ -156,7 +152,7 @@ TRRE_HD SpliceSub splice_open(const ScanArgs& a, const FbCopyArgs& ca, const Spl
 // a.dbg & 1: no global stores (timing experiments).
 // kBatches: edits per lane and window (2: 128 edits per window, the dictionary's density; 1: sparse edits — the window's
 // fixed costs, two prefix sums and a phase B per batch, are paid once)
-template <bool kG16, int kBatches = 2>
+template <int kBatches = 2>
 TRRE_HD void fb_splice_ranges(const ScanArgs& a, const SpliceTables& T, const FbCopyArgs& ca, const SpliceWork& W, int64_t lane_bytes,
                               const SpliceLds& L) {
     uint8_t* const tin = L.tin();
@@ -227,35 +223,7 @@ TRRE_HD void fb_splice_ranges(const ScanArgs& a, const SpliceTables& T, const Fb
         SP(fp) = 0xffffffffu; SP(n) = 0; SP(kb) = 0; SP(tlo) = 0; SP(thi) = 0; SP(ex) = 0;                      \
         if (SP(raw) != 0xffffffffu) {                                                                             \
             const uint32_t id = SP(raw) >> 16, p = SP(raw) & 0xffffu;                                             \
-            if (kG16) {                                   /* the transition's entry; it stands for the byte it read */ \
-                int32_t ci = 16 + (int32_t)(lo + (int64_t)p - tin0);                                              \
-                ci = ci < 0 ? 0 : (ci > (int32_t)kSpIn + 14 ? (int32_t)kSpIn + 14 : ci);   /* (an edit beyond the window: looked at again there) */ \
-                const uint32_t c = tin[ci];                                                                       \
-                const U128 e = (id & 0x8000u) ? *reinterpret_cast<const U128*>(T.p32 + 32u * (id & 0x7fffu))      \
-                                              : *reinterpret_cast<const U128*>(T.g16 + 16u * id);                 \
-                SP(kb) = 1u; SP(fp) = p;                                                                          \
-                if (id & 0x8000u) {                       /* a pair step: both transitions, two input bytes */    \
-                    const uint64_t e2 = *reinterpret_cast<const uint64_t*>(T.p32 + 32u * (id & 0x7fffu) + 16u);   \
-                    const uint32_t ws = c | (uint32_t)tin[ci + 1] << 8;                                           \
-                    SP(tlo) = perm_b32(ws, e.z, e.w); SP(thi) = perm_b32(ws, (uint32_t)e2, (uint32_t)(e2 >> 32)); \
-                    SP(n) = e.y & 15u; SP(kb) = 2u;                                                               \
-                } else if (!(e.y & 128u)) {                                                                       \
-                    SP(tlo) = perm_b32(c, e.z, e.w); SP(n) = e.y & 7u;                                            \
-                } else {                                  /* more than 4 bytes, or a pooled text (rare) */        \
-                    const uint64_t e8 = T.ent8[id];                                                               \
-                    const uint32_t l8 = (uint32_t)e8, h8 = (uint32_t)(e8 >> 32), ol = (l8 >> 24) & 7u, cc = (l8 >> 27) & 1u; \
-                    if (ol != 7u) {                                                                               \
-                        SP(tlo) = ol < 4u ? (h8 | (cc ? c << (8u * ol) : 0u)) : h8;                               \
-                        SP(thi) = ol == 4u && cc ? c : 0u;                                                        \
-                        SP(n) = ol + cc;                                                                          \
-                    } else {                                                                                      \
-                        const uint32_t off = (h8 & 0xffffffu) << 2;                                               \
-                        uint32_t len = h8 >> 24;                                                                  \
-                        if (len == 255u) len = *reinterpret_cast<const uint32_t*>(T.pool + off);                  \
-                        SP(ex) = 1u + off + 4u; SP(n) = len + cc; SP(tlo) = c; SP(thi) = cc;                      \
-                    }                                                                                             \
-                }                                                                                                 \
-            } else if (!(id & 0x8000u)) {                                                                         \
+            if (!(id & 0x8000u)) {                                                                                \
                 U128 r;                                                                                           \
                 if (T.lit) r = T.lit[id];                                                                         \
                 else { const uint64_t tx = T.lit_text[id]; r.x = (uint32_t)tx; r.y = (uint32_t)(tx >> 32); r.z = T.lit_meta[id]; r.w = 0; } \
@@ -266,7 +234,6 @@ TRRE_HD void fb_splice_ranges(const ScanArgs& a, const SpliceTables& T, const Fb
             }                                                                                                     \
         }                                                                                                         \
         SP(cum) = (SP(fp) < w1 && SP(n) > SP(kb)) ? (int32_t)(SP(n) - SP(kb)) : 0;
-        SP_WAVE_SYNC();                                                                  // (the staged input is looked at: kG16)
         SP_FOR {
             SP_DECODE(praw0, fp0, n0, kb0, tlo0, thi0, esc0, cum0)
             if (kB2) { SP_DECODE(praw1, fp1, n1, kb1, tlo1, thi1, esc1, cum1) }
@@ -426,20 +393,15 @@ TRRE_HD void fb_splice_ranges(const ScanArgs& a, const SpliceTables& T, const Fb
         if (escmask0 | escmask1) {                                                       // texts from memory (rare; they may be longer than 8 bytes)
             SP_WAVE_SYNC();
             SP_FOR {
-                // (kG16: thi = 1: the text is followed by the input byte, kept in tlo)
                 if (SP_LANE < m0 && SP(esc0)) {
                     const uint8_t* text = T.pool + (SP(esc0) - 1u);
                     uint8_t* t = tout + oa + (uint32_t)SP(P0);
-                    const uint32_t nt = kG16 ? SP(n0) - SP(thi0) : SP(n0);
-                    for (uint32_t i = 0; i < nt; ++i) t[i] = text[i];
-                    if (kG16 && SP(thi0)) t[nt] = (uint8_t)SP(tlo0);
+                    for (uint32_t i = 0; i < SP(n0); ++i) t[i] = text[i];
                 }
                 if (kB2 && SP_LANE < m1 && SP(esc1)) {
                     const uint8_t* text = T.pool + (SP(esc1) - 1u);
                     uint8_t* t = tout + oa + (uint32_t)SP(P1);
-                    const uint32_t nt = kG16 ? SP(n1) - SP(thi1) : SP(n1);
-                    for (uint32_t i = 0; i < nt; ++i) t[i] = text[i];
-                    if (kG16 && SP(thi1)) t[nt] = (uint8_t)SP(tlo1);
+                    for (uint32_t i = 0; i < SP(n1); ++i) t[i] = text[i];
                 }
             }
         }
