@@ -14,11 +14,11 @@ PY
 ls -la $f
 for env in "" "TRRE_NO_PINNED_DIRECT=1" "TRRE_CLI_BLOCK=67108864" "TRRE_CLI_BLOCK=1073741824"; do
   for rep in 1 2; do
-    /usr/bin/time -f "%e s wall  %U user %S sys  ($env)" env TRRE_TRACE=1 $env trre_amd/bin/trre_dft '[a:A-z:Z]' $f > /dev/null
+    echo "## $env"; ( time env TRRE_TRACE=1 $env trre_amd/bin/trre_dft '[a:A-z:Z]' $f > /dev/null ) 2>&1 | grep -v "^$\|^user\|^sys"
   done
 done
 echo "--- pipe"
-/usr/bin/time -f "%e s wall (cat | trre_dft)" bash -c "cat $f | TRRE_TRACE=1 trre_amd/bin/trre_dft '[a:A-z:Z]' > /dev/null"
+( time bash -c "cat $f | TRRE_TRACE=1 trre_amd/bin/trre_dft '[a:A-z:Z]' > /dev/null" ) 2>&1 | grep -v "^$\|^user\|^sys"
 echo "--- reference read speed: cat to /dev/null, dd"
-/usr/bin/time -f "%e s wall (cat > /dev/null)" cat $f > /dev/null
+( time cat $f > /dev/null ) 2>&1 | grep real
 rm -f $f

@@ -10,19 +10,21 @@
 // yet" like the reference (trre_dft.c:1227-1229).
 //
 // Like the reference's getline loop (trre_nft.c:776-790) the input is streamed, neither the input nor the output has to
-// fit in host memory — as a three-stage pipeline (round 5; round 4 read, scanned and wrote one block after the other):
-//   reader   fills block buffers: a regular file by parallel pread()s (one thread moves ~6 GB/s out of the page cache, the link
-//            takes 28 each way), a pipe or a terminal by read() — whatever has arrived goes on as soon as it ends in a '\n', so
-//            that an interactive producer sees its lines answered (the reference prints per getline);
-//   scan     every block is cut after its last '\n' (the rest is carried into the next block) and scanned line-sharded on all
-//            visible GPUs (trre_scan_host_multi).  The block buffers are pinned (hipHostMalloc): the library sends them over the
-//            link as they are, without its staging copies;
-//   writer   write()s the finished blocks in order.
-// Buffers are reused, never zero-filled, and sized by the input (a 1 MB file does not pin 256 MiB).  TRRE_DEVICES=<mask>
-// restricts the GPUs used, TRRE_CLI_BLOCK=<bytes> sets the block size (default 256 MiB).
+// fit in host memory — as a pipeline (round 5; round 4 read, scanned and wrote one block after the other):
+//   input    a regular file is MAPPED and handed to the scan block by block as it lies in the page cache: no read(), no copy of the
+//            input on the host but the library's own staging copy into pinned memory (a thread ahead of the scan touches the next
+//            block's pages).  A pipe or a terminal is read() into block buffers — whatever has arrived goes on as soon as it ends
+//            in a '\n', so that an interactive producer sees its lines answered (the reference prints per getline);
+//   scan     every block is cut after its last '\n' (the rest goes with the next block) and scanned line-sharded on all visible
+//            GPUs (trre_scan_host_multi);
+//   writer   write()s the finished blocks in order while the next one is scanned.
+// Buffers are reused, never zero-filled, sized by the input, and NOT pinned: pinning costs a second per gigabyte on this platform
+// (measured: five pinned 256 MiB blocks took 1.1-1.4 s of a 1.3 s run; the library pins its 32 MiB staging slots once).
+// TRRE_DEVICES=<mask> restricts the GPUs used, TRRE_CLI_BLOCK=<bytes> sets the block size (default 256 MiB), TRRE_TRACE=1 says
+// where the time went.
 #include <fcntl.h>
-#include <hip/hip_runtime_api.h>
 #include <poll.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -45,31 +47,25 @@
 
 namespace {
 
-// a buffer the link can read and write directly; plain memory when there is no device to pin it for (the scan will say so)
+// a block of input or output: a buffer of its own (reused, never zero-filled), or a window of the mapped input file
 struct Block {
     uint8_t* p = nullptr;
     size_t cap = 0;
-    bool pinned = false;
+    bool mapped = false;   // p points into the mapping: nothing to free
     size_t n = 0;          // bytes that go to the scan (whole records)
     size_t have = 0;       // bytes filled (n + the carried partial line)
     bool last = false;
     void reserve(size_t want) {
-        if (cap >= want) return;
-        uint8_t* q = nullptr;
-        bool pin = hipHostMalloc(reinterpret_cast<void**>(&q), want, hipHostMallocDefault) == hipSuccess;
-        if (!pin) {
-            (void)hipGetLastError();
-            q = static_cast<uint8_t*>(std::malloc(want));
-            if (!q) { std::fprintf(stderr, "error: out of memory\n"); std::_Exit(EXIT_FAILURE); }
-        }
-        if (p && have) std::memcpy(q, p, have);
+        if (!mapped && cap >= want) return;
+        uint8_t* q = static_cast<uint8_t*>(std::malloc(want));
+        if (!q) { std::fprintf(stderr, "error: out of memory\n"); std::_Exit(EXIT_FAILURE); }
+        if (!mapped && p && have) std::memcpy(q, p, have);
         release();
-        p = q; cap = want; pinned = pin;
+        p = q; cap = want; mapped = false;
     }
     void release() {
-        if (!p) return;
-        if (pinned) (void)hipHostFree(p); else std::free(p);
-        p = nullptr; cap = 0;
+        if (p && !mapped) std::free(p);
+        p = nullptr; cap = 0; mapped = false;
     }
 };
 
@@ -103,36 +99,6 @@ bool write_all(int fd, const uint8_t* p, size_t n) {
         p += k; n -= (size_t)k;
     }
     return true;
-}
-
-// [off, off + len) of a regular file into dst, a few threads at a time
-bool pread_parallel(int fd, uint8_t* dst, off_t off, size_t len) {
-    const size_t piece = (size_t)16 << 20;
-    const int ways = (int)std::min<size_t>(8, (len + piece - 1) / piece);
-    if (ways <= 1) {
-        for (size_t got = 0; got < len;) {
-            const ssize_t k = ::pread(fd, dst + got, len - got, off + (off_t)got);
-            if (k < 0) { if (errno == EINTR) continue; return false; }
-            if (k == 0) return false;
-            got += (size_t)k;
-        }
-        return true;
-    }
-    std::vector<std::thread> th;
-    std::vector<char> ok((size_t)ways, 1);
-    const size_t per = ((len / (size_t)ways) + 4095) & ~(size_t)4095;
-    for (int t = 0; t < ways; ++t)
-        th.emplace_back([&, t] {
-            const size_t lo = per * (size_t)t, hi = std::min(len, lo + per);
-            for (size_t got = lo; got < hi;) {
-                const ssize_t k = ::pread(fd, dst + got, hi - got, off + (off_t)got);
-                if (k < 0 && errno == EINTR) continue;
-                if (k <= 0) { ok[(size_t)t] = 0; return; }
-                got += (size_t)k;
-            }
-        });
-    for (auto& x : th) x.join();
-    return std::all_of(ok.begin(), ok.end(), [](char c) { return c != 0; });
 }
 
 }  // namespace
@@ -185,6 +151,7 @@ int main(int argc, char** argv) {
     off_t file_off = regular ? ::lseek(fd, 0, SEEK_CUR) : 0;
     if (file_off < 0) file_off = 0;
     const size_t file_left0 = regular && sb.st_size > file_off ? (size_t)(sb.st_size - file_off) : 0;
+    if (regular && !file_left0) { trre_free(prog); return 0; }            // an empty file: nothing is printed
 
     constexpr int kIn = 3, kOut = 2;
     Block inb[kIn], outb[kOut];
@@ -199,42 +166,65 @@ int main(int argc, char** argv) {
     double t_read = 0, t_alloc = 0, t_scan = 0, t_write = 0, t_wait_in = 0, t_wait_out = 0;
     const double t_begin = now_s();
 
-    // ---- reader ----------------------------------------------------------------------------------------------------------------
+    // ---- input -----------------------------------------------------------------------------------------------------------------
+    const uint8_t* map = nullptr;
+    if (regular && file_left0) {
+        void* m = ::mmap(nullptr, file_left0 + (size_t)(file_off & 4095), PROT_READ, MAP_PRIVATE, fd, file_off & ~(off_t)4095);
+        if (m == MAP_FAILED) { std::fprintf(stderr, "error: can not map the input file\n"); return EXIT_FAILURE; }
+        (void)::madvise(m, file_left0 + (size_t)(file_off & 4095), MADV_SEQUENTIAL);
+        map = static_cast<const uint8_t*>(m) + (file_off & 4095);
+    }
     std::thread reader([&] {
+        if (regular) {
+            // windows of the mapping, cut after their last '\n'; the pages of a window are touched here, a window or two ahead of the scan
+            size_t pos = 0;
+            while (pos < file_left0) {
+                const int b = in_free.pop();
+                Block& B = inb[b];
+                B.release();
+                const double t0 = now_s();
+                size_t end = std::min(file_left0, pos + block);
+                while (end < file_left0) {
+                    const void* nl = ::memrchr(map + pos, '\n', end - pos);
+                    if (nl) { end = (size_t)(static_cast<const uint8_t*>(nl) - map) + 1; break; }
+                    end = std::min(file_left0, end + block);       // one line longer than the block: a longer window
+                }
+                B.p = const_cast<uint8_t*>(map + pos); B.mapped = true; B.cap = 0;
+                B.n = B.have = end - pos;
+                B.last = end == file_left0;
+                volatile uint8_t sink = 0;
+                for (size_t k = pos; k < end; k += 4096) sink = sink ^ map[k];
+                t_read += now_s() - t0;
+                pos = end;
+                in_full.push(b);
+            }
+            in_full.push(-1);
+            return;
+        }
         std::vector<uint8_t> carry;
-        size_t cur = regular ? block : std::min(block, (size_t)1 << 20);     // a pipe starts small (its first answer is not 256 MiB away) and grows
-        size_t left = file_left0;
-        off_t off = file_off;
+        size_t cur = std::min(block, (size_t)1 << 20);     // a pipe starts small (its first answer is not 256 MiB away) and grows
         bool eof = false;
         while (!eof) {
             const int b = in_free.pop();
             Block& B = inb[b];
             B.have = 0; B.n = 0; B.last = false;
             for (;;) {
-                // room: the carried bytes and a block's worth (a regular file: no more than it still holds)
-                const size_t want = regular ? std::min(block, left) : cur;
                 double t0 = now_s();
-                B.reserve(std::max<size_t>(carry.size() + want + 64, 4096));
+                B.reserve(std::max<size_t>(carry.size() + cur + 64, 4096));
                 t_alloc += now_s() - t0;
                 t0 = now_s();
                 if (!carry.empty()) { std::memcpy(B.p, carry.data(), carry.size()); B.have = carry.size(); carry.clear(); }
-                if (regular) {
-                    if (want && !pread_parallel(fd, B.p + B.have, off, want)) { std::fprintf(stderr, "error: read failed\n"); std::_Exit(EXIT_FAILURE); }
-                    B.have += want; off += (off_t)want; left -= want;
-                    eof = left == 0;
-                } else {
-                    // a pipe or a terminal: block for the first bytes, then take what is there without waiting — until the block is
-                    // full — and go on as soon as the bytes end in a record
-                    while (B.have < B.cap - 64) {
-                        const ssize_t k = ::read(fd, B.p + B.have, std::min(B.cap - 64 - B.have, (size_t)1 << 30));
-                        if (k < 0) { if (errno == EINTR) continue; std::fprintf(stderr, "error: read failed\n"); std::_Exit(EXIT_FAILURE); }
-                        if (k == 0) { eof = true; break; }
-                        B.have += (size_t)k;
-                        struct pollfd pf{fd, POLLIN, 0};
-                        if (B.p[B.have - 1] == '\n' && ::poll(&pf, 1, 0) <= 0) break;
-                    }
-                    if (B.have >= B.cap - 64) cur = std::min(block, cur * 4);
+                // a pipe or a terminal: block for the first bytes, then take what is there without waiting — until the block is
+                // full — and go on as soon as the bytes end in a record
+                while (B.have < B.cap - 64) {
+                    const ssize_t k = ::read(fd, B.p + B.have, std::min(B.cap - 64 - B.have, (size_t)1 << 30));
+                    if (k < 0) { if (errno == EINTR) continue; std::fprintf(stderr, "error: read failed\n"); std::_Exit(EXIT_FAILURE); }
+                    if (k == 0) { eof = true; break; }
+                    B.have += (size_t)k;
+                    struct pollfd pf{fd, POLLIN, 0};
+                    if (B.p[B.have - 1] == '\n' && ::poll(&pf, 1, 0) <= 0) break;
                 }
+                if (B.have >= B.cap - 64) cur = std::min(block, cur * 4);
                 // up to the last record end; the very last block goes as it is (a final record without '\n' loses its last byte,
                 // like every record: trre_nft.c:777)
                 size_t n = B.have;
@@ -245,7 +235,8 @@ int main(int argc, char** argv) {
                 if (n == 0 && !eof) {                  // one line longer than the block: keep reading into a larger buffer
                     carry.assign(B.p, B.p + B.have);
                     B.have = 0;
-                    if (!regular) { cur *= 2; if (block < cur) block = cur; }
+                    cur *= 2;
+                    if (block < cur) block = cur;
                     continue;
                 }
                 B.n = n;
