@@ -12,7 +12,7 @@ d = corpora.printable_lines($n, corpora.SEED0 + 2, torch.device("cuda", 0))
 d.cpu().numpy().tofile("$f")
 PY
 ls -la $f
-for env in "" "TRRE_NO_PINNED_DIRECT=1" "TRRE_CLI_BLOCK=67108864" "TRRE_CLI_BLOCK=1073741824"; do
+for env in "" "TRRE_CLI_BLOCK=67108864"; do
   for rep in 1 2; do
     echo "## $env"; ( time env TRRE_TRACE=1 $env trre_amd/bin/trre_dft '[a:A-z:Z]' $f > /dev/null ) 2>&1 | grep -v "^$\|^user\|^sys"
   done

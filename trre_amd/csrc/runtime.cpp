@@ -868,8 +868,6 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
     const trre::StreamTables& stt = is_guided(family) ? p->gt.fwd : p->stt;       // the stream-form tables this launch walks
     args.status = cx->d_status;
     args.cap = cap;
-    static const uint32_t emit_dbg = getenv("TRRE_EMIT_DBG") ? (uint32_t)atoi(getenv("TRRE_EMIT_DBG")) : 0u;
-    args.dbg = emit_dbg;
     // a mask scratch left by an earlier, smaller scan must not be used: the kernel asks for one again
     args.gscratch = cx->scratch_bytes >= (n + 32) * (size_t)p->mask_bytes ? cx->d_scratch : nullptr;
     const bool backtrack = family == TRRE_KERNEL_BACKTRACK;
@@ -906,14 +904,12 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
         while (lane_auto < 8192 && (int64_t)n / (lane_auto * 2) >= 262144) lane_auto *= 2;
     const int64_t lane_bytes = lane_bytes_env > 0 ? (lane_bytes_env + 127) / 128 * 128 : lane_auto;
     const bool direct = (is_stream(family) && stream_impl >= 1) || is_guided(family);
-    static const int64_t rev_lane_env = getenv("TRRE_REV_LANE_BYTES") ? atoll(getenv("TRRE_REV_LANE_BYTES")) : 0;      // (A/B runs: the backward pass's sub-ranges)
-    const int64_t rev_lane_bytes = rev_lane_env > 0 ? (rev_lane_env + 127) / 128 * 128 : (lane_bytes_env > 0 ? lane_bytes : 2048);
+    const int64_t rev_lane_bytes = lane_bytes_env > 0 ? lane_bytes : 2048;
     const bool direct_ent_lds = stt.ok && stt.ent.size() * 8 <= (size_t)direct_ent_lds_bytes();
     const bool g16_slow = (stt.flags & kFlagG16Slow) != 0;
-    static const bool no_nib = getenv("TRRE_NO_NIBBLES") != nullptr;      // A/B: one symbol per byte
     static const bool no_g16_env = getenv("TRRE_NO_G16") != nullptr;       // A/B: the 8-byte entries
     static const bool no_fb_env = getenv("TRRE_NO_FB") != nullptr;         // A/B: large tables walk their 8-byte rows in both passes
-    const int sym_mode = !is_guided(family) ? 0 : (p->gt.sym_bits == 4 && !no_nib && !no_g16_env ? 2 : 1);
+    const int sym_mode = !is_guided(family) ? 0 : (p->gt.sym_bits == 4 && !no_g16_env ? 2 : 1);
     if (direct) n_chunks = (args.vend + lane_bytes * direct_block_threads() - 1) / (lane_bytes * direct_block_threads());
 
     if (!is_gen(family) && cap < n) return TRRE_OK;   // finish() reports the capacity error
@@ -997,19 +993,11 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
         launch_wide_fwd(2, args, lane_bytes, n_chunks, stream);
         pd.total_at = cx->d_chunk_base + n_chunks;
     } else if (direct && !is_gen(family)) {
-        // length-preserving without a window form: the emit pass alone, every lane writing its lines where it read
-        // them (TRRE_LP_RING=1: the older in-place walker with an LDS ring, 2.3x slower; kept for A/B runs)
-        static const bool lp_ring = getenv("TRRE_LP_RING") != nullptr;
+        // length-preserving without a window form: the emit pass alone, every lane writing its lines where it read them
         const int g16 = stt.g16_ok && !no_g16_env ? (int)(align_up(stt.g16.size() * 4, 16) + stt.p32.size() * 4) : 0;   // LDS room: 16-byte + pair forms
         if (is_guided(family)) launch_rev_sweep(args, (int)p->gt.n_rev * 256, rev_lane_bytes, stream, sym_mode == 2);
-        static const bool rev_only = getenv("TRRE_REV_DBG") != nullptr;       // experiments on the backward pass alone (its output may be void)
-        if (is_guided(family) && rev_only) {
-        } else if (lp_ring) {
-            launch_direct_kernel(0, direct_ent_lds, args, lane_bytes, n_chunks, stream, 0, sym_mode);
-        } else {
-            args.lp_emit = 1;
-            launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, sym_mode, g16_slow);
-        }
+        args.lp_emit = 1;
+        launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, sym_mode, g16_slow);
     } else if (direct && !is_guided(family) && stt.fb_ok && !no_fb_env) {
         // a large table (a dictionary) in its fallback form: the count pass with every per-byte lookup in LDS (0.86 ms per
         // GiB against 1.62 on the 8-byte rows through L1/L2).  The emit pass over the same form (TRRE_FB_EMIT=1) is
@@ -1213,7 +1201,7 @@ int finish_inner(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
         const int64_t n_chunks = (args.vend + kLazyLaneBytes * 256 - 1) / (kLazyLaneBytes * 256);
         std::vector<uint32_t> miss;
         size_t spec = 1024;
-        static const bool lazy_trace = getenv("TRRE_LAZY_TRACE") != nullptr;
+        static const bool lazy_trace = getenv("TRRE_TRACE") != nullptr;
         for (int round = 1; (status & kStMiss) && !(status & (kStEditOverflow | kStDiverge)); ++round) {
             uint32_t head[2] = {0, 0};
             HIP_TRY(hipMemcpyAsync(head, cx->d_miss, 8, hipMemcpyDeviceToHost, was.stream));
@@ -1259,7 +1247,7 @@ int finish_inner(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
         HIP_TRY(hipMemcpyAsync(both, cx->d_status + 2, 8, hipMemcpyDeviceToHost, was.stream));
         HIP_TRY(hipStreamSynchronize(was.stream));
         uint32_t misses = both[1];
-        static const bool spec_trace0 = getenv("TRRE_SPEC_TRACE") != nullptr;
+        static const bool spec_trace0 = getenv("TRRE_TRACE") != nullptr;
         if (both[0] && was.x_rev_lane_bytes) {
             // the backward pass guessed wrong somewhere: its flagged lanes sweep again (and on to the left while what they arrive with is not what
             // was assumed there) until every guess is what the lane to the right found; then the forward passes run — they had left at once
@@ -1291,7 +1279,7 @@ int finish_inner(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
         if (misses && !(status & (kStOverflow | kStDiverge))) {
             ScanArgs xa = was.xargs;
             const int64_t n_lanes = (xa.vend + was.x_lane_bytes - 1) / was.x_lane_bytes;
-            static const bool spec_trace = getenv("TRRE_SPEC_TRACE") != nullptr;
+            static const bool spec_trace = getenv("TRRE_TRACE") != nullptr;
             for (int64_t round = 0; misses; ++round) {
                 if (spec_trace) fprintf(stderr, "trre: exact sub-ranges: round %lld, %u lane(s) to repair\n", (long long)round, misses);
                 if (round > was.x_n_chunks + 64) {           // (every round settles at least the first flagged lane's workgroup: cannot happen)
@@ -1399,7 +1387,7 @@ int finish_inner(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
         }
         return again(was.family);
     }
-    static const bool trace_void = getenv("TRRE_TRACE_VOID") != nullptr;      // (why a launch was void, on stderr)
+    static const bool trace_void = getenv("TRRE_TRACE") != nullptr;      // (why a launch was void, on stderr)
     if (trace_void && was.patched && (status & (kStEditOverflow | kStNul | kStOverflow | kStDiverge)))
         fprintf(stderr, "trre: a mark + splice launch of family %d was void: status 0x%x\n", was.family, status);
     if (was.patched && (status & (kStEditOverflow | kStNul))) {
@@ -1562,8 +1550,8 @@ int compile_impl(const std::string& pattern, int engine, trre_prog** out, int mo
             }
             make_guard(true);
         } else {
-            // TRRE_COMPILE_TRACE=1: the stages of the NFT compile on stderr as they start (to find the one a pattern is slow in)
-            static const bool trace_on = getenv("TRRE_COMPILE_TRACE") != nullptr;
+            // TRRE_TRACE=1: the stages of the NFT compile on stderr as they start (to find the one a pattern is slow in)
+            static const bool trace_on = getenv("TRRE_TRACE") != nullptr;
             auto trace = [&](const char* what) { if (trace_on) fprintf(stderr, "compile: %s\n", what); };
             trace("nodes");
             const NftNodes nodes = build_nft_nodes(nft);
@@ -2042,7 +2030,7 @@ private:
     std::vector<std::thread> workers_;
     bool stop_ = false;
 };
-constexpr int kCopyWays = 8;
+constexpr int kCopyWays = 8;         // (4 and 16 measured the same through the command line, round 5)
 
 // Host buffers on one device.  The input goes through in chunks cut at line ends (lines are independent, so
 // the chunks' outputs simply concatenate), kHostSlots chunks in flight, each on its slot's stream: while one

@@ -466,7 +466,7 @@ __global__ __launch_bounds__(kDirectThreads) void k_stream_g16(ScanArgs a, int64
     __syncthreads();
     T.cls = smem;
     T.g16 = smem + 256;
-    if (h.p32_bytes && !(a.dbg & 4u)) { T.p32 = smem + 256 + ((h.g16_bytes + 15u) & ~15u); T.p32_slow = h.p32_slow; }   // (TRRE_EMIT_DBG=4: A/B without pairs)
+    if (h.p32_bytes) { T.p32 = smem + 256 + ((h.g16_bytes + 15u) & ~15u); T.p32_slow = h.p32_slow; }
     T.ent = reinterpret_cast<const uint64_t*>(a.blob + h.off_ent);
     T.pool = a.blob + h.off_pool;
     T.long_pool = h.max_out >= 255u;
@@ -1120,23 +1120,8 @@ void launch_tile_kernel(int which, int engine, int mask_bytes, const ScanArgs& a
     }
 }
 
-// experiment hook: alternative in-place geometries (TRRE_STREAM_GEO=1|2)
-using GeoStreamB = Geometry<256, 256 * 260, 2032>;    // 65 dwords per lane, 8 waves/CU
-using GeoStreamC = Geometry<512, 512 * 260, 2032>;    // 65 dwords per lane, one workgroup per CU
-template <class GL, bool kLdsEnt>
-void launch_stream_lp_geo(const ScanArgs& a, hipStream_t s) {
-    const int64_t n_chunks = (a.vend + GL::CHUNK - 1) / GL::CHUNK;
-    allow_big_lds<&k_stream_lp<GL, kLdsEnt>>();
-    hipLaunchKernelGGL((k_stream_lp<GL, kLdsEnt>), dim3((unsigned)n_chunks), dim3(GL::THREADS), StreamCarve<GL>::kBytesOneTile, s, a);
-}
-
 template <bool kLdsEnt>
 void launch_stream_t(int which, const ScanArgs& a, int64_t n_chunks, hipStream_t s) {
-    if (which == 0) {
-        static const int geo = getenv("TRRE_STREAM_GEO") ? atoi(getenv("TRRE_STREAM_GEO")) : 0;
-        if (geo == 1) { launch_stream_lp_geo<GeoStreamB, kLdsEnt>(a, s); return; }
-        if (geo == 2) { launch_stream_lp_geo<GeoStreamC, kLdsEnt>(a, s); return; }
-    }
     using GL = GeoStream;
     using GG = GeoStreamGen;
     allow_big_lds<&k_stream_lp<GL, kLdsEnt>>();
@@ -1386,13 +1371,10 @@ void launch_rev_sweep(const ScanArgs& a, int tab_bytes, int64_t lane_bytes, void
     const int64_t vtop = packed ? (a.vend + 127) & ~(int64_t)127 : (a.vend + 63) & ~(int64_t)63;
     const int64_t n_lanes = (vtop + lane_bytes - 1) / lane_bytes;
     const dim3 grid((unsigned)((n_lanes + kRevThreads - 1) / kRevThreads));
-    static const int dbg = getenv("TRRE_REV_DBG") ? atoi(getenv("TRRE_REV_DBG")) : 0;
     allow_big_lds<&k_rev_sweep<0, false>>();
     allow_big_lds<&k_rev_sweep<0, true>>();
-    static const int tiles = getenv("TRRE_REV_NO_TILE") ? 0 : (kRevThreads / kWave) * 4096;      // A/B: every lane stores its own 64 bytes
+    const int tiles = (kRevThreads / kWave) * 4096;      // (packed symbols: interior waves store through a 4 KiB tile each)
     if (packed) hipLaunchKernelGGL((k_rev_sweep<0, true>), grid, dim3(kRevThreads), ((tab_bytes + 15) & ~15) + tiles, s, a, lane_bytes, tiles);
-    else if (dbg == 1) hipLaunchKernelGGL((k_rev_sweep<1, false>), grid, dim3(kRevThreads), tab_bytes, s, a, lane_bytes, 0);
-    else if (dbg == 2) hipLaunchKernelGGL((k_rev_sweep<2, false>), grid, dim3(kRevThreads), tab_bytes, s, a, lane_bytes, 0);
     else hipLaunchKernelGGL((k_rev_sweep<0, false>), grid, dim3(kRevThreads), tab_bytes, s, a, lane_bytes, 0);
 }
 
@@ -1480,7 +1462,7 @@ int fb_copy_lds(const StreamBlobHeader& h, int threads) {
 void launch_fb_copy(const ScanArgs& a, const FbCopyArgs& ca, const void* hdr, int64_t lane_bytes, int64_t n_chunks, void* stream) {
     const StreamBlobHeader& h = *static_cast<const StreamBlobHeader*>(hdr);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static const int want = getenv("TRRE_COPY_THREADS") ? atoi(getenv("TRRE_COPY_THREADS")) : 1024;      // (A/B runs)
+    constexpr int want = 1024;
     if (want >= 1024 && fb_copy_lds(h, 1024) <= kLdsLimit) {
         allow_big_lds<&k_fb_copy<1024>>();
         hipLaunchKernelGGL(k_fb_copy<1024>, dim3((unsigned)((n_chunks + 3) / 4)), dim3(1024), fb_copy_lds(h, 1024), s, a, ca, lane_bytes, n_chunks);
@@ -1499,10 +1481,9 @@ void launch_fb_splice(const ScanArgs& a, const FbCopyArgs& ca, const void* hdr, 
     const StreamBlobHeader& h = *static_cast<const StreamBlobHeader*>(hdr);
     hipStream_t s = static_cast<hipStream_t>(stream);
     // workgroups of 512: eight waves share the literals and the sub-range bases of two chunks; two of them per CU.  The literals
-    // in LDS — or (TRRE_SPLICE_LIT_MEM=1, and for tables whose literals do not fit) read from memory, which makes room for a third
-    // workgroup per CU with windows of 2 176 bytes and buys nothing: 2.04 against 1.94 ms per GiB for the whole scan (round 4)
-    static const bool lit_lds = getenv("TRRE_SPLICE_LIT_MEM") == nullptr;
-    if (lit_lds && fb_splice_lds(h, 512, true) <= kLdsLimit) {
+    // in LDS — or, for tables whose literals do not fit, read from memory (for every table that made room for a third workgroup per CU with
+    // windows of 2 176 bytes and bought nothing: 2.04 against 1.94 ms per GiB for the whole scan, round 4)
+    if (fb_splice_lds(h, 512, true) <= kLdsLimit) {
         allow_big_lds<&k_fb_splice<512, true>>();
         hipLaunchKernelGGL((k_fb_splice<512, true>), dim3((unsigned)((n_chunks + 1) / 2)), dim3(512), fb_splice_lds(h, 512, true), s, a, ca, lane_bytes, n_chunks);
     } else {
@@ -1633,28 +1614,13 @@ void launch_bytemap_shift(const uint8_t* blob, const uint8_t* src, uint8_t* dst,
 void launch_bytemap(const ScanArgs& a, void* stream) {
     const int64_t vfirst = a.vbeg & ~(int64_t)15;
     const int64_t nvec = (a.vend - vfirst + 15) / 16;
-    // tuning knobs for A/B runs: TRRE_MAP_UNROLL (2|4|8), TRRE_MAP_NT (0|1), TRRE_MAP_WGS (workgroups per CU, 0 = one pass).
-    // Measured on 1 GiB (ms per launch): unroll 4 / non-temporal / one pass 0.361; unroll 4 / plain / 16 per CU 0.399;
-    // unroll 8 and unroll 2 are slower in every combination.
-    static const int unroll = getenv("TRRE_MAP_UNROLL") ? atoi(getenv("TRRE_MAP_UNROLL")) : 4;
-    static const int nt = getenv("TRRE_MAP_NT") ? atoi(getenv("TRRE_MAP_NT")) : 1;
-    static const int wgs = getenv("TRRE_MAP_WGS") ? atoi(getenv("TRRE_MAP_WGS")) : 0;
-    const int64_t per_block = (int64_t)kMapThreads * unroll;
+    // Four 16-byte vectors per lane, non-temporal stores, one pass over the grid.  (Rounds 1-4 kept knobs for the alternatives; measured on
+    // 1 GiB, ms per launch: this form 0.361; plain stores with 16 workgroups per CU 0.399; unroll 8 and unroll 2 slower in every combination.)
+    constexpr int kUnroll = 4;
+    const int64_t per_block = (int64_t)kMapThreads * kUnroll;
     int64_t blocks = (nvec + per_block - 1) / per_block;
-    const int64_t cap = wgs > 0 ? 256 * (int64_t)wgs : blocks;      // grid-stride beyond `cap` workgroups
-    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const dim3 g((unsigned)blocks), b(kMapThreads);
-    if (nt) {
-        if (unroll == 2) hipLaunchKernelGGL((k_bytemap<2, true>), g, b, 0, s, a, nvec);
-        else if (unroll == 8) hipLaunchKernelGGL((k_bytemap<8, true>), g, b, 0, s, a, nvec);
-        else hipLaunchKernelGGL((k_bytemap<4, true>), g, b, 0, s, a, nvec);
-    } else {
-        if (unroll == 2) hipLaunchKernelGGL((k_bytemap<2, false>), g, b, 0, s, a, nvec);
-        else if (unroll == 8) hipLaunchKernelGGL((k_bytemap<8, false>), g, b, 0, s, a, nvec);
-        else hipLaunchKernelGGL((k_bytemap<4, false>), g, b, 0, s, a, nvec);
-    }
+    hipLaunchKernelGGL((k_bytemap<kUnroll, true>), dim3((unsigned)blocks), dim3(kMapThreads), 0, static_cast<hipStream_t>(stream), a, nvec);
 }
 
 }  // namespace trre

@@ -477,7 +477,7 @@ private:
     };
     void build_fallback(StreamTables& t, const StreamPackInput& in, const std::array<uint8_t, 256>& cls, bool allow_literal_plans) {
         const uint32_t n0 = first_copy_, C = t.n_cls;
-        const bool dbg = getenv("TRRE_FB_DEBUG") != nullptr;
+        const bool dbg = getenv("TRRE_TRACE") != nullptr;             // (why a table gets no fallback form, on stderr)
         if (t.g16_ok || bounded_ || C > 31 || n0 > 8000 || n0 < 64) return;   // small tables have the 16-byte form; 5-bit classes, 13-bit ids
         std::vector<std::vector<Cell>> rows(in.rows.begin(), in.rows.begin() + n0);
         for (const Undo& u : undo_) rows[u.s][cls[u.c]] = u.cell;
