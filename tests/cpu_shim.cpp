@@ -921,7 +921,7 @@ int shim_lazy_round(const uint8_t* cls, uint64_t* ent, const uint8_t* pool, uint
         DirectLane L;
         uint32_t lst = 0;
         bool voided = false;
-        lazy_lane<2>(a, la, lane, lane_bytes, base[lane], L, lst, voided);
+        lazy_lane<2>(a, la, lane, lane_bytes, base[lane], L, lst, voided, lane_counts[lane]);
         if (L.count != lane_counts[lane] || voided) status |= 1u << 30;    // count and emit passes disagree
     }
     *status_out = status;

@@ -69,10 +69,10 @@ TRRE_HD void lazy_note_miss(const LazyArgs& la, uint32_t row, uint32_t k, int64_
 #endif
 }
 
-// kMode 1: count (L.count; void: kLazyVoid is the caller's business — `voided` says so); 2: emit at a.out + out_base
+// kMode 1: count (L.count; void: kLazyVoid is the caller's business — `voided` says so); 2: emit at a.out + out_base, lane_total bytes
 template <int kMode>
 TRRE_HD void lazy_lane(const ScanArgs& a, const LazyArgs& la, int64_t lane, int64_t lane_bytes, uint64_t out_base, DirectLane& L, uint32_t& status,
-                       bool& voided) {
+                       bool& voided, uint64_t lane_total = 0) {
     const int64_t lo = lane * lane_bytes;
     int64_t hi = lo + lane_bytes;
     if (hi > a.vend) hi = a.vend;
@@ -117,9 +117,12 @@ TRRE_HD void lazy_lane(const ScanArgs& a, const LazyArgs& la, int64_t lane, int6
                 break;
             }
             // one attempt from v (infer_dft): walk until the first final state; a dead edge or the end of the line discards it
+            // (the emit pass writes as it walks: a lane's output region is its own, an attempt that fails is simply written over —
+            // and one that would run past the region's end is failing: its bytes beyond `lane_total` are not stored)
             uint32_t row = 0, k;
             int64_t i = v;
             uint64_t e = entry(0, c0, k), acc = 0;
+            const uint64_t attempt_at = cnt;
             bool ok = false, miss = false;
             for (;;) {
                 if (++steps > la.budget) { status |= kStEditOverflow; L.count = cnt; return; }
@@ -132,36 +135,26 @@ TRRE_HD void lazy_lane(const ScanArgs& a, const LazyArgs& la, int64_t lane, int6
                 if (kind == 3u) { status |= kStDiverge; L.count = cnt; return; }     // the reference's closure never returns from this edge
                 if (kind == 0u) break;
                 if (kMode == 1) acc += out_len(e);
+                else {
+                    const uint32_t il = ent_ilen(e);
+                    if (il != 7u) {
+                        uint32_t w = ent_hi(e);
+                        for (uint32_t b = 0; b < il; ++b) { if (cnt < lane_total) op[cnt] = (uint8_t)w; ++cnt; w >>= 8; }
+                    } else {
+                        const uint8_t* r = la.pool + ent_hi(e);
+                        const uint32_t len = (uint32_t)r[0] | (uint32_t)r[1] << 8 | (uint32_t)r[2] << 16 | (uint32_t)r[3] << 24;
+                        for (uint32_t b = 0; b < len; ++b) if (cnt + b < lane_total) op[cnt + b] = r[4 + b];
+                        cnt += len;
+                    }
+                }
                 ++i;
                 if (kind == 2u) { ok = true; break; }
                 row = ent_next(e);
                 e = entry(row, byte_at(i), k);
             }
             if (miss) { voided = true; status |= kStMiss; dry = true; continue; }
-            if (!ok) { put1(c0); ++v; continue; }           // trre_dft.c:1281-1282
-            if (kMode == 1) {
-                cnt += acc;
-            } else {                                        // the attempt again, this time printing (trre_dft.c:1121-1122)
-                uint32_t r2 = 0, k2;
-                int64_t j = v;
-                uint64_t e2 = entry(0, c0, k2);
-                for (;;) {
-                    const uint32_t il = ent_ilen(e2);
-                    if (il != 7u) {
-                        uint32_t w = ent_hi(e2);
-                        for (uint32_t b = 0; b < il; ++b) { op[cnt++] = (uint8_t)w; w >>= 8; }
-                    } else {
-                        const uint8_t* r = la.pool + ent_hi(e2);
-                        const uint32_t len = (uint32_t)r[0] | (uint32_t)r[1] << 8 | (uint32_t)r[2] << 16 | (uint32_t)r[3] << 24;
-                        for (uint32_t b = 0; b < len; ++b) op[cnt + b] = r[4 + b];
-                        cnt += len;
-                    }
-                    ++j;
-                    if (ent_kind(e2) == 2u) break;
-                    r2 = ent_next(e2);
-                    e2 = entry(r2, byte_at(j), k2);
-                }
-            }
+            if (!ok) { cnt = attempt_at; put1(c0); ++v; continue; }       // trre_dft.c:1281-1282 (what the attempt had written is overwritten)
+            if (kMode == 1) cnt += acc;
             v = i;
         }
     }

@@ -1476,7 +1476,7 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
             uint32_t c = 0, fl = 0, r = row;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const uint64_t g = *reinterpret_cast<const uint64_t*>(T.p32 + r * pair_mul + ((kk[2 * h] * n_cls + kk[2 * h + 1]) << 5));
+                const uint64_t g = *reinterpret_cast<const uint64_t*>(T.p32 + mul24(r, pair_mul) + ((mul24(kk[2 * h], n_cls) + kk[2 * h + 1]) << 5));
                 const uint32_t meta = (uint32_t)(g >> 32);
                 c += meta & 15u;
                 fl |= meta;
@@ -1497,7 +1497,7 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
         } else {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const uint8_t* ep = T.p32 + row * pair_mul + ((kk[2 * h] * n_cls + kk[2 * h + 1]) << 5);
+                const uint8_t* ep = T.p32 + mul24(row, pair_mul) + ((mul24(kk[2 * h], n_cls) + kk[2 * h + 1]) << 5);
                 const U128 e = *reinterpret_cast<const U128*>(ep);
                 const uint32_t ws = w >> (16 * h);
                 bool as_pair = true;

@@ -255,6 +255,15 @@ TRRE_HD uint32_t perm_b32(uint32_t s0, uint32_t s1, uint32_t sel) {
     return r;
 #endif
 }
+// a * b for operands below 2^24 (table offsets, class counts): v_mul_u32_u24 issues at full rate, v_mul_lo_u32 at a quarter of it — and the
+// pair walks of the small tables multiply twice per step
+TRRE_HD uint32_t mul24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return a * b;
+#endif
+}
 TRRE_HD uint32_t alignbit_b32(uint32_t hi, uint32_t lo, uint32_t sh) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_alignbit(hi, lo, sh);
