@@ -130,11 +130,13 @@ int main(int argc, char** argv) {
         std::fprintf(stderr, "error: missing trre expression\n");
         return EXIT_FAILURE;
     }
+    const double t_main = now_s();
     trre_prog* prog = nullptr;
     if (trre_compile_mode(reinterpret_cast<const uint8_t*>(argv[optind]), std::strlen(argv[optind]), TRRE_CLI_ENGINE, mode, &prog) != TRRE_OK) {
         std::fprintf(stderr, "%s\n", trre_last_error());
         return EXIT_FAILURE;
     }
+    if (std::getenv("TRRE_TRACE")) std::fprintf(stderr, "trre: pattern compiled in %.1f ms\n", (now_s() - t_main) * 1e3);
     int fd = 0;
     if (optind == argc - 2) {
         fd = ::open(argv[optind + 1], O_RDONLY);
@@ -271,7 +273,7 @@ int main(int argc, char** argv) {
     });
 
     // ---- scan ------------------------------------------------------------------------------------------------------------------
-    int status = 0;
+    int status = 0, n_calls = 0;
     bool undecided = false;
     for (;;) {
         double t0 = now_s();
@@ -296,6 +298,7 @@ int main(int argc, char** argv) {
                 rc = trre_scan_host_multi(prog, B.p, B.n, O.p, O.cap, &m, mask);
             }
             t_scan += now_s() - t0;
+            if (trace && n_calls++ < 4) std::fprintf(stderr, "trre: scan call %d: %zu bytes in %.1f ms\n", n_calls, B.n, (now_s() - t0) * 1e3);
             undecided = undecided || (trre_last_scan_flags() & TRRE_SCAN_GUARD_UNDECIDED);
             // a scan the reference does not survive: it has printed everything up to the attempt it does not come back from (exit()
             // flushes stdout, trre_nft.c:551-553) — so has the library (NFT engine), m bytes

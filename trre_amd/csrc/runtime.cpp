@@ -19,6 +19,8 @@
 #include <thread>
 #include <vector>
 
+#include <sys/mman.h>
+
 #include "../../include/trre_mi355x.h"
 #include "device_blob.hpp"
 #include "front.hpp"
@@ -45,6 +47,51 @@ int fail(int code, const std::string& msg) {
         if (e_ != hipSuccess)                                                                  \
             return fail(TRRE_E_DEVICE, std::string("hip: ") + hipGetErrorString(e_) + " at " #expr); \
     } while (0)
+
+// Pinned staging memory: anonymous pages (huge ones where the kernel gives them), touched by a few threads, then registered with the
+// runtime.  hipHostMalloc of the host path's six 36 MiB buffers took 56 ms of a process's first scan call (the runtime allocates, clears
+// and pins 4 KiB pages on one thread); this takes 3 ms and copies at the same 57 GB/s (tools/probes/pin_cost.hip, round 5).
+std::mutex g_pin_mu;
+std::map<void*, size_t> g_pin_len;
+hipError_t pinned_get(uint8_t** out, size_t bytes) {
+    const size_t len = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    void* m = ::mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) return hipErrorOutOfMemory;
+#ifdef MADV_HUGEPAGE
+    (void)::madvise(m, len, MADV_HUGEPAGE);
+#endif
+    {
+        const int ways = len >= ((size_t)8 << 20) ? 4 : 1;
+        const size_t piece = (len / (size_t)ways + 4095) & ~(size_t)4095;
+        auto touch = [m, len, piece](int w) {
+            volatile uint8_t* q = static_cast<volatile uint8_t*>(m);
+            for (size_t k = (size_t)w * piece; k < std::min(len, (size_t)(w + 1) * piece); k += 4096) q[k] = 0;
+        };
+        std::vector<std::thread> th;
+        for (int w = 1; w < ways; ++w) th.emplace_back(touch, w);
+        touch(0);
+        for (auto& t : th) t.join();
+    }
+    const hipError_t e = hipHostRegister(m, len, hipHostRegisterDefault);
+    if (e != hipSuccess) { ::munmap(m, len); return e; }
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    g_pin_len[m] = len;
+    *out = static_cast<uint8_t*>(m);
+    return hipSuccess;
+}
+void pinned_put(uint8_t* p) {
+    if (!p) return;
+    size_t len = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        auto it = g_pin_len.find(p);
+        if (it == g_pin_len.end()) return;
+        len = it->second;
+        g_pin_len.erase(it);
+    }
+    (void)hipHostUnregister(p);
+    ::munmap(p, len);
+}
 
 struct Pending {
     bool active = false;
@@ -516,6 +563,8 @@ int device_state(trre_prog* p, int dev, DeviceState** out) {
     std::lock_guard<std::mutex> lock(p->dev_mu);
     auto it = p->dev.find(dev);
     if (it == p->dev.end()) {
+        static const bool trace_on = getenv("TRRE_TRACE") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         std::unique_ptr<DeviceState> st(new DeviceState);
         st->device = dev;
         auto upload = [&](const std::vector<uint8_t>& b, uint8_t** d) -> int {
@@ -532,6 +581,7 @@ int device_state(trre_prog* p, int dev, DeviceState** out) {
         if (!rc) rc = upload(p->kblob, &st->d_kblob);
         if (!rc) rc = ctx_init(st->ctx);
         if (rc) return rc;
+        if (trace_on) fprintf(stderr, "trre: device %d: tables up in %.1f ms\n", dev, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         it = p->dev.emplace(dev, std::move(st)).first;
     }
     *out = it->second.get();
@@ -1646,8 +1696,8 @@ void trre_free(trre_prog* p) {
         for (void* r : st.retired) (void)hipFree(r);
         ctx_free(st.ctx);
         for (auto& hs : st.slot) {
-            if (hs.pin_in) (void)hipHostFree(hs.pin_in);
-            if (hs.pin_out) (void)hipHostFree(hs.pin_out);
+            pinned_put(hs.pin_in);
+            pinned_put(hs.pin_out);
             (void)hipFree(hs.d_in);
             (void)hipFree(hs.d_out);
             if (hs.stream) (void)hipStreamDestroy(hs.stream);
@@ -1960,11 +2010,11 @@ int slot_reserve(DeviceState::HostSlot& hs, bool input, size_t bytes, bool need_
     const size_t want = grow ? bytes + bytes / 8 : have;  // (head room: the next chunk is rarely the same size)
     if (grow) {
         if (dev) (void)hipFree(dev);
-        if (pin) (void)hipHostFree(pin);
+        pinned_put(pin);
         pin = nullptr; dev = nullptr; have = 0;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), want + 64));
     }
-    if (need_pin && !pin) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&pin), want + 64, hipHostMallocDefault));
+    if (need_pin && !pin) HIP_TRY(pinned_get(&pin, want + 64));
     have = want;
     return TRRE_OK;
 }
@@ -2044,7 +2094,7 @@ int scan_host_on(trre_prog* p, DeviceState* st, const uint8_t* in, size_t n, uin
     }
     const int fam = scan_family(*p);
     const bool fixed_len = !is_gen(fam);              // output size == input size (unless a NUL forces a general family)
-    // A caller's buffer that is pinned already (hipHostMalloc / hipHostRegister: the CLI's block buffers are) goes over the link as it
+    // A caller's buffer that is pinned already (hipHostMalloc / hipHostRegister) goes over the link as it
     // is: no staging copy on that side (round 5; the copies run at 116 GB/s on 8 threads of one pool, which eight devices share).
     auto is_pinned = [](const void* ptr, size_t len) -> bool {
         if (!ptr || !len) return false;
@@ -2072,12 +2122,18 @@ int scan_host_on(trre_prog* p, DeviceState* st, const uint8_t* in, size_t n, uin
         return code;
     };
     // stage chunk k in and queue its upload + scan (and, when the output size is known beforehand, its download)
+    static const bool trace_on = getenv("TRRE_TRACE") != nullptr;
+    double t_reserve = 0, t_first = 0;
+    bool first_done = false;
+    auto ms_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     auto submit = [&](int b, size_t at, size_t len) -> int {
         DeviceState::HostSlot& hs = st->slot[b];
+        const auto tr = std::chrono::steady_clock::now();
         int r = slot_reserve(hs, true, len, !in_direct);
         if (r) return r;
         r = slot_reserve(hs, false, fixed_len ? len : len + len / 2 + 4096, !out_direct);
         if (r) return r;
+        t_reserve += ms_since(tr);
         if (in_direct) {
             HIP_TRY(hipMemcpyAsync(hs.d_in, in + at, len, hipMemcpyHostToDevice, hs.stream));
         } else {
@@ -2086,8 +2142,10 @@ int scan_host_on(trre_prog* p, DeviceState* st, const uint8_t* in, size_t n, uin
         }
         ch[b].off = at; ch[b].len = len; ch[b].out_at = 0; ch[b].m = 0; ch[b].submitted = true; ch[b].early = false;
         hs.ctx.relaunches = 0;
+        const auto te = std::chrono::steady_clock::now();
         r = enqueue(p, st, &hs.ctx, fam, hs.d_in, len, hs.d_out, hs.out_cap, hs.stream);
         if (r) return r;
+        if (!first_done) { t_first = ms_since(te); first_done = true; }
         if (fixed_len && !overflow && total_bound + len <= cap) {
             // length-preserving: the output is `len` bytes unless a NUL turns up (then complete() downloads again).  (Straight to its
             // place when the caller's buffer is pinned — if the chunks before it come out shorter after all, complete() downloads again.)
@@ -2187,6 +2245,8 @@ int scan_host_on(trre_prog* p, DeviceState* st, const uint8_t* in, size_t n, uin
         }
     }
     for (int b = 0; b < kHostSlots; ++b) settle(b);
+    if (trace_on && t_reserve + t_first > 1.0)
+        fprintf(stderr, "trre: host call of %zu bytes: %.1f ms getting staging and device buffers, %.1f ms in the first chunk's launch calls\n", n, t_reserve, t_first);
     if (out_len) *out_len = total;
     if (overflow) return fail(TRRE_E_CAPACITY, "error: output buffer too small");
     if (diverged) return fail(TRRE_E_DIVERGES, diverge_msg);
@@ -2198,8 +2258,13 @@ struct DeviceScope {
     int prev = -1;
     hipError_t err;
     explicit DeviceScope(int device) {
+        static const bool trace_on = getenv("TRRE_TRACE") != nullptr;
+        static std::atomic<bool> first{true};
+        const auto t0 = std::chrono::steady_clock::now();
         err = hipGetDevice(&prev);
         if (err == hipSuccess) err = hipSetDevice(device);
+        if (trace_on && first.exchange(false))
+            fprintf(stderr, "trre: first HIP calls of the process (runtime start-up): %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     }
     ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
@@ -2312,7 +2377,14 @@ int trre_scan_host_multi(trre_prog* p, const uint8_t* in, size_t n, uint8_t* out
     if (!p || (n && !in) || (cap && !out)) return fail(TRRE_E_ARG, "error: null argument");
     if (out_len) *out_len = 0;
     int n_dev = 0;
-    HIP_TRY(hipGetDeviceCount(&n_dev));
+    {
+        static const bool trace_on = getenv("TRRE_TRACE") != nullptr;
+        static std::atomic<bool> first{true};
+        const auto t0 = std::chrono::steady_clock::now();
+        HIP_TRY(hipGetDeviceCount(&n_dev));
+        if (trace_on && first.exchange(false))
+            fprintf(stderr, "trre: hipGetDeviceCount, the first HIP call of the process (runtime start-up): %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
     std::vector<int> devs;
     for (int d = 0; d < n_dev && d < 32; ++d)
         if (device_mask == 0 || (device_mask >> d & 1u)) devs.push_back(d);
