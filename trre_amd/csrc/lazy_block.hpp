@@ -34,6 +34,13 @@ struct LazyArgs {
                                // (trre_dft.c:1135-1175 goes on from a miss the same way), so that a deep walk costs a round per 49 states, not one each
     uint32_t miss_cap;
     uint64_t budget;           // table steps per sub-range
+    // the kernel's copy in LDS: the classes and the first rows_l rows (the root row — every attempt starts there and most end there — and
+    // whatever else fits; a row beyond is read from `ent`).  Stale entries are harmless: the tables only grow, an entry that reads as
+    // unexplored here is looked at again in `ent` by lazy_note_miss's compare-and-swap.  (Host: not used.)
+    uint32_t n_rows = 0;
+    const uint8_t* cls_l = nullptr;
+    const uint64_t* ent_l = nullptr;
+    uint32_t rows_l = 0;
 };
 
 constexpr uint32_t kLazyFollow = 48;     // (kLazyMissWords: front.hpp / below)
@@ -81,18 +88,52 @@ TRRE_HD void lazy_lane(const ScanArgs& a, const LazyArgs& la, int64_t lane, int6
     voided = false;
     if (lo >= hi) return;
     uint8_t* const op = kMode == 2 ? a.out + out_base : nullptr;
+    // the emit pass's output: up to 8 bytes — the positions [cnt - on, cnt) — wait in a register and leave as one store (a lane's region is its
+    // own up to lane_total; what a failing attempt has stored is written over)
+    uint64_t ow = 0;
+    uint32_t on = 0;
     auto put1 = [&](uint8_t c) {
-        if (kMode == 2) op[cnt] = c;
         cnt += 1;
+        if (kMode == 2) {
+            ow |= (uint64_t)c << (8u * on);
+            if (++on == 8u) {                               // the positions [cnt - 8, cnt)
+                if (cnt <= lane_total) __builtin_memcpy(op + cnt - 8, &ow, 8);
+                else for (uint32_t b = 0; b < 8u; ++b) if (cnt - 8 + b < lane_total) op[cnt - 8 + b] = (uint8_t)(ow >> (8u * b));
+                ow = 0; on = 0;
+            }
+        }
+    };
+    auto flush_out = [&]() {
+        if (kMode == 2) {
+            for (uint32_t b = 0; b < on; ++b) if (cnt - on + b < lane_total) op[cnt - on + b] = (uint8_t)(ow >> (8u * b));
+            ow = 0; on = 0;
+        }
+    };
+    auto rewind_out = [&](uint64_t to) {                    // a failed attempt: back to `to` (<= cnt)
+        if (kMode == 2) {
+            const uint64_t wstart = cnt - on;
+            if (to >= wstart) { on = (uint32_t)(to - wstart); ow = on ? ow & (~0ull >> (64u - 8u * on)) : 0; }
+            else { on = 0; ow = 0; }                        // (the bytes below `to` have left already)
+        }
+        cnt = to;
     };
     // a record's content ends at its '\n', at a NUL before it (Q2) or at the last byte of the input, which ends its record
-    // whatever it is (Q1)
-    auto byte_at = [&](int64_t v) -> uint8_t { return v >= a.vend - 1 ? (uint8_t)'\n' : a.in_v0[v]; };
+    // whatever it is (Q1).  The input through an 8-byte window (aligned: the block that holds a byte of the input is readable).
+    uint64_t iw = 0;
+    int64_t iwb = -8;
+    auto byte_at = [&](int64_t v) -> uint8_t {
+        if (v >= a.vend - 1) return (uint8_t)'\n';
+        const int64_t b = v & ~(int64_t)7;
+        if (b != iwb) { iw = *reinterpret_cast<const uint64_t*>(a.in_v0 + b); iwb = b; }
+        return (uint8_t)(iw >> (8u * (uint32_t)(v & 7)));
+    };
     auto entry = [&](uint32_t row, uint8_t c, uint32_t& k) -> uint64_t {
-        k = la.cls[c];
 #if defined(__HIP_DEVICE_COMPILE__)
+        k = la.cls_l[c];
+        if (row < la.rows_l) return la.ent_l[row * la.n_cls + k];
         return __hip_atomic_load(la.ent + (uint64_t)row * la.n_cls + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
+        k = la.cls[c];
         return la.ent[(uint64_t)row * la.n_cls + k];
 #endif
     };
@@ -139,12 +180,11 @@ TRRE_HD void lazy_lane(const ScanArgs& a, const LazyArgs& la, int64_t lane, int6
                     const uint32_t il = ent_ilen(e);
                     if (il != 7u) {
                         uint32_t w = ent_hi(e);
-                        for (uint32_t b = 0; b < il; ++b) { if (cnt < lane_total) op[cnt] = (uint8_t)w; ++cnt; w >>= 8; }
+                        for (uint32_t b = 0; b < il; ++b) { put1((uint8_t)w); w >>= 8; }
                     } else {
                         const uint8_t* r = la.pool + ent_hi(e);
                         const uint32_t len = (uint32_t)r[0] | (uint32_t)r[1] << 8 | (uint32_t)r[2] << 16 | (uint32_t)r[3] << 24;
-                        for (uint32_t b = 0; b < len; ++b) if (cnt + b < lane_total) op[cnt + b] = r[4 + b];
-                        cnt += len;
+                        for (uint32_t b = 0; b < len; ++b) put1(r[4 + b]);
                     }
                 }
                 ++i;
@@ -153,11 +193,12 @@ TRRE_HD void lazy_lane(const ScanArgs& a, const LazyArgs& la, int64_t lane, int6
                 e = entry(row, byte_at(i), k);
             }
             if (miss) { voided = true; status |= kStMiss; dry = true; continue; }
-            if (!ok) { cnt = attempt_at; put1(c0); ++v; continue; }       // trre_dft.c:1281-1282 (what the attempt had written is overwritten)
+            if (!ok) { rewind_out(attempt_at); put1(c0); ++v; continue; }       // trre_dft.c:1281-1282 (what the attempt had written is overwritten)
             if (kMode == 1) cnt += acc;
             v = i;
         }
     }
+    flush_out();
     L.count = cnt;
 }
 

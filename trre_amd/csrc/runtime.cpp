@@ -835,6 +835,7 @@ int lazy_round(trre_prog* p, DeviceState* st, ScanCtx* cx, const trre::ScanArgs&
     la.ent = st->d_lent;
     la.pool = st->d_lpool;
     la.n_cls = p->lazy->n_cls();
+    la.n_rows = st->lazy_rows_up;
     la.miss = cx->d_miss;
     la.miss_cap = kLazyMissCap;
     static const uint64_t budget = getenv("TRRE_LAZY_BUDGET") ? (uint64_t)atoll(getenv("TRRE_LAZY_BUDGET")) : kLazyBudget;

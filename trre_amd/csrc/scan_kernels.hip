@@ -937,9 +937,20 @@ __global__ __launch_bounds__(kGenThreads) void k_bt(ScanArgs a, GenArgs ga, int6
 // The deterministic engine on tables still being built (lazy_block.hpp): a thread per sub-range; a lane with a result from an
 // earlier round of the same scan keeps it (the tables only grow), the others walk again.
 template <int kMode>
-__global__ __launch_bounds__(kGenThreads) void k_lazy(ScanArgs a, LazyArgs la, int64_t lane_bytes) {
+__global__ __launch_bounds__(kGenThreads) void k_lazy(ScanArgs a, LazyArgs la, int64_t lane_bytes, int rows_l) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];    // cls[256] | the first rows_l rows
     __shared__ uint64_t part[kGenThreads / kWave];
     __shared__ uint32_t wpart[kGenThreads / kWave];
+    for (int k = threadIdx.x; k < 256; k += kGenThreads) smem[k] = la.cls[k];
+    {
+        uint64_t* d = reinterpret_cast<uint64_t*>(smem + 256);
+        const int n = rows_l * (int)la.n_cls;
+        for (int k = threadIdx.x; k < n; k += kGenThreads) d[k] = __hip_atomic_load(la.ent + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    la.cls_l = smem;
+    la.ent_l = reinterpret_cast<const uint64_t*>(smem + 256);
+    la.rows_l = (uint32_t)rows_l;
     const int64_t lane = (int64_t)blockIdx.x * kGenThreads + threadIdx.x;
     uint64_t base = 0;
     if (kMode == 2) {
@@ -1501,8 +1512,12 @@ void launch_gen(int which, const ScanArgs& a, const GenArgs& ga, int64_t lane_by
 }
 void launch_lazy(int which, const ScanArgs& a, const LazyArgs& la, int64_t lane_bytes, int64_t n_chunks, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (which == 1) hipLaunchKernelGGL(k_lazy<1>, dim3((unsigned)n_chunks), dim3(kGenThreads), 0, s, a, la, lane_bytes);
-    else hipLaunchKernelGGL(k_lazy<2>, dim3((unsigned)n_chunks), dim3(kGenThreads), 0, s, a, la, lane_bytes);
+    // the table's first rows in LDS: all of them when they fit in 32 KiB (4 workgroups per CU), else as many as do
+    const int row_bytes = (int)la.n_cls * 8;
+    const int rows_l = (int)std::min<int64_t>((int64_t)la.n_rows, (32 * 1024) / row_bytes);
+    const int lds = 256 + rows_l * row_bytes;
+    if (which == 1) hipLaunchKernelGGL(k_lazy<1>, dim3((unsigned)n_chunks), dim3(kGenThreads), lds, s, a, la, lane_bytes, rows_l);
+    else hipLaunchKernelGGL(k_lazy<2>, dim3((unsigned)n_chunks), dim3(kGenThreads), lds, s, a, la, lane_bytes, rows_l);
 }
 void launch_spec_verify(const ScanArgs& a, int64_t n_lanes, void* stream) {
     hipLaunchKernelGGL(k_spec_verify, dim3((unsigned)((n_lanes + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a, n_lanes);
