@@ -92,28 +92,35 @@ TRRE_HD void lazy_lane(const ScanArgs& a, const LazyArgs& la, int64_t lane, int6
     // own up to lane_total; what a failing attempt has stored is written over)
     uint64_t ow = 0;
     uint32_t on = 0;
-    auto put1 = [&](uint8_t c) {
-        cnt += 1;
+    // n <= 8 bytes (the low ones of `bytes`, zero above them) behind the output so far
+    auto append = [&](uint64_t bytes, uint32_t n) {
+        cnt += n;
         if (kMode == 2) {
-            ow |= (uint64_t)c << (8u * on);
-            if (++on == 8u) {                               // the positions [cnt - 8, cnt)
-                if (cnt <= lane_total) __builtin_memcpy(op + cnt - 8, &ow, 8);
-                else for (uint32_t b = 0; b < 8u; ++b) if (cnt - 8 + b < lane_total) op[cnt - 8 + b] = (uint8_t)(ow >> (8u * b));
-                ow = 0; on = 0;
+            ow |= bytes << (8u * on);
+            const uint32_t tot = on + n;
+            if (tot >= 8u) {                                // the positions [cnt - tot, cnt - tot + 8) leave
+                const uint64_t at = cnt - tot;
+                if (at + 8 <= lane_total) __builtin_memcpy(op + at, &ow, 8);
+                else for (uint32_t b = 0; b < 8u; ++b) if (at + b < lane_total) op[at + b] = (uint8_t)(ow >> (8u * b));
+                ow = on ? bytes >> (8u * (8u - on)) : 0;
+                on = tot - 8u;
+            } else {
+                on = tot;
             }
         }
     };
+    auto put1 = [&](uint8_t c) { append((uint64_t)c, 1u); };
     auto flush_out = [&]() {
         if (kMode == 2) {
             for (uint32_t b = 0; b < on; ++b) if (cnt - on + b < lane_total) op[cnt - on + b] = (uint8_t)(ow >> (8u * b));
             ow = 0; on = 0;
         }
     };
-    auto rewind_out = [&](uint64_t to) {                    // a failed attempt: back to `to` (<= cnt)
+    auto rewind_out = [&](uint64_t to) {                    // a failed attempt: back to `to` (<= cnt); bytes below `to` that have left stay
         if (kMode == 2) {
             const uint64_t wstart = cnt - on;
-            if (to >= wstart) { on = (uint32_t)(to - wstart); ow = on ? ow & (~0ull >> (64u - 8u * on)) : 0; }
-            else { on = 0; ow = 0; }                        // (the bytes below `to` have left already)
+            on = to >= wstart ? (uint32_t)(to - wstart) : 0u;
+            ow = on ? ow & (~0ull >> (64u - 8u * on)) : 0;
         }
         cnt = to;
     };
@@ -145,59 +152,79 @@ TRRE_HD void lazy_lane(const ScanArgs& a, const LazyArgs& la, int64_t lane, int6
     };
     int64_t v = lo;
     if (!(lo == a.vbeg || (lo > a.vbeg && a.in_v0[lo - 1] == (uint8_t)'\n'))) v = lo < a.vbeg ? a.vbeg : first_line_start_safe(a, lo, hi);
-    // the lines that START in [lo, hi)
-    while (v < hi) {
-        bool dry = false;                                   // the line met a miss: nothing more to learn from it
-        for (;;) {
-            const uint8_t c0 = byte_at(v);
-            if (c0 == (uint8_t)'\n' || c0 == 0 || dry) {
-                // (the attempt on the empty tail — trre_dft.c:1284 — looks at no byte and the start state is never final: it prints nothing)
-                put1((uint8_t)'\n');
-                while (byte_at(v) != (uint8_t)'\n') ++v;    // behind a NUL (or a miss): the rest of the record is nobody's
-                ++v;
-                break;
-            }
-            // one attempt from v (infer_dft): walk until the first final state; a dead edge or the end of the line discards it
-            // (the emit pass writes as it walks: a lane's output region is its own, an attempt that fails is simply written over —
-            // and one that would run past the region's end is failing: its bytes beyond `lane_total` are not stored)
-            uint32_t row = 0, k;
-            int64_t i = v;
-            uint64_t e = entry(0, c0, k), acc = 0;
-            const uint64_t attempt_at = cnt;
-            bool ok = false, miss = false;
-            for (;;) {
-                if (++steps > la.budget) { status |= kStEditOverflow; L.count = cnt; return; }
-                if (e == kLazyUnexplored || e == kLazyNoted) {
-                    if (e == kLazyUnexplored) lazy_note_miss(la, row, k, i + 1, byte_at);
-                    miss = true;
-                    break;
-                }
-                const uint32_t kind = ent_kind(e);
-                if (kind == 3u) { status |= kStDiverge; L.count = cnt; return; }     // the reference's closure never returns from this edge
-                if (kind == 0u) break;
-                if (kMode == 1) acc += out_len(e);
-                else {
-                    const uint32_t il = ent_ilen(e);
-                    if (il != 7u) {
-                        uint32_t w = ent_hi(e);
-                        for (uint32_t b = 0; b < il; ++b) { put1((uint8_t)w); w >>= 8; }
-                    } else {
-                        const uint8_t* r = la.pool + ent_hi(e);
-                        const uint32_t len = (uint32_t)r[0] | (uint32_t)r[1] << 8 | (uint32_t)r[2] << 16 | (uint32_t)r[3] << 24;
-                        for (uint32_t b = 0; b < len; ++b) put1(r[4 + b]);
-                    }
-                }
-                ++i;
-                if (kind == 2u) { ok = true; break; }
-                row = ent_next(e);
-                e = entry(row, byte_at(i), k);
-            }
-            if (miss) { voided = true; status |= kStMiss; dry = true; continue; }
-            if (!ok) { rewind_out(attempt_at); put1(c0); ++v; continue; }       // trre_dft.c:1281-1282 (what the attempt had written is overwritten)
-            if (kMode == 1) cnt += acc;
-            v = i;
+    // The lines that START in [lo, hi), as ONE loop that takes one table step per turn: an attempt (infer_dft) that goes on, the start of the
+    // next one, the rest of a record nobody looks at — all are states of the lane, so the lanes of a wave, each somewhere else in its own
+    // text, run the same few instructions per turn.  (The first version nested the attempt's loop in the position's in the line's: every
+    // wave ran the longest attempt of its 64 lanes at every position, and 375 scalar instructions of branch bookkeeping per step.)
+    int64_t i = v;                 // the attempt's cursor (== v: an attempt starts here)
+    uint32_t row = 0;
+    uint64_t acc = 0, attempt_at = 0;
+    uint8_t c0 = 0;
+    bool at_start = true;          // v is a line start
+    bool skip = false;             // behind a NUL or a miss: the rest of the record is nobody's
+    // One turn per byte looked at, written with selects and no way out of the middle of the loop: the lanes of a wave are each somewhere
+    // else — an attempt starting, one going on, one dying, a line ending, a record's rest being skipped — and every `if` on such a
+    // condition is a stretch of code the whole wave walks through, every `continue` a page of scalar mask bookkeeping (the first flat
+    // version: 140 scalar instructions per turn).  Branches are left where a lane rarely goes: a miss, an escape to the pool, a full
+    // output window.
+    bool stop = false;
+    while (!stop && !(at_start && v >= hi)) {
+        const uint8_t c = byte_at(i);                      // (i == v while skipping)
+        const bool in_skip = skip;
+        const bool starting = !in_skip && i == v;
+        // (the attempt on the empty tail — trre_dft.c:1284 — looks at no byte and the start state is never final: it prints nothing)
+        const bool nul = starting && c == 0, eol = starting && c == (uint8_t)'\n', nl = nul || eol;
+        // one attempt from v (infer_dft): walk until the first final state; a dead edge or the end of the line discards it
+        c0 = starting ? c : c0;
+        attempt_at = starting ? cnt : attempt_at;
+        acc = starting ? 0 : acc;
+        row = (starting || in_skip) ? 0u : row;
+        const bool walk = !nl && !in_skip;
+        steps += walk ? 1u : 0u;
+        uint32_t k;
+        const uint64_t e = entry(row, c, k);
+        uint32_t kind = walk ? ent_kind(e) : 0u;
+        bool missed = false;
+        if (walk && (e == kLazyUnexplored || e == kLazyNoted)) {
+            if (e == kLazyUnexplored) lazy_note_miss(la, row, k, i + 1, byte_at);
+            voided = true;
+            status |= kStMiss;
+            missed = true;                                 // nothing more to learn from this line
+            kind = 0u;
         }
+        if (steps > la.budget) { status |= kStEditOverflow; stop = true; }
+        if (kind == 3u) { status |= kStDiverge; stop = true; kind = 0u; }     // the reference's closure never returns from this edge
+        const bool go = kind != 0u;                        // the attempt takes this byte
+        const bool one = !go && !in_skip;                  // one byte goes out: '\n' (a line end, a NUL, a miss) or the dead attempt's first byte (trre_dft.c:1281-1282)
+        uint32_t il = go ? ent_ilen(e) : 0u;
+        if (kMode == 1) {
+            if (il == 7u) il = out_len(e);
+            acc += il;
+            cnt += go ? (kind == 2u ? acc : 0u) : (one ? 1u : 0u);
+        } else {
+            // the emit pass writes as it walks — a lane's output region is its own, an attempt that fails is written over, and one that
+            // would run past the region's end is failing: its bytes beyond `lane_total` are not stored
+            rewind_out(one ? attempt_at : cnt);
+            if (il != 7u) {
+                const uint64_t bytes = one ? (uint64_t)((nl || missed) ? (uint8_t)'\n' : c0) : ((uint64_t)ent_hi(e) & (il ? ~0ull >> (64u - 8u * il) : 0ull));
+                append(bytes, one ? 1u : il);
+            } else {
+                const uint8_t* r = la.pool + ent_hi(e);
+                const uint32_t len = (uint32_t)r[0] | (uint32_t)r[1] << 8 | (uint32_t)r[2] << 16 | (uint32_t)r[3] << 24;
+                for (uint32_t b = 0; b < len; ++b) put1(r[4 + b]);
+            }
+        }
+        // where the lane stands next: behind the attempt's byte (it goes on, or is done: the next one starts there), or one byte on (a dead
+        // edge, a line end, a skipped byte); a NUL or a miss stays where it is: the skipping starts there
+        const bool to_skip = nul || missed;
+        const int64_t v1 = in_skip ? v + 1 : (kind == 2u ? i + 1 : ((go || to_skip) ? v : v + 1));
+        i = go ? i + 1 : v1;
+        v = v1;
+        row = ent_next(e);                                 // (kind 1; any other: reset when the next attempt starts)
+        skip = in_skip ? c != (uint8_t)'\n' : to_skip;
+        at_start = in_skip ? c == (uint8_t)'\n' : eol;
     }
+    if (stop) { L.count = cnt; return; }
     flush_out();
     L.count = cnt;
 }
