@@ -748,10 +748,14 @@ int guard_check(trre_prog* p, DeviceState* st, ScanCtx* cx, const uint8_t* d_in,
 // the backtracking fallback: sub-range per thread, frames (= bytes an attempt may consume) and path bytes per thread, workgroups in the pool, steps per sub-range
 constexpr int64_t kBtLaneBytes = 1024;
 constexpr uint32_t kBtBudget = 16u << 20;
-// The pool of stacks and path buffers sizes the scratch, not the input: 4.3-4.6 GB in every tier.  A launch in which an attempt outgrew its
-// stack or its path buffer runs again on the next tier (round 4 gave up at the first: attempts of 4 096 bytes / 4 KiB of output).
+// The pool of stacks and path buffers sizes the scratch, not the input: 3.4-4.6 GB in every tier.  A launch in which an attempt outgrew its
+// stack or its path buffer runs again on the next tier (round 4 gave up at 4 096 bytes / 4 KiB of output).  The search waits on memory — a
+// stack frame, list bounds, a follow entry, the byte, its set: dependent loads — so the first tier is sized for the MACHINE: 1 536 workgroups
+// are six waves per SIMD (k_bt's registers allow six), and 512 frames are what such a pool can have; the second tier is round 4's
+// (one wave per SIMD: a sixth of the rate).
 struct BtTier { int64_t pool_blocks; uint32_t frames, path_cap; };
-constexpr BtTier kBtTiers[3] = {{256, 4096, 4096}, {16, 65536, 65536}, {1, 1u << 20, 1u << 20}};
+constexpr int kBtTierCount = 4;
+constexpr BtTier kBtTiers[kBtTierCount] = {{1536, 512, 512}, {256, 4096, 4096}, {16, 65536, 65536}, {1, 1u << 20, 1u << 20}};
 // ---- the deterministic engine on tables still being built (front.hpp: LazyDft, lazy_block.hpp) ----
 constexpr int64_t kLazyLaneBytes = 1024;
 constexpr uint32_t kLazyMissCap = 1u << 16;
@@ -1415,7 +1419,7 @@ int finish_inner(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
         uint32_t why = 0;
         HIP_TRY(hipMemcpyAsync(&why, cx->d_status + 2, 4, hipMemcpyDeviceToHost, was.stream));
         HIP_TRY(hipStreamSynchronize(was.stream));
-        if (!(why & kBtWhyBudget) && cx->bt_tier < 2) {
+        if (!(why & kBtWhyBudget) && cx->bt_tier < kBtTierCount - 1) {
             const int tier = cx->bt_tier;
             cx->bt_tier = tier + 1;
             const int rc = again(was.family);
