@@ -179,6 +179,10 @@ TRRE_HD void gen_lane(const ScanArgs& a, const GenView& G, const GenArgs& ga, in
 // (trre_nft.c:635-642); an accepted line prints its output and '\n', a rejected one nothing (trre_nft.c:791-797).
 // =============================================================================================
 constexpr uint32_t kBtWhyBudget = 1u, kBtWhyFrames = 2u, kBtWhyPath = 4u;
+#ifndef TRRE_BT_SCAN_BYTES
+#define TRRE_BT_SCAN_BYTES 4
+#endif
+constexpr int kBtScanBytes = TRRE_BT_SCAN_BYTES;
 template <int kMode>
 TRRE_HD void bt_lane(const ScanArgs& a, const GenView& G, const GenArgs& ga, int64_t slot, int64_t lane, int64_t lane_bytes, uint64_t out_base,
                      uint32_t budget, DirectLane& L, uint32_t& status, uint32_t& why) {
@@ -265,37 +269,114 @@ TRRE_HD void bt_lane(const ScanArgs& a, const GenView& G, const GenArgs& ga, int
     }
     int64_t v = lo;
     if (!(lo == a.vbeg || (lo > a.vbeg && a.in_v0[lo - 1] == (uint8_t)'\n'))) v = lo < a.vbeg ? a.vbeg : first_line_start_safe(a, lo, hi);
-    // the lines that START in [lo, hi), byte by byte; 16 input bytes at a time in registers
+    // The lines that START in [lo, hi), byte by byte; 16 input bytes at a time in registers.  ONE loop: a turn is either one byte of the
+    // line loop (trre_nft.c:780-788: most bytes cannot begin a match and are copied) or one step of the search an earlier turn began —
+    // the lanes of a wave are each somewhere else in their own text, and with the search as a loop of its own inside the line loop every
+    // wave ran the longest search of its 64 lanes at every position (round 5's counters: 1 170 vector and 1 000 scalar instructions per
+    // byte looked at).  No `continue`, one way out (see lazy_block.hpp on what those cost).
     U128 blk{};
     int64_t blk_at = -16;
     bool open = false;                                                              // inside a line of this lane's
-    for (;;) {
-        if (!open) {
-            if (v >= hi) break;
-            open = true;
-        }
-        if ((v & ~(int64_t)15) != blk_at) { blk_at = v & ~(int64_t)15; blk = *reinterpret_cast<const U128*>(a.in_v0 + blk_at); }
-        const uint32_t q = (uint32_t)(v >> 2) & 3u;
-        const uint32_t dw = q == 0 ? blk.x : (q == 1 ? blk.y : (q == 2 ? blk.z : blk.w));
-        const uint8_t c0 = (uint8_t)(dw >> (8u * ((uint32_t)v & 3u)));
-        if (ends(v, c0)) {
-            if (attempt(v) == -2) break;                                            // the empty tail (trre_nft.c:788)
-            put1((uint8_t)'\n');
-            if (c0 != (uint8_t)'\n') {                                              // behind a NUL: the rest of the record is nobody's
-                while (v < a.vend - 1 && a.in_v0[v] != (uint8_t)'\n') ++v;
-            }
-            ++v;
-            open = false;
-            continue;
-        }
-        uint32_t fw = first[0];
+    uint32_t mode = 0;                                                              // 0: the line loop; 1: searching from v (c0 could begin a match); 2: searching the empty tail at v
+    uint32_t sp = 0;
+    uint8_t c0 = 0;
+    bool stop = false;
+    while (!stop) {
+        if (mode == 0u) {
+            // (up to kBtScanBytes bytes of the line loop per turn: a search step waits on memory — a frame, list bounds, a follow entry, the
+            // byte, its set — and nearly every turn has some lane of the wave in one; the lanes that copy do not wait with it byte by byte)
+#pragma clang loop unroll(disable)
+            for (int t = 0; t < kBtScanBytes && mode == 0u && !stop; ++t) {
+                if (!open && v >= hi) {
+                    stop = true;
+                } else {
+                    open = true;
+                    if ((v & ~(int64_t)15) != blk_at) { blk_at = v & ~(int64_t)15; blk = *reinterpret_cast<const U128*>(a.in_v0 + blk_at); }
+                    const uint32_t q = (uint32_t)(v >> 2) & 3u;
+                    const uint32_t dw = q == 0 ? blk.x : (q == 1 ? blk.y : (q == 2 ? blk.z : blk.w));
+                    c0 = (uint8_t)(dw >> (8u * ((uint32_t)v & 3u)));
+                    uint32_t fw = first[0];
 #pragma unroll
-        for (int w = 1; w < 8; ++w) fw = (c0 >> 5) == w ? first[w] : fw;
-        if (!((fw >> (c0 & 31u)) & 1u)) { put1(c0); ++v; continue; }               // trre_nft.c:780-786
-        const int64_t r = attempt(v);
-        if (r == -2) break;
-        if (r > 0) v += r;
-        else { put1(c0); ++v; }                                                     // no match, or an empty one (its output is printed: Q3)
+                    for (int w = 1; w < 8; ++w) fw = (c0 >> 5) == w ? first[w] : fw;
+                    const bool tail = ends(v, c0);                                  // the empty tail is searched too (trre_nft.c:788)
+                    if (tail || ((fw >> (c0 & 31u)) & 1u)) {
+                        mode = tail ? 2u : 1u;
+                        sp = 1;
+                        stack[0] = G.n_nodes; stack[1] = 0; stack[2] = 0; stack[3] = 0;
+                    } else {
+                        put1(c0);                                                   // trre_nft.c:780-786
+                        ++v;
+                    }
+                }
+            }
+        } else {
+            // one step of the search (infer_backtrack, all = 0): r — the bytes the first accepting path consumed, -1: no path; -3: not done
+            int64_t r = -3;
+            if (++steps > budget) {
+                status |= kStEditOverflow; why |= kBtWhyBudget; stop = true;
+            } else {
+                uint32_t* f = stack + 4 * (sp - 1);
+                const uint32_t list = f[0], idx = f[1], fi = f[2], fo = f[3];
+                const uint32_t beg = G.foff[list], end = G.foff[list + 1];
+                if (beg + idx >= end) {
+                    --sp;
+                    if (sp == 0) r = -1;
+                } else {
+                    f[1] = idx + 1;
+                    const uint32_t* e = G.follow + 3 * (size_t)(beg + idx);
+                    const uint32_t target = e[0], out_off = e[1], out_len = e[2] & 0xffffu, mute = e[2] >> 16;
+                    const uint32_t olen = fo & 0x7fffffffu, muted = fo >> 31;
+                    if (target == kGenTgtDiverge) {
+                        status |= kStDiverge; stop = true;
+                    } else if (target == kGenTgtFinal) {                            // trre_nft.c:643-648: print, return the offset
+                        put(path, olen);
+                        if (!muted) put(G.pool + out_off, out_len);
+                        r = (int64_t)fi;
+                    } else {
+                        const uint8_t c = a.in_v0[v + fi];
+                        if (!ends(v + fi, c) && ((G.bytes[8 * (size_t)target + (c >> 5)] >> (c & 31u)) & 1u)) {
+                            uint32_t nlen = olen, nmuted = muted;
+                            bool room = true;
+                            if (!muted) {
+                                if (olen + out_len + 1u > ga.path_cap) {
+                                    status |= kStEditOverflow; why |= kBtWhyPath; stop = true; room = false;
+                                } else {
+                                    for (uint32_t k = 0; k < out_len; ++k) path[olen + k] = G.pool[out_off + k];
+                                    nlen = olen + out_len;
+                                    if (mute) nmuted = 1;
+                                    else if (G.echo[target]) path[nlen++] = c;
+                                }
+                            }
+                            if (room) {
+                                if (sp >= ga.frames) {
+                                    status |= kStEditOverflow; why |= kBtWhyFrames; stop = true;
+                                } else {
+                                    uint32_t* nf = stack + 4 * sp;
+                                    nf[0] = target; nf[1] = 0; nf[2] = fi + 1; nf[3] = nlen | nmuted << 31;
+                                    ++sp;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (r != -3) {
+                if (mode == 2u) {
+                    put1((uint8_t)'\n');
+                    if (c0 != (uint8_t)'\n') {                                      // behind a NUL: the rest of the record is nobody's
+                        while (v < a.vend - 1 && a.in_v0[v] != (uint8_t)'\n') ++v;
+                    }
+                    ++v;
+                    open = false;
+                } else if (r > 0) {
+                    v += r;
+                } else {
+                    put1(c0);                                                       // no match, or an empty one (its output is printed: Q3)
+                    ++v;
+                }
+                mode = 0u;
+            }
+        }
     }
     L.count = cnt;
 }
