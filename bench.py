@@ -89,7 +89,8 @@ def pmc_traffic(kernel_name, nbytes):
 
 
 # HBM traffic per GiB of input of the other configurations, from the committed PMC passes of tools/profile_round.sh /
-# tools/pmc_dict4.sh (1 GiB runs; FETCH_SIZE doubled as for the headline): summed over the kernels of one scan.  Measured
+# tools/pmc_dict4.sh (1 GiB runs; FETCH_SIZE doubled as for the headline — round 5's calibration, tools/probes/fetch_calib.hip, found the
+# factor 2 right for every access pattern the kernels use): summed over the kernels of one scan.  Measured
 # under rocprofv3 in separate passes, NOT in this run — labelled as such in the record.
 CONFIG_PMC = {"cfg4": "cfg4_nft", "cfg4_guided": "cfg4_nft_guided", "cfg5_dft": "dict1000_dft", "cfg5_nft": "dict1000_dft", "expand": "expand_dft",
               "nft_loop": "nft_loop_guided", "dft_loop": "dft_loop_guided", "tile_fallback": "tile_dft"}
@@ -113,7 +114,9 @@ def config_traffic(name):
         total += mul * sum(float(v) for v in vals) * 1024
         src.append(os.path.relpath(files[-1], ROOT))
     return {"hbm_bytes_per_GiB_of_input": int(total),
-            "source": "rocprofv3 --pmc passes at 1 GiB (256 MiB for the tile kernels), committed (not this run): " + ", ".join(src)}
+            "source": "rocprofv3 --pmc passes at 1 GiB (256 MiB for the tile kernels), committed (not this run): " + ", ".join(src)
+                      + "; FETCH_SIZE x 2 for every access pattern, WRITE_SIZE x 1: calibrated in profiles/r05_fetch_calibration.txt (every read request "
+                        "of the L2s is 128 B and the counter charges 64; what the re-fetches of half-used lines add is real traffic at the L2s' far side)"}
 
 
 def cpu_baseline(pattern, engine, sample, cores_mt=0):

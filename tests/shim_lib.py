@@ -58,17 +58,23 @@ def mask_bytes_of(blob, engine):
 
 def shim_scan(blob, engine, family, data, geo=1, in_mis=0, out_mis=0, scratch=True, cap=None):
     """Run one kernel family of the device code on the host.  Returns (output bytes, status)."""
+    auto_cap = cap is None
     if cap is None:
         cap = len(data) * 8 + 64 if family in (3, 5, 7, 9, 22, 23, 25, 27, 29, 32, 33) else len(data)     # (20, 21: length-preserving)
-    out = ctypes.create_string_buffer(max(cap, 1))
-    m = ctypes.c_size_t()
-    st = ctypes.c_uint32()
-    rc = lib().shim_scan(blob, engine, mask_bytes_of(blob, engine), family, geo, data, len(data), in_mis, out, cap,
-                         out_mis, 1 if scratch else 0, ctypes.byref(m), ctypes.byref(st))
-    if rc == -5:
-        return None, 0                      # this table has no window form
-    if rc:
-        raise RuntimeError("shim rc %d" % rc)
+    for _ in range(2):
+        out = ctypes.create_string_buffer(max(cap, 1))
+        m = ctypes.c_size_t()
+        st = ctypes.c_uint32()
+        rc = lib().shim_scan(blob, engine, mask_bytes_of(blob, engine), family, geo, data, len(data), in_mis, out, cap,
+                             out_mis, 1 if scratch else 0, ctypes.byref(m), ctypes.byref(st))
+        if rc == -5:
+            return None, 0                      # this table has no window form
+        if rc:
+            raise RuntimeError("shim rc %d" % rc)
+        if auto_cap and st.value & ST_CAPACITY and m.value > cap:
+            cap = m.value + 64                  # (a pattern that prints more than 8 bytes per input byte: the size the count pass asked for,
+            continue                            #  as a caller of the C ABI does on TRRE_E_CAPACITY)
+        break
     return out.raw[:m.value], st.value
 
 
@@ -124,13 +130,18 @@ def shim_scan_guided(prog, family, data, geo=1, in_mis=0, out_mis=0):
     rblob, gblob = prog.export_guided_tables()
     assert rblob and gblob
     cap = len(data) * 8 + 64 if family not in GUIDED_LP_ALL else len(data)
-    out = ctypes.create_string_buffer(max(cap, 1))
-    m = ctypes.c_size_t()
-    st = ctypes.c_uint32()
-    rc = lib().shim_scan_guided(rblob, gblob, family, geo, data, len(data), in_mis, out, cap, out_mis, ctypes.byref(m),
-                                ctypes.byref(st))
-    if rc:
-        raise RuntimeError("shim rc %d" % rc)
+    for _ in range(2):
+        out = ctypes.create_string_buffer(max(cap, 1))
+        m = ctypes.c_size_t()
+        st = ctypes.c_uint32()
+        rc = lib().shim_scan_guided(rblob, gblob, family, geo, data, len(data), in_mis, out, cap, out_mis, ctypes.byref(m),
+                                    ctypes.byref(st))
+        if rc:
+            raise RuntimeError("shim rc %d" % rc)
+        if st.value & ST_CAPACITY and m.value > cap:
+            cap = m.value + 64                  # (more than 8 bytes of output per input byte)
+            continue
+        break
     return out.raw[:m.value], st.value
 
 

@@ -80,6 +80,8 @@ def main():
             fams = T.shim_families(p)
             if eng == "nft" and trre_amd.KERNEL_BACKTRACK in p.allowed_kernels():
                 fams = fams + [shim_lib.BACKTRACK]         # (round 4: the backtracking fallback runs any NFT pattern)
+            if eng == "dft" and trre_amd.KERNEL_DFT_LAZY in p.allowed_kernels() and shim_lib.DFT_LAZY not in fams:
+                fams = fams + [shim_lib.DFT_LAZY]          # (round 5: the lazily determinised family runs any DFT scan pattern)
             for fam in fams:
                 for geo in (1, 0):
                     try:

@@ -2057,8 +2057,10 @@ public:
 private:
     struct Piece { Job* job; uint8_t* dst; const uint8_t* src; size_t n; };
     CopyPool() {
+        // (a copy asks for kCopyWays = 8 workers; trre_scan_host_multi runs one staging copy in and one out per device at a time: on a host with
+        // the cores for it the pool holds 8 x 8 workers, so that eight devices do not queue behind two devices' worth of them)
         unsigned hw = std::thread::hardware_concurrency();
-        const unsigned n = hw >= 32 ? 16 : (hw >= 8 ? hw / 2 : 2);
+        const unsigned n = hw >= 256 ? 64 : (hw >= 128 ? 32 : (hw >= 32 ? 16 : (hw >= 8 ? hw / 2 : 2)));
         for (unsigned i = 0; i < n; ++i) workers_.emplace_back([this] { run(); });
     }
     ~CopyPool() {
