@@ -610,3 +610,23 @@ def test_exact_sub_ranges_on_every_golden_vector():
                 assert shim_lib.scan_like_runtime(p, data, geo=geo, family=fam, in_mis=3) == want, (pat, eng, fam, geo)
                 n_rounds += shim_lib.last_rounds()
     assert n_rounds > 40, n_rounds
+
+
+def test_more_than_eight_output_bytes_per_input_byte():
+    """a pattern whose epsilon loops print a dozen bytes around every input byte (found by tools/shim_fuzz.py, seed 503, round 5 — the
+    kernels were right, the harness's output buffer of 8 x the input was not): the count pass reports the size, the caller comes back
+    with it (the C ABI's TRRE_E_CAPACITY contract), every family prints the reference's bytes; slow entries (pooled texts of up to 25
+    bytes) in every transition of a 7-state table."""
+    pat = r"(:(xc{,2})(y[b:a-c:c]|ax)(c)|a(yb[a:b-c:a]+)+?a|((b)|.\y).:){,2}|[b-y]:((b{1,2})|b:[c-y](b:(:xx(yx)|..a:yb)|.:))*c|ca:"
+    rng = random.Random(11)
+    data = b"ccabxyxx\nyax\nybaxxa\n" + bytes(rng.choice(b"abcxy\n") for _ in range(3000))
+    want = Oracle(pat, "nft").scan(data)
+    assert len(want) > 9 * len(data)
+    p = prog(pat, "nft")
+    for fam in shim_families(p) + [shim_lib.BACKTRACK]:
+        for geo in (1, 0):
+            assert shim_lib.scan_like_runtime(p, data, geo=geo, family=fam) == want, (fam, geo)
+    # the same through the exact sub-ranges of the small table
+    if shim_lib.has_g16(p.export_stream_tables()):
+        for fam in (shim_lib.STREAM_G16_EXACT, shim_lib.STREAM_G16_EXACT_MISS):
+            assert shim_lib.scan_like_runtime(p, data, geo=1, family=fam) == want, fam
