@@ -96,7 +96,12 @@ CONFIG_PMC = {"cfg4": "cfg4_nft", "cfg4_guided": "cfg4_nft_guided", "cfg5_dft": 
               "nft_loop": "nft_loop_guided", "dft_loop": "dft_loop_guided", "tile_fallback": "tile_dft"}
 
 
+THIS_ROUND = "r06"          # PMC passes are collected per round (tools/profile_round.sh); a record that quotes another round's says so
+
+
 def config_traffic(name):
+    """HBM bytes per GiB of input from the committed PMC passes (separate rocprofv3 runs at 1 GiB, not this run).  This round's
+    passes are preferred; an older round's are quoted only with "stale_round" in the record (same kernels or not, the reader is told)."""
     import glob
     import re
     tag = CONFIG_PMC.get(name)
@@ -104,6 +109,7 @@ def config_traffic(name):
         return None
     total = 0.0
     src = []
+    rounds = set()
     for c, mul in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_%s.txt" % (tag, c))))
         if not files:
@@ -113,10 +119,15 @@ def config_traffic(name):
             return None
         total += mul * sum(float(v) for v in vals) * 1024
         src.append(os.path.relpath(files[-1], ROOT))
-    return {"hbm_bytes_per_GiB_of_input": int(total),
-            "source": "rocprofv3 --pmc passes at 1 GiB (256 MiB for the tile kernels), committed (not this run): " + ", ".join(src)
-                      + "; FETCH_SIZE x 2 for every access pattern, WRITE_SIZE x 1: calibrated in profiles/r05_fetch_calibration.txt (every read request "
-                        "of the L2s is 128 B and the counter charges 64; what the re-fetches of half-used lines add is real traffic at the L2s' far side)"}
+        rounds.add(os.path.basename(files[-1]).split("_")[0])
+    if len(rounds) != 1:
+        return None                                   # FETCH and WRITE passes of different rounds do not add up to one scan
+    rec = {"hbm_bytes_per_GiB_of_input": int(total),
+           "source": "rocprofv3 --pmc passes at 1 GiB, committed (not this run): " + ", ".join(src) + "; FETCH_SIZE x 2, WRITE_SIZE x 1 (profiles/r05_fetch_calibration.txt)"}
+    rnd = rounds.pop()
+    if rnd != THIS_ROUND:
+        rec["stale_round"] = rnd
+    return rec
 
 
 def cpu_baseline(pattern, engine, sample, cores_mt=0):
@@ -397,6 +408,89 @@ def cli_records_for(trre_amd, inp, out, n, want_cpu):
     return recs
 
 
+LINE_BUDGET = 3500          # bytes; the driver keeps an 8 KB tail of stdout and parses its last line (round 5's 23 KB line was cut: parsed null)
+DETAILS_FILE = "bench_configs.json"
+
+
+def _num(x, nd=4):
+    return round(x, nd) if isinstance(x, float) else x
+
+
+def compact_line(line):
+    """The ONE line the driver parses: the contract's keys, `roofline` and `cpu_baseline` as flat scalars, and a numbers-only summary
+    of the `configs` records.  The prose (workload / verify / traffic sources / notes) stays in DETAILS_FILE."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    out = {k: line.get(k) for k in keep}
+    cfg = line.get("config") or {}
+    out["config"] = {k: cfg.get(k) for k in ("workload", "pattern", "engine", "corpus", "bytes_per_gpu", "output_bytes_per_gpu", "kernel", "parallelism")}
+    rf = line.get("roofline") or {}
+    out["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "algorithmic_bytes_per_launch",
+                                              "achieved_read_plus_write")}
+    cb = line.get("cpu_baseline")
+    out["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample", "value_all_cores", "cores_all", "kind_all_cores") if k in cb} if cb else None
+    out["verified"] = line.get("verified")
+    for k in ("pcie_inclusive_GBps", "pcie_inclusive_pinned_GBps"):
+        if k in line:
+            out[k] = line[k]
+    if "configs" in line:
+        short = []
+        for c in line["configs"]:
+            r = {"name": c.get("name")}
+            if "n_gpus" in c:
+                r["n_gpus"], r["scaling"] = c["n_gpus"], c.get("scaling")
+            if "input_GBps" in c:
+                r["GBps"] = _num(c["input_GBps"])
+            if "frac" in c or "frac_per_gpu_rank0" in c:
+                r["frac"] = _num(c.get("frac", c.get("frac_per_gpu_rank0")))
+            if isinstance(c.get("traffic"), dict):
+                r["x_alg"] = c["traffic"].get("x_algorithmic")
+                if c["traffic"].get("stale_round"):
+                    r["x_alg_round"] = c["traffic"]["stale_round"]
+            if "cli_wall_ms" in c:
+                r["wall_ms"] = c["cli_wall_ms"]
+            elif "input_GBps" not in c and "ms_per_step" in c:
+                r["ms"] = c["ms_per_step"]
+            r["verified"] = c.get("verified")
+            short.append(r)
+        out["configs"] = short
+        out["configs_verified"] = line.get("configs_verified")
+    out["details"] = DETAILS_FILE
+    text = json.dumps(out, separators=(",", ":"))
+    # never outgrow the budget: shed the optional parts, the contract's keys last
+    for drop in ("configs", "pcie_inclusive_pinned_GBps", "pcie_inclusive_GBps"):
+        if len(text) <= LINE_BUDGET:
+            break
+        if drop == "configs" and "configs" in out:
+            out["configs"] = [{k: r[k] for k in ("name", "GBps", "frac", "verified") if k in r} for r in out["configs"]]
+            text = json.dumps(out, separators=(",", ":"))
+            if len(text) <= LINE_BUDGET:
+                break
+        out.pop(drop, None)
+        text = json.dumps(out, separators=(",", ":"))
+    if len(text) > LINE_BUDGET:
+        out["config"]["workload"] = (out["config"].get("workload") or "")[:120]
+        if out.get("cpu_baseline"):
+            out["cpu_baseline"]["sample"] = (out["cpu_baseline"].get("sample") or "")[:80]
+        text = json.dumps(out, separators=(",", ":"))
+    assert len(text) <= LINE_BUDGET + 500, len(text)
+    return text
+
+
+def emit(line):
+    """rank 0: the full record (every config with its prose) to DETAILS_FILE next to this script (and to gpurun_out/ when that exists,
+    so it comes back from a GPU box); then, as the LAST line of stdout, the compact line."""
+    full = json.dumps(line, indent=1)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, DETAILS_FILE), "w") as f:
+                    f.write(full + "\n")
+            except OSError as e:
+                print("bench.py: could not write %s in %s: %r" % (DETAILS_FILE, d, e), file=sys.stderr)
+    sys.stderr.flush()
+    print(compact_line(line), flush=True)
+
+
 class StubProgram:
     """TRRE_BENCH_STUB=1 (tests/test_bench_spawn.py, no GPU): stands in for trre_amd.Program so that the launch, barrier,
     timing and reduction plumbing of the N-rank path runs on CPU over gloo.  It scans nothing; the line it yields says
@@ -509,15 +603,15 @@ def main():
         dev = torch.device("cuda", local)
         sync = torch.cuda.synchronize
     dist = None
-    if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run: one rank per GPU over RCCL
+    if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run: one rank per GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if stub or share:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        # gloo: the data path has no collective (north_star: "no RCCL collectives"); the only exchanges are the timing barrier and
+        # scalar reductions of elapsed time / flags / byte counts, and they run on host tensors
+        dist.init_process_group("gloo")
 
     def barrier():
+        sync()
         if dist is not None:
             dist.barrier()
         sync()
@@ -525,7 +619,7 @@ def main():
     def reduce(x, op):
         if dist is None:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device="cpu" if share else dev)
+        t = torch.tensor([x], dtype=torch.float64)
         dist.all_reduce(t, op={"max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN, "sum": dist.ReduceOp.SUM}[op])
         return float(t.item())
 
@@ -761,6 +855,14 @@ def main():
             {"name": "nft_greedy", "workload": "NFT, greedy loop ' +: ' (bounded fold, runs <= 64)", "pattern": " +: ", "engine": "nft", "steps": 20,
              "cpu_sample": 16 << 20},
         ]
+        # BASELINE configs[1] at the size its text names (1 GiB; the headline above is the same scan at north_star's >= 8 GiB)
+        def upper_check(x, y):
+            return torch.equal(y, torch.where((x >= 97) & (x <= 122), x - 32, x))
+
+        one_gib = corpora.printable_lines(1 << 30, corpora.SEED0 + 2, dev)
+        configs.append(run_config(trre_amd, {"name": "cfg2_1gib", "workload": "BASELINE configs[1] as stated: '[a:A-z:Z]' DFT scan over 1 GiB of synthetic ASCII lines, 1 GPU",
+                                             "pattern": "[a:A-z:Z]", "engine": "dft", "steps": 50, "torch_check": upper_check, "cpu_sample": 0}, one_gib, out, tmp, False))
+        del one_gib
         for spec in printable:
             configs.append(run_config(trre_amd, spec, inp, out, tmp, want_cpu))
         nt = min(n, 1 << 30)
@@ -897,7 +999,7 @@ def main():
         line["configs_verified"] = all(c.get("verified") for c in configs)
 
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        emit(line)
     if dist is not None:
         dist.destroy_process_group()
 
