@@ -882,10 +882,16 @@ int shim_backtrack(const uint8_t* nblob, int geo, const uint8_t* in, size_t n, i
 // (tests/shim_lib.py) has the library explore the listed misses and comes back with the grown tables.  ent: the caller's copy (lanes mark
 // the misses they list).
 int shim_lazy_round(const uint8_t* cls, uint64_t* ent, const uint8_t* pool, uint32_t n_cls, int geo, const uint8_t* in, size_t n, int in_mis,
-                    uint32_t* lane_counts, uint32_t* miss, uint32_t miss_cap, uint64_t budget, uint8_t* out, size_t cap, size_t* m, uint32_t* status_out) {
+                    uint32_t* lane_counts, uint32_t* miss, uint32_t miss_cap, uint64_t budget, uint8_t* out, size_t cap, size_t* m, uint32_t* status_out,
+                    size_t ent_words, int foreign_marks) {
     *m = 0; *status_out = 0;
     miss[0] = 0;
     if (n == 0) return 0;
+    // foreign_marks: every unexplored edge carries the mark of ANOTHER launch (a chunk in flight on the same table that listed it in ITS
+    // miss list, runtime.cpp: the host path's slots) — this launch must list the edges it needs all the same
+    if (foreign_marks)
+        for (size_t k = 0; k < ent_words; ++k)
+            if (ent[k] == kLazyUnexplored) ent[k] = kLazyNoted | (uint64_t)0xdead << 32;
     std::vector<uint8_t> ibuf(n + 64, 0xAA);
     uint8_t* ia = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(ibuf.data()) + 15) & ~(uintptr_t)15) + in_mis;
     std::memcpy(ia, in, n);
@@ -899,6 +905,7 @@ int shim_lazy_round(const uint8_t* cls, uint64_t* ent, const uint8_t* pool, uint
     a.out = out;
     a.cap = cap;
     LazyArgs la{cls, ent, pool, n_cls, miss, miss_cap, budget};
+    la.gen = 1;
     const int64_t lane_bytes = geo == 0 ? 1024 : 64;
     const int64_t n_lanes = (a.vend + lane_bytes - 1) / lane_bytes;
     for (int64_t lane = n_lanes - 1; lane >= 0; --lane) {

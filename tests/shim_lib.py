@@ -44,7 +44,7 @@ def lib():
                                  ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
         L.shim_lazy_round.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t,
                                       ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_size_t,
-                                      ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_uint32)]
+                                      ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_uint32), ctypes.c_size_t, ctypes.c_int]
         _lib = L
     return _lib
 
@@ -276,7 +276,7 @@ DFT_LAZY = 31                                        # the deterministic engine 
 ST_MISS = 128
 
 
-def scan_lazy(prog, data, geo=1, in_mis=0, miss_cap=1 << 16, spec=64, budget=1 << 32, max_rounds=100000):
+def scan_lazy(prog, data, geo=1, in_mis=0, miss_cap=1 << 16, spec=64, budget=1 << 32, max_rounds=100000, foreign_marks=False):
     """the lazy family as the runtime runs it: rounds of (count pass for the lanes without a result; the library explores the edges
     the round listed) until a round lists none, then the emit pass.  Returns (output, status, rounds); ST_DIVERGE: the reference dies here"""
     import numpy as np
@@ -294,7 +294,7 @@ def scan_lazy(prog, data, geo=1, in_mis=0, miss_cap=1 << 16, spec=64, budget=1 <
         m = ctypes.c_size_t()
         st = ctypes.c_uint32()
         rc = lib().shim_lazy_round(cls, entb.ctypes.data, pool if pool else b"\0", n_cls, geo, data, len(data), in_mis, lane_counts.ctypes.data,
-                                   miss.ctypes.data, miss_cap, budget, out, cap, ctypes.byref(m), ctypes.byref(st))
+                                   miss.ctypes.data, miss_cap, budget, out, cap, ctypes.byref(m), ctypes.byref(st), entb.size, int(foreign_marks))
         if rc:
             raise RuntimeError("shim rc %d" % rc)
         rounds += 1

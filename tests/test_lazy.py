@@ -55,6 +55,19 @@ def test_over_cap_vectors_on_the_shim():
     _lazy_vectors(64)
 
 
+def test_marks_of_another_launch_do_not_starve_this_one():
+    """the host path keeps several chunks in flight on ONE device table; an edge that a later chunk's launch had marked as listed
+    (in ITS miss list) used to void the earlier chunk's lanes without being listed there — a round with a miss and an empty list, for ever.
+    Marks carry their launch's id now: every unexplored edge starts each round with a foreign mark, the scan still ends with the reference's bytes."""
+    n = 0
+    for pat, name, data, exp in golden_lib.lazy_cases():
+        p = trre_amd.Program(pat, "dft")
+        got, st, rounds = shim_lib.scan_lazy(p, data, 1, spec=0, foreign_marks=True)      # (scan_lazy asserts that a void round lists a miss)
+        assert not st and got == exp, (pat, name)
+        n += rounds > 1
+    assert n >= 5
+
+
 def test_over_cap_vectors_from_nothing(no_seed):
     assert _lazy_vectors(0) > 10           # (rounds were needed: the tables really grew from the misses)
 

@@ -149,11 +149,13 @@ int main(int argc, char** argv) {
     size_t block = std::getenv("TRRE_CLI_BLOCK") ? (size_t)std::strtoull(std::getenv("TRRE_CLI_BLOCK"), nullptr, 0) : (size_t)256 << 20;
     if (block < 64) block = 64;
     struct stat sb;
-    const bool regular = ::fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
+    // A regular file WITH a size is mapped; anything else is read to its end like a pipe — also files that report size 0 (/proc and sysfs
+    // entries are S_ISREG with st_size 0 and have content: the reference reads them with getline) and files the map fails on.
+    bool regular = ::fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
     off_t file_off = regular ? ::lseek(fd, 0, SEEK_CUR) : 0;
     if (file_off < 0) file_off = 0;
-    const size_t file_left0 = regular && sb.st_size > file_off ? (size_t)(sb.st_size - file_off) : 0;
-    if (regular && !file_left0) { trre_free(prog); return 0; }            // an empty file: nothing is printed
+    size_t file_left0 = regular && sb.st_size > file_off ? (size_t)(sb.st_size - file_off) : 0;
+    if (!file_left0) regular = false;
 
     constexpr int kIn = 3, kOut = 2;
     Block inb[kIn], outb[kOut];
@@ -172,9 +174,13 @@ int main(int argc, char** argv) {
     const uint8_t* map = nullptr;
     if (regular && file_left0) {
         void* m = ::mmap(nullptr, file_left0 + (size_t)(file_off & 4095), PROT_READ, MAP_PRIVATE, fd, file_off & ~(off_t)4095);
-        if (m == MAP_FAILED) { std::fprintf(stderr, "error: can not map the input file\n"); return EXIT_FAILURE; }
-        (void)::madvise(m, file_left0 + (size_t)(file_off & 4095), MADV_SEQUENTIAL);
-        map = static_cast<const uint8_t*>(m) + (file_off & 4095);
+        if (m == MAP_FAILED) {
+            regular = false;                               // read() it instead
+            file_left0 = 0;
+        } else {
+            (void)::madvise(m, file_left0 + (size_t)(file_off & 4095), MADV_SEQUENTIAL);
+            map = static_cast<const uint8_t*>(m) + (file_off & 4095);
+        }
     }
     std::thread reader([&] {
         if (regular) {

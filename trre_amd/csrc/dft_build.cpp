@@ -313,12 +313,13 @@ struct LazyDft::Impl : LazyNftCopy, ClosureCore {
     int32_t add_state(const std::string& key, bool final, bool diverges, std::string final_out) {
         if (bytes_held() + key.size() + (size_t)n_cls * 8 > lim.max_bytes)
             throw Error(kErrTooBig, "error: the determinised tables this input needs exceed the memory limit (TRRE_LAZY_MAX_BYTES; the reference keeps every state it meets, too)");
+        // (every check before the index learns the key: a throw that a caller swallows must not leave an id without a state — ADVICE r5)
+        if (!final && !diverges && state_of_row.size() >= (1u << 27) - 1) throw Error(kErrTooBig, "error: too many table rows");
         const int32_t id = (int32_t)states.size();
         auto ins = index.emplace(key, id);
         key_bytes += key.size();
         State s{&ins.first->first, -1, final, diverges, std::move(final_out)};
         if (!final && !diverges) {
-            if (state_of_row.size() >= (1u << 27) - 1) throw Error(kErrTooBig, "error: too many table rows");
             s.row = (int32_t)state_of_row.size();
             state_of_row.push_back(id);
             row_epoch.push_back(epoch);

@@ -41,18 +41,29 @@ struct LazyArgs {
     const uint8_t* cls_l = nullptr;
     const uint64_t* ent_l = nullptr;
     uint32_t rows_l = 0;
+    uint32_t gen = 0;          // this launch's id: a mark is kLazyNoted | gen << 32.  Several scan contexts share one table (the host path's
+                               // chunks in flight): a mark left by ANOTHER launch says nothing about this launch's list, so the edge is
+                               // listed again (without the id a chunk could wait for ever on an edge only a later chunk had listed)
 };
 
 constexpr uint32_t kLazyFollow = 48;     // (kLazyMissWords: front.hpp / below)
 template <class ByteAt>
 TRRE_HD void lazy_note_miss(const LazyArgs& la, uint32_t row, uint32_t k, int64_t behind, ByteAt byte_at) {
     uint64_t* e = la.ent + (uint64_t)row * la.n_cls + k;
+    const uint64_t mine = kLazyNoted | (uint64_t)la.gen << 32;
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (atomicCAS(reinterpret_cast<unsigned long long*>(e), (unsigned long long)kLazyUnexplored, (unsigned long long)kLazyNoted) != kLazyUnexplored) return;
+    unsigned long long cur = __hip_atomic_load(reinterpret_cast<unsigned long long*>(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        if (cur == mine) return;                                               // listed by this launch already
+        if (cur != kLazyUnexplored && (uint32_t)cur != (uint32_t)kLazyNoted) return;   // built meanwhile
+        const unsigned long long was = atomicCAS(reinterpret_cast<unsigned long long*>(e), cur, (unsigned long long)mine);
+        if (was == cur) break;
+        cur = was;
+    }
     const uint32_t at = atomicAdd(la.miss, 1u);
 #else
-    if (*e != kLazyUnexplored) return;
-    *e = kLazyNoted;
+    if (*e == mine || (*e != kLazyUnexplored && (uint32_t)*e != (uint32_t)kLazyNoted)) return;
+    *e = mine;
     const uint32_t at = la.miss[0]++;
 #endif
     if (at < la.miss_cap) {
@@ -185,8 +196,8 @@ TRRE_HD void lazy_lane(const ScanArgs& a, const LazyArgs& la, int64_t lane, int6
         const uint64_t e = entry(row, c, k);
         uint32_t kind = walk ? ent_kind(e) : 0u;
         bool missed = false;
-        if (walk && (e == kLazyUnexplored || e == kLazyNoted)) {
-            if (e == kLazyUnexplored) lazy_note_miss(la, row, k, i + 1, byte_at);
+        if (walk && (e == kLazyUnexplored || (uint32_t)e == (uint32_t)kLazyNoted)) {
+            if (e != (kLazyNoted | (uint64_t)la.gen << 32)) lazy_note_miss(la, row, k, i + 1, byte_at);
             voided = true;
             status |= kStMiss;
             missed = true;                                 // nothing more to learn from this line

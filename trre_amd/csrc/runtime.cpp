@@ -842,6 +842,8 @@ int lazy_round(trre_prog* p, DeviceState* st, ScanCtx* cx, const trre::ScanArgs&
     la.n_rows = st->lazy_rows_up;
     la.miss = cx->d_miss;
     la.miss_cap = kLazyMissCap;
+    static std::atomic<uint32_t> launch_id{0};
+    la.gen = ++launch_id;                     // (lazy_block.hpp: marks of other launches — other chunks in flight on the same table — are listed again)
     static const uint64_t budget = getenv("TRRE_LAZY_BUDGET") ? (uint64_t)atoll(getenv("TRRE_LAZY_BUDGET")) : kLazyBudget;
     la.budget = budget;
     launch_lazy(1, args, la, kLazyLaneBytes, n_chunks, stream);
@@ -1256,12 +1258,26 @@ int finish_inner(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
         const int64_t n_chunks = (args.vend + kLazyLaneBytes * 256 - 1) / (kLazyLaneBytes * 256);
         std::vector<uint32_t> miss;
         size_t spec = 1024;
+        int empty_rounds = 0;
         static const bool lazy_trace = getenv("TRRE_TRACE") != nullptr;
         for (int round = 1; (status & kStMiss) && !(status & (kStEditOverflow | kStDiverge)); ++round) {
             uint32_t head[2] = {0, 0};
             HIP_TRY(hipMemcpyAsync(head, cx->d_miss, 8, hipMemcpyDeviceToHost, was.stream));
             HIP_TRY(hipStreamSynchronize(was.stream));
             const uint32_t n_miss = head[0] < kLazyMissCap ? head[0] : kLazyMissCap;
+            // a void lane lists the edge it stopped at unless this very launch has listed it (or the list was full: then it holds other
+            // edges), so a round with a miss and an empty list cannot be — if it is, the device's rows go up afresh, and the scan gives up
+            // rather than spin
+            if (!n_miss) {
+                if (++empty_rounds > 3) {
+                    if (out_len) *out_len = 0;
+                    return fail(TRRE_E_DEVICE, "error: the lazy tables make no progress (a miss with nothing listed, four rounds running)");
+                }
+                std::lock_guard<std::mutex> lock(p->lazy_mu);
+                st->lazy_rows_up = 0;
+            } else {
+                empty_rounds = 0;
+            }
             miss.resize((size_t)trre::kLazyMissWords * n_miss + 2);
             if (n_miss) HIP_TRY(hipMemcpyAsync(miss.data(), cx->d_miss + 2, (size_t)n_miss * trre::kLazyMissWords * 4, hipMemcpyDeviceToHost, was.stream));
             HIP_TRY(hipStreamSynchronize(was.stream));
@@ -1487,6 +1503,9 @@ int finish_inner(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
 int finish(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
     using namespace trre;
     const Pending was = cx->pend;
+    // the long-line probe's verdict holds for the batch it was asked in (identical launches); the caller may put other bytes into the same
+    // buffer afterwards — the host path's slots do for every chunk — so the next batch asks again
+    cx->probe_in = nullptr; cx->probe_n = 0;
     GuardHit hit;
     if (was.active && was.guard_hit) {                     // found before an in-place launch: nothing has run yet
         cx->pend = Pending();
