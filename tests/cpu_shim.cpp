@@ -18,6 +18,7 @@
 #include "../trre_amd/csrc/splice_block.hpp"
 #include "../trre_amd/csrc/gen_block.hpp"
 #include "../trre_amd/csrc/lazy_block.hpp"
+#include "../trre_amd/csrc/one_block.hpp"
 #include "../trre_amd/csrc/guard_block.hpp"
 
 using namespace trre;
@@ -358,6 +359,79 @@ void run_direct_gen_exact(ScanArgs a, int64_t lane_bytes, uint32_t& status, uint
     }
 }
 
+// ONE walk (round 6; one_block.hpp) as k_stream_one runs it: tiles of `nl` lanes of `S` bytes; per tile the walk from guessed entry
+// states into private regions of R bytes, the verification against the lane before with repair rounds, the prefix sums, the tile's place
+// in the output (the running sum — what the look-back finds) with the check of the tile's first guess against the exit of the tile before,
+// then the output line by line through one_mark / one_store_line.  kStOneVoid: the kernel would have left the buffer to the count / emit pair.
+template <int kSym = 0>
+void run_direct_gen_one(ScanArgs a, uint32_t S, uint32_t R, uint32_t look, int nl, uint32_t& status, uint64_t& total_out, int& rounds) {
+    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
+    const StreamView T = direct_view(a);
+    const int64_t n_lanes = (a.vend + S - 1) / S;
+    const int64_t n_tiles = (n_lanes + nl - 1) / nl;
+    const bool slow = (h.flags & kFlagG16SlowBit) != 0;
+    a.spec_look = look;
+    std::vector<uint8_t> regions_raw((size_t)nl * R + 64 + 16);
+    uint8_t* regions = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(regions_raw.data()) + 15) & ~(uintptr_t)15);
+    std::vector<uint32_t> offs(nl + 1), exits(nl), used(nl), known(nl), lens(nl), sts(nl);
+    std::vector<uint8_t> need(nl);
+    std::vector<uint8_t> marks((size_t)nl * R / 16 + 32);
+    uint64_t base = 0;
+    uint32_t prev_exit = 0;
+    rounds = 0;
+    for (int64_t tile = 0; tile < n_tiles; ++tile) {
+        std::fill(regions_raw.begin(), regions_raw.end(), 0xCD);
+        auto walk = [&](int t, uint32_t entry) {
+            DirectLane L;
+            L.entry = entry;
+            uint32_t st = 0;
+            const int64_t lane = tile * nl + t;
+            if (slow) g16_lane<3, kSym, true>(a, T, h.n_cls, lane, (int64_t)S, regions + (size_t)t * R, (uint64_t)R, L, st);
+            else g16_lane<3, kSym, false>(a, T, h.n_cls, lane, (int64_t)S, regions + (size_t)t * R, (uint64_t)R, L, st);
+            exits[t] = L.exit; used[t] = L.entry; lens[t] = (uint32_t)L.count; sts[t] = st;
+            if (entry == kOneGuess) known[t] = L.known;
+        };
+        for (int t = nl - 1; t >= 0; --t) walk(t, kOneGuess);
+        bool gave_up = false;
+        for (int round = 0;; ++round) {
+            bool any = false;
+            const std::vector<uint32_t> exits_before = exits;            // (what the threads read before any of them walks again)
+            for (int t = 1; t < nl; ++t) {
+                const bool live = (tile * nl + t) * (int64_t)S < a.vend;
+                need[t] = live && !known[t] && used[t] != exits_before[t - 1];
+                any = any || need[t];
+            }
+            if (!any) break;
+            if (round + 1 >= kOneRounds) { gave_up = true; break; }
+            ++rounds;
+            for (int t = nl - 1; t >= 1; --t) if (need[t]) walk(t, exits_before[t - 1]);
+        }
+        uint32_t st = 0;
+        for (int t = 0; t < nl; ++t) st |= sts[t];
+        if (gave_up) st |= kStOneVoid;
+        uint32_t run = 0;
+        for (int t = 0; t < nl; ++t) { offs[t] = run; run += (st & kStOneVoid) ? 0u : lens[t]; }      // (a void tile: an empty output, as in the kernel)
+        offs[nl] = run;
+        const uint32_t total = run;
+        if (tile > 0 && !known[0] && used[0] != prev_exit) st |= kStOneVoid;      // the guess nobody repairs in place
+        prev_exit = exits[nl - 1];
+        status |= st;
+        OneTile tv{regions, offs.data(), marks.data(), R};
+        const uint32_t hh = (uint32_t)((reinterpret_cast<uintptr_t>(a.out) + base) & 15u);
+        std::fill(marks.begin(), marks.end(), 0xEE);
+        for (int t = 0; t < nl; ++t) one_mark(tv, t, hh);
+        const bool write = base + total <= a.cap;
+        if (!write) status |= kStCapacity;
+        const uint32_t n_lines = (hh + total + 15u) >> 4;
+        for (uint32_t c = 0; c < n_lines; c += 2) {
+            const uint32_t cc[2] = {c, c + 1};
+            one_store_lines<2>(tv, a.out, base, hh, cc, total, write);
+        }
+        base += total;
+    }
+    total_out = base;
+}
+
 
 // large tables in their fallback form (k_stream_fb): count, scan, emit — lane by lane
 FbView fb_view(const ScanArgs& a) {
@@ -611,7 +685,7 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
     a.gscratch = want_scratch ? scratch.data() : nullptr;
     uint32_t status = 0;
     uint64_t total = 0;
-    if (family != 3 && family != 5 && family != 7 && family != 9 && family != 22 && family != 23 && family != 24 && family != 25 && cap < n) return -9;
+    if (family != 3 && family != 5 && family != 7 && family != 9 && family != 22 && family != 23 && family != 24 && family != 25 && family != 34 && family != 35 && family != 36 && cap < n) return -9;
     if (family == 1) { run_bytemap(a, status); total = n; }
     else if (family == 8) {
         if (reinterpret_cast<const StreamBlobHeader*>(blob)->lpw_bytes == 0) return -5;
@@ -644,6 +718,14 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
         if (reinterpret_cast<const StreamBlobHeader*>(blob)->g16_bytes == 0) return -5;
         int rounds = 0;
         run_direct_gen_exact<>(a, geo == 0 ? 2048 : 64, status, total, family == 33 ? 4u : (uint32_t)kSpecLook, geo == 0 ? 256 : 3, rounds);
+        g_last_rounds = rounds;
+    }
+    else if (family == 34 || family == 35 || family == 36) {   // ... in ONE walk (one_block.hpp); 35: a look-back of 4 bytes and tiles of 3 lanes (wrong guesses: repair
+        if (reinterpret_cast<const StreamBlobHeader*>(blob)->g16_bytes == 0) return -5;     // rounds, void tiles); 36: regions of 76 bytes for 64 of input
+        int rounds = 0;
+        if (family == 34) run_direct_gen_one<>(a, geo == 0 ? 128u : 64u, geo == 0 ? 172u : 100u, 32u, geo == 0 ? 256 : 5, status, total, rounds);
+        else if (family == 35) run_direct_gen_one<>(a, 64u, 140u, 4u, 3, status, total, rounds);
+        else run_direct_gen_one<>(a, 64u, 76u, 32u, 4, status, total, rounds);
         g_last_rounds = rounds;
     }
     else if (family == 4) {
@@ -720,7 +802,8 @@ int shim_scan_guided(const uint8_t* rblob, const uint8_t* gblob, int family, int
     if ((family == 10 || family == 13 || family == 14) && cap < n) return -9;
     // like the runtime: symbols are packed two per byte when the backward DFA allows it and the walk uses the 16-byte entries
     const bool has_g16 = reinterpret_cast<const StreamBlobHeader*>(gblob)->g16_bytes != 0;
-    const bool packed = reinterpret_cast<const RevBlobHeader*>(rblob)->sym_bits == 4 && has_g16 && (family == 10 || family == 11 || family == 17 || family == 18);
+    const bool packed = reinterpret_cast<const RevBlobHeader*>(rblob)->sym_bits == 4 && has_g16 &&
+                        (family == 10 || family == 11 || family == 17 || family == 18 || family == 40 || family == 41);
     if (reinterpret_cast<const RevBlobHeader*>(rblob)->sym_bits == 16) {
         // wide guided tables (more than 256 backward states): k_rev_wide, k_wide_fwd<count>, scan, k_wide_fwd<emit>
         if (family == 10 || family == 13 || family == 14) return -5;
@@ -745,8 +828,8 @@ int shim_scan_guided(const uint8_t* rblob, const uint8_t* gblob, int family, int
         return 0;
     }
     int rev_rounds = 0;
-    if (family == 17 || family == 18) {
-        rev_rounds = run_rev_sweep_exact(a, lane_bytes, packed, family == 18 ? 4u : (uint32_t)kSpecLook);
+    if (family == 17 || family == 18 || family == 40 || family == 41) {
+        rev_rounds = run_rev_sweep_exact(a, lane_bytes, packed, family == 18 || family == 41 ? 4u : (uint32_t)kSpecLook);
         if (rev_rounds < 0) { *status_out = 1u << 29; *m = 0; return 0; }
     } else {
         run_rev_sweep(a, lane_bytes, packed);
@@ -763,6 +846,16 @@ int shim_scan_guided(const uint8_t* rblob, const uint8_t* gblob, int family, int
         int rounds = 0;
         if (packed) run_direct_gen_exact<2>(a, lane_bytes, status, total, family == 18 ? 4u : (uint32_t)kSpecLook, geo == 0 ? 256 : 3, rounds);
         else run_direct_gen_exact<1>(a, lane_bytes, status, total, family == 18 ? 4u : (uint32_t)kSpecLook, geo == 0 ? 256 : 3, rounds);
+        g_last_rounds = rounds + rev_rounds;
+    }
+    else if (family == 40 || family == 41) {
+        // the general guided family in ONE forward walk behind the backward pass (one_block.hpp); 41: look-backs of 4 bytes, tiles of 3 lanes
+        if (!has_g16) return -5;
+        int rounds = 0;
+        const uint32_t S = family == 41 ? 64u : (geo == 0 ? 128u : 64u), R = family == 41 ? 140u : (geo == 0 ? 172u : 100u);
+        const int nl = family == 41 ? 3 : (geo == 0 ? 256 : 5);
+        if (packed) run_direct_gen_one<2>(a, S, R, family == 41 ? 4u : 32u, nl, status, total, rounds);
+        else run_direct_gen_one<1>(a, S, R, family == 41 ? 4u : 32u, nl, status, total, rounds);
         g_last_rounds = rounds + rev_rounds;
     }
     else if (packed) run_direct_gen<2>(a, lane_bytes, status, total, true);

@@ -60,7 +60,7 @@ def shim_scan(blob, engine, family, data, geo=1, in_mis=0, out_mis=0, scratch=Tr
     """Run one kernel family of the device code on the host.  Returns (output bytes, status)."""
     auto_cap = cap is None
     if cap is None:
-        cap = len(data) * 8 + 64 if family in (3, 5, 7, 9, 22, 23, 25, 27, 29, 32, 33) else len(data)     # (20, 21: length-preserving)
+        cap = len(data) * 8 + 64 if family in (3, 5, 7, 9, 22, 23, 25, 27, 29, 32, 33, 34, 35, 36) else len(data)     # (20, 21: length-preserving)
     for _ in range(2):
         out = ctypes.create_string_buffer(max(cap, 1))
         m = ctypes.c_size_t()
@@ -114,6 +114,12 @@ ST_EDIT_OVERFLOW = 64
 GUIDED_LP, GUIDED_GEN, GUIDED_GEN8, GUIDED_LP_RING, GUIDED_LP8 = 10, 11, 12, 13, 14
 GUIDED_GEN_EXACT, GUIDED_GEN_EXACT_MISS = 17, 18     # general guided family with exact sub-ranges (round 5); 18: a look-back of 4 bytes (repair rounds)
 STREAM_G16_EXACT, STREAM_G16_EXACT_MISS = 32, 33     # stream general family, the same
+# ONE walk (round 6, one_block.hpp): the production geometry (geo 0: 256 lanes of 128 bytes; geo 1: 5 lanes of 64); _MISS: look-backs of 4 bytes and tiles
+# of 3 lanes (wrong guesses: repair rounds inside a tile, void launches across tiles); _TIGHT: regions of 76 bytes for 64 of input (outgrown regions)
+STREAM_ONE, STREAM_ONE_MISS, STREAM_ONE_TIGHT = 34, 35, 36
+GUIDED_ONE, GUIDED_ONE_MISS = 40, 41
+ST_ONE_VOID = 256
+one_stats = {"runs": 0, "void": 0}                  # how often the one-pass form answered / left the buffer to the pair
 GUIDED_LP_ALL = (GUIDED_LP, GUIDED_LP_RING, GUIDED_LP8)
 STREAM_LP_EMIT, STREAM_LP_EMIT8 = 20, 21            # stream LP family by the emit pass alone (no window form)
 STREAM_LPW_PAIR = 26                                 # the window kernel on the pair form of its entries (what the runtime launches when the tables have one)
@@ -151,6 +157,20 @@ def last_rounds():
 
 
 def scan_guided_like_runtime(prog, data, geo=1, family=GUIDED_LP, in_mis=0, out_mis=0):
+    if family in (GUIDED_ONE, GUIDED_ONE_MISS):
+        # like finish(): a void one-pass launch leaves the buffer to the count / emit pair with exact sub-ranges
+        try:
+            out, st = shim_scan_guided(prog, family, data, geo, in_mis, out_mis)
+        except RuntimeError as e:
+            if "rc -5" not in str(e):
+                raise
+            out, st = None, ST_ONE_VOID
+        one_stats["runs"] += 1
+        assert not st & (1 << 29), "the backward pass's repair rounds did not converge"
+        if not st & (ST_ONE_VOID | ST_DIVERGE | ST_OVERFLOW):
+            return out
+        one_stats["void"] += 1
+        family = GUIDED_GEN_EXACT if family == GUIDED_ONE else GUIDED_GEN_EXACT_MISS
     if family in (GUIDED_GEN_EXACT, GUIDED_GEN_EXACT_MISS):
         lib()
         rblob, gblob = prog.export_guided_tables()
@@ -186,7 +206,7 @@ def scan_like_runtime(prog, data, geo=1, family=None, in_mis=0, out_mis=0):
     fam = family
     if not fam:                       # ABI ids -> shim ids (the shim's 6..9 are the direct walkers of the stream families)
         fam = {6: GUIDED_LP, 7: GUIDED_GEN}.get(info.kernel, info.kernel)
-    if fam in (GUIDED_LP, GUIDED_GEN, GUIDED_GEN8, GUIDED_LP_RING, GUIDED_LP8, GUIDED_GEN_EXACT, GUIDED_GEN_EXACT_MISS):
+    if fam in (GUIDED_LP, GUIDED_GEN, GUIDED_GEN8, GUIDED_LP_RING, GUIDED_LP8, GUIDED_GEN_EXACT, GUIDED_GEN_EXACT_MISS, GUIDED_ONE, GUIDED_ONE_MISS):
         return scan_guided_like_runtime(prog, data, geo, fam, in_mis, out_mis)
     if family == DFT_LAZY or (not family and info.kernel == 10):
         out, st, _ = scan_lazy(prog, data, geo, in_mis)
@@ -202,7 +222,14 @@ def scan_like_runtime(prog, data, geo=1, family=None, in_mis=0, out_mis=0):
         if st & ST_DIVERGE:
             raise RuntimeError("diverges")
         return out
-    blob = prog.export_stream_tables() if fam in (4, 5, 6, 7, 8, 9, 20, 21, 22, 23, 25, 27, 32, 33, STREAM_LPW_PAIR) else prog.export_tables()
+    blob = prog.export_stream_tables() if fam in (4, 5, 6, 7, 8, 9, 20, 21, 22, 23, 25, 27, 32, 33, 34, 35, 36, STREAM_LPW_PAIR) else prog.export_tables()
+    if fam in (STREAM_ONE, STREAM_ONE_MISS, STREAM_ONE_TIGHT):
+        out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
+        one_stats["runs"] += 1
+        if out is not None and not st & (ST_ONE_VOID | ST_DIVERGE | ST_OVERFLOW):
+            return out
+        one_stats["void"] += 1
+        fam = STREAM_G16_EXACT_MISS if fam == STREAM_ONE_MISS else STREAM_G16_EXACT      # like finish(): the pair takes the buffer
     if fam in (STREAM_G16_EXACT, STREAM_G16_EXACT_MISS):
         out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
         if out is not None and not st & (ST_DIVERGE | ST_OVERFLOW):

@@ -612,6 +612,56 @@ def test_exact_sub_ranges_on_every_golden_vector():
     assert n_rounds > 40, n_rounds
 
 
+def test_one_walk_on_every_golden_vector():
+    """round 6 (one_block.hpp): the general families on small tables in ONE walk — lanes of 64 / 128 bytes from guessed
+    states, verified against the lane before and walked again where wrong, the tile's output gathered from the lanes' regions line by
+    line, tiles chained by their running totals.  Every golden vector through it, stream and guided tables, the production geometry and
+    tiny ones (look-backs of 4 bytes and tiles of 3 lanes: repair rounds and void launches; regions of 76 bytes for 64 of input:
+    outgrown regions) — a void launch answers through the count / emit pair, as finish() does."""
+    n = n_rounds = 0
+    shim_lib.one_stats.update(runs=0, void=0)
+    for k, (pat, name, data, eng, exp) in enumerate(golden_lib.cases()):
+        if exp is None or len(data) > 30000 or k % 2:
+            continue
+        p = prog(pat, eng)
+        info = p.info
+        fams = []
+        if info.stream_states and shim_lib.has_g16(p.export_stream_tables()):
+            fams += [shim_lib.STREAM_ONE, shim_lib.STREAM_ONE_MISS, shim_lib.STREAM_ONE_TIGHT]
+        if info.guided_rev_states and info.guided_rev_states <= 256 and shim_lib.has_g16(p.export_guided_tables()[1]):
+            fams += [shim_lib.GUIDED_ONE, shim_lib.GUIDED_ONE_MISS]
+        for fam in fams:
+            for geo, mis, omis in ((1, 0, 0), (0, 7, 5)):
+                got = shim_lib.scan_like_runtime(p, data, geo=geo, family=fam, in_mis=mis, out_mis=omis)
+                assert got == exp, (pat, name, eng, fam, geo)
+                n_rounds += shim_lib.last_rounds()
+                n += 1
+    assert n > 1500 and n_rounds > 3, (n, n_rounds)
+    # it answered itself most of the time (the tiny geometries are there to void it)
+    assert shim_lib.one_stats["void"] < shim_lib.one_stats["runs"] // 2, shim_lib.one_stats
+    # long lines, a NUL in front of one (SKIP travels through every lane of the line: rounds, then a tile gives up), every output alignment
+    rng = random.Random(5)
+    text = b"".join(bytes(rng.choice(b"abc  xyz,cat dog") for _ in range(rng.randint(800, 4000))) + b"\n" for _ in range(12))
+    data = text + b"aa\0bbb" + text[:9000] + b"tail   x"
+    for pat, eng in [(" +: ", "nft"), ("a:xyz", "dft"), ("(a|b)*c:x", "nft"), ("(cat:dog|dog:cat)", "nft"), ("[a-z]+g:X", "dft"), ("(a|b)*c:x", "dft"), ("[aie]:", "nft"),
+                     ("a:", "dft"), (".:xy", "dft")]:
+        p = prog(pat, eng)
+        want = Oracle(pat, eng).scan(data)
+        fams = (shim_lib.STREAM_ONE, shim_lib.STREAM_ONE_MISS, shim_lib.STREAM_ONE_TIGHT) if p.info.kernel in (4, 5) else (shim_lib.GUIDED_ONE, shim_lib.GUIDED_ONE_MISS)
+        for fam in fams:
+            for geo in (0, 1):
+                for omis in (0, 1, 9, 15):
+                    assert shim_lib.scan_like_runtime(p, data, geo=geo, family=fam, in_mis=3, out_mis=omis) == want, (pat, eng, fam, geo, omis)
+    # and what the form is for: the output of text really comes out of it, not out of the fallback
+    shim_lib.one_stats.update(runs=0, void=0)
+    plain = b"".join(bytes(rng.choice(b"the quick brown fox jumps over a lazy dog, cat. ") for _ in range(rng.randint(20, 300))) + b"\n" for _ in range(400))
+    for pat, eng in [("a:xyz", "dft"), (" +: ", "nft"), ("(a|b)*c:x", "nft")]:
+        p = prog(pat, eng)
+        fam = shim_lib.STREAM_ONE if p.info.kernel in (4, 5) else shim_lib.GUIDED_ONE
+        assert shim_lib.scan_like_runtime(p, plain, geo=0, family=fam) == Oracle(pat, eng).scan(plain)
+    assert shim_lib.one_stats == {"runs": 3, "void": 0}, shim_lib.one_stats
+
+
 def test_more_than_eight_output_bytes_per_input_byte():
     """a pattern whose epsilon loops print a dozen bytes around every input byte (found by tools/shim_fuzz.py, seed 503, round 5 — the
     kernels were right, the harness's output buffer of 8 x the input was not): the count pass reports the size, the caller comes back

@@ -21,6 +21,7 @@ ap.add_argument("--bytes", type=int, default=1 << 30)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--dict", type=int, default=0, help="use the seeded N-entry key:value dictionary pattern and corpus (config 5)")
 ap.add_argument("--out-mis", type=int, default=0, help="misalign the output buffer by this many bytes")
+ap.add_argument("--sum", action="store_true", help="print a position-weighted checksum of the output (A/B runs in separate processes compare it)")
 ap.add_argument("--case", action="append", default=[], help="pattern;;engine;;corpus;;kernel (repeatable)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -50,5 +51,14 @@ for pat, eng, corp, kern in cases:
         p.enqueue(inp, out)
     m = p.finish()
     dt = (time.perf_counter() - t0) / a.steps
-    print("pattern=%.40s engine=%s corpus=%s kernel=%s bytes=%d out=%d  %.3f ms/step  %.1f GB/s  (events %.3f ms)" % (
-        pat, eng, corp, trre_amd.KERNEL_NAMES[FAMS[kern] or p.info.kernel], a.bytes, m, dt * 1e3, a.bytes / dt / 1e9, p.last_kernel_ms()), flush=True)
+    chk = ""
+    if a.sum:
+        acc = 0
+        step = 1 << 28
+        for lo in range(0, m, step):
+            x = out[lo:min(m, lo + step)].to(torch.int64)
+            w = (torch.arange(lo, lo + x.numel(), device=dev, dtype=torch.int64) % 65521) + 1
+            acc = (acc + int((x * w).sum())) % (1 << 61)
+        chk = "  sum=%016x" % acc
+    print("pattern=%.40s engine=%s corpus=%s kernel=%s bytes=%d out=%d  %.3f ms/step  %.1f GB/s  (events %.3f ms)%s" % (
+        pat, eng, corp, trre_amd.KERNEL_NAMES[FAMS[kern] or p.info.kernel], a.bytes, m, dt * 1e3, a.bytes / dt / 1e9, p.last_kernel_ms(), chk), flush=True)

@@ -9,6 +9,7 @@ struct FbCopyArgs;
 struct GenArgs;
 struct GuardArgs;
 struct LazyArgs;
+struct OneArgs;
 
 constexpr int kEngineNft = 0, kEngineDft = 1;
 
@@ -29,6 +30,9 @@ int direct_block_threads();
 // (16-byte entries only)
 void launch_direct_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, void* stream, int g16_bytes = 0,
                           int sym = 0, bool g16_slow = true);
+// the one-pass form of the general families on small tables (one_block.hpp: one walk, the workgroup's output in LDS, look-back for its place);
+// oa.desc / oa.ticket zeroed by the caller; -1: the tables and regions do not fit the LDS
+int launch_one(const ScanArgs& a, const OneArgs& oa, void* stream, int g16_bytes, int sym, bool g16_slow);
 // backward pass of the guided families: fills a.sym_v0 for positions [0 .. round_up(a.vend, 64)) (packed: round_up(.., 128), two per byte)
 void launch_rev_sweep(const ScanArgs& a, int tab_bytes, int64_t lane_bytes, void* stream, bool packed);
 // wide guided tables (more than 256 backward states: 16-bit symbols at a.sym_v0, both tables through L1 / L2); which: 1 count, 2 emit

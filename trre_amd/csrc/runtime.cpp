@@ -29,6 +29,7 @@
 #include "splice_block.hpp"
 #include "gen_block.hpp"
 #include "lazy_block.hpp"
+#include "one_block.hpp"
 #include "guard_block.hpp"
 
 namespace {
@@ -106,6 +107,7 @@ struct Pending {
     int count = 0;          // launches in the current batch
     const uint64_t* total_at = nullptr;   // general families: where the launch leaves its output size
     bool patched = false;                 // the launch was the mark + splice pair of a large table's copy form, not a count / emit pair
+    bool one = false;                     // the launch was the one-pass kernel (one_block.hpp), not a count / emit pair
     // the stack guard found, before an in-place launch, a line on which the reference's search runs out of stack: nothing was launched
     // exact sub-ranges (scan_block.hpp: ScanArgs::exact): what finish() needs to run repair rounds and the emit pass again
     bool exact = false;
@@ -159,6 +161,10 @@ struct ScanCtx {
     size_t probe_n = 0;
     bool long_lines = false;
     bool exact_off = false;           // finish() runs a scan again the old way (a diverging attempt: the first lane in stream order has to be named)
+    // the one-pass kernel (one_block.hpp): look-back descriptors [tiles], then the ticket counter and the total
+    uint64_t* d_one = nullptr;
+    int64_t one_tiles = 0;
+    bool one_off = false;             // finish() runs the scan again as a count / emit pair (a void one-pass launch)
     uint32_t* d_miss = nullptr;       // lazy tables (lazy_block.hpp): [0] misses listed, then {row, class} pairs
     int bt_tier = 0;                  // the backtracking fallback: which size of stacks and path buffers the next launch uses (kBtTiers)
     bool guard_off = false;           // finish() scans the lines before a line the guard stopped at: not to be guarded again
@@ -232,6 +238,7 @@ struct trre_prog {
     bool profiling = false;
     std::atomic<float> last_ms{-1.f};
     std::atomic<bool> bounded_off{false};     // a launch on a bounded stream table met a run it was not built for: the guided / tile kernels from now on
+    std::atomic<int> one_fails{0};            // void launches of the one-pass kernel (a region outgrown, a first guess wrong): after two the pair from now on
     std::atomic<bool> copy_form_off{false};   // a launch of the copy form met more texts than its event lists hold: the count / emit pair from now on
     std::mutex dev_mu;                                  // guards the map (not the states)
     std::map<int, std::unique_ptr<DeviceState>> dev;
@@ -550,6 +557,7 @@ void ctx_free(ScanCtx& c) {
     (void)hipFree(c.d_gflags); (void)hipFree(c.d_gruns); (void)hipFree(c.d_gstack); (void)hipFree(c.d_gobuf); (void)hipFree(c.d_gout);
     (void)hipFree(c.d_miss);
     (void)hipFree(c.d_spec);
+    (void)hipFree(c.d_one);
     (void)hipFree(c.d_probe);
     (void)hipFree(c.d_cevents);
     (void)hipFree(c.d_chdr);
@@ -1127,6 +1135,51 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
             launch_rev_sweep(args, (int)p->gt.n_rev * 256, rev_lane_bytes, stream, sym_mode == 2);
             if (use_exact) launch_rev_verify(args, rev_lane_bytes, stream, sym_mode == 2);
         }
+        // ONE walk (round 6; one_block.hpp — SURVEY.md row f2): lanes of 128 bytes from guessed-and-verified states, a workgroup's whole output
+        // staged in LDS, its place in the output by look-back over the workgroups' totals: the input is read once and walked once.  What the
+        // kernel cannot answer in place — a lane whose output outgrows its LDS region, a workgroup whose first lane guessed wrong, a replacement
+        // text of more than 8 bytes, a wrong guess of the backward pass — voids the launch (kStOneVoid) and finish() runs the pair below;
+        // after two such launches the program stops trying.
+        // MEASURED (profiles/r06_expand_one_*): bit-identical output, 1.05 GiB fetched and 1.06 GiB written per GiB (the pair:
+        // 2.2 x that) — and HALF the pair's speed (8 GiB of 'a:xyz': 15.7 ms against 7.9): with a workgroup's output held in LDS only three
+        // waves per SIMD are resident, and the walk is a chain of dependent table reads that wants twice that to hide.  So the pair stays
+        // the default and this form is opt-in: TRRE_ONE=1.
+        static const int one_env = getenv("TRRE_ONE") ? atoi(getenv("TRRE_ONE")) : 0;
+        static const int one_lane_env = getenv("TRRE_ONE_LANE") ? atoi(getenv("TRRE_ONE_LANE")) : 0;
+        static const int one_region_env = getenv("TRRE_ONE_REGION") ? atoi(getenv("TRRE_ONE_REGION")) : 0;
+        static const int one_look_env = getenv("TRRE_ONE_LOOK") ? atoi(getenv("TRRE_ONE_LOOK")) : 0;
+        if (use_exact && one_env == 1 && !cx->one_off && p->one_fails.load() < 2 && stt.max_out <= 8u) {
+            OneArgs oa{};
+            oa.lane_bytes = one_lane_env > 0 ? (uint32_t)((one_lane_env + 63) / 64 * 64) : 128u;
+            oa.region = one_region_env > 0 ? (uint32_t)(one_region_env / 8 * 8 + 4) : 172u;          // (an odd number of dwords)
+            oa.look = one_look_env > 0 ? (uint32_t)((one_look_env + 15) / 16 * 16) : 32u;
+            oa.spin = 1u << 20;
+            oa.n_tiles = (args.vend + (int64_t)oa.lane_bytes * kOneThreads - 1) / ((int64_t)oa.lane_bytes * kOneThreads);
+            if (cx->one_tiles < oa.n_tiles) {
+                if (cx->d_one) (void)hipFree(cx->d_one);
+                cx->d_one = nullptr; cx->one_tiles = 0;
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&cx->d_one), (size_t)(oa.n_tiles + 2 + 8 + 2 * (oa.n_tiles / 32 + 1)) * 8));
+                cx->one_tiles = oa.n_tiles;
+            }
+            oa.desc = cx->d_one;
+            oa.ticket = reinterpret_cast<uint32_t*>(cx->d_one + oa.n_tiles);
+            oa.total = cx->d_one + oa.n_tiles + 1;
+            oa.gsum = cx->d_one + oa.n_tiles + 2 + 8;
+            oa.ginc = oa.gsum + (oa.n_tiles / 32 + 1);
+            HIP_TRY(hipMemsetAsync(cx->d_one, 0, (size_t)(oa.n_tiles + 2 + 8 + 2 * (oa.n_tiles / 32 + 1)) * 8, stream));
+            static const bool one_prof = getenv("TRRE_ONE_PROF") != nullptr;        // (phase clocks of the kernel, printed by finish())
+            oa.prof = one_prof ? cx->d_one + oa.n_tiles + 2 : nullptr;
+            ScanArgs wa = args;
+            wa.spec_look = oa.look;                            // (the forward lanes' look-back; the backward pass above kept kSpecLook)
+            if (launch_one(wa, oa, stream, (int)align_up(stt.g16.size() * 4, 16), sym_mode, g16_slow) == 0) {      // (the 16-byte form alone: no pair form in LDS)
+                pd.total_at = oa.total;
+                pd.one = true;
+                HIP_TRY(hipGetLastError());
+                pd.launched = true;
+                pd.count += 1;
+                return TRRE_OK;
+            }
+        }
         // (Rounds 3 and 4 had two one-walk forms here — record + patch, and mark + splice for small tables; both lost to this pair and were removed
         // in round 5: DESIGN.md §4.5.)
         launch_direct_kernel(1, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, sym_mode, g16_slow);
@@ -1378,7 +1431,27 @@ int finish_inner(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
             status = cx->h_status[0];
         }
     }
-    if (was.exact && (status & kStDiverge)) {
+    if (was.one && getenv("TRRE_ONE_PROF")) {
+        uint64_t pr[8] = {};
+        HIP_TRY(hipMemcpy(pr, was.total_at + 1, sizeof(pr), hipMemcpyDeviceToHost));
+        const double t = pr[7] ? (double)pr[7] : 1.0;
+        fprintf(stderr, "trre: one-pass phases, shader clocks per tile (%llu tiles): ticket %.0f  walk %.0f  verify %.0f  sizes %.0f  look-back %.0f  store %.0f\n",
+                (unsigned long long)pr[7], pr[0] / t, pr[1] / t, pr[2] / t, pr[3] / t, pr[4] / t, pr[5] / t);
+    }
+    if (was.one && (status & kStOneVoid)) {
+        // the one-pass kernel could not answer (one_block.hpp: what voids it): the count / emit pair takes the buffer — and, the corpus being
+        // what it is, after two such launches the program's later scans too
+        static const bool one_trace = getenv("TRRE_TRACE") != nullptr;
+        if (one_trace) fprintf(stderr, "trre: a one-pass launch of family %d was void: status 0x%x\n", was.family, status);
+        p->one_fails.fetch_add(1);
+        cx->one_off = true;
+        cx->relaunches += 1;
+        int rc = enqueue(p, st, cx, was.family, was.d_in, was.n, was.d_out, was.cap, was.stream);
+        if (!rc) rc = finish_inner(p, st, cx, out_len);
+        cx->one_off = false;
+        return rc;
+    }
+    if ((was.exact || was.one) && (status & kStDiverge)) {
         // an attempt that does not return: the lane bookkeeping of the error path (the first such lane in stream order, the sizes of the lanes
         // before it) is that of lanes that own lines — the same scan again, the old way
         cx->exact_off = true;

@@ -668,7 +668,13 @@ struct WtRow {
 
 struct DirectLane {
     uint64_t count = 0;        // kMode 1: bytes this lane emits
+    // the one-pass walk (g16_lane<3>, one_block.hpp): in — the row offset of the state at lo, or kOneGuess: look back and guess it;
+    // out — the state it walked from, whether that is exact by construction, and the state at hi
+    uint32_t entry = 0xffffffffu, known = 0, exit = 0;
 };
+constexpr uint32_t kOneGuess = 0xffffffffu;
+constexpr uint32_t kStOneVoid = 1u << 8;       // the one-pass kernel could not answer (a lane's output outgrew its LDS region, a workgroup's first guess was wrong,
+                                               // a text too long for the staging): the count / emit pair runs the buffer
 
 // 16 input bytes at v (16-byte aligned in v-space) as the walkers see them: bytes from the last one of
 // the input on read as '\n' (every record ends in '\n', Q1), the byte right before the input as '\n'
@@ -702,6 +708,22 @@ TRRE_HD U128 direct_load(const ScanArgs& a, int64_t v) {
     }
     return w;
 }
+
+// ... as a call (the one-pass kernel: the care for the input's two ends, inlined ten times, was a thousand instructions and fifty
+// spilled registers on a path that two tiles of a launch take)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __attribute__((noinline)) U128 direct_load_cold(const uint8_t* in_v0, int64_t vbeg, int64_t vend, int64_t v) {
+    ScanArgs a{};
+    a.in_v0 = in_v0; a.vbeg = vbeg; a.vend = vend;
+    return direct_load(a, v);
+}
+#else
+inline U128 direct_load_cold(const uint8_t* in_v0, int64_t vbeg, int64_t vend, int64_t v) {
+    ScanArgs a{};
+    a.in_v0 = in_v0; a.vbeg = vbeg; a.vend = vend;
+    return direct_load(a, v);
+}
+#endif
 
 // flush the ring: bytes [of, o) of the lane's output (offsets from obase) are in ring[x & 63]
 template <bool kAll>
@@ -771,6 +793,28 @@ TRRE_HD void stage_begin(Stage& s, uint8_t* buf, uint8_t* first_out_byte) {
     s.fp = 0;
     s.lo = 0;
 }
+// The one-pass walk's staging (one_block.hpp): the lane's WHOLE output goes to a private linear region of LDS — its place in the output
+// is not known before every lane of the workgroup has walked — through the same register window as the ring's.  A write beyond the
+// region lands on its last dword instead (lim = region bytes - 4): the walk goes on counting, the caller finds wp > lim and gives up.
+struct PStage {
+    uint8_t* buf;        // the region (4-byte aligned)
+    uint32_t lo, wp, sh; // as in Stage: the dword being filled, its offset in the region, 8 x its filled bytes
+    uint32_t lim;        // offset of the region's last dword
+    uint32_t dbg;
+    uint32_t* wsc;
+};
+TRRE_HD void stage_begin(PStage& s, uint8_t* buf, uint8_t*) { s.buf = buf; s.lo = 0; s.wp = 0; s.sh = 0; }
+TRRE_HD uint32_t stage_fill_end(const PStage& s) { return s.wp + (s.sh >> 3); }
+TRRE_HD void stage_append_bits(PStage& s, uint32_t v, uint32_t n8) {
+    const uint64_t vv = (uint64_t)v << s.sh;
+    const uint32_t x = s.lo | (uint32_t)vv;
+    *reinterpret_cast<uint32_t*>(s.buf + (s.wp < s.lim ? s.wp : s.lim)) = x;
+    const uint32_t t = s.sh + n8;
+    s.lo = t >= 32u ? (uint32_t)(vv >> 32) : x;
+    s.wp += (t >> 5) << 2;
+    s.sh = t & 31u;
+}
+
 // The byte-granular variant (fb_lane): no register window — a transition stores its 8 bytes straight into the ring at the
 // byte position (LDS takes unaligned 8-byte stores on gfx950) and moves on by as many as count; what lies beyond is
 // overwritten by the next one.  A store that runs over the end of the ring is repeated 128 bytes lower, so the ring has
@@ -815,6 +859,7 @@ TRRE_HD uint32_t stage_fill_end(const Stage& s) { return s.wp + (s.sh >> 3); }  
 TRRE_HD uint32_t stage_fill_end(const BStage& s) { return s.wp; }
 TRRE_HD void stage_spill(Stage& s) { *reinterpret_cast<uint32_t*>(s.buf + (s.wp & (kRingBytes - 1u))) = s.lo; }   // the dword being filled
 TRRE_HD void stage_spill(BStage&) {}
+TRRE_HD void stage_spill(PStage& s) { *reinterpret_cast<uint32_t*>(s.buf + (s.wp < s.lim ? s.wp : s.lim)) = s.lo; }
 template <class St>
 TRRE_HD uint8_t* stage_out_ptr(const St& s) { return s.g0 + stage_fill_end(s); }      // where the next byte goes
 // append the low n (0..4) bytes of v; the bytes of v above n must be zero.
@@ -842,6 +887,19 @@ TRRE_HD void stage_append(Stage& s, uint64_t v, uint32_t n) {
 TRRE_HD void stage_append_text_c(Stage& s, uint64_t text, uint32_t len, uint32_t c, uint32_t cc) {
     stage_append_n4(s, (uint32_t)text, 4u);
     const uint32_t rest = len - 4u;                                     // 1..4 bytes
+    const uint32_t hi = (uint32_t)(text >> 32) & (0xffffffffu >> (32u - 8u * rest));
+    stage_append_n4(s, hi, rest);
+    stage_append_n4(s, cc ? c : 0u, cc);
+}
+TRRE_HD void stage_append_n4(PStage& s, uint32_t v, uint32_t n) { stage_append_bits(s, v, 8u * n); }
+TRRE_HD void stage_append(PStage& s, uint64_t v, uint32_t n) {
+    const uint32_t n1 = n < 4u ? n : 4u;
+    stage_append_n4(s, (uint32_t)v, n1);
+    if (TRRE_WAVE_ANY(n > 4u)) stage_append_n4(s, (uint32_t)(v >> 32), n - n1);
+}
+TRRE_HD void stage_append_text_c(PStage& s, uint64_t text, uint32_t len, uint32_t c, uint32_t cc) {
+    stage_append_n4(s, (uint32_t)text, 4u);
+    const uint32_t rest = len - 4u;
     const uint32_t hi = (uint32_t)(text >> 32) & (0xffffffffu >> (32u - 8u * rest));
     stage_append_n4(s, hi, rest);
     stage_append_n4(s, cc ? c : 0u, cc);
@@ -943,6 +1001,9 @@ TRRE_HD void stage_flush(St& s) {
         s.skip = end & (kUnitBytes - 1u);     // (a caller that goes on restarts with stage_begin at stage_out_ptr)
     }
 }
+
+template <bool kAll>
+TRRE_HD void stage_flush(PStage&) {}           // nothing leaves a private region before the workgroup knows where it goes
 
 // position after the first '\n' at or after lo - 1, anywhere in the input (reads through direct_load); >= hi: none
 TRRE_HD int64_t first_line_start_safe(const ScanArgs& a, int64_t lo, int64_t hi) {
@@ -1262,19 +1323,79 @@ constexpr int kMarkStageStride = 17;
 template <int kMode, int kSym, bool kHasSlow>
 TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, int64_t lane, int64_t lane_bytes, uint8_t* ring,
                       uint64_t out_base, DirectLane& L, uint32_t& status, uint32_t* wave_scratch = nullptr) {
-    static_assert(kMode == 1 || kMode == 2, "count or emit");
+    // kMode 3 (one_block.hpp): ONE walk — an emit walk of exactly [lo, hi) into the lane's private LDS region `ring` (out_base: its size),
+    // from the state L.entry (kOneGuess: guessed from a.spec_look bytes of context, like the count pass of the exact sub-ranges); leaves
+    // L.count, L.entry / L.known, L.exit
+    static_assert(kMode == 1 || kMode == 2 || kMode == 3, "count, emit or both at once");
     const uint32_t done_row = kDoneState * n_cls * 16u;
     const int64_t lo = lane * lane_bytes;
     int64_t hi = lo + lane_bytes;
     if (hi > a.vend) hi = a.vend;
     const uint32_t rhi = (uint32_t)(hi > lo ? hi - lo : 0);
     uint32_t row;
+    const uint32_t exact = kMode == 3 ? 1u : a.exact;                // (uniform)
+    // the one-pass walk asks for everything it reads at once — the first piece and the 32 bytes before it (a tile's time is
+    // made of memory latencies: one round trip instead of five)
+    U128 c0{}, c1{}, c2{}, c3{};
+    if constexpr (kMode == 3) {
+        U128 wb0{}, wb1{}, ws0{}, ws1{};
+        const bool warm = lo < hi && lo > a.vbeg && L.entry == kOneGuess;
+        // (direct_load's care for the two ends of the input is a few hundred instructions when it is inlined six times — a third of what
+        // a lane of 128 bytes has to do at all: a wave that lies inside the input loads plainly)
+        if (TRRE_WAVE_ALL(lo - 32 >= a.vbeg && lo + 64 < a.vend - 1)) {
+            if (warm) {
+                wb0 = *reinterpret_cast<const U128*>(a.in_v0 + lo - 32); wb1 = *reinterpret_cast<const U128*>(a.in_v0 + lo - 16);
+            }
+            c0 = *reinterpret_cast<const U128*>(a.in_v0 + lo); c1 = *reinterpret_cast<const U128*>(a.in_v0 + lo + 16);
+            c2 = *reinterpret_cast<const U128*>(a.in_v0 + lo + 32); c3 = *reinterpret_cast<const U128*>(a.in_v0 + lo + 48);
+        } else {
+            if (warm) { wb0 = direct_load_cold(a.in_v0, a.vbeg, a.vend, lo - 32); wb1 = direct_load_cold(a.in_v0, a.vbeg, a.vend, lo - 16); }
+            c0 = direct_load_cold(a.in_v0, a.vbeg, a.vend, lo); c1 = direct_load_cold(a.in_v0, a.vbeg, a.vend, lo + 16);
+            c2 = direct_load_cold(a.in_v0, a.vbeg, a.vend, lo + 32); c3 = direct_load_cold(a.in_v0, a.vbeg, a.vend, lo + 48);
+        }
+        if (warm) {
+            if (kSym == 1) { ws0 = *reinterpret_cast<const U128*>(a.sym_v0 + lo - 32); ws1 = *reinterpret_cast<const U128*>(a.sym_v0 + lo - 16); }
+            if (kSym == 2) ws0 = *reinterpret_cast<const U128*>(a.sym_v0 + ((lo - 32) >> 1));
+        }
+        L.known = 1u;
+        if (lo >= hi) row = done_row;
+        else if (L.entry != kOneGuess) { row = L.entry; L.known = 0u; }
+        else if (lo < a.vbeg) row = kSkipState * n_cls * 16u;
+        else if (lo == a.vbeg) row = 0u;
+        else {
+            // the state at lo: the root state a.spec_look (16 or 32) bytes back, walked up to lo.  A '\n' among those bytes makes it exact
+            // whatever the walk began in (every state goes to the root there: meta bit 5), and so does the start of the input; else it is
+            // a guess — transducers of this kind forget — that the caller checks against the lane before.
+            const int64_t s0 = lo - (int64_t)a.spec_look > a.vbeg ? lo - (int64_t)a.spec_look : a.vbeg;
+            uint32_t r = 0u, seen_eol = s0 == a.vbeg ? 32u : 0u;
+            // one 16-byte block at v: its bytes w, its symbols y (per byte) / yn (packed)
+            auto warm_block = [&](const int64_t v, const U128& w, const U128& y, const uint64_t yn) {
+                const uint32_t wd[4] = {w.x, w.y, w.z, w.w};
+                const uint32_t yd[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    uint32_t kk;
+                    if (kSym == 2) kk = (uint32_t)(yn >> (4 * k)) & 15u;
+                    else if (kSym == 1) kk = (yd[k >> 2] >> (8 * (k & 3))) & 0xffu;
+                    else kk = T.cls[(wd[k >> 2] >> (8 * (k & 3))) & 0xffu];
+                    const uint64_t g = *reinterpret_cast<const uint64_t*>(T.g16 + r + (kk << 4));
+                    const bool take = v + k >= s0;
+                    r = take ? (uint32_t)g : r;
+                    seen_eol |= take ? (uint32_t)(g >> 32) : 0u;
+                }
+            };
+            if (TRRE_WAVE_ANY(lo - 16 > s0)) warm_block(lo - 32, wb0, ws0, (uint64_t)ws0.y << 32 | ws0.x);
+            warm_block(lo - 16, wb1, ws1, (uint64_t)ws0.w << 32 | ws0.z);
+            row = r;
+            L.known = (seen_eol >> 5) & 1u;
+        }
+    } else {
     if (lo >= hi) row = done_row;
     else if (lo < a.vbeg) row = kSkipState * n_cls * 16u;             // filler then '\n' right before the input
     else row = (lo == a.vbeg || a.in_v0[lo - 1] == (uint8_t)'\n') ? 0u : kSkipState * n_cls * 16u;
-    const uint32_t exact = (kMode == 1 || kMode == 2) ? a.exact : 0u;   // (uniform)
+    }
     uint32_t xrow = row;                                             // exact sub-ranges: the state at hi
-    if (exact && lo < hi) {
+    if (kMode != 3 && exact && lo < hi) {
         if (exact >= 2u) {
             row = a.entry_rows[lane] & ~1u;
         } else if (lo > a.vbeg && row != 0u) {
@@ -1324,9 +1445,14 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
         }
         xrow = row;
     }
-    Stage S{};
+    if (kMode == 3) { L.entry = row; xrow = row; }
+    std::conditional_t<kMode == 3, PStage, Stage> S{};
     S.dbg = a.dbg;
     S.wsc = wave_scratch;
+    if (kMode == 3) {
+        stage_begin(S, ring, nullptr);
+        if constexpr (kMode == 3) S.lim = (uint32_t)out_base - 4u;
+    }
     if (kMode == 2) {
         if (a.lp_emit) {
             // no count pass: this lane's lines are written where they were read
@@ -1373,11 +1499,15 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
         // long replacement text: empty the staging buffer, write straight to memory
         const uint8_t* rec = T.pool + str_pool_off(ehi);
         if (len == 255u) len = str_pool_len(T, ehi);
-        stage_flush_solo(S);
-        uint8_t* gp = stage_out_ptr(S);
-        for (uint32_t i = 0; i < len; ++i) gp[i] = rec[4 + i];
-        stage_begin(S, S.buf, gp + len);
-        stage_append(S, (uint64_t)(cc ? c : 0u), cc);
+        if constexpr (kMode == 3) {
+            status |= kStOneVoid;                                    // (no memory to write to yet: the pair takes the buffer)
+        } else {
+            stage_flush_solo(S);
+            uint8_t* gp = stage_out_ptr(S);
+            for (uint32_t i = 0; i < len; ++i) gp[i] = rec[4 + i];
+            stage_begin(S, S.buf, gp + len);
+            stage_append(S, (uint64_t)(cc ? c : 0u), cc);
+        }
     };
     // one dword (4 input bytes) whose first byte lies rp bytes into the sub-range; kEnd: a lane may finish in it
     auto dword = [&](auto end_tag, const uint32_t w, const uint32_t sw, const uint32_t rp) {
@@ -1556,7 +1686,7 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
         TRRE_SCHED_FENCE();
     };
     // 64 bytes at a time; a lane's four 16-byte loads of a piece are issued together, one piece ahead
-    U128 c0 = direct_load(a, lo), c1 = direct_load(a, lo + 16), c2 = direct_load(a, lo + 32), c3 = direct_load(a, lo + 48);
+    if (kMode != 3) { c0 = direct_load(a, lo); c1 = direct_load(a, lo + 16); c2 = direct_load(a, lo + 32); c3 = direct_load(a, lo + 48); }
     U128 s0 = sym_at(lo), s1 = kSym == 2 ? sym_at(lo + 32) : sym_at(lo + 16), s2 = kSym == 1 ? sym_at(lo + 32) : U128{},
          s3 = kSym == 1 ? sym_at(lo + 48) : U128{};
     // the symbols of block q of the piece
@@ -1581,12 +1711,18 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
         U128 n0 = *reinterpret_cast<const U128*>(a.in_v0 + x0), n1 = *reinterpret_cast<const U128*>(a.in_v0 + x1),
              n2 = *reinterpret_cast<const U128*>(a.in_v0 + x2), n3 = *reinterpret_cast<const U128*>(a.in_v0 + x3);
         if (TRRE_WAVE_ANY(vn < a.vbeg || vn + 64 > a.vend - 1)) {
-            n0 = direct_load(a, vn); n1 = direct_load(a, vn + 16); n2 = direct_load(a, vn + 32); n3 = direct_load(a, vn + 48);
+            if (kMode == 3) {
+                n0 = direct_load_cold(a.in_v0, a.vbeg, a.vend, vn); n1 = direct_load_cold(a.in_v0, a.vbeg, a.vend, vn + 16);
+                n2 = direct_load_cold(a.in_v0, a.vbeg, a.vend, vn + 32); n3 = direct_load_cold(a.in_v0, a.vbeg, a.vend, vn + 48);
+            } else {
+                n0 = direct_load(a, vn); n1 = direct_load(a, vn + 16); n2 = direct_load(a, vn + 32); n3 = direct_load(a, vn + 48);
+            }
         }
         const U128 t0 = sym_at(vn), t1 = kSym == 2 ? sym_at(vn + 32) : sym_at(vn + 16), t2 = kSym == 1 ? sym_at(vn + 32) : U128{},
                    t3 = kSym == 1 ? sym_at(vn + 48) : U128{};
         const uint32_t rp = (uint32_t)(v - lo);
-        if (TRRE_WAVE_ALL(rp + 64u < rhi)) {
+        // (the one-pass walk owns exactly [lo, hi): a piece that ends AT hi is interior too)
+        if (kMode == 3 ? TRRE_WAVE_ALL(rp + 64u <= rhi) : TRRE_WAVE_ALL(rp + 64u < rhi)) {
             // interior piece: a lane finishes at the first record end whose '\n' is the last byte of its sub-range or lies
             // beyond it, and every byte of this piece lies before that last byte
 #pragma clang loop unroll(disable)
@@ -1618,8 +1754,14 @@ TRRE_HD void g16_lane(const ScanArgs& a, const StreamView& T, uint32_t n_cls, in
     if (kMode == 1 && exact && lo < hi) a.exit_rows[lane] = xrow;
     if (kMode == 2) stage_flush<true>(S);
     if (kMode == 2 && a.lp_emit && ((seen & 8u) || (seen2 & 256u))) status |= kStNul;
-    if (kMode == 1 && ((seen | seen2) & 64u)) status |= kStOverflow;            // bounded fold: the launch is void
-    if ((kMode == 1 || a.lp_emit) && ((seen | seen2) & 16u)) status |= kStDiverge;   // guided tables: the reference's search never returns
+    if ((kMode == 1 || kMode == 3) && ((seen | seen2) & 64u)) status |= kStOverflow;            // bounded fold: the launch is void
+    if ((kMode == 1 || kMode == 3 || a.lp_emit) && ((seen | seen2) & 16u)) status |= kStDiverge;   // guided tables: the reference's search never returns
+    if constexpr (kMode == 3) {
+        L.exit = xrow;
+        stage_spill(S);                                              // the dword being filled
+        cnt = stage_fill_end(S);
+        if (S.wp > S.lim) status |= kStOneVoid;                      // the region could not hold it all
+    }
     L.count = cnt;
 }
 

@@ -22,6 +22,7 @@
 #include "launch.hpp"
 #include "scan_block.hpp"
 #include "splice_block.hpp"
+#include "one_block.hpp"
 #include "gen_block.hpp"
 #include "lazy_block.hpp"
 #include "guard_block.hpp"
@@ -1309,6 +1310,302 @@ void launch_g16(int which, const ScanArgs& a, int64_t lane_bytes, int64_t n_bloc
     allow_big_lds<&k_stream_g16<2, kSym, kHasSlow>>();
     if (which == 1) hipLaunchKernelGGL((k_stream_g16<1, kSym, kHasSlow>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds_count, s, a, lane_bytes, room);
     else hipLaunchKernelGGL((k_stream_g16<2, kSym, kHasSlow>), dim3((unsigned)n_blocks), dim3(kDirectThreads), lds, s, a, lane_bytes, room);
+}
+// ONE walk for the general families on small tables (one_block.hpp): short lanes from guessed-and-verified states, the
+// workgroup's whole output in LDS, its place in the output by decoupled look-back over the tiles' totals, stores as whole 16-byte lines.
+// Workgroups are persistent: each takes tiles (kOneThreads lanes of oa.lane_bytes bytes) from a ticket counter until none is left.
+//   smem: cls[256] | g16[g16_room] | pooled text (2 KiB) | regions[kOneThreads x R] + 32 | offs[kOneThreads + 4] | exits[kOneThreads] |
+//         misc[16] | marks[kOneThreads x R / 16 + 16]
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    const int lid = threadIdx.x & (kWave - 1);
+    for (int d = 1; d < kWave; d <<= 1) {
+        const uint32_t o = __shfl_up(v, d, kWave);
+        if (lid >= d) v += o;
+    }
+    return v;
+}
+// the tile's tail: sizes, look-back, stores (a function of its own: its registers are not the walk's)
+// (everything by value: a reference to the kernel's arguments would put a copy of them on the stack — scratch memory per lane, and the
+// scratch ring's size is what the dispatcher admits waves by)
+struct OneTailArgs {
+    uint8_t* out;
+    uint64_t cap;
+    uint32_t* status;
+    uint64_t *desc, *gsum, *ginc, *total;
+    int64_t n_tiles;
+    uint32_t spin;
+};
+__device__ __forceinline__ uint32_t one_tail(OneTailArgs q, const uint8_t* regions, uint32_t* offs, uint8_t* marks, uint32_t region, const uint32_t* exits,
+                                                       uint32_t* misc, int64_t tile, uint32_t count, uint32_t flags, uint32_t used, uint32_t st_in) {
+    const int tid = threadIdx.x;
+    const int wave = tid / kWave, lid = tid & (kWave - 1);
+    uint32_t st = st_in;
+    const bool tile_void = flags & 1u, live = flags & 2u;
+    const uint32_t known = (flags >> 2) & 1u;
+    const OneTile tv{regions, offs, marks, region};
+    struct { uint8_t* out; uint64_t cap; uint32_t* status; } a{q.out, q.cap, q.status};
+    struct { uint64_t *desc, *gsum, *ginc, *total; int64_t n_tiles; uint32_t spin; } oa{q.desc, q.gsum, q.ginc, q.total, q.n_tiles, q.spin};
+        // ---- sizes: the lanes' places in the tile's output ---------------------------------------------------------------------------
+        const uint32_t len = tile_void ? 0u : count;
+        const uint32_t incl = wave_incl_scan_u32(len);
+        if (lid == kWave - 1) misc[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; ++w) woff += misc[w];
+        offs[tid] = woff + incl - len;
+        const uint32_t total = misc[0] + misc[1] + misc[2] + misc[3];
+        if (tid == kOneThreads - 1) offs[kOneThreads] = total;
+        // ---- base: look back over the tiles before this one (wave 0) ------------------------------------------------------------------
+        // Two levels (the resident workgroups move in step: when a tile looks back, the hundreds of tiles before it have their totals out
+        // and none its running total — tile by tile that was a dozen rounds of 64 polls, most of the tile's time): tiles also add their
+        // total to their GROUP of 32 (one atomic: count and sum together), and the last tile of a group leaves the group's running total.
+        // Lanes 0..31 poll the tiles before this one in its own group, lanes 32..63 the 32 groups before it: one round as a rule.
+        if (wave == 0) {
+            const uint32_t exit_last = exits[kOneThreads - 1];
+            const int64_t grp = tile >> 5;
+            const int r = (int)(tile & 31);
+            if (lid == 0) {
+                __hip_atomic_store(oa.desc + tile, one_desc(tile == 0 ? kOneDescInc : kOneDescAgg, exit_last, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(oa.gsum + grp, (1ull << 58) | (uint64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            uint64_t base = 0;
+            uint32_t lb_st = 0;
+            if (tile > 0) {
+                uint32_t polls = 0;
+                int64_t gtop = grp - 1;                   // the newest group the upper lanes look at
+                uint64_t part = 0;                        // what the windows so far have added up
+                bool tiles_done = false;
+                for (;;) {
+                    // lanes 0..31: the tile lid + 1 before this one (lane 0 always: its exit row is checked), while it is in this group
+                    const bool t_mine = lid < 32 && (lid < r || lid == 0) && !tiles_done;
+                    const uint64_t d = t_mine ? __hip_atomic_load(oa.desc + (tile - 1 - lid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                    // lanes 32..63: group gtop - (lid - 32): its count and sum, and its running total if it has one
+                    const int64_t gq = gtop - (lid - 32);
+                    const bool g_mine = lid >= 32 && gq >= 0;
+                    const uint64_t gs = g_mine ? __hip_atomic_load(oa.gsum + gq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                    const uint64_t gi = g_mine ? __hip_atomic_load(oa.ginc + gq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (lid >= 32 ? (1ull << 63) : 0ull);
+                    const uint32_t kind = (uint32_t)(d >> 62);
+                    bool wait = false;
+                    uint64_t v = 0;
+                    bool finished = false;
+                    if (!tiles_done) {
+                        const uint64_t in_grp = __ballot(lid < r);                                  // the tiles of this group before this one
+                        const uint64_t zero = __ballot(t_mine && kind == 0u), inc = __ballot(lid < r && kind == 2u) & in_grp;
+                        const int jinc = inc ? __builtin_ctzll(inc) : 64;
+                        const uint64_t upto = (jinc >= 63 ? ~0ull : (1ull << (jinc + 1)) - 1ull) & (in_grp | 1ull);
+                        if (zero & upto) wait = true;
+                        else {
+                            // the one guess nobody can repair in place: this tile's first lane against the exit of the tile before it
+                            const uint32_t pred_exit = __shfl(one_desc_exit(d), 0, kWave);
+                            if (lid == 0 && !known && live && used != pred_exit) lb_st |= kStOneVoid;
+                            v = (lid < r && ((upto >> lid) & 1ull)) ? (d & kOneValMask) : 0ull;
+                            if (jinc < 64) finished = true;
+                        }
+                    }
+                    if (!wait && !finished) {
+                        // the groups: down to the first one with a running total, every one above it complete
+                        const uint64_t ginc_at = __ballot(lid >= 32 && (gi >> 63)) >> 32;          // bit q: group gtop - q has its running total
+                        const uint64_t gfull = __ballot(lid >= 32 && (gs >> 58) == 32u) >> 32;
+                        const int qinc = ginc_at ? __builtin_ctzll(ginc_at) : 32;
+                        const uint64_t above = qinc >= 32 ? 0xffffffffull : (1ull << qinc) - 1ull;
+                        if ((gfull & above) != above) wait = true;
+                        else {
+                            const int q = lid - 32;
+                            if (lid >= 32 && q < qinc) v += gs & ((1ull << 58) - 1ull);
+                            if (lid >= 32 && q == qinc) v += gi & ~(1ull << 63);
+                            if (qinc < 32) finished = true;
+                        }
+                    }
+                    if (wait) {
+                        if (++polls > oa.spin) { lb_st |= kStOneVoid; break; }                     // (cannot be: tickets are taken in order)
+                        __builtin_amdgcn_s_sleep(2);
+                        continue;
+                    }
+                    for (int dd = 32; dd; dd >>= 1) v += __shfl_xor(v, dd, kWave);
+                    part += v;
+                    if (finished) break;
+                    tiles_done = true;                     // 32 complete groups and no running total among them: the 32 before those
+                    gtop -= 32;
+                }
+                base = part;
+            }
+            if (lid == 0) {
+                if (tile > 0) __hip_atomic_store(oa.desc + tile, one_desc(kOneDescInc, exit_last, base + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (r == 31) __hip_atomic_store(oa.ginc + grp, (1ull << 63) | (base + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *reinterpret_cast<uint64_t*>(misc + 6) = base;
+                if (tile == oa.n_tiles - 1) *oa.total = base + total;
+                misc[5] = (lb_st | st | __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & kStOneVoid;
+            }
+            st |= lb_st;
+        }
+        __syncthreads();
+        const uint64_t base = *reinterpret_cast<const uint64_t*>(misc + 6);
+        // ---- store: a thread per 16-byte line of the output, two at a time -----------------------------------------------------------
+        const uint32_t hh = (uint32_t)((reinterpret_cast<uintptr_t>(a.out) + base) & 15u);
+        one_mark(tv, tid, hh);
+        __syncthreads();
+        const bool write = base + total <= a.cap;
+        if (!write) st |= kStCapacity;
+        const uint32_t n_lines = (hh + total + 15u) >> 4;
+        for (uint32_t c0 = 0; c0 < n_lines; c0 += 2 * kOneThreads) {
+            const uint32_t cc[2] = {c0 + (uint32_t)tid, c0 + kOneThreads + (uint32_t)tid};
+            one_store_lines<2>(tv, a.out, base, hh, cc, total, write);
+        }
+    return st;
+}
+template <int kSym, bool kHasSlow>
+__global__ __launch_bounds__(kOneThreads, 3) void k_stream_one(ScanArgs a, OneArgs oa, int g16_room) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
+    const int tid = threadIdx.x;
+    for (int k = tid; k < 256; k += kOneThreads) smem[k] = a.blob[h.off_cls + k];
+    {
+        const U128* e = reinterpret_cast<const U128*>(a.blob + h.off_g16);
+        U128* d = reinterpret_cast<U128*>(smem + 256);
+        for (int k = tid; k < (int)(h.g16_bytes / 16); k += kOneThreads) d[k] = e[k];
+    }
+    StreamView T;
+    uint8_t* pool_lds = smem + 256 + g16_room;
+    if ((int)h.pool_bytes <= kDirectPoolSmall) {
+        const uint32_t* e = reinterpret_cast<const uint32_t*>(a.blob + h.off_pool);
+        uint32_t* d = reinterpret_cast<uint32_t*>(pool_lds);
+        for (int k = tid; k < (int)(h.pool_bytes / 4); k += kOneThreads) d[k] = e[k];
+        T.pool_fast = pool_lds;
+    }
+    T.cls = smem;
+    T.g16 = smem + 256;
+    // (the pair form of the table is not walked here: measured, no difference — at three waves per SIMD the walk runs at the pace of its chain of
+    // dependent table reads, not of its instruction count)
+    T.ent = reinterpret_cast<const uint64_t*>(a.blob + h.off_ent);
+    T.pool = a.blob + h.off_pool;
+    T.long_pool = h.max_out >= 255u;
+    const uint32_t R = oa.region;
+    uint8_t* regions = pool_lds + kDirectPoolSmall;
+    uint8_t* my = regions + (size_t)tid * R;
+    uint32_t* offs = reinterpret_cast<uint32_t*>(regions + (((size_t)kOneThreads * R + 32 + 15) & ~(size_t)15));
+    uint32_t* exits = offs + kOneThreads + 4;
+    uint32_t* misc = exits + kOneThreads;                 // [0..3] the waves' totals, [4] the tile, [5] void seen, [6..7] the tile's base
+    uint8_t* marks = reinterpret_cast<uint8_t*>(misc + 16);
+    OneTile tv{regions, offs, marks, R};
+    // (the backward pass of a guided family guessed wrong somewhere: its symbols are not final, finish() repairs them and runs the pair)
+    if (kSym != 0 && __hip_atomic_load(a.status + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        if (tid == 0 && blockIdx.x == 0) atomicOr(a.status, kStOneVoid);
+        return;
+    }
+    const int wave = tid / kWave, lid = tid & (kWave - 1);
+    uint32_t st_all = 0;
+    const bool prof = oa.prof != nullptr && tid == 0;
+    auto stamp = [&](uint64_t& t, int slot) {
+        if (prof) {
+            const uint64_t now = clock64();
+            atomicAdd(reinterpret_cast<unsigned long long*>(oa.prof + slot), (unsigned long long)(now - t));
+            t = now;
+        }
+    };
+    // A tile is taken when its walk begins, never earlier: a ticket held while the tile before it is still being worked on is a tile that
+    // every later tile's look-back waits for (asking ahead was tried: the look-backs took a whole tile's time).
+    if (tid == 0) {
+        misc[4] = atomicAdd(oa.ticket, 1u);
+        misc[5] = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kStOneVoid;
+    }
+    __syncthreads();
+    int64_t tile = (int64_t)misc[4];
+    uint32_t void_seen = misc[5];
+    for (;;) {
+        if (tile >= oa.n_tiles) break;
+        uint64_t tclk = prof ? clock64() : 0;
+        if (void_seen) {
+            // the launch is void already: nothing to walk, but whoever looks back at this tile must not wait for it
+            if (tid == 0) {
+                __hip_atomic_store(oa.desc + tile, one_desc(kOneDescInc, 0u, 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(oa.gsum + (tile >> 5), 1ull << 58, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((tile & 31) == 31) __hip_atomic_store(oa.ginc + (tile >> 5), 1ull << 63, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                misc[4] = atomicAdd(oa.ticket, 1u);
+            }
+            __syncthreads();
+            tile = (int64_t)misc[4];
+            __syncthreads();
+            continue;
+        }
+        const int64_t lane = tile * kOneThreads + tid;
+        const bool live = lane * (int64_t)oa.lane_bytes < a.vend;
+        // ---- walk, verify against the lane before, walk again where the guess was wrong --------------------------------------------
+        DirectLane L;
+        uint32_t st = 0, entry = kOneGuess, used = 0, known = 0;
+        bool need = true, gave_up = false;
+        for (int round = 0;; ++round) {
+            if (need) {
+                L.entry = entry;
+                st = 0;
+                g16_lane<3, kSym, kHasSlow>(a, T, h.n_cls, lane, (int64_t)oa.lane_bytes, my, (uint64_t)R, L, st);
+                exits[tid] = L.exit;
+                used = L.entry;
+                if (round == 0) { known = L.known; stamp(tclk, 1); }
+            }
+            __syncthreads();
+            need = tid > 0 && live && !known && used != exits[tid - 1];
+            if (need) entry = exits[tid - 1];
+            if (!__syncthreads_or(need ? 1 : 0)) break;
+            if (round + 1 >= kOneRounds) { gave_up = true; break; }
+        }
+        if (gave_up) st |= kStOneVoid;
+        // (a tile that cannot answer — a region outgrown, no agreement on the states — keeps the protocol going with an empty output: the
+        // launch is void, and sizes that are not backed by bytes in the regions must not reach the gather)
+        const bool tile_void = __syncthreads_or((st & kStOneVoid) ? 1 : 0) != 0;
+        stamp(tclk, 2);
+        st = one_tail(OneTailArgs{a.out, a.cap, a.status, oa.desc, oa.gsum, oa.ginc, oa.total, oa.n_tiles, oa.spin}, regions, offs, marks, R, exits, misc, tile,
+                      (uint32_t)L.count, (tile_void ? 1u : 0u) | (live ? 2u : 0u) | (known ? 4u : 0u), used, st);
+        void_seen = misc[5];
+        stamp(tclk, 5);
+        if (prof) atomicAdd(reinterpret_cast<unsigned long long*>(oa.prof + 7), 1ull);
+        st_all |= st;
+        if (tid == 0) misc[4] = atomicAdd(oa.ticket, 1u);  // the next tile, now that this one is out
+        __syncthreads();                                   // (... and every thread is done with the regions, the offsets and the marks)
+        tile = (int64_t)misc[4];
+        stamp(tclk, 0);
+    }
+    st_all = wave_or(st_all);
+    if (st_all && lid == 0) atomicOr(a.status, st_all);
+}
+template <int kSym, bool kHasSlow>
+int launch_one_t(const ScanArgs& a, const OneArgs& oa, hipStream_t s, int g16_bytes) {
+    const int room = (g16_bytes + 15) / 16 * 16;
+    const int lds = 256 + room + kDirectPoolSmall + ((kOneThreads * (int)oa.region + 32 + 15) & ~15) + (kOneThreads + 4 + kOneThreads + 16) * 4 +
+                    kOneThreads * (int)oa.region / 16 + 32;
+    // (the kernel has 256 bytes of static LDS — __syncthreads_or's — so the whole 160 KiB cannot be asked for as dynamic: ask for what it needs)
+    if (lds > kLdsLimit - 1024) return -1;
+    static std::atomic<int> allowed{0};
+    if (allowed.load() < lds) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_one<kSym, kHasSlow>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return -1;
+        }
+        allowed.store(lds);
+    }
+    // persistent workgroups: about as many as the device holds at once — 3 waves per SIMD by the kernel's registers (launch bounds), and what
+    // the LDS admits.  (More would only queue for a CU and find the tickets gone; tiles are handed out by the ticket counter, not by block.)
+    static std::atomic<int> cus_cache{0};
+    if (!cus_cache.load()) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        hipDeviceProp_t prop;
+        cus_cache.store(hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+    }
+    const int cus = cus_cache.load();
+    int per_cu = kLdsLimit / lds;
+    if (per_cu > 3) per_cu = 3;
+    if (per_cu < 1) per_cu = 1;
+    int64_t blocks = (int64_t)cus * per_cu;
+    if (blocks > oa.n_tiles) blocks = oa.n_tiles;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((k_stream_one<kSym, kHasSlow>), dim3((unsigned)blocks), dim3(kOneThreads), lds, s, a, oa, room);
+    return 0;
+}
+int launch_one(const ScanArgs& a, const OneArgs& oa, void* stream, int g16_bytes, int sym, bool g16_slow) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (sym == 2) return g16_slow ? launch_one_t<2, true>(a, oa, s, g16_bytes) : launch_one_t<2, false>(a, oa, s, g16_bytes);
+    if (sym == 1) return g16_slow ? launch_one_t<1, true>(a, oa, s, g16_bytes) : launch_one_t<1, false>(a, oa, s, g16_bytes);
+    return g16_slow ? launch_one_t<0, true>(a, oa, s, g16_bytes) : launch_one_t<0, false>(a, oa, s, g16_bytes);
 }
 template <int kSym>
 void launch_direct_sym(int which, bool ent_in_lds, const ScanArgs& a, int64_t lane_bytes, int64_t n_blocks, hipStream_t s, int g16_bytes, bool g16_slow) {
