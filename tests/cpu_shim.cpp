@@ -29,7 +29,6 @@ int g_last_rounds = 0;       // repair rounds of the last exact-sub-range run (s
 
 constexpr uint32_t kFlagG16SlowBit = 1u << 3;    // front.hpp: kFlagG16Slow
 using GeoTiny = Geometry<4, 64, 32>;
-using GeoTinyStream = Geometry<4, 4 * 20, 32>;   // SUB = 20 bytes = 5 dwords (odd), like the production stream geometry
 
 template <class G, class Engine>
 struct Block {
@@ -99,79 +98,6 @@ void run_gen(ScanArgs a, int64_t n_chunks, uint32_t& status, uint64_t& total_out
             ByteSink s{staged ? tout + shift + lane_base : a.out + gbase + lane_base};
             lane_walk_gen<G, Engine>(a, T, L, v0, tin, t, s, status);
             if (s.n != lane_counts[(size_t)b * G::THREADS + t]) status |= 1u << 30;   // count/emit disagree
-            lane_base += lane_counts[(size_t)b * G::THREADS + t];
-        }
-        if (staged)
-            for (int t = 0; t < G::THREADS; ++t) tile_store_seq<G>(a.out + gbase, tout, shift, (int64_t)total, t);
-    }
-}
-
-// ---- stream engine ------------------------------------------------------------------------
-template <class G>
-void run_stream_lp(const ScanArgs& a, uint32_t& status) {
-    const int64_t n_chunks = (a.vend + G::CHUNK - 1) / G::CHUNK;
-    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
-    std::vector<uint8_t> tile_v(G::TILE_ALLOC + 32), tab_v(StreamEngine::kLdsBytes + 32);
-    uint8_t* tile = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(tile_v.data()) + 15) & ~(uintptr_t)15);
-    uint8_t* tab = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(tab_v.data()) + 15) & ~(uintptr_t)15);
-    for (int64_t b = 0; b < n_chunks; ++b) {
-        const int64_t v0 = b * G::CHUNK - G::PRE;
-        for (int t = 0; t < G::THREADS; ++t) { StreamEngine::stage(a.blob, tab, t, G::THREADS); tile_load<G>(a, v0, tile, t); }
-        const StreamView T = StreamEngine::ent_fits(h) ? StreamEngine::view<true>(a.blob, tab) : StreamEngine::view<false>(a.blob, tab);
-        int32_t first = 0x7fffffff, last = -1;
-        // lanes run in REVERSE order here: a later lane rewriting its bytes must never
-        // disturb an earlier lane that is still reading (they touch disjoint lines)
-        for (int t = G::THREADS - 1; t >= 0; --t) {
-            int32_t f, l;
-            stream_lane_lp<G>(a, T, h.n_cls, v0, tile, t, f, l, status);
-            if (f < first) first = f;
-            if (l > last) last = l;
-        }
-        for (int t = 0; t < G::THREADS; ++t) tile_store_lp<G>(a, v0, tile, first, last, t);
-    }
-}
-
-template <class G>
-void run_stream_gen(ScanArgs a, uint32_t& status, uint64_t& total_out) {
-    const int64_t n_chunks = (a.vend + G::CHUNK - 1) / G::CHUNK;
-    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
-    std::vector<uint8_t> tin_v(G::TILE_ALLOC + 32), tout_v(G::TILE_ALLOC + 32), tab_v(StreamEngine::kLdsBytes + 32);
-    uint8_t* tin = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(tin_v.data()) + 15) & ~(uintptr_t)15);
-    uint8_t* tout = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(tout_v.data()) + 15) & ~(uintptr_t)15);
-    uint8_t* tab = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(tab_v.data()) + 15) & ~(uintptr_t)15);
-    std::vector<uint32_t> lane_counts((size_t)n_chunks * G::THREADS);
-    std::vector<uint64_t> chunk_total(n_chunks), chunk_base(n_chunks + 1);
-    auto view = [&]() { return StreamEngine::ent_fits(h) ? StreamEngine::view<true>(a.blob, tab) : StreamEngine::view<false>(a.blob, tab); };
-    for (int64_t b = 0; b < n_chunks; ++b) {
-        const int64_t v0 = b * G::CHUNK - G::PRE;
-        for (int t = 0; t < G::THREADS; ++t) { StreamEngine::stage(a.blob, tab, t, G::THREADS); tile_load<G>(a, v0, tin, t); }
-        const StreamView T = view();
-        uint64_t tot = 0;
-        for (int t = 0; t < G::THREADS; ++t) {
-            CountSink s;
-            stream_lane_gen<G>(a, T, h.n_cls, v0, tin, t, s, status);
-            lane_counts[(size_t)b * G::THREADS + t] = (uint32_t)s.n;
-            tot += s.n;
-        }
-        chunk_total[b] = tot;
-    }
-    uint64_t run = 0;
-    for (int64_t b = 0; b < n_chunks; ++b) { chunk_base[b] = run; run += chunk_total[b]; }
-    total_out = run;
-    if (run > a.cap) { status |= kStCapacity; return; }
-    for (int64_t b = 0; b < n_chunks; ++b) {
-        const int64_t v0 = b * G::CHUNK - G::PRE;
-        for (int t = 0; t < G::THREADS; ++t) { StreamEngine::stage(a.blob, tab, t, G::THREADS); tile_load<G>(a, v0, tin, t); }
-        std::memset(tout, 0xEE, G::TILE_ALLOC);
-        const StreamView T = view();
-        const uint64_t total = chunk_total[b], gbase = chunk_base[b];
-        const int shift = (int)((reinterpret_cast<uintptr_t>(a.out) + gbase) & 15u);
-        const bool staged = (uint64_t)shift + total <= (uint64_t)G::TILE;
-        uint64_t lane_base = 0;
-        for (int t = 0; t < G::THREADS; ++t) {
-            ByteSink s{staged ? tout + shift + lane_base : a.out + gbase + lane_base};
-            stream_lane_gen<G>(a, T, h.n_cls, v0, tin, t, s, status);
-            if (s.n != lane_counts[(size_t)b * G::THREADS + t]) status |= 1u << 30;
             lane_base += lane_counts[(size_t)b * G::THREADS + t];
         }
         if (staged)
@@ -474,9 +400,9 @@ void run_fb_gen(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64_
     }
 }
 
-// The copy form of a large table (k_fb_mark / k_chunk_scan / k_fb_copy): the comb walk marks where the replacement texts go,
-// the copy pass walks no automaton.  ev_cap: ids per lane (small in the tests: the overflow route runs too).
-void run_fb_copy(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64_t& total_out, uint32_t ev_cap, bool splice = false, bool mark8 = false) {
+// The copy form of a large table (k_fb_mark / k_chunk_scan / k_fb_splice): the comb walk marks where the replacement texts go,
+// the second pass — the wave-cooperative splice — walks no automaton.  ev_cap: ids per lane (small in the tests: the overflow route runs too).
+void run_fb_copy(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64_t& total_out, uint32_t ev_cap, bool mark8 = false) {
     const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
     const FbView T = fb_view(a);
     const uint16_t* lit_meta = reinterpret_cast<const uint16_t*>(a.blob + h.off_fb_lit_meta);
@@ -517,13 +443,8 @@ void run_fb_copy(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64
     std::vector<U128> lit(h.fb_lits + 1);
     const uint64_t* tx = reinterpret_cast<const uint64_t*>(a.blob + h.off_fb_lit);
     for (uint32_t k = 0; k < h.fb_lits; ++k) lit[k] = U128{(uint32_t)tx[k], (uint32_t)(tx[k] >> 32), (uint32_t)lit_meta[k], 0u};
-    FbCopyTables CT;
-    CT.lit = lit.data();
-    CT.esc = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_esc);
-    CT.pool = a.blob + h.off_fb_pool;
-    alignas(16) uint8_t ring[kRingStride];
     std::memset(a.out, 0xEE, (size_t)run);
-    if (splice) {
+    {
         // the wave-cooperative second pass (k_fb_splice): one emulated wave per sub-range, its LDS carve poisoned every time
         // (as the kernel deals them out: a wave takes every fourth sub-range of a chunk of 256)
         alignas(16) static uint8_t lds[kSpLdsPerWave];
@@ -534,13 +455,13 @@ void run_fb_copy(const ScanArgs& a, int64_t lane_bytes, uint32_t& status, uint64
                 if (left <= 0) continue;
                 const SpliceWork W{first + w, 4, (int)std::min<int64_t>(64, (left + 3) / 4), base.data() + first + w, 4};
                 SpliceTables ST;
-                ST.lit = CT.lit; ST.esc = CT.esc; ST.pool = CT.pool;
+                ST.lit = lit.data();
+                ST.esc = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_esc);
+                ST.pool = a.blob + h.off_fb_pool;
                 fb_splice_ranges<2>(a, ST, ca, W, lane_bytes, SpliceLds{lds});
             }
         }
-        return;
     }
-    for (int64_t lane = n_lanes - 1; lane >= 0; --lane) fb_copy_lane(a, CT, ca, lane, lane_bytes, ring, base[lane], status);
 }
 
 // Host emulation of the window kernel (k_stream_lpw): 64 lanes in lockstep over an
@@ -659,7 +580,7 @@ int run_family(int family, ScanArgs& a, uint32_t& status, uint64_t& total) {
 
 extern "C" {
 
-// family: 1 bytemap, 2 tile LP, 3 tile general, 4 stream LP (in place), 5 stream general.
+// family: 1 bytemap, 2 tile LP, 3 tile general (4 / 5, the LDS-tile walkers of the stream tables, went in round 6).
 // 20 / 21 stream LP by the emit pass alone (16-byte / 8-byte entries),
 // 8 positional-window stream LP, 9 direct stream general on the 8-byte entries (7 prefers the 16-byte ones), 6 direct stream LP, 7 direct stream general (geo: 0 -> 2048-byte lanes, 1 -> 48-byte lanes).
 // geo: 0 production, 1 tiny.
@@ -685,7 +606,7 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
     a.gscratch = want_scratch ? scratch.data() : nullptr;
     uint32_t status = 0;
     uint64_t total = 0;
-    if (family != 3 && family != 5 && family != 7 && family != 9 && family != 22 && family != 23 && family != 24 && family != 25 && family != 34 && family != 35 && family != 36 && cap < n) return -9;
+    if (family != 3 && family != 7 && family != 9 && family != 22 && family != 23 && family != 24 && family != 34 && family != 35 && family != 36 && cap < n) return -9;
     if (family == 1) { run_bytemap(a, status); total = n; }
     else if (family == 8) {
         if (reinterpret_cast<const StreamBlobHeader*>(blob)->lpw_bytes == 0) return -5;
@@ -728,29 +649,17 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
         else run_direct_gen_one<>(a, 64u, 76u, 32u, 4, status, total, rounds);
         g_last_rounds = rounds;
     }
-    else if (family == 4) {
-        if (geo == 0) run_stream_lp<GeoStream>(a, status); else run_stream_lp<GeoTinyStream>(a, status);
-        total = n;
-    } else if (family == 5) {
-        if (geo == 0) run_stream_gen<GeoStreamGen>(a, status, total); else run_stream_gen<GeoTinyStream>(a, status, total);
-    }
-    else if (family == 25) {
-        // large table by its copy form
-        const StreamBlobHeader& sh = *reinterpret_cast<const StreamBlobHeader*>(blob);
-        if (!sh.fb_slots || !sh.off_fb_lit_meta) return -5;
-        run_fb_copy(a, geo == 0 ? 2048 : 128, status, total, geo == 0 ? 256u : 64u);
-    }
     else if (family == 27) {
         // ... its second pass by the wave-cooperative splice (what the runtime launches by default)
         const StreamBlobHeader& sh = *reinterpret_cast<const StreamBlobHeader*>(blob);
         if (!sh.fb_slots || !sh.off_fb_lit_meta) return -5;
-        run_fb_copy(a, geo == 0 ? 2048 : 128, status, total, geo == 0 ? 256u : 64u, true);
+        run_fb_copy(a, geo == 0 ? 2048 : 128, status, total, geo == 0 ? 256u : 64u);
     }
     else if (family == 29) {
         // ... with the first pass on the 8-byte comb (round 3's mark pass; what tables without the mark form run)
         const StreamBlobHeader& sh = *reinterpret_cast<const StreamBlobHeader*>(blob);
         if (!sh.fb_slots || !sh.off_fb_lit_meta) return -5;
-        run_fb_copy(a, geo == 0 ? 2048 : 128, status, total, geo == 0 ? 256u : 64u, true, true);
+        run_fb_copy(a, geo == 0 ? 2048 : 128, status, total, geo == 0 ? 256u : 64u, true);
     }
     else if (engine == 1) {
         if (geo == 0) run_family<GeoDft, DftEngine>(family, a, status, total);

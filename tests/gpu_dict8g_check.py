@@ -23,7 +23,7 @@ import torch  # noqa: E402
 import corpora  # noqa: E402
 import dictgen  # noqa: E402
 import trre_amd  # noqa: E402
-from oracle_lib import Oracle  # noqa: E402
+from oracle_lib import Oracle, scan_mt  # noqa: E402
 
 N = 8 << 30
 SLICE = 4 << 20
@@ -71,6 +71,20 @@ def main():
                 bad += 1
             if s == marks[-1] and at + piece.numel() != m:
                 print("MISMATCH total", eng, at + piece.numel(), m)
+                bad += 1
+        if eng == "nft" and not os.environ.get("TRRE_NO_FB") and not os.environ.get("TRRE_FB_EMIT"):
+            # (the NFT engine was checked against the DFT oracle and a 128 KiB head of its own.)  64 MiB right above the
+            # 4 GiB mark against the NFT oracle on all host cores (0.3 MB/s per core on this 24 kB pattern: line-sharded threads), placed
+            # in the full output by a prefix scan — once per process family (the alternative walkers of the large table: the slices above)
+            s = line_start(inp, (4 << 30) + (64 << 20))
+            e2 = line_start(inp, s + (64 << 20))
+            at = 0
+            for lo, hi in ((0, line_start(inp, N // 2)), (line_start(inp, N // 2), s)):
+                if hi > lo:
+                    at += p.scan_tensor(inp[lo:hi], out=tmp).numel()
+            want = scan_mt(pat, "nft", os.cpu_count() or 1, inp[s:e2].cpu().numpy().tobytes())
+            if out[at:at + len(want)].cpu().numpy().tobytes() != want:
+                print("MISMATCH nft all-cores oracle", s, at)
                 bad += 1
         if eng == "nft":
             e = line_start(inp, 128 << 10)

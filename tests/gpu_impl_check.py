@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Run by tests/test_gpu_parity.py in a subprocess with TRRE_STREAM_IMPL /
+"""Run by tests/test_gpu_parity.py in a subprocess with
 TRRE_LANE_BYTES / TRRE_NO_G16 / TRRE_NO_FB / TRRE_FB_EMIT / TRRE_NO_FB_COPY set: checks the alternative implementations of the stream kernel families
 against the oracle (the environment is read once per process by the library)."""
 import os

@@ -60,7 +60,7 @@ def shim_scan(blob, engine, family, data, geo=1, in_mis=0, out_mis=0, scratch=Tr
     """Run one kernel family of the device code on the host.  Returns (output bytes, status)."""
     auto_cap = cap is None
     if cap is None:
-        cap = len(data) * 8 + 64 if family in (3, 5, 7, 9, 22, 23, 25, 27, 29, 32, 33, 34, 35, 36) else len(data)     # (20, 21: length-preserving)
+        cap = len(data) * 8 + 64 if family in (3, 7, 9, 22, 23, 27, 29, 32, 33, 34, 35, 36) else len(data)     # (20, 21: length-preserving)
     for _ in range(2):
         out = ctypes.create_string_buffer(max(cap, 1))
         m = ctypes.c_size_t()
@@ -127,7 +127,6 @@ STREAM_FB_SPLICE8 = 29                               # ... with the mark pass on
 STREAM_FB_SPLICE = 27                                # ... the second pass as the wave-cooperative splice (what the runtime launches by default)
 STREAM_FB_SPLICE8 = 29                               # ... with the mark pass on the 8-byte comb (tables without the mark form; round 3's first pass)
 STREAM_FB_SPLICE = 27                                # ... the second pass as the wave-cooperative splice (what the runtime launches by default)
-STREAM_FB_COPY = 25                                  # ... by its copy form: mark pass + copy pass (what the runtime launches by default)
 STREAM_FB, STREAM_FB_COUNT = 22, 23                  # stream general family on the fallback form of a large table: both passes /
                                                      # the count pass only, emit on the 8-byte rows (what the runtime launches)
 
@@ -205,7 +204,9 @@ def scan_like_runtime(prog, data, geo=1, family=None, in_mis=0, out_mis=0):
     info = prog.info
     fam = family
     if not fam:                       # ABI ids -> shim ids (the shim's 6..9 are the direct walkers of the stream families)
-        fam = {6: GUIDED_LP, 7: GUIDED_GEN}.get(info.kernel, info.kernel)
+        # (ABI 4 / 5, the stream families: the window kernel — the emit pass alone where the tables have no window form — and the direct
+        # count / emit pair, as runtime.cpp launches them; the shim's own 4 / 5, the LDS-tile walkers, went in round 6)
+        fam = {4: 8, 5: 7, 6: GUIDED_LP, 7: GUIDED_GEN}.get(info.kernel, info.kernel)
     if fam in (GUIDED_LP, GUIDED_GEN, GUIDED_GEN8, GUIDED_LP_RING, GUIDED_LP8, GUIDED_GEN_EXACT, GUIDED_GEN_EXACT_MISS, GUIDED_ONE, GUIDED_ONE_MISS):
         return scan_guided_like_runtime(prog, data, geo, fam, in_mis, out_mis)
     if family == DFT_LAZY or (not family and info.kernel == 10):
@@ -222,7 +223,7 @@ def scan_like_runtime(prog, data, geo=1, family=None, in_mis=0, out_mis=0):
         if st & ST_DIVERGE:
             raise RuntimeError("diverges")
         return out
-    blob = prog.export_stream_tables() if fam in (4, 5, 6, 7, 8, 9, 20, 21, 22, 23, 25, 27, 32, 33, 34, 35, 36, STREAM_LPW_PAIR) else prog.export_tables()
+    blob = prog.export_stream_tables() if fam in (6, 7, 8, 9, 20, 21, 22, 23, 27, 29, 32, 33, 34, 35, 36, STREAM_LPW_PAIR) else prog.export_tables()
     if fam in (STREAM_ONE, STREAM_ONE_MISS, STREAM_ONE_TIGHT):
         out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
         one_stats["runs"] += 1
@@ -237,22 +238,22 @@ def scan_like_runtime(prog, data, geo=1, family=None, in_mis=0, out_mis=0):
             return out
         fam = 7                             # no 16-byte entries, a bounded fold that overflowed, an attempt that does not return: the old way
     out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
-    if out is None:                         # family 8 / 26 without a window (pair) form: nothing to run
-        fam = 6
+    if out is None:                         # family 8 / 26 without a window (pair) form: the emit pass alone, like the runtime
+        fam = STREAM_LP_EMIT
         out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
-    if fam in (5, 7, 9) and st & ST_OVERFLOW:           # bounded stream table: the guided (or the tile) kernels take over
+    if fam in (7, 9) and st & ST_OVERFLOW:           # bounded stream table: the guided (or the tile) kernels take over
         if info.guided_rev_states:
             return scan_guided_like_runtime(prog, data, geo, GUIDED_GEN, in_mis, out_mis)
         fam = 3
         blob = prog.export_tables()
         out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
     assert not st & ST_MISMATCH, "count and emit passes disagree"
-    lp = fam not in (3, 5, 7, 9, 22, 23)
+    lp = fam not in (3, 7, 9, 22, 23)
     if st & ST_DIVERGE and not (lp and st & ST_NUL):      # (a positional launch that met a NUL is void, whatever else it says)
         raise RuntimeError("diverges")
     if lp and st & ST_NUL:
-        gen = (7 if fam in (6, 8, 20, 21, STREAM_LPW_PAIR) else 5) if info.stream_states else 3
-        blob = prog.export_stream_tables() if gen in (5, 7) else prog.export_tables()
+        gen = 7 if info.stream_states else 3
+        blob = prog.export_stream_tables() if gen == 7 else prog.export_tables()
         out, st = shim_scan(blob, info.engine, gen, data, geo, in_mis, out_mis)
         assert not st & ST_MISMATCH
         if st & ST_DIVERGE:

@@ -8,7 +8,7 @@ import sys
 import pytest
 
 import trre_amd
-from oracle_lib import Oracle
+from oracle_lib import Oracle, scan_mt
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,7 +25,7 @@ def line_start(inp, pos):
     return pos + int(nl[0]) if nl.numel() else inp.numel()
 
 
-def check_slices(p, oracle, inp, out, m, fam):
+def check_slices(p, oracle, inp, out, m, fam, full_oracle=None):
     """length-preserving families: output offset == input offset at line starts, so slices compare directly;
     general families: a slice of the input is scanned on its own and must reappear in the full output at the
     offset the scan of everything before it produces — checked for the two halves around the 4 GiB mark"""
@@ -41,6 +41,7 @@ def check_slices(p, oracle, inp, out, m, fam):
         return
     tmp = torch.empty(inp.numel() // 2 + inp.numel() // 8 + (4 << 20), dtype=torch.uint8, device="cuda")
     at = 0
+    second_half_at = None
     for lo, hi in ((0, cut), (cut, n)):
         part = p.scan_tensor(inp[lo:hi], out=tmp)
         k = part.numel()
@@ -48,8 +49,20 @@ def check_slices(p, oracle, inp, out, m, fam):
         e = line_start(inp, lo + SLICE)
         want = oracle.scan(inp[lo:e].cpu().numpy().tobytes())
         assert part[:len(want)].cpu().numpy().tobytes() == want, (fam, lo)
+        if lo:
+            second_half_at = at
         at += k
     assert at == m
+    # ... and the FULL output's second half against the oracle itself, not against the engine: every byte that the first
+    # GiB of input above the 4 GiB mark becomes, checked by the oracle on all host cores (line-sharded threads; two slabs of 512 MiB)
+    if full_oracle is not None:
+        pattern, engine = full_oracle
+        pos, opos = cut, second_half_at
+        for _ in range(2):
+            end = line_start(inp, min(n, pos + (512 << 20)))
+            want = scan_mt(pattern, engine, os.cpu_count() or 1, inp[pos:end].cpu().numpy().tobytes())
+            assert out[opos:opos + len(want)].cpu().numpy().tobytes() == want, (fam, "all-cores oracle", pos)
+            pos, opos = end, opos + len(want)
 
 
 def test_caesar_8gib_all_families():
@@ -83,7 +96,7 @@ def test_cfg4_8gib_all_families():
     for fam in fams:
         p.set_kernel(fam)
         got = p.scan_tensor(inp, out=out)
-        check_slices(p, oracle, inp, out, got.numel(), p.info.kernel)
+        check_slices(p, oracle, inp, out, got.numel(), p.info.kernel, ("(cat:dog|dog:cat)", "nft") if fam == trre_amd.KERNEL_AUTO else None)
     p.set_kernel(trre_amd.KERNEL_AUTO)
 
 
@@ -97,14 +110,14 @@ def test_general_families_8gib():
     for pat, eng in (("a:xyz", "dft"), ("(a|b)*c:x", "nft")):
         p = trre_amd.Program(pat, eng)
         got = p.scan_tensor(inp, out=out)
-        check_slices(p, Oracle(pat, eng), inp, out, got.numel(), p.info.kernel)
+        check_slices(p, Oracle(pat, eng), inp, out, got.numel(), p.info.kernel, (pat, eng))
 
 
-@pytest.mark.parametrize("env", [{}, {"TRRE_NO_FB_SPLICE": "1"}, {"TRRE_NO_FB_MARK4": "1"}, {"TRRE_NO_FB_COPY": "1"}, {"TRRE_NO_FB": "1"}, {"TRRE_FB_EMIT": "1"}])
+@pytest.mark.parametrize("env", [{}, {"TRRE_NO_FB_MARK4": "1"}, {"TRRE_NO_FB_COPY": "1"}, {"TRRE_NO_FB": "1"}, {"TRRE_FB_EMIT": "1"}])
 def test_dictionary_8gib(env):
     """BASELINE configs[4] at its per-GPU size: the 1000-entry dictionary over 8 GiB of its own corpus (offsets
     beyond 2^32 through the large-table kernels), both engines, the automatic choice (the copy form: mark pass on the 32-bit comb, wave-cooperative
-    splice), round 3's second pass (TRRE_NO_FB_SPLICE) and first pass (TRRE_NO_FB_MARK4) and the three alternative walkers of the large table (the library reads the environment once per process: subprocess)"""
+    splice), round 3's first pass (TRRE_NO_FB_MARK4) and the three alternative walkers of the large table (the library reads the environment once per process: subprocess)"""
     import subprocess
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_dict8g_check.py")
     e = dict(os.environ)

@@ -275,11 +275,10 @@ def test_very_long_lines_through_the_guided_families():
                 assert time.time() - t0 < 20, (pat, fam, "the backward pass must not be quadratic in the line length")
 
 
-@pytest.mark.parametrize("env", [{"TRRE_STREAM_IMPL": "0"}, {"TRRE_STREAM_IMPL": "1"}, {"TRRE_STREAM_IMPL": "1", "TRRE_LANE_BYTES": "256"},
-                                 {"TRRE_STREAM_IMPL": "2", "TRRE_LANE_BYTES": "4096"}, {"TRRE_STREAM_IMPL": "2", "TRRE_LANE_BYTES": "1024"},
+@pytest.mark.parametrize("env", [{"TRRE_LANE_BYTES": "256"}, {"TRRE_LANE_BYTES": "4096"}, {"TRRE_LANE_BYTES": "1024"},
                                  {"TRRE_NO_G16": "1"}, {"TRRE_NO_FB": "1"}, {"TRRE_FB_EMIT": "1"}, {"TRRE_NO_FB_COPY": "1"}, {"TRRE_NO_LPW_PAIR": "1"}])
 def test_alternative_stream_implementations(env):
-    """LDS-tile and direct variants of the stream families, other lane sizes, 8-byte entries only, large tables without their
+    """the stream families at other lane sizes, on the 8-byte entries only, large tables without their
     fallback form / with both passes on it / without its copy form, the window walk one byte per step (selected by environment, which the library reads once per process)"""
     import os
     import subprocess

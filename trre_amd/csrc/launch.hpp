@@ -19,11 +19,8 @@ int block_threads(int engine, int mask_bytes);
 
 // which: 0 length-preserving scan, 1 count pass, 2 emit pass
 void launch_tile_kernel(int which, int engine, int mask_bytes, const ScanArgs& a, int64_t n_chunks, void* stream);
-// stream engine (tables from stream_build.cpp); which: 0 in-place length-preserving, 1 count, 2 emit
-int stream_chunk_bytes(int which);
-int stream_block_threads(int which);
-void launch_stream_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t n_chunks, void* stream);
-// direct stream kernels (no LDS tile); which: 0 length-preserving, 1 count, 2 emit
+// stream families (tables from stream_build.cpp): the direct kernels — a lane walks a long sub-range straight from memory; which: 1 count, 2 emit
+// (0: the in-place ring walker, kept for the window kernel's redo lanes only)
 int direct_ent_lds_bytes();
 int direct_block_threads();
 // sym: guided families — columns are the symbols of the backward pass (a.sym_v0): 1 one per byte, 2 packed two per byte
@@ -43,9 +40,8 @@ void launch_lpw_kernel(int ent_bytes, bool wide, bool direct_ent_in_lds, const S
 // blob's header.  Chunks are those of the direct kernels (direct_block_threads() lanes each).
 void launch_fb_kernel(int which, const ScanArgs& a, const void* hdr, int64_t lane_bytes, int64_t n_chunks, void* stream);
 bool fb_fits(const void* hdr);
-// the copy form of a large table (scan_block.hpp): mark pass (count + flags + ids), copy pass (no automaton)
+// the copy form of a large table (scan_block.hpp): mark pass (count + events); the second pass is the splice below
 void launch_fb_mark(const ScanArgs& a, const FbCopyArgs& ca, const void* hdr, int64_t lane_bytes, int64_t n_chunks, void* stream);
-void launch_fb_copy(const ScanArgs& a, const FbCopyArgs& ca, const void* hdr, int64_t lane_bytes, int64_t n_chunks, void* stream);
 bool fb_copy_fits(const void* hdr);
 // ... its second pass as a wave-cooperative splice (splice_block.hpp); the workspace's chunks must be full (the mark pass fills every lane's header)
 void launch_fb_splice(const ScanArgs& a, const FbCopyArgs& ca, const void* hdr, int64_t lane_bytes, int64_t n_chunks, void* stream);

@@ -938,21 +938,16 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
     const bool backtrack = family == TRRE_KERNEL_BACKTRACK;
     const bool lazy = family == TRRE_KERNEL_DFT_LAZY;
     if (lazy) { rc = lazy_ensure(p); if (rc) return rc; }
+    // (the stream and guided families run the direct kernels — a lane walks a long sub-range straight from memory —: their chunks are
+    // counted below, once the sub-range is known.  Rounds 1-5 also kept LDS-tile kernels for the stream tables, TRRE_STREAM_IMPL=0:
+    // 10-100 GB/s, no job since round 2, removed in round 6)
     const int chunk = backtrack ? (int)kBtLaneBytes * 256 : lazy ? (int)kLazyLaneBytes * 256
-                      : is_stream(family) ? stream_chunk_bytes(family == TRRE_KERNEL_STREAM_LP ? 0 : 1)
-                                          : chunk_bytes(p->engine, p->mask_bytes);
-    const int threads = backtrack || lazy ? 256
-                        : is_stream(family) ? stream_block_threads(family == TRRE_KERNEL_STREAM_LP ? 0 : 1)
-                                            : block_threads(p->engine, p->mask_bytes);
+                      : is_stream(family) ? 2048 * direct_block_threads() : chunk_bytes(p->engine, p->mask_bytes);
+    const int threads = backtrack || lazy ? 256 : is_stream(family) ? direct_block_threads() : block_threads(p->engine, p->mask_bytes);
     int64_t n_chunks = (args.vend + chunk - 1) / chunk;
-    const bool ent_lds = stt.ok && stt.ent.size() * 8 <= (size_t)StreamEngine::kLdsEntBytes;
-    // stream families have three implementations (TRRE_STREAM_IMPL, for A/B measurements):
-    //   0 LDS tile (k_stream_lp / k_stream_count+emit)      1 direct walkers only
-    //   2 (default) positional-window kernel (wave-tiled I/O) for length-preserving tables that have
-    //     the window form, direct walkers otherwise
-    static const int stream_impl = getenv("TRRE_STREAM_IMPL") ? atoi(getenv("TRRE_STREAM_IMPL")) : 2;
     static const int64_t lane_bytes_env = getenv("TRRE_LANE_BYTES") ? atoll(getenv("TRRE_LANE_BYTES")) : 0;
-    const bool window = is_stream(family) && stream_impl == 2 && family == TRRE_KERNEL_STREAM_LP && p->stt.lpw_ok &&
+    // the positional-window kernel (wave-tiled I/O) for length-preserving tables that have the window form, the direct walkers otherwise
+    const bool window = is_stream(family) && family == TRRE_KERNEL_STREAM_LP && p->stt.lpw_ok &&
                         (reinterpret_cast<uintptr_t>(args.out_v0) & 15u) == 0;   // its 16-byte stores: in and out congruent mod 16 (unaligned they work, at the pace
                                                                                  // of the emit pass alone: 0.94 against 0.98 ms per GiB, round 4)
     // sub-range per lane: 2 KiB, growing with the input so that about half a million lanes (8192 waves)
@@ -965,10 +960,10 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
     // 32 KiB; ' +: ' 896 / 947 / 805 — and so does the mark + splice pair of a large table, its event lists growing with the sub-range:
     // cfg 5 at 4 GiB 594 / 663 (4 KiB) / 675; the guided families do not: 647 / 641)
     // (the guided families' forward passes gain 2 % at 8 GiB, their backward pass loses 15 %: it keeps 2 KiB)
-    if ((family == TRRE_KERNEL_STREAM_GEN && stream_impl >= 1 && (p->stt.g16_ok || p->stt.fb_ok)) || (is_guided(family) && !p->gt.wide))
+    if ((family == TRRE_KERNEL_STREAM_GEN && (p->stt.g16_ok || p->stt.fb_ok)) || (is_guided(family) && !p->gt.wide))
         while (lane_auto < 8192 && (int64_t)n / (lane_auto * 2) >= 262144) lane_auto *= 2;
     const int64_t lane_bytes = lane_bytes_env > 0 ? (lane_bytes_env + 127) / 128 * 128 : lane_auto;
-    const bool direct = (is_stream(family) && stream_impl >= 1) || is_guided(family);
+    const bool direct = is_stream(family) || is_guided(family);
     const int64_t rev_lane_bytes = lane_bytes_env > 0 ? lane_bytes : 2048;
     const bool direct_ent_lds = stt.ok && stt.ent.size() * 8 <= (size_t)direct_ent_lds_bytes();
     const bool g16_slow = (stt.flags & kFlagG16Slow) != 0;
@@ -1075,7 +1070,12 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
         // count pass + the emit pass on the 8-byte rows, for A/B runs and what finish() falls back to (a NUL in the input,
         // more texts in a sub-range than its event list holds).
         static const bool no_copy_env = getenv("TRRE_NO_FB_COPY") != nullptr;
-        if (!no_copy_env && !fb_emit_env && !cx->patch_off && !p->copy_form_off.load() && lane_bytes % 64 == 0 && fb_copy_fits(p->sblob.data())) {
+        // (the second pass is the wave-cooperative splice of splice_block.hpp; a table with an escape text longer than its tiles take — more than
+        // 255 bytes — or too large for its LDS has no copy form: the pair below)
+        uint32_t esc_max = 0;
+        for (size_t k = 0; k + 3 < p->stt.fb_esc.size(); k += 4) esc_max = std::max(esc_max, p->stt.fb_esc[k + 1]);
+        if (!no_copy_env && !fb_emit_env && !cx->patch_off && !p->copy_form_off.load() && lane_bytes % 64 == 0 && fb_copy_fits(p->sblob.data()) &&
+            esc_max <= kSpMaxText && fb_splice_fits(p->sblob.data())) {
             const int64_t n_lanes = n_chunks * direct_block_threads();
             const int64_t ev_rows = (lane_bytes + 2047) / 2048;                  // (the event list grows with the sub-range)
             rc = ensure_copy_workspace(cx, n_lanes * ev_rows);
@@ -1086,13 +1086,7 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
             ca.ev_cap = kCopyEvCap * (uint32_t)ev_rows;
             launch_fb_mark(args, ca, p->sblob.data(), lane_bytes, n_chunks, stream);
             launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);
-            // second pass: the wave-cooperative splice (splice_block.hpp; round 4), or — TRRE_NO_FB_SPLICE=1 for A/B runs, and for tables
-            // with an escape text longer than its tiles take — the lane-sequential copy pass
-            static const bool no_splice_env = getenv("TRRE_NO_FB_SPLICE") != nullptr;
-            uint32_t esc_max = 0;
-            for (size_t k = 0; k + 3 < p->stt.fb_esc.size(); k += 4) esc_max = std::max(esc_max, p->stt.fb_esc[k + 1]);
-            if (!no_splice_env && esc_max <= kSpMaxText && fb_splice_fits(p->sblob.data())) launch_fb_splice(args, ca, p->sblob.data(), lane_bytes, n_chunks, stream);
-            else launch_fb_copy(args, ca, p->sblob.data(), lane_bytes, n_chunks, stream);
+            launch_fb_splice(args, ca, p->sblob.data(), lane_bytes, n_chunks, stream);
             pd.total_at = cx->d_chunk_base + n_chunks;
             pd.patched = true;
         } else {
@@ -1193,13 +1187,6 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
             pd.xargs = args; pd.x_lane_bytes = lane_bytes; pd.x_n_chunks = n_chunks; pd.x_g16 = g16; pd.x_sym = sym_mode; pd.x_slow = g16_slow; pd.x_ent_lds = direct_ent_lds;
             pd.x_rev_lane_bytes = is_guided(family) ? rev_lane_bytes : 0;
         }
-    } else if (family == TRRE_KERNEL_STREAM_LP) {
-        launch_stream_kernel(0, ent_lds, args, n_chunks, stream);
-    } else if (family == TRRE_KERNEL_STREAM_GEN) {
-        launch_stream_kernel(1, ent_lds, args, n_chunks, stream);
-        launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);
-        launch_stream_kernel(2, ent_lds, args, n_chunks, stream);
-        pd.total_at = cx->d_chunk_base + n_chunks;
     } else {
         launch_tile_kernel(1, p->engine, p->mask_bytes, args, n_chunks, stream);
         launch_chunk_scan(cx->d_chunk_total, cx->d_chunk_base, n_chunks, stream);

@@ -377,79 +377,6 @@ struct NftEngine {
 };
 constexpr uint32_t kStNeedScratch = 1u << 4;   // NFT long line met without mask scratch: relaunch with it
 
-// =============================================================================================
-// Stream engine: one table lookup per byte, no rollback.  Lanes run a flat loop
-// over all their lines (no per-line reconvergence).
-// =============================================================================================
-struct StreamEngine {
-    using View = StreamView;
-    static constexpr int kLdsEntBytes = 8192;    // table rows kept in LDS when they fit, else read through L2
-    static constexpr int kLdsBytes = 256 + kLdsEntBytes;
-
-    TRRE_HD static bool ent_fits(const StreamBlobHeader& h) { return h.ent_bytes <= (uint32_t)kLdsEntBytes; }
-    TRRE_HD static void stage(const uint8_t* blob, uint8_t* lds, int tid, int nthreads) {
-        const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(blob);
-        const uint8_t* c = blob + h.off_cls;
-        for (int k = tid; k < 256; k += nthreads) lds[k] = c[k];
-        if (ent_fits(h)) {
-            const uint64_t* e = reinterpret_cast<const uint64_t*>(blob + h.off_ent);
-            uint64_t* d = reinterpret_cast<uint64_t*>(lds + 256);
-            const int n = (int)(h.ent_bytes / 8);
-            for (int k = tid; k < n; k += nthreads) d[k] = e[k];
-        }
-    }
-    template <bool kLdsEnt>
-    TRRE_HD static View view(const uint8_t* blob, const uint8_t* lds) {
-        const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(blob);
-        View v;
-        v.cls = lds;
-        v.ent = kLdsEnt ? reinterpret_cast<const uint64_t*>(lds + 256) : reinterpret_cast<const uint64_t*>(blob + h.off_ent);
-        v.pool = blob + h.off_pool;
-        return v;
-    }
-};
-
-// one line redone straight from HBM (it left the tile); LP: out position == in position
-TRRE_HD void stream_line_lp_global(const ScanArgs& a, const StreamView& T, int64_t v, uint32_t& status) {
-    GlobalIn in{a.in_v0, a.vend - 1};
-    int64_t p = v, o = v;
-    uint32_t row = 0;
-    for (;;) {
-        const uint8_t c = in(p);
-        const uint64_t e = T.ent[row + T.cls[c]];
-        const uint32_t lo = (uint32_t)e, hi = (uint32_t)(e >> 32);
-        o = str_emit(T, a.out_v0, o, lo, hi, c);
-        row = str_next(lo);
-        ++p;
-        if (lo & kStrEol) break;
-    }
-    if (o != p) status |= kStNul;
-}
-template <class Sink>
-TRRE_HD uint32_t stream_line_gen_global(const ScanArgs& a, const StreamView& T, Sink& sink, int64_t v) {
-    GlobalIn in{a.in_v0, a.vend - 1};
-    int64_t p = v;
-    uint32_t row = 0, seen = 0;
-    for (;;) {
-        const uint8_t c = in(p);
-        const uint64_t e = T.ent[row + T.cls[c]];
-        const uint32_t lo = (uint32_t)e, hi = (uint32_t)(e >> 32);
-        if constexpr (Sink::kCountOnly) sink.add(str_count(T, lo, hi));
-        else sink.n = (uint64_t)str_emit(T, sink.o, (int64_t)sink.n, lo, hi, c);
-        row = str_next(lo);
-        seen |= lo;
-        ++p;
-        if (lo & kStrEol) break;
-    }
-    return seen;                                  // (entry flags met: the caller looks for kStrOvf)
-}
-
-// start of the line that contains position v (HBM, slow path only)
-TRRE_HD int64_t line_start_global(const ScanArgs& a, int64_t v) {
-    while (v > a.vbeg && a.in_v0[v - 1] != (uint8_t)'\n') --v;
-    return v;
-}
-
 #if defined(__HIP_DEVICE_COMPILE__)
 #define TRRE_WAVE_ANY(x) __any(x)
 #define TRRE_WAVE_ALL(x) __all(x)
@@ -469,167 +396,6 @@ TRRE_HD int64_t line_start_global(const ScanArgs& a, int64_t v) {
 constexpr uint32_t kStrNul = 1u << 29;
 constexpr uint32_t kStrDiv = 1u << 31;       // guided tables: the reference's search would not terminate on this input
 constexpr uint32_t kSkipState = 1, kDoneState = 2;
-
-// Lane start for the synchronous walks.  Every lane of a wave reads byte
-// (lo + k) at step k: sub-ranges start 4-byte aligned and SUB/4 is odd, so the
-// 64 dword reads of a wave fall into distinct LDS banks.  A lane whose sub-range
-// does not begin at a line start begins in SKIP (silent until the first '\n'),
-// a lane without input begins in DONE.
-template <class G>
-TRRE_HD void stream_lane_start(const ScanArgs& a, int64_t v0, const uint8_t* tile, int tid, uint32_t n_cls, int& lo, int& hi,
-                               uint32_t& row) {
-    int64_t lo64, hi64;
-    lane_range<G>(a, v0, tid, lo64, hi64);
-    lo = (int)lo64 & ~3;          // only a lane clamped to the start of the input is unaligned; the bytes
-    hi = (int)hi64;               // before the input are staged as non-newline filler + one '\n'
-    if (lo64 >= hi64) { row = kDoneState * n_cls; lo = hi = G::PRE; return; }
-    row = tile[lo - 1] == (uint8_t)'\n' ? 0u : kSkipState * n_cls;
-}
-
-// Input pipeline of the synchronous walks: the dword two steps ahead and the
-// byte classes of the dword one step ahead are fetched while the current dword
-// is being walked, so the only LDS access on a lane's dependent chain is the
-// table entry itself.
-struct StreamPipe {
-    uint32_t w0, w1;             // current dword, next dword
-    uint8_t k0, k1, k2, k3;      // classes of the current dword's bytes
-};
-template <class G>
-TRRE_HD uint32_t pipe_load(const uint32_t* t32, int p) {
-    const int pr = p < G::TILE ? p : G::TILE;       // finished lanes idle on the sentinel dword
-    return t32[pr >> 2];
-}
-template <class G>
-TRRE_HD void pipe_init(StreamPipe& q, const StreamView& T, const uint32_t* t32, int p) {
-    q.w0 = pipe_load<G>(t32, p);
-    q.w1 = pipe_load<G>(t32, p + 4);
-    q.k0 = T.cls[q.w0 & 0xffu]; q.k1 = T.cls[(q.w0 >> 8) & 0xffu]; q.k2 = T.cls[(q.w0 >> 16) & 0xffu]; q.k3 = T.cls[q.w0 >> 24];
-}
-
-// ---- phase: length-preserving IN-PLACE walk: the tile is input and output ------------------
-// Output never overtakes input (the cursor trails by the pending bytes) and a
-// record end resynchronises it, so writing at tile[o] is safe; lanes in SKIP or
-// DONE write nothing.  Reports [first,last): first owned line start .. end of the
-// last owned line.  One table lookup per byte, no data-dependent branches except
-// the rare multi-byte emission and the record-end bookkeeping.
-template <class G>
-TRRE_HD void stream_lane_lp(const ScanArgs& a, const StreamView& T, uint32_t n_cls, int64_t v0, uint8_t* tile, int tid,
-                            int32_t& first, int32_t& last, uint32_t& status) {
-    int lo, hi;
-    uint32_t row;
-    stream_lane_start<G>(a, v0, tile, tid, n_cls, lo, hi, row);
-    const uint32_t done_row = kDoneState * n_cls;
-    int o = lo;
-    int ls = row == 0u ? lo : -1;          // start of the line being scanned (position after the last record end)
-    int fs = row == 0u ? lo : 0x7fffffff;  // first line start seen
-    uint32_t seen = 0;
-    bool over = false;
-    const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tile);
-    StreamPipe q;
-    pipe_init<G>(q, T, t32, lo);
-    for (int p = lo; TRRE_WAVE_ANY(row != done_row); p += 4) {
-        const uint32_t w = q.w0;
-        const uint8_t kk[4] = {q.k0, q.k1, q.k2, q.k3};
-        // prefetch: dword p+8, classes of dword p+4
-        const uint32_t w2 = pipe_load<G>(t32, p + 8);
-        q.k0 = T.cls[q.w1 & 0xffu]; q.k1 = T.cls[(q.w1 >> 8) & 0xffu]; q.k2 = T.cls[(q.w1 >> 16) & 0xffu]; q.k3 = T.cls[q.w1 >> 24];
-        q.w0 = q.w1;
-        q.w1 = w2;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint8_t c = (uint8_t)(w >> (8 * j));
-            const uint64_t e = T.ent[row + kk[j]];
-            const uint32_t elo = (uint32_t)e, ehi = (uint32_t)(e >> 32);
-            const uint32_t ol = str_olen(elo), cc = (elo >> 27) & 1u;
-            uint32_t n = ol + cc;
-            if (n) tile[o] = ol ? (uint8_t)ehi : c;
-            if (TRRE_WAVE_ANY(n >= 2u)) {                     // rare: replacement text / flushed pending bytes
-                if (n >= 2u) n = (uint32_t)(str_emit(T, tile, o, elo, ehi, c) - o);
-            }
-            o += (int)n;
-            row = str_next(elo);
-            seen |= elo;
-            if (elo & kStrEol) {
-                const int p1 = p + j + 1;
-                if (p1 <= G::TILE) {
-                    o = p1;                                   // resynchronise (leaving SKIP, or after a NUL)
-                    ls = p1;
-                    fs = fs < p1 ? fs : p1;
-                } else {
-                    over = true;                              // that was the sentinel, not a record end
-                }
-                if (p1 >= hi) row = done_row;
-            }
-        }
-    }
-    if (seen & kStrNul) status |= kStNul;
-    if (seen & kStrDiv) status |= kStDiverge;
-    first = fs;
-    last = ls;
-    if (over && ls >= 0) {                    // the line that starts at ls leaves the tile: redo it from HBM
-        status |= kStLongLine;
-        stream_line_lp_global(a, T, v0 + ls, status);
-    }
-}
-
-// ---- phase: general stream walk into a sequential sink (count or emit) ----------------------
-template <class G, class Sink>
-TRRE_HD void stream_lane_gen(const ScanArgs& a, const StreamView& T, uint32_t n_cls, int64_t v0, const uint8_t* tin, int tid,
-                             Sink& sink, uint32_t& status) {
-    int lo, hi;
-    uint32_t row;
-    stream_lane_start<G>(a, v0, tin, tid, n_cls, lo, hi, row);
-    const uint32_t done_row = kDoneState * n_cls;
-    int ls = row == 0u ? lo : -1;
-    bool over = false;
-    uint32_t seen = 0;
-    uint64_t mark = sink.n;                   // sink position at the start of the current line
-    const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tin);
-    StreamPipe q;
-    pipe_init<G>(q, T, t32, lo);
-    for (int p = lo; TRRE_WAVE_ANY(row != done_row); p += 4) {
-        const uint32_t w = q.w0;
-        const uint8_t kk[4] = {q.k0, q.k1, q.k2, q.k3};
-        const uint32_t w2 = pipe_load<G>(t32, p + 8);
-        q.k0 = T.cls[q.w1 & 0xffu]; q.k1 = T.cls[(q.w1 >> 8) & 0xffu]; q.k2 = T.cls[(q.w1 >> 16) & 0xffu]; q.k3 = T.cls[q.w1 >> 24];
-        q.w0 = q.w1;
-        q.w1 = w2;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint8_t c = (uint8_t)(w >> (8 * j));
-            const uint64_t e = T.ent[row + kk[j]];
-            const uint32_t elo = (uint32_t)e, ehi = (uint32_t)(e >> 32);
-            if constexpr (Sink::kCountOnly) {
-                const uint32_t ol = str_olen(elo);
-                uint32_t n = ol + ((elo >> 27) & 1u);
-                if (TRRE_WAVE_ANY(ol == 7u)) { if (ol == 7u) n = str_count(T, elo, ehi); }
-                sink.n += n;
-            } else {
-                const uint32_t ol = str_olen(elo), cc = (elo >> 27) & 1u;
-                uint32_t n = ol + cc;
-                if (n) sink.o[sink.n] = ol ? (uint8_t)ehi : c;
-                if (TRRE_WAVE_ANY(n >= 2u)) {
-                    if (n >= 2u) n = (uint32_t)(str_emit(T, sink.o, (int64_t)sink.n, elo, ehi, c) - (int64_t)sink.n);
-                }
-                sink.n += n;
-            }
-            row = str_next(elo);
-            seen |= elo;
-            if (elo & kStrEol) {
-                const int p1 = p + j + 1;
-                if (p1 <= G::TILE) { ls = p1; mark = sink.n; } else over = true;
-                if (p1 >= hi) row = done_row;
-            }
-        }
-    }
-    if (seen & kStrOvf) status |= kStOverflow;
-    if (seen & kStrDiv) status |= kStDiverge;
-    if (over && ls >= 0) {                    // the line that starts at ls leaves the tile: redo it from HBM
-        status |= kStLongLine;
-        sink.n = mark;
-        if (stream_line_gen_global(a, T, sink, v0 + ls) & kStrOvf) status |= kStOverflow;
-    }
-}
 
 // =============================================================================================
 // Direct stream walk: no LDS tile.  Each lane walks a long contiguous sub-range (lane_bytes, a few
@@ -2196,162 +1962,16 @@ TRRE_HD void fb_mark4_lane(const ScanArgs& a, const Fb4View& T, int64_t lane, in
 //                  start of the lane's sub-range) of the byte on which the text came out — a text is known only when its
 //                  key is complete: it stands for the kb bytes right before that byte — and [31:16] the text's id
 //                  (0x8000 | index: an escape record).  Plus the lane's first line start and the end of its last line.
-//   fb_copy_lane   no automaton: input and events in, copy the bytes, insert the texts, skip what they stand for.
-//                  Per input dword and event: the bytes before the text, the text, and on the next turn the bytes after
-//                  it, each one append of a contiguous byte range with no branch on the data.
+//   second pass    no automaton: input and events in, copy the bytes, insert the texts, skip what they stand for — the
+//                  wave-cooperative splice of splice_block.hpp (round 4).  (Round 3's lane-sequential copy pass, fb_copy_lane / k_fb_copy —
+//                  35 instructions per byte, every lane copying its own sub-range through a staging ring — stayed as the route for
+//                  escape texts of more than 255 bytes until round 6; such tables run the count / emit pair now.)
 //
-// A lane's events lie side by side (a row of ev_cap per lane).  The copy pass takes them one at a time, the next one
-// requested when one has been used.  Measured alternatives: slot i of a wave's 64 lanes as one
-// 256-byte row — the lanes drift apart by tens of slots, the rows end up as scattered 4-byte accesses, same speed and
-// same traffic in sum; events 16 bytes at a time with eight more requested at the top of every
-// piece — no waiting for memory inside a piece, but the register shuffling costs what the waiting did (1.52 against
-// 1.43 ms).  With the events switched off (TRRE_EMIT_DBG=4: a plain copy through the same loop) the pass takes 0.75 ms,
-// without its stores and ring writes 0.55: it is bound by its own instructions, 35 per byte.
 // A NUL ends a line early (the rest of the record is swallowed, not passed through): the launch is void and the count /
 // emit pair runs (kStNul), as for the length-preserving kernels.  So does a lane with more than ev_cap events, or with an
 // event more than 64 KiB behind its start (a very long last line): kStEditOverflow.
 // =============================================================================================
 
-// what the copy pass needs about a literal: its text (8 bytes, zero beyond its length), its length and the input bytes it stands for
-struct FbCopyTables {
-    const U128* lit;           // [fb_lits] {text lo, text hi, n | kb << 8, -}  (LDS)
-    const uint32_t* esc;       // escape records (global) ...
-    const uint8_t* pool;       // ... and their texts
-};
-TRRE_HD uint32_t copy_mask(uint32_t cnt) { return cnt >= 4u ? 0xffffffffu : (1u << (8u * cnt)) - 1u; }
-template <class Dummy = void>
-TRRE_HD void fb_copy_lane(const ScanArgs& a, const FbCopyTables& T, const FbCopyArgs& ca, int64_t lane, int64_t lane_bytes, uint8_t* ring,
-                          uint64_t out_base, uint32_t& status, uint32_t* wave_scratch = nullptr) {
-    const int64_t lo = lane * lane_bytes;
-    const bool exists = lo < a.vend;
-    const uint32_t* hdr = ca.lane_hdr + (size_t)lane * 4;
-    uint32_t n_ev = exists ? hdr[0] : 0u;
-    const uint32_t b_rel = exists ? hdr[1] : 0u, e_rel = exists ? hdr[2] : 0u;
-    int64_t end = lo + (int64_t)e_rel;
-    if (end > a.vend) end = a.vend;
-    int64_t v = (lo + (int64_t)b_rel) & ~(int64_t)63;
-    uint32_t skip = (uint32_t)(lo + (int64_t)b_rel - v);                   // bytes still to drop: up to the first line start, then what the texts stand for
-    if (e_rel <= b_rel) { v = lo; end = lo; n_ev = 0; skip = 0; }
-    if (a.dbg & 4u) n_ev = 0;                                              // (timing experiments: a plain copy)
-    uint32_t prel = (uint32_t)(v - lo);                                    // position of the piece, as the events count it
-    Stage S{};
-    S.dbg = a.dbg;
-    S.wsc = wave_scratch;
-    stage_begin(S, ring, a.out + out_base);
-    // The event in front of the lane, decoded: where its text goes, the text, and what it stands for.  The raw events come
-    // 16 bytes (four events) at a time: E holds the four the lane is taking, E1 and E2 the eight after them — asked for at
-    // the top of a piece, for all lanes at once, a piece or more before they are needed.  (A lane that asked for its next
-    // event when it had used one — the first version — made the whole wave wait for memory: `s_waitcnt vmcnt` is per wave,
-    // and in almost every dword some lane had just asked.)  A lane that runs through all twelve between two piece tops
-    // asks on the spot.
-    const uint32_t* evp = copy_event_row(ca, lane);
-    uint32_t nfp = 0xffffffffu, nn = 0, nkb = 0, nesc = 0;                // nesc: 1 + offset of an escape's text in the pool
-    uint64_t ntext = 0;
-    uint32_t raw1 = n_ev > 1u ? evp[1] : 0u;
-    uint32_t taken = 0;                                                    // events decoded so far
-    auto decode = [&](uint32_t raw) {
-        const uint32_t id = raw >> 16, pos = raw & 0xffffu;
-        nesc = 0;
-        if (!(id & 0x8000u)) {
-            const U128 r = T.lit[id];
-            ntext = (uint64_t)r.x | (uint64_t)r.y << 32;
-            nn = r.z & 255u;
-            nkb = r.z >> 8;
-            nfp = pos - nkb;
-        }
-        if (TRRE_WAVE_ANY((id & 0x8000u) != 0u)) {
-            if (id & 0x8000u) {
-                const uint32_t* r = T.esc + 4u * (id & 0x7fffu);
-                nesc = 1u + r[0];
-                nn = r[1];
-                nkb = r[3] & 255u;
-                nfp = pos - (r[3] >> 8);
-            }
-        }
-    };
-    if (n_ev) { decode(evp[0]); taken = 1; }
-    auto advance = [&]() {               // (only lanes that met their event call this)
-        if (taken < n_ev) {
-            decode(raw1);
-            ++taken;
-            if (taken < n_ev) raw1 = evp[taken];
-        } else {
-            nfp = 0xffffffffu;
-        }
-    };
-    const int64_t vlast = (a.vend - 1) & ~(int64_t)15;
-    // a piece's input is requested while the piece before it is copied
-    auto fetch = [&](int64_t at, U128* c) {
-        const int64_t vv = at < end ? at : lo;                             // (a finished lane reads something harmless)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int64_t x = vv + 16 * q < vlast ? vv + 16 * q : vlast;
-            c[q] = *reinterpret_cast<const U128*>(a.in_v0 + x);
-        }
-        if (TRRE_WAVE_ANY(vv < a.vbeg || vv + 64 > a.vend - 1)) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) c[q] = direct_load(a, vv + 16 * q);
-        }
-    };
-    U128 c[4], nx[4];
-    fetch(v, c);
-    for (;; v += 64, prel += 64u) {
-        const bool act = v < end;
-        if (!TRRE_WAVE_ANY(act)) break;
-        fetch(v + 64, nx);
-        const int32_t rem = !act ? 0 : (end - v >= 64 ? 64 : (int32_t)(end - v));
-#pragma clang loop unroll(disable)
-        for (int q = 0; q < 4; ++q) {
-            // (selects, not an indexed array: that would live in scratch memory)
-            U128 b;
-            b.x = q == 0 ? c[0].x : (q == 1 ? c[1].x : (q == 2 ? c[2].x : c[3].x));
-            b.y = q == 0 ? c[0].y : (q == 1 ? c[1].y : (q == 2 ? c[2].y : c[3].y));
-            b.z = q == 0 ? c[0].z : (q == 1 ? c[1].z : (q == 2 ? c[2].z : c[3].z));
-            b.w = q == 0 ? c[0].w : (q == 1 ? c[1].w : (q == 2 ? c[2].w : c[3].w));
-#pragma clang loop unroll(disable)
-            for (int r = 0; r < 4; ++r) {
-                const uint32_t w = r == 0 ? b.x : (r == 1 ? b.y : (r == 2 ? b.z : b.w));
-                const uint32_t p = prel + 16u * (uint32_t)q + 4u * (uint32_t)r;
-                const int32_t left = rem - (16 * q + 4 * r);               // input bytes of the lane from this dword on
-                const uint32_t nval = left <= 0 ? 0u : (left >= 4 ? 4u : (uint32_t)left);
-                uint32_t cur = 0;                                          // bytes of the dword dealt with
-                for (;;) {
-                    const bool has = nfp - p < nval;                       // a text goes in front of one of these bytes
-                    const uint32_t fpos = has ? nfp - p : nval;
-                    // the bytes up to there (those that an earlier text does not stand for)
-                    const uint32_t gap = fpos - cur;
-                    const uint32_t a0 = skip < gap ? skip : gap;
-                    const uint32_t from = cur + a0, cnt = fpos - from;
-                    stage_append_n4(S, (w >> (8u * (from & 3u))) & copy_mask(cnt), cnt);
-                    skip -= a0;
-                    cur = fpos;
-                    if (!TRRE_WAVE_ANY(has)) break;
-                    if (has) {
-                        if (!nesc) stage_append(S, ntext, nn);
-                    }
-                    if (TRRE_WAVE_ANY(has && nesc)) {
-                        if (has && nesc) {                                 // a text spelled out in memory: straight to memory (rare)
-                            const uint8_t* text = T.pool + (nesc - 1u);
-                            stage_flush_solo(S);
-                            uint8_t* gp = stage_out_ptr(S);
-                            for (uint32_t i = 0; i < nn; ++i) gp[i] = text[i];
-                            stage_begin(S, S.buf, gp + nn);
-                        }
-                    }
-                    if (has) {
-                        skip = nkb;
-                        advance();
-                    }
-                }
-                stage_flush<false>(S);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) c[q] = nx[q];
-    }
-    stage_flush<true>(S);
-    (void)status;
-}
 
 // =============================================================================================
 // Positional-window walk for length-preserving stream tables (window form of
@@ -3176,8 +2796,5 @@ using GeoNft8 = Geometry<256, 16384, 2032>;
 using GeoNft16 = Geometry<256, 16384, 2032>;
 using GeoNft32 = Geometry<256, 8192, 2032>;
 using GeoNft64 = Geometry<256, 8192, 2032>;
-// stream engine: SUB = 132 bytes = 33 dwords per lane (odd), see stream_lane_start
-using GeoStream = Geometry<512, 512 * 132, 2032>;     // in-place: one tile per workgroup, two workgroups per CU
-using GeoStreamGen = Geometry<256, 256 * 132, 2032>;  // count / emit passes (input tile + staging tile)
 
 }  // namespace trre

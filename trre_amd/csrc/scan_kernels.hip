@@ -227,130 +227,6 @@ __global__ __launch_bounds__(G::THREADS) void k_scan_emit(ScanArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Stream engine kernels (tables from stream_build.cpp): no rollback, flat per-lane loops.
-template <class G>
-struct StreamCarve {
-    static constexpr int kTab = (StreamEngine::kLdsBytes + 15) & ~15;
-    static constexpr int off_tin = 0;
-    static constexpr int off_tab = G::TILE_ALLOC;
-    static constexpr int off_red = off_tab + kTab;
-    static constexpr int kBytesOneTile = off_red + 64 + 16 * 8;
-    static constexpr int off_tout = kBytesOneTile;                 // emit pass only
-    static constexpr int kBytesTwoTiles = off_tout + G::TILE_ALLOC;
-};
-
-// length-preserving, in place: the LDS tile is loaded, rewritten by the lanes and copied out
-template <class G, bool kLdsEnt>
-__global__ __launch_bounds__(G::THREADS) void k_stream_lp(ScanArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    using C = StreamCarve<G>;
-    uint8_t* tile = smem + C::off_tin;
-    uint8_t* tab = smem + C::off_tab;
-    int32_t* red = reinterpret_cast<int32_t*>(smem + C::off_red);
-    const int tid = threadIdx.x;
-    const int64_t v0 = (int64_t)blockIdx.x * G::CHUNK - G::PRE;
-
-    StreamEngine::stage(a.blob, tab, tid, G::THREADS);
-    tile_load<G>(a, v0, tile, tid);
-    if (tid == 0) { red[0] = 0x7fffffff; red[1] = -1; }
-    __syncthreads();
-
-    const StreamView T = StreamEngine::view<kLdsEnt>(a.blob, tab);
-    const uint32_t n_cls = reinterpret_cast<const StreamBlobHeader*>(a.blob)->n_cls;
-    int32_t first, last;
-    uint32_t st = 0;
-    stream_lane_lp<G>(a, T, n_cls, v0, tile, tid, first, last, st);
-
-    first = wave_min(first);
-    last = wave_max(last);
-    st = wave_or(st);
-    if ((tid & (kWave - 1)) == 0) {
-        atomicMin(&red[0], first);
-        atomicMax(&red[1], last);
-        if (st) atomicOr(a.status, st);
-    }
-    __syncthreads();
-    tile_store_lp<G>(a, v0, tile, red[0], red[1], tid);
-}
-
-template <class G, bool kLdsEnt>
-__global__ __launch_bounds__(G::THREADS) void k_stream_count(ScanArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    using C = StreamCarve<G>;
-    uint8_t* tin = smem + C::off_tin;
-    uint8_t* tab = smem + C::off_tab;
-    uint64_t* part = reinterpret_cast<uint64_t*>(smem + C::off_red + 64);
-    const int tid = threadIdx.x;
-    const int64_t v0 = (int64_t)blockIdx.x * G::CHUNK - G::PRE;
-
-    StreamEngine::stage(a.blob, tab, tid, G::THREADS);
-    tile_load<G>(a, v0, tin, tid);
-    __syncthreads();
-
-    const StreamView T = StreamEngine::view<kLdsEnt>(a.blob, tab);
-    CountSink sink;
-    uint32_t st = 0;
-    const uint32_t n_cls = reinterpret_cast<const StreamBlobHeader*>(a.blob)->n_cls;
-    stream_lane_gen<G>(a, T, n_cls, v0, tin, tid, sink, st);
-    if (sink.n > 0xffffffffull) { st |= kStCapacity; sink.n = 0xffffffffull; }
-    a.lane_counts[(size_t)blockIdx.x * G::THREADS + tid] = (uint32_t)sink.n;
-    const uint64_t wsum = wave_sum(sink.n);
-    st = wave_or(st);
-    if ((tid & (kWave - 1)) == 0) {
-        part[tid / kWave] = wsum;
-        if (st) atomicOr(a.status, st);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        uint64_t t = 0;
-        for (int w = 0; w < G::THREADS / kWave; ++w) t += part[w];
-        a.chunk_total[blockIdx.x] = t;
-    }
-}
-
-template <class G, bool kLdsEnt>
-__global__ __launch_bounds__(G::THREADS) void k_stream_emit(ScanArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    using C = StreamCarve<G>;
-    uint8_t* tin = smem + C::off_tin;
-    uint8_t* tout = smem + C::off_tout;
-    uint8_t* tab = smem + C::off_tab;
-    uint32_t* wpart = reinterpret_cast<uint32_t*>(smem + C::off_red);
-    const int tid = threadIdx.x;
-    const int64_t v0 = (int64_t)blockIdx.x * G::CHUNK - G::PRE;
-
-    StreamEngine::stage(a.blob, tab, tid, G::THREADS);
-    tile_load<G>(a, v0, tin, tid);
-    const uint32_t mine = a.lane_counts[(size_t)blockIdx.x * G::THREADS + tid];
-    const uint32_t incl = wave_scan_incl(mine);
-    if ((tid & (kWave - 1)) == kWave - 1) wpart[tid / kWave] = incl;
-    __syncthreads();
-    uint32_t wbase = 0;
-    for (int w = 0; w < tid / kWave; ++w) wbase += wpart[w];
-    const uint64_t lane_base = (uint64_t)wbase + incl - mine;
-    const uint64_t total = a.chunk_total[blockIdx.x];
-    const uint64_t gbase = a.chunk_base[blockIdx.x];
-    if (gbase + total > a.cap) {
-        if (tid == 0) atomicOr(a.status, kStCapacity);
-        return;
-    }
-    const int shift = (int)((reinterpret_cast<uintptr_t>(a.out) + gbase) & 15u);
-    const bool staged = (uint64_t)shift + total <= (uint64_t)G::TILE;
-
-    const StreamView T = StreamEngine::view<kLdsEnt>(a.blob, tab);
-    ByteSink sink{staged ? tout + shift + lane_base : a.out + gbase + lane_base};
-    uint32_t st = 0;
-    const uint32_t n_cls = reinterpret_cast<const StreamBlobHeader*>(a.blob)->n_cls;
-    stream_lane_gen<G>(a, T, n_cls, v0, tin, tid, sink, st);
-    st = wave_or(st);
-    if (st && (tid & (kWave - 1)) == 0) atomicOr(a.status, st);
-    if (staged) {
-        __syncthreads();
-        tile_store_seq<G>(a.out + gbase, tout, shift, (int64_t)total, tid);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // Direct stream kernels: no tile, one long sub-range per lane (see stream_direct_lane).
 constexpr int kDirectThreads = 256;
 constexpr int kDirectEntBytes = 2048;      // table rows in LDS when they all fit ...
@@ -742,52 +618,7 @@ __global__ __launch_bounds__(kFbMarkThreads, 4) void k_fb_mark4(ScanArgs a, FbCo
     st = wave_or(st);
     if (st && (threadIdx.x & (kWave - 1)) == 0) atomicOr(a.status, st);
 }
-// Copy pass: no automaton.  kThreads / 256 chunks per workgroup: as many lanes per CU as the rings leave room for (they
-// share the literals).   smem: literals[fb_lits x 16] | rings[kThreads] | 64 x groups | posting tables
-template <int kThreads>
-__global__ __launch_bounds__(kThreads) void k_fb_copy(ScanArgs a, FbCopyArgs ca, int64_t lane_bytes, int64_t n_chunks) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
-    U128* lit = reinterpret_cast<U128*>(smem);
-    {
-        const uint64_t* tx = reinterpret_cast<const uint64_t*>(a.blob + h.off_fb_lit);
-        const uint16_t* m = reinterpret_cast<const uint16_t*>(a.blob + h.off_fb_lit_meta);
-        for (int k = threadIdx.x; k < (int)h.fb_lits; k += kThreads) lit[k] = U128{(uint32_t)tx[k], (uint32_t)(tx[k] >> 32), (uint32_t)m[k], 0u};
-    }
-    constexpr int kGroups = kThreads / kDirectThreads;
-    uint8_t* top = smem + h.fb_lits * 16u;
-    uint8_t* ring = top + threadIdx.x * kRingStride;
-    uint8_t* tail = top + kThreads * kRingStride;
-    const int group = threadIdx.x / kDirectThreads, gtid = threadIdx.x % kDirectThreads;
-    const int64_t chunk = (int64_t)blockIdx.x * kGroups + group;
-    const int64_t lane = chunk * kDirectThreads + gtid;
-    const bool live = chunk < n_chunks;
-    uint32_t* wpart = reinterpret_cast<uint32_t*>(tail + 64 * group);
-    const uint32_t mine = live ? a.lane_counts[lane] : 0u;
-    const uint32_t incl = wave_scan_incl(mine);
-    if ((threadIdx.x & (kWave - 1)) == kWave - 1) wpart[gtid / kWave] = incl;
-    __syncthreads();
-    uint32_t wbase = 0;
-    for (int w = 0; w < gtid / kWave; ++w) wbase += wpart[w];
-    const uint64_t base = live ? a.chunk_base[chunk] + wbase + incl - mine : 0ull;
-    // (bases grow with the chunk index: if the last chunk of this workgroup does not fit, the output is void anyway)
-    const int64_t last = ((int64_t)blockIdx.x + 1) * kGroups - 1 < n_chunks - 1 ? ((int64_t)blockIdx.x + 1) * kGroups - 1 : n_chunks - 1;
-    if (a.chunk_base[last] + a.chunk_total[last] > a.cap) {
-        if (threadIdx.x == 0) atomicOr(a.status, kStCapacity);
-        return;
-    }
-    // a void launch (the mark pass met a NUL, or more events than a lane's row holds: its sizes and the rows disagree):
-    // nothing is written, finish() runs the count / emit pair
-    if (*a.status & (kStEditOverflow | kStNul)) return;
-    FbCopyTables T;
-    T.lit = lit;
-    T.esc = reinterpret_cast<const uint32_t*>(a.blob + h.off_fb_esc);
-    T.pool = a.blob + h.off_fb_pool;
-    uint32_t* wsc = reinterpret_cast<uint32_t*>(tail + 64 * kGroups) + (threadIdx.x / kWave) * (kWaveScratchBytes / 4);
-    uint32_t st = 0;
-    if (live) fb_copy_lane(a, T, ca, lane, lane_bytes, ring, base, st, wsc);
-}
-// The same pass as a wave-cooperative splice (splice_block.hpp): a workgroup takes kThreads / 256 chunks of the workspace (256
+// The second pass — no automaton — as a wave-cooperative splice (splice_block.hpp): a workgroup takes kThreads / 256 chunks of the workspace (256
 // sub-ranges of the mark pass each), the four waves of a chunk take its sub-ranges in turn, a whole wave on each.  The pass
 // is a chain of dependent steps per window (edits -> offsets -> markers -> phase A -> phase B -> store), so it wants waves to
 // switch between: 1024 threads share one copy of the literals, two such workgroups fill a CU's 32 wave slots.
@@ -1134,19 +965,6 @@ void launch_tile_kernel(int which, int engine, int mask_bytes, const ScanArgs& a
     }
 }
 
-template <bool kLdsEnt>
-void launch_stream_t(int which, const ScanArgs& a, int64_t n_chunks, hipStream_t s) {
-    using GL = GeoStream;
-    using GG = GeoStreamGen;
-    allow_big_lds<&k_stream_lp<GL, kLdsEnt>>();
-    allow_big_lds<&k_stream_count<GG, kLdsEnt>>();
-    allow_big_lds<&k_stream_emit<GG, kLdsEnt>>();
-    const dim3 grid((unsigned)n_chunks);
-    if (which == 0) hipLaunchKernelGGL((k_stream_lp<GL, kLdsEnt>), grid, dim3(GL::THREADS), StreamCarve<GL>::kBytesOneTile, s, a);
-    else if (which == 1) hipLaunchKernelGGL((k_stream_count<GG, kLdsEnt>), grid, dim3(GG::THREADS), StreamCarve<GG>::kBytesOneTile, s, a);
-    else hipLaunchKernelGGL((k_stream_emit<GG, kLdsEnt>), grid, dim3(GG::THREADS), StreamCarve<GG>::kBytesTwoTiles, s, a);
-}
-
 // ---- positional-window kernel for length-preserving stream tables in window form, wave-tiled I/O (see scan_block.hpp)
 constexpr int kWtThreads = 256;
 constexpr int kWtWaves = kWtThreads / kWave;
@@ -1486,13 +1304,12 @@ __global__ __launch_bounds__(kOneThreads, 3) void k_stream_one(ScanArgs a, OneAr
     uint32_t* exits = offs + kOneThreads + 4;
     uint32_t* misc = exits + kOneThreads;                 // [0..3] the waves' totals, [4] the tile, [5] void seen, [6..7] the tile's base
     uint8_t* marks = reinterpret_cast<uint8_t*>(misc + 16);
-    OneTile tv{regions, offs, marks, R};
     // (the backward pass of a guided family guessed wrong somewhere: its symbols are not final, finish() repairs them and runs the pair)
     if (kSym != 0 && __hip_atomic_load(a.status + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
         if (tid == 0 && blockIdx.x == 0) atomicOr(a.status, kStOneVoid);
         return;
     }
-    const int wave = tid / kWave, lid = tid & (kWave - 1);
+    const int lid = tid & (kWave - 1);
     uint32_t st_all = 0;
     const bool prof = oa.prof != nullptr && tid == 0;
     auto stamp = [&](uint64_t& t, int slot) {
@@ -1766,24 +1583,6 @@ void launch_fb_mark(const ScanArgs& a, const FbCopyArgs& ca, const void* hdr, in
     hipLaunchKernelGGL(k_fb_mark, dim3((unsigned)((n_chunks + kG - 1) / kG)), dim3(kFbMarkThreads), lds, static_cast<hipStream_t>(stream), a, ca, lane_bytes, n_chunks);
 }
 // workgroup size of the copy pass: the largest whose rings fit next to the literals
-int fb_copy_lds(const StreamBlobHeader& h, int threads) {
-    return (int)h.fb_lits * 16 + threads * kRingStride + 64 * (threads / kDirectThreads) + (threads / kWave) * kWaveScratchBytes;
-}
-void launch_fb_copy(const ScanArgs& a, const FbCopyArgs& ca, const void* hdr, int64_t lane_bytes, int64_t n_chunks, void* stream) {
-    const StreamBlobHeader& h = *static_cast<const StreamBlobHeader*>(hdr);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    constexpr int want = 1024;
-    if (want >= 1024 && fb_copy_lds(h, 1024) <= kLdsLimit) {
-        allow_big_lds<&k_fb_copy<1024>>();
-        hipLaunchKernelGGL(k_fb_copy<1024>, dim3((unsigned)((n_chunks + 3) / 4)), dim3(1024), fb_copy_lds(h, 1024), s, a, ca, lane_bytes, n_chunks);
-    } else if (want >= 512 && fb_copy_lds(h, 512) <= kLdsLimit) {
-        allow_big_lds<&k_fb_copy<512>>();
-        hipLaunchKernelGGL(k_fb_copy<512>, dim3((unsigned)((n_chunks + 1) / 2)), dim3(512), fb_copy_lds(h, 512), s, a, ca, lane_bytes, n_chunks);
-    } else {
-        allow_big_lds<&k_fb_copy<256>>();
-        hipLaunchKernelGGL(k_fb_copy<256>, dim3((unsigned)n_chunks), dim3(256), fb_copy_lds(h, 256), s, a, ca, lane_bytes, n_chunks);
-    }
-}
 int fb_splice_lds(const StreamBlobHeader& h, int threads, bool lit_lds) {
     return (lit_lds ? (int)h.fb_lits * 16 : 0) + threads * 8 + 64 * (threads / kDirectThreads) + (threads / kWave) * (int)kSpLdsPerWave;
 }
@@ -1843,16 +1642,7 @@ bool fb_copy_fits(const void* hdr) {
     const StreamBlobHeader& h = *static_cast<const StreamBlobHeader*>(hdr);
     if (!h.off_fb_lit_meta) return false;
     const int mark = 256 + (int)((h.fb_slots * 8u + 15u) & ~15u) + (int)((h.fb_lits * 2u + 15u) & ~15u) + kFbMarkThreads * kMarkStageStride * 4 + 256;
-    return mark <= kLdsLimit && fb_copy_lds(h, 256) <= kLdsLimit;
-}
-
-int stream_chunk_bytes(int which) { return which == 0 ? GeoStream::CHUNK : GeoStreamGen::CHUNK; }
-int stream_block_threads(int which) { return which == 0 ? GeoStream::THREADS : GeoStreamGen::THREADS; }
-
-void launch_stream_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t n_chunks, void* stream) {
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (ent_in_lds) launch_stream_t<true>(which, a, n_chunks, s);
-    else launch_stream_t<false>(which, a, n_chunks, s);
+    return mark <= kLdsLimit;
 }
 
 constexpr int kFbCountThreads = 1024, kFbEmitThreads = 512;
