@@ -92,7 +92,7 @@ def pmc_traffic(kernel_name, nbytes):
 # tools/pmc_dict4.sh (1 GiB runs; FETCH_SIZE doubled as for the headline — round 5's calibration, tools/probes/fetch_calib.hip, found the
 # factor 2 right for every access pattern the kernels use): summed over the kernels of one scan.  Measured
 # under rocprofv3 in separate passes, NOT in this run — labelled as such in the record.
-CONFIG_PMC = {"cfg4": "cfg4_nft", "cfg4_guided": "cfg4_nft_guided", "cfg5_dft": "dict1000_dft", "cfg5_nft": "dict1000_dft", "expand": "expand_dft",
+CONFIG_PMC = {"expand_one": "expand_one", "cfg4": "cfg4_nft", "cfg4_guided": "cfg4_nft_guided", "cfg5_dft": "dict1000_dft", "cfg5_nft": "dict1000_dft", "expand": "expand_dft",
               "nft_loop": "nft_loop_guided", "dft_loop": "dft_loop_guided", "tile_fallback": "tile_dft"}
 
 
@@ -491,6 +491,39 @@ def emit(line):
     print(compact_line(line), flush=True)
 
 
+def one_walk_record(n):
+    """'a:xyz' through the one-walk form (TRRE_ONE=1) in a child process: its rate (HIP events of the batch), its output's checksum against
+    the count / emit pair's (a second child), the committed PMC passes of this round for its traffic."""
+    import re
+
+    def child(env):
+        e = dict(os.environ)
+        e.pop("TRRE_ONE", None)
+        e.update(env)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kbench.py"), "--bytes", str(n), "--steps", "10", "--sum", "--case",
+                            "a:xyz;;dft;;printable;;auto"], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        m = re.search(r"out=(\d+)\s+([0-9.]+) ms/step.*\(events ([0-9.]+) ms\)\s+sum=([0-9a-f]+)", r.stdout.decode())
+        if r.returncode or not m:
+            raise RuntimeError("kbench failed: " + r.stderr.decode()[-300:])
+        return int(m.group(1)), float(m.group(2)), float(m.group(3)), m.group(4), r.stderr.decode()
+    m1, ms1, ev1, sum1, err1 = child({"TRRE_ONE": "1", "TRRE_TRACE": "1"})
+    m0, ms0, ev0, sum0, _ = child({})
+    void = "one-pass launch" in err1 and "void" in err1
+    rec = {"name": "expand_one", "pattern": "a:xyz", "engine": "dft", "bytes": n, "output_bytes": m1, "kernel_family": "stream_gen",
+           "kernels": "k_stream_one (TRRE_ONE=1: one walk, the workgroup's output staged in LDS, look-back for its place)",
+           "workload": "general path in ONE walk (row f2, opt-in): 'a:xyz' DFT, %.0f GiB, a child process with TRRE_ONE=1; beside it the count / emit pair in "
+                       "a child without the switch: %.3f ms (%.1f GB/s)" % (n / 2**30, ev0, n / (ev0 * 1e-3) / 1e9),
+           "steps": 10, "ms_per_step": ms1, "kernel_ms": ev1, "input_GBps": round(n / (ms1 * 1e-3) / 1e9, 1), "achieved_GBps": round(n / (ev1 * 1e-3) / 1e9, 1),
+           "frac": round(n / (ev1 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "pair_kernel_ms": ev0,
+           "verified": bool(m1 == m0 and sum1 == sum0 and not void),
+           "verify": "output size and a position-weighted checksum of every output byte equal the pair's; no void launch in the trace"}
+    tr = config_traffic("expand_one")
+    if tr:
+        tr["x_algorithmic"] = round(tr["hbm_bytes_per_GiB_of_input"] / ((1 << 30) * (1.0 + m1 / float(n))), 2)
+        rec["traffic"] = tr
+    return rec
+
+
 class StubProgram:
     """TRRE_BENCH_STUB=1 (tests/test_bench_spawn.py, no GPU): stands in for trre_amd.Program so that the launch, barrier,
     timing and reduction plumbing of the N-rank path runs on CPU over gloo.  It scans nothing; the line it yields says
@@ -865,6 +898,12 @@ def main():
         del one_gib
         for spec in printable:
             configs.append(run_config(trre_amd, spec, inp, out, tmp, want_cpu))
+        # the general family in ONE walk (round 6, row f2: one_block.hpp — opt-in, TRRE_ONE=1, read once per process: a child of tools/kbench.py
+        # with the switch, a second one without it for the checksum of the pair's output)
+        try:
+            configs.append(one_walk_record(n))
+        except Exception as e:      # (the headline must not depend on it)
+            configs.append({"name": "expand_one", "verified": False, "verify": "failed: %r" % (e,)})
         nt = min(n, 1 << 30)
         # long lines (round 5: exact sub-ranges): the same text with one line end left per 400 KB — JSON lines, minified files
         try:

@@ -50,6 +50,10 @@ def test_engine_limits_are_errors_not_fallbacks():
     # more than 16 384 backward states with more than 64 nodes: round 3 refused it, the backtracking fallback runs it
     p = trre_amd.Program("a(a|b|c|d|e|f|g|h){12}c:x", "nft")
     assert p.info.kernel == trre_amd.KERNEL_BACKTRACK and p.allowed_kernels() == [trre_amd.KERNEL_BACKTRACK]
+    # the same pattern on the DFT engine — 99 determinised states, no fold, beyond the guided tables: rounds 1-5 ran it on the tile kernels
+    # (48 GB/s), round 6 on the lazily determinised family (twice that); the tile kernels stay selectable
+    p = trre_amd.Program("a(a|b|c|d|e|f|g|h){12}c:x", "dft")
+    assert p.info.kernel == trre_amd.KERNEL_DFT_LAZY and trre_amd.KERNEL_TILE_GEN in p.allowed_kernels()
     p = trre_amd.Program("a(a|b|c){9}c:x", "nft")            # 29 nodes: the bitmask tile kernels could run it, the wide tables are
     assert p.info.kernel == trre_amd.KERNEL_GUIDED_GEN and p.info.guided_rev_states > 256 and trre_amd.KERNEL_TILE_GEN in p.allowed_kernels()   # 2x faster
     # an epsilon cycle is not a compile error: like the reference's lazy tables, the scan fails (TRRE_E_DIVERGES) only

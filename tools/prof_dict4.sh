@@ -1,4 +1,4 @@
-# round 4: kernel stats of the dictionary configuration, with the splice and with the older copy pass
+# kernel stats of the dictionary configuration (mark + splice; round 4 also ran round 3's copy pass beside it: removed in round 6)
 cd /tmp && export TMPDIR=/tmp
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 out=gpurun_out/profiles; mkdir -p $out gpurun_out/raw
@@ -9,5 +9,4 @@ run() { # name, env
   cat $out/${tag}_dict1000_dft_$1_kernel_stats.txt | cut -c1-150
 }
 run splice A=1
-run copy TRRE_NO_FB_SPLICE=1
 rm -rf gpurun_out/raw

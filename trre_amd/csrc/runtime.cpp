@@ -477,6 +477,7 @@ int general_family(const trre_prog& p, bool stream_ok) {
     if (p.lazy_only) return TRRE_KERNEL_DFT_LAZY;
     if (stream_ok && p.stt.ok) return TRRE_KERNEL_STREAM_GEN;
     if (p.gt.ok) return TRRE_KERNEL_GUIDED_GEN;
+    if (p.engine == TRRE_ENGINE_DFT && p.mode == TRRE_MODE_SCAN) return TRRE_KERNEL_DFT_LAZY;      // (round 6: 100 GB/s against the tile kernels' 48)
     return p.has_engine_tables ? TRRE_KERNEL_TILE_GEN : TRRE_KERNEL_BACKTRACK;
 }
 
@@ -498,6 +499,11 @@ int auto_family(const trre_prog& p) {
     if (p.gt.ok) return lp_inplace(p.gt.fwd.flags) && !p.gt.wide ? TRRE_KERNEL_GUIDED_LP : TRRE_KERNEL_GUIDED_GEN;
     if (p.mode == TRRE_MODE_MATCH) return TRRE_KERNEL_BACKTRACK;
     if (p.engine == TRRE_ENGINE_DFT) {
+        // A DFT pattern without a fold and beyond the guided tables (a reduced backward automaton of more than 16 384 states, or one that its
+        // construction's budget does not reach).  Rounds 1-5: the tile kernels, 48 GB/s; round 6: the lazily determinised family, which runs any
+        // DFT scan at twice that once its tables have grown — a first scan that needs more than kLazyAutoRounds rounds of
+        // growing hands the buffer to the tile kernels (finish_inner) and the tables keep what they learnt.
+        if (p.mode == TRRE_MODE_SCAN) return TRRE_KERNEL_DFT_LAZY;
         if ((p.dt.flags & kFlagLengthPreserving) && (p.dt.flags & kFlagNoOverrun)) return TRRE_KERNEL_TILE_LP;
         return TRRE_KERNEL_TILE_GEN;
     }
@@ -1332,6 +1338,14 @@ int finish_inner(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
                 return fail(TRRE_E_TOO_BIG, "error: out of memory while determinising");
             }
             if (lazy_trace) fprintf(stderr, "trre: lazy round %d: %u misses, %u rows, %u states\n", round, n_miss, p->lazy->n_rows(), p->lazy->n_states());
+            // the automatic choice for a pattern that also has its eager tables: a scan that is still growing the lazy ones after kLazyAutoRounds
+            // goes to the tile kernels (the next scan finds the tables that much further)
+            constexpr int kLazyAutoRounds = 64;
+            if (round >= kLazyAutoRounds && !p->forced_family && !p->lazy_only && p->has_engine_tables) {
+                cx->relaunches += 1;
+                const int rc = enqueue(p, st, cx, TRRE_KERNEL_TILE_GEN, was.d_in, was.n, was.d_out, was.cap, was.stream);
+                return rc ? rc : finish_inner(p, st, cx, out_len);
+            }
             if (spec < (1u << 16)) spec *= 2;                      // (the deeper the input digs, the further ahead the host looks)
             HIP_TRY(hipMemsetAsync(cx->d_status, 0, 8, was.stream));
             cx->relaunches += 1;
