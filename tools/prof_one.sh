@@ -15,8 +15,8 @@ run() {   # name, suffix, rocprof args..., -- case
     timeout 300 rocprofv3 "${args[@]}" -d gpurun_out/raw/q_$name -o p -- python tools/kbench.py --case "$1" --steps ${STEPS:-2} > gpurun_out/raw/q_$name.log 2>&1
     { echo "# TRRE_ONE=${TRRE_ONE:-1} kbench --case '$1' --steps ${STEPS:-2}   (rocprofv3 ${args[*]})"; python tools/rocpd_summary.py gpurun_out/raw/q_$name/p_results.db trre 2>&1 | tail -n 40; grep '^pattern' gpurun_out/raw/q_$name.log; } > $out/${tag}_${name}_$suf.txt
 }
-for c in "expand_one|a:xyz;;dft;;printable;;auto" ${ONLY_EXPAND:+} ; do
-    n=${c%%|*}; k=${c#*|}
+for c in "expand_one|1|a:xyz;;dft;;printable;;auto" "expand_pair|0|a:xyz;;dft;;printable;;auto"; do
+    n=${c%%|*}; k=${c#*|}; export TRRE_ONE=${k%%|*}; k=${k#*|}
     STEPS=5 run $n kernel_stats --kernel-trace --stats -- "$k"
     run $n pmc_FETCH_SIZE --pmc FETCH_SIZE -- "$k"
     run $n pmc_WRITE_SIZE --pmc WRITE_SIZE -- "$k"
@@ -25,4 +25,4 @@ for c in "expand_one|a:xyz;;dft;;printable;;auto" ${ONLY_EXPAND:+} ; do
     run $n pmc_sq_3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU -- "$k"
 done
 rm -rf gpurun_out/raw
-for f in $out/${tag}_expand_one_*; do echo "== $f"; cut -c1-86,96-150 $f | grep -v "^$" | head -30; done
+for f in $out/${tag}_expand_one_* $out/${tag}_expand_pair_pmc_sq_2*; do echo "== $f"; cut -c1-86,96-150 $f | grep -v "^$" | head -30; done
