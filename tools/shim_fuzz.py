@@ -82,6 +82,11 @@ def main():
                 fams = fams + [shim_lib.BACKTRACK]         # (round 4: the backtracking fallback runs any NFT pattern)
             if eng == "dft" and trre_amd.KERNEL_DFT_LAZY in p.allowed_kernels() and shim_lib.DFT_LAZY not in fams:
                 fams = fams + [shim_lib.DFT_LAZY]          # (round 5: the lazily determinised family runs any DFT scan pattern)
+            # (round 6: the general families in ONE walk, one_block.hpp — the production geometry, tiny tiles with look-backs of 4 bytes, tight regions)
+            if p.info.stream_states and shim_lib.has_g16(p.export_stream_tables()) and trre_amd.KERNEL_STREAM_GEN in p.allowed_kernels():
+                fams = fams + [shim_lib.STREAM_ONE, shim_lib.STREAM_ONE_MISS, shim_lib.STREAM_ONE_TIGHT]
+            if p.info.guided_rev_states and p.info.guided_rev_states <= 256 and trre_amd.KERNEL_GUIDED_GEN in p.allowed_kernels() and shim_lib.has_g16(p.export_guided_tables()[1]):
+                fams = fams + [shim_lib.GUIDED_ONE, shim_lib.GUIDED_ONE_MISS]
             for fam in fams:
                 for geo in (1, 0):
                     try:
