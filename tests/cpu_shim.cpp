@@ -19,6 +19,7 @@
 #include "../trre_amd/csrc/gen_block.hpp"
 #include "../trre_amd/csrc/lazy_block.hpp"
 #include "../trre_amd/csrc/one_block.hpp"
+#include "../trre_amd/csrc/map_block.hpp"
 #include "../trre_amd/csrc/guard_block.hpp"
 
 using namespace trre;
@@ -358,6 +359,71 @@ void run_direct_gen_one(ScanArgs a, uint32_t S, uint32_t R, uint32_t look, int n
     total_out = base;
 }
 
+// A memoryless program in one pass (round 6; map_block.hpp) as k_mapgen runs it: tiles of nw waves x 8 rows x nl lanes x 8 bytes; per tile the
+// lengths, the prefix sums in (wave, row, lane) order, the tile's place (the running sum: what the look-back finds), the bytes' texts into a
+// window of `window` bytes — as many windows as the tile's output needs —, the window out line by line.  Interior tiles whose output fits the
+// window take the kernel's fast bodies (<kEdge = false, kClip = false>), the others the clipped ones.  kStNul: a NUL — the launch would be void.
+template <bool kFirst, bool kMulti>
+void run_mapgen_t(const ScanArgs& a, const MapGenView& T, uint32_t& status, uint64_t& total_out, uint32_t window, int nw, int nl) {
+    const int64_t row_bytes = (int64_t)nl * kMgLaneBytes, wave_bytes = row_bytes * kMgRows, tile_bytes = wave_bytes * nw;
+    const int64_t n_tiles = (a.vend + tile_bytes - 1) / tile_bytes;
+    std::vector<uint8_t> win_raw(window + 64 + 8);
+    uint8_t* win = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(win_raw.data()) + 15) & ~(uintptr_t)15);
+    const uint32_t sink = window + 40;               // (one for all: the lanes run one after the other here)
+    const int lanes = nw * kMgRows * nl;
+    std::vector<uint32_t> cnt(lanes), off(lanes), dlo(lanes), dhi(lanes);
+    const int64_t vl = (a.vend + 15) & ~(int64_t)15;
+    uint64_t base = 0;
+    for (int64_t tile = 0; tile < n_tiles; ++tile) {
+        const int64_t t0 = tile * tile_bytes;
+        const bool edge = t0 < a.vbeg || t0 + tile_bytes > a.vend - 1;
+        uint32_t total = 0, orsum = 0;
+        for (int i = 0; i < lanes; ++i) {                // (wave, row, lane): the order of the input
+            const int64_t v = t0 + (int64_t)i * kMgLaneBytes;
+            uint32_t lo = 0, hi = 0;
+            if (v < vl) { std::memcpy(&lo, a.in_v0 + v, 4); std::memcpy(&hi, a.in_v0 + v + 4, 4); }
+            dlo[i] = lo; dhi[i] = hi;
+            const uint32_t n = edge ? mg_count8<true>(T, lo, hi, mg_edge(v, a.vbeg, a.vend)) : mg_count8<false>(T, lo, hi, MgEdge{});
+            orsum |= n;
+            cnt[i] = n; off[i] = total; total += n;
+        }
+        if (orsum >= kMgNul) { status |= kStNul; continue; }      // (the kernel: nothing expanded, nothing stored; the launch is void)
+        const bool write = base + total <= a.cap;
+        if (!write) status |= kStCapacity;
+        for (uint32_t wlo = 0; wlo < total; wlo += window) {
+            const uint32_t whi = wlo + window < total ? wlo + window : total;
+            const uint32_t hh = (uint32_t)((reinterpret_cast<uintptr_t>(a.out) + base + wlo) & 15u);
+            std::fill(win_raw.begin(), win_raw.end(), 0xCD);
+            for (int i = lanes - 1; i >= 0; --i) {       // (lanes in another order than the positions': nobody may lean on its neighbour's stores)
+                const int64_t v = t0 + (int64_t)i * kMgLaneBytes;
+                uint32_t end;
+                if (total <= window && !edge) end = mg_expand8<kFirst, kMulti, false, false>(T, dlo[i], dhi[i], MgEdge{}, win, sink, off[i], 0u, 0u);
+                else end = mg_expand8<kFirst, kMulti, true, true>(T, dlo[i], dhi[i], mg_edge(v, a.vbeg, a.vend), win, sink, off[i], wlo, whi - wlo);
+                if (end != off[i] + cnt[i]) status |= 1u << 30;          // count and expand disagree
+            }
+            const uint32_t n_lines = (hh + (whi - wlo) + 15u) >> 4;
+            for (uint32_t c = 0; c < n_lines; ++c) mg_store_line(win, a.out, base, wlo, whi - wlo, hh, c, write);
+        }
+        base += total;
+    }
+    total_out = base;
+}
+void run_mapgen(const ScanArgs& a, uint32_t& status, uint64_t& total_out, uint32_t window, int nw, int nl) {
+    const StreamBlobHeader& h = *reinterpret_cast<const StreamBlobHeader*>(a.blob);
+    const uint32_t* mg = reinterpret_cast<const uint32_t*>(a.blob + h.off_mg);
+    std::vector<uint8_t> len(256), first(256);
+    std::vector<uint64_t> text(256);
+    bool first_lookup = false;
+    for (int k = 0; k < 256; ++k) {
+        len[k] = (uint8_t)mg[4 * k + 2]; first[k] = (uint8_t)mg[4 * k]; text[k] = (uint64_t)mg[4 * k + 1] << 32 | mg[4 * k];
+        if ((len[k] & 15u) == 1u && first[k] != k) first_lookup = true;        // (runtime.cpp: MapGenArgs::first_lookup)
+    }
+    const MapGenView T{len.data(), first.data(), text.data()};
+    const bool multi = h.mg_max > 1;
+    if (first_lookup) multi ? run_mapgen_t<true, true>(a, T, status, total_out, window, nw, nl) : run_mapgen_t<true, false>(a, T, status, total_out, window, nw, nl);
+    else multi ? run_mapgen_t<false, true>(a, T, status, total_out, window, nw, nl) : run_mapgen_t<false, false>(a, T, status, total_out, window, nw, nl);
+}
+
 
 // large tables in their fallback form (k_stream_fb): count, scan, emit — lane by lane
 FbView fb_view(const ScanArgs& a) {
@@ -606,7 +672,7 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
     a.gscratch = want_scratch ? scratch.data() : nullptr;
     uint32_t status = 0;
     uint64_t total = 0;
-    if (family != 3 && family != 7 && family != 9 && family != 22 && family != 23 && family != 24 && family != 34 && family != 35 && family != 36 && cap < n) return -9;
+    if (family != 3 && family != 7 && family != 9 && family != 22 && family != 23 && family != 24 && family != 34 && family != 35 && family != 36 && family != 37 && family != 38 && cap < n) return -9;
     if (family == 1) { run_bytemap(a, status); total = n; }
     else if (family == 8) {
         if (reinterpret_cast<const StreamBlobHeader*>(blob)->lpw_bytes == 0) return -5;
@@ -640,6 +706,11 @@ int shim_scan(const uint8_t* blob, int engine, int mask_bytes, int family, int g
         int rounds = 0;
         run_direct_gen_exact<>(a, geo == 0 ? 2048 : 64, status, total, family == 33 ? 4u : (uint32_t)kSpecLook, geo == 0 ? 256 : 3, rounds);
         g_last_rounds = rounds;
+    }
+    else if (family == 37 || family == 38) {          // a memoryless program in one pass (map_block.hpp); 38: tiles of 3 threads, windows of 48 bytes
+        if (reinterpret_cast<const StreamBlobHeader*>(blob)->mg_max == 0) return -5;
+        if (family == 37) run_mapgen(a, status, total, geo == 0 ? 40960u : 256u, geo == 0 ? kMapGenThreads / kMgLanes : 2, geo == 0 ? kMgLanes : 3);
+        else run_mapgen(a, status, total, 48u, 1, 1);
     }
     else if (family == 34 || family == 35 || family == 36) {   // ... in ONE walk (one_block.hpp); 35: a look-back of 4 bytes and tiles of 3 lanes (wrong guesses: repair
         if (reinterpret_cast<const StreamBlobHeader*>(blob)->g16_bytes == 0) return -5;     // rounds, void tiles); 36: regions of 76 bytes for 64 of input

@@ -13,7 +13,7 @@ ST_NUL, ST_DIVERGE, ST_CAPACITY, ST_LONGLINE, ST_NEEDSCRATCH, ST_OVERFLOW, ST_MI
 
 
 def build():
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("scan_block.hpp", "scan_core.hpp", "device_blob.hpp", "splice_block.hpp", "gen_block.hpp", "lazy_block.hpp", "guard_block.hpp")]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("scan_block.hpp", "scan_core.hpp", "device_blob.hpp", "splice_block.hpp", "gen_block.hpp", "lazy_block.hpp", "guard_block.hpp", "one_block.hpp", "map_block.hpp")]
     if os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(d) for d in deps):
         return SO
     os.makedirs(os.path.dirname(SO), exist_ok=True)
@@ -60,7 +60,7 @@ def shim_scan(blob, engine, family, data, geo=1, in_mis=0, out_mis=0, scratch=Tr
     """Run one kernel family of the device code on the host.  Returns (output bytes, status)."""
     auto_cap = cap is None
     if cap is None:
-        cap = len(data) * 8 + 64 if family in (3, 7, 9, 22, 23, 27, 29, 32, 33, 34, 35, 36) else len(data)     # (20, 21: length-preserving)
+        cap = len(data) * 8 + 64 if family in (3, 7, 9, 22, 23, 27, 29, 32, 33, 34, 35, 36, 37, 38) else len(data)     # (20, 21: length-preserving)
     for _ in range(2):
         out = ctypes.create_string_buffer(max(cap, 1))
         m = ctypes.c_size_t()
@@ -85,6 +85,12 @@ def has_g16(stream_blob):
 
 def _g16_bytes(blob):
     return struct.unpack_from("<I", blob, 60)[0]          # (device_blob.hpp: the 16th word of StreamBlobHeader)
+
+
+def has_mapgen(prog):
+    """the stream tables carry the memoryless form (StreamBlobHeader::mg_max: the longest text; 0: none)"""
+    blob = prog.export_stream_tables()
+    return bool(blob) and len(blob) >= 192 and struct.unpack_from("<48I", blob, 0)[46] != 0
 
 
 def has_fallback_form(prog):
@@ -118,6 +124,9 @@ STREAM_G16_EXACT, STREAM_G16_EXACT_MISS = 32, 33     # stream general family, th
 # of 3 lanes (wrong guesses: repair rounds inside a tile, void launches across tiles); _TIGHT: regions of 76 bytes for 64 of input (outgrown regions)
 STREAM_ONE, STREAM_ONE_MISS, STREAM_ONE_TIGHT = 34, 35, 36
 GUIDED_ONE, GUIDED_ONE_MISS = 40, 41
+# memoryless programs of any output length in one pass (round 6, map_block.hpp): the production geometry (geo 0: 8 waves of 64 lanes, a window of
+# 40 KiB; geo 1: 2 waves of 3 lanes, 256 bytes); _TINY: tiles of one lane (64 bytes), windows of 48 bytes (several windows per tile)
+STREAM_MAPGEN, STREAM_MAPGEN_TINY = 37, 38
 ST_ONE_VOID = 256
 one_stats = {"runs": 0, "void": 0}                  # how often the one-pass form answered / left the buffer to the pair
 GUIDED_LP_ALL = (GUIDED_LP, GUIDED_LP_RING, GUIDED_LP8)
@@ -223,7 +232,14 @@ def scan_like_runtime(prog, data, geo=1, family=None, in_mis=0, out_mis=0):
         if st & ST_DIVERGE:
             raise RuntimeError("diverges")
         return out
-    blob = prog.export_stream_tables() if fam in (6, 7, 8, 9, 20, 21, 22, 23, 27, 29, 32, 33, 34, 35, 36, STREAM_LPW_PAIR) else prog.export_tables()
+    blob = prog.export_stream_tables() if fam in (6, 7, 8, 9, 20, 21, 22, 23, 27, 29, 32, 33, 34, 35, 36, 37, 38, STREAM_LPW_PAIR) else prog.export_tables()
+    if fam in (STREAM_MAPGEN, STREAM_MAPGEN_TINY):
+        out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
+        assert out is not None, "the tables have no memoryless form"
+        assert not st & ST_MISMATCH, "count and expand disagree"
+        if not st & ST_NUL:
+            return out
+        fam = 7                             # like finish(): a NUL voids the launch, the general small-table family takes the buffer
     if fam in (STREAM_ONE, STREAM_ONE_MISS, STREAM_ONE_TIGHT):
         out, st = shim_scan(blob, info.engine, fam, data, geo, in_mis, out_mis)
         one_stats["runs"] += 1

@@ -662,6 +662,44 @@ def test_one_walk_on_every_golden_vector():
     assert shim_lib.one_stats == {"runs": 3, "void": 0}, shim_lib.one_stats
 
 
+def test_memoryless_programs_in_one_pass():
+    """round 6 (map_block.hpp): a program whose folded scan loop never leaves the root state — every attempt decided by one byte — has no
+    state to carry: lengths, a prefix sum, the bytes' texts at their places.  Every golden vector of such a program (58 of them, both
+    engines: 'a:xyz', '[aie]:', ':x', '.', the byte maps, the DFT engine's one-byte decisions like ' +: ') through the kernel's bodies on the
+    host — the production tile and window, tiles of 3 threads with windows of 48 bytes (several windows per tile) —, texts of up to 8
+    bytes, inputs with NULs (the launch is void: the general family answers), no final newline, every alignment; and what is NOT one."""
+    n = 0
+    progs = set()
+    for k, (pat, name, data, eng, exp) in enumerate(golden_lib.cases()):
+        if exp is None:
+            continue
+        p = prog(pat, eng)
+        if not (p.info.stream_states and shim_lib.has_mapgen(p)):
+            continue
+        progs.add((pat, eng))
+        for fam in (shim_lib.STREAM_MAPGEN, shim_lib.STREAM_MAPGEN_TINY):
+            for geo, mis, omis in ((1, 0, 0), (0, 7, 5)):
+                assert shim_lib.scan_like_runtime(p, data, geo=geo, family=fam, in_mis=mis, out_mis=omis) == exp, (pat, name, eng, fam, geo)
+                n += 1
+    assert n > 1500 and len(progs) >= 50, (n, len(progs))
+    rng = random.Random(77)
+    text = b"".join(bytes(rng.choice(b"the <quick> & brown fox; aeiou \xe9\xff") for _ in range(rng.randint(0, 200))) + b"\n" for _ in range(300))
+    for pat, eng in [("a:xyz", "dft"), ("a:xyz", "nft"), ("[aie]:", "nft"), ("(<:&lt;|>:&gt;|&:&amp;)", "dft"), ("(<:&lt;|>:&gt;|&:&amp;)", "nft"), (".:xy", "dft"),
+                     (":x", "nft"), ("e:12345678", "dft"), ("(a:xyz|e:)|.:uv", "dft"), ("[a-z]:", "nft")]:
+        p = prog(pat, eng)
+        assert shim_lib.has_mapgen(p), (pat, eng)
+        o = Oracle(pat, eng)
+        for data in (text, text + b"tail without newline", text[:5000] + b"nul\0in a line\n" + text[5000:], b"", b"a", b"\n", b"aaa\n" * 40000):
+            want = o.scan(data)
+            for fam in (shim_lib.STREAM_MAPGEN, shim_lib.STREAM_MAPGEN_TINY):
+                for geo in (0, 1):
+                    for omis in (0, 1, 15):
+                        assert shim_lib.scan_like_runtime(p, data, geo=geo, family=fam, in_mis=3, out_mis=omis) == want, (pat, eng, fam, geo, omis, len(data))
+    # not memoryless: a key of two bytes, a text of nine, a loop before the decision (NFT)
+    for pat, eng in [("ab:x", "dft"), ("e:123456789", "dft"), ("a*b:x", "nft"), ("(cat:dog|dog:cat)", "nft")]:
+        assert not shim_lib.has_mapgen(prog(pat, eng)), (pat, eng)
+
+
 def test_more_than_eight_output_bytes_per_input_byte():
     """a pattern whose epsilon loops print a dozen bytes around every input byte (found by tools/shim_fuzz.py, seed 503, round 5 — the
     kernels were right, the harness's output buffer of 8 x the input was not): the count pass reports the size, the caller comes back

@@ -167,3 +167,65 @@ def test_dft_patterns_beyond_the_guided_tables_run_lazily():
     assert p.scan(data) == want
     p.set_kernel(trre_amd.KERNEL_TILE_GEN)
     assert p.scan_tensor(t).cpu().numpy().tobytes() == want
+
+
+MAPGEN_SCRIPT = r'''
+import hashlib, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch, trre_amd, corpora
+dev = torch.device("cuda", 0)
+res = {}
+inp = corpora.printable_lines(256 << 20, corpora.SEED0 + 2, dev)
+out = torch.empty(inp.numel() * 3 + 4096, dtype=torch.uint8, device=dev)
+for pat, eng in [("a:xyz", "dft"), ("a:xyz", "nft"), ("[aie]:", "nft"), ("(a:xyz|e:)|.:uv", "dft"), ("(<:&lt;|>:&gt;|&:&amp;)", "nft"), ("[a-z]:", "dft"), (":x", "nft"), ("e:12345678", "dft")]:
+    p = trre_amd.Program(pat, eng)
+    for off, size in ((0, inp.numel()), (7, (64 << 20) + 12345), (0, 1), (3, 70000)):
+        view = inp[off:off + size]
+        for rep in range(2):
+            p.enqueue(view, out[off:]); m = p.finish()
+        res[(pat, eng, off, size)] = (m, hashlib.md5(out[off:off + m].cpu().numpy().tobytes()).hexdigest())
+# a NUL (the launch is void: the general family answers), a capacity one byte short
+p = trre_amd.Program("a:xyz", "dft")
+nul = inp[:8 << 20].clone()
+nul[5 << 20] = 0
+res["nul"] = hashlib.md5(p.scan_tensor(nul).cpu().numpy().tobytes()).hexdigest()
+tail = inp[:(1 << 20) + 37]
+m_full = p.scan_tensor(tail).numel()
+small = torch.empty(m_full - 1, dtype=torch.uint8, device=dev)
+try:
+    p.enqueue(tail, small); p.finish()
+    res["capacity"] = "no error"
+except trre_amd.TrreError as e:
+    res["capacity"] = e.code
+print(repr(res))
+'''
+
+
+def test_memoryless_programs_in_one_pass_on_gpu():
+    """map_block.hpp on the device (k_mapgen, opt-in: TRRE_MAPGEN=1 — lengths, prefix sum with look-back, the texts at their places, one
+    read and one write): eight memoryless programs on 256 MiB, 64 MiB unaligned, one byte and 70 000 bytes, each twice (the descriptors of
+    the launch before are gone), a NUL in the input, a buffer one byte short — byte for byte what the count / emit pair prints (a process
+    of its own without the switch); heads against the oracle.  (Round 6 met, here, one tile in 6 000 counted twice: the compiler had left
+    the s_barrier at a loop's head without the s_waitcnt for an LDS store at the loop's end — tools/barrier_audit.py looks for that.)"""
+    def child(env):
+        e = dict(os.environ)
+        e.pop("TRRE_MAPGEN", None)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", MAPGEN_SCRIPT % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools"))], stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, env=e, timeout=1200)
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+        return eval(r.stdout.decode().strip().splitlines()[-1]), r.stderr.decode()
+    (new, err1), (old, err0) = child({"TRRE_MAPGEN": "1", "TRRE_MAPGEN_PROF": "1"}), child({"TRRE_MAPGEN_PROF": "1"})
+    assert err1.count("memoryless kernel") >= 60 and "memoryless kernel" not in err0      # (the kernel's phase clocks, printed by finish(): it ran — and only there)
+    assert set(new) == set(old) and len(new) == 34
+    for k in new:
+        assert new[k] == old[k], k
+    assert new["capacity"] == trre_amd.api.E_CAPACITY
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import corpora
+    inp = corpora.printable_lines(256 << 20, corpora.SEED0 + 2, torch.device("cuda", 0))
+    head = inp[:1 << 20].cpu().numpy().tobytes()
+    head = head[:head.rfind(b"\n") + 1]
+    for pat, eng in [("a:xyz", "dft"), ("[aie]:", "nft"), ("(<:&lt;|>:&gt;|&:&amp;)", "nft")]:
+        assert trre_amd.Program(pat, eng).scan_tensor(inp[:len(head)]).cpu().numpy().tobytes() == Oracle(pat, eng).scan(head), (pat, eng)

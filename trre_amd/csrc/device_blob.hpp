@@ -60,7 +60,8 @@ struct StreamBlobHeader {
     uint32_t off_fb_dense_base;               // u16[fb4_dense]
     uint32_t fb_pad;
     uint32_t fb_start4[3];
-    uint32_t pad4[3];
+    uint32_t off_mg, mg_max;                  // memoryless programs (map_block.hpp): u32[256][4] = {text lo, text hi, length | kMgNul, 0}; mg_max = the longest text, 0: not one
+    uint32_t pad4[1];
 };
 static_assert(sizeof(StreamBlobHeader) == 192, "header layout");
 

@@ -238,6 +238,11 @@ struct StreamTables {
     // mark pass of the splice form ([9] and not [10]), [23:16] bytes emitted - 1 (signed, 0 bytes for a slow entry)
     bool g16_ok = false;
     std::vector<uint32_t> g16;              // [n_states][n_cls][4]
+    // A MEMORYLESS program (stream_build.cpp: every cell of the root row leads back to the root, a NUL aside): what a byte becomes is a
+    // function of that byte alone — [256][4] = {text lo, text hi, length (0..8) | 0x80: the byte cuts its record short, 0}, by raw byte.
+    // mg_max: the longest text; 0: the program is not one (or prints more than 8 bytes for some byte).  map_block.hpp runs it in one pass.
+    std::vector<uint32_t> mg;
+    uint32_t mg_max = 0;
     // Pair form of a small table: one entry per (state, class of byte 0, class of byte 1) = the two transitions composed,
     // 32 bytes: {next row offset (in the 16-byte form), meta, bytes 0..3, selector, bytes 4..7, selector, 0, 0}; meta [3:0] =
     // bytes the pair appends (0..8: literal bytes and the two input bytes, v_perm picks 4 / 5), [4] diverge, [5] a record

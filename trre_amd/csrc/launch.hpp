@@ -10,6 +10,7 @@ struct GenArgs;
 struct GuardArgs;
 struct LazyArgs;
 struct OneArgs;
+struct MapGenArgs;
 
 constexpr int kEngineNft = 0, kEngineDft = 1;
 
@@ -30,6 +31,9 @@ void launch_direct_kernel(int which, bool ent_in_lds, const ScanArgs& a, int64_t
 // the one-pass form of the general families on small tables (one_block.hpp: one walk, the workgroup's output in LDS, look-back for its place);
 // oa.desc / oa.ticket zeroed by the caller; -1: the tables and regions do not fit the LDS
 int launch_one(const ScanArgs& a, const OneArgs& oa, void* stream, int g16_bytes, int sym, bool g16_slow);
+// memoryless programs of any output length in one pass (map_block.hpp); a.blob: the stream blob with its mg table; oa's arrays zeroed by the caller;
+// -1: the window does not fit the LDS
+int launch_mapgen(const ScanArgs& a, const MapGenArgs& oa, void* stream);
 // backward pass of the guided families: fills a.sym_v0 for positions [0 .. round_up(a.vend, 64)) (packed: round_up(.., 128), two per byte)
 void launch_rev_sweep(const ScanArgs& a, int tab_bytes, int64_t lane_bytes, void* stream, bool packed);
 // wide guided tables (more than 256 backward states: 16-bit symbols at a.sym_v0, both tables through L1 / L2); which: 1 count, 2 emit

@@ -30,6 +30,7 @@
 #include "gen_block.hpp"
 #include "lazy_block.hpp"
 #include "one_block.hpp"
+#include "map_block.hpp"
 #include "guard_block.hpp"
 
 namespace {
@@ -108,6 +109,7 @@ struct Pending {
     const uint64_t* total_at = nullptr;   // general families: where the launch leaves its output size
     bool patched = false;                 // the launch was the mark + splice pair of a large table's copy form, not a count / emit pair
     bool one = false;                     // the launch was the one-pass kernel (one_block.hpp), not a count / emit pair
+    bool mapgen = false;                  // ... the memoryless one-pass kernel (map_block.hpp)
     // the stack guard found, before an in-place launch, a line on which the reference's search runs out of stack: nothing was launched
     // exact sub-ranges (scan_block.hpp: ScanArgs::exact): what finish() needs to run repair rounds and the emit pass again
     bool exact = false;
@@ -165,6 +167,9 @@ struct ScanCtx {
     uint64_t* d_one = nullptr;
     int64_t one_tiles = 0;
     bool one_off = false;             // finish() runs the scan again as a count / emit pair (a void one-pass launch)
+    uint64_t* d_mg = nullptr;         // the memoryless kernel (map_block.hpp): descriptors, group sums and totals, the total
+    int64_t mg_tiles = 0;
+    bool mapgen_off = false;          // finish() runs the scan again on the general family (a NUL in the input)
     uint32_t* d_miss = nullptr;       // lazy tables (lazy_block.hpp): [0] misses listed, then {row, class} pairs
     int bt_tier = 0;                  // the backtracking fallback: which size of stacks and path buffers the next launch uses (kBtTiers)
     bool guard_off = false;           // finish() scans the lines before a line the guard stopped at: not to be guarded again
@@ -342,10 +347,12 @@ void serialize_stream(const trre::StreamTables& t, std::vector<uint8_t>& b) {
         }
         std::memcpy(h.fb_start, t.fb_start, sizeof h.fb_start);
     }
+    if (t.mg_max) { h.off_mg = (uint32_t)off; h.mg_max = t.mg_max; off = align_up(off + t.mg.size() * 4, 16); }
     off = align_up(off + 16, 16);
     h.total_bytes = (uint32_t)off;
     b.assign(off, 0);
     put(b, 0, &h, 1);
+    if (t.mg_max) put(b, h.off_mg, t.mg.data(), t.mg.size());
     if (t.fb_ok) {
         put(b, h.off_fb_comb, t.fb_comb.data(), t.fb_comb.size());
         put(b, h.off_fb_lit, t.fb_lit.data(), t.fb_lit.size());
@@ -564,6 +571,7 @@ void ctx_free(ScanCtx& c) {
     (void)hipFree(c.d_miss);
     (void)hipFree(c.d_spec);
     (void)hipFree(c.d_one);
+    (void)hipFree(c.d_mg);
     (void)hipFree(c.d_probe);
     (void)hipFree(c.d_cevents);
     (void)hipFree(c.d_chdr);
@@ -867,6 +875,44 @@ int lazy_round(trre_prog* p, DeviceState* st, ScanCtx* cx, const trre::ScanArgs&
     return TRRE_OK;
 }
 
+// the memoryless kernel's workspace and launch (map_block.hpp); 0: launched (pd.total_at set), else the caller takes another route
+int mapgen_launch(trre_prog* p, ScanCtx* cx, const trre::ScanArgs& args, const trre::StreamTables& stt, hipStream_t stream, Pending& pd) {
+    using namespace trre;
+    MapGenArgs oa{};
+    oa.n_tiles = (args.vend + kMapGenTile - 1) / kMapGenTile;
+    const size_t groups = (size_t)(oa.n_tiles / 64 + 1);
+    static const char* dbg_env = getenv("TRRE_MAPGEN_DBG");                // (a file: every tile's total and place, written by finish())
+    const size_t words = (size_t)oa.n_tiles + 2 * groups + 1 + 8 + (dbg_env ? 16 * (size_t)oa.n_tiles : 0);   // descriptors, group sums, group totals, the total, phase clocks
+    if (cx->mg_tiles < oa.n_tiles || dbg_env) {
+        if (cx->d_mg) (void)hipFree(cx->d_mg);
+        cx->d_mg = nullptr; cx->mg_tiles = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&cx->d_mg), words * 8) != hipSuccess) { (void)hipGetLastError(); return -1; }
+        cx->mg_tiles = oa.n_tiles;
+    }
+    oa.desc = cx->d_mg;
+    oa.gsum = cx->d_mg + oa.n_tiles;
+    oa.ginc = oa.gsum + groups;
+    oa.total = oa.ginc + groups;
+    // the window: the whole output of a tile as a rule (16 KiB of input and a quarter: four workgroups share a CU's LDS with room to spare)
+    static const int window_env = getenv("TRRE_MAPGEN_WINDOW") ? atoi(getenv("TRRE_MAPGEN_WINDOW")) : 0;
+    uint32_t window = window_env > 0 ? (uint32_t)window_env : (uint32_t)(kMapGenTile + kMapGenTile / 4);
+    oa.window = (window + 15u) & ~15u;
+    oa.spin = 1u << 16;
+    static const bool mg_prof = getenv("TRRE_MAPGEN_PROF") != nullptr;       // (phase clocks of the kernel, printed by finish())
+    oa.prof = mg_prof ? oa.total + 1 : nullptr;
+    oa.dbg = dbg_env ? oa.total + 1 + 8 : nullptr;
+    oa.longest = stt.mg_max;
+    oa.first_lookup = 0;
+    for (int c = 0; c < 256; ++c)
+        if ((stt.mg[4 * c + 2] & 15u) == 1u && (stt.mg[4 * c] & 0xffu) != (uint32_t)c) oa.first_lookup = 1;
+    if (hipMemsetAsync(cx->d_mg, 0, words * 8, stream) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    if (launch_mapgen(args, oa, stream) != 0) return -1;
+    pd.total_at = oa.total;
+    pd.mapgen = true;
+    (void)p;
+    return 0;
+}
+
 int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap,
             hipStream_t stream) {
     using namespace trre;
@@ -975,6 +1021,7 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
     const bool g16_slow = (stt.flags & kFlagG16Slow) != 0;
     static const bool no_g16_env = getenv("TRRE_NO_G16") != nullptr;       // A/B: the 8-byte entries
     static const bool no_fb_env = getenv("TRRE_NO_FB") != nullptr;         // A/B: large tables walk their 8-byte rows in both passes
+    static const bool mapgen_env = getenv("TRRE_MAPGEN") != nullptr && atoi(getenv("TRRE_MAPGEN")) != 0;   // opt-in: memoryless programs in ONE pass (map_block.hpp)
     const int sym_mode = !is_guided(family) ? 0 : (p->gt.sym_bits == 4 && !no_g16_env ? 2 : 1);
     if (direct) n_chunks = (args.vend + lane_bytes * direct_block_threads() - 1) / (lane_bytes * direct_block_threads());
 
@@ -1064,6 +1111,10 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
         if (is_guided(family)) launch_rev_sweep(args, (int)p->gt.n_rev * 256, rev_lane_bytes, stream, sym_mode == 2);
         args.lp_emit = 1;
         launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, sym_mode, g16_slow);
+    } else if (direct && family == TRRE_KERNEL_STREAM_GEN && stt.mg_max && mapgen_env && !cx->mapgen_off &&
+               mapgen_launch(p, cx, args, stt, stream, pd) == 0) {
+        // a MEMORYLESS program (map_block.hpp; round 6, opt-in): no state, so no walk — lengths, a prefix sum with look-back, the bytes' texts
+        // at their places: ONE pass, one read of the input.  A NUL voids it (finish()).
     } else if (direct && !is_guided(family) && stt.fb_ok && !no_fb_env) {
         // a large table (a dictionary) in its fallback form: the count pass with every per-byte lookup in LDS (0.86 ms per
         // GiB against 1.62 on the 8-byte rows through L1/L2).  The emit pass over the same form (TRRE_FB_EMIT=1) is
@@ -1438,6 +1489,30 @@ int finish_inner(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
         const double t = pr[7] ? (double)pr[7] : 1.0;
         fprintf(stderr, "trre: one-pass phases, shader clocks per tile (%llu tiles): ticket %.0f  walk %.0f  verify %.0f  sizes %.0f  look-back %.0f  store %.0f\n",
                 (unsigned long long)pr[7], pr[0] / t, pr[1] / t, pr[2] / t, pr[3] / t, pr[4] / t, pr[5] / t);
+    }
+    if (was.mapgen && getenv("TRRE_MAPGEN_PROF")) {
+        uint64_t pr[8] = {};
+        HIP_TRY(hipMemcpy(pr, was.total_at + 1, sizeof(pr), hipMemcpyDeviceToHost));
+        const double t = pr[7] ? (double)pr[7] : 1.0;
+        fprintf(stderr, "trre: memoryless kernel, shader clocks per tile (%llu tiles): expand %.0f  next tile counted %.0f  look-back %.0f  store %.0f  barrier %.0f\n",
+                (unsigned long long)pr[7], pr[1] / t, pr[2] / t, pr[3] / t, pr[4] / t, pr[5] / t);
+    }
+    if (was.mapgen && getenv("TRRE_MAPGEN_DBG")) {
+        const int64_t nt = ((int64_t)was.n + 15 + kMapGenTile) / kMapGenTile + 1;
+        std::vector<uint64_t> d(16 * (size_t)cx->mg_tiles);
+        HIP_TRY(hipMemcpy(d.data(), was.total_at + 1 + 8, d.size() * 8, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(getenv("TRRE_MAPGEN_DBG"), "wb")) { fwrite(d.data(), 8, d.size(), f); fclose(f); }
+        (void)nt;
+    }
+    if (was.mapgen && (status & (kStNul | kStOneVoid))) {
+        // a NUL cuts its record short — the rest of the record is swallowed: state after all — (or, never seen, a look-back that gave up):
+        // the general small-table family takes the buffer
+        cx->mapgen_off = true;
+        cx->relaunches += 1;
+        int rc = enqueue(p, st, cx, was.family, was.d_in, was.n, was.d_out, was.cap, was.stream);
+        if (!rc) rc = finish_inner(p, st, cx, out_len);
+        cx->mapgen_off = false;
+        return rc;
     }
     if (was.one && (status & kStOneVoid)) {
         // the one-pass kernel could not answer (one_block.hpp: what voids it): the count / emit pair takes the buffer — and, the corpus being

@@ -458,12 +458,41 @@ private:
         in.bounded = bounded_;
         StreamTables t = pack_stream_tables(in);
         t.cls = cls;
+        build_mapgen(t);
         // (first without "a literal in front of the root row" as a way to describe a state: such a state is owed AND has slots of
         // its own, which the 32-bit mark form cannot express; if the comb does not come out with that form, as before)
         StreamTables t2 = t;
         build_fallback(t2, in, cls, false);
         if (!t2.fb_mark4_ok) { t2 = t; build_fallback(t2, in, cls, true); }
         return t2;
+    }
+
+    // The memoryless form (front.hpp: StreamTables::mg; map_block.hpp): the root row as it was before spread_long_outputs, by raw byte — if
+    // every cell of it leads back to the root (a NUL may cut its record short: SKIP), nothing diverges or overflows and no text exceeds 8 bytes.
+    void build_mapgen(StreamTables& t) const {
+        std::vector<Cell> root = rows_[0];
+        for (const Undo& u : undo_)
+            if (u.s == 0) root[u.c] = u.cell;
+        std::vector<uint32_t> v(256 * 4, 0);
+        uint32_t longest = 0;
+        for (int c = 0; c < 256; ++c) {
+            const Cell& x = root[c];
+            if (x.ovf || x.diverge) return;
+            const bool cut = c == 0 && x.next == skip_;
+            if (x.next != 0u && !cut) return;
+            std::string text = x.out;
+            if (x.copy_c) text.push_back((char)c);
+            if (text.size() > 8) return;
+            uint64_t bytes = 0;
+            for (size_t k = 0; k < text.size(); ++k) bytes |= (uint64_t)(uint8_t)text[k] << (8 * k);
+            v[4 * c] = (uint32_t)bytes;
+            v[4 * c + 1] = (uint32_t)(bytes >> 32);
+            v[4 * c + 2] = (uint32_t)text.size() | (cut ? 0x80u : 0u);
+            longest = std::max<uint32_t>(longest, (uint32_t)text.size());
+        }
+        if (!longest) return;
+        t.mg = std::move(v);
+        t.mg_max = longest;
     }
 
     // Fallback form of a large table (front.hpp, StreamTables::fb_*), built from the rows as they were before
