@@ -92,7 +92,7 @@ def pmc_traffic(kernel_name, nbytes):
 # tools/pmc_dict4.sh (1 GiB runs; FETCH_SIZE doubled as for the headline — round 5's calibration, tools/probes/fetch_calib.hip, found the
 # factor 2 right for every access pattern the kernels use): summed over the kernels of one scan.  Measured
 # under rocprofv3 in separate passes, NOT in this run — labelled as such in the record.
-CONFIG_PMC = {"expand_one": "expand_one", "cfg4": "cfg4_nft", "cfg4_guided": "cfg4_nft_guided", "cfg5_dft": "dict1000_dft", "cfg5_nft": "dict1000_dft", "expand": "expand_dft",
+CONFIG_PMC = {"expand_one": "expand_one", "expand_map": "expand_map", "delete_map": "delete_map", "cfg4": "cfg4_nft", "cfg4_guided": "cfg4_nft_guided", "cfg5_dft": "dict1000_dft", "cfg5_nft": "dict1000_dft", "expand": "expand_dft",
               "nft_loop": "nft_loop_guided", "dft_loop": "dft_loop_guided", "tile_fallback": "tile_dft"}
 
 
@@ -491,37 +491,49 @@ def emit(line):
     print(compact_line(line), flush=True)
 
 
-def one_walk_record(n):
-    """'a:xyz' through the one-walk form (TRRE_ONE=1) in a child process: its rate (HIP events of the batch), its output's checksum against
-    the count / emit pair's (a second child), the committed PMC passes of this round for its traffic."""
+def switched_record(n, name, switch, pat, eng, kernels, what, void_mark, pmc_tag):
+    """One pattern through an opt-in form (`switch`=1) in a child process: its rate (HIP events of the batch), its output's checksum against
+    the count / emit pair's (a second child without the switch), the committed PMC passes of this round for its traffic."""
     import re
 
     def child(env):
         e = dict(os.environ)
-        e.pop("TRRE_ONE", None)
+        e.pop(switch, None)
         e.update(env)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kbench.py"), "--bytes", str(n), "--steps", "10", "--sum", "--case",
-                            "a:xyz;;dft;;printable;;auto"], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+                            "%s;;%s;;printable;;auto" % (pat, eng)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         m = re.search(r"out=(\d+)\s+([0-9.]+) ms/step.*\(events ([0-9.]+) ms\)\s+sum=([0-9a-f]+)", r.stdout.decode())
         if r.returncode or not m:
             raise RuntimeError("kbench failed: " + r.stderr.decode()[-300:])
         return int(m.group(1)), float(m.group(2)), float(m.group(3)), m.group(4), r.stderr.decode()
-    m1, ms1, ev1, sum1, err1 = child({"TRRE_ONE": "1", "TRRE_TRACE": "1"})
+    m1, ms1, ev1, sum1, err1 = child({switch: "1", "TRRE_TRACE": "1"})
     m0, ms0, ev0, sum0, _ = child({})
-    void = "one-pass launch" in err1 and "void" in err1
-    rec = {"name": "expand_one", "pattern": "a:xyz", "engine": "dft", "bytes": n, "output_bytes": m1, "kernel_family": "stream_gen",
-           "kernels": "k_stream_one (TRRE_ONE=1: one walk, the workgroup's output staged in LDS, look-back for its place)",
-           "workload": "general path in ONE walk (row f2, opt-in): 'a:xyz' DFT, %.0f GiB, a child process with TRRE_ONE=1; beside it the count / emit pair in "
-                       "a child without the switch: %.3f ms (%.1f GB/s)" % (n / 2**30, ev0, n / (ev0 * 1e-3) / 1e9),
+    void = void_mark in err1 and "void" in err1
+    rec = {"name": name, "pattern": pat, "engine": eng, "bytes": n, "output_bytes": m1, "kernel_family": "stream_gen", "kernels": kernels,
+           "workload": "%s: '%s' %s, %.0f GiB, a child process with %s=1; beside it the count / emit pair in a child without the switch: %.3f ms (%.1f GB/s)"
+                       % (what, pat, eng.upper(), n / 2**30, switch, ev0, n / (ev0 * 1e-3) / 1e9),
            "steps": 10, "ms_per_step": ms1, "kernel_ms": ev1, "input_GBps": round(n / (ms1 * 1e-3) / 1e9, 1), "achieved_GBps": round(n / (ev1 * 1e-3) / 1e9, 1),
            "frac": round(n / (ev1 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "pair_kernel_ms": ev0,
            "verified": bool(m1 == m0 and sum1 == sum0 and not void),
            "verify": "output size and a position-weighted checksum of every output byte equal the pair's; no void launch in the trace"}
-    tr = config_traffic("expand_one")
+    tr = config_traffic(pmc_tag)
     if tr:
         tr["x_algorithmic"] = round(tr["hbm_bytes_per_GiB_of_input"] / ((1 << 30) * (1.0 + m1 / float(n))), 2)
         rec["traffic"] = tr
     return rec
+
+
+def one_walk_record(n):
+    """'a:xyz' through the one-walk form of the general families (TRRE_ONE=1, one_block.hpp)"""
+    return switched_record(n, "expand_one", "TRRE_ONE", "a:xyz", "dft", "k_stream_one (TRRE_ONE=1: one walk, the workgroup's output staged in LDS, look-back for its place)",
+                           "general path in ONE walk (row f2, opt-in)", "one-pass launch", "expand_one")
+
+
+def mapgen_records(n):
+    """'a:xyz' and '[aie]:' through the memoryless one-pass kernel (TRRE_MAPGEN=1, map_block.hpp)"""
+    k = "k_mapgen (TRRE_MAPGEN=1: no walk — lengths, DPP prefix sums, look-back, the texts at their places in an LDS window; one read of the input)"
+    return [switched_record(n, "expand_map", "TRRE_MAPGEN", "a:xyz", "dft", k, "a memoryless program in ONE pass (row f2, opt-in)", "one-pass launch", "expand_map"),
+            switched_record(n, "delete_map", "TRRE_MAPGEN", "[aie]:", "nft", k, "a memoryless program in ONE pass (row f2, opt-in)", "one-pass launch", "delete_map")]
 
 
 class StubProgram:
@@ -904,6 +916,10 @@ def main():
             configs.append(one_walk_record(n))
         except Exception as e:      # (the headline must not depend on it)
             configs.append({"name": "expand_one", "verified": False, "verify": "failed: %r" % (e,)})
+        try:
+            configs.extend(mapgen_records(n))
+        except Exception as e:
+            configs.append({"name": "expand_map", "verified": False, "verify": "failed: %r" % (e,)})
         nt = min(n, 1 << 30)
         # long lines (round 5: exact sub-ranges): the same text with one line end left per 400 KB — JSON lines, minified files
         try:

@@ -416,7 +416,7 @@ void run_mapgen(const ScanArgs& a, uint32_t& status, uint64_t& total_out, uint32
     bool first_lookup = false;
     for (int k = 0; k < 256; ++k) {
         len[k] = (uint8_t)mg[4 * k + 2]; first[k] = (uint8_t)mg[4 * k]; text[k] = (uint64_t)mg[4 * k + 1] << 32 | mg[4 * k];
-        if ((len[k] & 15u) == 1u && first[k] != k) first_lookup = true;        // (runtime.cpp: MapGenArgs::first_lookup)
+        if ((len[k] & (15u | kMgNul)) == 1u && first[k] != k) first_lookup = true;        // (runtime.cpp: MapGenArgs::first_lookup)
     }
     const MapGenView T{len.data(), first.data(), text.data()};
     const bool multi = h.mg_max > 1;

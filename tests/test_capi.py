@@ -89,3 +89,28 @@ def test_scan_without_gpu_fails_loudly():
     with pytest.raises(trre_amd.TrreError) as e:
         trre_amd.Program("cat:dog", "nft").scan(b"cat\n")
     assert e.value.code == api.E_DEVICE
+
+
+def test_no_barrier_is_left_with_lds_stores_in_flight(tmp_path):
+    """round 6: hipcc emitted a loop head's s_barrier without the s_waitcnt lgkmcnt(0) for a ds_write at the loop's end, and one
+    tile in 6 000 was counted twice.  tools/barrier_audit.py walks a device listing for every s_barrier that an LDS store can reach without
+    that wait; here over map_kernels.hip (seconds to compile; scan_kernels.hip takes two minutes: `hipcc -S --cuda-device-only`, by hand) —
+    and over a listing with the fault, which it must flag."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    audit = os.path.join(ROOT, "tools", "barrier_audit.py")
+    lst = str(tmp_path / "map_kernels.s")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", os.path.join(ROOT, "trre_amd", "csrc", "map_kernels.hip"), "-o", lst],
+                   check=True, stderr=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, audit, lst, "60"], stdout=subprocess.PIPE, check=True)
+    assert r.stdout.decode().strip().splitlines()[-1] == "barriers flagged: 0", r.stdout.decode()[-2000:]
+    bad = str(tmp_path / "bad.s")
+    with open(bad, "w") as f:
+        f.write("_Z3badv:\n\ts_load_dword s0, s[4:5], 0x0\n.LBB0_1:\n\ts_barrier\n\tds_read_b32 v1, v0\n\ts_waitcnt lgkmcnt(0)\n\tv_add_u32_e32 v1, 1, v1\n"
+                "\tds_write_b32 v0, v1\n\ts_cbranch_scc1 .LBB0_1\n\ts_endpgm\n")
+    r = subprocess.run([sys.executable, audit, bad], stdout=subprocess.PIPE, check=True)
+    assert "BAD ds_write_b32" in r.stdout.decode() and r.stdout.decode().strip().splitlines()[-1] == "barriers flagged: 1"

@@ -229,3 +229,40 @@ def test_memoryless_programs_in_one_pass_on_gpu():
     head = head[:head.rfind(b"\n") + 1]
     for pat, eng in [("a:xyz", "dft"), ("[aie]:", "nft"), ("(<:&lt;|>:&gt;|&:&amp;)", "nft")]:
         assert trre_amd.Program(pat, eng).scan_tensor(inp[:len(head)]).cpu().numpy().tobytes() == Oracle(pat, eng).scan(head), (pat, eng)
+
+
+GIVEUP_SCRIPT = r'''
+import hashlib, sys, time
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch, trre_amd, corpora
+dev = torch.device("cuda", 0)
+inp = corpora.printable_lines(256 << 20, corpora.SEED0 + 2, dev)
+p = trre_amd.Program("[aie]:", "nft")
+out = p.scan_tensor(inp)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+out = p.scan_tensor(inp)
+torch.cuda.synchronize()
+print(repr((out.numel(), hashlib.md5(out.cpu().numpy().tobytes()).hexdigest(), time.perf_counter() - t0)))
+'''
+
+
+def test_a_grid_that_is_not_resident_gives_up_and_the_pair_answers():
+    """k_mapgen's workgroups take their tiles in turn and a tile's look-back waits for the tiles of the others: every workgroup of the grid must be
+    resident.  launch_mapgen asks the runtime how many fit; if they are not (another process on the device — here: TRRE_MAPGEN_OVERSUB=3, a grid
+    three times the machine), a look-back finds a tile untouched, gives up after its spin, says so in the status word, everybody still waiting
+    leaves at the next poll, and finish() runs the buffer on the count / emit pair: the same bytes, a fraction of a second later — never a hang."""
+    def child(env):
+        e = dict(os.environ)
+        for k in ("TRRE_MAPGEN", "TRRE_MAPGEN_OVERSUB"):
+            e.pop(k, None)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", GIVEUP_SCRIPT % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools"))], stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, env=e, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+        return eval(r.stdout.decode().strip().splitlines()[-1]), r.stderr.decode()
+    (m1, sum1, dt1), err1 = child({"TRRE_MAPGEN": "1", "TRRE_MAPGEN_OVERSUB": "3", "TRRE_TRACE": "1"})
+    (m0, sum0, dt0), err0 = child({})
+    assert "memoryless kernel was void" in err1 and "was void" not in err0
+    assert (m1, sum1) == (m0, sum0)
+    assert dt1 < 20.0, dt1

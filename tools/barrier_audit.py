@@ -63,7 +63,7 @@ for name, lines in funcs.items():
     for b in order:
         for k, t in enumerate(blocks[b]):
             if t.startswith("s_barrier"):
-                r = walk(b, k, 12, set())
+                r = walk(b, k, int(sys.argv[2]) if len(sys.argv) > 2 else 12, set())
                 if r != "ok":
                     bad_total += 1
                     print(name[:70], b, r)

@@ -87,6 +87,9 @@ def main():
                 fams = fams + [shim_lib.STREAM_ONE, shim_lib.STREAM_ONE_MISS, shim_lib.STREAM_ONE_TIGHT]
             if p.info.guided_rev_states and p.info.guided_rev_states <= 256 and trre_amd.KERNEL_GUIDED_GEN in p.allowed_kernels() and shim_lib.has_g16(p.export_guided_tables()[1]):
                 fams = fams + [shim_lib.GUIDED_ONE, shim_lib.GUIDED_ONE_MISS]
+            # (round 6: memoryless programs in one pass, map_block.hpp — the production geometry, tiles of one lane with windows of 48 bytes)
+            if p.info.stream_states and shim_lib.has_mapgen(p) and trre_amd.KERNEL_STREAM_GEN in p.allowed_kernels():
+                fams = fams + [shim_lib.STREAM_MAPGEN, shim_lib.STREAM_MAPGEN_TINY]
             for fam in fams:
                 for geo in (1, 0):
                     try:

@@ -84,14 +84,19 @@ __device__ __forceinline__ bool mg_lb_step(MgLb& s, int64_t tile, const MgPoll& 
 }
 // the rounds after the first (mg_lb_step with the answers asked for before the tile was expanded), then the tile's own running total out.
 // Returns the tile's place; ok = false: gave up after `spin` polls (the launch is void).
-__device__ __forceinline__ uint64_t mg_lb_finish(MgLb s, uint64_t* desc, uint64_t* gsum, uint64_t* ginc, int64_t tile, uint64_t total, uint32_t spin, bool& ok) {
+__device__ __forceinline__ uint64_t mg_lb_finish(MgLb s, uint64_t* desc, uint64_t* gsum, uint64_t* ginc, int64_t tile, uint64_t total, uint32_t spin, uint32_t* status, bool& ok) {
     const int lid = threadIdx.x & (kWave - 1);
     ok = true;
     uint32_t polls = 0;
     while (!s.done) {
         const MgPoll p = mg_poll(desc, gsum, ginc, tile, s.gtop, s.tiles_done);
         if (!mg_lb_step(s, tile, p)) {
-            if (++polls > spin) { ok = false; break; }
+            // (somebody gave up — a workgroup of the grid is not resident, or the spin ran out here: the launch is void, and nobody waits on)
+            if ((__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kStOneVoid) || ++polls > spin) {
+                if (lid == 0) atomicOr(status, kStOneVoid);
+                ok = false;
+                break;
+            }
             __builtin_amdgcn_s_sleep(8);
         }
     }
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(kMapGenThreads, 4) void k_mapgen(ScanArgs a, MapGen
     uint8_t* lenp = smem;
     uint8_t* firstp = smem + 256;
     uint64_t* textp = reinterpret_cast<uint64_t*>(smem + 512);
-    uint32_t* misc = reinterpret_cast<uint32_t*>(smem + 512 + 2048);     // [0..7] the waves' totals ([31]: a NUL), [10..11] the base
+    uint32_t* misc = reinterpret_cast<uint32_t*>(smem + 512 + 2048);     // [0..7] the waves' totals ([31]: a NUL), [10..11] the base, [12] the look-back gave up
     uint8_t* win = smem + 512 + 2048 + 128;
     const uint32_t W = oa.window;
     const uint32_t sink = W + 32u + 4u * (uint32_t)tid;   // (the lane's sink, window-relative: a bank of its own within the wave)
@@ -300,8 +305,9 @@ __global__ __launch_bounds__(kMapGenThreads, 4) void k_mapgen(ScanArgs a, MapGen
         // ---- this tile's place --------------------------------------------------------------------------------------------------------------
         if (wave == 0) {
             bool ok;
-            const uint64_t b = mg_lb_finish(lb, oa.desc, oa.gsum, oa.ginc, tile, (uint64_t)total_k, oa.spin, ok);
+            const uint64_t b = mg_lb_finish(lb, oa.desc, oa.gsum, oa.ginc, tile, (uint64_t)total_k, oa.spin, a.status, ok);
             if (lid == 0) {
+                misc[12] = ok ? 0u : 1u;
                 *reinterpret_cast<uint64_t*>(misc + 10) = b;
                 if (tile == oa.n_tiles - 1) *oa.total = b + total_k;
                 if (oa.dbg) { oa.dbg[16 * tile] = total_k; oa.dbg[16 * tile + 1] = b; oa.dbg[16 * tile + 10] = blockIdx.x; oa.dbg[16 * tile + 11] = clock64(); }
@@ -309,6 +315,7 @@ __global__ __launch_bounds__(kMapGenThreads, 4) void k_mapgen(ScanArgs a, MapGen
             if (!ok) st |= kStOneVoid;
         }
         MG_SYNC();
+        if (misc[12]) { st_all |= kStOneVoid; break; }     // (uniform: the launch is void — the pair will run the buffer)
         const uint64_t base = *reinterpret_cast<const uint64_t*>(misc + 10);
         const bool write = base + total_k <= a.cap;
         if (!write) st |= kStCapacity;
@@ -356,6 +363,8 @@ int launch_mapgen_t(const ScanArgs& a, const MapGenArgs& oa, hipStream_t s, int 
     int per_cu = per_cu_cache.load();
     if (per_cu_env > 0 && per_cu_env < per_cu) per_cu = per_cu_env;
     int64_t blocks = (int64_t)cus * per_cu;
+    static const int oversub_env = getenv("TRRE_MAPGEN_OVERSUB") ? atoi(getenv("TRRE_MAPGEN_OVERSUB")) : 0;   // (tests: a grid that is NOT resident — the launch must give up, not hang)
+    if (oversub_env > 1) blocks *= oversub_env;
     if (blocks > oa.n_tiles) blocks = oa.n_tiles;
     hipLaunchKernelGGL((k_mapgen<kFirst, kMulti>), dim3((unsigned)blocks), dim3(kMapGenThreads), lds, s, a, oa);
     return 0;

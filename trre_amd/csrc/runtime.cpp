@@ -904,7 +904,7 @@ int mapgen_launch(trre_prog* p, ScanCtx* cx, const trre::ScanArgs& args, const t
     oa.longest = stt.mg_max;
     oa.first_lookup = 0;
     for (int c = 0; c < 256; ++c)
-        if ((stt.mg[4 * c + 2] & 15u) == 1u && (stt.mg[4 * c] & 0xffu) != (uint32_t)c) oa.first_lookup = 1;
+        if ((stt.mg[4 * c + 2] & (15u | kMgNul)) == 1u && (stt.mg[4 * c] & 0xffu) != (uint32_t)c) oa.first_lookup = 1;   // (a NUL voids the launch: whatever it prints)
     if (hipMemsetAsync(cx->d_mg, 0, words * 8, stream) != hipSuccess) { (void)hipGetLastError(); return -1; }
     if (launch_mapgen(args, oa, stream) != 0) return -1;
     pd.total_at = oa.total;
@@ -1505,8 +1505,10 @@ int finish_inner(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
         (void)nt;
     }
     if (was.mapgen && (status & (kStNul | kStOneVoid))) {
-        // a NUL cuts its record short — the rest of the record is swallowed: state after all — (or, never seen, a look-back that gave up):
-        // the general small-table family takes the buffer
+        // a NUL cuts its record short — the rest of the record is swallowed: state after all — (or a look-back that gave up: a workgroup of
+        // the grid was not resident — another process on the device —, tests: TRRE_MAPGEN_OVERSUB): the general small-table family takes the buffer
+        static const bool mg_trace = getenv("TRRE_TRACE") != nullptr;
+        if (mg_trace) fprintf(stderr, "trre: a one-pass launch of the memoryless kernel was void: status 0x%x\n", status);
         cx->mapgen_off = true;
         cx->relaunches += 1;
         int rc = enqueue(p, st, cx, was.family, was.d_in, was.n, was.d_out, was.cap, was.stream);
