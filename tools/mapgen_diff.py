@@ -55,3 +55,20 @@ if lens is not None:
         print(" tile", i, "total", dbg[i, 0], "want", tot[i], "block", dbg[i, 10], "clock", dbg[i, 11])
     for i in list(bad_b[:4]):
         print(" tile", i, "place", dbg[i, 1], "want", bas[i], "diff", dbg[i, 1] - bas[i])
+    if dbg.shape[1] > 13:
+        first = dbg[1:, 12]
+        clk = dbg[1:, 13]
+        print("look-back: first answers enough for %.1f%% of the tiles; clocks in the rest of it: mean %.0f, median %.0f, p90 %.0f, p99 %.0f, max %.0f; when the first answers were enough: mean %.0f; when not: mean %.0f"
+              % (100.0 * first.mean(), clk.mean(), np.median(clk), np.percentile(clk, 90), np.percentile(clk, 99), clk.max(), clk[first == 1].mean() if (first == 1).any() else 0, clk[first == 0].mean() if (first == 0).any() else 0))
+        # per round: the spread of the workgroups' clocks
+        G = int(dbg[:, 10].max()) + 1
+        t = dbg[:, 11]
+        for k in (2, 5, 10):
+            if (k + 1) * G <= nt:
+                r = t[k * G:(k + 1) * G]
+                print("  round %d: the workgroups' look-back ends spread over %.0f clocks (p10..p90 %.0f); a round takes %.0f" % (k, r.max() - r.min(), np.percentile(r, 90) - np.percentile(r, 10), np.median(t[(k + 1) * G:(k + 2) * G]) - np.median(r) if (k + 2) * G <= nt else 0))
+        blk = dbg[1:, 10]
+        for m in (8, 32):
+            rates = [first[blk % m == x].mean() for x in range(m)]
+            print("  first answers enough, by workgroup index mod %d: %s" % (m, " ".join("%.2f" % v for v in rates)))
+        cu = (blk // 8) % 32

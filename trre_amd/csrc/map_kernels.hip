@@ -122,7 +122,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
 // And: __syncthreads() is a fence too — s_waitcnt vmcnt(0) — which would wait for the bytes asked for a tile ahead; the barriers here order
 // LDS traffic only.
 #define MG_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-//   smem: len[256] | first[256] | text[256 x 8] | misc[32 x 4] | window[oa.window + 32] | sinks[kMapGenThreads x 4]
+//   smem: len[256] | first[256] | text[256 x 8] | misc[32 x 4] | 2 x window[oa.window + 32] | sinks[kMapGenThreads x 4]
 // Workgroup w of G takes the tiles w, w + G, w + 2 G, .. — no ticket to wait for, the next tiles known ahead — and its loop is a pipeline in
 // which every trip to memory is asked for a phase or a whole tile before its answer is needed, and a tile's total is out a whole round before
 // anyone looks back at it (a look-back waits for the SLOWEST of the 767 tiles before it: with totals published just in time — the ticket
@@ -143,7 +143,6 @@ __global__ __launch_bounds__(kMapGenThreads, 4) void k_mapgen(ScanArgs a, MapGen
     uint32_t* misc = reinterpret_cast<uint32_t*>(smem + 512 + 2048);     // [0..7] the waves' totals ([31]: a NUL), [10..11] the base, [12] the look-back gave up
     uint8_t* win = smem + 512 + 2048 + 128;
     const uint32_t W = oa.window;
-    const uint32_t sink = W + 32u + 4u * (uint32_t)tid;   // (the lane's sink, window-relative: a bank of its own within the wave)
     {
         const uint32_t* mg = reinterpret_cast<const uint32_t*>(a.blob + h.off_mg);
         for (int k = tid; k < 256; k += kMapGenThreads) {
@@ -154,6 +153,7 @@ __global__ __launch_bounds__(kMapGenThreads, 4) void k_mapgen(ScanArgs a, MapGen
     }
     const MapGenView T{lenp, firstp, textp};
     uint32_t st_all = 0;
+    if (tid == 0) misc[12] = 0;
     const bool prof = oa.prof != nullptr && tid == 0;
     auto stamp = [&](uint64_t& t, int slot) {
         if (prof) {
@@ -234,107 +234,127 @@ __global__ __launch_bounds__(kMapGenThreads, 4) void k_mapgen(ScanArgs a, MapGen
         }
         return st;
     };
-    int64_t tile = (int64_t)blockIdx.x;
-    uint32_t st = 0;
-    if (tile < oa.n_tiles) {
-        ask(tile, xlo, xhi);
-        ask(tile + G, ylo, yhi);
-        st = count_and_publish(tile);                      // (the barrier inside: the tables are staged)
-    }
-    while (tile < oa.n_tiles) {
-        uint64_t tclk = prof ? clock64() : 0;
-        const bool edge = is_edge(tile);                    // (uniform)
+    // ---- the pipeline.  Per trip: tile `cur` (counted, its total out, its bytes in x) is expanded into its window; tile `nxt`'s bytes have
+    // come (y): they move to x, the tile after it is asked for, `nxt` is counted and its total goes out; tile `prv` — expanded a trip ago
+    // into the OTHER window — gets its place from a look-back whose loads were issued a trip ago, and is stored.  Two barriers per trip.
+    auto win_of = [&](int64_t k) { return win + (size_t)((k / G) & 1) * (W + 32u); };
+    auto sink_of = [&](int64_t k) { return (uint32_t)(2u * (W + 32u) - ((k / G) & 1) * (W + 32u)) + 4u * (uint32_t)tid; };   // (the sinks lie behind both windows)
+    auto expand_clipped = [&](int64_t tile, uint32_t woff_k, uint32_t wlo, uint32_t wsize) {
         const int64_t vw = tile * kMapGenTile + vlane;
-        const uint32_t total_k = total;                    // (the tile's: count_and_publish below leaves the next tile's)
-        MgPoll first{0, 0, 0};
-        if (wave == 0 && tile > 0) first = mg_poll(oa.desc, oa.gsum, oa.ginc, tile, (tile >> 6) - 1, false);   // (asked for; looked at behind the expansion)
-        // ---- expand into the window (it does not need the tile's place).  The clipped form (an edge of the input, or a tile of more than one
-        // window: rare): row by row, the bytes read again
-        auto expand_clipped = [&](uint32_t wlo, uint32_t wsize, uint32_t woff_k) {
-            uint32_t rowbase = woff_k;
+        uint32_t rowbase = woff_k;
 #pragma clang loop unroll(disable)
-            for (int r = 0; r < kMgRows; ++r) {
-                const int64_t v = vw + r * kMgRowBytes;
-                uint2 d{0u, 0u};
-                if (v < vl) d = *reinterpret_cast<const uint2*>(a.in_v0 + v);
-                const MgEdge e = mg_edge(v, a.vbeg, a.vend);
-                const uint32_t n = mg_count8<true>(T, d.x, d.y, e);
-                const uint32_t in = wave_incl_scan_dpp(n);
-                mg_expand8<kFirst, kMulti, true, true>(T, d.x, d.y, e, win, sink, rowbase + in - n, wlo, wsize);
-                rowbase += (uint32_t)__builtin_amdgcn_readlane((int)in, kWave - 1);
+        for (int r = 0; r < kMgRows; ++r) {
+            const int64_t v = vw + r * kMgRowBytes;
+            uint2 d{0u, 0u};
+            if (v < vl) d = *reinterpret_cast<const uint2*>(a.in_v0 + v);
+            const MgEdge e = mg_edge(v, a.vbeg, a.vend);
+            const uint32_t n = mg_count8<true>(T, d.x, d.y, e);
+            const uint32_t in = wave_incl_scan_dpp(n);
+            mg_expand8<kFirst, kMulti, true, true>(T, d.x, d.y, e, win_of(tile), sink_of(tile), rowbase + in - n, wlo, wsize);
+            rowbase += (uint32_t)__builtin_amdgcn_readlane((int)in, kWave - 1);
+        }
+    };
+    auto store_window = [&](int64_t tile, uint64_t base, uint32_t wlo, uint32_t wsize, bool write) {
+        const uint32_t hh = (uint32_t)((reinterpret_cast<uintptr_t>(a.out) + base + wlo) & 15u);
+        const uint32_t n_lines = (hh + wsize + 15u) >> 4;
+        for (uint32_t c = (uint32_t)tid; c < n_lines; c += kMapGenThreads) mg_store_line(win_of(tile), a.out, base, wlo, wsize, hh, c, write);
+    };
+    int64_t cur = (int64_t)blockIdx.x, prv = -1;
+    uint32_t st_cur = 0, st_prv = 0, total_prv = 0, woff_prv = 0;
+    bool fits_prv = false;                                 // `prv` lies expanded in its window (else: an edge tile or one of several windows — at its store)
+    MgPoll poll_prv{0, 0, 0}, poll_prv2{0, 0, 0};         // (the tile's own group and the 64 groups before it; the 64 before those: a machine full of
+                                                           // workgroups holds three tiles each — 48 groups and more between a tile and the newest running total)
+    if (cur < oa.n_tiles) {
+        ask(cur, xlo, xhi);
+        ask(cur + G, ylo, yhi);
+        st_cur = count_and_publish(cur);                   // (the barrier inside: the tables are staged)
+    } else {
+        cur = -1;
+    }
+    while (cur >= 0 || prv >= 0) {
+        uint64_t tclk = prof ? clock64() : 0;
+        // ---- `prv`'s place: the look-back's loads went out a trip ago (wave 0; the others go on) -------------------------------------------
+        if (wave == 0 && prv >= 0) {
+            bool ok = true;
+            uint64_t b = 0;
+            const uint64_t lb_t0 = oa.dbg ? clock64() : 0;
+            MgLb lb{0, (prv >> 6) - 1, false, prv == 0};
+            if (prv > 0 && mg_lb_step(lb, prv, poll_prv) && !lb.done) (void)mg_lb_step(lb, prv, poll_prv2);
+            const bool lb_first = lb.done;
+            if (oa.spin == 7u) b = (uint64_t)prv * (kMapGenTile + kMapGenTile / 16);      // EXPERIMENT (TRRE_MAPGEN_NOLB): no look-back, the output is void
+            else b = mg_lb_finish(lb, oa.desc, oa.gsum, oa.ginc, prv, (uint64_t)total_prv, oa.spin, a.status, ok);
+            if (lid == 0) {
+                misc[12] = ok ? 0u : 1u;
+                *reinterpret_cast<uint64_t*>(misc + 10) = b;
+                if (prv == oa.n_tiles - 1) *oa.total = b + total_prv;
+                if (oa.dbg) { oa.dbg[16 * prv] = total_prv; oa.dbg[16 * prv + 1] = b; oa.dbg[16 * prv + 10] = blockIdx.x; oa.dbg[16 * prv + 11] = clock64(); oa.dbg[16 * prv + 12] = lb_first; oa.dbg[16 * prv + 13] = clock64() - lb_t0; }
             }
-        };
-        auto store_window = [&](uint64_t base, uint32_t wlo, uint32_t wsize, bool write) {
-            const uint32_t hh = (uint32_t)((reinterpret_cast<uintptr_t>(a.out) + base + wlo) & 15u);
-            const uint32_t n_lines = (hh + wsize + 15u) >> 4;
-            for (uint32_t c = (uint32_t)tid; c < n_lines; c += kMapGenThreads) mg_store_line(win, a.out, base, wlo, wsize, hh, c, write);
-        };
-        const uint32_t w0 = total_k < W ? total_k : W;     // the first window's bytes
-        const uint32_t woff_k = woff;
-        if (total_k && total_k <= W && !edge) {
-            uint32_t rowbase = woff_k;
+        }
+        stamp(tclk, 1);
+        // ---- `cur` into its window (it does not need its place) ---------------------------------------------------------------------------
+        const uint32_t total_cur = total, woff_cur = woff;
+        const bool fits_cur = cur >= 0 && total_cur != 0u && total_cur <= W && !is_edge(cur);
+        if (fits_cur) {
+            uint8_t* const wk = win_of(cur);
+            const uint32_t sk = sink_of(cur);
+            uint32_t rowbase = woff_cur;
 #pragma unroll
             for (int k = 0; k < kMgRows / 2; ++k) {
                 const uint32_t e = inc[k] - u[k];
                 // (the rows' bytes are picked apart anew: what the count pass extracted is not kept — 64 registers, spilled)
                 asm volatile("" : "+v"(xlo[2 * k]), "+v"(xhi[2 * k]), "+v"(xlo[2 * k + 1]), "+v"(xhi[2 * k + 1]));
-                mg_expand8<kFirst, kMulti, false, false>(T, xlo[2 * k], xhi[2 * k], MgEdge{}, win, sink, rowbase + (e & 0xffffu), 0u, 0u);
+                mg_expand8<kFirst, kMulti, false, false>(T, xlo[2 * k], xhi[2 * k], MgEdge{}, wk, sk, rowbase + (e & 0xffffu), 0u, 0u);
                 rowbase += tot[k] & 0xffffu;
                 TRRE_SCHED_FENCE();
-                mg_expand8<kFirst, kMulti, false, false>(T, xlo[2 * k + 1], xhi[2 * k + 1], MgEdge{}, win, sink, rowbase + (e >> 16), 0u, 0u);
+                mg_expand8<kFirst, kMulti, false, false>(T, xlo[2 * k + 1], xhi[2 * k + 1], MgEdge{}, wk, sk, rowbase + (e >> 16), 0u, 0u);
                 rowbase += tot[k] >> 16;
                 TRRE_SCHED_FENCE();
             }
-        } else if (total_k) {
-            expand_clipped(0u, w0, woff_k);
         }
-        // (the look-back's first answers are here — nothing else of this wave's is on its way — and as a rule they are all it needs)
-        MgLb lb{0, (tile >> 6) - 1, false, tile == 0};
-        if (wave == 0 && tile > 0) (void)mg_lb_step(lb, tile, first);
-        stamp(tclk, 1);
-        // ---- the next tile: its bytes are here (they came while the tile before this one was stored); the one after it is asked for, the
-        // next one counted and its total out — a whole round before the workgroups behind look back at it ------------------------------------
-        const int64_t ntile = tile + G;
-        uint32_t st_next = 0;
-#pragma unroll
-        for (int r = 0; r < kMgRows; ++r) { xlo[r] = ylo[r]; xhi[r] = yhi[r]; }
-        ask(ntile + G, ylo, yhi);
-        if (ntile < oa.n_tiles) st_next = count_and_publish(ntile);
-        else MG_SYNC();                                    // (the barrier of count_and_publish: the window is written)
         stamp(tclk, 2);
-        // ---- this tile's place --------------------------------------------------------------------------------------------------------------
-        if (wave == 0) {
-            bool ok;
-            const uint64_t b = mg_lb_finish(lb, oa.desc, oa.gsum, oa.ginc, tile, (uint64_t)total_k, oa.spin, a.status, ok);
-            if (lid == 0) {
-                misc[12] = ok ? 0u : 1u;
-                *reinterpret_cast<uint64_t*>(misc + 10) = b;
-                if (tile == oa.n_tiles - 1) *oa.total = b + total_k;
-                if (oa.dbg) { oa.dbg[16 * tile] = total_k; oa.dbg[16 * tile + 1] = b; oa.dbg[16 * tile + 10] = blockIdx.x; oa.dbg[16 * tile + 11] = clock64(); }
-            }
-            if (!ok) st |= kStOneVoid;
-        }
-        MG_SYNC();
-        if (misc[12]) { st_all |= kStOneVoid; break; }     // (uniform: the launch is void — the pair will run the buffer)
-        const uint64_t base = *reinterpret_cast<const uint64_t*>(misc + 10);
-        const bool write = base + total_k <= a.cap;
-        if (!write) st |= kStCapacity;
-        stamp(tclk, 3);
-        if (w0) store_window(base, 0u, w0, write);
-        for (uint32_t wlo = W; wlo < total_k; wlo += W) {  // (more windows: rare)
-            const uint32_t wsize = wlo + W < total_k ? W : total_k - wlo;
-            MG_SYNC();                                     // (the window before has left)
-            expand_clipped(wlo, wsize, woff_k);
+        // ---- the next tile: its bytes are here (asked for two trips ago); the one after it is asked for, the next one counted and its total
+        // out — a whole trip before this workgroup, and the others, look back at it -----------------------------------------------------------
+        int64_t nxt = cur >= 0 && cur + G < oa.n_tiles ? cur + G : -1;
+        uint32_t st_nxt = 0;
+        if (nxt >= 0) {
+#pragma unroll
+            for (int r = 0; r < kMgRows; ++r) { xlo[r] = ylo[r]; xhi[r] = yhi[r]; }
+            ask(nxt + G, ylo, yhi);
+            st_nxt = count_and_publish(nxt);               // (barrier)
+        } else {
             MG_SYNC();
-            store_window(base, wlo, wsize, write);
+        }
+        stamp(tclk, 3);
+        // ---- `prv` leaves: its window as aligned lines (a tile of several windows, or at an end of the input: expanded here, window by window)
+        if (prv >= 0) {
+            if (misc[12]) { st_all |= kStOneVoid; break; } // (uniform: a look-back gave up, the launch is void — the pair will run the buffer)
+            const uint64_t base = *reinterpret_cast<const uint64_t*>(misc + 10);
+            const bool write = base + total_prv <= a.cap;
+            if (!write) st_prv |= kStCapacity;
+            if (fits_prv) {
+                store_window(prv, base, 0u, total_prv, write);
+            } else {
+                for (uint32_t wlo = 0; wlo < total_prv; wlo += W) {
+                    const uint32_t wsize = wlo + W < total_prv ? W : total_prv - wlo;
+                    if (wlo) MG_SYNC();                    // (the window before has left)
+                    expand_clipped(prv, woff_prv, wlo, wsize);
+                    MG_SYNC();
+                    store_window(prv, base, wlo, wsize, write);
+                }
+            }
+            st_all |= st_prv;
+        }
+        // ---- `cur`'s look-back is asked for: looked at a trip from now ---------------------------------------------------------------------
+        if (wave == 0 && cur > 0) {
+            poll_prv = mg_poll(oa.desc, oa.gsum, oa.ginc, cur, (cur >> 6) - 1, false);
+            poll_prv2 = mg_poll(oa.desc, oa.gsum, oa.ginc, cur, (cur >> 6) - 65, true);
         }
         stamp(tclk, 4);
-        MG_SYNC();                                         // (the window has left: the next tile may be expanded into it)
+        MG_SYNC();                                         // (`prv`'s window has left: the tile after `cur` will be expanded into it)
         stamp(tclk, 5);
         if (prof) atomicAdd(reinterpret_cast<unsigned long long*>(oa.prof + 7), 1ull);
-        st_all |= st;
-        st = st_next;
-        tile = ntile;
+        prv = cur; st_prv = st_cur; total_prv = total_cur; woff_prv = woff_cur; fits_prv = fits_cur;
+        cur = nxt; st_cur = st_nxt;
     }
     st_all = wave_or(st_all);
     if (st_all && lid == 0) atomicOr(a.status, st_all);
@@ -371,7 +391,7 @@ int launch_mapgen_t(const ScanArgs& a, const MapGenArgs& oa, hipStream_t s, int 
 }
 int launch_mapgen(const ScanArgs& a, const MapGenArgs& oa, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int lds = 512 + 2048 + 128 + (int)oa.window + 32 + 4 * kMapGenThreads + 32;
+    const int lds = 512 + 2048 + 128 + 2 * ((int)oa.window + 32) + 4 * kMapGenThreads + 32;
     if (lds > kLdsLimit - 1024) return -1;
     static std::atomic<int> cus_cache{0};
     if (!cus_cache.load()) {

@@ -893,11 +893,13 @@ int mapgen_launch(trre_prog* p, ScanCtx* cx, const trre::ScanArgs& args, const t
     oa.gsum = cx->d_mg + oa.n_tiles;
     oa.ginc = oa.gsum + groups;
     oa.total = oa.ginc + groups;
-    // the window: the whole output of a tile as a rule (16 KiB of input and a quarter: four workgroups share a CU's LDS with room to spare)
+    // the windows (two: a tile is stored a trip after it was expanded): the whole output of a tile as a rule — 16 KiB of input and an eighth: four
+    // workgroups' pairs of windows share a CU's 160 KiB; a tile that prints more takes the clipped path, window by window
     static const int window_env = getenv("TRRE_MAPGEN_WINDOW") ? atoi(getenv("TRRE_MAPGEN_WINDOW")) : 0;
-    uint32_t window = window_env > 0 ? (uint32_t)window_env : (uint32_t)(kMapGenTile + kMapGenTile / 4);
+    uint32_t window = window_env > 0 ? (uint32_t)window_env : (uint32_t)(kMapGenTile + kMapGenTile / 8);
     oa.window = (window + 15u) & ~15u;
     oa.spin = 1u << 16;
+    if (getenv("TRRE_MAPGEN_NOLB")) oa.spin = 7u;      // (an experiment: no look-back — the pace of the rest; the output is void)
     static const bool mg_prof = getenv("TRRE_MAPGEN_PROF") != nullptr;       // (phase clocks of the kernel, printed by finish())
     oa.prof = mg_prof ? oa.total + 1 : nullptr;
     oa.dbg = dbg_env ? oa.total + 1 + 8 : nullptr;
@@ -1494,7 +1496,7 @@ int finish_inner(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
         uint64_t pr[8] = {};
         HIP_TRY(hipMemcpy(pr, was.total_at + 1, sizeof(pr), hipMemcpyDeviceToHost));
         const double t = pr[7] ? (double)pr[7] : 1.0;
-        fprintf(stderr, "trre: memoryless kernel, shader clocks per tile (%llu tiles): expand %.0f  next tile counted %.0f  look-back %.0f  store %.0f  barrier %.0f\n",
+        fprintf(stderr, "trre: memoryless kernel, shader clocks per trip (%llu trips): look-back %.0f  expand %.0f  next tile counted %.0f  store %.0f  barrier %.0f\n",
                 (unsigned long long)pr[7], pr[1] / t, pr[2] / t, pr[3] / t, pr[4] / t, pr[5] / t);
     }
     if (was.mapgen && getenv("TRRE_MAPGEN_DBG")) {
