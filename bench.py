@@ -507,7 +507,7 @@ def switched_record(n, name, switch, pat, eng, kernels, what, void_mark, pmc_tag
             raise RuntimeError("kbench failed: " + r.stderr.decode()[-300:])
         return int(m.group(1)), float(m.group(2)), float(m.group(3)), m.group(4), r.stderr.decode()
     m1, ms1, ev1, sum1, err1 = child({switch: "1", "TRRE_TRACE": "1"})
-    m0, ms0, ev0, sum0, _ = child({})
+    m0, ms0, ev0, sum0, _ = child({"TRRE_MAPGEN": "0"})          # (the count / emit pair: no one-pass form, not even the ones that are on by default)
     void = void_mark in err1 and "void" in err1
     rec = {"name": name, "pattern": pat, "engine": eng, "bytes": n, "output_bytes": m1, "kernel_family": "stream_gen", "kernels": kernels,
            "workload": "%s: '%s' %s, %.0f GiB, a child process with %s=1; beside it the count / emit pair in a child without the switch: %.3f ms (%.1f GB/s)"
@@ -533,7 +533,7 @@ def mapgen_records(n):
     """'a:xyz' and '[aie]:' through the memoryless one-pass kernel (TRRE_MAPGEN=1, map_block.hpp)"""
     k = "k_mapgen (TRRE_MAPGEN=1: no walk — lengths, DPP prefix sums, look-back, the texts at their places in an LDS window; one read of the input)"
     return [switched_record(n, "expand_map", "TRRE_MAPGEN", "a:xyz", "dft", k, "a memoryless program in ONE pass (row f2, opt-in)", "one-pass launch", "expand_map"),
-            switched_record(n, "delete_map", "TRRE_MAPGEN", "[aie]:", "nft", k, "a memoryless program in ONE pass (row f2, opt-in)", "one-pass launch", "delete_map")]
+            switched_record(n, "delete_map", "TRRE_MAPGEN", "[aie]:", "nft", k, "a memoryless program in ONE pass (row f2; the default for programs that print one byte or none per byte)", "one-pass launch", "delete_map")]
 
 
 class StubProgram:

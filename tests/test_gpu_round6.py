@@ -77,6 +77,7 @@ print(repr(res))
 def _child(env):
     e = dict(os.environ)
     e.pop("TRRE_ONE", None)
+    e["TRRE_MAPGEN"] = "0"                # (the one-walk form and the pair: not the memoryless kernel, which takes the programs it can by default)
     e.update(env)
     r = subprocess.run([sys.executable, "-c", ONE_SCRIPT % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools"))], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, env=e, timeout=1500)
@@ -202,10 +203,10 @@ print(repr(res))
 
 
 def test_memoryless_programs_in_one_pass_on_gpu():
-    """map_block.hpp on the device (k_mapgen, opt-in: TRRE_MAPGEN=1 — lengths, prefix sum with look-back, the texts at their places, one
+    """map_block.hpp on the device (k_mapgen; TRRE_MAPGEN=1: every memoryless program, by default those that print one byte or none per byte — lengths, prefix sum with look-back, the texts at their places, one
     read and one write): eight memoryless programs on 256 MiB, 64 MiB unaligned, one byte and 70 000 bytes, each twice (the descriptors of
     the launch before are gone), a NUL in the input, a buffer one byte short — byte for byte what the count / emit pair prints (a process
-    of its own without the switch); heads against the oracle.  (Round 6 met, here, one tile in 6 000 counted twice: the compiler had left
+    of its own with TRRE_MAPGEN=0); heads against the oracle.  (Round 6 met, here, one tile in 6 000 counted twice: the compiler had left
     the s_barrier at a loop's head without the s_waitcnt for an LDS store at the loop's end — tools/barrier_audit.py looks for that.)"""
     def child(env):
         e = dict(os.environ)
@@ -215,7 +216,7 @@ def test_memoryless_programs_in_one_pass_on_gpu():
                            stderr=subprocess.PIPE, env=e, timeout=1200)
         assert r.returncode == 0, r.stderr.decode()[-3000:]
         return eval(r.stdout.decode().strip().splitlines()[-1]), r.stderr.decode()
-    (new, err1), (old, err0) = child({"TRRE_MAPGEN": "1", "TRRE_MAPGEN_PROF": "1"}), child({"TRRE_MAPGEN_PROF": "1"})
+    (new, err1), (old, err0) = child({"TRRE_MAPGEN": "1", "TRRE_MAPGEN_PROF": "1"}), child({"TRRE_MAPGEN": "0", "TRRE_MAPGEN_PROF": "1"})
     assert err1.count("memoryless kernel") >= 60 and "memoryless kernel" not in err0      # (the kernel's phase clocks, printed by finish(): it ran — and only there)
     assert set(new) == set(old) and len(new) == 34
     for k in new:
@@ -262,7 +263,7 @@ def test_a_grid_that_is_not_resident_gives_up_and_the_pair_answers():
         assert r.returncode == 0, r.stderr.decode()[-3000:]
         return eval(r.stdout.decode().strip().splitlines()[-1]), r.stderr.decode()
     (m1, sum1, dt1), err1 = child({"TRRE_MAPGEN": "1", "TRRE_MAPGEN_OVERSUB": "3", "TRRE_TRACE": "1"})
-    (m0, sum0, dt0), err0 = child({})
+    (m0, sum0, dt0), err0 = child({"TRRE_MAPGEN": "0"})
     assert "memoryless kernel was void" in err1 and "was void" not in err0
     assert (m1, sum1) == (m0, sum0)
     assert dt1 < 20.0, dt1

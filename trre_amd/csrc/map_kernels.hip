@@ -140,7 +140,7 @@ __global__ __launch_bounds__(kMapGenThreads, 4) void k_mapgen(ScanArgs a, MapGen
     uint8_t* lenp = smem;
     uint8_t* firstp = smem + 256;
     uint64_t* textp = reinterpret_cast<uint64_t*>(smem + 512);
-    uint32_t* misc = reinterpret_cast<uint32_t*>(smem + 512 + 2048);     // [0..7] the waves' totals ([31]: a NUL), [10..11] the base, [12] the look-back gave up
+    uint32_t* misc = reinterpret_cast<uint32_t*>(smem + 512 + 2048);     // [0..7] the waves' totals ([31]: a NUL), [10..11] the base, [12] the look-back gave up, [14] it is still open
     uint8_t* win = smem + 512 + 2048 + 128;
     const uint32_t W = oa.window;
     {
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kMapGenThreads, 4) void k_mapgen(ScanArgs a, MapGen
     }
     const MapGenView T{lenp, firstp, textp};
     uint32_t st_all = 0;
-    if (tid == 0) misc[12] = 0;
+    if (tid == 0) misc[12] = misc[14] = 0;
     const bool prof = oa.prof != nullptr && tid == 0;
     auto stamp = [&](uint64_t& t, int slot) {
         if (prof) {
@@ -273,21 +273,34 @@ __global__ __launch_bounds__(kMapGenThreads, 4) void k_mapgen(ScanArgs a, MapGen
     }
     while (cur >= 0 || prv >= 0) {
         uint64_t tclk = prof ? clock64() : 0;
-        // ---- `prv`'s place: the look-back's loads went out a trip ago (wave 0; the others go on) -------------------------------------------
-        if (wave == 0 && prv >= 0) {
+        // ---- `prv`'s place: the look-back's loads went out a trip ago (wave 0).  As a rule their answers are enough; if not — some tile before
+        // `prv` had not published when they were asked for — the loads go out again and are looked at behind the next tile's count: a round trip
+        // hidden, where waiting here would hold the whole workgroup at the barrier
+        MgLb lb{0, (prv >> 6) - 1, false, prv <= 0};
+        MgPoll again{0, 0, 0};
+        bool lb_pending = false;
+        const uint64_t lb_t0 = oa.dbg ? clock64() : 0;
+        auto lb_close = [&](bool first) {                  // the rest of the look-back (polls until it is done), `prv`'s running total out, its place into LDS
             bool ok = true;
-            uint64_t b = 0;
-            const uint64_t lb_t0 = oa.dbg ? clock64() : 0;
-            MgLb lb{0, (prv >> 6) - 1, false, prv == 0};
-            if (prv > 0 && mg_lb_step(lb, prv, poll_prv) && !lb.done) (void)mg_lb_step(lb, prv, poll_prv2);
-            const bool lb_first = lb.done;
+            uint64_t b;
             if (oa.spin == 7u) b = (uint64_t)prv * (kMapGenTile + kMapGenTile / 16);      // EXPERIMENT (TRRE_MAPGEN_NOLB): no look-back, the output is void
             else b = mg_lb_finish(lb, oa.desc, oa.gsum, oa.ginc, prv, (uint64_t)total_prv, oa.spin, a.status, ok);
             if (lid == 0) {
                 misc[12] = ok ? 0u : 1u;
                 *reinterpret_cast<uint64_t*>(misc + 10) = b;
                 if (prv == oa.n_tiles - 1) *oa.total = b + total_prv;
-                if (oa.dbg) { oa.dbg[16 * prv] = total_prv; oa.dbg[16 * prv + 1] = b; oa.dbg[16 * prv + 10] = blockIdx.x; oa.dbg[16 * prv + 11] = clock64(); oa.dbg[16 * prv + 12] = lb_first; oa.dbg[16 * prv + 13] = clock64() - lb_t0; }
+                if (oa.dbg) { oa.dbg[16 * prv] = total_prv; oa.dbg[16 * prv + 1] = b; oa.dbg[16 * prv + 10] = blockIdx.x; oa.dbg[16 * prv + 11] = clock64(); oa.dbg[16 * prv + 12] = first; oa.dbg[16 * prv + 13] = clock64() - lb_t0; }
+            }
+        };
+        if (wave == 0 && prv >= 0) {
+            if (prv > 0 && mg_lb_step(lb, prv, poll_prv) && !lb.done) (void)mg_lb_step(lb, prv, poll_prv2);
+            if (lb.done || oa.spin == 7u) {
+                lb_close(true);
+                if (lid == 0) misc[14] = 0;
+            } else {
+                again = mg_poll(oa.desc, oa.gsum, oa.ginc, prv, lb.gtop, lb.tiles_done);
+                lb_pending = true;
+                if (lid == 0) misc[14] = 1;
             }
         }
         stamp(tclk, 1);
@@ -319,13 +332,21 @@ __global__ __launch_bounds__(kMapGenThreads, 4) void k_mapgen(ScanArgs a, MapGen
         if (nxt >= 0) {
 #pragma unroll
             for (int r = 0; r < kMgRows; ++r) { xlo[r] = ylo[r]; xhi[r] = yhi[r]; }
-            ask(nxt + G, ylo, yhi);
+            if (!lb_pending) ask(nxt + G, ylo, yhi);       // (wave 0 with a look-back still open asks below: nothing of its own shall lie between it and the answers)
             st_nxt = count_and_publish(nxt);               // (barrier)
         } else {
             MG_SYNC();
         }
         stamp(tclk, 3);
         // ---- `prv` leaves: its window as aligned lines (a tile of several windows, or at an end of the input: expanded here, window by window)
+        if (prv >= 0 && misc[14]) {                        // (uniform) the look-back's second answers, and whatever else it takes
+            if (wave == 0) {
+                (void)mg_lb_step(lb, prv, again);
+                lb_close(false);
+                if (nxt >= 0) ask(nxt + G, ylo, yhi);
+            }
+            MG_SYNC();
+        }
         if (prv >= 0) {
             if (misc[12]) { st_all |= kStOneVoid; break; } // (uniform: a look-back gave up, the launch is void — the pair will run the buffer)
             const uint64_t base = *reinterpret_cast<const uint64_t*>(misc + 10);

@@ -170,6 +170,8 @@ struct ScanCtx {
     uint64_t* d_mg = nullptr;         // the memoryless kernel (map_block.hpp): descriptors, group sums and totals, the total
     int64_t mg_tiles = 0;
     bool mapgen_off = false;          // finish() runs the scan again on the general family (a NUL in the input)
+    int mapgen_voids = 0;             // launches of the memoryless kernel that were void (a NUL; a grid that was not resident): after two, the pair from the start
+    bool mapgen_dense = false;        // a program with longer texts printed 4 % more than it read: its texts are frequent ('a:xyz': the pair is 7 % faster there)
     uint32_t* d_miss = nullptr;       // lazy tables (lazy_block.hpp): [0] misses listed, then {row, class} pairs
     int bt_tier = 0;                  // the backtracking fallback: which size of stacks and path buffers the next launch uses (kBtTiers)
     bool guard_off = false;           // finish() scans the lines before a line the guard stopped at: not to be guarded again
@@ -875,6 +877,12 @@ int lazy_round(trre_prog* p, DeviceState* st, ScanCtx* cx, const trre::ScanArgs&
     return TRRE_OK;
 }
 
+// Launches of the memoryless kernel wait for one another, device by device: the kernel wants its whole grid resident (a tile's look-back waits for
+// the tiles of the other workgroups), and two of them on two streams — the host path's chunks in flight — would each hold a part of the machine
+// and wait for the rest until their spins ran out.  (Other kernels beside it only delay it: they end, its workgroups move in.)
+struct MapGenChain { std::mutex mu; hipEvent_t ev = nullptr; bool any = false; };
+MapGenChain g_mapgen_chain[64];
+
 // the memoryless kernel's workspace and launch (map_block.hpp); 0: launched (pd.total_at set), else the caller takes another route
 int mapgen_launch(trre_prog* p, ScanCtx* cx, const trre::ScanArgs& args, const trre::StreamTables& stt, hipStream_t stream, Pending& pd) {
     using namespace trre;
@@ -908,7 +916,17 @@ int mapgen_launch(trre_prog* p, ScanCtx* cx, const trre::ScanArgs& args, const t
     for (int c = 0; c < 256; ++c)
         if ((stt.mg[4 * c + 2] & (15u | kMgNul)) == 1u && (stt.mg[4 * c] & 0xffu) != (uint32_t)c) oa.first_lookup = 1;   // (a NUL voids the launch: whatever it prints)
     if (hipMemsetAsync(cx->d_mg, 0, words * 8, stream) != hipSuccess) { (void)hipGetLastError(); return -1; }
-    if (launch_mapgen(args, oa, stream) != 0) return -1;
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        MapGenChain& ch = g_mapgen_chain[dev & 63];
+        std::lock_guard<std::mutex> lk(ch.mu);
+        if (!ch.ev && hipEventCreateWithFlags(&ch.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ch.ev = nullptr; return -1; }
+        if (ch.any && hipStreamWaitEvent(stream, ch.ev, 0) != hipSuccess) { (void)hipGetLastError(); return -1; }
+        if (launch_mapgen(args, oa, stream) != 0) return -1;
+        if (hipEventRecord(ch.ev, stream) != hipSuccess) { (void)hipGetLastError(); return -1; }
+        ch.any = true;
+    }
     pd.total_at = oa.total;
     pd.mapgen = true;
     (void)p;
@@ -1023,7 +1041,11 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
     const bool g16_slow = (stt.flags & kFlagG16Slow) != 0;
     static const bool no_g16_env = getenv("TRRE_NO_G16") != nullptr;       // A/B: the 8-byte entries
     static const bool no_fb_env = getenv("TRRE_NO_FB") != nullptr;         // A/B: large tables walk their 8-byte rows in both passes
-    static const bool mapgen_env = getenv("TRRE_MAPGEN") != nullptr && atoi(getenv("TRRE_MAPGEN")) != 0;   // opt-in: memoryless programs in ONE pass (map_block.hpp)
+    // memoryless programs in ONE pass (map_block.hpp) — `[aie]:` in 6.2 ms per 8 GiB where the pair takes 7.6, HTML escapes 8.4 against 11.0.
+    // A program whose longer texts turn out to be frequent (finish(): the output 4 % longer than the input; `a:xyz` on text: 8.6 ms against 8.0)
+    // goes back to the pair for the context's later scans.  TRRE_MAPGEN=1: every memoryless program, always; TRRE_MAPGEN=0: none
+    static const int mapgen_env = getenv("TRRE_MAPGEN") ? atoi(getenv("TRRE_MAPGEN")) : -1;
+    const bool mapgen_on = stt.mg_max != 0 && (mapgen_env < 0 ? !(stt.mg_max > 1u && cx->mapgen_dense) : mapgen_env != 0) && !cx->mapgen_off && cx->mapgen_voids < 2;
     const int sym_mode = !is_guided(family) ? 0 : (p->gt.sym_bits == 4 && !no_g16_env ? 2 : 1);
     if (direct) n_chunks = (args.vend + lane_bytes * direct_block_threads() - 1) / (lane_bytes * direct_block_threads());
 
@@ -1113,7 +1135,7 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
         if (is_guided(family)) launch_rev_sweep(args, (int)p->gt.n_rev * 256, rev_lane_bytes, stream, sym_mode == 2);
         args.lp_emit = 1;
         launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, sym_mode, g16_slow);
-    } else if (direct && family == TRRE_KERNEL_STREAM_GEN && stt.mg_max && mapgen_env && !cx->mapgen_off &&
+    } else if (direct && family == TRRE_KERNEL_STREAM_GEN && mapgen_on &&
                mapgen_launch(p, cx, args, stt, stream, pd) == 0) {
         // a MEMORYLESS program (map_block.hpp; round 6, opt-in): no state, so no walk — lengths, a prefix sum with look-back, the bytes' texts
         // at their places: ONE pass, one read of the input.  A NUL voids it (finish()).
@@ -1512,11 +1534,18 @@ int finish_inner(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
         static const bool mg_trace = getenv("TRRE_TRACE") != nullptr;
         if (mg_trace) fprintf(stderr, "trre: a one-pass launch of the memoryless kernel was void: status 0x%x\n", status);
         cx->mapgen_off = true;
+        cx->mapgen_voids += 1;
         cx->relaunches += 1;
         int rc = enqueue(p, st, cx, was.family, was.d_in, was.n, was.d_out, was.cap, was.stream);
         if (!rc) rc = finish_inner(p, st, cx, out_len);
         cx->mapgen_off = false;
         return rc;
+    }
+    if (was.mapgen) {
+        // (the longer texts are frequent in what this context scans: see enqueue())
+        uint64_t m = 0;
+        std::memcpy(&m, cx->h_status + 2, 8);
+        if (m > (uint64_t)was.n + (uint64_t)was.n / 25) cx->mapgen_dense = true;
     }
     if (was.one && (status & kStOneVoid)) {
         // the one-pass kernel could not answer (one_block.hpp: what voids it): the count / emit pair takes the buffer — and, the corpus being
