@@ -7,24 +7,27 @@
 // every cell of the root row leads back to it) has NO state to carry: what byte i becomes is a function of byte i alone, and where it goes
 // is a prefix sum of lengths — stream compaction / expansion, the textbook single-pass scan:
 //
-//   tile     4 waves x 8 ROWS of 512 bytes (16 KiB of input); workgroup w of G takes the tiles w, w + G, w + 2 G, ..  A lane holds 8 consecutive
+//   tile     4 waves x 8 ROWS of 512 bytes (16 KiB of input); workgroup w of G takes the tiles w, w + G, w + 2 G, .. (no ticket: its next tiles
+//            are known ahead, their bytes can be on their way).  A lane holds 8 consecutive
 //            bytes of each of its wave's rows (a `global_load_dwordx2`: 512 bytes side by side per instruction) — the lanes of a wave then write
 //            to LDS 8-odd bytes apart: two lanes per bank, which a byte store's own cost (4 cycles) covers.  64 consecutive bytes per lane, the
 //            first form of this kernel, put sixteen lanes on one bank: it ran at the pace of those conflicts;
 //   lengths  a lane sums the output lengths of its 8 bytes per row (a 256-byte table of lengths in LDS);
 //   places   the rows' sums two to a word through DPP prefix sums over the wave, the rows' and waves' totals, then a two-level decoupled
-//            look-back over the tiles' totals (groups of 64 tiles: one round trip reaches 4 096 tiles back);
+//            look-back over the tiles' totals (groups of 64 tiles: one round trip reaches 8 192 tiles back);
 //   expand   a lane writes its bytes' texts at their places in a WINDOW of the tile's output in LDS: one byte store per input byte (a byte
 //            that prints nothing stores into a sink: a select instead of a branch) and, for the lanes whose byte prints a longer text, the
 //            text's other bytes — in as many rounds as the output needs windows (one, as a rule);
 //   store    the window leaves as whole aligned 16-byte lines, the two ends of a tile byte by byte.
-// The loop is a software pipeline (map_kernels.hip): a tile's bytes are asked for two tiles ahead, its total is out a whole round before the
-// workgroups behind look back at it, the look-back's loads are issued before the expansion and read after it.
+// The loop is a software pipeline (map_kernels.hip): a tile's bytes are asked for two tiles ahead, its total is out a whole trip before anybody
+// looks back at it, it is expanded into one of TWO windows and stored a trip later — when its look-back, whose loads went out a trip before,
+// has its answers (and if they are not enough, the second round is hidden behind the next tile's count).  Two barriers per tile.
 //
 // The input is read once, the output written once, nothing else touches memory but 24 bytes per 16 KiB tile.  A NUL (the rest of its record
 // is swallowed: state after all) voids the launch and the general family runs the buffer, as for the byte map.
-// Measured (round 6): 8 GiB of '[aie]:' in 9.1 ms, of 'a:xyz' in 11.8 ms — against 7.7 / 8.0 ms of the count / emit pair that
-// reads the input twice.  Opt-in (TRRE_MAPGEN=1).
+// Measured (round 6), 8 GiB: '[aie]:' 6.2 ms (1.39 TB/s; the count / emit pair that reads the input twice: 7.6), '(a:b|e:)' 6.5 (7.7),
+// HTML escapes 8.4 (11.0), 'a:xyz' — a longer text every 35 bytes — 8.5 (8.0).  On by default for the programs it takes (runtime.cpp: a context whose
+// longer texts turn out frequent goes back to the pair); TRRE_MAPGEN=0 / 1: never / always.
 // Matches: the scan loops trre_dft.c:1272-1286 / trre_nft.c:775-790 with infer_* deciding after one byte; emits trre_dft.c:1121-1122, trre_nft.c:645.
 // The per-lane bodies are TRRE_HD: tests/cpu_shim.cpp runs them lane by lane.
 #pragma once
@@ -54,13 +57,13 @@ struct MapGenArgs {
     uint64_t* ginc;          // [n_tiles / 64 + 1] the running total at the end of a group (zeroed)
     uint64_t* total;         // [1] the size of the whole output (written by the last tile)
     int64_t n_tiles;
-    uint32_t window;         // bytes of the output window in LDS (a multiple of 16)
+    uint32_t window;         // bytes of ONE of the two output windows in LDS (a multiple of 16)
     uint32_t spin;           // look-back polls before a tile gives up (void launch — never a hang)
     uint32_t first_lookup;   // some byte prints ONE byte that is not itself: the expansion looks every first byte up (else: the byte itself,
                              // and the texts of two bytes and more bring their own)
     uint32_t longest;        // the longest text (StreamTables::mg_max)
-    uint64_t* prof;          // TRRE_MAPGEN_PROF=1: [8] shader clocks per phase summed over the tiles (thread 0's): [1] expand + the look-back's first
-                             // answers, [2] the next tile counted and published, [3] the look-back's end, [4] store, [5] the last barrier; [7] the tiles; else null
+    uint64_t* prof;          // TRRE_MAPGEN_PROF=1: [8] shader clocks per phase summed over the trips (thread 0's): [1] the look-back's answers, [2] expand,
+                             // [3] the next tile counted and published, [4] store, [5] the last barrier; [7] the trips; else null
     uint64_t* dbg;           // TRRE_MAPGEN_DBG=<file>: [n_tiles][16] every tile's total, place, workgroup and clock (tools/mapgen_diff.py checks them); else null
 };
 

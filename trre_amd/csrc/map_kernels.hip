@@ -124,14 +124,17 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
 #define MG_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 //   smem: len[256] | first[256] | text[256 x 8] | misc[32 x 4] | 2 x window[oa.window + 32] | sinks[kMapGenThreads x 4]
 // Workgroup w of G takes the tiles w, w + G, w + 2 G, .. — no ticket to wait for, the next tiles known ahead — and its loop is a pipeline in
-// which every trip to memory is asked for a phase or a whole tile before its answer is needed, and a tile's total is out a whole round before
-// anyone looks back at it (a look-back waits for the SLOWEST of the 767 tiles before it: with totals published just in time — the ticket
-// forms of this kernel — that was the tail of the memory's latency under load, 60 000 clocks per tile):
-//   holding: tile k counted and its total out; tile k + 1's bytes on their way
-//   ask for the first round of tile k's look-back - expand tile k into the window - tile k + 1's bytes are here: ask for tile k + 2's, count
-//   tile k + 1, its total out - tile k's place from the look-back's answers - store the window.
-// All G workgroups must be resident (launch_mapgen asks the runtime how many fit); a look-back that finds a tile untouched for `spin` polls
-// gives up and the launch is void (the pair runs the buffer) — never a hang.
+// which every trip to memory is asked for a phase or a whole tile before its answer is needed, and a tile's total is out a whole trip before
+// anyone looks back at it (a look-back waits for the SLOWEST of the thousand tiles before it: with totals published just in time — the ticket
+// forms of this kernel — that was the tail of the memory's latency under load, 60 000 clocks per tile; tickets asked for ahead hold a tile
+// unpublished behind its holder's waits, and their answers come back through the same in-order counter as the bytes asked for ahead):
+//   holding: `prv` expanded into one window, its look-back's loads out; `cur` counted, its total out; the bytes of the tile after `cur` on their way
+//   `prv`'s place from the look-back's answers (wave 0; not enough: asked again, closed behind the count below) - `cur` into the OTHER window -
+//   the next tile's bytes are here: the tile after it asked for, the next one counted, its total out - `prv`'s window stored - `cur`'s look-back asked for.
+// Two barriers per trip (raw s_barrier with the LDS counter drained: __syncthreads() is a fence and would wait for the bytes asked for ahead).
+// All G workgroups must be resident (launch_mapgen asks the runtime how many fit; launches wait for one another per device: runtime.cpp); a
+// look-back that finds a tile untouched for `spin` polls gives up, says so in the status word — whoever else is waiting leaves at its next
+// poll — and the launch is void (the pair runs the buffer): never a hang.
 template <bool kFirst, bool kMulti>
 __global__ __launch_bounds__(kMapGenThreads, 4) void k_mapgen(ScanArgs a, MapGenArgs oa) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
