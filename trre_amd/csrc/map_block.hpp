@@ -108,26 +108,23 @@ TRRE_HD uint32_t mg_expand8(const MapGenView& T, uint32_t lo, uint32_t hi, MgEdg
         }
         bb[j] = b;
         l[j] = inside ? (uint32_t)T.len[b] : 0u;
-        // (a program with longer texts: the text's first four bytes come with the length — the first byte among them —, so the lanes that meet
-        // one below have nothing to wait for)
-        f[j] = kMulti ? reinterpret_cast<const uint32_t*>(T.text)[2u * b] : (kFirst ? (uint32_t)T.first[b] : b);
+        f[j] = kFirst ? (uint32_t)T.first[b] : b;
     }
     // (pointers, not indices: the window's address is added once, not per store)
     uint8_t* p = win + (int32_t)(pos - wlo);       // (window-relative; beyond wsize — or before the window — outside it)
     uint8_t* const sk = win + sink;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        uint32_t x = f[j];                          // (kMulti: the text's bytes 0 .. 3, zero beyond its length: a byte that prints itself has itself there)
+        uint32_t x = f[j];
         if (kMulti && l[j] > 1u) {                 // (the lanes that meet a longer text; the others wait — or, no such lane, skip)
-            const uint32_t t4 = f[j];
+            const uint64_t t = T.text[bb[j]];
+            const uint32_t t4 = (uint32_t)t;
+            x = t4;
             if (!kClip || (uint32_t)(p + 1 - win) < wsize) p[1] = (uint8_t)(t4 >> 8);
             *(l[j] > 2u && (!kClip || (uint32_t)(p + 2 - win) < wsize) ? p + 2 : sk) = (uint8_t)(t4 >> 16);
-            if (l[j] > 3u) {                                 // (a text of four bytes and more: rare)
-                const uint64_t t = T.text[bb[j]];
 #pragma clang loop vectorize(disable) unroll(disable)
-                for (uint32_t q = 3; q < l[j]; ++q)
-                    if (!kClip || (uint32_t)(p + q - win) < wsize) p[q] = (uint8_t)(t >> (8 * q));
-            }
+            for (uint32_t q = 3; q < l[j]; ++q)              // (a text of four bytes and more: rare)
+                if (!kClip || (uint32_t)(p + q - win) < wsize) p[q] = (uint8_t)(t >> (8 * q));
         }
         *(l[j] != 0u && (!kClip || (uint32_t)(p - win) < wsize) ? p : sk) = (uint8_t)x;
         p += l[j];
