@@ -43,6 +43,8 @@ constexpr int kMgRowBytes = kMgLanes * kMgLaneBytes;
 constexpr int kMgWaveBytes = kMgRows * kMgRowBytes;
 constexpr int kMapGenTile = (kMapGenThreads / kMgLanes) * kMgWaveBytes;
 constexpr uint32_t kMgNul = 0x80u;               // length table: the byte cuts its record short (a NUL): the launch is void
+constexpr uint32_t kStMapDense = 1u << 9;        // status: a workgroup met two tiles in a row that outgrow the window — the program's longer texts are
+                                                 // frequent here, window by window it would crawl (`e:12345678`: 45 ms per 8 GiB): the launch is void, the pair runs
 
 // the tables (StreamTables::mg, 256 x 16 bytes in the blob: {text lo, text hi, length | kMgNul, 0}) as the kernel keeps them in LDS
 struct MapGenView {
