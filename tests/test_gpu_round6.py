@@ -217,9 +217,8 @@ def test_memoryless_programs_in_one_pass_on_gpu():
         assert r.returncode == 0, r.stderr.decode()[-3000:]
         return eval(r.stdout.decode().strip().splitlines()[-1]), r.stderr.decode()
     (new, err1), (old, err0) = child({"TRRE_MAPGEN": "1", "TRRE_MAPGEN_PROF": "1"}), child({"TRRE_MAPGEN": "0", "TRRE_MAPGEN_PROF": "1"})
-    # (the kernel's phase clocks, printed by finish(): it ran — and only there.  Not 64 times: a program whose tiles outgrow the window — '.:uv' doubles
-    # its input, 'e:12345678' — makes the launch void at once, twice, and is the pair's from then on)
-    assert err1.count("memoryless kernel") >= 30 and "memoryless kernel" not in err0
+    # (the kernel's phase clocks, printed by finish(): it ran — and only there)
+    assert err1.count("memoryless kernel") >= 60 and "memoryless kernel" not in err0
     assert set(new) == set(old) and len(new) == 34
     for k in new:
         assert new[k] == old[k], k

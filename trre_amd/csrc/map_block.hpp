@@ -43,8 +43,6 @@ constexpr int kMgRowBytes = kMgLanes * kMgLaneBytes;
 constexpr int kMgWaveBytes = kMgRows * kMgRowBytes;
 constexpr int kMapGenTile = (kMapGenThreads / kMgLanes) * kMgWaveBytes;
 constexpr uint32_t kMgNul = 0x80u;               // length table: the byte cuts its record short (a NUL): the launch is void
-constexpr uint32_t kStMapDense = 1u << 9;        // status: a workgroup met two tiles in a row that outgrow the window — the program's longer texts are
-                                                 // frequent here, window by window it would crawl (`e:12345678`: 45 ms per 8 GiB): the launch is void, the pair runs
 
 // the tables (StreamTables::mg, 256 x 16 bytes in the blob: {text lo, text hi, length | kMgNul, 0}) as the kernel keeps them in LDS
 struct MapGenView {
@@ -139,6 +137,9 @@ TRRE_HD uint32_t mg_expand8(const MapGenView& T, uint32_t lo, uint32_t hi, MgEdg
 // the tile's place in the output); output line c is the 16 aligned bytes at (address of out + base + wlo - h) + 16 c, h = that address & 15:
 // read from the window at 16 c - h through a funnel shift (aligned dwords), stored whole when all its bytes are this window's, byte by byte
 // at the two ends.  write = false: nothing is stored (the output does not fit the caller's buffer).
+// kSel: the line's first dword within its 16-byte block of the window, (16 - h) & 15 >> 2 — the same for every line of a tile (the kernel branches on it
+// once per window instead of selecting per line); -1: worked out here.
+template <int kSel = -1>
 TRRE_HD void mg_store_line(const uint8_t* win, uint8_t* out, uint64_t base, uint32_t wlo, uint32_t n, uint32_t h, uint32_t c, bool write) {
     const int32_t lo = (int32_t)(c << 4) - (int32_t)h;   // window offset of the line's first byte (negative: the tile's first line)
     if (lo >= (int32_t)n || !write) return;
@@ -146,7 +147,7 @@ TRRE_HD void mg_store_line(const uint8_t* win, uint8_t* out, uint64_t base, uint
     if (lo >= 0 && (uint32_t)lo + 16u <= n) {
         // two aligned 16-byte reads (no bank conflicts: a wave's lines lie side by side) and a funnel over their eight dwords
         const U128 x = *reinterpret_cast<const U128*>(win + ((uint32_t)lo & ~15u)), y = *reinterpret_cast<const U128*>(win + ((uint32_t)lo & ~15u) + 16);
-        const uint32_t dsel = ((uint32_t)lo >> 2) & 3u, sh = (uint32_t)lo & 3u;
+        const uint32_t dsel = kSel >= 0 ? (uint32_t)kSel : ((uint32_t)lo >> 2) & 3u, sh = (uint32_t)lo & 3u;
         const uint32_t r0 = dsel == 0 ? x.x : (dsel == 1 ? x.y : (dsel == 2 ? x.z : x.w));
         const uint32_t r1 = dsel == 0 ? x.y : (dsel == 1 ? x.z : (dsel == 2 ? x.w : y.x));
         const uint32_t r2 = dsel == 0 ? x.z : (dsel == 1 ? x.w : (dsel == 2 ? y.x : y.y));

@@ -258,13 +258,13 @@ __global__ __launch_bounds__(kMapGenThreads, 4) void k_mapgen(ScanArgs a, MapGen
         }
     };
     auto store_window = [&](int64_t tile, uint64_t base, uint32_t wlo, uint32_t wsize, bool write) {
-        const uint32_t hh = (uint32_t)((reinterpret_cast<uintptr_t>(a.out) + base + wlo) & 15u);
+        // (hh is the same for every lane — and so is the dword a line starts at in its 16-byte block: mg_store_line's selects are scalar)
+        const uint32_t hh = (uint32_t)__builtin_amdgcn_readfirstlane((int)((reinterpret_cast<uintptr_t>(a.out) + base + wlo) & 15u));
         const uint32_t n_lines = (hh + wsize + 15u) >> 4;
         for (uint32_t c = (uint32_t)tid; c < n_lines; c += kMapGenThreads) mg_store_line(win_of(tile), a.out, base, wlo, wsize, hh, c, write);
     };
     int64_t cur = (int64_t)blockIdx.x, prv = -1;
     uint32_t st_cur = 0, st_prv = 0, total_prv = 0, woff_prv = 0;
-    uint32_t dense_run = 0, poll_st = 0;
     bool fits_prv = false;                                 // `prv` lies expanded in its window (else: an edge tile or one of several windows — at its store)
     MgPoll poll_prv{0, 0, 0}, poll_prv2{0, 0, 0};         // (the tile's own group and the 64 groups before it; the 64 before those: a machine full of
                                                            // workgroups holds three tiles each — 48 groups and more between a tile and the newest running total)
@@ -298,9 +298,7 @@ __global__ __launch_bounds__(kMapGenThreads, 4) void k_mapgen(ScanArgs a, MapGen
         };
         if (wave == 0 && prv >= 0) {
             if (prv > 0 && mg_lb_step(lb, prv, poll_prv) && !lb.done) (void)mg_lb_step(lb, prv, poll_prv2);
-            if (poll_st & kStOneVoid) {                    // (the launch is void already: leave)
-                if (lid == 0) { misc[12] = 1u; misc[14] = 0; }
-            } else if (lb.done || oa.spin == 7u) {
+            if (lb.done || oa.spin == 7u) {
                 lb_close(true);
                 if (lid == 0) misc[14] = 0;
             } else {
@@ -313,9 +311,6 @@ __global__ __launch_bounds__(kMapGenThreads, 4) void k_mapgen(ScanArgs a, MapGen
         // ---- `cur` into its window (it does not need its place) ---------------------------------------------------------------------------
         const uint32_t total_cur = total, woff_cur = woff;
         const bool fits_cur = cur >= 0 && total_cur != 0u && total_cur <= W && !is_edge(cur);
-        // (two tiles in a row that outgrow the window: not a stray dense page — the launch is void, at once)
-        if (cur >= 0 && total_cur > W) { if (++dense_run >= 2u && tid == 0) atomicOr(a.status, kStOneVoid | kStMapDense); }
-        else if (cur >= 0) dense_run = 0;
         if (fits_cur) {
             uint8_t* const wk = win_of(cur);
             const uint32_t sk = sink_of(cur);
@@ -357,7 +352,7 @@ __global__ __launch_bounds__(kMapGenThreads, 4) void k_mapgen(ScanArgs a, MapGen
             MG_SYNC();
         }
         if (prv >= 0) {
-            if (misc[12] || dense_run >= 2u) { st_all |= kStOneVoid; break; } // (uniform: a look-back gave up / the tiles outgrow the window: the launch is void — the pair will run the buffer)
+            if (misc[12]) { st_all |= kStOneVoid; break; } // (uniform: a look-back gave up, the launch is void — the pair will run the buffer)
             const uint64_t base = *reinterpret_cast<const uint64_t*>(misc + 10);
             const bool write = base + total_prv <= a.cap;
             if (!write) st_prv |= kStCapacity;
@@ -377,7 +372,6 @@ __global__ __launch_bounds__(kMapGenThreads, 4) void k_mapgen(ScanArgs a, MapGen
         // ---- `cur`'s look-back is asked for: looked at a trip from now ---------------------------------------------------------------------
         if (wave == 0 && cur > 0) {
             poll_prv = mg_poll(oa.desc, oa.gsum, oa.ginc, cur, (cur >> 6) - 1, false);
-            poll_st = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (somebody gave up? looked at with the answers)
             poll_prv2 = mg_poll(oa.desc, oa.gsum, oa.ginc, cur, (cur >> 6) - 65, true);
         }
         stamp(tclk, 4);

@@ -1535,7 +1535,6 @@ int finish_inner(trre_prog* p, DeviceState* st, ScanCtx* cx, size_t* out_len) {
         if (mg_trace) fprintf(stderr, "trre: a one-pass launch of the memoryless kernel was void: status 0x%x\n", status);
         cx->mapgen_off = true;
         cx->mapgen_voids += 1;
-        if (status & kStMapDense) cx->mapgen_dense = true;   // (the tiles outgrew the window: this context's later scans start on the pair)
         cx->relaunches += 1;
         int rc = enqueue(p, st, cx, was.family, was.d_in, was.n, was.d_out, was.cap, was.stream);
         if (!rc) rc = finish_inner(p, st, cx, out_len);
