@@ -268,3 +268,38 @@ def test_a_grid_that_is_not_resident_gives_up_and_the_pair_answers():
     assert "memoryless kernel was void" in err1 and "was void" not in err0
     assert (m1, sum1) == (m0, sum0)
     assert dt1 < 20.0, dt1
+
+
+CLIP_SCRIPT = r'''
+import hashlib, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch, trre_amd, corpora
+dev = torch.device("cuda", 0)
+inp = corpora.printable_lines(64 << 20, corpora.SEED0 + 5, dev)
+res = {}
+for pat, eng in [("a:xyz", "dft"), ("(<:&lt;|>:&gt;|&:&amp;)", "nft"), (".:uv", "dft"), ("e:12345678", "dft"), ("[aie]:", "nft")]:
+    for off, size in ((0, inp.numel()), (5, (8 << 20) + 777)):
+        p = trre_amd.Program(pat, eng)             # (a program of its own per scan: none has gone back to the pair yet)
+        out = p.scan_tensor(inp[off:off + size])
+        res[(pat, eng, off, size)] = (out.numel(), hashlib.md5(out.cpu().numpy().tobytes()).hexdigest())
+print(repr(res))
+'''
+
+
+def test_tiles_that_outgrow_the_window_on_gpu():
+    """k_mapgen's clipped path on the device — a tile whose output does not fit its window is expanded and stored window by window, its bytes read
+    again: the first scan of a program that doubles its input ('.:uv'), and, with a window of exactly the tile's size (TRRE_MAPGEN_WINDOW=16384),
+    every tile of 'a:xyz' (two windows each) — byte for byte what the pair prints."""
+    def child(env):
+        e = dict(os.environ)
+        for k in ("TRRE_MAPGEN", "TRRE_MAPGEN_WINDOW"):
+            e.pop(k, None)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", CLIP_SCRIPT % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools"))], stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, env=e, timeout=900)
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+        return eval(r.stdout.decode().strip().splitlines()[-1])
+    pair = child({"TRRE_MAPGEN": "0"})
+    assert child({"TRRE_MAPGEN": "1"}) == pair
+    assert child({"TRRE_MAPGEN": "1", "TRRE_MAPGEN_WINDOW": "16384"}) == pair
+    assert child({"TRRE_MAPGEN": "1", "TRRE_MAPGEN_WINDOW": "8192"}) == pair
