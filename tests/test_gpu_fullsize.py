@@ -101,13 +101,14 @@ def test_cfg4_8gib_all_families():
 
 
 def test_general_families_8gib():
-    """variable-length output beyond 2^32 bytes: an expanding DFT pattern (stream family) and an NFT pattern that
-    only the guided family runs"""
+    """variable-length output beyond 2^32 bytes: an expanding DFT pattern (stream family; a memoryless program: its first scan — the full
+    buffer, compared with the oracle's slices — is k_mapgen's, the half scans after it the pair's, map_block.hpp), an NFT pattern that only the
+    guided family runs, and a deleting memoryless program (k_mapgen throughout)"""
     import torch
     import corpora
     inp = corpora.printable_lines(N, corpora.SEED0 + 2, "cuda")
     out = torch.empty(N + N // 4, dtype=torch.uint8, device="cuda")
-    for pat, eng in (("a:xyz", "dft"), ("(a|b)*c:x", "nft")):
+    for pat, eng in (("a:xyz", "dft"), ("(a|b)*c:x", "nft"), ("[aie]:", "dft")):
         p = trre_amd.Program(pat, eng)
         got = p.scan_tensor(inp, out=out)
         check_slices(p, Oracle(pat, eng), inp, out, got.numel(), p.info.kernel, (pat, eng))
