@@ -1137,7 +1137,7 @@ int enqueue(trre_prog* p, DeviceState* st, ScanCtx* cx, int family, const uint8_
         launch_direct_kernel(2, direct_ent_lds, args, lane_bytes, n_chunks, stream, g16, sym_mode, g16_slow);
     } else if (direct && family == TRRE_KERNEL_STREAM_GEN && mapgen_on &&
                mapgen_launch(p, cx, args, stt, stream, pd) == 0) {
-        // a MEMORYLESS program (map_block.hpp; round 6, opt-in): no state, so no walk — lengths, a prefix sum with look-back, the bytes' texts
+        // a MEMORYLESS program (map_block.hpp; round 6): no state, so no walk — lengths, a prefix sum with look-back, the bytes' texts
         // at their places: ONE pass, one read of the input.  A NUL voids it (finish()).
     } else if (direct && !is_guided(family) && stt.fb_ok && !no_fb_env) {
         // a large table (a dictionary) in its fallback form: the count pass with every per-byte lookup in LDS (0.86 ms per
