@@ -404,9 +404,7 @@ int launch_mapgen_t(const ScanArgs& a, const MapGenArgs& oa, hipStream_t s, int 
         }
         per_cu_cache.store(n);
     }
-    static const int per_cu_env = getenv("TRRE_MAPGEN_PER_CU") ? atoi(getenv("TRRE_MAPGEN_PER_CU")) : 0;      // (experiments)
-    int per_cu = per_cu_cache.load();
-    if (per_cu_env > 0 && per_cu_env < per_cu) per_cu = per_cu_env;
+    const int per_cu = per_cu_cache.load();
     int64_t blocks = (int64_t)cus * per_cu;
     static const int oversub_env = getenv("TRRE_MAPGEN_OVERSUB") ? atoi(getenv("TRRE_MAPGEN_OVERSUB")) : 0;   // (tests: a grid that is NOT resident — the launch must give up, not hang)
     if (oversub_env > 1) blocks *= oversub_env;
